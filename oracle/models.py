@@ -1,0 +1,127 @@
+"""Oracle rows A4 (SequentialGNN), A7 (gather), A8 (Basic / Hybrid heads), A9 (per-user top-k).
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Weights travel as plain dicts of numpy arrays:
+
+    gnn     {'kind': 'gcn'|'lightgcn'|'sage'|'gat', 'embeddings': [N,d],
+             'layers': [ {'kernel','bias'} | {} | {'kernel','bias'} | {'kernel','attn_self','attn_neigh','bias'} ],
+             'final_node': 'concatenation'|'mean'|'sum'|'last'}
+    basic   {'unet': [(W,b)..], 'inet': [(W,b)..], 'clf': [(W,b).., (W_out,b_out)]}
+    hybrid  {'dense1a','dense1b','dense2a','dense2b','dense3a','dense3b': [(W,b)..], 'clf': [...]}
+"""
+import numpy as np
+
+from oracle import graph as ograph
+from oracle import layers as olayers
+
+
+def propagate(adj, gnn, dtype=np.float32, self_loops=True):
+    """SequentialGNN.call (gnn.py:74-84) under GNN.call (gnn.py:263-264): inputs are ignored.
+
+    `adj` is the raw symmetric COO adjacency from build_adjacency_matrix; GCN and LightGCN first
+    run gcn_filter on it (gnn.py:283,381), GraphSAGE and GAT consume it as is (gnn.py:316-319,349-352).
+    """
+    kind = gnn['kind']
+    x = gnn['embeddings'].astype(dtype)
+    hs = [x]
+    if kind in ('gcn', 'lightgcn'):
+        a_hat = ograph.gcn_filter(adj)
+        for lw in gnn['layers']:
+            if kind == 'gcn':
+                x = olayers.gcn_conv(x, a_hat, lw['kernel'].astype(dtype), lw['bias'].astype(dtype))
+            else:
+                x = olayers.lightgcn_conv(x, a_hat)
+            hs.append(x)
+    elif kind in ('sage', 'gat'):
+        row, col, _ = ograph.reordered_coo(adj)
+        for lw in gnn['layers']:
+            if kind == 'sage':
+                x = olayers.sage_conv(x, row, col, lw['kernel'].astype(dtype), lw['bias'].astype(dtype),
+                                      self_loops=self_loops)
+            else:
+                x, _ = olayers.gat_conv(x, row, col, lw['kernel'].astype(dtype), lw['attn_self'].astype(dtype),
+                                        lw['attn_neigh'].astype(dtype), lw['bias'].astype(dtype),
+                                        self_loops=self_loops)
+            hs.append(x)
+    else:
+        raise ValueError("Unknown GNN kind {}".format(kind))
+    final_node = 'mean' if kind == 'lightgcn' else gnn.get('final_node', 'concatenation')   # gnn.py:378
+    return olayers.reduce_layers(hs, final_node)
+
+
+def _cast_net(net, dtype):
+    return [(w.astype(dtype), b.astype(dtype)) for w, b in net]
+
+
+def basic_rs(u, i, head, activation='relu'):
+    """BasicRS.call (basic.py:31-37): unet(u), inet(i), concat, clf -> [B,1]."""
+    dtype = u.dtype
+    u = olayers.dense_network(u, _cast_net(head['unet'], dtype), activation)
+    i = olayers.dense_network(i, _cast_net(head['inet'], dtype), activation)
+    return olayers.dense_classifier(np.concatenate([u, i], axis=1), _cast_net(head['clf'], dtype), activation)
+
+
+def hybrid_cbrs(ug, ig, ub, ib, head, activation='relu'):
+    """HybridCBRS.call (hybrid.py:72-89), feature_based=True, fusion 'concatenate', residual=False."""
+    dtype = ug.dtype
+    net = lambda name, x: olayers.dense_network(x, _cast_net(head[name], dtype), activation)
+    ug, ig, ub, ib = net('dense1a', ug), net('dense1b', ig), net('dense2a', ub), net('dense2b', ib)
+    x1 = net('dense3a', np.concatenate([ug, ig], axis=1))
+    x2 = net('dense3b', np.concatenate([ub, ib], axis=1))
+    return olayers.dense_classifier(np.concatenate([x1, x2], axis=1), _cast_net(head['clf'], dtype), activation)
+
+
+def basic_gnn_scores(adj, gnn, head, u_ids, i_ids, dtype=np.float32, batch=None):
+    """BasicGNN.call (basic.py:61-75): E = gnn(None); E[u], E[i]; BasicRS.  Returns [P,1].
+
+    `batch` re-runs the propagation per batch exactly like the reference ('faithful' mode); the
+    result is identical because gnn(None) does not depend on the batch.
+    """
+    if batch is None:
+        e = propagate(adj, gnn, dtype)
+        return basic_rs(e[u_ids], e[i_ids], head)
+    outs = []
+    for lo in range(0, len(u_ids), batch):
+        e = propagate(adj, gnn, dtype)
+        outs.append(basic_rs(e[u_ids[lo:lo + batch]], e[i_ids[lo:lo + batch]], head))
+    return np.concatenate(outs, axis=0)
+
+
+def hybrid_gnn_scores(adj, gnn, head, u_ids, i_ids, bert, dtype=np.float32):
+    """HybridBertGNN.call (hybrid.py:126-140) with host-side BERT row gather (datasets.py:65-66)."""
+    e = propagate(adj, gnn, dtype)
+    bert = bert.astype(dtype)
+    return hybrid_cbrs(e[u_ids], e[i_ids], bert[u_ids], bert[i_ids], head)
+
+
+def top_k(u_idx, i_idx, scores, users, items, k):
+    """metrics.py:11-34 with a deterministic tie rule.
+
+    Rows (raw user, raw item, score) sorted by user ascending then score descending, first k per
+    user among that user's test pairs.  The reference sorts with pandas' default (unstable)
+    quicksort, so equal scores have no defined order there; here ties break on raw item id
+    ascending.  Scores are compared in float64 like the reference's DataFrame column.
+    """
+    n_users = len(users)
+    raw_u = users[np.asarray(u_idx, dtype=np.int64)]
+    raw_i = items[np.asarray(i_idx, dtype=np.int64) - n_users]
+    s = np.asarray(scores, dtype=np.float64).reshape(-1)
+    order = np.lexsort((raw_i, -s, raw_u))
+    raw_u, raw_i, s = raw_u[order], raw_i[order], s[order]
+    start = np.searchsorted(raw_u, raw_u, side='left')
+    keep = (np.arange(len(raw_u)) - start) < k
+    return raw_u[keep], raw_i[keep], s[keep]
+
+
+def count_params(*trees):
+    """Trainable-parameter count (keras.py:10-22 semantics) of nested weight containers."""
+    total = 0
+    for t in trees:
+        if isinstance(t, np.ndarray):
+            total += t.size
+        elif isinstance(t, dict):
+            total += count_params(*[v for v in t.values() if not isinstance(v, str)])
+        elif isinstance(t, (list, tuple)):
+            total += count_params(*t)
+    return total

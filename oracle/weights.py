@@ -1,0 +1,84 @@
+"""Seeded Keras-style initialisers for fixtures.  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+glorot_uniform = U(+-sqrt(6 / (fan_in + fan_out))) with Keras' `_compute_fans`: for a 2-D
+kernel fan_in, fan_out = shape; for rank > 2 the leading dims are a receptive field.  The
+embedding table is a plain [N, d] weight (gnn.py:41-46), so fan_in = N.  Biases are zeros in
+the reference; fixtures draw them U(+-0.05) so that bias paths are exercised.
+"""
+import numpy as np
+
+
+def glorot_uniform(rng, shape):
+    shape = tuple(int(s) for s in shape)
+    if len(shape) == 1:
+        fan_in = fan_out = shape[0]
+    elif len(shape) == 2:
+        fan_in, fan_out = shape
+    else:
+        rf = int(np.prod(shape[:-2]))
+        fan_in, fan_out = shape[-2] * rf, shape[-1] * rf
+    limit = np.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-limit, limit, size=shape).astype(np.float32)
+
+
+def _bias(rng, n, bias_range):
+    if bias_range:
+        return rng.uniform(-bias_range, bias_range, size=n).astype(np.float32)
+    return np.zeros(n, dtype=np.float32)
+
+
+def dense_net(rng, in_dim, units, bias_range=0.0):
+    layers = []
+    for u in units:
+        layers.append((glorot_uniform(rng, (in_dim, u)), _bias(rng, u, bias_range)))
+        in_dim = u
+    return layers
+
+
+def gnn(rng, kind, n_nodes, embedding_dim=8, n_hiddens=(8, 8), n_layers=2, final_node='concatenation',
+        bias_range=0.0):
+    w = {'kind': kind, 'embeddings': glorot_uniform(rng, (n_nodes, embedding_dim)), 'layers': [],
+         'final_node': final_node}
+    f_in = embedding_dim
+    if kind == 'lightgcn':
+        w['layers'] = [{} for _ in range(n_layers)]
+        w['final_node'] = 'mean'
+        return w
+    for c in n_hiddens:
+        if kind == 'gcn':
+            lw = {'kernel': glorot_uniform(rng, (f_in, c)), 'bias': _bias(rng, c, bias_range)}
+        elif kind == 'sage':
+            lw = {'kernel': glorot_uniform(rng, (2 * f_in, c)), 'bias': _bias(rng, c, bias_range)}
+        elif kind == 'gat':
+            # Spektral shapes: kernel [F, heads=1, C]; attn kernels [C, heads=1, 1]
+            lw = {'kernel': glorot_uniform(rng, (f_in, 1, c)).reshape(f_in, c),
+                  'attn_self': glorot_uniform(rng, (c, 1, 1)).reshape(c),
+                  'attn_neigh': glorot_uniform(rng, (c, 1, 1)).reshape(c),
+                  'bias': _bias(rng, c, bias_range)}
+        else:
+            raise ValueError(kind)
+        w['layers'].append(lw)
+        f_in = c
+    return w
+
+
+def gnn_out_dim(w):
+    d = w['embeddings'].shape[1]
+    if w['kind'] == 'lightgcn' or w['final_node'] in ('mean', 'sum'):
+        return d
+    widths = [d] + [lw['kernel'].shape[1] for lw in w['layers']]
+    return sum(widths) if w['final_node'] == 'concatenation' else widths[-1]
+
+
+def basic_head(rng, in_dim, dense_units, clf_units, bias_range=0.0):
+    return {'unet': dense_net(rng, in_dim, dense_units, bias_range),
+            'inet': dense_net(rng, in_dim, dense_units, bias_range),
+            'clf': dense_net(rng, 2 * dense_units[-1], list(clf_units) + [1], bias_range)}
+
+
+def hybrid_head(rng, g_dim, b_dim, dense_units, clf_units, bias_range=0.0):
+    d1, d2, d3 = dense_units
+    return {'dense1a': dense_net(rng, g_dim, d1, bias_range), 'dense1b': dense_net(rng, g_dim, d1, bias_range),
+            'dense2a': dense_net(rng, b_dim, d2, bias_range), 'dense2b': dense_net(rng, b_dim, d2, bias_range),
+            'dense3a': dense_net(rng, 2 * d1[-1], d3, bias_range), 'dense3b': dense_net(rng, 2 * d2[-1], d3, bias_range),
+            'clf': dense_net(rng, 2 * d3[-1], list(clf_units) + [1], bias_range)}

@@ -1,0 +1,167 @@
+#!/usr/bin/env python
+"""Headline benchmark: (user, item) pairs scored per second, ML-1M-shape basic-gnn (2-layer GCN).
+
+One step = one pass of the hot path over one batch of synthetic input:
+full-graph propagation (X_0.W_1 prologue + one fused CSR-SpMM kernel per GCN layer) followed by
+scoring every test pair (embedding gather + BasicRS towers + classifier) — the "hoisted" mode of
+SURVEY.md §8d: one propagation per weight state, then all pairs.  Inputs (CSR graph, weights,
+pair ids) are resident in HBM before the timed region.
+
+Workload: ml1m(s) graph of MovieLens-1M shape scaled by s (default 64: |U| = 386 304,
+|I| = 204 288, ~56 M non-zeros in A_hat, ~12 M test pairs), econfigs/basic-gnn.yaml grid1 model
+(GCN d=8, n_hiddens [8, 8], concat -> 24, dense [24, 24], clf [48, 48]), fp32.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel = the fused GCN
+SpMM layer, algorithmic bytes nnz*8 + (N+1)*4 + 2*N*F*4 per launch over its HIP-event time)
+and `cpu_baseline` (the oracle timed on one host core on a bounded ml1m(s=1) sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+GRID1 = dict(embedding_dim=8, n_hiddens=[8, 8], n_layers=2, dense_units=[24, 24], clf_units=[48, 48],
+             l2_regularizer=1e-4, final_node='concatenation', activation='relu')
+HBM_PEAK_GBPS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--scale', type=int, default=64, help='ml1m(s) scale factor of the synthetic graph')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    return ap.parse_args()
+
+
+def cpu_baseline():
+    """Oracle (numpy/scipy port of the reference arithmetic) on ml1m(s=1), one host thread, hoisted mode."""
+    from threadpoolctl import threadpool_limits
+    from oracle import models as om, weights as ow
+    from tests import helpers
+    g = helpers.ml1m_indexed(1)
+    rng = np.random.default_rng(42)
+    n = g['adj_ui'].shape[0]
+    gnn = ow.gnn(rng, 'gcn', n, 8, (8, 8))
+    head = ow.basic_head(rng, 24, [24, 24], [48, 48])
+    u, i = g['test'][:, 0], g['test'][:, 1]
+    with threadpool_limits(limits=1):
+        om.basic_gnn_scores(g['adj_ui'], gnn, head, u[:1000], i[:1000])          # warm
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 10.0 or reps < 3:
+            om.basic_gnn_scores(g['adj_ui'], gnn, head, u, i)
+            reps += 1
+        dt = (time.perf_counter() - t0) / reps
+    return {'value': len(u) / dt, 'unit': 'pairs/s', 'cores': 1, 'kind': 'port',
+            'sample': 'ml1m(s=1): gcn_filter + 2-layer GCN propagation + {} test pairs, hoisted, {} reps of {:.3f} s'
+                      .format(len(u), reps, dt)}
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get('RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl')
+    assert world == args.gpus, "--gpus {} but WORLD_SIZE={}".format(args.gpus, world)
+
+    from deep_cbrs_amar_renaissance_amd import capi, engine
+    from deep_cbrs_amar_renaissance_amd.data import synthetic
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter_device
+    from deep_cbrs_amar_renaissance_amd import parallel
+
+    capi.load()
+    engine.set_seed(42)
+    dev = torch.device('cuda', local_rank)
+    data = synthetic.ml1m_device(args.scale, device=dev)
+    n_nodes = data['n_users'] + data['n_items']
+    a_hat = gcn_filter_device(data['train_pos'][:, 0], data['train_pos'][:, 1], n_nodes)
+    nnz = a_hat.nnz
+    model = basic.BasicGCN(a_hat, **GRID1)
+    u_all = data['test'][:, 0].to(torch.int32).contiguous()
+    i_all = data['test'][:, 1].to(torch.int32).contiguous()
+    n_pairs = int(u_all.numel())
+    del data
+    torch.cuda.empty_cache()
+
+    runner = parallel.make_runner(model, u_all, i_all, rank, world)
+
+    spmm_events = []
+    raw_gcn_layer = capi.gcn_layer
+
+    def timed_gcn_layer(*a, **k):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        raw_gcn_layer(*a, **k)
+        e1.record()
+        spmm_events.append((e0, e1))
+    capi.gcn_layer = timed_gcn_layer
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        runner.step()
+    barrier()
+    spmm_events.clear()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        runner.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    capi.gcn_layer = raw_gcn_layer
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    spmm_ms = [e0.elapsed_time(e1) for e0, e1 in spmm_events]
+    rows_local = runner.local_rows
+    nnz_local = runner.local_nnz
+    f = GRID1['n_hiddens'][0]
+    alg_bytes = nnz_local * 8 + (rows_local + 1) * 4 + (n_nodes + rows_local) * f * 4
+    avg_ms = float(np.mean(spmm_ms)) if spmm_ms else float('nan')
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        out = {
+            'metric': '(user,item) pairs scored/sec, ML-1M basic-gnn 2-layer',
+            'value': n_pairs * args.steps / dt, 'unit': 'pairs/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
+            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'ml1m(s={}) user-item graph: N={} nodes, nnz(A_hat)={}, {} test pairs; '
+                                   'econfigs/basic-gnn.yaml grid1 BasicGCN d=8 L=2 concat, dense [24,24], clf [48,48]; '
+                                   'one propagation + all pairs per step (hoisted)'.format(args.scale, n_nodes, nnz, n_pairs),
+                       'scale': args.scale, 'parallelism': runner.describe()},
+            'roofline': {'bound': 'hbm', 'kernel': 'spmm_row_kernel<8> (fused GCN layer)', 'achieved': achieved,
+                         'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': None,
+                         'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': avg_ms,
+                         'launches_timed': len(spmm_ms)},
+            'propagation_ms': runner.last_propagation_ms(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,221 @@
+"""ctypes binding of the C-ABI in ``include/amar_hip.h`` (``libamar_hip.so``).
+
+torch is only the carrier here: tensors provide device memory (``data_ptr()``) and the current
+HIP stream; every function below checks shapes on the host, hands raw pointers to the library
+and raises on a non-zero return code.  There is NO fallback: if the shared library is missing,
+or a tensor is not on a GPU, the call fails loudly.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libamar_hip.so')
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+ACT_CODES = {None: ACT_NONE, 'linear': ACT_NONE, 'relu': ACT_RELU, 'sigmoid': ACT_SIGMOID}
+SPMM_BIAS, SPMM_RELU, SPMM_ACCUM, SPMM_ACCUM_DIV = 1, 2, 4, 8
+
+_P = ctypes.c_void_p
+_I32, _I64, _U32, _F32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_float
+
+# symbol -> (restype, argtypes); kept in the order of include/amar_hip.h
+SIGNATURES = {
+    'amar_version': (ctypes.c_int, []),
+    'amar_error_string': (ctypes.c_char_p, [ctypes.c_int]),
+    'amar_last_hip_error': (ctypes.c_int, []),
+    'amar_spmm_csr_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _P, _I64, _I32, _I32, _U32, _P,
+                                         _P, _I64, _P, _I64, _F32, _P]),
+    'amar_gcn_layer_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _I64, _P, _I32, _P, _I64, _I32, _P]),
+    'amar_rowwise_xw_f32': (ctypes.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _P, _I64, _P, _P, _P, _P, _I32, _P]),
+    'amar_sage_layer_f32': (ctypes.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _I32, _P, _I64, _I32, _I32, _P]),
+    'amar_gat_layer_f32': (ctypes.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _P, _I64, _I32, _I32, _P]),
+    'amar_dense_f32': (ctypes.c_int, [_P, _I64, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _P]),
+    'amar_copy_columns_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I32, _P]),
+    'amar_reduce_layers_f32': (ctypes.c_int, [_P, _I64, _I32, _I32, _P, _I64, _I64, _I32, _P]),
+    'amar_topk_segmented_f32': (ctypes.c_int, [_P, _P, _P, _I32, _I32, _P, _P, _P]),
+}
+
+_lib = None
+
+
+class AmarError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libamar_hip.so (once). Raises if it has not been built: there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise AmarError(
+                "{} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C deep_cbrs_amar_renaissance_amd/csrc`. The HIP path has no fallback.".format(LIB_PATH))
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = restype, argtypes
+        _lib = lib
+    return _lib
+
+
+def _check(code, what):
+    if code != 0:
+        lib = load()
+        msg = lib.amar_error_string(code).decode()
+        raise (ValueError if code == -1 else AmarError)(
+            "{} failed: {} (code {}, hipError {})".format(what, msg, code, lib.amar_last_hip_error()))
+
+
+def _ptr(t, dtype=None, name='tensor'):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise AmarError("{} must live on the GPU (got {}); the HIP path has no CPU fallback".format(name, t.device))
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError("{} must be {} (got {})".format(name, dtype, t.dtype))
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ld(t, name):
+    """Leading dimension of a 2-D row-major view (last dim contiguous)."""
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError("{} must be a 2-D tensor whose last dimension is contiguous".format(name))
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def spmm_csr(rowptr, colidx, vals, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc_div=None):
+    """Y = A.X (+bias, ReLU); optionally acc_out = (acc_in + Y) [/ acc_div]. Tensors are views into device memory."""
+    n_rows = rowptr.numel() - 1
+    F = X.shape[1]
+    if colidx.numel() and int(X.shape[0]) < 1:
+        raise ValueError("X has no rows")
+    flags = (SPMM_BIAS if bias is not None else 0) | (SPMM_RELU if relu else 0)
+    if acc_out is not None:
+        flags |= SPMM_ACCUM | (SPMM_ACCUM_DIV if acc_div is not None else 0)
+        if acc_in is None or acc_in.shape != (n_rows, F) or acc_out.shape != (n_rows, F):
+            raise ValueError("acc_in/acc_out must be [n_rows, F]")
+    if Y is not None and tuple(Y.shape) != (n_rows, F):
+        raise ValueError("Y must be [n_rows, F]")
+    if vals is not None and vals.numel() != colidx.numel():
+        raise ValueError("vals and colidx differ in length")
+    code = load().amar_spmm_csr_f32(
+        _ptr(rowptr, torch.int32, 'rowptr'), _ptr(colidx, torch.int32, 'colidx'), _ptr(vals, torch.float32, 'vals'),
+        _ptr(X, torch.float32, 'X'), _ld(X, 'X'), _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y') if Y is not None else 0,
+        n_rows, F, flags, _ptr(bias, torch.float32, 'bias'),
+        _ptr(acc_in, torch.float32, 'acc_in'), _ld(acc_in, 'acc_in') if acc_in is not None else 0,
+        _ptr(acc_out, torch.float32, 'acc_out'), _ld(acc_out, 'acc_out') if acc_out is not None else 0,
+        float(acc_div) if acc_div is not None else 1.0, _stream())
+    _check(code, 'amar_spmm_csr_f32')
+
+
+def gcn_layer(rowptr, colidx, vals, H, bias, Y, Wnext=None, Hnext=None):
+    n_rows = rowptr.numel() - 1
+    C = H.shape[1]
+    if tuple(Y.shape) != (n_rows, C) or bias.numel() != C or H.shape[0] < n_rows:
+        raise ValueError("gcn_layer: H [>=n_rows, C], bias [C], Y [n_rows, C] expected")
+    Cn = 0
+    if Wnext is not None:
+        if Wnext.shape[0] != C or not Wnext.is_contiguous() or Hnext is None or tuple(Hnext.shape) != (n_rows, Wnext.shape[1]):
+            raise ValueError("gcn_layer: Wnext [C, Cn] contiguous and Hnext [n_rows, Cn] expected")
+        Cn = Wnext.shape[1]
+    code = load().amar_gcn_layer_f32(
+        _ptr(rowptr, torch.int32, 'rowptr'), _ptr(colidx, torch.int32, 'colidx'), _ptr(vals, torch.float32, 'vals'),
+        _ptr(H, torch.float32, 'H'), _ld(H, 'H'), C, _ptr(bias, torch.float32, 'bias'),
+        _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y'),
+        _ptr(Wnext, torch.float32, 'Wnext'), Cn, _ptr(Hnext, torch.float32, 'Hnext'),
+        _ld(Hnext, 'Hnext') if Hnext is not None else 0, n_rows, _stream())
+    _check(code, 'amar_gcn_layer_f32')
+
+
+def rowwise_xw(X, W, H, copy_to=None, a_self=None, a_neigh=None, s_self=None, s_neigh=None):
+    n_rows, F = X.shape
+    if W.shape[0] != F or not W.is_contiguous() or tuple(H.shape) != (n_rows, W.shape[1]):
+        raise ValueError("rowwise_xw: W [F, C] contiguous and H [n_rows, C] expected")
+    if copy_to is not None and tuple(copy_to.shape) != (n_rows, F):
+        raise ValueError("rowwise_xw: copy_to must be [n_rows, F]")
+    for v, nm in ((s_self, 's_self'), (s_neigh, 's_neigh')):
+        if v is not None and (v.numel() != n_rows or not v.is_contiguous()):
+            raise ValueError("rowwise_xw: {} must be a contiguous [n_rows] vector".format(nm))
+    code = load().amar_rowwise_xw_f32(
+        _ptr(X, torch.float32, 'X'), _ld(X, 'X'), F, _ptr(W, torch.float32, 'W'), W.shape[1],
+        _ptr(H, torch.float32, 'H'), _ld(H, 'H'),
+        _ptr(copy_to, torch.float32, 'copy_to'), _ld(copy_to, 'copy_to') if copy_to is not None else 0,
+        _ptr(a_self, torch.float32, 'a_self'), _ptr(a_neigh, torch.float32, 'a_neigh'),
+        _ptr(s_self, torch.float32, 's_self'), _ptr(s_neigh, torch.float32, 's_neigh'), n_rows, _stream())
+    _check(code, 'amar_rowwise_xw_f32')
+
+
+def sage_layer(rowptr, colidx, X, W, bias, Y, self_loop=True):
+    n_rows = rowptr.numel() - 1
+    F = X.shape[1]
+    if W.shape[0] != 2 * F or not W.is_contiguous() or bias.numel() != W.shape[1] or \
+            tuple(Y.shape) != (n_rows, W.shape[1]) or X.shape[0] < n_rows:
+        raise ValueError("sage_layer: W [2F, C] contiguous, bias [C], Y [n_rows, C] expected")
+    code = load().amar_sage_layer_f32(
+        _ptr(rowptr, torch.int32, 'rowptr'), _ptr(colidx, torch.int32, 'colidx'),
+        _ptr(X, torch.float32, 'X'), _ld(X, 'X'), F, _ptr(W, torch.float32, 'W'), _ptr(bias, torch.float32, 'bias'),
+        W.shape[1], _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y'), 1 if self_loop else 0, n_rows, _stream())
+    _check(code, 'amar_sage_layer_f32')
+
+
+def gat_layer(rowptr, colidx, H, s_self, s_neigh, bias, Y, self_loop=True):
+    n_rows = rowptr.numel() - 1
+    C = H.shape[1]
+    if tuple(Y.shape) != (n_rows, C) or bias.numel() != C or s_self.numel() < n_rows or s_neigh.numel() < H.shape[0]:
+        raise ValueError("gat_layer: bias [C], Y [n_rows, C], s_self/s_neigh [n] expected")
+    code = load().amar_gat_layer_f32(
+        _ptr(rowptr, torch.int32, 'rowptr'), _ptr(colidx, torch.int32, 'colidx'),
+        _ptr(H, torch.float32, 'H'), _ld(H, 'H'), C, _ptr(s_self, torch.float32, 's_self'),
+        _ptr(s_neigh, torch.float32, 's_neigh'), _ptr(bias, torch.float32, 'bias'),
+        _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y'), 1 if self_loop else 0, n_rows, _stream())
+    _check(code, 'amar_gat_layer_f32')
+
+
+def dense(X, W, bias, Y, act='relu', ids=None):
+    """Y = act(X[ids] . W + bias). Y may be a column slice of a wider buffer (concatenation)."""
+    K, N = W.shape
+    M = ids.numel() if ids is not None else X.shape[0]
+    if X.shape[1] != K or not W.is_contiguous() or tuple(Y.shape) != (M, N):
+        raise ValueError("dense: X [*, K], W [K, N] contiguous, Y [M, N] expected")
+    if bias is not None and (bias.numel() != N or not bias.is_contiguous()):
+        raise ValueError("dense: bias must be a contiguous [N] vector")
+    code = load().amar_dense_f32(
+        _ptr(X, torch.float32, 'X'), _ld(X, 'X'), _ptr(ids, torch.int32, 'ids'),
+        _ptr(W, torch.float32, 'W'), _ptr(bias, torch.float32, 'bias'), _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y'),
+        M, K, N, ACT_CODES[act], _stream())
+    _check(code, 'amar_dense_f32')
+
+
+def copy_columns(src, dst):
+    if tuple(src.shape) != tuple(dst.shape):
+        raise ValueError("copy_columns: shapes differ")
+    code = load().amar_copy_columns_f32(_ptr(src, torch.float32, 'src'), _ld(src, 'src'),
+                                        _ptr(dst, torch.float32, 'dst'), _ld(dst, 'dst'),
+                                        src.shape[0], src.shape[1], _stream())
+    _check(code, 'amar_copy_columns_f32')
+
+
+def reduce_layers(cat, n_layers, width, out, mean=False):
+    if cat.shape[1] != n_layers * width or tuple(out.shape) != (cat.shape[0], width):
+        raise ValueError("reduce_layers: cat [n, n_layers*width], out [n, width] expected")
+    code = load().amar_reduce_layers_f32(_ptr(cat, torch.float32, 'cat'), _ld(cat, 'cat'), n_layers, width,
+                                         _ptr(out, torch.float32, 'out'), _ld(out, 'out'), cat.shape[0],
+                                         1 if mean else 0, _stream())
+    _check(code, 'amar_reduce_layers_f32')
+
+
+def topk_segmented(seg_ptr, item_ids, scores, k):
+    n_users = seg_ptr.numel() - 1
+    out_items = torch.empty((n_users, k), dtype=torch.int32, device=scores.device)
+    out_scores = torch.empty((n_users, k), dtype=torch.float32, device=scores.device)
+    code = load().amar_topk_segmented_f32(
+        _ptr(seg_ptr, torch.int32, 'seg_ptr'), _ptr(item_ids, torch.int32, 'item_ids'),
+        _ptr(scores, torch.float32, 'scores'), n_users, k, _ptr(out_items), _ptr(out_scores), _stream())
+    _check(code, 'amar_topk_segmented_f32')
+    return out_items, out_scores

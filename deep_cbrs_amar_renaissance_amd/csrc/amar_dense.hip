@@ -1,0 +1,198 @@
+// Scoring-head kernels for gfx950: fp32 MFMA dense layer with fused row gather, bias and
+// activation.  Reference semantics: Keras Dense / Concatenate / tf.nn.embedding_lookup as cited
+// in include/amar_hip.h.
+//
+// v_mfma_f32_32x32x2_f32 is exact fp32 (a k-ordered fmaf chain), so results match a plain fp32
+// dot product bit for bit in k order; there is no reduced-precision path on gfx950.
+//
+// Tile: 128 (rows) x 64 (cols) per 256-thread workgroup, K stepped by 16 through LDS.
+//   wave w owns rows [32w, 32w+32) and both 32-column halves -> 2 accumulators of 16 VGPRs.
+//   LDS images are k-major so that the MFMA operand fetch (lane l: row/col l&31, k = l>>5)
+//   is a conflict-free ds_read_b32 for A and B alike.
+#include "amar_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 64, BK = 16;
+constexpr int A_LD = BM + 4;     // +4 floats: the transposing store is at most 2-way conflicted
+constexpr int B_LD = BN;
+
+struct DenseArgs {
+    const float *X; int64_t ldx; const int32_t *ids;
+    const float *W; const float *bias; float *Y; int64_t ldy;
+    int64_t M; int K; int N; int act;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == AMAR_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == AMAR_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+    return v;
+}
+
+template <bool VEC_X, bool VEC_W>
+__global__ __launch_bounds__(256) void dense_mfma_kernel(const DenseArgs a) {
+    __shared__ float As[BK * A_LD];
+    __shared__ float Bs[BK * B_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+
+    // staging assignment: X tile = 128 rows x 4 float4 -> 2 rows per thread; W tile = 16 x 16 float4 -> 1 per thread
+    const int xr = tid >> 2, xq = tid & 3;
+    int64_t src_row[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int64_t m = m0 + xr + 64 * h;
+        src_row[h] = m < a.M ? (a.ids ? (int64_t)a.ids[m] : m) : -1;
+    }
+    const int wk = tid >> 4, wq = tid & 15;
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+    for (int k0 = 0; k0 < a.K; k0 += BK) {
+        // global -> registers
+        float xa[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = k0 + 4 * xq;
+            if (src_row[h] >= 0 && VEC_X && k + 3 < a.K) {
+                const float4 v = *reinterpret_cast<const float4 *>(a.X + src_row[h] * a.ldx + k);
+                xa[h][0] = v.x; xa[h][1] = v.y; xa[h][2] = v.z; xa[h][3] = v.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    xa[h][i] = (src_row[h] >= 0 && k + i < a.K) ? a.X[src_row[h] * a.ldx + k + i] : 0.f;
+            }
+        }
+        float wb[4];
+        {
+            const int k = k0 + wk, n = n0 + 4 * wq;
+            if (k < a.K && VEC_W && n + 3 < a.N) {
+                const float4 v = *reinterpret_cast<const float4 *>(a.W + (int64_t)k * a.N + n);
+                wb[0] = v.x; wb[1] = v.y; wb[2] = v.z; wb[3] = v.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wb[i] = (k < a.K && n + i < a.N) ? a.W[(int64_t)k * a.N + n + i] : 0.f;
+            }
+        }
+        __syncthreads();                                // previous tile fully consumed
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) As[(4 * xq + i) * A_LD + xr + 64 * h] = xa[h][i];
+        *reinterpret_cast<float4 *>(&Bs[wk * B_LD + 4 * wq]) = make_float4(wb[0], wb[1], wb[2], wb[3]);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int k = kk + (lane >> 5);
+            const float av = As[k * A_LD + 32 * wave + (lane & 31)];
+            const float b0 = Bs[k * B_LD + (lane & 31)];
+            const float b1 = Bs[k * B_LD + 32 + (lane & 31)];
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
+        }
+    }
+
+    // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int col = lane & 31;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int n = n0 + 32 * half + col;
+        if (n >= a.N) continue;
+        const float b = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < a.M) {
+                const float v = (half == 0 ? acc0[r] : acc1[r]) + b;
+                a.Y[m * a.ldy + n] = apply_act(v, a.act);
+            }
+        }
+    }
+}
+
+// ---- per-user top-k --------------------------------------------------------------------------
+// One wave per user.  Round t picks the best pair that comes strictly after round t-1's winner in
+// the order (score descending, item id ascending); items are distinct within a user.
+__global__ __launch_bounds__(256) void topk_segmented_kernel(const int32_t *__restrict__ seg_ptr,
+                                                              const int32_t *__restrict__ item_ids,
+                                                              const float *__restrict__ scores, int n_users, int k,
+                                                              int32_t *__restrict__ out_items,
+                                                              float *__restrict__ out_scores) {
+    const int lane = threadIdx.x & 63;
+    const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= n_users) return;
+    const int beg = seg_ptr[u], end = seg_ptr[u + 1];
+    float prev_s = INFINITY;
+    int prev_i = -1;
+    for (int t = 0; t < k; ++t) {
+        float best_s = -INFINITY;
+        int best_i = 0x7fffffff;
+        for (int p = beg + lane; p < end; p += 64) {
+            const float s = scores[p];
+            const int it = item_ids[p];
+            const bool after_prev = (s < prev_s) || (s == prev_s && it > prev_i);
+            const bool better = (s > best_s) || (s == best_s && it < best_i);
+            if (after_prev && better) { best_s = s; best_i = it; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float os = __shfl_xor(best_s, off, 64);
+            const int oi = __shfl_xor(best_i, off, 64);
+            if (os > best_s || (os == best_s && oi < best_i)) { best_s = os; best_i = oi; }
+        }
+        const bool found = best_i != 0x7fffffff;
+        if (lane == 0) {
+            out_items[(int64_t)u * k + t] = found ? best_i : -1;
+            out_scores[(int64_t)u * k + t] = found ? best_s : -INFINITY;
+        }
+        if (!found) {
+            if (lane == 0)
+                for (int r = t + 1; r < k; ++r) { out_items[(int64_t)u * k + r] = -1; out_scores[(int64_t)u * k + r] = -INFINITY; }
+            break;
+        }
+        prev_s = best_s; prev_i = best_i;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int amar_dense_f32(const float *X, int64_t ldx, const int32_t *ids,
+                   const float *W, const float *bias, float *Y, int64_t ldy,
+                   int64_t M, int32_t K, int32_t N, int32_t act, amar_stream_t stream) {
+    if (M < 0 || K < 1 || N < 1 || !X || !W || !Y || ldx < K || ldy < N) return AMAR_EINVAL;
+    if (act != AMAR_ACT_NONE && act != AMAR_ACT_RELU && act != AMAR_ACT_SIGMOID) return AMAR_EINVAL;
+    if (M == 0) return AMAR_OK;
+    const int64_t gx = (M + BM - 1) / BM;
+    if (gx > 0x7fffffffLL) return AMAR_EUNSUPPORTED;
+    DenseArgs a{X, ldx, ids, W, bias, Y, ldy, M, K, N, act};
+    const dim3 grid((unsigned)gx, (unsigned)((N + BN - 1) / BN)), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool vx = (ldx & 3) == 0 && amar_aligned16(X);
+    const bool vw = (N & 3) == 0 && amar_aligned16(W);
+    if (vx && vw) hipLaunchKernelGGL((dense_mfma_kernel<true, true>), grid, block, 0, st, a);
+    else if (vx) hipLaunchKernelGGL((dense_mfma_kernel<true, false>), grid, block, 0, st, a);
+    else if (vw) hipLaunchKernelGGL((dense_mfma_kernel<false, true>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((dense_mfma_kernel<false, false>), grid, block, 0, st, a);
+    return amar_check_launch();
+}
+
+int amar_topk_segmented_f32(const int32_t *seg_ptr, const int32_t *item_ids, const float *scores,
+                            int32_t n_users, int32_t k, int32_t *out_items, float *out_scores,
+                            amar_stream_t stream) {
+    if (n_users < 0 || k < 1 || !seg_ptr || !out_items || !out_scores) return AMAR_EINVAL;
+    if (k > 64) return AMAR_EUNSUPPORTED;
+    if (n_users == 0) return AMAR_OK;
+    if (!item_ids || !scores) return AMAR_EINVAL;
+    hipLaunchKernelGGL(topk_segmented_kernel, dim3((n_users + 3) / 4), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), seg_ptr, item_ids, scores, n_users, k, out_items, out_scores);
+    return amar_check_launch();
+}
+
+}  // extern "C"

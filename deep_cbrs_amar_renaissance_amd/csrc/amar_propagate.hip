@@ -1,0 +1,374 @@
+// GNN propagation kernels for gfx950: CSR row gather-reduce with fused layer epilogues.
+//
+// Work decomposition (all four convolutions share it):
+//   one 64-lane wavefront per CSR row; a row of width F floats is F/4 float4 "quads", so
+//   LPN = F/4 lanes cooperate on one non-zero (one coalesced 4F-byte read of the source row)
+//   and NS = 64/LPN non-zeros are in flight per wave-instruction.  Partial sums stay in
+//   registers and are combined with a fixed xor-butterfly of wavefront shuffles, so results are
+//   bitwise reproducible (no atomics).  The epilogue (bias, ReLU, running layer sum, the next
+//   layer's tiny dense product, GraphSAGE's concat-dense-normalise, GAT's softmax weights) runs
+//   in the same kernel on the reduced row, and the result is written once, straight into the
+//   layer's column slice of the concatenation buffer.
+//
+// Reference semantics: see include/amar_hip.h (each entry point cites the reference file:line).
+#include "amar_common.h"
+
+namespace {
+
+constexpr int WAVES_PER_BLOCK = 4;
+
+// Sum over the row's non-zeros of w_p * X[col_p, 4q:4q+4]; every lane returns the row total of its quad.
+template <int LPN, bool HAS_VALS>
+__device__ __forceinline__ float4 row_gather_sum(const int32_t *__restrict__ colidx, const float *__restrict__ vals,
+                                                 const float *__restrict__ X, int64_t ldx, int beg, int end,
+                                                 int slot, int q) {
+    constexpr int NS = AMAR_WAVE / LPN;
+    float4 acc = f4_zero();
+    int p = beg + slot;
+    // two non-zeros per lane in flight: both index loads are issued before either gather
+    for (; p + NS < end; p += 2 * NS) {
+        const int c0 = colidx[p], c1 = colidx[p + NS];
+        const float v0 = HAS_VALS ? vals[p] : 1.f, v1 = HAS_VALS ? vals[p + NS] : 1.f;
+        const float4 x0 = *reinterpret_cast<const float4 *>(X + (int64_t)c0 * ldx + 4 * q);
+        const float4 x1 = *reinterpret_cast<const float4 *>(X + (int64_t)c1 * ldx + 4 * q);
+        acc = f4_fma(v0, x0, acc);
+        acc = f4_fma(v1, x1, acc);
+    }
+    if (p < end) {
+        const int c0 = colidx[p];
+        const float v0 = HAS_VALS ? vals[p] : 1.f;
+        const float4 x0 = *reinterpret_cast<const float4 *>(X + (int64_t)c0 * ldx + 4 * q);
+        acc = f4_fma(v0, x0, acc);
+    }
+#pragma unroll
+    for (int off = AMAR_WAVE / 2; off >= LPN; off >>= 1) acc = f4_add(acc, f4_shfl_xor(acc, off));
+    return acc;
+}
+
+// All lanes receive the full reduced row y[0:F] (lane qq of slot 0 holds quad qq).
+template <int F>
+__device__ __forceinline__ void broadcast_row(const float4 yq, float (&full)[F]) {
+#pragma unroll
+    for (int qq = 0; qq < F / 4; ++qq) {
+        const float4 t = f4_shfl(yq, qq);
+        full[4 * qq + 0] = t.x; full[4 * qq + 1] = t.y; full[4 * qq + 2] = t.z; full[4 * qq + 3] = t.w;
+    }
+}
+
+struct SpmmArgs {
+    const int32_t *rowptr; const int32_t *colidx; const float *vals;
+    const float *X; int64_t ldx;
+    float *Y; int64_t ldy;
+    const float *bias; int relu;
+    const float *acc_in; int64_t ld_acc_in; float *acc_out; int64_t ld_acc_out; float acc_div; int accum; int accum_div;
+    const float *Wn; int Cn; float *Hn; int64_t ldhn;
+    int n_rows;
+};
+
+template <int F, bool HAS_VALS, bool FUSE_NEXT>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void spmm_row_kernel(const SpmmArgs a) {
+    constexpr int LPN = F / 4;
+    const int lane = threadIdx.x & (AMAR_WAVE - 1);
+    const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= a.n_rows) return;                       // wave-uniform
+    const int q = lane % LPN, slot = lane / LPN;
+
+    float wn[F];                                       // column `lane` of the next layer's kernel
+    if (FUSE_NEXT) {
+#pragma unroll
+        for (int k = 0; k < F; ++k) wn[k] = lane < a.Cn ? a.Wn[k * a.Cn + lane] : 0.f;
+    }
+
+    const int beg = a.rowptr[row], end = a.rowptr[row + 1];
+    float4 y = row_gather_sum<LPN, HAS_VALS>(a.colidx, a.vals, a.X, a.ldx, beg, end, slot, q);
+
+    if (a.bias) {
+        const float4 b = *reinterpret_cast<const float4 *>(a.bias + 4 * q);
+        y = f4_add(y, b);
+    }
+    if (a.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+    if (slot == 0) {
+        if (a.Y) *reinterpret_cast<float4 *>(a.Y + (int64_t)row * a.ldy + 4 * q) = y;
+        if (a.accum) {
+            float4 s = *reinterpret_cast<const float4 *>(a.acc_in + (int64_t)row * a.ld_acc_in + 4 * q);
+            s = f4_add(s, y);
+            if (a.accum_div) { s.x /= a.acc_div; s.y /= a.acc_div; s.z /= a.acc_div; s.w /= a.acc_div; }
+            *reinterpret_cast<float4 *>(a.acc_out + (int64_t)row * a.ld_acc_out + 4 * q) = s;
+        }
+    }
+    if (FUSE_NEXT) {
+        float full[F];
+        broadcast_row<F>(y, full);
+        float h = 0.f;
+#pragma unroll
+        for (int k = 0; k < F; ++k) h = fmaf(full[k], wn[k], h);
+        if (lane < a.Cn) a.Hn[(int64_t)row * a.ldhn + lane] = h;
+    }
+}
+
+template <bool HAS_VALS, bool FUSE_NEXT>
+int launch_spmm(const SpmmArgs &a, int F, hipStream_t st) {
+    const dim3 grid((a.n_rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVES_PER_BLOCK * AMAR_WAVE);
+    switch (F) {
+    case 4:  hipLaunchKernelGGL((spmm_row_kernel<4, HAS_VALS, FUSE_NEXT>), grid, block, 0, st, a); break;
+    case 8:  hipLaunchKernelGGL((spmm_row_kernel<8, HAS_VALS, FUSE_NEXT>), grid, block, 0, st, a); break;
+    case 16: hipLaunchKernelGGL((spmm_row_kernel<16, HAS_VALS, FUSE_NEXT>), grid, block, 0, st, a); break;
+    case 32: hipLaunchKernelGGL((spmm_row_kernel<32, HAS_VALS, FUSE_NEXT>), grid, block, 0, st, a); break;
+    case 64: hipLaunchKernelGGL((spmm_row_kernel<64, HAS_VALS, FUSE_NEXT>), grid, block, 0, st, a); break;
+    default: return AMAR_EUNSUPPORTED;
+    }
+    return amar_check_launch();
+}
+
+bool ld_ok(int64_t ld, int F) { return ld >= F && (ld & 3) == 0; }
+
+// ---- row-wise X.W prologue -------------------------------------------------------------------
+struct XwArgs {
+    const float *X; int64_t ldx; int F; const float *W; int C;
+    float *H; int64_t ldh; float *copy_to; int64_t ld_copy;
+    const float *a_self; const float *a_neigh; float *s_self; float *s_neigh;
+    int n_rows;
+};
+
+// One wave handles 64/CP rows at a time (CP = C rounded up to a power of two): lane = (row slot, out column).
+__global__ __launch_bounds__(256) void rowwise_xw_kernel(const XwArgs a, int CP) {
+    extern __shared__ float w_lds[];                   // W[F][C]
+    for (int i = threadIdx.x; i < a.F * a.C; i += blockDim.x) w_lds[i] = a.W[i];
+    __syncthreads();
+    const int rows_per_block = blockDim.x / CP;
+    const int c = threadIdx.x % CP, rslot = threadIdx.x / CP;
+    for (int64_t row = (int64_t)blockIdx.x * rows_per_block + rslot; row < a.n_rows;
+         row += (int64_t)gridDim.x * rows_per_block) {
+        const float *x = a.X + row * a.ldx;
+        float h = 0.f;
+        if (c < a.C) {
+            for (int k = 0; k < a.F; ++k) h = fmaf(x[k], w_lds[k * a.C + c], h);
+            a.H[row * a.ldh + c] = h;
+        }
+        if (a.copy_to) for (int k = c; k < a.F; k += CP) a.copy_to[row * a.ld_copy + k] = x[k];
+        if (a.s_self) {
+            float ps = c < a.C ? h * a.a_self[c] : 0.f, pn = c < a.C ? h * a.a_neigh[c] : 0.f;
+            for (int off = CP / 2; off >= 1; off >>= 1) { ps += __shfl_xor(ps, off, 64); pn += __shfl_xor(pn, off, 64); }
+            if (c == 0) { a.s_self[row] = ps; a.s_neigh[row] = pn; }
+        }
+    }
+}
+
+// ---- GraphSAGE (mean) ------------------------------------------------------------------------
+struct SageArgs {
+    const int32_t *rowptr; const int32_t *colidx; const float *X; int64_t ldx;
+    const float *W; const float *bias; int C; float *Y; int64_t ldy; int self_loop; int n_rows;
+};
+
+template <int F>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void sage_row_kernel(const SageArgs a) {
+    constexpr int LPN = F / 4;
+    const int lane = threadIdx.x & (AMAR_WAVE - 1);
+    const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= a.n_rows) return;
+    const int q = lane % LPN, slot = lane / LPN;
+
+    float wx[F], wa[F];                                // column `lane` of W[0:F] (self) and W[F:2F] (aggregate)
+#pragma unroll
+    for (int k = 0; k < F; ++k) {
+        wx[k] = lane < a.C ? a.W[k * a.C + lane] : 0.f;
+        wa[k] = lane < a.C ? a.W[(F + k) * a.C + lane] : 0.f;
+    }
+    const int beg = a.rowptr[row], end = a.rowptr[row + 1];
+    float4 agg = row_gather_sum<LPN, false>(a.colidx, nullptr, a.X, a.ldx, beg, end, slot, q);
+    const float4 xs = *reinterpret_cast<const float4 *>(a.X + (int64_t)row * a.ldx + 4 * q);
+    float cnt = (float)(end - beg);
+    if (a.self_loop) { agg = f4_add(agg, xs); cnt += 1.f; }
+    cnt = fmaxf(cnt, 1.f);                             // unsorted_segment_mean of an empty segment is 0
+    agg.x /= cnt; agg.y /= cnt; agg.z /= cnt; agg.w /= cnt;
+
+    float fx[F], fa[F];
+    broadcast_row<F>(xs, fx);
+    broadcast_row<F>(agg, fa);
+    float o = 0.f;
+#pragma unroll
+    for (int k = 0; k < F; ++k) o = fmaf(fx[k], wx[k], o);
+#pragma unroll
+    for (int k = 0; k < F; ++k) o = fmaf(fa[k], wa[k], o);
+    o = lane < a.C ? o + a.bias[lane] : 0.f;
+    float ss = o * o;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    o *= rsqrtf(fmaxf(ss, 1e-12f));                    // tf.nn.l2_normalize(axis=-1), before the activation
+    o = fmaxf(o, 0.f);
+    if (lane < a.C) a.Y[(int64_t)row * a.ldy + lane] = o;
+}
+
+// ---- GAT (1 head) ----------------------------------------------------------------------------
+struct GatArgs {
+    const int32_t *rowptr; const int32_t *colidx; const float *H; int64_t ldh;
+    const float *s_self; const float *s_neigh; const float *bias; float *Y; int64_t ldy; int self_loop; int n_rows;
+};
+
+__device__ __forceinline__ float leaky02(float x) { return x > 0.f ? x : 0.2f * x; }
+
+template <int C>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void gat_row_kernel(const GatArgs a) {
+    constexpr int LPN = C / 4, NS = AMAR_WAVE / LPN;
+    const int lane = threadIdx.x & (AMAR_WAVE - 1);
+    const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= a.n_rows) return;
+    const int q = lane % LPN, slot = lane / LPN;
+    const int beg = a.rowptr[row], end = a.rowptr[row + 1];
+    const float si = a.s_self[row];
+
+    // pass 1: LeakyReLU is monotone, so max_j e_ij = LeakyReLU(s_i + max_j n_j)
+    float mn = a.self_loop ? a.s_neigh[row] : -INFINITY;
+    for (int p = beg + lane; p < end; p += AMAR_WAVE) mn = fmaxf(mn, a.s_neigh[a.colidx[p]]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) mn = fmaxf(mn, __shfl_xor(mn, off, 64));
+    const float emax = leaky02(si + mn);
+
+    // pass 2: un-normalised softmax weights and the weighted sum of source rows
+    float4 acc = f4_zero();
+    float den = 0.f;
+    for (int p = beg + slot; p < end; p += NS) {
+        const int c = a.colidx[p];
+        const float w = expf(leaky02(si + a.s_neigh[c]) - emax);
+        const float4 h = *reinterpret_cast<const float4 *>(a.H + (int64_t)c * a.ldh + 4 * q);
+        acc = f4_fma(w, h, acc);
+        if (q == 0) den += w;
+    }
+    if (a.self_loop && slot == 0) {
+        const float w = expf(leaky02(si + a.s_neigh[row]) - emax);
+        const float4 h = *reinterpret_cast<const float4 *>(a.H + (int64_t)row * a.ldh + 4 * q);
+        acc = f4_fma(w, h, acc);
+        if (q == 0) den += w;
+    }
+#pragma unroll
+    for (int off = AMAR_WAVE / 2; off >= LPN; off >>= 1) acc = f4_add(acc, f4_shfl_xor(acc, off));
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) den += __shfl_xor(den, off, 64);
+    const float inv = 1.f / (den + 1e-9f);
+    if (slot == 0) {
+        const float4 b = *reinterpret_cast<const float4 *>(a.bias + 4 * q);
+        float4 y = make_float4(fmaxf(acc.x * inv + b.x, 0.f), fmaxf(acc.y * inv + b.y, 0.f),
+                               fmaxf(acc.z * inv + b.z, 0.f), fmaxf(acc.w * inv + b.w, 0.f));
+        *reinterpret_cast<float4 *>(a.Y + (int64_t)row * a.ldy + 4 * q) = y;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int amar_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, const float *vals,
+                      const float *X, int64_t ldx, float *Y, int64_t ldy,
+                      int32_t n_rows, int32_t F, uint32_t flags, const float *bias,
+                      const float *acc_in, int64_t ld_acc_in, float *acc_out, int64_t ld_acc_out,
+                      float acc_div, amar_stream_t stream) {
+    if (n_rows < 0 || !rowptr || !X) return AMAR_EINVAL;
+    if (n_rows == 0) return AMAR_OK;
+    if (!colidx) return AMAR_EINVAL;
+    const bool accum = flags & AMAR_SPMM_ACCUM;
+    if (!Y && !accum) return AMAR_EINVAL;
+    if (!ld_ok(ldx, F) || !amar_aligned16(X)) return AMAR_EINVAL;
+    if (Y && (!ld_ok(ldy, F) || !amar_aligned16(Y))) return AMAR_EINVAL;
+    if ((flags & AMAR_SPMM_BIAS) && (!bias || !amar_aligned16(bias))) return AMAR_EINVAL;
+    if (accum && (!acc_in || !acc_out || !ld_ok(ld_acc_in, F) || !ld_ok(ld_acc_out, F) ||
+                  !amar_aligned16(acc_in) || !amar_aligned16(acc_out))) return AMAR_EINVAL;
+    if ((flags & AMAR_SPMM_ACCUM_DIV) && !(acc_div != 0.f)) return AMAR_EINVAL;
+    SpmmArgs a{};
+    a.rowptr = rowptr; a.colidx = colidx; a.vals = vals; a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy;
+    a.bias = (flags & AMAR_SPMM_BIAS) ? bias : nullptr; a.relu = (flags & AMAR_SPMM_RELU) ? 1 : 0;
+    a.acc_in = acc_in; a.ld_acc_in = ld_acc_in; a.acc_out = acc_out; a.ld_acc_out = ld_acc_out;
+    a.acc_div = acc_div; a.accum = accum ? 1 : 0; a.accum_div = (flags & AMAR_SPMM_ACCUM_DIV) ? 1 : 0;
+    a.n_rows = n_rows;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return vals ? launch_spmm<true, false>(a, F, st) : launch_spmm<false, false>(a, F, st);
+}
+
+int amar_gcn_layer_f32(const int32_t *rowptr, const int32_t *colidx, const float *vals,
+                       const float *H, int64_t ldh, int32_t C, const float *bias,
+                       float *Y, int64_t ldy,
+                       const float *Wnext, int32_t Cn, float *Hnext, int64_t ldhn,
+                       int32_t n_rows, amar_stream_t stream) {
+    if (n_rows < 0 || !rowptr || !H || !Y || !bias) return AMAR_EINVAL;
+    if (n_rows == 0) return AMAR_OK;
+    if (!colidx) return AMAR_EINVAL;
+    if (!ld_ok(ldh, C) || !ld_ok(ldy, C) || !amar_aligned16(H) || !amar_aligned16(Y) || !amar_aligned16(bias))
+        return AMAR_EINVAL;
+    if (Wnext && (!Hnext || Cn < 1 || ldhn < Cn)) return AMAR_EINVAL;
+    if (Wnext && Cn > 64) return AMAR_EUNSUPPORTED;
+    SpmmArgs a{};
+    a.rowptr = rowptr; a.colidx = colidx; a.vals = vals; a.X = H; a.ldx = ldh; a.Y = Y; a.ldy = ldy;
+    a.bias = bias; a.relu = 1; a.Wn = Wnext; a.Cn = Cn; a.Hn = Hnext; a.ldhn = ldhn; a.n_rows = n_rows;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (Wnext) return vals ? launch_spmm<true, true>(a, C, st) : launch_spmm<false, true>(a, C, st);
+    return vals ? launch_spmm<true, false>(a, C, st) : launch_spmm<false, false>(a, C, st);
+}
+
+int amar_rowwise_xw_f32(const float *X, int64_t ldx, int32_t F, const float *W, int32_t C,
+                        float *H, int64_t ldh, float *copy_to, int64_t ld_copy,
+                        const float *a_self, const float *a_neigh, float *s_self, float *s_neigh,
+                        int32_t n_rows, amar_stream_t stream) {
+    if (n_rows < 0 || !X || !W || !H || F < 1 || C < 1 || ldx < F || ldh < C) return AMAR_EINVAL;
+    if (F > 64 || C > 64) return AMAR_EUNSUPPORTED;
+    if (copy_to && ld_copy < F) return AMAR_EINVAL;
+    const bool attn = a_self || a_neigh || s_self || s_neigh;
+    if (attn && !(a_self && a_neigh && s_self && s_neigh)) return AMAR_EINVAL;
+    if (n_rows == 0) return AMAR_OK;
+    int CP = 1;
+    while (CP < C) CP <<= 1;
+    XwArgs a{X, ldx, F, W, C, H, ldh, copy_to, ld_copy, a_self, a_neigh, attn ? s_self : nullptr, s_neigh, n_rows};
+    const int rows_per_block = 256 / CP;
+    int64_t blocks = ((int64_t)n_rows + rows_per_block - 1) / rows_per_block;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(rowwise_xw_kernel, dim3((unsigned)blocks), dim3(256), (size_t)F * C * sizeof(float),
+                       static_cast<hipStream_t>(stream), a, CP);
+    return amar_check_launch();
+}
+
+int amar_sage_layer_f32(const int32_t *rowptr, const int32_t *colidx,
+                        const float *X, int64_t ldx, int32_t F,
+                        const float *W, const float *bias, int32_t C,
+                        float *Y, int64_t ldy, int32_t self_loop,
+                        int32_t n_rows, amar_stream_t stream) {
+    if (n_rows < 0 || !rowptr || !X || !W || !bias || !Y || C < 1 || ldy < C) return AMAR_EINVAL;
+    if (!ld_ok(ldx, F) || !amar_aligned16(X)) return AMAR_EINVAL;
+    if (C > 64) return AMAR_EUNSUPPORTED;
+    if (n_rows == 0) return AMAR_OK;
+    if (!colidx) return AMAR_EINVAL;
+    SageArgs a{rowptr, colidx, X, ldx, W, bias, C, Y, ldy, self_loop ? 1 : 0, n_rows};
+    const dim3 grid((n_rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVES_PER_BLOCK * AMAR_WAVE);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (F) {
+    case 4:  hipLaunchKernelGGL(sage_row_kernel<4>, grid, block, 0, st, a); break;
+    case 8:  hipLaunchKernelGGL(sage_row_kernel<8>, grid, block, 0, st, a); break;
+    case 16: hipLaunchKernelGGL(sage_row_kernel<16>, grid, block, 0, st, a); break;
+    case 32: hipLaunchKernelGGL(sage_row_kernel<32>, grid, block, 0, st, a); break;
+    default: return AMAR_EUNSUPPORTED;
+    }
+    return amar_check_launch();
+}
+
+int amar_gat_layer_f32(const int32_t *rowptr, const int32_t *colidx,
+                       const float *H, int64_t ldh, int32_t C,
+                       const float *s_self, const float *s_neigh, const float *bias,
+                       float *Y, int64_t ldy, int32_t self_loop,
+                       int32_t n_rows, amar_stream_t stream) {
+    if (n_rows < 0 || !rowptr || !H || !s_self || !s_neigh || !bias || !Y) return AMAR_EINVAL;
+    if (!ld_ok(ldh, C) || !ld_ok(ldy, C) || !amar_aligned16(H) || !amar_aligned16(Y) || !amar_aligned16(bias))
+        return AMAR_EINVAL;
+    if (n_rows == 0) return AMAR_OK;
+    if (!colidx) return AMAR_EINVAL;
+    GatArgs a{rowptr, colidx, H, ldh, s_self, s_neigh, bias, Y, ldy, self_loop ? 1 : 0, n_rows};
+    const dim3 grid((n_rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVES_PER_BLOCK * AMAR_WAVE);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (C) {
+    case 4:  hipLaunchKernelGGL(gat_row_kernel<4>, grid, block, 0, st, a); break;
+    case 8:  hipLaunchKernelGGL(gat_row_kernel<8>, grid, block, 0, st, a); break;
+    case 16: hipLaunchKernelGGL(gat_row_kernel<16>, grid, block, 0, st, a); break;
+    case 32: hipLaunchKernelGGL(gat_row_kernel<32>, grid, block, 0, st, a); break;
+    case 64: hipLaunchKernelGGL(gat_row_kernel<64>, grid, block, 0, st, a); break;
+    default: return AMAR_EUNSUPPORTED;
+    }
+    return amar_check_launch();
+}
+
+}  // extern "C"

@@ -193,3 +193,42 @@ def write_dataset(ds, dirpath, bert_dim=None, kge_dim=None):
         with open(paths['graph_filepath'], 'w') as fp:
             json.dump({'ent_embeddings': entity_embeddings(n_ent, kge_dim, 'kge').tolist()}, fp)
     return paths
+
+
+def ml1m_device(scale=64, seed=GRAPH_SEED, device=None):
+    """ml1m(s) drawn directly in index space on the GPU (torch as plumbing), for large scales.
+
+    Same shape laws as :func:`ml1m` (user activity, item popularity, 57.22 % positives, 80/20
+    split) but a different random stream: torch's device generator instead of numpy, and a
+    single draw-and-dedupe round.  Returns a dict of device tensors:
+    ``train_pos`` [E, 2] (user index, item index + |U|) of positive train ratings,
+    ``test`` [P, 2] pairs, plus ``n_users``, ``n_items``.  Used by bench.py only.
+    """
+    import torch
+    s = int(scale)
+    device = device or torch.device('cuda')
+    n_users, n_items = ML1M_USERS * s, ML1M_ITEMS * s
+    rng = np.random.default_rng(seed)
+    deg = torch.from_numpy(_user_degrees(rng, n_users, n_items, ML1M_RATINGS * s)).to(device)
+    gen = torch.Generator(device=device)
+    gen.manual_seed(seed)
+    item_of_rank = torch.randperm(n_items, device=device, generator=gen)
+    users = torch.repeat_interleave(torch.arange(n_users, device=device), deg)
+    uni = torch.rand(users.numel(), device=device, generator=gen, dtype=torch.float64)
+    c = _POP_OFFSET * n_items
+    e = 1.0 - _POP_ALPHA
+    lo, hi = c ** e, (n_items + c) ** e
+    ranks = ((lo + uni * (hi - lo)) ** (1.0 / e) - c).long().clamp_(0, n_items - 1)
+    del uni
+    keys = torch.unique(users * n_items + item_of_rank[ranks])
+    del users, ranks
+    u, i = keys // n_items, keys % n_items
+    del keys
+    liked = torch.rand(u.numel(), device=device, generator=gen) < ML1M_POSITIVE / ML1M_RATINGS
+    is_test = torch.rand(u.numel(), device=device, generator=gen) < 0.2
+    train_cnt = torch.bincount(i[~is_test], minlength=n_items)
+    is_test &= train_cnt[i] > 0
+    tr = liked & ~is_test
+    train_pos = torch.stack([u[tr], i[tr] + n_users], dim=1)
+    test = torch.stack([u[is_test], i[is_test] + n_users], dim=1)
+    return {'train_pos': train_pos, 'test': test, 'n_users': n_users, 'n_items': n_items, 'scale': s}

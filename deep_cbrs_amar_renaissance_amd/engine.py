@@ -1,0 +1,180 @@
+"""Minimal Keras-protocol layer/model base on top of torch tensors.
+
+The reference's driver talks to its models through the Keras protocol (`experiment.py:155-198`:
+``compile``, ``model(batch)``, ``summary``, ``trainable_weights``, ``fit``, ``evaluate``,
+``predict``).  This module provides that protocol for models whose arithmetic is the HIP
+library behind :mod:`deep_cbrs_amar_renaissance_amd.capi`; torch only owns the weights
+(device memory) and the stream.  Weights are created lazily on the first call, like Keras
+``build``, from a seeded numpy generator so that a given seed gives the same weights on every
+machine (`experiment.py:56` seeds TensorFlow the same way; the streams differ, the
+distributions — glorot_uniform kernels, zero biases — do not).
+"""
+import numpy as np
+import torch
+
+_SEED = 42
+_RNG = np.random.default_rng(_SEED)
+
+
+def set_seed(seed):
+    """Counterpart of ``tf.random.set_seed(config.seed)`` (experiment.py:56)."""
+    global _SEED, _RNG
+    _SEED = int(seed)
+    _RNG = np.random.default_rng(_SEED)
+
+
+def default_device():
+    return torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu')
+
+
+def glorot_uniform(shape, rng=None):
+    """Keras GlorotUniform with `_compute_fans`: leading dims of rank>2 kernels are a receptive field."""
+    shape = tuple(int(s) for s in shape)
+    if len(shape) == 1:
+        fan_in = fan_out = shape[0]
+    elif len(shape) == 2:
+        fan_in, fan_out = shape
+    else:
+        rf = int(np.prod(shape[:-2]))
+        fan_in, fan_out = shape[-2] * rf, shape[-1] * rf
+    limit = np.sqrt(6.0 / (fan_in + fan_out))
+    return (rng or _RNG).uniform(-limit, limit, size=shape).astype(np.float32)
+
+
+class L2:
+    """keras.regularizers.l2 stand-in: only carries the factor (training is out of scope)."""
+    def __init__(self, l2=0.01):
+        self.l2 = float(l2)
+
+
+class Layer(torch.nn.Module):
+    """A Keras-like layer: weights appear at the first call (``build``), then ``call`` runs."""
+
+    def __init__(self):
+        super().__init__()
+        self.built = False
+
+    def add_weight(self, name, shape, initializer='glorot_uniform', regularizer=None, trainable=True):
+        if initializer == 'glorot_uniform':
+            value = glorot_uniform(shape)
+        elif initializer == 'zeros':
+            value = np.zeros(shape, dtype=np.float32)
+        elif initializer == 'ones':
+            value = np.ones(shape, dtype=np.float32)
+        else:
+            raise ValueError("Unknown initializer {}".format(initializer))
+        p = torch.nn.Parameter(torch.from_numpy(value).to(default_device()), requires_grad=trainable)
+        p.regularizer = regularizer
+        self.__dict__.pop(name, None)                 # a `self.kernel = None` placeholder set in __init__
+        self.register_parameter(name, p)
+        return p
+
+    def build(self, input_shape):
+        pass
+
+    def call(self, inputs, **kwargs):
+        raise NotImplementedError
+
+    @staticmethod
+    def _shape_of(inputs):
+        if isinstance(inputs, (list, tuple)):
+            return [Layer._shape_of(i) for i in inputs]
+        return tuple(inputs.shape) if hasattr(inputs, 'shape') else None
+
+    def forward(self, inputs=None, **kwargs):
+        if not self.built:
+            self.build(self._shape_of(inputs))
+            self.built = True
+        with torch.no_grad():
+            return self.call(inputs, **kwargs)
+
+    @property
+    def trainable_weights(self):
+        return [p for p in self.parameters() if p.requires_grad]
+
+    @property
+    def non_trainable_weights(self):
+        return [p for p in self.parameters() if not p.requires_grad]
+
+    @property
+    def weights_version(self):
+        """Changes whenever any weight is modified in place or replaced (hoisting cache key)."""
+        return tuple((id(p), p._version) for p in self.parameters())
+
+
+def to_device_tensor(x, dtype=torch.float32):
+    """numpy / torch input -> contiguous device tensor of `dtype` (no copy if already there)."""
+    if isinstance(x, torch.Tensor):
+        t = x
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(x))
+    return t.to(device=default_device(), dtype=dtype).contiguous()
+
+
+def ids_to_device(ids):
+    """Host int64 ids (numpy default, datasets.py:203) -> device int32."""
+    if isinstance(ids, torch.Tensor):
+        t = ids
+    else:
+        t = torch.from_numpy(np.ascontiguousarray(ids))
+    if t.numel() and (int(t.max()) >= 2 ** 31 or int(t.min()) < 0):
+        raise ValueError("ids must be in [0, 2^31)")
+    return t.to(device=default_device(), dtype=torch.int32).contiguous()
+
+
+class Model(Layer):
+    """Keras ``Model`` protocol used by the reference driver (experiment.py:155-198)."""
+
+    def compile(self, loss=None, optimizer=None, metrics=None):
+        self.loss, self.optimizer, self.metrics = loss, optimizer, list(metrics or [])
+
+    def summary(self, print_fn=print, expand_nested=False):
+        print_fn('Model: "{}"'.format(type(self).__name__))
+        rows = self.named_parameters() if expand_nested else \
+            ((n, p) for n, p in self.named_parameters())
+        for name, p in rows:
+            print_fn('  {:<48s} {:>18s} {:>10d}'.format(name, str(tuple(p.shape)), p.numel()))
+        trainable = sum(p.numel() for p in self.trainable_weights)
+        print_fn('Trainable params: {}'.format(trainable))
+        print_fn('Non-trainable params: {}'.format(sum(p.numel() for p in self.non_trainable_weights)))
+
+    def fit(self, *args, **kwargs):
+        raise NotImplementedError(
+            "training (BCE + Adam backward pass) is the next scope row (SURVEY.md §8f N1); "
+            "this build implements the forward / scoring path")
+
+    # -- inference ---------------------------------------------------------------------------
+    def _predict_batches(self, sequence):
+        outs = []
+        for b in range(len(sequence)):
+            inputs, _ = sequence[b]
+            outs.append(self(inputs))
+        return torch.cat(outs, dim=0) if outs else torch.empty((0, 1), device=default_device())
+
+    def predict(self, sequence, hoist=True, **kwargs):
+        """Scores for every pair of `sequence` as an ``ndarray[P, 1]`` (experiment.py:197-198).
+
+        hoist=True runs the (input-independent, gnn.py:263-264) graph propagation once for the
+        whole call; hoist=False re-runs it for every batch exactly like the reference does.
+        """
+        self._hoist_begin(hoist)
+        try:
+            return self._predict_batches(sequence).cpu().numpy()
+        finally:
+            self._hoist_end()
+
+    def _hoist_begin(self, hoist):
+        pass
+
+    def _hoist_end(self):
+        pass
+
+    def evaluate(self, sequence, **kwargs):
+        """Loss (binary cross-entropy) and accuracy on `sequence` (experiment.py:194)."""
+        pred = self.predict(sequence).reshape(-1).astype(np.float64)
+        y = np.concatenate([np.asarray(sequence[b][1]).reshape(-1) for b in range(len(sequence))]).astype(np.float64)
+        eps = 1e-7                                                   # keras backend epsilon
+        p = np.clip(pred, eps, 1 - eps)
+        loss = float(-np.mean(y * np.log(p) + (1 - y) * np.log(1 - p))) if len(y) else 0.0
+        acc = float(np.mean((pred > 0.5) == (y > 0.5))) if len(y) else 0.0
+        return [loss, acc]

@@ -1,0 +1,42 @@
+"""GraphSageConv: the Spektral layer the reference instantiates at `src/models/gnn.py:354-361`.
+
+Spektral 1.x semantics, aggregate='mean' (`config.yaml:18`):
+
+    a    <- add_self_loops(a)
+    agg  =  unsorted_segment_mean( X[source], target )       edge values ignored, duplicates counted
+    X'   =  act( l2_normalize( [X || agg] . W + b ) )         W [2 F, C]; normalise BEFORE the activation
+
+Spektral is not installed here, so three points are explicit switches: the added
+self loop (``self_loops``), the concat order ``[x, agg]`` and normalise-before-activation (fixed).
+"""
+import torch
+
+from deep_cbrs_amar_renaissance_amd import capi
+from deep_cbrs_amar_renaissance_amd.engine import Layer
+
+
+class GraphSageConv(Layer):
+    def __init__(self, channels, aggregate='mean', activation=None, use_bias=True, kernel_regularizer=None,
+                 bias_regularizer=None, self_loops=True, **kwargs):
+        super().__init__()
+        if aggregate != 'mean':
+            raise NotImplementedError("only aggregate='mean' (config.yaml:18) has a HIP kernel")
+        if activation != 'relu' or not use_bias:
+            raise NotImplementedError("the HIP GraphSAGE layer is built for activation='relu', use_bias=True")
+        self.channels, self.aggregate, self.self_loops = channels, aggregate, self_loops
+        self.kernel_regularizer, self.bias_regularizer = kernel_regularizer, bias_regularizer
+        self.kernel = self.bias = None
+
+    def build(self, input_shape):
+        f_in = input_shape[0][-1]
+        self.kernel = self.add_weight('kernel', (2 * f_in, self.channels), 'glorot_uniform', self.kernel_regularizer)
+        self.bias = self.add_weight('bias', (self.channels,), 'zeros', self.bias_regularizer)
+
+    def call(self, inputs, out=None, **kwargs):
+        x, a = inputs
+        if a.vals is not None:
+            raise ValueError("GraphSageConv expects the raw edge list (DeviceCSR without values)")
+        if out is None:
+            out = torch.empty((a.shape[0], self.channels), dtype=torch.float32, device=x.device)
+        capi.sage_layer(a.rowptr, a.colidx, x, self.kernel, self.bias, out, self_loop=self.self_loops)
+        return out

@@ -1,0 +1,79 @@
+"""Dense stacks of the scoring heads — mirrors `/root/reference/src/models/dense.py:4-17`.
+
+``Dense`` is Keras' layer (act(x . W + b), W [in, out] glorot_uniform, b zeros) running on
+`amar_dense_f32` (fp32 MFMA).  ``Sequential`` threads two layout hooks through a stack:
+``ids`` lets the FIRST layer gather its input rows from a table (the embedding lookup of
+`basic.py:73-74` fused into the GEMM's load), and ``out`` lets the LAST layer write into a
+column slice of a wider buffer (the Concatenate of `basic.py:35`).
+"""
+import torch
+
+from deep_cbrs_amar_renaissance_amd import capi
+from deep_cbrs_amar_renaissance_amd.engine import Layer, to_device_tensor
+
+
+class Dense(Layer):
+    def __init__(self, units, activation=None, **kwargs):
+        super().__init__()
+        if activation not in capi.ACT_CODES:
+            raise NotImplementedError("activation '{}' has no HIP epilogue (relu, sigmoid, linear do)".format(activation))
+        self.units, self.activation = int(units), activation
+        self.kernel = self.bias = None
+
+    def build(self, input_shape):
+        self.kernel = self.add_weight('kernel', (input_shape[-1], self.units), 'glorot_uniform')
+        self.bias = self.add_weight('bias', (self.units,), 'zeros')
+
+    def call(self, x, out=None, ids=None, **kwargs):
+        m = ids.numel() if ids is not None else x.shape[0]
+        if out is None:
+            out = torch.empty((m, self.units), dtype=torch.float32, device=x.device)
+        capi.dense(x, self.kernel, self.bias, out, act=self.activation, ids=ids)
+        return out
+
+
+class Sequential(Layer):
+    def __init__(self, layers):
+        super().__init__()
+        self.layers = torch.nn.ModuleList(layers)
+
+    def call(self, x, out=None, ids=None, **kwargs):
+        x = to_device_tensor(x)
+        n = len(self.layers)
+        if n == 0:
+            if ids is not None or out is not None:
+                raise ValueError("an empty dense stack cannot gather or redirect its output")
+            return x
+        for k, layer in enumerate(self.layers):
+            x = layer(x, out=out if k == n - 1 else None, ids=ids if k == 0 else None)
+        return x
+
+    def build_chain(self, in_dim):
+        """Create every layer's weights for a known input width (no device work); returns the output width."""
+        for layer in self.layers:
+            if not layer.built:
+                layer.build((None, in_dim))
+                layer.built = True
+            in_dim = layer.units
+        self.built = True
+        return in_dim
+
+    @property
+    def output_units(self):
+        return self.layers[-1].units if len(self.layers) else None
+
+
+def build_dense_network(units, **kwargs):
+    return Sequential([Dense(u, **kwargs) for u in units])
+
+
+def build_dense_classifier(units, n_classes, **kwargs):
+    if n_classes != 1:
+        raise NotImplementedError("softmax classifiers are not on the hot path (n_classes=1 everywhere in the reference)")
+    clf_kwargs = dict(kwargs)
+    clf_kwargs['activation'] = 'sigmoid'
+    return Sequential([Dense(u, **kwargs) for u in units] + [Dense(n_classes, **clf_kwargs)])
+
+
+def build_residual_dense_network(units, **kwargs):
+    raise NotImplementedError("residual heads (hybrid-gnn-tweaks) are out of scope for the HIP path (SURVEY.md §8f N4)")

@@ -1,0 +1,241 @@
+"""Graph propagation models — mirrors `/root/reference/src/models/gnn.py:13-84, 210-388`.
+
+``SequentialGNN`` owns the trainable [N, d] node table and the constant adjacency (in HBM as
+CSR) and runs the convolution stack over the FULL graph; its output does not depend on the
+batch (`gnn.py:263-264` passes ``None``).  Every layer writes its result straight into its
+column slice of one [N, d(L+1)] buffer, which makes the 'concatenation' reduction free.
+
+All-GCN stacks take a fused route: one `amar_rowwise_xw_f32` prologue (X_0.W_1, plus the X_0
+slice copy) and then ONE kernel per layer, whose epilogue applies bias + ReLU, stores the
+slice and multiplies by the next layer's kernel.  LightGCN stacks keep the running layer sum in
+the SpMM epilogue ('mean' reduction).  GraphSAGE / GAT consume the raw edge list (duplicates
+kept, `utilities/math.py`), exactly as the reference hands Spektral an un-normalised matrix
+(`gnn.py:316-319, 349-352`).
+
+DGCF and the Half/FullInput variants are out of scope.
+"""
+import abc
+
+import torch
+
+from deep_cbrs_amar_renaissance_amd import capi
+from deep_cbrs_amar_renaissance_amd.engine import Layer, Model, L2
+from deep_cbrs_amar_renaissance_amd.layers.gat_conv import GATConv
+from deep_cbrs_amar_renaissance_amd.layers.gcn_conv import GCNConv
+from deep_cbrs_amar_renaissance_amd.layers.graphsage_conv import GraphSageConv
+from deep_cbrs_amar_renaissance_amd.layers.lightgcn_conv import LightGCNConv
+from deep_cbrs_amar_renaissance_amd.layers.reduction import ReductionLayer
+from deep_cbrs_amar_renaissance_amd.utilities.math import convert_to_tensor
+
+
+class SequentialGNN(Model):
+    def __init__(
+            self,
+            adj_matrix,
+            seq_layers,
+            embedding_dim=8,
+            final_node='concatenation',
+            dropout=None,
+            regularizer=None,
+            cache_neighbours=False
+    ):
+        """
+        :param adj_matrix: the (sparse) graph adjacency matrix, already pre-processed for the layer type.
+        :param seq_layers: list of GNN layers.
+        :param embedding_dim: width of the trainable node table.
+        :param final_node: 'concatenation', 'sum', 'mean' or 'last'.
+        :param dropout: must be None (no `dropout` key exists in config.yaml; training-only anyway).
+        :param regularizer: regulariser object carried by the node table.
+        :param cache_neighbours: must be False (the reference raises NotImplementedError too, gnn.py:52-53).
+        """
+        super().__init__()
+        if cache_neighbours:
+            raise NotImplementedError("Multi-hops neighbours caching is not yet completely supported!")
+        if dropout:
+            raise NotImplementedError("dropout is a training-time feature; inference treats it as identity")
+        self.cache_neighbours = cache_neighbours
+        self.embeddings = self.add_weight('embeddings', (adj_matrix.shape[0], embedding_dim),
+                                          'glorot_uniform', regularizer)
+        # GraphSAGE / GAT ignore edge values and add their own self loop
+        edge_list = any(isinstance(l, (GraphSageConv, GATConv)) for l in seq_layers)
+        self.adj_matrix = convert_to_tensor(adj_matrix, with_values=not edge_list, drop_diagonal=edge_list)
+        self.dropout = None
+        self.final_node = final_node
+        self.reduce = ReductionLayer(final_node)
+        self.seq_layers = torch.nn.ModuleList(seq_layers)
+        self.built = True
+
+    @property
+    def n_hops(self):
+        return len(self.seq_layers)
+
+    def __len__(self):
+        return self.n_hops
+
+    def layer_widths(self):
+        widths = [int(self.embeddings.shape[1])]
+        for layer in self.seq_layers:
+            widths.append(int(layer.channels) if layer.channels is not None else widths[-1])
+        return widths
+
+    def output_dim(self):
+        widths = self.layer_widths()
+        return sum(widths) if self.final_node == 'concatenation' else widths[-1]
+
+    def _build_layers(self, widths):
+        for layer, f_in in zip(self.seq_layers, widths[:-1]):
+            if not layer.built:
+                layer.build([(self.embeddings.shape[0], f_in), self.adj_matrix.shape])
+                layer.built = True
+
+    def call(self, inputs=None, **kwargs):
+        x, a = self.embeddings, self.adj_matrix
+        n = x.shape[0]
+        widths = self.layer_widths()
+        self._build_layers(widths)
+        dev = x.device
+        layers = list(self.seq_layers)
+
+        if self.final_node == 'mean' and layers and all(isinstance(l, LightGCNConv) for l in layers):
+            # running sum S_l = S_{l-1} + X_l in the SpMM epilogue; the last layer divides by L+1
+            acc = x
+            for k, layer in enumerate(layers):
+                last = k == len(layers) - 1
+                acc_out = torch.empty((n, widths[0]), dtype=torch.float32, device=dev)
+                nxt = None if last else torch.empty((n, widths[0]), dtype=torch.float32, device=dev)
+                capi.spmm_csr(a.rowptr, a.colidx, a.vals, x, nxt, acc_in=acc, acc_out=acc_out,
+                              acc_div=len(layers) + 1 if last else None)
+                x, acc = nxt, acc_out
+            return acc
+
+        cat = torch.empty((n, sum(widths)), dtype=torch.float32, device=dev)
+        offs = [sum(widths[:k]) for k in range(len(widths) + 1)]
+        slices = [cat[:, offs[k]:offs[k + 1]] for k in range(len(widths))]
+
+        if layers and all(isinstance(l, GCNConv) for l in layers):
+            h = torch.empty((n, widths[1]), dtype=torch.float32, device=dev)
+            capi.rowwise_xw(x, layers[0].kernel, h, copy_to=slices[0])
+            for k, layer in enumerate(layers):
+                nxt = layers[k + 1] if k + 1 < len(layers) else None
+                h_next = torch.empty((n, widths[k + 2]), dtype=torch.float32, device=dev) if nxt is not None else None
+                capi.gcn_layer(a.rowptr, a.colidx, a.vals, h, layer.bias, slices[k + 1],
+                               Wnext=nxt.kernel if nxt is not None else None, Hnext=h_next)
+                h = h_next
+        else:
+            capi.copy_columns(x, slices[0])
+            for k, layer in enumerate(layers):
+                layer([slices[k], a], out=slices[k + 1])
+
+        if self.final_node == 'concatenation':
+            return cat
+        if self.final_node == 'last':
+            return slices[-1]
+        if len(set(widths)) != 1:
+            raise ValueError("'{}' needs layers of equal width".format(self.final_node))
+        out = torch.empty((n, widths[0]), dtype=torch.float32, device=dev)
+        capi.reduce_layers(cat, len(widths), widths[0], out, mean=self.final_node == 'mean')
+        return out
+
+
+class GNN(Model, abc.ABC):
+    def __init__(
+            self,
+            adj_matrix,
+            n_hops,
+            embedding_dim=8,
+            final_node="concatenation",
+            dropout=None,
+            l2_regularizer=None,
+            cache_neighbours=False,
+            **kwargs
+    ):
+        """
+        :param adj_matrix: the (sparse) graph adjacency matrix.
+        :param n_hops: number of convolution layers.
+        :param embedding_dim: width of the trainable node table.
+        :param final_node: 'concatenation', 'sum', 'mean' or 'last'.
+        :param dropout: see SequentialGNN.
+        :param l2_regularizer: L2 factor carried by the node table and the layers' weights (may be None).
+        :param cache_neighbours: see SequentialGNN.
+        :param kwargs: unused (the driver passes the whole `model:` config section, experiment.py:146-153).
+        """
+        super().__init__()
+        if isinstance(l2_regularizer, str):                   # PyYAML reads '1e-4' (no dot) as a string
+            l2_regularizer = float(l2_regularizer)
+        regularizer = L2(l2_regularizer) if l2_regularizer is not None else None
+        gnn_layers = [self.build_gnn_layer(i, regularizer=regularizer) for i in range(n_hops)]
+        self.gnn_layers = SequentialGNN(
+            adj_matrix, gnn_layers,
+            embedding_dim=embedding_dim, final_node=final_node,
+            dropout=dropout, regularizer=regularizer, cache_neighbours=cache_neighbours
+        )
+        self.built = True
+        self._hoisted = None
+        self.hoist = False
+
+    @abc.abstractmethod
+    def build_gnn_layer(self, i, **kwargs):
+        pass
+
+    def output_dim(self):
+        return self.gnn_layers.output_dim()
+
+    def call(self, inputs=None, **kwargs):
+        """Node representations [N, F_out]; `inputs` is ignored like in the reference (gnn.py:263-264)."""
+        if not self.hoist:
+            return self.gnn_layers(None)
+        version = self.weights_version
+        if self._hoisted is None or self._hoisted[0] != version:
+            self._hoisted = (version, self.gnn_layers(None))
+        return self._hoisted[1]
+
+
+class GCN(GNN):
+    def __init__(self, adj_matrix, n_hiddens=(8, 8, 8), **kwargs):
+        self.n_hiddens = list(n_hiddens)
+        adj_matrix = GCNConv.preprocess(adj_matrix)           # gnn.py:283
+        super().__init__(adj_matrix, len(self.n_hiddens), **kwargs)
+
+    def build_gnn_layer(self, i, regularizer=None, **kwargs):
+        return GCNConv(self.n_hiddens[i], activation='relu',
+                       kernel_regularizer=regularizer, bias_regularizer=regularizer)
+
+
+class GAT(GNN):
+    def __init__(self, adj_matrix, n_hiddens=(8, 8, 8), dropout_rate=0.0, **kwargs):
+        self.n_hiddens = list(n_hiddens)
+        self.dropout_rate = dropout_rate
+        super().__init__(adj_matrix, len(self.n_hiddens), **kwargs)
+
+    def build_gnn_layer(self, i, regularizer=None, **kwargs):
+        return GATConv(self.n_hiddens[i], dropout_rate=self.dropout_rate, activation='relu',
+                       kernel_regularizer=regularizer, bias_regularizer=regularizer)
+
+
+class GraphSage(GNN):
+    def __init__(self, adj_matrix, n_hiddens=(8, 8, 8), aggregate='mean', **kwargs):
+        self.n_hiddens = list(n_hiddens)
+        self.aggregate = aggregate
+        super().__init__(adj_matrix, len(self.n_hiddens), **kwargs)
+
+    def build_gnn_layer(self, i, regularizer=None, **kwargs):
+        return GraphSageConv(self.n_hiddens[i], activation='relu', aggregate=self.aggregate,
+                             kernel_regularizer=regularizer, bias_regularizer=regularizer)
+
+
+class LightGCN(GNN):
+    def __init__(self, adj_matrix, n_layers=3, **kwargs):
+        kwargs['final_node'] = 'mean'                          # gnn.py:378
+        adj_matrix = LightGCNConv.preprocess(adj_matrix)       # gnn.py:381
+        super().__init__(adj_matrix, n_layers, **kwargs)
+
+    def build_gnn_layer(self, i, **kwargs):
+        return LightGCNConv()
+
+
+class DGCF(GNN):
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("DGCF is out of scope for the HIP path (SURVEY.md §8f N4)")
+
+    def build_gnn_layer(self, i, **kwargs):
+        raise NotImplementedError

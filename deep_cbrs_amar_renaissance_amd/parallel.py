@@ -1,0 +1,189 @@
+"""Multi-GPU execution of the hot path: node-range partition + per-layer all-gather.
+
+The reference is single-device; this layer is new design.  One process per GPU
+(``torch.distributed``, backend ``nccl`` = RCCL over xGMI).  The graph propagation Y = A_hat.X
+is row-separable, the scoring head is pair-separable:
+
+* rows of A_hat are split into contiguous ranges of (nearly) equal non-zero count, one per rank;
+* node tables live in a *padded* index space: node j owned by rank r at local offset o sits at
+  row r*R + o (R = largest range), so that ``all_gather_into_tensor`` of equal [R, C] shards
+  lands directly in the layout the next SpMM gathers from — the local CSR's column indices are
+  remapped once, at partition time, and no compaction pass is needed;
+* per GCN layer: ONE local fused SpMM kernel, then ONE all-gather of the [R, C_next] block the
+  next layer consumes (the bipartite id grouping means every rank needs nearly all rows of the
+  other node type, so a plain all-gather beats a sparse halo exchange);
+* the weights (node table included) are replicated, so the X_0.W_1 prologue needs no exchange;
+* after the last layer the [R, F_cat] block of final node representations is all-gathered once,
+  and every rank scores its contiguous 1/G slice of the pair list.
+
+``ops`` is the kernel provider (the ctypes binding by default); tests inject a CPU stand-in to
+exercise the partition / exchange logic under ``gloo`` without a GPU.
+"""
+import numpy as np
+import torch
+
+from deep_cbrs_amar_renaissance_amd import capi
+from deep_cbrs_amar_renaissance_amd.layers.gcn_conv import GCNConv
+from deep_cbrs_amar_renaissance_amd.utilities.math import DeviceCSR
+
+
+def partition_rows_by_nnz(rowptr, world):
+    """Boundaries b[0..world] of contiguous row ranges with (nearly) equal non-zero counts."""
+    rowptr = rowptr.to(torch.int64)
+    n = rowptr.numel() - 1
+    nnz = int(rowptr[-1])
+    targets = torch.arange(1, world, dtype=torch.int64, device=rowptr.device) * nnz // world
+    cuts = torch.searchsorted(rowptr, targets, right=False).clamp_(0, n)
+    bounds = [0] + [int(c) for c in cuts.cpu()] + [n]
+    for k in range(1, len(bounds)):                      # monotone even for degenerate inputs
+        bounds[k] = max(bounds[k], bounds[k - 1])
+    return bounds
+
+
+class RowPartition:
+    def __init__(self, bounds):
+        self.bounds = list(bounds)
+        self.world = len(bounds) - 1
+        self.n = bounds[-1]
+        self.R = max(1, max(bounds[k + 1] - bounds[k] for k in range(self.world)))
+        # round the shard height up so that every shard base stays 16-byte aligned for any width
+        self.R = (self.R + 3) // 4 * 4
+
+    def rows(self, rank):
+        return self.bounds[rank + 1] - self.bounds[rank]
+
+    def padded_index(self, ids):
+        """Global node ids (int tensor) -> rows of the padded [world*R, *] tables."""
+        b = torch.tensor(self.bounds, dtype=torch.int64, device=ids.device)
+        ids = ids.to(torch.int64)
+        owner = torch.searchsorted(b, ids, right=True) - 1
+        owner.clamp_(0, self.world - 1)
+        return owner * self.R + (ids - b[owner])
+
+    def pad_table(self, table):
+        """[n, C] table in global order -> [world*R, C] padded layout (padding rows zero)."""
+        out = torch.zeros((self.world * self.R, table.shape[1]), dtype=table.dtype, device=table.device)
+        idx = self.padded_index(torch.arange(self.n, device=table.device))
+        out[idx] = table
+        return out
+
+    def local_csr(self, a, rank):
+        """Rows [b_r, b_{r+1}) of `a` with column indices remapped to the padded space."""
+        lo, hi = self.bounds[rank], self.bounds[rank + 1]
+        rp = a.rowptr[lo:hi + 1].to(torch.int64)
+        p0, p1 = int(rp[0]), int(rp[-1])
+        colidx = self.padded_index(a.colidx[p0:p1]).to(torch.int32).contiguous()
+        vals = a.vals[p0:p1].contiguous() if a.vals is not None else None
+        return DeviceCSR((rp - p0).to(torch.int32).contiguous(), colidx, vals, (hi - lo, self.world * self.R),
+                         gcn_filtered=a.gcn_filtered)
+
+
+class SingleRunner:
+    """world == 1: the model's own path, no padding, no exchange."""
+
+    def __init__(self, model, u_ids, i_ids):
+        self.model, self.u_ids, self.i_ids = model, u_ids, i_ids
+        a = model.gnn.gnn_layers.adj_matrix
+        self.local_rows, self.local_nnz = a.shape[0], a.nnz
+        self._prop_ms = None
+
+    def step(self):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        emb = self.model.gnn(None)
+        e1.record()
+        self._events = (e0, e1)
+        return self.model.rs([emb, emb], u_ids=self.u_ids, i_ids=self.i_ids)
+
+    def last_propagation_ms(self):
+        e0, e1 = self._events
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+
+    def describe(self):
+        return 'single GPU'
+
+
+class PartitionedGCNRunner:
+    """BasicGCN over `world` ranks: row-range SpMM + per-layer all-gather, pair-sharded scoring."""
+
+    def __init__(self, model, u_ids, i_ids, rank, world, ops=capi, dist=None, timing=True):
+        self.ops, self.rank, self.world, self.timing = ops, rank, world, timing
+        self.dist = dist if dist is not None else torch.distributed
+        seq = model.gnn.gnn_layers
+        if not all(isinstance(l, GCNConv) for l in seq.seq_layers) or seq.final_node != 'concatenation':
+            raise NotImplementedError("the partitioned runner covers GCN stacks with the 'concatenation' reduction")
+        self.model, self.seq = model, seq
+        a = seq.adj_matrix
+        self.part = RowPartition(partition_rows_by_nnz(a.rowptr, world))
+        self.csr = self.part.local_csr(a, rank)
+        self.local_rows, self.local_nnz = self.csr.shape[0], self.csr.nnz
+        self.widths = seq.layer_widths()
+        # replicated node table in the padded layout (rebuilt when the weights change)
+        self._x0_version, self._x0p = None, None
+        # this rank's contiguous slice of the pair list, ids moved to the padded space
+        p = int(u_ids.numel())
+        lo, hi = p * rank // world, p * (rank + 1) // world
+        self.u_ids = self.part.padded_index(u_ids[lo:hi]).to(torch.int32).contiguous()
+        self.i_ids = self.part.padded_index(i_ids[lo:hi]).to(torch.int32).contiguous()
+        self.pair_range = (lo, hi)
+        self._events = None
+
+    def _x0_padded(self):
+        emb = self.seq.embeddings
+        if self._x0_version != emb._version:
+            self._x0p, self._x0_version = self.part.pad_table(emb.detach()), emb._version
+        return self._x0p
+
+    def propagate(self):
+        """Returns the [world*R, F_cat] table of final node representations (padded layout)."""
+        ops, part, R, dev = self.ops, self.part, self.part.R, self.seq.embeddings.device
+        layers, widths = list(self.seq.seq_layers), self.widths
+        rows = self.local_rows
+        x0p = self._x0_padded()
+        base = self.rank * R
+        f_cat = sum(widths)
+        e_local = torch.zeros((R, f_cat), dtype=torch.float32, device=dev)
+        offs = np.cumsum([0] + widths)
+        ops.copy_columns(x0p[base:base + rows], e_local[:rows, :widths[0]])
+        h = torch.empty((self.world * R, widths[1]), dtype=torch.float32, device=dev)
+        ops.rowwise_xw(x0p, layers[0].kernel, h)                           # replicated weights: no exchange
+        for k, layer in enumerate(layers):
+            nxt = layers[k + 1] if k + 1 < len(layers) else None
+            h_next = torch.zeros((R, widths[k + 2]), dtype=torch.float32, device=dev) if nxt is not None else None
+            ops.gcn_layer(self.csr.rowptr, self.csr.colidx, self.csr.vals, h, layer.bias,
+                          e_local[:rows, offs[k + 1]:offs[k + 2]],
+                          Wnext=nxt.kernel if nxt is not None else None,
+                          Hnext=h_next[:rows] if nxt is not None else None)
+            if nxt is not None:
+                h = torch.empty((self.world * R, widths[k + 2]), dtype=torch.float32, device=dev)
+                self.dist.all_gather_into_tensor(h, h_next)
+        e_all = torch.empty((self.world * R, f_cat), dtype=torch.float32, device=dev)
+        self.dist.all_gather_into_tensor(e_all, e_local)
+        return e_all
+
+    def step(self):
+        if self.timing:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        emb = self.propagate()
+        if self.timing:
+            e1.record()
+            self._events = (e0, e1)
+        return self.model.rs([emb, emb], u_ids=self.u_ids, i_ids=self.i_ids)
+
+    def last_propagation_ms(self):
+        if not self._events:
+            return None
+        e0, e1 = self._events
+        e1.synchronize()
+        return e0.elapsed_time(e1)
+
+    def describe(self):
+        return 'node-range partition over {} GPUs (equal nnz), per-layer RCCL all-gather, pair-sharded scoring'.format(self.world)
+
+
+def make_runner(model, u_ids, i_ids, rank=0, world=1):
+    if world == 1:
+        return SingleRunner(model, u_ids, i_ids)
+    return PartitionedGCNRunner(model, u_ids, i_ids, rank, world)

@@ -1,0 +1,139 @@
+"""Adjacency helpers of the hot path: symmetrisation, GCN filter, scipy -> device CSR.
+
+Mirrors `/root/reference/src/utilities/math.py:6-56` (``symmetrize_matrix``, ``convert_to_tensor``,
+``sparse_matrix_to_tensor``) and Spektral's ``utils.gcn_filter`` (call sites
+`src/models/gnn.py:283,381`, `src/layers/lightgcn_conv.py:56-58`).  Where the reference builds a
+``tf.SparseTensor`` (COO, int64 indices, row-major reorder) this builds a :class:`DeviceCSR`
+(int32 rowptr/colidx + fp32 values resident in HBM): the same non-zeros in the same row-major
+order — duplicates included — in 8 bytes per non-zero instead of 20.
+"""
+import numpy as np
+import torch
+from scipy import sparse
+
+from deep_cbrs_amar_renaissance_amd.engine import default_device
+
+
+def symmetrize_matrix(x):
+    """Symmetrise a matrix; a sparse one by appending the transposed triplets (no dedupe)."""
+    if sparse.issparse(x):
+        x = x.tocoo()
+        rows = np.concatenate([x.row, x.col])
+        cols = np.concatenate([x.col, x.row])
+        data = np.concatenate([x.data, x.data])
+        return sparse.coo_matrix((data, (rows, cols)), shape=x.shape, dtype=x.dtype)
+    return np.maximum(x, x.T)
+
+
+def gcn_filter(a, symmetric=True):
+    """D^-1/2 (A + I) D^-1/2 (or D^-1 (A + I)) in the matrix dtype, as Spektral's ``gcn_filter``.
+
+    Sparse input: duplicates are summed (CSR), 1 is added on the diagonal, infinite inverse
+    degrees become 0, column indices come out sorted.
+    """
+    if isinstance(a, DeviceCSR):
+        if not a.gcn_filtered:
+            raise ValueError("a DeviceCSR handed to gcn_filter must come from gcn_filter_device")
+        return a
+    if sparse.issparse(a):
+        m = sparse.csr_matrix(a, copy=True)
+        m.sum_duplicates()
+        m = (m + sparse.identity(m.shape[0], dtype=m.dtype, format='csr')).tocsr()
+        with np.errstate(divide='ignore'):
+            dinv = np.power(np.asarray(m.sum(1)).ravel(), -0.5 if symmetric else -1.0).astype(m.dtype)
+        dinv[np.isinf(dinv)] = 0.0
+        coo = m.tocoo()
+        data = (dinv[coo.row] * coo.data).astype(m.dtype)          # D . A first,
+        if symmetric:
+            data = (data * dinv[coo.col]).astype(m.dtype)          # ... then (D . A) . D: two fp32 roundings
+        out = sparse.csr_matrix((data, (coo.row, coo.col)), shape=m.shape)
+        out.sort_indices()
+        return out
+    m = np.array(a, copy=True)
+    m[np.diag_indices_from(m)] += 1
+    with np.errstate(divide='ignore'):
+        dinv = np.power(m.sum(1), -0.5 if symmetric else -1.0)
+    dinv[np.isinf(dinv)] = 0.0
+    return (dinv[:, None] * m) * dinv[None, :] if symmetric else dinv[:, None] * m
+
+
+class DeviceCSR:
+    """Canonical CSR in HBM: int32 ``rowptr`` [n+1], int32 ``colidx`` [nnz], fp32 ``vals`` [nnz] or None.
+
+    ``vals is None`` means an all-ones matrix (GraphSAGE / GAT ignore edge values).  Duplicate
+    (row, col) entries are kept as parallel non-zeros.
+    """
+
+    def __init__(self, rowptr, colidx, vals, shape, gcn_filtered=False):
+        self.rowptr, self.colidx, self.vals, self.shape = rowptr, colidx, vals, tuple(shape)
+        self.gcn_filtered = gcn_filtered          # already D^-1/2 (A+I) D^-1/2 (built by gcn_filter_device)
+
+    @property
+    def nnz(self):
+        return int(self.colidx.numel())
+
+    @classmethod
+    def from_scipy(cls, x, with_values=True, drop_diagonal=False, device=None):
+        device = device or default_device()
+        coo = x.tocoo()
+        row, col, data = coo.row.astype(np.int64), coo.col.astype(np.int64), coo.data
+        if drop_diagonal:
+            keep = row != col
+            row, col, data = row[keep], col[keep], data[keep]
+        if coo.shape[0] >= 2 ** 31 or len(row) >= 2 ** 31:
+            raise ValueError("graph too large for int32 CSR")
+        order = np.lexsort((col, row))                      # tf.sparse.reorder: row-major, stable on duplicates
+        row, col = row[order], col[order]
+        rowptr = np.zeros(coo.shape[0] + 1, dtype=np.int64)
+        np.cumsum(np.bincount(row, minlength=coo.shape[0]), out=rowptr[1:])
+        vals = torch.from_numpy(data[order].astype(np.float32)).to(device) if with_values else None
+        return cls(torch.from_numpy(rowptr.astype(np.int32)).to(device),
+                   torch.from_numpy(col.astype(np.int32)).to(device), vals, coo.shape)
+
+    def to_scipy(self):
+        rowptr = self.rowptr.cpu().numpy()
+        colidx = self.colidx.cpu().numpy()
+        vals = self.vals.cpu().numpy() if self.vals is not None else np.ones(len(colidx), dtype=np.float32)
+        return sparse.csr_matrix((vals, colidx, rowptr), shape=self.shape)
+
+
+def sparse_matrix_to_tensor(x, dtype=torch.float32, **kwargs):
+    """scipy sparse -> :class:`DeviceCSR` (row-major order, duplicates kept)."""
+    assert sparse.issparse(x), "The input matrix should be sparse"
+    if dtype != torch.float32:
+        raise ValueError("the HIP path computes in float32 only")
+    return DeviceCSR.from_scipy(x, **kwargs)
+
+
+def convert_to_tensor(x, dtype=torch.float32, **kwargs):
+    """Array (dense or sparse) -> device tensor / :class:`DeviceCSR`."""
+    if isinstance(x, DeviceCSR):
+        return x
+    if sparse.issparse(x):
+        return sparse_matrix_to_tensor(x, dtype=dtype, **kwargs)
+    raise ValueError("dense adjacency matrices are not supported by the HIP path (sparse_adjacency: True in every config)")
+
+
+def gcn_filter_device(rows, cols, n_nodes):
+    """``symmetrize_matrix`` + ``gcn_filter`` + CSR conversion done on the GPU with torch sorts.
+
+    `rows`/`cols` are the device int64 endpoints of the UN-symmetrised unit-weight edges
+    (positive ratings, item-property links).  Produces the same :class:`DeviceCSR`, bit for bit,
+    as ``DeviceCSR.from_scipy(gcn_filter(symmetrize_matrix(coo)))`` — duplicates summed, unit
+    diagonal added, fp32 ``(d_i^-1/2 * a_ij) * d_j^-1/2`` — without the host round trip, which is
+    what makes s=64 graphs (112 M non-zeros) practical to build.
+    """
+    dev = rows.device
+    loops = torch.arange(n_nodes, device=dev, dtype=torch.int64)
+    keys = torch.cat([rows * n_nodes + cols, cols * n_nodes + rows, loops * n_nodes + loops])
+    keys, counts = torch.unique(keys, return_counts=True)            # sorted row-major; counts = summed duplicates
+    r, c = keys // n_nodes, keys % n_nodes
+    a = counts.to(torch.float32)
+    deg = torch.zeros(n_nodes, dtype=torch.float32, device=dev).index_add_(0, r, a)
+    # per-row sums of small integers are exact in fp32 in any order (< 2^24)
+    dinv = torch.from_numpy(np.power(deg.cpu().numpy(), np.float32(-0.5)).astype(np.float32)).to(dev)
+    dinv[torch.isinf(dinv)] = 0
+    vals = (dinv[r] * a) * dinv[c]
+    rowptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(torch.bincount(r, minlength=n_nodes), 0)
+    return DeviceCSR(rowptr.to(torch.int32), c.to(torch.int32), vals, (n_nodes, n_nodes), gcn_filtered=True)

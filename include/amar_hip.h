@@ -1,0 +1,144 @@
+/*
+ * amar_hip.h — C-ABI of the MI355X (gfx950) GNN-propagation + hybrid-scoring hot path.
+ *
+ * The reference (swapUniba/Deep_CBRS_Amar_Renaissance) is pure Python on TensorFlow/Keras/
+ * Spektral and has no FFI of its own; each entry point below replaces the framework call the
+ * reference makes at the cited file:line (paths relative to the reference root).  A maintainer
+ * binds these with ctypes — see INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing here allocates, frees or
+ *     synchronises; work is enqueued on `stream` (a hipStream_t passed as void*, NULL = default)
+ *   - matrices are row-major fp32 with an explicit leading dimension (in elements), so a layer
+ *     can write straight into its column slice of the [N, d(L+1)] concatenation buffer
+ *     (ReductionLayer 'concatenation', src/layers/reduction.py:15-16)
+ *   - CSR is canonical: int32 rowptr[n_rows+1], int32 colidx[nnz] ascending within a row
+ *   - return value: 0 = ok, <0 = AMAR_E* below; never throws, never aborts
+ *   - re-entrant for distinct streams; no global mutable state
+ */
+#ifndef AMAR_HIP_H
+#define AMAR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMAR_OK            0
+#define AMAR_EINVAL       -1   /* bad argument (null pointer, negative size, misaligned ld)   */
+#define AMAR_EUNSUPPORTED -2   /* shape outside what the kernels are built for                */
+#define AMAR_ELAUNCH      -3   /* HIP reported an error at launch (see amar_last_hip_error)   */
+
+#define AMAR_ACT_NONE     0
+#define AMAR_ACT_RELU     1
+#define AMAR_ACT_SIGMOID  2
+
+/* flags of amar_spmm_csr_f32 */
+#define AMAR_SPMM_BIAS      1u   /* y += bias[F]                                              */
+#define AMAR_SPMM_RELU      2u   /* y = max(y, 0) after bias                                  */
+#define AMAR_SPMM_ACCUM     4u   /* acc_out = acc_in + y (LightGCN running layer sum)         */
+#define AMAR_SPMM_ACCUM_DIV 8u   /* ... and acc_out /= acc_div (ReductionLayer 'mean')        */
+
+typedef void *amar_stream_t;
+
+int amar_version(void);
+const char *amar_error_string(int code);
+int amar_last_hip_error(void);          /* last hipError_t seen by this thread, 0 if none */
+
+/* ---- propagation --------------------------------------------------------------------------
+ * Y[n_rows, F] = A . X   (+ bias, ReLU, running sum)        fp32, CSR, F in {4, 8, 16, 32, 64}
+ * Replaces spektral.layers.ops.modal_dot -> tf.sparse.sparse_dense_matmul at
+ * src/layers/lightgcn_conv.py:51-54 and inside GCNConv.call (built at src/models/gnn.py:289-295,
+ * invoked at src/models/gnn.py:78).  vals == NULL means an all-ones (binary) matrix.
+ * ldx, ldy (and ld_acc) must be multiples of 4 and the bases 16-byte aligned.
+ * Y may be NULL when only the running sum is wanted (last LightGCN layer).
+ */
+int amar_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, const float *vals,
+                      const float *X, int64_t ldx, float *Y, int64_t ldy,
+                      int32_t n_rows, int32_t F, uint32_t flags, const float *bias,
+                      const float *acc_in, int64_t ld_acc_in, float *acc_out, int64_t ld_acc_out,
+                      float acc_div, amar_stream_t stream);
+
+/* One fused GCN layer (src/models/gnn.py:289-295 + gnn.py:78, Spektral GCNConv.call):
+ *     Y[i, 0:C]      = ReLU( sum_j A_hat[i,j] . H[j, 0:C] + bias )      H = X_prev . W  (pre-multiplied)
+ *     Hnext[i, 0:Cn] = Y[i, :] . Wnext[C, Cn]                            (only if Wnext != NULL)
+ * so that layer l's epilogue performs layer l+1's dense product and each layer is ONE kernel.
+ * C in {4,8,16,32,64}; Cn <= 64.
+ */
+int amar_gcn_layer_f32(const int32_t *rowptr, const int32_t *colidx, const float *vals,
+                       const float *H, int64_t ldh, int32_t C, const float *bias,
+                       float *Y, int64_t ldy,
+                       const float *Wnext, int32_t Cn, float *Hnext, int64_t ldhn,
+                       int32_t n_rows, amar_stream_t stream);
+
+/* Row-wise small dense product used as the GNN prologue (Keras `K.dot(x, kernel)` inside
+ * GCNConv / GATConv; reference call site src/models/gnn.py:78):
+ *     H[i, 0:C] = X[i, 0:F] . W[F, C]                     F, C <= 64
+ *     copy_to != NULL:  copy_to[i, 0:F] = X[i, 0:F]       (X_0 slice of the concat buffer)
+ *     a_self/a_neigh != NULL (GAT):  s_self[i] = H[i,:].a_self,  s_neigh[i] = H[i,:].a_neigh
+ */
+int amar_rowwise_xw_f32(const float *X, int64_t ldx, int32_t F, const float *W, int32_t C,
+                        float *H, int64_t ldh, float *copy_to, int64_t ld_copy,
+                        const float *a_self, const float *a_neigh, float *s_self, float *s_neigh,
+                        int32_t n_rows, amar_stream_t stream);
+
+/* One GraphSAGE-mean layer (Spektral 1.x GraphSageConv, built at src/models/gnn.py:354-361):
+ *     agg_i = ( [self_loop] X_i + sum_{j in N(i)} X_j ) / ( [self_loop] 1 + |N(i)| )
+ *     Y_i   = ReLU( l2_normalize( [X_i || agg_i] . W[2F, C] + bias ) )
+ * rowptr/colidx hold the raw symmetric adjacency with duplicate edges kept and no diagonal;
+ * edge values are ignored, as in the reference.  F in {4,8,16,32}; C <= 64.
+ */
+int amar_sage_layer_f32(const int32_t *rowptr, const int32_t *colidx,
+                        const float *X, int64_t ldx, int32_t F,
+                        const float *W, const float *bias, int32_t C,
+                        float *Y, int64_t ldy, int32_t self_loop,
+                        int32_t n_rows, amar_stream_t stream);
+
+/* One GAT layer, 1 head (Spektral 1.x GATConv._call_single, built at src/models/gnn.py:321-328):
+ *     e_ij  = LeakyReLU_0.2( s_self[i] + s_neigh[j] ),  j in N(i) (+ i itself if self_loop)
+ *     alpha = exp(e_ij - max_j e_ij) / ( sum_j exp(e_ij - max_j e_ij) + 1e-9 )
+ *     Y_i   = ReLU( sum_j alpha_ij H_j + bias )
+ * H, s_self, s_neigh come from amar_rowwise_xw_f32.  C in {4,8,16,32,64}.
+ */
+int amar_gat_layer_f32(const int32_t *rowptr, const int32_t *colidx,
+                       const float *H, int64_t ldh, int32_t C,
+                       const float *s_self, const float *s_neigh, const float *bias,
+                       float *Y, int64_t ldy, int32_t self_loop,
+                       int32_t n_rows, amar_stream_t stream);
+
+/* ---- scoring head -------------------------------------------------------------------------
+ * Y[M, N] = act( X[M, K] . W[K, N] + bias[N] )   fp32 MFMA GEMM (Keras Dense; src/models/dense.py:4-17)
+ * ids != NULL gathers the input rows first: row m of the product reads X[ids[m], :]
+ * (tf.nn.embedding_lookup at src/models/basic.py:73-74, src/models/hybrid.py:138-139).
+ * Y is written at column offset 0 of a matrix with leading dimension ldy, so two calls with
+ * Y and Y + N realise `Concatenate` (src/models/basic.py:35, src/layers/fusion.py:51-53).
+ */
+int amar_dense_f32(const float *X, int64_t ldx, const int32_t *ids,
+                   const float *W, const float *bias, float *Y, int64_t ldy,
+                   int64_t M, int32_t K, int32_t N, int32_t act, amar_stream_t stream);
+
+/* Concatenate / ReductionLayer as layout operations (src/layers/reduction.py:15-33,
+ * src/layers/fusion.py:51-53): copy a [n_rows, width] block between two strided matrices, and
+ * out = X_0 + X_1 + ... (+ division by n_layers for 'mean') over the n_layers equal-width column
+ * blocks of a concatenation buffer, added in layer order like tf.add_n.
+ */
+int amar_copy_columns_f32(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t n_rows, int32_t width,
+                          amar_stream_t stream);
+int amar_reduce_layers_f32(const float *cat, int64_t ld, int32_t n_layers, int32_t width, float *out, int64_t ldo,
+                           int64_t n_rows, int32_t mean, amar_stream_t stream);
+
+/* ---- ranking ------------------------------------------------------------------------------
+ * Per-user top-k over that user's own test pairs (src/utilities/metrics.py:11-34):
+ * pairs are grouped by user (seg_ptr[n_users+1] into item_ids/scores); for each user the k
+ * best (score desc, item id asc on ties) are written to out_items/out_scores [n_users, k],
+ * padded with -1 / -inf when the user has fewer than k pairs.  k <= 64.
+ */
+int amar_topk_segmented_f32(const int32_t *seg_ptr, const int32_t *item_ids, const float *scores,
+                            int32_t n_users, int32_t k, int32_t *out_items, float *out_scores,
+                            amar_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMAR_HIP_H */

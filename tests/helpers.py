@@ -1,0 +1,89 @@
+"""Shared test plumbing: synthetic graphs, and product-model -> oracle weight export."""
+import numpy as np
+from scipy import sparse
+
+
+def tiny_graph(n_users=40, n_items=30, n_ratings=400, seed=0, n_props=0, n_links=0):
+    """Random bipartite (optionally tripartite) rating graph in contiguous ids + a pair list to score."""
+    from deep_cbrs_amar_renaissance_amd.data.preprocess import build_adjacency_matrix
+    rng = np.random.default_rng(seed)
+    keys = rng.choice(n_users * n_items, size=min(n_ratings, n_users * n_items), replace=False)
+    u, i = keys // n_items, keys % n_items + n_users
+    ratings = np.stack([u, i, (rng.random(len(u)) < 0.6).astype(np.int64)], axis=1)
+    users, items = np.arange(n_users) * 3 + 1, np.arange(n_items) * 5 + 2
+    triples = props = None
+    kind = 'unary'
+    if n_props:
+        it = rng.integers(0, n_items, size=n_links)
+        pr = rng.integers(0, n_props, size=n_links) + n_items
+        triples = np.stack([it, pr, np.ones(n_links, dtype=np.int64)], axis=1)
+        triples = np.concatenate([triples, triples[: max(1, n_links // 10)]])      # duplicate (item, prop) links
+        props = np.arange(n_props)
+        kind = 'unary-uip'
+    adj = build_adjacency_matrix(ratings, users, items, triples, props, type_adjacency=kind)
+    pairs = rng.choice(n_users * n_items, size=min(300, n_users * n_items), replace=False)
+    return {'adj': adj, 'ratings': ratings, 'users': users, 'items': items, 'triples': triples, 'props': props,
+            'u_ids': pairs // n_items, 'i_ids': pairs % n_items + n_users, 'n_users': n_users, 'n_items': n_items}
+
+
+def ml1m_indexed(scale=1):
+    from deep_cbrs_amar_renaissance_amd.data import synthetic, loaders, preprocess
+    ds = synthetic.ml1m(scale)
+    (train, test), (users, items) = loaders.index_ratings(ds.train, ds.test)
+    triples, props = loaders.index_props(ds.props, items)
+    return {'train': train, 'test': test, 'users': users, 'items': items, 'triples': triples, 'props': props,
+            'adj_ui': preprocess.build_adjacency_matrix(train, users, items),
+            'adj_uip': preprocess.build_adjacency_matrix(train, users, items, triples, props, 'unary-uip'),
+            'raw': ds}
+
+
+def randomize_biases(model, seed=0, scale=0.05):
+    """Biases are zero-initialised in the reference; draw them U(+-0.05) so bias paths are tested."""
+    import torch
+    rng = np.random.default_rng(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith('bias'):
+                p.copy_(torch.from_numpy(rng.uniform(-scale, scale, size=tuple(p.shape)).astype(np.float32)))
+
+
+def _np(p):
+    return p.detach().cpu().numpy().copy()
+
+
+def gnn_to_oracle(gnn):
+    """models.gnn.GNN instance -> oracle weight dict (oracle/models.py)."""
+    from deep_cbrs_amar_renaissance_amd.layers.gcn_conv import GCNConv
+    from deep_cbrs_amar_renaissance_amd.layers.graphsage_conv import GraphSageConv
+    from deep_cbrs_amar_renaissance_amd.layers.gat_conv import GATConv
+    from deep_cbrs_amar_renaissance_amd.layers.lightgcn_conv import LightGCNConv
+    seq = gnn.gnn_layers
+    kinds = {GCNConv: 'gcn', GraphSageConv: 'sage', GATConv: 'gat', LightGCNConv: 'lightgcn'}
+    kind = kinds[type(seq.seq_layers[0])]
+    layers = []
+    for l in seq.seq_layers:
+        if kind == 'lightgcn':
+            layers.append({})
+        elif kind == 'gat':
+            c = l.channels
+            layers.append({'kernel': _np(l.kernel).reshape(-1, c), 'attn_self': _np(l.attn_kernel_self).reshape(c),
+                           'attn_neigh': _np(l.attn_kernel_neighs).reshape(c), 'bias': _np(l.bias)})
+        else:
+            layers.append({'kernel': _np(l.kernel), 'bias': _np(l.bias)})
+    return {'kind': kind, 'embeddings': _np(seq.embeddings), 'layers': layers, 'final_node': seq.final_node}
+
+
+def _net(seq):
+    return [(_np(l.kernel), _np(l.bias)) for l in seq.layers]
+
+
+def basic_head_to_oracle(rs):
+    return {'unet': _net(rs.unet), 'inet': _net(rs.inet), 'clf': _net(rs.clf)}
+
+
+def hybrid_head_to_oracle(rs):
+    return {k: _net(getattr(rs, k)) for k in ('dense1a', 'dense1b', 'dense2a', 'dense2b', 'dense3a', 'dense3b', 'clf')}
+
+
+def rel_err(got, want):
+    return float(np.abs(np.asarray(got, dtype=np.float64) - want).max() / max(1e-30, np.abs(want).max()))

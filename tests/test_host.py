@@ -1,0 +1,173 @@
+"""CPU: host-side logic of the drop-in boundary (no kernels run here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+from scipy import sparse
+
+from oracle import graph as og
+from tests import helpers
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_capi_library_exports_every_declared_symbol():
+    from deep_cbrs_amar_renaissance_amd import capi
+    header = open(os.path.join(ROOT, 'include', 'amar_hip.h')).read()
+    declared = set(re.findall(r'\b(amar_[a-z0-9_]+)\s*\(', header))
+    assert declared and declared == set(capi.SIGNATURES), declared ^ set(capi.SIGNATURES)
+    lib = capi.load()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.amar_version() == 100
+    assert b'invalid' in lib.amar_error_string(-1)
+
+
+def test_no_fallback_without_gpu_tensors():
+    from deep_cbrs_amar_renaissance_amd import capi
+    x = torch.zeros((4, 8))
+    with pytest.raises(capi.AmarError):
+        capi.dense(x, torch.zeros((8, 8)), torch.zeros(8), torch.zeros((4, 8)))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, 'deep_cbrs_amar_renaissance_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle\b', src, re.M), os.path.join(dirpath, f)
+
+
+def test_adjacency_and_filter_match_oracle(ml1m_s1):
+    from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter, DeviceCSR
+    g = ml1m_s1
+    nu, ni, npr = len(g['users']), len(g['items']), len(g['props'])
+    assert (nu, ni) == (6036, 3192)
+    for adj, want in ((g['adj_ui'], og.adjacency_unary(g['train'], nu, ni)),
+                      (g['adj_uip'], og.adjacency_unary_uip(g['train'], g['triples'], nu, ni, npr))):
+        assert adj.dtype == np.float32
+        assert np.array_equal(adj.row, want.row) and np.array_equal(adj.col, want.col) and np.array_equal(adj.data, want.data)
+        a, b = gcn_filter(adj), og.gcn_filter(want)
+        assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices) and np.array_equal(a.data, b.data)
+    # CSR conversion keeps duplicates, row-major order (tf.sparse.reorder)
+    csr = DeviceCSR.from_scipy(g['adj_uip'], with_values=False, drop_diagonal=True, device='cpu')
+    row, col, _ = og.reordered_coo(g['adj_uip'])
+    assert csr.nnz == g['adj_uip'].nnz == len(row)
+    assert np.array_equal(csr.colidx.numpy(), col) and np.array_equal(np.diff(csr.rowptr.numpy()), np.bincount(row, minlength=csr.shape[0]))
+    dup = len(row) - len(np.unique(row * csr.shape[0] + col))
+    assert dup > 0, "the UIP fixture must exercise duplicate edges"
+
+
+def test_build_adjacency_errors():
+    from deep_cbrs_amar_renaissance_amd.data.preprocess import build_adjacency_matrix
+    r = np.array([[0, 2, 1], [1, 3, 0]])
+    with pytest.raises(ValueError):
+        build_adjacency_matrix(r, [0, 1], [0, 1], type_adjacency='nope')
+    with pytest.raises(ValueError):
+        build_adjacency_matrix(r, [0, 1], [0, 1], type_adjacency='unary-uip')
+    a = build_adjacency_matrix(r, [0, 1], [0, 1], symmetric_adjacency=False)
+    assert a.nnz == 1 and a.shape == (4, 4)
+
+
+def test_loaders_roundtrip_through_reference_file_formats(tmp_path):
+    from deep_cbrs_amar_renaissance_amd.data import loaders, synthetic
+    ds = synthetic.ml1m(1)
+    ds.train, ds.test = ds.train[:60000], ds.test[np.isin(ds.test[:, 0], ds.train[:60000, 0]) & np.isin(ds.test[:, 1], ds.train[:60000, 1])][:5000]
+    ds.props = ds.props[np.isin(ds.props[:, 0], ds.train[:, 1])][:3000]
+    paths = synthetic.write_dataset(ds, str(tmp_path), bert_dim=16, kge_dim=8)
+    tr, te = loaders.load_user_item_graph(paths['train_ratings_filepath'], paths['test_ratings_filepath'],
+                                          paths['props_triples_filepath'], type_adjacency='unary-uip')
+    (otr, ote), (users, items) = og.remap_ratings(ds.train, ds.test)
+    assert np.array_equal(tr.ratings, otr) and np.array_equal(te.ratings, ote)
+    assert np.array_equal(tr.users, users) and np.array_equal(tr.items, items)
+    assert len(tr) == int(np.ceil(len(otr) / 1024)) and len(te) == int(np.ceil(len(ote) / 2048))
+    (u, i), y = te[len(te) - 1]
+    assert u.dtype == np.int64 and len(u) == len(ote) - 2048 * (len(te) - 1) and i.min() >= len(users)
+    # shuffling: RandomState(42) permutation, redrawn per epoch
+    idx0 = tr.indexes.copy()
+    expect = np.arange(len(otr)); np.random.RandomState(42).shuffle(expect)
+    assert np.array_equal(idx0, expect)
+    tr.on_epoch_end()
+    assert not np.array_equal(tr.indexes, idx0)
+    # hybrid loader: BERT rows follow users then items
+    htr, hte = loaders.load_user_item_graph_bert_embeddings(
+        paths['train_ratings_filepath'], paths['test_ratings_filepath'], paths['bert_user_filepath'], paths['bert_item_filepath'])
+    (hu, hi, hub, hib), _ = hte[0]
+    assert hub.shape == (len(hu), 16) and hub.dtype == np.float32
+    want_u = synthetic.entity_embeddings(len(users), 16, 'bert')
+    assert np.allclose(hub, want_u[hu], atol=1e-6)
+    # KGE loader
+    ktr, kte = loaders.load_graph_embeddings(paths['train_ratings_filepath'], paths['test_ratings_filepath'], paths['graph_filepath'])
+    (ku, ki), _ = kte[0]
+    assert ku.shape == (min(2048, len(ote)), 8)
+    with pytest.raises(ValueError):
+        loaders.index_ratings(ds.train, np.array([[10 ** 9, ds.train[0, 1], 1]]))
+
+
+def test_grid_and_yaml_semantics(tmp_path):
+    from deep_cbrs_amar_renaissance_amd.utilities.utils import make_grid, nested_dict_update, mlflow_linearize
+    from deep_cbrs_amar_renaissance_amd.experiment import load_yaml, AttrDict
+    p = tmp_path / 'c.yaml'
+    p.write_text("model:\n  l2_regularizer: 1e-4\n  name: basic.BasicGCN\ngrid:\n  g1:\n    model:\n      l2_regularizer: [1e-5, 1e-3]\n      n_hiddens: [[8, 8]]\n    dataset:\n      x: [a, b, c]\n")
+    cfg = load_yaml(str(p))
+    assert isinstance(cfg['model']['l2_regularizer'], float) and cfg['model']['l2_regularizer'] == 1e-4   # YAML 1.2 float
+    grid = make_grid(cfg['grid']['g1'])
+    assert len(grid) == 6 and grid[0] == {'model': {'l2_regularizer': 1e-5, 'n_hiddens': [8, 8]}, 'dataset': {'x': 'a'}}
+    with pytest.raises(ValueError):
+        make_grid({'a': 3})
+    base = {'model': {'name': 'x', 'k': 1}, 'seed': 1}
+    assert nested_dict_update(base, {'model': {'k': 2}}) == {'model': {'name': 'x', 'k': 2}, 'seed': 1}
+    assert mlflow_linearize({'a': {'b': {'c': 1}}, 'd': 2}) == {'a.b.c': 1, 'd': 2}
+    ad = AttrDict({'a': {'b': 3}})
+    assert ad.a.b == 3 and dict(**ad.a) == {'b': 3}
+
+
+def test_model_classes_resolve_and_param_counts():
+    from deep_cbrs_amar_renaissance_amd.models import basic, hybrid
+    N = 9228
+    adj = sparse.coo_matrix((np.ones(2, dtype=np.float32), ([0, 1], [1, 0])), shape=(N, N))
+    cfg = dict(name='basic.BasicGCN', embedding_dim=8, n_hiddens=[8, 8], l2_regularizer=1e-4, final_node='concatenation',
+               item_node='mean', user_item_node='mean', aggregate='mean', dropout_rate=0.0, n_layers=2,
+               dense_units=[24, 24], clf_units=[48, 48], activation='relu', feature_based=True,
+               fusion_method='concatenate', residual=False)              # the WHOLE model: section is passed (experiment.py:146-153)
+    count = lambda m: sum(p.numel() for p in m.parameters())
+    assert count(basic.BasicGCN(adj, **cfg)) == 81121
+    assert count(basic.BasicGraphSage(adj, **cfg)) == 81249
+    assert count(basic.BasicGAT(adj, **cfg)) == 81153
+    assert count(basic.BasicLightGCN(adj, **cfg)) == 80209
+    h = dict(cfg, embedding_dim=16, n_hiddens=[16, 16], dense_units=[[48, 48], [256, 64], [64, 64]], clf_units=[64, 64])
+    m = hybrid.HybridBertGCN(adj, **h)
+    m.rs.build_head(m.gnn.output_dim(), 768)
+    assert count(m) == 619489
+    for name in ['BasicTSGCN', 'BasicTWGAT', 'BasicDGCF', 'BasicKnowledgeGCN', 'BasicTSGNN', 'BasicTWGNN']:
+        assert hasattr(basic, name)
+    for name in ['HybridBertTSGCN', 'HybridBertTWLightGCN', 'HybridBertDGCF', 'HybridCBRS']:
+        assert hasattr(hybrid, name)
+    with pytest.raises(NotImplementedError):
+        basic.BasicDGCF(adj, **cfg)
+    with pytest.raises(ValueError):
+        basic.BasicGCN(adj, **dict(cfg, final_node='bogus'))
+    with pytest.raises(ValueError):
+        hybrid.HybridCBRS(fusion_method='bogus')
+    with pytest.raises(NotImplementedError):
+        basic.BasicGCN(adj, **cfg).fit(None)
+
+
+def test_seed_reproducibility_and_glorot_limits():
+    from deep_cbrs_amar_renaissance_amd import engine
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    adj = sparse.coo_matrix((np.ones(2, dtype=np.float32), ([0, 1], [1, 0])), shape=(500, 500))
+    cfg = dict(embedding_dim=8, n_hiddens=[8, 8], dense_units=[24, 24], clf_units=[48, 48])
+    engine.set_seed(42)
+    a = basic.BasicGCN(adj, **cfg)
+    engine.set_seed(42)
+    b = basic.BasicGCN(adj, **cfg)
+    for (na, pa), (nb, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert na == nb and torch.equal(pa, pb)
+    emb = a.gnn.gnn_layers.embeddings
+    assert float(emb.abs().max()) <= np.sqrt(6 / (500 + 8)) and float(emb.abs().max()) > 0.9 * np.sqrt(6 / 508)
+    assert all(float(p.abs().max()) == 0 for n, p in a.named_parameters() if n.endswith('bias'))

@@ -1,0 +1,246 @@
+"""GPU parity: every C-ABI kernel against the CPU oracle on seeded inputs (pytest -m gpu).
+
+Tolerances: fp32 kernels vs the fp32 oracle, relative to the largest reference magnitude:
+2e-6 for single sums of <= a few thousand terms (different but fixed summation orders),
+bit-exact for pure data movement and for top-k.
+"""
+import numpy as np
+import pytest
+import torch
+from scipy import sparse
+
+from oracle import layers as ol
+from tests.helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _rand_csr(n, avg_deg, seed, empty_rows=True, long_row=True, dup=False):
+    rng = np.random.default_rng(seed)
+    deg = rng.poisson(avg_deg, size=n)
+    if empty_rows:
+        deg[rng.integers(0, n, size=max(1, n // 10))] = 0
+    if long_row:
+        deg[rng.integers(0, n)] = min(n, 700)
+    rows = np.repeat(np.arange(n), deg)
+    cols = rng.integers(0, n, size=len(rows))
+    if not dup:
+        key = np.unique(rows * n + cols)
+        rows, cols = key // n, key % n
+    vals = rng.uniform(-1, 1, size=len(rows)).astype(np.float32)
+    return sparse.coo_matrix((vals, (rows, cols)), shape=(n, n))
+
+
+def _dev_csr(m, **kw):
+    from deep_cbrs_amar_renaissance_amd.utilities.math import DeviceCSR
+    return DeviceCSR.from_scipy(m, **kw)
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.mark.parametrize('F', [4, 8, 16, 32, 64])
+@pytest.mark.parametrize('n', [1, 67, 1000])
+def test_spmm_plain(hip, F, n):
+    m = _rand_csr(n, 9, seed=F + n)
+    a = _dev_csr(m)
+    x = np.random.default_rng(1).standard_normal((n, F)).astype(np.float32)
+    y = torch.full((n, F), float('nan'), device=DEV)
+    hip.spmm_csr(a.rowptr, a.colidx, a.vals, _t(x), y)
+    want = m.tocsr().astype(np.float64) @ x.astype(np.float64)
+    assert rel_err(y.cpu().numpy(), want) < 2e-6
+
+
+def test_spmm_binary_bias_relu_strided(hip):
+    n, F = 500, 8
+    m = _rand_csr(n, 12, seed=5, dup=True)
+    a = _dev_csr(m, with_values=False)
+    rng = np.random.default_rng(2)
+    xbuf = rng.standard_normal((n, 24)).astype(np.float32)
+    bias = rng.uniform(-1, 1, F).astype(np.float32)
+    xd = _t(xbuf)
+    out = torch.zeros((n, 24), device=DEV)
+    hip.spmm_csr(a.rowptr, a.colidx, None, xd[:, 8:16], out[:, 16:24], bias=_t(bias), relu=True)
+    ones = sparse.csr_matrix((np.ones(m.nnz), (m.row, m.col)), shape=m.shape)       # duplicates summed == counted
+    want = np.maximum(ones @ xbuf[:, 8:16].astype(np.float64) + bias, 0)
+    got = out.cpu().numpy()
+    assert rel_err(got[:, 16:24], want) < 2e-6
+    assert np.all(got[:, :16] == 0), "wrote outside its column slice"
+
+
+def test_spmm_running_mean(hip):
+    """LightGCN: S1 = X0 + A.X0 ; E = (S1 + A.X1) / 3 with X1 = A.X0 (reduction.py:28-30)."""
+    n, F = 300, 16
+    m = _rand_csr(n, 7, seed=9)
+    a = _dev_csr(m)
+    x0 = np.random.default_rng(3).standard_normal((n, F)).astype(np.float32)
+    x0d = _t(x0)
+    x1 = torch.empty((n, F), device=DEV)
+    s1 = torch.empty((n, F), device=DEV)
+    e = torch.empty((n, F), device=DEV)
+    hip.spmm_csr(a.rowptr, a.colidx, a.vals, x0d, x1, acc_in=x0d, acc_out=s1)
+    hip.spmm_csr(a.rowptr, a.colidx, a.vals, x1, None, acc_in=s1, acc_out=e, acc_div=3)
+    A = m.tocsr().astype(np.float32)
+    h1 = ol.lightgcn_conv(x0, A)
+    h2 = ol.lightgcn_conv(h1, A)
+    want = ol.reduce_layers([x0, h1, h2], 'mean')
+    assert rel_err(e.cpu().numpy(), want.astype(np.float64)) < 2e-6
+
+
+@pytest.mark.parametrize('C,Cn', [(8, 8), (16, 32), (32, 16), (64, 8), (4, 4)])
+def test_gcn_layer_fused_next(hip, C, Cn):
+    n = 400
+    m = _rand_csr(n, 10, seed=C)
+    a = _dev_csr(m)
+    rng = np.random.default_rng(C + Cn)
+    h = rng.standard_normal((n, C)).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, C).astype(np.float32)
+    wn = rng.uniform(-0.5, 0.5, (C, Cn)).astype(np.float32)
+    y = torch.empty((n, C), device=DEV)
+    hn = torch.empty((n, Cn), device=DEV)
+    hip.gcn_layer(a.rowptr, a.colidx, a.vals, _t(h), _t(b), y, Wnext=_t(wn), Hnext=hn)
+    want_y = np.maximum(m.tocsr().astype(np.float64) @ h.astype(np.float64) + b, 0)
+    assert rel_err(y.cpu().numpy(), want_y) < 2e-6
+    assert rel_err(hn.cpu().numpy(), want_y @ wn.astype(np.float64)) < 3e-6
+    y2 = torch.empty((n, C), device=DEV)
+    hip.gcn_layer(a.rowptr, a.colidx, a.vals, _t(h), _t(b), y2)
+    assert torch.equal(y, y2), "fused and unfused epilogues must agree bit for bit"
+
+
+@pytest.mark.parametrize('F,C', [(8, 8), (24, 8), (5, 3), (64, 64), (16, 32)])
+def test_rowwise_xw(hip, F, C):
+    n = 777
+    rng = np.random.default_rng(F * C)
+    x = rng.standard_normal((n, F)).astype(np.float32)
+    w = rng.standard_normal((F, C)).astype(np.float32)
+    a_s, a_n = rng.standard_normal(C).astype(np.float32), rng.standard_normal(C).astype(np.float32)
+    h = torch.empty((n, C), device=DEV)
+    cp = torch.empty((n, F), device=DEV)
+    ss, sn = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    hip.rowwise_xw(_t(x), _t(w), h, copy_to=cp, a_self=_t(a_s), a_neigh=_t(a_n), s_self=ss, s_neigh=sn)
+    want = x.astype(np.float64) @ w.astype(np.float64)
+    assert rel_err(h.cpu().numpy(), want) < 2e-6
+    assert np.array_equal(cp.cpu().numpy(), x)
+    assert rel_err(ss.cpu().numpy(), want @ a_s) < 3e-6
+    assert rel_err(sn.cpu().numpy(), want @ a_n) < 3e-6
+
+
+@pytest.mark.parametrize('F,C', [(8, 8), (16, 16), (32, 32), (4, 8), (8, 5)])
+@pytest.mark.parametrize('self_loop', [True, False])
+def test_sage_layer(hip, F, C, self_loop):
+    n = 350
+    m = _rand_csr(n, 8, seed=F + C, dup=True)
+    m = sparse.coo_matrix((m.data[m.row != m.col], (m.row[m.row != m.col], m.col[m.row != m.col])), shape=m.shape)
+    a = _dev_csr(m, with_values=False, drop_diagonal=True)
+    rng = np.random.default_rng(F)
+    x = rng.standard_normal((n, F)).astype(np.float32)
+    w = rng.uniform(-0.6, 0.6, (2 * F, C)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, C).astype(np.float32)
+    y = torch.empty((n, C), device=DEV)
+    hip.sage_layer(a.rowptr, a.colidx, _t(x), _t(w), _t(b), y, self_loop=self_loop)
+    # kernel: row i aggregates over its CSR row; oracle: targets = col -> feed the transposed edge list
+    want = ol.sage_conv(x.astype(np.float64), m.col, m.row, w.astype(np.float64), b.astype(np.float64),
+                        self_loops=self_loop)
+    assert rel_err(y.cpu().numpy(), want) < 5e-6
+
+
+@pytest.mark.parametrize('C', [4, 8, 16, 32, 64])
+@pytest.mark.parametrize('self_loop', [True, False])
+def test_gat_layer(hip, C, self_loop):
+    n, F = 350, 8
+    m = _rand_csr(n, 8, seed=C, dup=True)
+    m = sparse.coo_matrix((m.data[m.row != m.col], (m.row[m.row != m.col], m.col[m.row != m.col])), shape=m.shape)
+    a = _dev_csr(m, with_values=False, drop_diagonal=True)
+    rng = np.random.default_rng(C)
+    x = rng.standard_normal((n, F)).astype(np.float32)
+    w = rng.uniform(-0.6, 0.6, (F, C)).astype(np.float32)
+    a_s, a_n = rng.uniform(-1, 1, C).astype(np.float32), rng.uniform(-1, 1, C).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, C).astype(np.float32)
+    h = torch.empty((n, C), device=DEV)
+    ss, sn = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    hip.rowwise_xw(_t(x), _t(w), h, a_self=_t(a_s), a_neigh=_t(a_n), s_self=ss, s_neigh=sn)
+    y = torch.empty((n, C), device=DEV)
+    hip.gat_layer(a.rowptr, a.colidx, h, ss, sn, _t(b), y, self_loop=self_loop)
+    want, alpha = ol.gat_conv(x.astype(np.float64), m.col, m.row, w.astype(np.float64), a_s.astype(np.float64),
+                              a_n.astype(np.float64), b.astype(np.float64), self_loops=self_loop)
+    assert rel_err(y.cpu().numpy(), want) < 1e-5
+
+
+@pytest.mark.parametrize('M,K,N', [(1, 1, 1), (130, 24, 24), (257, 48, 48), (1000, 48, 1), (300, 768, 256),
+                                   (64, 17, 65), (2048, 96, 48), (5, 256, 64)])
+@pytest.mark.parametrize('act', ['relu', 'sigmoid', None])
+def test_dense(hip, M, K, N, act):
+    rng = np.random.default_rng(M + K + N)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    w = rng.uniform(-0.3, 0.3, (K, N)).astype(np.float32)
+    b = rng.uniform(-0.2, 0.2, N).astype(np.float32)
+    y = torch.empty((M, N), device=DEV)
+    hip.dense(_t(x), _t(w), _t(b), y, act=act)
+    want = ol.dense(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), act)
+    assert rel_err(y.cpu().numpy(), want) < 3e-6
+
+
+def test_dense_gather_and_concat_slices(hip):
+    """embedding_lookup fused into the load (basic.py:73-74) + two producers filling one concat buffer (basic.py:35)."""
+    rng = np.random.default_rng(0)
+    table = rng.standard_normal((500, 24)).astype(np.float32)
+    ids_u = rng.integers(0, 500, size=333).astype(np.int32)
+    ids_i = rng.integers(0, 500, size=333).astype(np.int32)
+    wu, wi = rng.uniform(-0.3, 0.3, (24, 20)).astype(np.float32), rng.uniform(-0.3, 0.3, (24, 20)).astype(np.float32)
+    bu, bi = rng.uniform(-0.2, 0.2, 20).astype(np.float32), rng.uniform(-0.2, 0.2, 20).astype(np.float32)
+    cat = torch.full((333, 40), float('nan'), device=DEV)
+    td = _t(table)
+    hip.dense(td, _t(wu), _t(bu), cat[:, :20], act='relu', ids=_t(ids_u))
+    hip.dense(td, _t(wi), _t(bi), cat[:, 20:], act='relu', ids=_t(ids_i))
+    want = np.concatenate([ol.dense(table[ids_u].astype(np.float64), wu.astype(np.float64), bu, 'relu'),
+                           ol.dense(table[ids_i].astype(np.float64), wi.astype(np.float64), bi, 'relu')], axis=1)
+    assert rel_err(cat.cpu().numpy(), want) < 3e-6
+
+
+def test_copy_and_reduce_layers(hip):
+    rng = np.random.default_rng(4)
+    xs = [rng.standard_normal((123, 8)).astype(np.float32) for _ in range(3)]
+    cat = torch.empty((123, 24), device=DEV)
+    for k, x in enumerate(xs):
+        hip.copy_columns(_t(x), cat[:, 8 * k:8 * k + 8])
+    assert np.array_equal(cat.cpu().numpy(), np.concatenate(xs, axis=1))
+    for mean in (False, True):
+        out = torch.empty((123, 8), device=DEV)
+        hip.reduce_layers(cat, 3, 8, out, mean=mean)
+        want = ol.reduce_layers(xs, 'mean' if mean else 'sum')
+        assert np.array_equal(out.cpu().numpy(), want), "same fp32 operations in the same order: bit-exact"
+
+
+def test_topk_segmented(hip):
+    from oracle import models as om
+    from deep_cbrs_amar_renaissance_amd.utilities.metrics import top_k_arrays
+    rng = np.random.default_rng(7)
+    n_users, n_items = 200, 500
+    counts = rng.integers(0, 90, size=n_users)
+    counts[3], counts[5], counts[7] = 0, 1, 300
+    u = np.repeat(np.arange(n_users), counts)
+    i = np.concatenate([rng.choice(n_items, size=c, replace=False) for c in counts]) + n_users
+    s = rng.random(len(u)).astype(np.float32)
+    s[rng.integers(0, len(s), size=len(s) // 3)] = 0.5                      # many exact ties
+    perm = rng.permutation(len(u))
+    u, i, s = u[perm], i[perm], s[perm]
+    users, items = np.arange(n_users) * 2 + 10, np.arange(n_items) * 3 + 7
+    for k in (5, 10):
+        seg_users, top_items, top_scores = top_k_arrays(u, i, s, k)
+        valid = top_items >= 0
+        got_u = users[np.repeat(seg_users, k).reshape(-1, k)[valid]]
+        got_i = items[top_items[valid] - n_users]
+        want_u, want_i, want_s = om.top_k(u, i, s, users, items, k)
+        assert np.array_equal(got_u, want_u) and np.array_equal(got_i, want_i)
+        assert np.array_equal(top_scores[valid].astype(np.float64), want_s)
+
+
+def test_bad_arguments_fail_loudly(hip):
+    a = _dev_csr(_rand_csr(10, 3, seed=1))
+    x = torch.zeros((10, 12), device=DEV)
+    with pytest.raises(Exception):
+        hip.spmm_csr(a.rowptr, a.colidx, a.vals, x, torch.empty((10, 12), device=DEV))      # F = 12 unsupported
+    with pytest.raises(Exception):
+        hip.spmm_csr(a.rowptr, a.colidx, a.vals, torch.zeros((10, 8)), torch.empty((10, 8), device=DEV))  # CPU tensor

@@ -1,0 +1,117 @@
+"""CPU, world_size 2 over gloo: the node-range partition + per-layer all-gather logic.
+
+The HIP kernels cannot run here, so the runner's kernel provider is replaced by a numpy stand-in
+(test infrastructure) while partitioning, the padded index space, CSR column remapping and the
+collectives are the shipped code.  Each rank's gathered node table must equal the single-process
+oracle propagation.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from scipy import sparse
+
+from tests import helpers
+
+GRID1 = dict(embedding_dim=8, n_hiddens=[8, 8], dense_units=[24, 24], clf_units=[48, 48])
+
+
+class NumpyOps:
+    """CPU stand-ins with the signatures of the capi functions the partitioned runner calls."""
+
+    @staticmethod
+    def copy_columns(src, dst):
+        dst.copy_(src)
+
+    @staticmethod
+    def rowwise_xw(X, W, H, **kw):
+        H.copy_(X @ W.detach())
+
+    @staticmethod
+    def gcn_layer(rowptr, colidx, vals, H, bias, Y, Wnext=None, Hnext=None):
+        n = rowptr.numel() - 1
+        a = sparse.csr_matrix((vals.numpy(), colidx.numpy(), rowptr.numpy()), shape=(n, H.shape[0]))
+        y = np.maximum(a @ H.numpy() + bias.detach().numpy(), 0)
+        Y.copy_(torch.from_numpy(y))
+        if Wnext is not None:
+            Hnext.copy_(torch.from_numpy(y @ Wnext.detach().numpy()))
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from deep_cbrs_amar_renaissance_amd import engine, parallel
+        from deep_cbrs_amar_renaissance_amd.models import basic
+        engine.set_seed(42)
+        g = helpers.tiny_graph(n_users=70, n_items=45, n_ratings=1500, seed=8, n_props=25, n_links=90)
+        model = basic.BasicGCN(g['adj'], **GRID1)
+        helpers.randomize_biases(model, seed=3)
+        u = torch.from_numpy(g['u_ids'])
+        i = torch.from_numpy(g['i_ids'])
+        runner = parallel.PartitionedGCNRunner(model, u, i, rank, world, ops=NumpyOps, dist=dist, timing=False)
+        e_pad = runner.propagate()
+        n = g['adj'].shape[0]
+        idx = runner.part.padded_index(torch.arange(n))
+        np.savez(os.path.join(out_dir, 'rank{}.npz'.format(rank)), e=e_pad[idx].numpy(),
+                 bounds=np.array(runner.part.bounds), pair_range=np.array(runner.pair_range),
+                 u_back=e_pad[runner.u_ids.long()].numpy(), nnz=np.array(runner.local_nnz))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.timeout(180)
+def test_partitioned_propagation_matches_oracle_world2(tmp_path):
+    from oracle import models as om
+    from deep_cbrs_amar_renaissance_amd import engine
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    engine.set_seed(42)
+    g = helpers.tiny_graph(n_users=70, n_items=45, n_ratings=1500, seed=8, n_props=25, n_links=90)
+    model = basic.BasicGCN(g['adj'], **GRID1)
+    helpers.randomize_biases(model, seed=3)
+    want = om.propagate(g['adj'], helpers.gnn_to_oracle(model.gnn), np.float64)
+    total_nnz, covered = 0, []
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), 'rank{}.npz'.format(r)))
+        assert helpers.rel_err(z['e'], want) < 1e-5, "rank {} holds a wrong node table".format(r)
+        lo, hi = z['pair_range']
+        assert helpers.rel_err(z['u_back'], want[g['u_ids'][lo:hi]]) < 1e-5     # padded pair ids hit the right rows
+        total_nnz += int(z['nnz'])
+        covered.append((int(lo), int(hi)))
+        assert z['bounds'][0] == 0 and z['bounds'][-1] == g['adj'].shape[0]
+    from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter
+    assert total_nnz == gcn_filter(g['adj']).nnz
+    assert covered[0][0] == 0 and covered[0][1] == covered[1][0] and covered[1][1] == len(g['u_ids'])
+
+
+def test_partition_balances_nnz_and_handles_edges():
+    from deep_cbrs_amar_renaissance_amd.parallel import partition_rows_by_nnz, RowPartition
+    deg = np.r_[np.full(100, 50), np.full(900, 2), [0, 0, 0]]
+    rowptr = torch.from_numpy(np.r_[0, np.cumsum(deg)])
+    for world in (1, 2, 4, 8):
+        b = partition_rows_by_nnz(rowptr, world)
+        assert b[0] == 0 and b[-1] == len(deg) and all(b[k] <= b[k + 1] for k in range(world))
+        per = [int(rowptr[b[k + 1]] - rowptr[b[k]]) for k in range(world)]
+        assert max(per) - min(per) <= 2 * 50
+        part = RowPartition(b)
+        ids = torch.arange(len(deg))
+        p = part.padded_index(ids)
+        assert len(torch.unique(p)) == len(deg) and int(p.max()) < world * part.R and part.R % 4 == 0
+        t = torch.arange(len(deg) * 3, dtype=torch.float32).reshape(-1, 3)
+        assert torch.equal(part.pad_table(t)[p], t)
+    b = partition_rows_by_nnz(torch.tensor([0, 0, 0]), 4)                 # empty graph
+    assert b == [0, 0, 0, 0, 2] or (b[0] == 0 and b[-1] == 2)

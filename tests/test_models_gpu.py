@@ -30,7 +30,6 @@ def _score_and_check(model, adj, data, users, items, check_topk=True):
     assert got.shape == want.shape == (len(u), 1)
     assert np.abs(got - want).max() < 1e-4
     if check_topk:
-        want32 = om.basic_gnn_scores(adj, gnn, head, u, i, dtype=np.float32)
         for k in (5, 10):
             seg_users, top_items, _ = top_k_arrays(u, i, got, k)
             valid = top_items >= 0
@@ -38,14 +37,15 @@ def _score_and_check(model, adj, data, users, items, check_topk=True):
             got_i = items[top_items[valid] - len(users)]
             want_u, want_i, _ = om.top_k(u, i, got, users, items, k)
             assert np.array_equal(got_u, want_u) and np.array_equal(got_i, want_i), "device top-k != host top-k"
-            # the ranked lists built from oracle scores: identical except where the oracle's own fp32 and fp64
-            # runs disagree (scores closer than rounding) — count those and require the rest to match
-            o64_u, o64_i, _ = om.top_k(u, i, want, users, items, k)
-            o32_u, o32_i, _ = om.top_k(u, i, want32, users, items, k)
-            ambiguous = set(o64_u[(o64_i != o32_i)].tolist())
-            mismatch = set(got_u[(got_i != o64_i)].tolist())
-            assert mismatch <= ambiguous, "top-{} lists differ from the oracle for users {}".format(k, sorted(mismatch - ambiguous)[:5])
-            assert len(ambiguous) <= 0.002 * len(set(o64_u.tolist())) + 1
+            # against the oracle's fp64 ranking: a list may differ only by swaps among near-ties, i.e. at every
+            # rank the oracle score of the item we picked equals the oracle's own pick within fp32 rounding
+            o_u, o_i, o_s = om.top_k(u, i, want, users, items, k)
+            assert np.array_equal(got_u, o_u)
+            score_of = {(int(a), int(b)): float(c) for a, b, c in zip(users[u], items[i - len(users)], want.reshape(-1))}
+            picked = np.array([score_of[(int(a), int(b))] for a, b in zip(got_u, got_i)])
+            assert np.abs(picked - o_s).max() < 1e-6, "top-{} differs from the oracle beyond near-ties".format(k)
+            differing_users = len(set(got_u[got_i != o_i].tolist()))
+            assert differing_users <= 0.005 * len(set(o_u.tolist())), differing_users
     return got
 
 

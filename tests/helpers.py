@@ -47,6 +47,14 @@ def randomize_biases(model, seed=0, scale=0.05):
                 p.copy_(torch.from_numpy(rng.uniform(-scale, scale, size=tuple(p.shape)).astype(np.float32)))
 
 
+def spread_scores(model, factor=30.0):
+    """Seed-initialised heads put every score within ~1e-2 of 0.5, so rankings hinge on fp32 rounding.
+    Scaling the output layer spreads the scores over (0, 1) like a trained model's, leaving few near-ties."""
+    import torch
+    with torch.no_grad():
+        model.rs.clf.layers[-1].kernel.mul_(factor)
+
+
 def _np(p):
     return p.detach().cpu().numpy().copy()
 

@@ -45,7 +45,7 @@ def _score_and_check(model, adj, data, users, items, check_topk=True):
             picked = np.array([score_of[(int(a), int(b))] for a, b in zip(got_u, got_i)])
             assert np.abs(picked - o_s).max() < 1e-6, "top-{} differs from the oracle beyond near-ties".format(k)
             differing_users = len(set(got_u[got_i != o_i].tolist()))
-            assert differing_users <= 0.005 * len(set(o_u.tolist())), differing_users
+            assert differing_users <= 0.01 * len(set(o_u.tolist())), differing_users
     return got
 
 
@@ -57,6 +57,7 @@ def test_basic_gnn_ml1m_grid1(hip, ml1m_s1, name, graph):
     engine.set_seed(42)
     model = getattr(basic, name)(ml1m_s1[graph], **GRID1)
     helpers.randomize_biases(model, seed=11)
+    helpers.spread_scores(model)
     _score_and_check(model, ml1m_s1[graph], ml1m_s1['test'], ml1m_s1['users'], ml1m_s1['items'])
 
 

@@ -12,6 +12,7 @@
 //
 // Reference semantics: see include/amar_hip.h (each entry point cites the reference file:line).
 #include "amar_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -65,23 +66,10 @@ struct SpmmArgs {
     int n_rows;
 };
 
-template <int F, bool HAS_VALS, bool FUSE_NEXT>
-__global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void spmm_row_kernel(const SpmmArgs a) {
-    constexpr int LPN = F / 4;
-    const int lane = threadIdx.x & (AMAR_WAVE - 1);
-    const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
-    if (row >= a.n_rows) return;                       // wave-uniform
-    const int q = lane % LPN, slot = lane / LPN;
-
-    float wn[F];                                       // column `lane` of the next layer's kernel
-    if (FUSE_NEXT) {
-#pragma unroll
-        for (int k = 0; k < F; ++k) wn[k] = lane < a.Cn ? a.Wn[k * a.Cn + lane] : 0.f;
-    }
-
-    const int beg = a.rowptr[row], end = a.rowptr[row + 1];
-    float4 y = row_gather_sum<LPN, HAS_VALS>(a.colidx, a.vals, a.X, a.ldx, beg, end, slot, q);
-
+// Bias / ReLU / store / running layer sum / next layer's dense product for one reduced row.
+template <int F, bool FUSE_NEXT>
+__device__ __forceinline__ void spmm_epilogue(const SpmmArgs &a, int row, float4 y, int q, int slot, int lane,
+                                              const float (&wn)[F]) {
     if (a.bias) {
         const float4 b = *reinterpret_cast<const float4 *>(a.bias + 4 * q);
         y = f4_add(y, b);
@@ -106,15 +94,120 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void spmm_row_kernel(c
     }
 }
 
+// v1: one wavefront per row (kept for A/B timing: AMAR_SPMM_V1=1).
+template <int F, bool HAS_VALS, bool FUSE_NEXT>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void spmm_row_kernel(const SpmmArgs a) {
+    constexpr int LPN = F / 4;
+    const int lane = threadIdx.x & (AMAR_WAVE - 1);
+    const int row = blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= a.n_rows) return;                       // wave-uniform
+    const int q = lane % LPN, slot = lane / LPN;
+    float wn[F];                                       // column `lane` of the next layer's kernel
+    if (FUSE_NEXT) {
+#pragma unroll
+        for (int k = 0; k < F; ++k) wn[k] = lane < a.Cn ? a.Wn[k * a.Cn + lane] : 0.f;
+    }
+    const int beg = a.rowptr[row], end = a.rowptr[row + 1];
+    const float4 y = row_gather_sum<LPN, HAS_VALS>(a.colidx, a.vals, a.X, a.ldx, beg, end, slot, q);
+    spmm_epilogue<F, FUSE_NEXT>(a, row, y, q, slot, lane, wn);
+}
+
+// v2: streaming form.  A wavefront owns `rpw` consecutive rows, i.e. ONE contiguous range of the
+// colidx/vals arrays.  It streams that range in coalesced 64-entry register tiles (lane l holds
+// entry pt + l), always one tile ahead of use, so the HBM latency of the CSR stream is paid once
+// per wave instead of once per row; row boundaries come from one coalesced rowptr load kept in a
+// register and read with v_readlane.  Gather slots pick their (column, value) out of the tile
+// registers with a wavefront shuffle (ds_bpermute), gather the source row quad, and accumulate;
+// rows are finished in order with the same xor-butterfly and epilogue as v1, so v1 and v2 agree
+// bit for bit whenever a row's non-zeros fall in the same slot order (they do: slot = index mod NS).
+template <int F, bool HAS_VALS, bool FUSE_NEXT>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void spmm_stream_kernel(const SpmmArgs a, const int rpw) {
+    constexpr int LPN = F / 4, NS = AMAR_WAVE / LPN;
+    const int lane = threadIdx.x & (AMAR_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    const int r0 = wave * rpw;
+    if (r0 >= a.n_rows) return;
+    const int nr = min(rpw, a.n_rows - r0);
+    const int q = lane % LPN, slot = lane / LPN;
+    float wn[F];
+    if (FUSE_NEXT) {
+#pragma unroll
+        for (int k = 0; k < F; ++k) wn[k] = lane < a.Cn ? a.Wn[k * a.Cn + lane] : 0.f;
+    }
+    const int rp = a.rowptr[r0 + min(lane, nr)];
+    const int p1 = __builtin_amdgcn_readlane(rp, nr);
+    int pt = __builtin_amdgcn_readlane(rp, 0);          // base of the current tile
+    int ccur = 0, cnxt = 0;
+    float vcur = 1.f, vnxt = 1.f;
+    if (pt + lane < p1) { ccur = a.colidx[pt + lane]; if (HAS_VALS) vcur = a.vals[pt + lane]; }
+    if (pt + 64 + lane < p1) { cnxt = a.colidx[pt + 64 + lane]; if (HAS_VALS) vnxt = a.vals[pt + 64 + lane]; }
+
+    int row_beg = pt;
+    for (int k = 0; k < nr; ++k) {
+        const int row_end = __builtin_amdgcn_readlane(rp, k + 1);
+        float4 acc = f4_zero();
+        int pos = row_beg;
+        // slot s of the row takes the row's non-zeros s, s+NS, s+2NS, ... exactly like v1
+        while (pos < row_end) {
+            if (pos >= pt + 64) {                       // advance one tile, keep one tile in flight
+                ccur = cnxt; vcur = vnxt; pt += 64;
+                cnxt = 0; vnxt = 1.f;
+                if (pt + 64 + lane < p1) { cnxt = a.colidx[pt + 64 + lane]; if (HAS_VALS) vnxt = a.vals[pt + 64 + lane]; }
+            }
+            const int hi = min(row_end, pt + 64);
+            for (int base = pos; base < hi; base += 2 * NS) {
+                // map tile positions back to the row-relative slot order: position p belongs to slot (p - row_beg) % NS
+                const int i0 = base + ((slot - (base - row_beg)) & (NS - 1));
+                const int i1 = i0 + NS;
+                const int c0 = __shfl(ccur, (i0 - pt) & 63, 64), c1 = __shfl(ccur, (i1 - pt) & 63, 64);
+                float v0 = 1.f, v1 = 1.f;
+                if (HAS_VALS) { v0 = __shfl(vcur, (i0 - pt) & 63, 64); v1 = __shfl(vcur, (i1 - pt) & 63, 64); }
+                float4 x0 = f4_zero(), x1 = f4_zero();
+                if (i0 < hi) x0 = *reinterpret_cast<const float4 *>(a.X + (int64_t)c0 * a.ldx + 4 * q);
+                if (i1 < hi) x1 = *reinterpret_cast<const float4 *>(a.X + (int64_t)c1 * a.ldx + 4 * q);
+                if (i0 < hi) acc = f4_fma(v0, x0, acc);
+                if (i1 < hi) acc = f4_fma(v1, x1, acc);
+            }
+            pos = hi;
+        }
+#pragma unroll
+        for (int off = AMAR_WAVE / 2; off >= LPN; off >>= 1) acc = f4_add(acc, f4_shfl_xor(acc, off));
+        spmm_epilogue<F, FUSE_NEXT>(a, r0 + k, acc, q, slot, lane, wn);
+        row_beg = row_end;
+    }
+}
+
+int spmm_rows_per_wave(int n_rows) {
+    // enough waves to fill 256 CUs x 32 wave slots a few times over, at most 16 rows per wave
+    int rpw = n_rows / (256 * 32 * 4);
+    return rpw < 1 ? 1 : (rpw > 16 ? 16 : rpw);
+}
+
 template <bool HAS_VALS, bool FUSE_NEXT>
 int launch_spmm(const SpmmArgs &a, int F, hipStream_t st) {
-    const dim3 grid((a.n_rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVES_PER_BLOCK * AMAR_WAVE);
+    static const bool use_v1 = getenv("AMAR_SPMM_V1") != nullptr;
+    const dim3 block(WAVES_PER_BLOCK * AMAR_WAVE);
+    if (use_v1) {
+        const dim3 grid((a.n_rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
+        switch (F) {
+        case 4:  hipLaunchKernelGGL((spmm_row_kernel<4, HAS_VALS, FUSE_NEXT>), grid, block, 0, st, a); break;
+        case 8:  hipLaunchKernelGGL((spmm_row_kernel<8, HAS_VALS, FUSE_NEXT>), grid, block, 0, st, a); break;
+        case 16: hipLaunchKernelGGL((spmm_row_kernel<16, HAS_VALS, FUSE_NEXT>), grid, block, 0, st, a); break;
+        case 32: hipLaunchKernelGGL((spmm_row_kernel<32, HAS_VALS, FUSE_NEXT>), grid, block, 0, st, a); break;
+        case 64: hipLaunchKernelGGL((spmm_row_kernel<64, HAS_VALS, FUSE_NEXT>), grid, block, 0, st, a); break;
+        default: return AMAR_EUNSUPPORTED;
+        }
+        return amar_check_launch();
+    }
+    const int rpw = spmm_rows_per_wave(a.n_rows);
+    const int waves = (a.n_rows + rpw - 1) / rpw;
+    const dim3 grid((waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK);
     switch (F) {
-    case 4:  hipLaunchKernelGGL((spmm_row_kernel<4, HAS_VALS, FUSE_NEXT>), grid, block, 0, st, a); break;
-    case 8:  hipLaunchKernelGGL((spmm_row_kernel<8, HAS_VALS, FUSE_NEXT>), grid, block, 0, st, a); break;
-    case 16: hipLaunchKernelGGL((spmm_row_kernel<16, HAS_VALS, FUSE_NEXT>), grid, block, 0, st, a); break;
-    case 32: hipLaunchKernelGGL((spmm_row_kernel<32, HAS_VALS, FUSE_NEXT>), grid, block, 0, st, a); break;
-    case 64: hipLaunchKernelGGL((spmm_row_kernel<64, HAS_VALS, FUSE_NEXT>), grid, block, 0, st, a); break;
+    case 4:  hipLaunchKernelGGL((spmm_stream_kernel<4, HAS_VALS, FUSE_NEXT>), grid, block, 0, st, a, rpw); break;
+    case 8:  hipLaunchKernelGGL((spmm_stream_kernel<8, HAS_VALS, FUSE_NEXT>), grid, block, 0, st, a, rpw); break;
+    case 16: hipLaunchKernelGGL((spmm_stream_kernel<16, HAS_VALS, FUSE_NEXT>), grid, block, 0, st, a, rpw); break;
+    case 32: hipLaunchKernelGGL((spmm_stream_kernel<32, HAS_VALS, FUSE_NEXT>), grid, block, 0, st, a, rpw); break;
+    case 64: hipLaunchKernelGGL((spmm_stream_kernel<64, HAS_VALS, FUSE_NEXT>), grid, block, 0, st, a, rpw); break;
     default: return AMAR_EUNSUPPORTED;
     }
     return amar_check_launch();

@@ -35,6 +35,7 @@ def main():
     pos = torch.arange(nnz, device=dev, dtype=torch.int64)
 
     def run(colidx, F, policy=0, unroll=2, nt=0, label=''):
+        torch.manual_seed(F)
         x = torch.randn((n, F), device=dev)
         y = torch.empty((n, F), device=dev)
         st = torch.cuda.current_stream().cuda_stream
@@ -59,10 +60,6 @@ def main():
         'all zero column (broadcast)': torch.zeros(nnz, device=dev, dtype=torch.int32),
     }
     print('-- gather patterns (plain loads)')
-    for label, c in pats.items():
-        run(c, 8, label=label)
-    for label in ('real graph', 'random in 2^16 rows (2 MB @F8: L2)', 'sequential (p mod N): no gather misses'):
-        run(pats[label], 32, label=label)
     print('-- cache policy / unroll / nt-stream on the real graph, F=8')
     ref = run(real, 8, 0, 2, 0, 'ref')
     for pol in (0, 1, 2, 3, 4):
@@ -75,6 +72,10 @@ def main():
         run(pats['random in 2^16 rows (2 MB @F8: L2)'], 8, pol, 4, 1, 'L2-resident')
     for pol in (0, 1, 2, 3, 4):
         run(real, 32, pol, 2, 0, 'real F=32')
+    print('-- all-zero column (stream floor), unroll/nt variants')
+    for unr in (2, 4):
+        for nt in (0, 1):
+            run(pats['all zero column (broadcast)'], 8, 0, unr, nt, 'floor')
 
 
 if __name__ == '__main__':

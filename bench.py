@@ -92,6 +92,7 @@ def main():
     a_hat = gcn_filter_device(data['train_pos'][:, 0], data['train_pos'][:, 1], n_nodes)
     nnz = a_hat.nnz
     model = basic.BasicGCN(a_hat, **GRID1)
+    model.n_users, model.n_items = data['n_users'], data['n_items']
     u_all = data['test'][:, 0].to(torch.int32).contiguous()
     i_all = data['test'][:, 1].to(torch.int32).contiguous()
     n_pairs = int(u_all.numel())

@@ -32,7 +32,10 @@ SIGNATURES = {
     'amar_sage_layer_f32': (ctypes.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _I32, _P, _I64, _I32, _I32, _P]),
     'amar_gat_layer_f32': (ctypes.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _P, _I64, _I32, _I32, _P]),
     'amar_dense_f32': (ctypes.c_int, [_P, _I64, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _P]),
-    'amar_copy_columns_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I32, _P]),
+    'amar_chain_pack_floats': (ctypes.c_int64, [_P, _I32]),
+    'amar_chain_pack_f32': (ctypes.c_int, [_P, _P, _P, _I32, _P]),
+    'amar_chain_f32': (ctypes.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _I32, _P, _I32, _P, _P, _P, _I32, _P, _I64, _I64, _P]),
+    'amar_copy_columns_f32': (ctypes.c_int, [_P, _I64, _P, _I32, _P, _I64, _I64, _I32, _P]),
     'amar_reduce_layers_f32': (ctypes.c_int, [_P, _I64, _I32, _I32, _P, _I64, _I64, _I32, _P]),
     'amar_topk_segmented_f32': (ctypes.c_int, [_P, _P, _P, _I32, _I32, _P, _P, _P]),
 }
@@ -192,12 +195,64 @@ def dense(X, W, bias, Y, act='relu', ids=None):
     _check(code, 'amar_dense_f32')
 
 
-def copy_columns(src, dst):
-    if tuple(src.shape) != tuple(dst.shape):
+CHAIN_MAX_WIDTH, CHAIN_MAX_LAYERS = 128, 8
+
+
+def chain_supported(dims, in_a, in_b=0):
+    """True when amar_chain_f32 can run a dense stack with these widths (else use dense() per layer)."""
+    return (1 <= len(dims) - 1 <= CHAIN_MAX_LAYERS and max(dims) <= CHAIN_MAX_WIDTH and in_a % 4 == 0 and in_a >= 4
+            and in_b % 4 == 0 and dims[0] == in_a + in_b and (dims[-1] % 4 == 0 or (dims[-1] == 1 and len(dims) > 2)))
+
+
+def chain_pack(kernels, biases):
+    """Host-side packing of a Dense stack into MFMA fragment order; returns a device float32 blob + dims."""
+    import numpy as np
+    ks = [np.ascontiguousarray(k, dtype=np.float32) for k in kernels]
+    bs = [np.ascontiguousarray(b, dtype=np.float32) for b in biases]
+    dims = [ks[0].shape[0]] + [k.shape[1] for k in ks]
+    for k, b, kin, n in zip(ks, bs, dims[:-1], dims[1:]):
+        if k.shape != (kin, n) or b.shape != (n,):
+            raise ValueError("chain_pack: inconsistent layer shapes")
+    lib = load()
+    dims_c = (ctypes.c_int32 * len(dims))(*dims)
+    total = lib.amar_chain_pack_floats(dims_c, len(ks))
+    if total < 0:
+        _check(int(total), 'amar_chain_pack_floats')
+    out = np.empty(total, dtype=np.float32)
+    kp = (ctypes.c_void_p * len(ks))(*[k.ctypes.data for k in ks])
+    bp = (ctypes.c_void_p * len(bs))(*[b.ctypes.data for b in bs])
+    _check(lib.amar_chain_pack_f32(kp, bp, dims_c, len(ks), out.ctypes.data), 'amar_chain_pack_f32')
+    return out, dims
+
+
+def chain(A, wpack, dims, acts, out, ids_a=None, base_a=0, B=None, ids_b=None, base_b=0):
+    """out = DenseStack([A[ids_a - base_a] || B[ids_b - base_b]]); see amar_chain_f32 in include/amar_hip.h."""
+    P = out.shape[0]
+    Da, Db = A.shape[1], (B.shape[1] if B is not None else 0)
+    for ids, nm in ((ids_a, 'ids_a'), (ids_b, 'ids_b')):
+        if ids is not None and ids.numel() != P:
+            raise ValueError("chain: {} must have one id per output row".format(nm))
+    if ids_a is None and A.shape[0] < P or (B is not None and ids_b is None and B.shape[0] < P):
+        raise ValueError("chain: input blocks have fewer rows than the output")
+    dims_c = (ctypes.c_int32 * len(dims))(*dims)
+    acts_c = (ctypes.c_int32 * len(acts))(*[ACT_CODES[a] for a in acts])
+    code = load().amar_chain_f32(
+        _ptr(A, torch.float32, 'A'), _ld(A, 'A'), Da, _ptr(ids_a, torch.int32, 'ids_a'), int(base_a),
+        _ptr(B, torch.float32, 'B'), _ld(B, 'B') if B is not None else 0, Db, _ptr(ids_b, torch.int32, 'ids_b'), int(base_b),
+        _ptr(wpack, torch.float32, 'wpack'), dims_c, acts_c, len(acts),
+        _ptr(out, torch.float32, 'out'), _ld(out, 'out'), P, _stream())
+    _check(code, 'amar_chain_f32')
+
+
+def copy_columns(src, dst, ids=None, base=0):
+    """dst[r, :] = src[ids[r] - base, :] (or src[r, :] without ids); dst may be a column slice."""
+    n = ids.numel() if ids is not None else src.shape[0]
+    if src.shape[1] != dst.shape[1] or dst.shape[0] != n:
         raise ValueError("copy_columns: shapes differ")
     code = load().amar_copy_columns_f32(_ptr(src, torch.float32, 'src'), _ld(src, 'src'),
+                                        _ptr(ids, torch.int32, 'ids'), int(base),
                                         _ptr(dst, torch.float32, 'dst'), _ld(dst, 'dst'),
-                                        src.shape[0], src.shape[1], _stream())
+                                        n, src.shape[1], _stream())
     _check(code, 'amar_copy_columns_f32')
 
 

@@ -1,0 +1,265 @@
+// Fused gather + dense chain for the scoring heads (gfx950, fp32 MFMA 16x16x4).
+//
+// Computes, for every row p of a batch (a (user, item) pair, or an entity row):
+//     x   = [ A[ida(p), 0:Da] || B[idb(p), 0:Db] ]                     gather + Concatenate
+//     x   = act_l( x . W_l + b_l )   for each layer l                    Keras Dense stack
+// and writes either the last layer's [P, N] block or, when the last layer has one unit, the
+// [P] scores.  Reference semantics: tf.nn.embedding_lookup + Concatenate + Dense stacks at
+// src/models/basic.py:31-37,72-75, src/models/hybrid.py:72-89, src/models/dense.py:4-17.
+//
+// Formulation (transposed): Out^T[feature, pair] = W^T . X^T on v_mfma_f32_16x16x4_f32 with the
+// pair on the MFMA column (lane & 15) and features on rows.  The C/D layout of that instruction
+// (lane l, register r <-> row 4*(l>>4)+r, column l&15) is exactly its B-operand layout for
+// k = 4*(l>>4)+r, so a layer's accumulators — after bias (pre-loaded as the initial accumulator)
+// and ReLU — feed the next layer's MFMAs as B operands with NO cross-lane movement and no LDS
+// round trip: activations never leave registers.  The gathered input rows arrive in the same
+// layout for free: lane l loads the float4 at feature offset 16t + 4*(l>>4) of pair l&15.
+// Weights are pre-packed on the host into A-operand fragment order (one ds_read_b128 per lane
+// feeds 4 MFMAs x PT pair tiles) and live in LDS for the whole launch.
+//
+// f32 MFMA is an exact k-ordered fmaf chain, so results do not depend on tiling; the k order
+// differs from a plain dot product only by the fixed interleave (4g + r), well inside 1e-6.
+#include "amar_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CHAIN_MAX_LAYERS = 8;
+
+struct ChainArgs {
+    const float *A; int64_t lda; int Da; const int32_t *ids_a; int base_a;
+    const float *B; int64_t ldb; int Db; const int32_t *ids_b; int base_b;
+    const float *wpack; int wpack_floats;
+    int n_layers;                       // MFMA layers (a trailing 1-unit layer is the VALU `dot` stage)
+    int kt[CHAIN_MAX_LAYERS], nt[CHAIN_MAX_LAYERS], act[CHAIN_MAX_LAYERS];
+    int w_off[CHAIN_MAX_LAYERS], b_off[CHAIN_MAX_LAYERS];
+    int has_dot, dot_off, dot_bias_off, dot_act, dot_kt;
+    int n_out;                          // width of the written block (last MFMA layer) when !has_dot
+    float *out; int64_t ldo; int64_t P;
+};
+
+__device__ __forceinline__ float chain_act(float v, int act) {
+    if (act == AMAR_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == AMAR_ACT_SIGMOID) return 1.f / (1.f + expf(-v));
+    return v;
+}
+
+template <int MAXT, int PT>
+__global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float w_lds[];
+    for (int i = threadIdx.x * 4; i < a.wpack_floats; i += blockDim.x * 4)
+        *reinterpret_cast<float4 *>(&w_lds[i]) = *reinterpret_cast<const float4 *>(a.wpack + i);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, g = lane >> 4, col = lane & 15;
+    const int64_t pairs_per_wave = 16 * PT;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * 4 * pairs_per_wave;
+
+    for (int64_t base = wave0 * pairs_per_wave; base < a.P; base += stride) {
+        f32x4 x[MAXT][PT];
+        // ---- gather + concatenate: lane (g, col) holds features 16t+4g .. +3 of pair base + 16*pt + col
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int64_t p = base + 16 * pt + col;
+            const bool ok = p < a.P;
+            const int64_t ra = ok ? (a.ids_a ? (int64_t)a.ids_a[p] - a.base_a : p) : 0;
+            const int64_t rb = (ok && a.Db) ? (a.ids_b ? (int64_t)a.ids_b[p] - a.base_b : p) : 0;
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                const int f = 16 * t + 4 * g;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (t < a.kt[0] && ok) {
+                    if (f < a.Da) v = *reinterpret_cast<const f32x4 *>(a.A + ra * a.lda + f);
+                    else if (f < a.Da + a.Db) v = *reinterpret_cast<const f32x4 *>(a.B + rb * a.ldb + (f - a.Da));
+                }
+                x[t][pt] = v;
+            }
+        }
+        // ---- dense layers on MFMA, activations stay in registers
+        for (int l = 0; l < a.n_layers; ++l) {
+            const int KT = a.kt[l], NT = a.nt[l];
+            const float *wl = w_lds + a.w_off[l];
+            const float *bl = w_lds + a.b_off[l];
+            f32x4 y[MAXT][PT];
+#pragma unroll
+            for (int m = 0; m < MAXT; ++m) {
+                if (m < NT) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bl + 16 * m + 4 * g);
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) y[m][pt] = b4;
+#pragma unroll
+                    for (int t = 0; t < MAXT; ++t) {
+                        if (t < KT) {
+                            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wl + ((m * KT + t) * 64 + lane) * 4);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                                for (int pt = 0; pt < PT; ++pt)
+                                    y[m][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[r], x[t][pt][r], y[m][pt], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            const int act = a.act[l];
+#pragma unroll
+            for (int m = 0; m < MAXT; ++m)
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (m < NT) {
+                        v = y[m][pt];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = chain_act(v[r], act);
+                    }
+                    x[m][pt] = v;
+                }
+        }
+        // ---- output
+        if (a.has_dot) {
+            const float *wd = w_lds + a.dot_off;
+            const float bd = w_lds[a.dot_bias_off];
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                float s = 0.f;
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t) {
+                    if (t < a.dot_kt) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wd + 16 * t + 4 * g);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s = fmaf(x[t][pt][r], w4[r], s);
+                    }
+                }
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                const int64_t p = base + 16 * pt + col;
+                if (g == 0 && p < a.P) a.out[p * a.ldo] = chain_act(s + bd, a.dot_act);
+            }
+        } else {
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int64_t p = base + 16 * pt + col;
+#pragma unroll
+                for (int m = 0; m < MAXT; ++m) {
+                    const int f = 16 * m + 4 * g;
+                    if (p < a.P && f < a.n_out) *reinterpret_cast<f32x4 *>(a.out + p * a.ldo + f) = x[m][pt];
+                }
+            }
+        }
+    }
+}
+
+inline int tiles16(int n) { return (n + 15) / 16; }
+
+}  // namespace
+
+extern "C" {
+
+// Number of floats of the packed blob for layer widths dims[0..n_layers] (dims[0] = input width).
+int64_t amar_chain_pack_floats(const int32_t *dims, int32_t n_layers) {
+    if (!dims || n_layers < 1 || n_layers > CHAIN_MAX_LAYERS) return AMAR_EINVAL;
+    int64_t total = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        const int K = dims[l], N = dims[l + 1];
+        if (K < 1 || N < 1) return AMAR_EINVAL;
+        if (l == n_layers - 1 && N == 1 && n_layers > 1) total += 16 * tiles16(K) + 4;         // dot weights + bias
+        else total += (int64_t)tiles16(N) * tiles16(K) * 256 + 16 * tiles16(N);                // fragments + bias
+    }
+    return total;
+}
+
+// HOST-side packing: kernels[l] is row-major [dims[l], dims[l+1]] (Keras Dense kernel), biases[l] is [dims[l+1]].
+// Fragment order: W_p[m][t][lane][r] = W[16t + 4(lane>>4) + r][16m + (lane&15)], zero outside the matrix.
+int amar_chain_pack_f32(const float *const *kernels, const float *const *biases, const int32_t *dims,
+                        int32_t n_layers, float *out) {
+    if (!kernels || !biases || !out) return AMAR_EINVAL;
+    const int64_t total = amar_chain_pack_floats(dims, n_layers);
+    if (total < 0) return (int)total;
+    int64_t off = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        const int K = dims[l], N = dims[l + 1], KT = tiles16(K), NT = tiles16(N);
+        const float *W = kernels[l], *b = biases[l];
+        if (l == n_layers - 1 && N == 1 && n_layers > 1) {
+            for (int k = 0; k < 16 * KT; ++k) out[off + k] = k < K ? W[k] : 0.f;
+            off += 16 * KT;
+            out[off] = b[0]; out[off + 1] = out[off + 2] = out[off + 3] = 0.f;
+            off += 4;
+        } else {
+            for (int m = 0; m < NT; ++m)
+                for (int t = 0; t < KT; ++t)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int r = 0; r < 4; ++r) {
+                            const int k = 16 * t + 4 * (lane >> 4) + r, n = 16 * m + (lane & 15);
+                            out[off++] = (k < K && n < N) ? W[(int64_t)k * N + n] : 0.f;
+                        }
+            for (int n = 0; n < 16 * NT; ++n) out[off++] = n < N ? b[n] : 0.f;
+        }
+    }
+    return off == total ? AMAR_OK : AMAR_EINVAL;
+}
+
+int amar_chain_f32(const float *A, int64_t lda, int32_t Da, const int32_t *ids_a, int32_t base_a,
+                   const float *B, int64_t ldb, int32_t Db, const int32_t *ids_b, int32_t base_b,
+                   const float *wpack, const int32_t *dims, const int32_t *acts, int32_t n_layers,
+                   float *out, int64_t ldo, int64_t P, amar_stream_t stream) {
+    if (P < 0 || !A || !wpack || !dims || !acts || !out || Da < 4 || Db < 0) return AMAR_EINVAL;
+    if ((Da & 3) || (Db & 3) || (lda & 3) || lda < Da || !amar_aligned16(A) || !amar_aligned16(wpack)) return AMAR_EINVAL;
+    if (Db && (!B || (ldb & 3) || ldb < Db || !amar_aligned16(B))) return AMAR_EINVAL;
+    if (n_layers < 1 || n_layers > CHAIN_MAX_LAYERS || dims[0] != Da + Db) return AMAR_EINVAL;
+    ChainArgs a{};
+    a.A = A; a.lda = lda; a.Da = Da; a.ids_a = ids_a; a.base_a = base_a;
+    a.B = B; a.ldb = ldb; a.Db = Db; a.ids_b = ids_b; a.base_b = base_b;
+    a.wpack = wpack; a.out = out; a.ldo = ldo; a.P = P;
+    int maxw = 0, off = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        const int K = dims[l], N = dims[l + 1], act = acts[l];
+        if (K < 1 || N < 1 || (act != AMAR_ACT_NONE && act != AMAR_ACT_RELU && act != AMAR_ACT_SIGMOID)) return AMAR_EINVAL;
+        maxw = K > maxw ? K : maxw;
+        if (l == n_layers - 1 && N == 1 && n_layers > 1) {
+            a.has_dot = 1; a.dot_off = off; a.dot_kt = tiles16(K); a.dot_act = act;
+            off += 16 * tiles16(K);
+            a.dot_bias_off = off;
+            off += 4;
+        } else {
+            maxw = N > maxw ? N : maxw;
+            a.kt[a.n_layers] = tiles16(K); a.nt[a.n_layers] = tiles16(N); a.act[a.n_layers] = act;
+            a.w_off[a.n_layers] = off;
+            off += tiles16(N) * tiles16(K) * 256;
+            a.b_off[a.n_layers] = off;
+            off += 16 * tiles16(N);
+            a.n_layers++;
+            a.n_out = N;
+        }
+    }
+    a.wpack_floats = off;
+    if (a.n_layers < 1) return AMAR_EINVAL;
+    if (!a.has_dot && ((ldo & 3) || ldo < a.n_out || (a.n_out & 3) || !amar_aligned16(out))) return AMAR_EINVAL;
+    if (a.has_dot && ldo < 1) return AMAR_EINVAL;
+    if (maxw > 128 || (size_t)off * sizeof(float) > 150 * 1024) return AMAR_EUNSUPPORTED;
+    if (P == 0) return AMAR_OK;
+    const size_t lds_bytes = (size_t)off * sizeof(float);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (maxw <= 64) {
+        constexpr int PT = 4;
+        int64_t blocks = (P + 4 * 16 * PT - 1) / (4 * 16 * PT);
+        if (blocks > 2048) blocks = 2048;
+        auto kern = chain_kernel<4, PT>;
+        if (lds_bytes > 64 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return amar_check_launch() == AMAR_OK ? AMAR_ELAUNCH : AMAR_ELAUNCH;
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
+    } else {
+        constexpr int PT = 2;
+        int64_t blocks = (P + 4 * 16 * PT - 1) / (4 * 16 * PT);
+        if (blocks > 2048) blocks = 2048;
+        auto kern = chain_kernel<8, PT>;
+        if (lds_bytes > 64 * 1024 &&
+            hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+            return AMAR_ELAUNCH;
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
+    }
+    return amar_check_launch();
+}
+
+}  // extern "C"

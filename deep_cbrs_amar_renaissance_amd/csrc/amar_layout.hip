@@ -6,13 +6,15 @@
 namespace {
 
 __global__ __launch_bounds__(256) void copy_columns_kernel(const float *__restrict__ src, int64_t lds,
+                                                           const int32_t *__restrict__ ids, int base,
                                                            float *__restrict__ dst, int64_t ldd, int64_t n_rows,
                                                            int width) {
     const int64_t total = n_rows * width;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / width;
         const int c = (int)(i - r * width);
-        dst[r * ldd + c] = src[r * lds + c];
+        const int64_t sr = ids ? (int64_t)ids[r] - base : r;
+        dst[r * ldd + c] = src[sr * lds + c];
     }
 }
 
@@ -39,12 +41,12 @@ unsigned grid_for(int64_t total) {
 
 extern "C" {
 
-int amar_copy_columns_f32(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t n_rows, int32_t width,
-                          amar_stream_t stream) {
+int amar_copy_columns_f32(const float *src, int64_t lds, const int32_t *ids, int32_t base,
+                          float *dst, int64_t ldd, int64_t n_rows, int32_t width, amar_stream_t stream) {
     if (n_rows < 0 || width < 1 || !src || !dst || lds < width || ldd < width) return AMAR_EINVAL;
     if (n_rows == 0) return AMAR_OK;
     hipLaunchKernelGGL(copy_columns_kernel, dim3(grid_for(n_rows * width)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), src, lds, dst, ldd, n_rows, width);
+                       static_cast<hipStream_t>(stream), src, lds, ids, base, dst, ldd, n_rows, width);
     return amar_check_launch();
 }
 

@@ -117,7 +117,7 @@ def ids_to_device(ids):
         t = ids
     else:
         t = torch.from_numpy(np.ascontiguousarray(ids))
-    if t.numel() and (int(t.max()) >= 2 ** 31 or int(t.min()) < 0):
+    if not t.is_cuda and t.numel() and (int(t.max()) >= 2 ** 31 or int(t.min()) < 0):    # device ids: no sync here
         raise ValueError("ids must be in [0, 2^31)")
     return t.to(device=default_device(), dtype=torch.int32).contiguous()
 

@@ -163,6 +163,8 @@ class Experimenter:
             self.model = cls(self.trainset.adj_matrix, **model_cfg)
         else:
             self.model = cls(**model_cfg)
+        if hasattr(self.model, 'n_users'):                   # lets hoisted scoring run each tower on its own rows
+            self.model.n_users, self.model.n_items = len(self.trainset.users), len(self.trainset.items)
         self.model.compile(loss=self.parameters.loss, optimizer=self.optimizer, metrics=self.parameters.metrics)
         self.model(self.trainset[0][0])                       # one prediction builds every weight
         self.model.summary(print_fn=self.logger.info, expand_nested=True)

@@ -53,14 +53,21 @@ class BasicRS(Model):
         """inputs = (u, i): [B, F] feature blocks — or, with ``u_ids``/``i_ids``, two tables to gather from."""
         u, i = inputs
         u, i = to_device_tensor(u), to_device_tensor(i)
-        m = u_ids.numel() if u_ids is not None else u.shape[0]
         if len(self.dense_units) == 0:
             raise NotImplementedError("BasicRS needs at least one tower layer")
-        d = self.dense_units[-1]
-        x = torch.empty((m, 2 * d), dtype=torch.float32, device=u.device)
-        self.unet(u, out=x[:, :d], ids=u_ids)
-        self.inet(i, out=x[:, d:], ids=i_ids)
-        return self.clf(x)
+        if not self.built:
+            self.build_head(u.shape[1], i.shape[1])
+        tu = self.unet.apply2(u, ids_a=u_ids)
+        ti = self.inet.apply2(i, ids_a=i_ids)
+        return self.clf.apply2(tu, ti)                      # Concatenate([u, i]) happens in the kernel's gather
+
+    def towers(self, u_table, i_table):
+        """Per-ENTITY tower outputs: Dense stacks act row by row, so unet/inet can run once per user/item
+        instead of once per pair; `score_towers` then only gathers and classifies."""
+        return self.unet.apply2(u_table), self.inet.apply2(i_table)
+
+    def score_towers(self, tu, ti, u_ids, i_ids, u_base=0, i_base=0):
+        return self.clf.apply2(tu, ti, ids_a=u_ids, base_a=u_base, ids_b=i_ids, base_b=i_base)
 
 
 class BasicGNN(Model, abc.ABC):
@@ -73,6 +80,8 @@ class BasicGNN(Model, abc.ABC):
     ):
         super().__init__()
         self.rs = BasicRS(dense_units, clf_units, activation=activation)
+        self.n_users = self.n_items = None      # optional: lets the hoisted mode run each tower on its own rows only
+        self._towers = None
         self.built = True
 
     def call(self, inputs, **kwargs):
@@ -80,9 +89,23 @@ class BasicGNN(Model, abc.ABC):
         return self.embed_recommend(updated_embeddings, inputs)
 
     def embed_recommend(self, embeddings, inputs):
-        """Look up the user / item rows of `embeddings` and score them: inputs = (user ids, item ids)."""
-        u, i = inputs
-        return self.rs([embeddings, embeddings], u_ids=ids_to_device(u), i_ids=ids_to_device(i))
+        """Look up the user / item rows of `embeddings` and score them: inputs = (user ids, item ids).
+
+        Faithful mode gathers per pair.  Hoisted mode (predict) computes the two towers once per entity —
+        same kernel, same per-row arithmetic, so both modes return identical bits."""
+        u, i = ids_to_device(inputs[0]), ids_to_device(inputs[1])
+        if not self.gnn.hoist:
+            return self.rs([embeddings, embeddings], u_ids=u, i_ids=i)
+        key = (self.weights_version, embeddings.data_ptr())
+        if self._towers is None or self._towers[0] != key:
+            n = embeddings.shape[0]
+            nu = self.n_users if self.n_users is not None else n
+            lo = nu if self.n_users is not None else 0
+            hi = nu + self.n_items if (self.n_users is not None and self.n_items is not None) else n
+            tu, ti = self.rs.towers(embeddings[:nu], embeddings[lo:hi])
+            self._towers = (key, tu, ti, lo)
+        _, tu, ti, lo = self._towers
+        return self.rs.score_towers(tu, ti, u, i, 0, lo)
 
     def _hoist_begin(self, hoist):
         self.gnn.hoist = bool(hoist)
@@ -90,6 +113,7 @@ class BasicGNN(Model, abc.ABC):
     def _hoist_end(self):
         self.gnn.hoist = False
         self.gnn._hoisted = None
+        self._towers = None
 
 
 class BasicTSGNN(BasicGNN):

@@ -48,6 +48,52 @@ class Sequential(Layer):
             x = layer(x, out=out if k == n - 1 else None, ids=ids if k == 0 else None)
         return x
 
+    # -- fused execution ------------------------------------------------------------------------
+    def _packed(self):
+        """(device blob, dims, activations) of the stack in MFMA fragment order, re-packed when weights change."""
+        version = self.weights_version
+        if getattr(self, '_pack_cache', None) is None or self._pack_cache[0] != version:
+            blob, dims = capi.chain_pack([l.kernel.detach().cpu().numpy() for l in self.layers],
+                                         [l.bias.detach().cpu().numpy() for l in self.layers])
+            self._pack_cache = (version, torch.from_numpy(blob).to(self.layers[0].kernel.device), dims,
+                                [l.activation for l in self.layers])
+        return self._pack_cache[1:]
+
+    def dims(self, in_dim):
+        return [in_dim] + [l.units for l in self.layers]
+
+    def apply2(self, a, b=None, ids_a=None, base_a=0, ids_b=None, base_b=0, out=None):
+        """Run the stack on x = [a[ids_a - base_a] || b[ids_b - base_b]] (ids optional, b optional).
+
+        One fused launch (`amar_chain_f32`) when every width fits the register-resident chain;
+        otherwise gather/concatenate once and run `amar_dense_f32` layer by layer.
+        """
+        if len(self.layers) == 0:
+            raise ValueError("an empty dense stack has nothing to apply")
+        m = ids_a.numel() if ids_a is not None else a.shape[0]
+        in_a, in_b = a.shape[1], (b.shape[1] if b is not None else 0)
+        if not self.built:
+            self.build_chain(in_a + in_b)
+        dims = self.dims(in_a + in_b)
+        if out is None:
+            out = torch.empty((m, dims[-1]), dtype=torch.float32, device=a.device)
+        out_ok = out.stride(0) % 4 == 0 or dims[-1] == 1
+        if capi.chain_supported(dims, in_a, in_b) and out_ok:
+            blob, _, acts = self._packed()
+            capi.chain(a, blob, dims, acts, out, ids_a=ids_a, base_a=base_a, B=b, ids_b=ids_b, base_b=base_b)
+            return out
+        if b is None and base_a == 0:
+            x, ids = a, ids_a                                   # the first dense layer gathers by itself
+        else:
+            x, ids = torch.empty((m, in_a + in_b), dtype=torch.float32, device=a.device), None
+            capi.copy_columns(a, x[:, :in_a], ids=ids_a, base=base_a)
+            if b is not None:
+                capi.copy_columns(b, x[:, in_a:], ids=ids_b, base=base_b)
+        n = len(self.layers)
+        for k, layer in enumerate(self.layers):
+            x = layer(x, out=out if k == n - 1 else None, ids=ids if k == 0 else None)
+        return x
+
     def build_chain(self, in_dim):
         """Create every layer's weights for a known input width (no device work); returns the output width."""
         for layer in self.layers:

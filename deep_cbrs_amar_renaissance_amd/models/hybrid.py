@@ -82,27 +82,27 @@ class HybridCBRS(Model):
         ug, ig, ub, ib = [to_device_tensor(t) for t in inputs]
         gu, gi = g_ids if g_ids is not None else (None, None)
         bu, bi = b_ids if b_ids is not None else (None, None)
-        m = gu.numel() if gu is not None else ug.shape[0]
-        d1, d2, d3 = self.dense_units[0][-1], self.dense_units[1][-1], self.dense_units[2][-1]
-        dev = ug.device
+        if not self.built:
+            self.build_head(ug.shape[1], ub.shape[1])
+        towers = (self.dense1a.apply2(ug, ids_a=gu), self.dense1b.apply2(ig, ids_a=gi),
+                  self.dense2a.apply2(ub, ids_a=bu), self.dense2b.apply2(ib, ids_a=bi))
+        return self.score_towers(towers, None, None)
+
+    def towers(self, ug_table, ig_table, ub_table, ib_table):
+        """Per-ENTITY outputs of the four first-stage networks (row-wise independent, hence hoistable)."""
+        return (self.dense1a.apply2(ug_table), self.dense1b.apply2(ig_table),
+                self.dense2a.apply2(ub_table), self.dense2b.apply2(ib_table))
+
+    def score_towers(self, towers, u_ids, i_ids, u_base=0, i_base=0):
+        """dense3a / dense3b over the fused (concatenated) tower rows of each pair, then the classifier."""
+        tug, tig, tub, tib = towers
         if self.feature_based:
-            f1 = torch.empty((m, 2 * d1), dtype=torch.float32, device=dev)     # [ug || ig]
-            f2 = torch.empty((m, 2 * d2), dtype=torch.float32, device=dev)     # [ub || ib]
-            self.dense1a(ug, out=f1[:, :d1], ids=gu)
-            self.dense1b(ig, out=f1[:, d1:], ids=gi)
-            self.dense2a(ub, out=f2[:, :d2], ids=bu)
-            self.dense2b(ib, out=f2[:, d2:], ids=bi)
+            x1 = self.dense3a.apply2(tug, tig, ids_a=u_ids, base_a=u_base, ids_b=i_ids, base_b=i_base)
+            x2 = self.dense3b.apply2(tub, tib, ids_a=u_ids, base_a=u_base, ids_b=i_ids, base_b=i_base)
         else:
-            f1 = torch.empty((m, d1 + d2), dtype=torch.float32, device=dev)    # [ug || ub]
-            f2 = torch.empty((m, d1 + d2), dtype=torch.float32, device=dev)    # [ig || ib]
-            self.dense1a(ug, out=f1[:, :d1], ids=gu)
-            self.dense2a(ub, out=f1[:, d1:], ids=bu)
-            self.dense1b(ig, out=f2[:, :d1], ids=gi)
-            self.dense2b(ib, out=f2[:, d1:], ids=bi)
-        x = torch.empty((m, 2 * d3), dtype=torch.float32, device=dev)
-        self.dense3a(f1, out=x[:, :d3])
-        self.dense3b(f2, out=x[:, d3:])
-        return self.clf(x)
+            x1 = self.dense3a.apply2(tug, tub, ids_a=u_ids, base_a=u_base, ids_b=u_ids, base_b=u_base)
+            x2 = self.dense3b.apply2(tig, tib, ids_a=i_ids, base_a=i_base, ids_b=i_ids, base_b=i_base)
+        return self.clf.apply2(x1, x2)
 
 
 class HybridBertGNN(Model, abc.ABC):
@@ -126,6 +126,8 @@ class HybridBertGNN(Model, abc.ABC):
             residual=residual
         )
         self.bert_table = None
+        self.n_users = self.n_items = None
+        self._towers = None
         self.built = True
 
     def set_bert_table(self, table):
@@ -138,14 +140,27 @@ class HybridBertGNN(Model, abc.ABC):
 
     def embed_recommend(self, embeddings, inputs):
         """inputs = (user ids, item ids, user BERT block, item BERT block); the BERT blocks may be None
-        when a resident table was registered with :meth:`set_bert_table`."""
+        when a resident table was registered with :meth:`set_bert_table`.  With a resident table, hoisted
+        mode (predict) evaluates the four first-stage networks once per entity."""
         ug, ig, ub, ib = inputs
-        g_ids = (ids_to_device(ug), ids_to_device(ig))
+        u, i = ids_to_device(ug), ids_to_device(ig)
         if ub is None and ib is None:
             if self.bert_table is None:
                 raise ValueError("no BERT blocks in the batch and no resident table registered")
-            return self.rs([embeddings, embeddings, self.bert_table, self.bert_table], g_ids=g_ids, b_ids=g_ids)
-        return self.rs([embeddings, embeddings, ub, ib], g_ids=g_ids)
+            bert = self.bert_table
+            if not self.rs.built:
+                self.rs.build_head(embeddings.shape[1], bert.shape[1])
+            if not self.gnn.hoist:
+                return self.rs([embeddings, embeddings, bert, bert], g_ids=(u, i), b_ids=(u, i))
+            key = (self.weights_version, embeddings.data_ptr(), bert.data_ptr())
+            if self._towers is None or self._towers[0] != key:
+                n = min(embeddings.shape[0], bert.shape[0])
+                nu = self.n_users if self.n_users is not None else n
+                lo = nu if self.n_users is not None else 0
+                hi = nu + self.n_items if (self.n_users is not None and self.n_items is not None) else n
+                self._towers = (key, self.rs.towers(embeddings[:nu], embeddings[lo:hi], bert[:nu], bert[lo:hi]), lo)
+            return self.rs.score_towers(self._towers[1], u, i, 0, self._towers[2])
+        return self.rs([embeddings, embeddings, ub, ib], g_ids=(u, i))
 
     def _hoist_begin(self, hoist):
         self.gnn.hoist = bool(hoist)
@@ -153,6 +168,7 @@ class HybridBertGNN(Model, abc.ABC):
     def _hoist_end(self):
         self.gnn.hoist = False
         self.gnn._hoisted = None
+        self._towers = None
 
 
 def BasicGNNFactory(name, Parent, GNN):

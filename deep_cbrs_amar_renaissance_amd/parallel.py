@@ -93,7 +93,16 @@ class SingleRunner:
         emb = self.model.gnn(None)
         e1.record()
         self._events = (e0, e1)
-        return self.model.rs([emb, emb], u_ids=self.u_ids, i_ids=self.i_ids)
+        return self._score(emb)
+
+    def _score(self, emb):
+        # per-entity towers, then gather + classifier per pair (nothing is cached across steps)
+        nu, ni = self.model.n_users, self.model.n_items
+        if nu is None or ni is None:
+            tu, ti = self.model.rs.towers(emb, emb)
+            return self.model.rs.score_towers(tu, ti, self.u_ids, self.i_ids)
+        tu, ti = self.model.rs.towers(emb[:nu], emb[nu:nu + ni])
+        return self.model.rs.score_towers(tu, ti, self.u_ids, self.i_ids, 0, nu)
 
     def last_propagation_ms(self):
         e0, e1 = self._events
@@ -170,7 +179,8 @@ class PartitionedGCNRunner:
         if self.timing:
             e1.record()
             self._events = (e0, e1)
-        return self.model.rs([emb, emb], u_ids=self.u_ids, i_ids=self.i_ids)
+        tu, ti = self.model.rs.towers(emb, emb)           # replicated per-entity towers over the padded table
+        return self.model.rs.score_towers(tu, ti, self.u_ids, self.i_ids)
 
     def last_propagation_ms(self):
         if not self._events:

@@ -118,13 +118,36 @@ int amar_dense_f32(const float *X, int64_t ldx, const int32_t *ids,
                    const float *W, const float *bias, float *Y, int64_t ldy,
                    int64_t M, int32_t K, int32_t N, int32_t act, amar_stream_t stream);
 
+/* Fused gather + Concatenate + Dense stack (BasicRS / HybridCBRS towers and classifiers:
+ * src/models/basic.py:31-37,72-75, src/models/hybrid.py:72-89, src/models/dense.py:4-17).
+ * For every row p < P:
+ *     x = [ A[ida(p), 0:Da] || B[idb(p), 0:Db] ],  ida(p) = ids_a ? ids_a[p] - base_a : p   (same for B)
+ *     x = act_l( x . W_l + b_l )  for l = 0 .. n_layers-1      dims[0] = Da + Db, dims[l+1] = units of layer l
+ * out[p, 0:dims[n_layers]] = x.  A trailing 1-unit layer (the sigmoid scorer) is evaluated as a
+ * dot product and written to out[p * ldo].  Activations stay in registers between layers
+ * (fp32 MFMA 16x16x4); weights come pre-packed in fragment order from amar_chain_pack_f32 and
+ * stay in LDS.  Limits: every width <= 128, Da and Db multiples of 4, <= 8 layers; shapes
+ * outside them return AMAR_EUNSUPPORTED (use amar_dense_f32 layer by layer instead).
+ * amar_chain_pack_floats / amar_chain_pack_f32 run on the HOST (host pointers): kernels[l] is the
+ * row-major [dims[l], dims[l+1]] Keras kernel, biases[l] its bias; the blob is then copied to
+ * the device by the caller.
+ */
+int64_t amar_chain_pack_floats(const int32_t *dims, int32_t n_layers);
+int amar_chain_pack_f32(const float *const *kernels, const float *const *biases, const int32_t *dims,
+                        int32_t n_layers, float *out);
+int amar_chain_f32(const float *A, int64_t lda, int32_t Da, const int32_t *ids_a, int32_t base_a,
+                   const float *B, int64_t ldb, int32_t Db, const int32_t *ids_b, int32_t base_b,
+                   const float *wpack, const int32_t *dims, const int32_t *acts, int32_t n_layers,
+                   float *out, int64_t ldo, int64_t P, amar_stream_t stream);
+
 /* Concatenate / ReductionLayer as layout operations (src/layers/reduction.py:15-33,
- * src/layers/fusion.py:51-53): copy a [n_rows, width] block between two strided matrices, and
+ * src/layers/fusion.py:51-53): copy a [n_rows, width] block between two strided matrices
+ * (row r of dst reads row ids[r] - base of src when ids != NULL: tf.nn.embedding_lookup), and
  * out = X_0 + X_1 + ... (+ division by n_layers for 'mean') over the n_layers equal-width column
  * blocks of a concatenation buffer, added in layer order like tf.add_n.
  */
-int amar_copy_columns_f32(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t n_rows, int32_t width,
-                          amar_stream_t stream);
+int amar_copy_columns_f32(const float *src, int64_t lds, const int32_t *ids, int32_t base,
+                          float *dst, int64_t ldd, int64_t n_rows, int32_t width, amar_stream_t stream);
 int amar_reduce_layers_f32(const float *cat, int64_t ld, int32_t n_layers, int32_t width, float *out, int64_t ldo,
                            int64_t n_rows, int32_t mean, amar_stream_t stream);
 

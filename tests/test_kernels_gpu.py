@@ -244,3 +244,66 @@ def test_bad_arguments_fail_loudly(hip):
         hip.spmm_csr(a.rowptr, a.colidx, a.vals, x, torch.empty((10, 12), device=DEV))      # F = 12 unsupported
     with pytest.raises(Exception):
         hip.spmm_csr(a.rowptr, a.colidx, a.vals, torch.zeros((10, 8)), torch.empty((10, 8), device=DEV))  # CPU tensor
+
+
+CHAIN_CASES = [
+    # (Da, Db, units, final act)          towers / classifiers of the econfigs grids
+    (24, 0, [24, 24], 'relu'), (8, 0, [24, 24], 'relu'), (96, 0, [96, 48], 'relu'), (128, 0, [128, 64], 'relu'),
+    (24, 24, [48, 48, 1], 'sigmoid'), (48, 48, [64, 64, 1], 'sigmoid'), (64, 64, [64, 64, 1], 'sigmoid'),
+    (24, 24, [64, 64], 'relu'), (64, 64, [64, 64], 'relu'), (4, 0, [20], 'relu'), (16, 8, [12, 1], 'sigmoid'),
+]
+
+
+@pytest.mark.parametrize('Da,Db,units,final', CHAIN_CASES)
+@pytest.mark.parametrize('P', [1, 77, 5000])
+def test_chain_fused_stack(hip, Da, Db, units, final, P):
+    rng = np.random.default_rng(Da + Db + P + len(units))
+    na, nb = 300, 200
+    A = rng.standard_normal((na + 7, Da)).astype(np.float32)
+    B = rng.standard_normal((nb + 11, max(Db, 4))).astype(np.float32)[:, :Db] if Db else None
+    ids_a = rng.integers(7, na + 7, size=P).astype(np.int32)
+    ids_b = rng.integers(11, nb + 11, size=P).astype(np.int32)
+    dims = [Da + Db] + units
+    ks = [rng.uniform(-0.4, 0.4, (dims[k], dims[k + 1])).astype(np.float32) for k in range(len(units))]
+    bs = [rng.uniform(-0.2, 0.2, dims[k + 1]).astype(np.float32) for k in range(len(units))]
+    acts = ['relu'] * (len(units) - 1) + [final]
+    assert hip.chain_supported(dims, Da, Db)
+    blob, pdims = hip.chain_pack(ks, bs)
+    assert pdims == dims
+    out = torch.full((P, dims[-1]), float('nan'), device=DEV)
+    Ad = _t(A)[7:]                                   # row base folded into the view ...
+    Bd = _t(np.ascontiguousarray(B)) if Db else None
+    hip.chain(Ad, _t(blob), dims, acts, out, ids_a=_t(ids_a), base_a=7, B=Bd, ids_b=_t(ids_b) if Db else None, base_b=0)
+    x = A[ids_a].astype(np.float64)                  # ... so ids - base_a indexes the view: A[7:][ids - 7] == A[ids]
+    if Db:
+        x = np.concatenate([x, B[ids_b].astype(np.float64)], axis=1)
+    for k, b, a in zip(ks, bs, acts):
+        x = ol.dense(x, k.astype(np.float64), b.astype(np.float64), a)
+    assert rel_err(out.cpu().numpy(), x) < 5e-6
+    # no ids: rows taken in order
+    if P <= na and (not Db or P <= nb):
+        out2 = torch.empty((P, dims[-1]), device=DEV)
+        hip.chain(_t(A), _t(blob), dims, acts, out2, B=Bd)
+        x = A[:P].astype(np.float64)
+        if Db:
+            x = np.concatenate([x, B[:P].astype(np.float64)], axis=1)
+        for k, b, a in zip(ks, bs, acts):
+            x = ol.dense(x, k.astype(np.float64), b.astype(np.float64), a)
+        assert rel_err(out2.cpu().numpy(), x) < 5e-6
+
+
+def test_chain_rejects_unsupported_shapes(hip):
+    assert not hip.chain_supported([768, 512, 256, 128], 768)
+    assert not hip.chain_supported([48, 48, 1], 22, 26)
+    blob, dims = hip.chain_pack([np.zeros((8, 8), np.float32)], [np.zeros(8, np.float32)])
+    with pytest.raises(Exception):
+        hip.chain(torch.zeros((4, 6), device=DEV), _t(blob), dims, ['relu'], torch.zeros((4, 8), device=DEV))
+
+
+def test_gather_copy(hip):
+    rng = np.random.default_rng(1)
+    src = rng.standard_normal((50, 12)).astype(np.float32)
+    ids = rng.integers(5, 50, size=31).astype(np.int32)
+    dst = torch.zeros((31, 20), device=DEV)
+    hip.copy_columns(_t(src)[5:], dst[:, 4:16], ids=_t(ids), base=5)
+    assert np.array_equal(dst.cpu().numpy()[:, 4:16], src[ids])

@@ -72,7 +72,17 @@ def main():
         med, _ = timeit(lambda: model.gnn(None), reps=10)
         print('  propagation (xw + 2 fused layers): {:8.3f} ms'.format(med))
         emb = model.gnn(None)
-        med, _ = timeit(lambda: model.rs([emb, emb], u_ids=u, i_ids=i), reps=5)
+        nu, ni = data['n_users'], data['n_items']
+        def head():
+            tu, ti = model.rs.towers(emb[:nu], emb[nu:nu + ni])
+            return model.rs.score_towers(tu, ti, u, i, 0, nu)
+        med, _ = timeit(head, reps=5)
+        tu, ti = model.rs.towers(emb[:nu], emb[nu:nu + ni])
+        med_t, _ = timeit(lambda: model.rs.towers(emb[:nu], emb[nu:nu + ni]), reps=5)
+        med_c, _ = timeit(lambda: model.rs.score_towers(tu, ti, u, i, 0, nu), reps=5)
+        print('  towers (per entity): {:8.3f} ms   pair clf (gather + 48-48-48-1): {:8.3f} ms -> {:6.2f} G pairs/s'.format(med_t, med_c, P / med_c / 1e6))
+        med_f, _ = timeit(lambda: model.rs([emb, emb], u_ids=u, i_ids=i), reps=5)
+        print('  per-pair towers + clf (faithful form): {:8.3f} ms'.format(med_f))
         flops = P * 13920.0
         print('  head over {} pairs: {:8.3f} ms -> {:6.2f} G pairs/s, {:6.2f} TFLOP/s'.format(P, med, P / med / 1e6, flops / med / 1e9))
         t = torch.empty((P, 24), device=dev)

@@ -107,15 +107,17 @@ def main():
     runner = parallel.make_runner(model, u_all, i_all, rank, world)
 
     spmm_events = []
-    raw_gcn_layer = capi.gcn_layer
+    raw_gcn_layer, raw_spmm_sj = capi.gcn_layer, capi.spmm_sj
 
-    def timed_gcn_layer(*a, **k):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        raw_gcn_layer(*a, **k)
-        e1.record()
-        spmm_events.append((e0, e1))
-    capi.gcn_layer = timed_gcn_layer
+    def timed(fn):
+        def wrapper(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(*a, **k)
+            e1.record()
+            spmm_events.append((e0, e1))
+        return wrapper
+    capi.gcn_layer, capi.spmm_sj = timed(raw_gcn_layer), timed(raw_spmm_sj)   # whichever form the layer dispatches to
 
     def barrier():
         if world > 1:
@@ -131,7 +133,7 @@ def main():
         runner.step()
     barrier()
     dt = time.perf_counter() - t0
-    capi.gcn_layer = raw_gcn_layer
+    capi.gcn_layer, capi.spmm_sj = raw_gcn_layer, raw_spmm_sj
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -141,6 +143,8 @@ def main():
     rows_local = runner.local_rows
     nnz_local = runner.local_nnz
     f = GRID1['n_hiddens'][0]
+    from deep_cbrs_amar_renaissance_amd.utilities.math import spmm_kind
+    kind = spmm_kind(model.gnn.gnn_layers.adj_matrix, f) if world == 1 else 'csr'
     alg_bytes = nnz_local * 8 + (rows_local + 1) * 4 + (n_nodes + rows_local) * f * 4
     avg_ms = float(np.mean(spmm_ms)) if spmm_ms else float('nan')
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
@@ -165,7 +169,7 @@ def main():
                                    'econfigs/basic-gnn.yaml grid1 BasicGCN d=8 L=2 concat, dense [24,24], clf [48,48]; '
                                    'one propagation + per-entity towers + all pairs (shuffled order) per step (hoisted)'.format(args.scale, n_nodes, nnz, n_pairs),
                        'scale': args.scale, 'parallelism': runner.describe()},
-            'roofline': {'bound': 'hbm', 'kernel': 'spmm_stream_kernel<8> (fused GCN layer: CSR SpMM + bias + ReLU + next X.W)', 'achieved': achieved,
+            'roofline': {'bound': 'hbm', 'kernel': ('spmm_sj_kernel<8>' if kind == 'sj' else 'spmm_stream_kernel<8>') + ' (fused GCN layer: SpMM + bias + ReLU + next X.W)', 'achieved': achieved,
                          'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': avg_ms,
                          'launches_timed': len(spmm_ms)},

@@ -27,6 +27,8 @@ SIGNATURES = {
     'amar_last_hip_error': (ctypes.c_int, []),
     'amar_spmm_csr_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _P, _I64, _I32, _I32, _U32, _P,
                                          _P, _I64, _P, _I64, _F32, _P]),
+    'amar_spmm_sj_f32': (ctypes.c_int, [_P, _P, _P, _I32, _P, _I64, _P, _I64, _I32, _I32, _U32, _P,
+                                        _P, _I64, _P, _I64, _F32, _P, _I32, _P, _I64, _P]),
     'amar_gcn_layer_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _I64, _P, _I32, _P, _I64, _I32, _P]),
     'amar_rowwise_xw_f32': (ctypes.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _P, _I64, _P, _P, _P, _P, _I32, _P]),
     'amar_sage_layer_f32': (ctypes.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _I32, _P, _I64, _I32, _I32, _P]),
@@ -115,6 +117,38 @@ def spmm_csr(rowptr, colidx, vals, X, Y=None, bias=None, relu=False, acc_in=None
         _ptr(acc_out, torch.float32, 'acc_out'), _ld(acc_out, 'acc_out') if acc_out is not None else 0,
         float(acc_div) if acc_div is not None else 1.0, _stream())
     _check(code, 'amar_spmm_csr_f32')
+
+
+def spmm_sj(sj, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc_div=None, Wnext=None, Hnext=None):
+    """Y = A.X on the sliced-jagged image `sj` of A (utilities.math.SlicedJagged), with the epilogues of
+    spmm_csr / gcn_layer.  Used when the node table does not fit the per-XCD L2."""
+    n_rows = sj.shape[0]
+    F = X.shape[1]
+    flags = (SPMM_BIAS if bias is not None else 0) | (SPMM_RELU if relu else 0)
+    if acc_out is not None:
+        flags |= SPMM_ACCUM | (SPMM_ACCUM_DIV if acc_div is not None else 0)
+        if acc_in is None or tuple(acc_in.shape) != (n_rows, F) or tuple(acc_out.shape) != (n_rows, F):
+            raise ValueError("acc_in/acc_out must be [n_rows, F]")
+    if Y is not None and tuple(Y.shape) != (n_rows, F):
+        raise ValueError("Y must be [n_rows, F]")
+    if X.shape[0] < sj.shape[1]:
+        raise ValueError("X has fewer rows than the matrix has columns")
+    Cn = 0
+    if Wnext is not None:
+        if Wnext.shape[0] != F or not Wnext.is_contiguous() or Hnext is None or tuple(Hnext.shape) != (n_rows, Wnext.shape[1]):
+            raise ValueError("spmm_sj: Wnext [F, Cn] contiguous and Hnext [n_rows, Cn] expected")
+        Cn = Wnext.shape[1]
+    code = load().amar_spmm_sj_f32(
+        _ptr(sj.entries, torch.int32, 'entries'), _ptr(sj.counts, torch.int16, 'counts'),
+        _ptr(sj.wave_start, torch.int32, 'wave_start'), sj.n_slices,
+        _ptr(X, torch.float32, 'X'), _ld(X, 'X'), _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y') if Y is not None else 0,
+        n_rows, F, flags, _ptr(bias, torch.float32, 'bias'),
+        _ptr(acc_in, torch.float32, 'acc_in'), _ld(acc_in, 'acc_in') if acc_in is not None else 0,
+        _ptr(acc_out, torch.float32, 'acc_out'), _ld(acc_out, 'acc_out') if acc_out is not None else 0,
+        float(acc_div) if acc_div is not None else 1.0,
+        _ptr(Wnext, torch.float32, 'Wnext'), Cn, _ptr(Hnext, torch.float32, 'Hnext'),
+        _ld(Hnext, 'Hnext') if Hnext is not None else 0, _stream())
+    _check(code, 'amar_spmm_sj_f32')
 
 
 def gcn_layer(rowptr, colidx, vals, H, bias, Y, Wnext=None, Hnext=None):

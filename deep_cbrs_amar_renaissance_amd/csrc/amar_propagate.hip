@@ -213,6 +213,121 @@ int launch_spmm(const SpmmArgs &a, int F, hipStream_t st) {
     return amar_check_launch();
 }
 
+// ---- v3: sliced-jagged (SJ) SpMM ----------------------------------------------------------------
+// Why: on ml1m(s=64) the row-gather kernels above move 4.3 GB through the fabric per launch for
+// 0.49 GB of algorithmic bytes (rocprofv3: every L2 miss is a 128-B line fill for a 32-B gather,
+// L2 hit rate 45 %).  Here (format: utilities/math.py:SlicedJagged, include/amar_hip.h)
+//   * columns are cut into slices whose part of X fits the 4 MB per-XCD L2 and every wave sweeps
+//     the slices in the same order, so gathers hit L2 and each XCD fetches each slice once;
+//   * ONE LANE OWNS ONE ROW: its F partial sums stay in registers over all slices — no cross-lane
+//     reduction, no shuffles, no LDS; the sum runs in ascending column order (a scalar CSR loop);
+//   * inside a (wave, slice) block the non-zeros are in jagged-diagonal order, so at step j the
+//     active lanes (ballot + mbcnt) read consecutive 8-byte (col, val) entries: coalesced, unpadded.
+struct SjArgs {
+    const int2 *entries; const int16_t *counts; const int32_t *wave_start; int n_slices; int n_waves;
+    SpmmArgs e;                                        // X/ldx, outputs and epilogue options (rowptr/colidx/vals unused)
+};
+
+__device__ __forceinline__ int lanes_below(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+template <int F, bool FUSE_NEXT>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void spmm_sj_kernel(const SjArgs a) {
+    constexpr int LPN = F / 4;
+    const int lane = threadIdx.x & (AMAR_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * WAVES_PER_BLOCK + (threadIdx.x >> 6));
+    if (wave >= a.n_waves) return;
+    const int row = wave * AMAR_WAVE + lane;
+    const SpmmArgs &e = a.e;
+    int base = a.wave_start[wave];
+    const int16_t *cptr = a.counts + (int64_t)wave * a.n_slices * AMAR_WAVE + lane;
+    float4 acc[LPN];
+#pragma unroll
+    for (int q = 0; q < LPN; ++q) acc[q] = f4_zero();
+
+    int cnt_next = cptr[0];
+    for (int k = 0; k < a.n_slices; ++k) {
+        const int cnt = cnt_next;
+        if (k + 1 < a.n_slices) cnt_next = cptr[(k + 1) * AMAR_WAVE];
+        for (int j = 0;; j += 2) {
+            const bool a0 = cnt > j, a1 = cnt > j + 1;
+            const unsigned long long b0 = __ballot(a0);
+            if (b0 == 0ull) break;
+            const unsigned long long b1 = __ballot(a1);
+            const int n0 = __popcll(b0);
+            const int i0 = base + lanes_below(b0), i1 = base + n0 + lanes_below(b1);
+            base += n0 + __popcll(b1);
+            int2 e0 = make_int2(0, 0), e1 = make_int2(0, 0);
+            if (a0) e0 = a.entries[i0];
+            if (a1) e1 = a.entries[i1];
+            float4 x0[LPN], x1[LPN];
+#pragma unroll
+            for (int q = 0; q < LPN; ++q) {
+                x0[q] = f4_zero(); x1[q] = f4_zero();
+                if (a0) x0[q] = *reinterpret_cast<const float4 *>(e.X + (int64_t)e0.x * e.ldx + 4 * q);
+                if (a1) x1[q] = *reinterpret_cast<const float4 *>(e.X + (int64_t)e1.x * e.ldx + 4 * q);
+            }
+            const float v0 = __int_as_float(e0.y), v1 = __int_as_float(e1.y);
+#pragma unroll
+            for (int q = 0; q < LPN; ++q) {
+                if (a0) acc[q] = f4_fma(v0, x0[q], acc[q]);
+                if (a1) acc[q] = f4_fma(v1, x1[q], acc[q]);
+            }
+        }
+    }
+    if (row >= e.n_rows) return;
+
+    // epilogue: the lane holds its whole row
+#pragma unroll
+    for (int q = 0; q < LPN; ++q) {
+        float4 y = acc[q];
+        if (e.bias) y = f4_add(y, *reinterpret_cast<const float4 *>(e.bias + 4 * q));
+        if (e.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+        acc[q] = y;
+        if (e.Y) *reinterpret_cast<float4 *>(e.Y + (int64_t)row * e.ldy + 4 * q) = y;
+        if (e.accum) {
+            float4 s = *reinterpret_cast<const float4 *>(e.acc_in + (int64_t)row * e.ld_acc_in + 4 * q);
+            s = f4_add(s, y);
+            if (e.accum_div) { s.x /= e.acc_div; s.y /= e.acc_div; s.z /= e.acc_div; s.w /= e.acc_div; }
+            *reinterpret_cast<float4 *>(e.acc_out + (int64_t)row * e.ld_acc_out + 4 * q) = s;
+        }
+    }
+    if (FUSE_NEXT) {
+        // Hnext[row, :] = y . Wnext: Wnext is read with wave-uniform addresses (scalar loads)
+        for (int j0 = 0; j0 < e.Cn; j0 += 4) {
+            float h[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < LPN; ++q)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float yk = f4_get(acc[q], c);
+                    const float *w = e.Wn + (int64_t)(4 * q + c) * e.Cn + j0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (j0 + t < e.Cn) h[t] = fmaf(yk, w[t], h[t]);
+                }
+            float *dst = e.Hn + (int64_t)row * e.ldhn + j0;
+            if (j0 + 3 < e.Cn && (e.ldhn & 3) == 0) *reinterpret_cast<float4 *>(dst) = make_float4(h[0], h[1], h[2], h[3]);
+            else for (int t = 0; t < 4 && j0 + t < e.Cn; ++t) dst[t] = h[t];
+        }
+    }
+}
+
+template <bool FUSE_NEXT>
+int launch_spmm_sj(const SjArgs &a, int F, hipStream_t st) {
+    const dim3 grid((a.n_waves + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVES_PER_BLOCK * AMAR_WAVE);
+    switch (F) {
+    case 4:  hipLaunchKernelGGL((spmm_sj_kernel<4, FUSE_NEXT>), grid, block, 0, st, a); break;
+    case 8:  hipLaunchKernelGGL((spmm_sj_kernel<8, FUSE_NEXT>), grid, block, 0, st, a); break;
+    case 16: hipLaunchKernelGGL((spmm_sj_kernel<16, FUSE_NEXT>), grid, block, 0, st, a); break;
+    case 32: hipLaunchKernelGGL((spmm_sj_kernel<32, FUSE_NEXT>), grid, block, 0, st, a); break;
+    case 64: hipLaunchKernelGGL((spmm_sj_kernel<64, FUSE_NEXT>), grid, block, 0, st, a); break;
+    default: return AMAR_EUNSUPPORTED;
+    }
+    return amar_check_launch();
+}
+
 bool ld_ok(int64_t ld, int F) { return ld >= F && (ld & 3) == 0; }
 
 // ---- row-wise X.W prologue -------------------------------------------------------------------
@@ -462,6 +577,36 @@ int amar_gat_layer_f32(const int32_t *rowptr, const int32_t *colidx,
     default: return AMAR_EUNSUPPORTED;
     }
     return amar_check_launch();
+}
+
+int amar_spmm_sj_f32(const int32_t *entries, const int16_t *counts, const int32_t *wave_start, int32_t n_slices,
+                     const float *X, int64_t ldx, float *Y, int64_t ldy,
+                     int32_t n_rows, int32_t F, uint32_t flags, const float *bias,
+                     const float *acc_in, int64_t ld_acc_in, float *acc_out, int64_t ld_acc_out, float acc_div,
+                     const float *Wnext, int32_t Cn, float *Hnext, int64_t ldhn, amar_stream_t stream) {
+    if (n_rows < 0 || n_slices < 1 || !counts || !wave_start || !X) return AMAR_EINVAL;
+    if (n_rows == 0) return AMAR_OK;
+    if (!entries) return AMAR_EINVAL;
+    const bool accum = flags & AMAR_SPMM_ACCUM;
+    if (!Y && !accum) return AMAR_EINVAL;
+    if (!ld_ok(ldx, F) || !amar_aligned16(X)) return AMAR_EINVAL;
+    if (Y && (!ld_ok(ldy, F) || !amar_aligned16(Y))) return AMAR_EINVAL;
+    if ((flags & AMAR_SPMM_BIAS) && (!bias || !amar_aligned16(bias))) return AMAR_EINVAL;
+    if (accum && (!acc_in || !acc_out || !ld_ok(ld_acc_in, F) || !ld_ok(ld_acc_out, F) ||
+                  !amar_aligned16(acc_in) || !amar_aligned16(acc_out))) return AMAR_EINVAL;
+    if ((flags & AMAR_SPMM_ACCUM_DIV) && !(acc_div != 0.f)) return AMAR_EINVAL;
+    if (Wnext && (!Hnext || Cn < 1 || ldhn < Cn)) return AMAR_EINVAL;
+    if (Wnext && Cn > 64) return AMAR_EUNSUPPORTED;
+    SjArgs a{};
+    a.entries = reinterpret_cast<const int2 *>(entries); a.counts = counts; a.wave_start = wave_start;
+    a.n_slices = n_slices; a.n_waves = (n_rows + AMAR_WAVE - 1) / AMAR_WAVE;
+    a.e.X = X; a.e.ldx = ldx; a.e.Y = Y; a.e.ldy = ldy;
+    a.e.bias = (flags & AMAR_SPMM_BIAS) ? bias : nullptr; a.e.relu = (flags & AMAR_SPMM_RELU) ? 1 : 0;
+    a.e.acc_in = acc_in; a.e.ld_acc_in = ld_acc_in; a.e.acc_out = acc_out; a.e.ld_acc_out = ld_acc_out;
+    a.e.acc_div = acc_div; a.e.accum = accum ? 1 : 0; a.e.accum_div = (flags & AMAR_SPMM_ACCUM_DIV) ? 1 : 0;
+    a.e.Wn = Wnext; a.e.Cn = Cn; a.e.Hn = Hnext; a.e.ldhn = ldhn; a.e.n_rows = n_rows;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return Wnext ? launch_spmm_sj<true>(a, F, st) : launch_spmm_sj<false>(a, F, st);
 }
 
 }  // extern "C"

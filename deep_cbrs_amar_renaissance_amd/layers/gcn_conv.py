@@ -10,7 +10,7 @@ import torch
 
 from deep_cbrs_amar_renaissance_amd import capi
 from deep_cbrs_amar_renaissance_amd.engine import Layer
-from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter
+from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter, spmm_kind
 
 
 class GCNConv(Layer):
@@ -35,7 +35,10 @@ class GCNConv(Layer):
         capi.rowwise_xw(x, self.kernel, h)
         if out is None:
             out = torch.empty((n, self.channels), dtype=torch.float32, device=x.device)
-        capi.gcn_layer(a.rowptr, a.colidx, a.vals, h, self.bias, out)
+        if spmm_kind(a, self.channels) == 'sj':
+            capi.spmm_sj(a.sliced(self.channels), h, out, bias=self.bias, relu=True)
+        else:
+            capi.gcn_layer(a.rowptr, a.colidx, a.vals, h, self.bias, out)
         return out
 
     @staticmethod

@@ -9,7 +9,7 @@ import torch
 
 from deep_cbrs_amar_renaissance_amd import capi
 from deep_cbrs_amar_renaissance_amd.engine import Layer
-from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter
+from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter, spmm_kind
 
 
 class LightGCNConv(Layer):
@@ -25,7 +25,10 @@ class LightGCNConv(Layer):
         x, a = inputs
         if out is None and acc_out is None:
             out = torch.empty((a.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
-        capi.spmm_csr(a.rowptr, a.colidx, a.vals, x, out, acc_in=acc_in, acc_out=acc_out, acc_div=acc_div)
+        if spmm_kind(a, x.shape[1]) == 'sj':
+            capi.spmm_sj(a.sliced(x.shape[1]), x, out, acc_in=acc_in, acc_out=acc_out, acc_div=acc_div)
+        else:
+            capi.spmm_csr(a.rowptr, a.colidx, a.vals, x, out, acc_in=acc_in, acc_out=acc_out, acc_div=acc_div)
         return out
 
     @staticmethod

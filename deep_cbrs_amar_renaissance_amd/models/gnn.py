@@ -25,7 +25,7 @@ from deep_cbrs_amar_renaissance_amd.layers.gcn_conv import GCNConv
 from deep_cbrs_amar_renaissance_amd.layers.graphsage_conv import GraphSageConv
 from deep_cbrs_amar_renaissance_amd.layers.lightgcn_conv import LightGCNConv
 from deep_cbrs_amar_renaissance_amd.layers.reduction import ReductionLayer
-from deep_cbrs_amar_renaissance_amd.utilities.math import convert_to_tensor
+from deep_cbrs_amar_renaissance_amd.utilities.math import convert_to_tensor, spmm_kind
 
 
 class SequentialGNN(Model):
@@ -103,8 +103,12 @@ class SequentialGNN(Model):
                 last = k == len(layers) - 1
                 acc_out = torch.empty((n, widths[0]), dtype=torch.float32, device=dev)
                 nxt = None if last else torch.empty((n, widths[0]), dtype=torch.float32, device=dev)
-                capi.spmm_csr(a.rowptr, a.colidx, a.vals, x, nxt, acc_in=acc, acc_out=acc_out,
-                              acc_div=len(layers) + 1 if last else None)
+                if spmm_kind(a, widths[0]) == 'sj':
+                    capi.spmm_sj(a.sliced(widths[0]), x, nxt, acc_in=acc, acc_out=acc_out,
+                                 acc_div=len(layers) + 1 if last else None)
+                else:
+                    capi.spmm_csr(a.rowptr, a.colidx, a.vals, x, nxt, acc_in=acc, acc_out=acc_out,
+                                  acc_div=len(layers) + 1 if last else None)
                 x, acc = nxt, acc_out
             return acc
 
@@ -118,8 +122,12 @@ class SequentialGNN(Model):
             for k, layer in enumerate(layers):
                 nxt = layers[k + 1] if k + 1 < len(layers) else None
                 h_next = torch.empty((n, widths[k + 2]), dtype=torch.float32, device=dev) if nxt is not None else None
-                capi.gcn_layer(a.rowptr, a.colidx, a.vals, h, layer.bias, slices[k + 1],
-                               Wnext=nxt.kernel if nxt is not None else None, Hnext=h_next)
+                if spmm_kind(a, widths[k + 1]) == 'sj':
+                    capi.spmm_sj(a.sliced(widths[k + 1]), h, slices[k + 1], bias=layer.bias, relu=True,
+                                 Wnext=nxt.kernel if nxt is not None else None, Hnext=h_next)
+                else:
+                    capi.gcn_layer(a.rowptr, a.colidx, a.vals, h, layer.bias, slices[k + 1],
+                                   Wnext=nxt.kernel if nxt is not None else None, Hnext=h_next)
                 h = h_next
         else:
             capi.copy_columns(x, slices[0])

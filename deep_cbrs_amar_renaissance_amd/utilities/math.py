@@ -137,3 +137,85 @@ def gcn_filter_device(rows, cols, n_nodes):
     rowptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=dev)
     rowptr[1:] = torch.cumsum(torch.bincount(r, minlength=n_nodes), 0)
     return DeviceCSR(rowptr.to(torch.int32), c.to(torch.int32), vals, (n_nodes, n_nodes), gcn_filtered=True)
+
+
+class SlicedJagged:
+    """Sliced-jagged ("SJ") image of a CSR matrix for `amar_spmm_sj_f32` (see include/amar_hip.h).
+
+    Rows are taken 64 at a time (one wavefront, ONE LANE PER ROW); columns are cut into slices of
+    2^cbits columns (chosen so a slice of X, 2^cbits * F * 4 bytes, stays resident in the 4 MB
+    per-XCD L2).  For wave w and slice k the non-zeros are stored in jagged-diagonal order: first
+    the 1st non-zero of every row that has one in this slice (ascending lane), then the 2nd, ...
+    — so at step j the active lanes read consecutive 8-byte (col, val) entries and nothing is
+    padded.  Blocks follow each other in (wave, slice) order, so every wave sweeps the slices in
+    the same order (phase-major) and reads one contiguous range of `entries`.
+
+        entries    int32 [nnz, 2]   (global column, fp32 value bits), 8 bytes per non-zero as in CSR
+        counts     int16 [n_waves * n_slices * 64]   non-zeros of lane's row in (wave, slice)
+        wave_start int32 [n_waves + 1]               first entry of each wave
+    """
+
+    def __init__(self, entries, counts, wave_start, n_slices, cbits, shape):
+        self.entries, self.counts, self.wave_start = entries, counts, wave_start
+        self.n_slices, self.cbits, self.shape = n_slices, cbits, tuple(shape)
+
+    @classmethod
+    def from_csr(cls, a, cbits):
+        dev = a.rowptr.device
+        n_rows, n_cols = a.shape
+        nnz = a.nnz
+        n_waves = (n_rows + 63) // 64
+        n_slices = max(1, (n_cols + (1 << cbits) - 1) >> cbits)
+        deg = (a.rowptr[1:] - a.rowptr[:-1]).long()
+        if nnz and int(deg.max()) > 32767:
+            raise ValueError("rows longer than 32767 non-zeros are not supported by the SJ format")
+        rows = torch.repeat_interleave(torch.arange(n_rows, device=dev), deg)
+        cols = a.colidx.long()
+        sl = cols >> cbits
+        run = rows * n_slices + sl                                   # CSR order = (row, col) => runs are contiguous
+        counts_rs = torch.bincount(run, minlength=n_rows * n_slices)  # [row, slice]
+        run_start = torch.cumsum(counts_rs, 0) - counts_rs
+        j = torch.arange(nnz, device=dev) - run_start[run]           # rank inside the (row, slice) run
+        jmax = int(j.max()) + 1 if nnz else 1
+        key = (((rows >> 6) * n_slices + sl) * jmax + j) * 64 + (rows & 63)
+        order = torch.argsort(key)
+        vals = a.vals if a.vals is not None else torch.ones(nnz, dtype=torch.float32, device=dev)
+        entries = torch.stack([a.colidx[order], vals[order].view(torch.int32)], dim=1).contiguous()
+        pad_rows = n_waves * 64
+        c = torch.zeros((pad_rows, n_slices), dtype=torch.int64, device=dev)
+        c[:n_rows] = counts_rs.view(n_rows, n_slices)
+        counts = c.view(n_waves, 64, n_slices).permute(0, 2, 1).contiguous().view(-1).to(torch.int16)
+        per_wave = c.view(n_waves, -1).sum(1)
+        wave_start = torch.zeros(n_waves + 1, dtype=torch.int64, device=dev)
+        wave_start[1:] = torch.cumsum(per_wave, 0)
+        return cls(entries, counts, wave_start.to(torch.int32), n_slices, cbits, a.shape)
+
+
+def sj_column_bits(F, slice_bytes=2 << 20):
+    """log2(columns per slice) so that one slice of X ([2^cbits, F] fp32) is `slice_bytes`."""
+    cbits = 0
+    while (2 << cbits) * F * 4 <= slice_bytes:
+        cbits += 1
+    return cbits
+
+
+def spmm_kind(a, F):
+    """'sj' when the gathered node table ([n_cols, F] fp32) exceeds what stays resident in the 4 MB per-XCD L2,
+    else 'csr'.  AMAR_SPMM_KIND=csr|sj overrides (A/B timing)."""
+    import os
+    forced = os.environ.get('AMAR_SPMM_KIND')
+    if forced in ('csr', 'sj'):
+        return forced
+    return 'sj' if a.shape[1] * F * 4 > (3 << 20) else 'csr'
+
+
+def _csr_sliced(self, F):
+    """Cached SJ image for feature width F (built on first use; the graph is constant)."""
+    cache = self.__dict__.setdefault('_sj_cache', {})
+    cbits = sj_column_bits(F)
+    if cbits not in cache:
+        cache[cbits] = SlicedJagged.from_csr(self, cbits)
+    return cache[cbits]
+
+
+DeviceCSR.sliced = _csr_sliced

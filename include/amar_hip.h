@@ -60,6 +60,25 @@ int amar_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, const float 
                       const float *acc_in, int64_t ld_acc_in, float *acc_out, int64_t ld_acc_out,
                       float acc_div, amar_stream_t stream);
 
+/* The same product on the sliced-jagged (SJ) image of A, for graphs whose node table exceeds the
+ * per-XCD L2 (built by utilities/math.py:SlicedJagged.from_csr; any producer may build it):
+ *   rows are taken 64 at a time (wave w = rows [64w, 64w+64), lane = row & 63);
+ *   columns are cut into n_slices slices of 2^cbits columns (slice of col = col >> cbits);
+ *   for w = 0.., for slice = 0..n_slices-1, for j = 0,1,..: the j-th non-zero (ascending column) of
+ *   every row of w that has more than j non-zeros in that slice, in ascending lane order, is the
+ *   next entry:  entries[e] = (int32 global column, fp32 value bits)               8 bytes per non-zero
+ *   counts[(w * n_slices + slice) * 64 + lane] = non-zeros of that row in that slice (int16)
+ *   wave_start[w] = index of wave w's first entry; wave_start[n_waves] = nnz.
+ * flags / bias / acc_* as amar_spmm_csr_f32 (AMAR_SPMM_RELU with AMAR_SPMM_BIAS gives the GCN
+ * epilogue); Wnext != NULL additionally writes Hnext[i, 0:Cn] = Y[i, :] . Wnext (Cn <= 64) like
+ * amar_gcn_layer_f32.  Each row is summed in ascending column order by a single lane.
+ */
+int amar_spmm_sj_f32(const int32_t *entries, const int16_t *counts, const int32_t *wave_start, int32_t n_slices,
+                     const float *X, int64_t ldx, float *Y, int64_t ldy,
+                     int32_t n_rows, int32_t F, uint32_t flags, const float *bias,
+                     const float *acc_in, int64_t ld_acc_in, float *acc_out, int64_t ld_acc_out, float acc_div,
+                     const float *Wnext, int32_t Cn, float *Hnext, int64_t ldhn, amar_stream_t stream);
+
 /* One fused GCN layer (src/models/gnn.py:289-295 + gnn.py:78, Spektral GCNConv.call):
  *     Y[i, 0:C]      = ReLU( sum_j A_hat[i,j] . H[j, 0:C] + bias )      H = X_prev . W  (pre-multiplied)
  *     Hnext[i, 0:Cn] = Y[i, :] . Wnext[C, Cn]                            (only if Wnext != NULL)

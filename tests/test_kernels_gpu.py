@@ -307,3 +307,47 @@ def test_gather_copy(hip):
     dst = torch.zeros((31, 20), device=DEV)
     hip.copy_columns(_t(src)[5:], dst[:, 4:16], ids=_t(ids), base=5)
     assert np.array_equal(dst.cpu().numpy()[:, 4:16], src[ids])
+
+
+@pytest.mark.parametrize('F', [4, 8, 16, 32, 64])
+@pytest.mark.parametrize('n,cbits', [(1, 4), (67, 3), (1000, 6), (1000, 12), (4097, 9)])
+def test_spmm_sliced_jagged(hip, F, n, cbits):
+    """SJ image (lane-per-row, column slices) against the dense oracle product, all epilogues."""
+    from deep_cbrs_amar_renaissance_amd.utilities.math import SlicedJagged
+    m = _rand_csr(n, 9, seed=F + n + cbits)
+    a = _dev_csr(m)
+    sj = SlicedJagged.from_csr(a, cbits)
+    assert int(sj.wave_start[-1]) == a.nnz and sj.n_slices == max(1, (n + (1 << cbits) - 1) >> cbits)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((n, F)).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, F).astype(np.float32)
+    wn = rng.uniform(-0.5, 0.5, (F, 8)).astype(np.float32)
+    A = m.tocsr().astype(np.float64)
+    y = torch.full((n, F), float('nan'), device=DEV)
+    hip.spmm_sj(sj, _t(x), y)
+    assert rel_err(y.cpu().numpy(), A @ x.astype(np.float64)) < 2e-6
+    hn = torch.full((n, 8), float('nan'), device=DEV)
+    hip.spmm_sj(sj, _t(x), y, bias=_t(b), relu=True, Wnext=_t(wn), Hnext=hn)
+    want = np.maximum(A @ x.astype(np.float64) + b, 0)
+    assert rel_err(y.cpu().numpy(), want) < 2e-6 and rel_err(hn.cpu().numpy(), want @ wn.astype(np.float64)) < 3e-6
+    s1, e = torch.empty((n, F), device=DEV), torch.empty((n, F), device=DEV)
+    xd = _t(x)
+    hip.spmm_sj(sj, xd, y, acc_in=xd, acc_out=s1)
+    hip.spmm_sj(sj, y, None, acc_in=s1, acc_out=e, acc_div=3)
+    x1 = A @ x.astype(np.float64)
+    assert rel_err(e.cpu().numpy(), (x + x1 + A @ x1) / 3) < 3e-6
+
+
+def test_spmm_kinds_agree_on_models(hip, monkeypatch):
+    """The CSR and SJ forms of the propagation give the same node table (to rounding) for GCN and LightGCN."""
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    from tests import helpers
+    g = helpers.tiny_graph(n_users=90, n_items=70, n_ratings=2500, seed=6, n_props=40, n_links=120)
+    for name in ('BasicGCN', 'BasicLightGCN'):
+        model = getattr(basic, name)(g['adj'], embedding_dim=8, n_hiddens=[8, 16], n_layers=2, dense_units=[24, 24], clf_units=[48])
+        helpers.randomize_biases(model, seed=2)
+        monkeypatch.setenv('AMAR_SPMM_KIND', 'csr')
+        e_csr = model.gnn(None).cpu().numpy()
+        monkeypatch.setenv('AMAR_SPMM_KIND', 'sj')
+        e_sj = model.gnn(None).cpu().numpy()
+        assert rel_err(e_sj, e_csr.astype(np.float64)) < 2e-6

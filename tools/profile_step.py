@@ -62,8 +62,12 @@ def main():
             med, best = timeit(lambda: capi.gcn_layer(a.rowptr, a.colidx, a.vals, x, b, y, Wnext=w, Hnext=hn))
             print('  gcn  F={:2d}: {:8.3f} ms (best {:8.3f})  fused bias+relu+next XW -> {:7.1f} GB/s'.format(
                 F, med, best, alg / med / 1e6), flush=True)
-            med, best = timeit(lambda: capi.spmm_csr(a.rowptr, a.colidx, None, x, y))
-            print('  spmm F={:2d} value-free: {:8.3f} ms'.format(F, med), flush=True)
+            sj = a.sliced(F)
+            med, best = timeit(lambda: capi.spmm_sj(sj, x, y))
+            print('  SJ   F={:2d}: {:8.3f} ms (best {:8.3f})  {} slices -> {:7.1f} GB/s ({:4.1f}% of 8 TB/s)'.format(
+                F, med, best, sj.n_slices, alg / med / 1e6, 100 * alg / med / 1e6 / 8000), flush=True)
+            med, best = timeit(lambda: capi.spmm_sj(sj, x, y, bias=b, relu=True, Wnext=w, Hnext=hn))
+            print('  SJ gcn F={:2d}: {:8.3f} ms (best {:8.3f})  -> {:7.1f} GB/s'.format(F, med, best, alg / med / 1e6), flush=True)
         engine.set_seed(42)
         model = basic.BasicGCN(a, embedding_dim=8, n_hiddens=[8, 8], dense_units=[24, 24], clf_units=[48, 48])
         u = data['test'][:, 0].to(torch.int32).contiguous()

@@ -11,6 +11,7 @@ def main():
     scale = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     F = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+    kind = sys.argv[4] if len(sys.argv) > 4 else 'csr'
     from deep_cbrs_amar_renaissance_amd import capi
     from deep_cbrs_amar_renaissance_amd.data import synthetic
     from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter_device
@@ -22,8 +23,13 @@ def main():
     x = torch.randn((n, F), device=dev)
     y = torch.empty((n, F), device=dev)
     torch.cuda.synchronize()
+    sj = a.sliced(F) if kind == 'sj' else None
+    torch.cuda.synchronize()
     for _ in range(reps):
-        capi.spmm_csr(a.rowptr, a.colidx, a.vals, x, y)
+        if kind == 'sj':
+            capi.spmm_sj(sj, x, y)
+        else:
+            capi.spmm_csr(a.rowptr, a.colidx, a.vals, x, y)
     torch.cuda.synchronize()
     print('done', a.nnz)
 

@@ -35,3 +35,46 @@ __device__ __forceinline__ float4 f4_shfl(float4 v, int src) {
 __device__ __forceinline__ float f4_get(const float4 &v, int i) {
     return i == 0 ? v.x : (i == 1 ? v.y : (i == 2 ? v.z : v.w));
 }
+
+// ---- cross-lane reductions on the VALU (no LDS-pipe traffic) -----------------------------------------
+// DPP row rotations cover lane offsets 1..8 inside a 16-lane row; gfx950's v_permlane16_swap /
+// v_permlane32_swap cover offsets 16 and 32.  hipcc fuses `v + dpp(v)` into one v_add_f32_dpp.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float swap16_other(float v, float &own) {
+    auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    own = __builtin_bit_cast(float, r[0]);
+    return __builtin_bit_cast(float, r[1]);
+}
+__device__ __forceinline__ float swap32_other(float v, float &own) {
+    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    own = __builtin_bit_cast(float, r[0]);
+    return __builtin_bit_cast(float, r[1]);
+}
+// Sum over all lanes l' with l' % STRIDE == l % STRIDE; every lane receives the total. STRIDE in {1,2,4,8,16}.
+template <int STRIDE>
+__device__ __forceinline__ float wave_sum_stride(float v) {
+    if (STRIDE <= 8) v += dpp_mov<0x128>(v);          // row_ror:8
+    if (STRIDE <= 4) v += dpp_mov<0x124>(v);          // row_ror:4
+    if (STRIDE <= 2) v += dpp_mov<0x122>(v);          // row_ror:2
+    if (STRIDE <= 1) v += dpp_mov<0x121>(v);          // row_ror:1
+    float a, b;
+    b = swap16_other(v, a); v = a + b;                 // lane offset 16
+    b = swap32_other(v, a); v = a + b;                 // lane offset 32
+    return v;
+}
+__device__ __forceinline__ float wave_max_all(float v) {
+    v = fmaxf(v, dpp_mov<0x128>(v)); v = fmaxf(v, dpp_mov<0x124>(v));
+    v = fmaxf(v, dpp_mov<0x122>(v)); v = fmaxf(v, dpp_mov<0x121>(v));
+    float a, b;
+    b = swap16_other(v, a); v = fmaxf(a, b);
+    b = swap32_other(v, a); v = fmaxf(a, b);
+    return v;
+}
+template <int STRIDE>
+__device__ __forceinline__ float4 f4_wave_sum_stride(float4 v) {
+    return make_float4(wave_sum_stride<STRIDE>(v.x), wave_sum_stride<STRIDE>(v.y),
+                       wave_sum_stride<STRIDE>(v.z), wave_sum_stride<STRIDE>(v.w));
+}

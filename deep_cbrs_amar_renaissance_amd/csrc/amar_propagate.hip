@@ -41,18 +41,18 @@ __device__ __forceinline__ float4 row_gather_sum(const int32_t *__restrict__ col
         const float4 x0 = *reinterpret_cast<const float4 *>(X + (int64_t)c0 * ldx + 4 * q);
         acc = f4_fma(v0, x0, acc);
     }
-#pragma unroll
-    for (int off = AMAR_WAVE / 2; off >= LPN; off >>= 1) acc = f4_add(acc, f4_shfl_xor(acc, off));
-    return acc;
+    return f4_wave_sum_stride<LPN>(acc);
 }
 
 // All lanes receive the full reduced row y[0:F] (lane qq of slot 0 holds quad qq).
 template <int F>
 __device__ __forceinline__ void broadcast_row(const float4 yq, float (&full)[F]) {
 #pragma unroll
-    for (int qq = 0; qq < F / 4; ++qq) {
-        const float4 t = f4_shfl(yq, qq);
-        full[4 * qq + 0] = t.x; full[4 * qq + 1] = t.y; full[4 * qq + 2] = t.z; full[4 * qq + 3] = t.w;
+    for (int qq = 0; qq < F / 4; ++qq) {                  // v_readlane: the value becomes a scalar operand
+        full[4 * qq + 0] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yq.x), qq));
+        full[4 * qq + 1] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yq.y), qq));
+        full[4 * qq + 2] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yq.z), qq));
+        full[4 * qq + 3] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, yq.w), qq));
     }
 }
 
@@ -170,8 +170,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void spmm_stream_kerne
             }
             pos = hi;
         }
-#pragma unroll
-        for (int off = AMAR_WAVE / 2; off >= LPN; off >>= 1) acc = f4_add(acc, f4_shfl_xor(acc, off));
+        acc = f4_wave_sum_stride<LPN>(acc);
         spmm_epilogue<F, FUSE_NEXT>(a, r0 + k, acc, q, slot, lane, wn);
         row_beg = row_end;
     }
@@ -400,8 +399,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void sage_row_kernel(c
     for (int k = 0; k < F; ++k) o = fmaf(fa[k], wa[k], o);
     o = lane < a.C ? o + a.bias[lane] : 0.f;
     float ss = o * o;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    ss = wave_sum_stride<1>(ss);
     o *= rsqrtf(fmaxf(ss, 1e-12f));                    // tf.nn.l2_normalize(axis=-1), before the activation
     o = fmaxf(o, 0.f);
     if (lane < a.C) a.Y[(int64_t)row * a.ldy + lane] = o;
@@ -428,8 +426,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void gat_row_kernel(co
     // pass 1: LeakyReLU is monotone, so max_j e_ij = LeakyReLU(s_i + max_j n_j)
     float mn = a.self_loop ? a.s_neigh[row] : -INFINITY;
     for (int p = beg + lane; p < end; p += AMAR_WAVE) mn = fmaxf(mn, a.s_neigh[a.colidx[p]]);
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) mn = fmaxf(mn, __shfl_xor(mn, off, 64));
+    mn = wave_max_all(mn);
     const float emax = leaky02(si + mn);
 
     // pass 2: un-normalised softmax weights and the weighted sum of source rows
@@ -448,10 +445,8 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void gat_row_kernel(co
         acc = f4_fma(w, h, acc);
         if (q == 0) den += w;
     }
-#pragma unroll
-    for (int off = AMAR_WAVE / 2; off >= LPN; off >>= 1) acc = f4_add(acc, f4_shfl_xor(acc, off));
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) den += __shfl_xor(den, off, 64);
+    acc = f4_wave_sum_stride<LPN>(acc);
+    den = wave_sum_stride<1>(den);
     const float inv = 1.f / (den + 1e-9f);
     if (slot == 0) {
         const float4 b = *reinterpret_cast<const float4 *>(a.bias + 4 * q);

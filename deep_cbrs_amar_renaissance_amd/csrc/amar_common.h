@@ -43,13 +43,19 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
+// The instruction swaps rows between TWO registers; both operands start as v, so the copy must be a distinct
+// register (the empty asm keeps the compiler from merging them, which would swap a register with itself).
 __device__ __forceinline__ float swap16_other(float v, float &own) {
-    auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    float w = v;
+    asm volatile("" : "+v"(w));
+    auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, w), false, false);
     own = __builtin_bit_cast(float, r[0]);
     return __builtin_bit_cast(float, r[1]);
 }
 __device__ __forceinline__ float swap32_other(float v, float &own) {
-    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+    float w = v;
+    asm volatile("" : "+v"(w));
+    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, w), false, false);
     own = __builtin_bit_cast(float, r[0]);
     return __builtin_bit_cast(float, r[1]);
 }

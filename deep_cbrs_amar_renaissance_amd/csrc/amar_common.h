@@ -43,21 +43,21 @@ template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
 }
-// The instruction swaps rows between TWO registers; both operands start as v, so the copy must be a distinct
-// register (the empty asm keeps the compiler from merging them, which would swap a register with itself).
+// v_permlane16_swap / v_permlane32_swap exchange rows between TWO registers: with both holding v, one ends up with
+// the even rows (or low half) everywhere and the other with the odd rows (high half), i.e. `own` and the xor-16
+// (xor-32) partner's value.  ROCm 7.2's builtin loses the second result, so this is inline asm; hipcc adds no
+// wait states inside asm (cdna_hip_programming.md 5.7), hence the s_nop on both sides.
 __device__ __forceinline__ float swap16_other(float v, float &own) {
-    float w = v;
-    asm volatile("" : "+v"(w));
-    auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, w), false, false);
-    own = __builtin_bit_cast(float, r[0]);
-    return __builtin_bit_cast(float, r[1]);
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    own = a;
+    return b;
 }
 __device__ __forceinline__ float swap32_other(float v, float &own) {
-    float w = v;
-    asm volatile("" : "+v"(w));
-    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, w), false, false);
-    own = __builtin_bit_cast(float, r[0]);
-    return __builtin_bit_cast(float, r[1]);
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    own = a;
+    return b;
 }
 // Sum over all lanes l' with l' % STRIDE == l % STRIDE; every lane receives the total. STRIDE in {1,2,4,8,16}.
 template <int STRIDE>

@@ -23,6 +23,8 @@ def main():
     x = torch.randn((n, F), device=dev)
     y = torch.empty((n, F), device=dev)
     torch.cuda.synchronize()
+    if kind == 'zero':
+        a.colidx.zero_()
     sj = a.sliced(F) if kind == 'sj' else None
     torch.cuda.synchronize()
     for _ in range(reps):

@@ -107,7 +107,7 @@ def main():
     runner = parallel.make_runner(model, u_all, i_all, rank, world)
 
     spmm_events = []
-    raw_gcn_layer, raw_spmm_sj = capi.gcn_layer, capi.spmm_sj
+    raw_gcn_layer, raw_spmm_sj, raw_spmm_xs = capi.gcn_layer, capi.spmm_sj, capi.spmm_xs
 
     def timed(fn):
         def wrapper(*a, **k):
@@ -117,7 +117,7 @@ def main():
             e1.record()
             spmm_events.append((e0, e1))
         return wrapper
-    capi.gcn_layer, capi.spmm_sj = timed(raw_gcn_layer), timed(raw_spmm_sj)   # whichever form the layer dispatches to
+    capi.gcn_layer, capi.spmm_sj, capi.spmm_xs = timed(raw_gcn_layer), timed(raw_spmm_sj), timed(raw_spmm_xs)   # whichever form the layer dispatches to
 
     def barrier():
         if world > 1:
@@ -133,7 +133,7 @@ def main():
         runner.step()
     barrier()
     dt = time.perf_counter() - t0
-    capi.gcn_layer, capi.spmm_sj = raw_gcn_layer, raw_spmm_sj
+    capi.gcn_layer, capi.spmm_sj, capi.spmm_xs = raw_gcn_layer, raw_spmm_sj, raw_spmm_xs
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -169,7 +169,7 @@ def main():
                                    'econfigs/basic-gnn.yaml grid1 BasicGCN d=8 L=2 concat, dense [24,24], clf [48,48]; '
                                    'one propagation + per-entity towers + all pairs (shuffled order) per step (hoisted)'.format(args.scale, n_nodes, nnz, n_pairs),
                        'scale': args.scale, 'parallelism': runner.describe()},
-            'roofline': {'bound': 'hbm', 'kernel': ('spmm_sj_kernel<8>' if kind == 'sj' else 'spmm_stream_kernel<8>') + ' (fused GCN layer: SpMM + bias + ReLU + next X.W)', 'achieved': achieved,
+            'roofline': {'bound': 'hbm', 'kernel': {'sj': 'spmm_sj_kernel<8>', 'xs': 'spmm_xs_partial_kernel<8> + spmm_xs_combine_kernel<8>', 'csr': 'spmm_stream_kernel<8>'}[kind] + ' (fused GCN layer: SpMM + bias + ReLU + next X.W)', 'achieved': achieved,
                          'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': avg_ms,
                          'launches_timed': len(spmm_ms)},

@@ -29,6 +29,8 @@ SIGNATURES = {
                                          _P, _I64, _P, _I64, _F32, _P]),
     'amar_spmm_sj_f32': (ctypes.c_int, [_P, _P, _P, _I32, _P, _I64, _P, _I64, _I32, _I32, _U32, _P,
                                         _P, _I64, _P, _I64, _F32, _P, _I32, _P, _I64, _P]),
+    'amar_spmm_xs_f32': (ctypes.c_int, [_P, _P, _P, _P, _I32, _P, _I64, _P, _P, _I64, _I32, _I32, _U32, _P,
+                                        _P, _I64, _P, _I64, _F32, _P, _I32, _P, _I64, _P]),
     'amar_gcn_layer_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _I64, _P, _I32, _P, _I64, _I32, _P]),
     'amar_rowwise_xw_f32': (ctypes.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _P, _I64, _P, _P, _P, _P, _I32, _P]),
     'amar_sage_layer_f32': (ctypes.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _I32, _P, _I64, _I32, _I32, _P]),
@@ -149,6 +151,40 @@ def spmm_sj(sj, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc
         _ptr(Wnext, torch.float32, 'Wnext'), Cn, _ptr(Hnext, torch.float32, 'Hnext'),
         _ld(Hnext, 'Hnext') if Hnext is not None else 0, _stream())
     _check(code, 'amar_spmm_sj_f32')
+
+
+def spmm_xs(xs, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc_div=None, Wnext=None, Hnext=None):
+    """Y = A.X on the XCD-sliced image `xs` of A (utilities.math.XcdSliced): per-slice partial products with
+    XCD <-> L2 affinity, then the combine kernel with the epilogues of spmm_csr / gcn_layer."""
+    n_rows = xs.shape[0]
+    F = X.shape[1]
+    flags = (SPMM_BIAS if bias is not None else 0) | (SPMM_RELU if relu else 0)
+    if acc_out is not None:
+        flags |= SPMM_ACCUM | (SPMM_ACCUM_DIV if acc_div is not None else 0)
+        if acc_in is None or tuple(acc_in.shape) != (n_rows, F) or tuple(acc_out.shape) != (n_rows, F):
+            raise ValueError("acc_in/acc_out must be [n_rows, F]")
+    if Y is not None and tuple(Y.shape) != (n_rows, F):
+        raise ValueError("Y must be [n_rows, F]")
+    if X.shape[0] != n_rows:
+        raise ValueError("X must have one row per node")
+    Cn = 0
+    if Wnext is not None:
+        if Wnext.shape[0] != F or not Wnext.is_contiguous() or Hnext is None or tuple(Hnext.shape) != (n_rows, Wnext.shape[1]):
+            raise ValueError("spmm_xs: Wnext [F, Cn] contiguous and Hnext [n_rows, Cn] expected")
+        Cn = Wnext.shape[1]
+    P = xs.partials(F)
+    code = load().amar_spmm_xs_f32(
+        _ptr(xs.diag, torch.float32, 'diag'), _ptr(xs.rowptr, torch.int32, 'rowptr'), _ptr(xs.colidx, torch.int32, 'colidx'),
+        _ptr(xs.vals, torch.float32, 'vals'), xs.n_slices,
+        _ptr(X, torch.float32, 'X'), _ld(X, 'X'), _ptr(P, torch.float32, 'partials'),
+        _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y') if Y is not None else 0,
+        n_rows, F, flags, _ptr(bias, torch.float32, 'bias'),
+        _ptr(acc_in, torch.float32, 'acc_in'), _ld(acc_in, 'acc_in') if acc_in is not None else 0,
+        _ptr(acc_out, torch.float32, 'acc_out'), _ld(acc_out, 'acc_out') if acc_out is not None else 0,
+        float(acc_div) if acc_div is not None else 1.0,
+        _ptr(Wnext, torch.float32, 'Wnext'), Cn, _ptr(Hnext, torch.float32, 'Hnext'),
+        _ld(Hnext, 'Hnext') if Hnext is not None else 0, _stream())
+    _check(code, 'amar_spmm_xs_f32')
 
 
 def gcn_layer(rowptr, colidx, vals, H, bias, Y, Wnext=None, Hnext=None):

@@ -212,6 +212,46 @@ int launch_spmm(const SpmmArgs &a, int F, hipStream_t st) {
     return amar_check_launch();
 }
 
+// Epilogue for kernels where ONE LANE holds a whole reduced row (acc[q] = features 4q..4q+3):
+// bias, ReLU, store into the concat slice, running layer sum, and the next layer's X.W with
+// wave-uniform (scalar) reads of Wnext.
+template <int F, bool FUSE_NEXT>
+__device__ __forceinline__ void lane_row_epilogue(const SpmmArgs &e, int row, float4 (&acc)[F / 4]) {
+    constexpr int LPN = F / 4;
+#pragma unroll
+    for (int q = 0; q < LPN; ++q) {
+        float4 y = acc[q];
+        if (e.bias) y = f4_add(y, *reinterpret_cast<const float4 *>(e.bias + 4 * q));
+        if (e.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+        acc[q] = y;
+        if (e.Y) *reinterpret_cast<float4 *>(e.Y + (int64_t)row * e.ldy + 4 * q) = y;
+        if (e.accum) {
+            float4 s = *reinterpret_cast<const float4 *>(e.acc_in + (int64_t)row * e.ld_acc_in + 4 * q);
+            s = f4_add(s, y);
+            if (e.accum_div) { s.x /= e.acc_div; s.y /= e.acc_div; s.z /= e.acc_div; s.w /= e.acc_div; }
+            *reinterpret_cast<float4 *>(e.acc_out + (int64_t)row * e.ld_acc_out + 4 * q) = s;
+        }
+    }
+    if (FUSE_NEXT) {
+        for (int j0 = 0; j0 < e.Cn; j0 += 4) {
+            float h[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < LPN; ++q)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float yk = f4_get(acc[q], c);
+                    const float *w = e.Wn + (int64_t)(4 * q + c) * e.Cn + j0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        if (j0 + t < e.Cn) h[t] = fmaf(yk, w[t], h[t]);
+                }
+            float *dst = e.Hn + (int64_t)row * e.ldhn + j0;
+            if (j0 + 3 < e.Cn && (e.ldhn & 3) == 0) *reinterpret_cast<float4 *>(dst) = make_float4(h[0], h[1], h[2], h[3]);
+            else for (int t = 0; t < 4 && j0 + t < e.Cn; ++t) dst[t] = h[t];
+        }
+    }
+}
+
 // ---- v3: sliced-jagged (SJ) SpMM ----------------------------------------------------------------
 // Why: on ml1m(s=64) the row-gather kernels above move 4.3 GB through the fabric per launch for
 // 0.49 GB of algorithmic bytes (rocprofv3: every L2 miss is a 128-B line fill for a 32-B gather,
@@ -276,41 +316,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void spmm_sj_kernel(co
         }
     }
     if (row >= e.n_rows) return;
-
-    // epilogue: the lane holds its whole row
-#pragma unroll
-    for (int q = 0; q < LPN; ++q) {
-        float4 y = acc[q];
-        if (e.bias) y = f4_add(y, *reinterpret_cast<const float4 *>(e.bias + 4 * q));
-        if (e.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
-        acc[q] = y;
-        if (e.Y) *reinterpret_cast<float4 *>(e.Y + (int64_t)row * e.ldy + 4 * q) = y;
-        if (e.accum) {
-            float4 s = *reinterpret_cast<const float4 *>(e.acc_in + (int64_t)row * e.ld_acc_in + 4 * q);
-            s = f4_add(s, y);
-            if (e.accum_div) { s.x /= e.acc_div; s.y /= e.acc_div; s.z /= e.acc_div; s.w /= e.acc_div; }
-            *reinterpret_cast<float4 *>(e.acc_out + (int64_t)row * e.ld_acc_out + 4 * q) = s;
-        }
-    }
-    if (FUSE_NEXT) {
-        // Hnext[row, :] = y . Wnext: Wnext is read with wave-uniform addresses (scalar loads)
-        for (int j0 = 0; j0 < e.Cn; j0 += 4) {
-            float h[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < LPN; ++q)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float yk = f4_get(acc[q], c);
-                    const float *w = e.Wn + (int64_t)(4 * q + c) * e.Cn + j0;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        if (j0 + t < e.Cn) h[t] = fmaf(yk, w[t], h[t]);
-                }
-            float *dst = e.Hn + (int64_t)row * e.ldhn + j0;
-            if (j0 + 3 < e.Cn && (e.ldhn & 3) == 0) *reinterpret_cast<float4 *>(dst) = make_float4(h[0], h[1], h[2], h[3]);
-            else for (int t = 0; t < 4 && j0 + t < e.Cn; ++t) dst[t] = h[t];
-        }
-    }
+    lane_row_epilogue<F, FUSE_NEXT>(e, row, acc);
 }
 
 template <bool FUSE_NEXT>
@@ -324,6 +330,91 @@ int launch_spmm_sj(const SjArgs &a, int F, hipStream_t st) {
     case 64: hipLaunchKernelGGL((spmm_sj_kernel<64, FUSE_NEXT>), grid, block, 0, st, a); break;
     default: return AMAR_EUNSUPPORTED;
     }
+    return amar_check_launch();
+}
+
+// ---- v4: XCD-sliced (XS) SpMM = per-slice partial products + combine ------------------------------
+// Format and rationale: utilities/math.py:XcdSliced, include/amar_hip.h.  Workgroup b works on column
+// slice b % S only, so (with the round-robin dispatch of workgroups over the 8 XCDs) each XCD's L2
+// holds one slice of X and nothing else of it.  A (row, slice) segment is short (a row's non-zeros
+// spread over the slices), so rows are handled by GROUPS of 8 lanes (16 for F = 64): 64/GROUP rows per
+// pass, GROUP/(F/4) gather slots per row, a DPP reduction over the group's slots only.  The partial
+// row goes to P[slice][row]; a second kernel adds diag . X and the S partials in slice order (a fixed
+// order: results are bitwise reproducible) and applies the fused layer epilogue.
+struct XsArgs {
+    const int32_t *rowptr; const int32_t *colidx; const float *vals;     // XS image
+    const float *X; int64_t ldx; float *P; int n_rows; int n_slices; int blocks_per_slice;
+};
+
+template <int F>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void spmm_xs_partial_kernel(const XsArgs a) {
+    constexpr int LPN = F / 4;
+    constexpr int GROUP = LPN > 8 ? LPN : 8, SPG = GROUP / LPN, RPP = AMAR_WAVE / GROUP, PASSES = AMAR_WAVE / RPP;
+    const int lane = threadIdx.x & (AMAR_WAVE - 1);
+    const int k = blockIdx.x % a.n_slices;                           // slice <-> XCD affinity
+    const int chunk = blockIdx.x / a.n_slices;
+    const int r0 = __builtin_amdgcn_readfirstlane((chunk * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * AMAR_WAVE);
+    if (r0 >= a.n_rows) return;
+    const int nr = min(AMAR_WAVE, a.n_rows - r0);
+    const int32_t *rp = a.rowptr + (int64_t)k * a.n_rows + r0;
+    const int beg_l = rp[min(lane, nr)], end_l = rp[min(lane + 1, nr)];  // this lane's row of the wave
+    const int g = lane / GROUP, s = (lane % GROUP) / LPN, q = lane % LPN;
+    float *Pk = a.P + ((int64_t)k * a.n_rows + r0) * F;
+    for (int pass = 0; pass < PASSES; ++pass) {
+        const int rl = pass * RPP + g;                               // row of this lane's group within the wave
+        const int beg = __shfl(beg_l, rl, 64), end = __shfl(end_l, rl, 64);
+        float4 acc = f4_zero();
+        for (int i = beg + s; __any(i < end); i += 2 * SPG) {
+            const int i1 = i + SPG;
+            int c0 = 0, c1 = 0;
+            float v0 = 0.f, v1 = 0.f;
+            if (i < end) { c0 = a.colidx[i]; v0 = a.vals[i]; }
+            if (i1 < end) { c1 = a.colidx[i1]; v1 = a.vals[i1]; }
+            float4 x0 = f4_zero(), x1 = f4_zero();
+            if (i < end) x0 = *reinterpret_cast<const float4 *>(a.X + (int64_t)c0 * a.ldx + 4 * q);
+            if (i1 < end) x1 = *reinterpret_cast<const float4 *>(a.X + (int64_t)c1 * a.ldx + 4 * q);
+            acc = f4_fma(v0, x0, acc);
+            acc = f4_fma(v1, x1, acc);
+        }
+        // sum over the group's slots with DPP row_shl (lane i reads lane i + n; 0x100 + n): only the group's
+        // first LPN lanes need the total, lanes that read across a group boundary hold values nobody uses
+        if (SPG >= 8) { acc.x += dpp_mov<0x104>(acc.x); acc.y += dpp_mov<0x104>(acc.y); acc.z += dpp_mov<0x104>(acc.z); acc.w += dpp_mov<0x104>(acc.w); }
+        if (SPG >= 4) { constexpr int C = LPN == 1 ? 0x102 : 0x104; acc.x += dpp_mov<C>(acc.x); acc.y += dpp_mov<C>(acc.y); acc.z += dpp_mov<C>(acc.z); acc.w += dpp_mov<C>(acc.w); }
+        if (SPG >= 2) { constexpr int C = LPN == 1 ? 0x101 : (LPN == 2 ? 0x102 : 0x104); acc.x += dpp_mov<C>(acc.x); acc.y += dpp_mov<C>(acc.y); acc.z += dpp_mov<C>(acc.z); acc.w += dpp_mov<C>(acc.w); }
+        if (s == 0 && rl < nr) *reinterpret_cast<float4 *>(Pk + (int64_t)rl * F + 4 * q) = acc;
+    }
+}
+
+struct XsCombineArgs { const float *diag; const float *P; int n_slices; SpmmArgs e; };
+
+template <int F, bool FUSE_NEXT>
+__global__ __launch_bounds__(256) void spmm_xs_combine_kernel(const XsCombineArgs a) {
+    constexpr int LPN = F / 4;
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    const SpmmArgs &e = a.e;
+    if (row >= e.n_rows) return;
+    float4 acc[LPN];
+    const float d = a.diag[row];
+#pragma unroll
+    for (int q = 0; q < LPN; ++q) {
+        const float4 x = *reinterpret_cast<const float4 *>(e.X + (int64_t)row * e.ldx + 4 * q);
+        acc[q] = make_float4(d * x.x, d * x.y, d * x.z, d * x.w);
+    }
+    for (int k = 0; k < a.n_slices; ++k) {
+        const float *p = a.P + ((int64_t)k * e.n_rows + row) * F;
+#pragma unroll
+        for (int q = 0; q < LPN; ++q) acc[q] = f4_add(acc[q], *reinterpret_cast<const float4 *>(p + 4 * q));
+    }
+    lane_row_epilogue<F, FUSE_NEXT>(e, row, acc);
+}
+
+template <int F>
+int launch_spmm_xs(const XsArgs &pa, const XsCombineArgs &ca, bool fuse, hipStream_t st) {
+    const dim3 block(WAVES_PER_BLOCK * AMAR_WAVE);
+    hipLaunchKernelGGL((spmm_xs_partial_kernel<F>), dim3((unsigned)(pa.blocks_per_slice * pa.n_slices)), block, 0, st, pa);
+    const dim3 cgrid((ca.e.n_rows + 255) / 256);
+    if (fuse) hipLaunchKernelGGL((spmm_xs_combine_kernel<F, true>), cgrid, dim3(256), 0, st, ca);
+    else hipLaunchKernelGGL((spmm_xs_combine_kernel<F, false>), cgrid, dim3(256), 0, st, ca);
     return amar_check_launch();
 }
 
@@ -602,6 +693,44 @@ int amar_spmm_sj_f32(const int32_t *entries, const int16_t *counts, const int32_
     a.e.Wn = Wnext; a.e.Cn = Cn; a.e.Hn = Hnext; a.e.ldhn = ldhn; a.e.n_rows = n_rows;
     hipStream_t st = static_cast<hipStream_t>(stream);
     return Wnext ? launch_spmm_sj<true>(a, F, st) : launch_spmm_sj<false>(a, F, st);
+}
+
+int amar_spmm_xs_f32(const float *diag, const int32_t *rowptr, const int32_t *colidx, const float *vals, int32_t n_slices,
+                     const float *X, int64_t ldx, float *partials, float *Y, int64_t ldy,
+                     int32_t n_rows, int32_t F, uint32_t flags, const float *bias,
+                     const float *acc_in, int64_t ld_acc_in, float *acc_out, int64_t ld_acc_out, float acc_div,
+                     const float *Wnext, int32_t Cn, float *Hnext, int64_t ldhn, amar_stream_t stream) {
+    if (n_rows < 0 || n_slices < 1 || !diag || !rowptr || !X || !partials) return AMAR_EINVAL;
+    if (n_rows == 0) return AMAR_OK;
+    if (!colidx || !vals) return AMAR_EINVAL;
+    const bool accum = flags & AMAR_SPMM_ACCUM;
+    if (!Y && !accum) return AMAR_EINVAL;
+    if (!ld_ok(ldx, F) || !amar_aligned16(X) || !amar_aligned16(partials)) return AMAR_EINVAL;
+    if (Y && (!ld_ok(ldy, F) || !amar_aligned16(Y))) return AMAR_EINVAL;
+    if ((flags & AMAR_SPMM_BIAS) && (!bias || !amar_aligned16(bias))) return AMAR_EINVAL;
+    if (accum && (!acc_in || !acc_out || !ld_ok(ld_acc_in, F) || !ld_ok(ld_acc_out, F) ||
+                  !amar_aligned16(acc_in) || !amar_aligned16(acc_out))) return AMAR_EINVAL;
+    if ((flags & AMAR_SPMM_ACCUM_DIV) && !(acc_div != 0.f)) return AMAR_EINVAL;
+    if (Wnext && (!Hnext || Cn < 1 || ldhn < Cn)) return AMAR_EINVAL;
+    if (Wnext && Cn > 64) return AMAR_EUNSUPPORTED;
+    XsArgs pa{rowptr, colidx, vals, X, ldx, partials, n_rows, n_slices,
+              (n_rows + WAVES_PER_BLOCK * AMAR_WAVE - 1) / (WAVES_PER_BLOCK * AMAR_WAVE)};
+    XsCombineArgs ca{};
+    ca.diag = diag; ca.P = partials; ca.n_slices = n_slices;
+    ca.e.X = X; ca.e.ldx = ldx; ca.e.Y = Y; ca.e.ldy = ldy;
+    ca.e.bias = (flags & AMAR_SPMM_BIAS) ? bias : nullptr; ca.e.relu = (flags & AMAR_SPMM_RELU) ? 1 : 0;
+    ca.e.acc_in = acc_in; ca.e.ld_acc_in = ld_acc_in; ca.e.acc_out = acc_out; ca.e.ld_acc_out = ld_acc_out;
+    ca.e.acc_div = acc_div; ca.e.accum = accum ? 1 : 0; ca.e.accum_div = (flags & AMAR_SPMM_ACCUM_DIV) ? 1 : 0;
+    ca.e.Wn = Wnext; ca.e.Cn = Cn; ca.e.Hn = Hnext; ca.e.ldhn = ldhn; ca.e.n_rows = n_rows;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (F) {
+    case 4:  return launch_spmm_xs<4>(pa, ca, Wnext != nullptr, st);
+    case 8:  return launch_spmm_xs<8>(pa, ca, Wnext != nullptr, st);
+    case 16: return launch_spmm_xs<16>(pa, ca, Wnext != nullptr, st);
+    case 32: return launch_spmm_xs<32>(pa, ca, Wnext != nullptr, st);
+    case 64: return launch_spmm_xs<64>(pa, ca, Wnext != nullptr, st);
+    default: return AMAR_EUNSUPPORTED;
+    }
 }
 
 }  // extern "C"

@@ -35,7 +35,10 @@ class GCNConv(Layer):
         capi.rowwise_xw(x, self.kernel, h)
         if out is None:
             out = torch.empty((n, self.channels), dtype=torch.float32, device=x.device)
-        if spmm_kind(a, self.channels) == 'sj':
+        kind = spmm_kind(a, self.channels)
+        if kind == 'xs':
+            capi.spmm_xs(a.xcd_sliced(), h, out, bias=self.bias, relu=True)
+        elif kind == 'sj':
             capi.spmm_sj(a.sliced(self.channels), h, out, bias=self.bias, relu=True)
         else:
             capi.gcn_layer(a.rowptr, a.colidx, a.vals, h, self.bias, out)

@@ -25,7 +25,10 @@ class LightGCNConv(Layer):
         x, a = inputs
         if out is None and acc_out is None:
             out = torch.empty((a.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
-        if spmm_kind(a, x.shape[1]) == 'sj':
+        kind = spmm_kind(a, x.shape[1])
+        if kind == 'xs':
+            capi.spmm_xs(a.xcd_sliced(), x, out, acc_in=acc_in, acc_out=acc_out, acc_div=acc_div)
+        elif kind == 'sj':
             capi.spmm_sj(a.sliced(x.shape[1]), x, out, acc_in=acc_in, acc_out=acc_out, acc_div=acc_div)
         else:
             capi.spmm_csr(a.rowptr, a.colidx, a.vals, x, out, acc_in=acc_in, acc_out=acc_out, acc_div=acc_div)

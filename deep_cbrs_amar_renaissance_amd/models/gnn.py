@@ -103,7 +103,11 @@ class SequentialGNN(Model):
                 last = k == len(layers) - 1
                 acc_out = torch.empty((n, widths[0]), dtype=torch.float32, device=dev)
                 nxt = None if last else torch.empty((n, widths[0]), dtype=torch.float32, device=dev)
-                if spmm_kind(a, widths[0]) == 'sj':
+                kind = spmm_kind(a, widths[0])
+                if kind == 'xs':
+                    capi.spmm_xs(a.xcd_sliced(), x, nxt, acc_in=acc, acc_out=acc_out,
+                                 acc_div=len(layers) + 1 if last else None)
+                elif kind == 'sj':
                     capi.spmm_sj(a.sliced(widths[0]), x, nxt, acc_in=acc, acc_out=acc_out,
                                  acc_div=len(layers) + 1 if last else None)
                 else:
@@ -122,7 +126,11 @@ class SequentialGNN(Model):
             for k, layer in enumerate(layers):
                 nxt = layers[k + 1] if k + 1 < len(layers) else None
                 h_next = torch.empty((n, widths[k + 2]), dtype=torch.float32, device=dev) if nxt is not None else None
-                if spmm_kind(a, widths[k + 1]) == 'sj':
+                kind = spmm_kind(a, widths[k + 1])
+                if kind == 'xs':
+                    capi.spmm_xs(a.xcd_sliced(), h, slices[k + 1], bias=layer.bias, relu=True,
+                                 Wnext=nxt.kernel if nxt is not None else None, Hnext=h_next)
+                elif kind == 'sj':
                     capi.spmm_sj(a.sliced(widths[k + 1]), h, slices[k + 1], bias=layer.bias, relu=True,
                                  Wnext=nxt.kernel if nxt is not None else None, Hnext=h_next)
                 else:

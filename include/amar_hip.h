@@ -79,6 +79,22 @@ int amar_spmm_sj_f32(const int32_t *entries, const int16_t *counts, const int32_
                      const float *acc_in, int64_t ld_acc_in, float *acc_out, int64_t ld_acc_out, float acc_div,
                      const float *Wnext, int32_t Cn, float *Hnext, int64_t ldhn, amar_stream_t stream);
 
+/* The same product on the XCD-sliced (XS) image of a square A — the form used when the node table does
+ * not fit one 4 MB per-XCD L2 (utilities/math.py:XcdSliced.from_csr builds it; any producer may):
+ *   diag[n]                  the diagonal of A (duplicates summed)
+ *   the off-diagonal non-zeros sorted by (slice, row, column), columns cut into n_slices contiguous slices of
+ *   equal non-zero count:  colidx / vals, and rowptr[k * n + r] = first entry of (slice k, row r)  (int32 [n_slices*n + 1])
+ * Two launches: per-slice partial rows -> partials[n_slices, n, F] (caller-provided scratch), workgroup b touching
+ * slice b % n_slices only (XCD <-> L2 affinity under round-robin dispatch); then
+ *   Y[i] = epilogue( diag[i] . X[i] + sum_k partials[k][i] )   in slice order, epilogue as amar_spmm_sj_f32.
+ * The matrix must be square and X must be the same table the rows index (X[i] is row i's own features).
+ */
+int amar_spmm_xs_f32(const float *diag, const int32_t *rowptr, const int32_t *colidx, const float *vals, int32_t n_slices,
+                     const float *X, int64_t ldx, float *partials, float *Y, int64_t ldy,
+                     int32_t n_rows, int32_t F, uint32_t flags, const float *bias,
+                     const float *acc_in, int64_t ld_acc_in, float *acc_out, int64_t ld_acc_out, float acc_div,
+                     const float *Wnext, int32_t Cn, float *Hnext, int64_t ldhn, amar_stream_t stream);
+
 /* One fused GCN layer (src/models/gnn.py:289-295 + gnn.py:78, Spektral GCNConv.call):
  *     Y[i, 0:C]      = ReLU( sum_j A_hat[i,j] . H[j, 0:C] + bias )      H = X_prev . W  (pre-multiplied)
  *     Hnext[i, 0:Cn] = Y[i, :] . Wnext[C, Cn]                            (only if Wnext != NULL)

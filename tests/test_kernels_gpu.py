@@ -348,6 +348,40 @@ def test_spmm_kinds_agree_on_models(hip, monkeypatch):
         helpers.randomize_biases(model, seed=2)
         monkeypatch.setenv('AMAR_SPMM_KIND', 'csr')
         e_csr = model.gnn(None).cpu().numpy()
-        monkeypatch.setenv('AMAR_SPMM_KIND', 'sj')
-        e_sj = model.gnn(None).cpu().numpy()
-        assert rel_err(e_sj, e_csr.astype(np.float64)) < 2e-6
+        for kind in ('sj', 'xs'):
+            monkeypatch.setenv('AMAR_SPMM_KIND', kind)
+            e_k = model.gnn(None).cpu().numpy()
+            assert rel_err(e_k, e_csr.astype(np.float64)) < 2e-6
+
+
+@pytest.mark.parametrize('F', [4, 8, 16, 32, 64])
+@pytest.mark.parametrize('n', [1, 67, 1000, 4097])
+def test_spmm_xcd_sliced(hip, F, n):
+    """XS image (XCD-affine column slices: partial products + combine) against the dense oracle product."""
+    from deep_cbrs_amar_renaissance_amd.utilities.math import XcdSliced
+    m = _rand_csr(n, 9, seed=F + n) + sparse.identity(n, dtype=np.float32, format='coo') * 0.25
+    m = m.tocoo()
+    a = _dev_csr(m)
+    xs = XcdSliced.from_csr(a)
+    assert xs.colidx.numel() + int((xs.diag != 0).sum()) >= 0 and xs.rowptr.numel() == xs.n_slices * n + 1
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((n, F)).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, F).astype(np.float32)
+    wn = rng.uniform(-0.5, 0.5, (F, 12)).astype(np.float32)
+    A = m.tocsr().astype(np.float64)
+    y = torch.full((n, F), float('nan'), device=DEV)
+    hip.spmm_xs(xs, _t(x), y)
+    assert rel_err(y.cpu().numpy(), A @ x.astype(np.float64)) < 2e-6
+    hn = torch.full((n, 12), float('nan'), device=DEV)
+    cat = torch.zeros((n, 2 * F + 4), device=DEV)
+    hip.spmm_xs(xs, _t(x), cat[:, 4:4 + F], bias=_t(b), relu=True, Wnext=_t(wn), Hnext=hn)
+    want = np.maximum(A @ x.astype(np.float64) + b, 0)
+    got = cat.cpu().numpy()
+    assert rel_err(got[:, 4:4 + F], want) < 2e-6 and rel_err(hn.cpu().numpy(), want @ wn.astype(np.float64)) < 3e-6
+    assert np.all(got[:, :4] == 0) and np.all(got[:, 4 + F:] == 0)
+    s1, e = torch.empty((n, F), device=DEV), torch.empty((n, F), device=DEV)
+    xd = _t(x)
+    hip.spmm_xs(xs, xd, y, acc_in=xd, acc_out=s1)
+    hip.spmm_xs(xs, y, None, acc_in=s1, acc_out=e, acc_div=3)
+    x1 = A @ x.astype(np.float64)
+    assert rel_err(e.cpu().numpy(), (x + x1 + A @ x1) / 3) < 3e-6

@@ -62,6 +62,11 @@ def main():
             med, best = timeit(lambda: capi.gcn_layer(a.rowptr, a.colidx, a.vals, x, b, y, Wnext=w, Hnext=hn))
             print('  gcn  F={:2d}: {:8.3f} ms (best {:8.3f})  fused bias+relu+next XW -> {:7.1f} GB/s'.format(
                 F, med, best, alg / med / 1e6), flush=True)
+            xs = a.xcd_sliced()
+            med, best = timeit(lambda: capi.spmm_xs(xs, x, y))
+            print('  XS   F={:2d}: {:8.3f} ms (best {:8.3f})  -> {:7.1f} GB/s ({:4.1f}% of 8 TB/s)'.format(F, med, best, alg / med / 1e6, 100 * alg / med / 1e6 / 8000), flush=True)
+            med, best = timeit(lambda: capi.spmm_xs(xs, x, y, bias=b, relu=True, Wnext=w, Hnext=hn))
+            print('  XS gcn F={:2d}: {:8.3f} ms (best {:8.3f})  -> {:7.1f} GB/s'.format(F, med, best, alg / med / 1e6), flush=True)
             sj = a.sliced(F)
             med, best = timeit(lambda: capi.spmm_sj(sj, x, y))
             print('  SJ   F={:2d}: {:8.3f} ms (best {:8.3f})  {} slices -> {:7.1f} GB/s ({:4.1f}% of 8 TB/s)'.format(

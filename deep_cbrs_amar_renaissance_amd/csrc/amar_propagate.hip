@@ -702,7 +702,7 @@ int amar_spmm_xs_f32(const float *diag, const int32_t *rowptr, const int32_t *co
                      const float *Wnext, int32_t Cn, float *Hnext, int64_t ldhn, amar_stream_t stream) {
     if (n_rows < 0 || n_slices < 1 || !diag || !rowptr || !X || !partials) return AMAR_EINVAL;
     if (n_rows == 0) return AMAR_OK;
-    if (!colidx || !vals) return AMAR_EINVAL;
+    // colidx / vals may be NULL when the matrix has no off-diagonal entry (every segment is then empty)
     const bool accum = flags & AMAR_SPMM_ACCUM;
     if (!Y && !accum) return AMAR_EINVAL;
     if (!ld_ok(ldx, F) || !amar_aligned16(X) || !amar_aligned16(partials)) return AMAR_EINVAL;

@@ -26,10 +26,13 @@ def main():
     if kind == 'zero':
         a.colidx.zero_()
     sj = a.sliced(F) if kind == 'sj' else None
+    xs = a.xcd_sliced() if kind == 'xs' else None
     torch.cuda.synchronize()
     for _ in range(reps):
         if kind == 'sj':
             capi.spmm_sj(sj, x, y)
+        elif kind == 'xs':
+            capi.spmm_xs(xs, x, y)
         else:
             capi.spmm_csr(a.rowptr, a.colidx, a.vals, x, y)
     torch.cuda.synchronize()

@@ -336,20 +336,40 @@ int launch_spmm_sj(const SjArgs &a, int F, hipStream_t st) {
 // ---- v4: XCD-sliced (XS) SpMM = per-slice partial products + combine ------------------------------
 // Format and rationale: utilities/math.py:XcdSliced, include/amar_hip.h.  Workgroup b works on column
 // slice b % S only, so (with the round-robin dispatch of workgroups over the 8 XCDs) each XCD's L2
-// holds one slice of X and nothing else of it.  A (row, slice) segment is short (a row's non-zeros
-// spread over the slices), so rows are handled by GROUPS of 8 lanes (16 for F = 64): 64/GROUP rows per
-// pass, GROUP/(F/4) gather slots per row, a DPP reduction over the group's slots only.  The partial
-// row goes to P[slice][row]; a second kernel adds diag . X and the S partials in slice order (a fixed
-// order: results are bitwise reproducible) and applies the fused layer epilogue.
+// holds one slice of X and nothing else of it.  The partial rows of a (64-row block, slice) pair go to
+// P[slice][row]; a second kernel adds diag . X and the non-empty partials in slice order (a fixed order:
+// results are bitwise reproducible) and applies the fused layer epilogue.
 struct XsArgs {
     const int32_t *rowptr; const int32_t *colidx; const float *vals;     // XS image
     const float *X; int64_t ldx; float *P; int n_rows; int n_slices; int blocks_per_slice;
 };
 
+// Lanes take CONSECUTIVE entries of the wave's (64-row block, slice) range: lane = q * EPS + s handles feature
+// quad q of entry s of the current step (EPS = 64 / (F/4) entries per step), so colidx/vals loads are coalesced
+// and every lane gathers.  The row of an entry rides in bits 26..31 of its column word (row & 63); since entries
+// are sorted by row, a DPP segmented inclusive scan over s (add the value d lanes back iff its key is equal)
+// leaves each row-run's sum in the run's last lane, which adds it to the wave's LDS accumulator [64 rows][F].
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_pull(float v) {     // lanes outside ROW_MASK / without a source get 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_pull_key(int k) {     // ... and key -1 (matches no row)
+    return __builtin_amdgcn_update_dpp(-1, k, CTRL, ROW_MASK, 0xF, false);
+}
+
+template <int CTRL, int ROW_MASK, int DIST, int EPS>
+__device__ __forceinline__ void seg_scan_step(float4 &p, int key, int s) {
+    const int kprev = dpp_pull_key<CTRL, ROW_MASK>(key);
+    const float m = (kprev == key && (DIST == 0 || s >= DIST)) ? 1.f : 0.f;
+    p.x = fmaf(m, dpp_pull<CTRL, ROW_MASK>(p.x), p.x); p.y = fmaf(m, dpp_pull<CTRL, ROW_MASK>(p.y), p.y);
+    p.z = fmaf(m, dpp_pull<CTRL, ROW_MASK>(p.z), p.z); p.w = fmaf(m, dpp_pull<CTRL, ROW_MASK>(p.w), p.w);
+}
+
 template <int F>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void spmm_xs_partial_kernel(const XsArgs a) {
-    constexpr int LPN = F / 4;
-    constexpr int GROUP = LPN > 8 ? LPN : 8, SPG = GROUP / LPN, RPP = AMAR_WAVE / GROUP, PASSES = AMAR_WAVE / RPP;
+    constexpr int LPN = F / 4, EPS = AMAR_WAVE / LPN;
+    __shared__ float lds_acc[WAVES_PER_BLOCK][AMAR_WAVE * F];
     const int lane = threadIdx.x & (AMAR_WAVE - 1);
     const int k = blockIdx.x % a.n_slices;                           // slice <-> XCD affinity
     const int chunk = blockIdx.x / a.n_slices;
@@ -357,35 +377,52 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void spmm_xs_partial_k
     if (r0 >= a.n_rows) return;
     const int nr = min(AMAR_WAVE, a.n_rows - r0);
     const int32_t *rp = a.rowptr + (int64_t)k * a.n_rows + r0;
-    const int beg_l = rp[min(lane, nr)], end_l = rp[min(lane + 1, nr)];  // this lane's row of the wave
-    const int g = lane / GROUP, s = (lane % GROUP) / LPN, q = lane % LPN;
-    float *Pk = a.P + ((int64_t)k * a.n_rows + r0) * F;
-    for (int pass = 0; pass < PASSES; ++pass) {
-        const int rl = pass * RPP + g;                               // row of this lane's group within the wave
-        const int beg = __shfl(beg_l, rl, 64), end = __shfl(end_l, rl, 64);
-        float4 acc = f4_zero();
-        for (int i = beg + s; __any(i < end); i += 2 * SPG) {
-            const int i1 = i + SPG;
-            int c0 = 0, c1 = 0;
-            float v0 = 0.f, v1 = 0.f;
-            if (i < end) { c0 = a.colidx[i]; v0 = a.vals[i]; }
-            if (i1 < end) { c1 = a.colidx[i1]; v1 = a.vals[i1]; }
-            float4 x0 = f4_zero(), x1 = f4_zero();
-            if (i < end) x0 = *reinterpret_cast<const float4 *>(a.X + (int64_t)c0 * a.ldx + 4 * q);
-            if (i1 < end) x1 = *reinterpret_cast<const float4 *>(a.X + (int64_t)c1 * a.ldx + 4 * q);
-            acc = f4_fma(v0, x0, acc);
-            acc = f4_fma(v1, x1, acc);
+    const int beg = rp[0], end = rp[nr];                             // wave-uniform (scalar loads)
+    if (beg == end) return;                                          // empty (block, slice): the combine skips it too
+    float *acc = lds_acc[threadIdx.x >> 6];
+#pragma unroll
+    for (int c = 0; c < F; ++c) acc[c * AMAR_WAVE + lane] = 0.f;     // wave-private region; LDS ops of a wave stay in order
+    const int q = lane / EPS, s = lane % EPS;
+
+    for (int base = beg; base < end; base += EPS) {
+        const int i = base + s;
+        const bool ok = i < end;
+        int key = 0x7fffffff;
+        float4 p = f4_zero();
+        if (ok) {
+            const int cw = a.colidx[i];
+            const float v = a.vals[i];
+            key = (unsigned)cw >> 26;
+            const float4 x = *reinterpret_cast<const float4 *>(a.X + (int64_t)(cw & 0x3ffffff) * a.ldx + 4 * q);
+            p = make_float4(v * x.x, v * x.y, v * x.z, v * x.w);
         }
-        // sum over the group's slots with DPP row_shl (lane i reads lane i + n; 0x100 + n): only the group's
-        // first LPN lanes need the total, lanes that read across a group boundary hold values nobody uses
-        if (SPG >= 8) { acc.x += dpp_mov<0x104>(acc.x); acc.y += dpp_mov<0x104>(acc.y); acc.z += dpp_mov<0x104>(acc.z); acc.w += dpp_mov<0x104>(acc.w); }
-        if (SPG >= 4) { constexpr int C = LPN == 1 ? 0x102 : 0x104; acc.x += dpp_mov<C>(acc.x); acc.y += dpp_mov<C>(acc.y); acc.z += dpp_mov<C>(acc.z); acc.w += dpp_mov<C>(acc.w); }
-        if (SPG >= 2) { constexpr int C = LPN == 1 ? 0x101 : (LPN == 2 ? 0x102 : 0x104); acc.x += dpp_mov<C>(acc.x); acc.y += dpp_mov<C>(acc.y); acc.z += dpp_mov<C>(acc.z); acc.w += dpp_mov<C>(acc.w); }
-        if (s == 0 && rl < nr) *reinterpret_cast<float4 *>(Pk + (int64_t)rl * F + 4 * q) = acc;
+        // segmented inclusive scan over s (row_shr:d = 0x110 + d; row_bcast15 = 0x142; row_bcast31 = 0x143)
+        if (EPS >= 2) seg_scan_step<0x111, 0xF, (EPS < 16 ? 1 : 0), EPS>(p, key, s);
+        if (EPS >= 4) seg_scan_step<0x112, 0xF, (EPS < 16 ? 2 : 0), EPS>(p, key, s);
+        if (EPS >= 8) seg_scan_step<0x114, 0xF, (EPS < 16 ? 4 : 0), EPS>(p, key, s);
+        if (EPS >= 16) seg_scan_step<0x118, 0xF, 0, EPS>(p, key, s);
+        if (EPS >= 32) seg_scan_step<0x142, 0xA, 0, EPS>(p, key, s);
+        if (EPS >= 64) seg_scan_step<0x143, 0xC, 0, EPS>(p, key, s);
+        // a run ends where the next entry has another key (or the step ends)
+        const int knext = __shfl_down(key, 1, 64);
+        const bool run_end = ok && (s == EPS - 1 || knext != key);
+        if (run_end) {
+            float *dst = acc + key;                                   // acc[feature][row]: lanes of one instruction hit distinct rows
+            atomicAdd(dst + (4 * q + 0) * AMAR_WAVE, p.x); atomicAdd(dst + (4 * q + 1) * AMAR_WAVE, p.y);
+            atomicAdd(dst + (4 * q + 2) * AMAR_WAVE, p.z); atomicAdd(dst + (4 * q + 3) * AMAR_WAVE, p.w);
+        }
+    }
+    if (lane < nr) {
+        float *out = a.P + ((int64_t)k * a.n_rows + r0 + lane) * F;
+#pragma unroll
+        for (int c4 = 0; c4 < LPN; ++c4)
+            *reinterpret_cast<float4 *>(out + 4 * c4) =
+                make_float4(acc[(4 * c4 + 0) * AMAR_WAVE + lane], acc[(4 * c4 + 1) * AMAR_WAVE + lane],
+                            acc[(4 * c4 + 2) * AMAR_WAVE + lane], acc[(4 * c4 + 3) * AMAR_WAVE + lane]);
     }
 }
 
-struct XsCombineArgs { const float *diag; const float *P; int n_slices; SpmmArgs e; };
+struct XsCombineArgs { const float *diag; const float *P; const int32_t *rowptr; int n_slices; SpmmArgs e; };
 
 template <int F, bool FUSE_NEXT>
 __global__ __launch_bounds__(256) void spmm_xs_combine_kernel(const XsCombineArgs a) {
@@ -400,7 +437,11 @@ __global__ __launch_bounds__(256) void spmm_xs_combine_kernel(const XsCombineArg
         const float4 x = *reinterpret_cast<const float4 *>(e.X + (int64_t)row * e.ldx + 4 * q);
         acc[q] = make_float4(d * x.x, d * x.y, d * x.z, d * x.w);
     }
+    const int w0 = __builtin_amdgcn_readfirstlane(row & ~(AMAR_WAVE - 1));      // the partial kernel's 64-row block
+    const int w1 = min(w0 + AMAR_WAVE, e.n_rows);
     for (int k = 0; k < a.n_slices; ++k) {
+        const int32_t *rp = a.rowptr + (int64_t)k * e.n_rows;
+        if (rp[w0] == rp[w1]) continue;                              // nothing was written for this (block, slice)
         const float *p = a.P + ((int64_t)k * e.n_rows + row) * F;
 #pragma unroll
         for (int q = 0; q < LPN; ++q) acc[q] = f4_add(acc[q], *reinterpret_cast<const float4 *>(p + 4 * q));
@@ -716,7 +757,7 @@ int amar_spmm_xs_f32(const float *diag, const int32_t *rowptr, const int32_t *co
     XsArgs pa{rowptr, colidx, vals, X, ldx, partials, n_rows, n_slices,
               (n_rows + WAVES_PER_BLOCK * AMAR_WAVE - 1) / (WAVES_PER_BLOCK * AMAR_WAVE)};
     XsCombineArgs ca{};
-    ca.diag = diag; ca.P = partials; ca.n_slices = n_slices;
+    ca.diag = diag; ca.P = partials; ca.rowptr = rowptr; ca.n_slices = n_slices;
     ca.e.X = X; ca.e.ldx = ldx; ca.e.Y = Y; ca.e.ldy = ldy;
     ca.e.bias = (flags & AMAR_SPMM_BIAS) ? bias : nullptr; ca.e.relu = (flags & AMAR_SPMM_RELU) ? 1 : 0;
     ca.e.acc_in = acc_in; ca.e.ld_acc_in = ld_acc_in; ca.e.acc_out = acc_out; ca.e.ld_acc_out = ld_acc_out;

@@ -234,7 +234,7 @@ class XcdSliced:
 
         diag     fp32 [n]            the diagonal of A (summed duplicates), applied by the combine kernel
         rowptr   int32 [S*n + 1]     start of (slice k, row r) at index k*n + r in the reordered arrays
-        colidx   int32 [nnz_offdiag] global column ids, sorted by (slice, row, column)
+        colidx   int32 [nnz_offdiag] (row & 63) << 26 | global column, sorted by (slice, row, column)
         vals     fp32  [nnz_offdiag]
         bounds   int64 [S + 1]       column range of every slice (host list)
     """
@@ -280,7 +280,11 @@ class XcdSliced:
         order = torch.argsort(seg * n + cols)
         rowptr = torch.zeros(n_slices * n + 1, dtype=torch.int64, device=dev)
         rowptr[1:] = torch.cumsum(torch.bincount(seg, minlength=n_slices * n), 0)
-        return cls(diag, rowptr.to(torch.int32), cols[order].to(torch.int32).contiguous(), vals[order].contiguous(),
+        if n > (1 << 26):
+            raise ValueError("the XS image packs the row (6 bits) above a 26-bit column: n must be <= 2^26")
+        packed = ((rows[order] & 63) << 26) | cols[order]
+        packed = torch.where(packed >= (1 << 31), packed - (1 << 32), packed)      # two's-complement int32
+        return cls(diag, rowptr.to(torch.int32), packed.to(torch.int32).contiguous(), vals[order].contiguous(),
                    bounds, a.shape)
 
 

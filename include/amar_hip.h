@@ -83,7 +83,8 @@ int amar_spmm_sj_f32(const int32_t *entries, const int16_t *counts, const int32_
  * not fit one 4 MB per-XCD L2 (utilities/math.py:XcdSliced.from_csr builds it; any producer may):
  *   diag[n]                  the diagonal of A (duplicates summed)
  *   the off-diagonal non-zeros sorted by (slice, row, column), columns cut into n_slices contiguous slices of
- *   equal non-zero count:  colidx / vals, and rowptr[k * n + r] = first entry of (slice k, row r)  (int32 [n_slices*n + 1])
+ *   equal non-zero count:  colidx (= (row & 63) << 26 | column; n <= 2^26) / vals, and
+ *   rowptr[k * n + r] = first entry of (slice k, row r)  (int32 [n_slices*n + 1])
  * Two launches: per-slice partial rows -> partials[n_slices, n, F] (caller-provided scratch), workgroup b touching
  * slice b % n_slices only (XCD <-> L2 affinity under round-robin dispatch); then
  *   Y[i] = epilogue( diag[i] . X[i] + sum_k partials[k][i] )   in slice order, epilogue as amar_spmm_sj_f32.

@@ -384,17 +384,25 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void spmm_xs_partial_k
     for (int c = 0; c < F; ++c) acc[c * AMAR_WAVE + lane] = 0.f;     // wave-private region; LDS ops of a wave stay in order
     const int q = lane / EPS, s = lane % EPS;
 
-    for (int base = beg; base < end; base += EPS) {
-        const int i = base + s;
-        const bool ok = i < end;
-        int key = 0x7fffffff;
-        float4 p = f4_zero();
-        if (ok) {
-            const int cw = a.colidx[i];
-            const float v = a.vals[i];
-            key = (unsigned)cw >> 26;
-            const float4 x = *reinterpret_cast<const float4 *>(a.X + (int64_t)(cw & 0x3ffffff) * a.ldx + 4 * q);
-            p = make_float4(v * x.x, v * x.y, v * x.z, v * x.w);
+    auto reduce_step = [&](int key, float4 p, bool ok) {
+        // whole step one row-run (the common case for long rows): a plain strided wave sum, result in every lane
+        const int kfirst = __builtin_amdgcn_readfirstlane(key);
+        if (__all(key == kfirst || !ok) && kfirst != 0x7fffffff) {
+            // lanes = q * EPS + s: sum over s inside each group of EPS lanes
+            if (EPS >= 2) { p.x += dpp_mov<0x121>(p.x); p.y += dpp_mov<0x121>(p.y); p.z += dpp_mov<0x121>(p.z); p.w += dpp_mov<0x121>(p.w); }
+            if (EPS >= 4) { p.x += dpp_mov<0x122>(p.x); p.y += dpp_mov<0x122>(p.y); p.z += dpp_mov<0x122>(p.z); p.w += dpp_mov<0x122>(p.w); }
+            if (EPS >= 8) { p.x += dpp_mov<0x124>(p.x); p.y += dpp_mov<0x124>(p.y); p.z += dpp_mov<0x124>(p.z); p.w += dpp_mov<0x124>(p.w); }
+            if (EPS >= 16) { p.x += dpp_mov<0x128>(p.x); p.y += dpp_mov<0x128>(p.y); p.z += dpp_mov<0x128>(p.z); p.w += dpp_mov<0x128>(p.w); }
+            if (EPS >= 32) { float o, w; w = swap16_other(p.x, o); p.x = o + w; w = swap16_other(p.y, o); p.y = o + w;
+                             w = swap16_other(p.z, o); p.z = o + w; w = swap16_other(p.w, o); p.w = o + w; }
+            if (EPS >= 64) { float o, w; w = swap32_other(p.x, o); p.x = o + w; w = swap32_other(p.y, o); p.y = o + w;
+                             w = swap32_other(p.z, o); p.z = o + w; w = swap32_other(p.w, o); p.w = o + w; }
+            if (s == 0) {
+                float *dst = acc + kfirst;
+                atomicAdd(dst + (4 * q + 0) * AMAR_WAVE, p.x); atomicAdd(dst + (4 * q + 1) * AMAR_WAVE, p.y);
+                atomicAdd(dst + (4 * q + 2) * AMAR_WAVE, p.z); atomicAdd(dst + (4 * q + 3) * AMAR_WAVE, p.w);
+            }
+            return;
         }
         // segmented inclusive scan over s (row_shr:d = 0x110 + d; row_bcast15 = 0x142; row_bcast31 = 0x143)
         if (EPS >= 2) seg_scan_step<0x111, 0xF, (EPS < 16 ? 1 : 0), EPS>(p, key, s);
@@ -411,6 +419,21 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void spmm_xs_partial_k
             atomicAdd(dst + (4 * q + 0) * AMAR_WAVE, p.x); atomicAdd(dst + (4 * q + 1) * AMAR_WAVE, p.y);
             atomicAdd(dst + (4 * q + 2) * AMAR_WAVE, p.z); atomicAdd(dst + (4 * q + 3) * AMAR_WAVE, p.w);
         }
+    };
+
+    for (int base = beg; base < end; base += 2 * EPS) {              // two steps in flight: both index loads, then both gathers
+        const int i0 = base + s, i1 = base + EPS + s;
+        const bool ok0 = i0 < end, ok1 = i1 < end;
+        int cw0 = 0, cw1 = 0;
+        float v0 = 0.f, v1 = 0.f;
+        if (ok0) { cw0 = a.colidx[i0]; v0 = a.vals[i0]; }
+        if (ok1) { cw1 = a.colidx[i1]; v1 = a.vals[i1]; }
+        float4 x0 = f4_zero(), x1 = f4_zero();
+        if (ok0) x0 = *reinterpret_cast<const float4 *>(a.X + (int64_t)(cw0 & 0x3ffffff) * a.ldx + 4 * q);
+        if (ok1) x1 = *reinterpret_cast<const float4 *>(a.X + (int64_t)(cw1 & 0x3ffffff) * a.ldx + 4 * q);
+        reduce_step(ok0 ? (int)((unsigned)cw0 >> 26) : 0x7fffffff, make_float4(v0 * x0.x, v0 * x0.y, v0 * x0.z, v0 * x0.w), ok0);
+        if (base + EPS < end)
+            reduce_step(ok1 ? (int)((unsigned)cw1 >> 26) : 0x7fffffff, make_float4(v1 * x1.x, v1 * x1.y, v1 * x1.z, v1 * x1.w), ok1);
     }
     if (lane < nr) {
         float *out = a.P + ((int64_t)k * a.n_rows + r0 + lane) * F;

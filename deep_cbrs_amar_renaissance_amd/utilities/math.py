@@ -207,7 +207,8 @@ def spmm_kind(a, F):
     forced = os.environ.get('AMAR_SPMM_KIND')
     if forced in ('csr', 'sj', 'xs'):
         return forced
-    return 'xs' if (a.shape[0] == a.shape[1] and a.shape[1] * F * 4 > (3 << 20)) else 'csr'
+    # measured on ml1m(s=64): XS wins at F <= 8, ties at 16, loses at 32 (its per-step scan is amortised over 64/(F/4) entries)
+    return 'xs' if (a.shape[0] == a.shape[1] and F <= 8 and a.shape[1] * F * 4 > (3 << 20)) else 'csr'
 
 
 def _csr_sliced(self, F):

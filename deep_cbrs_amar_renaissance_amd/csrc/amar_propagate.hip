@@ -387,7 +387,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void spmm_xs_partial_k
     auto reduce_step = [&](int key, float4 p, bool ok) {
         // whole step one row-run (the common case for long rows): a plain strided wave sum, result in every lane
         const int kfirst = __builtin_amdgcn_readfirstlane(key);
-        if (__all(key == kfirst || !ok) && kfirst != 0x7fffffff) {
+        if (EPS >= 16 && __all(key == kfirst || !ok) && kfirst != 0x7fffffff) {   // (EPS < 16: a 16-lane DPP row spans several q groups)
             // lanes = q * EPS + s: sum over s inside each group of EPS lanes
             if (EPS >= 2) { p.x += dpp_mov<0x121>(p.x); p.y += dpp_mov<0x121>(p.y); p.z += dpp_mov<0x121>(p.z); p.w += dpp_mov<0x121>(p.w); }
             if (EPS >= 4) { p.x += dpp_mov<0x122>(p.x); p.y += dpp_mov<0x122>(p.y); p.z += dpp_mov<0x122>(p.z); p.w += dpp_mov<0x122>(p.w); }

@@ -207,8 +207,9 @@ def spmm_kind(a, F):
     forced = os.environ.get('AMAR_SPMM_KIND')
     if forced in ('csr', 'sj', 'xs'):
         return forced
-    # measured on ml1m(s=64): XS wins at F <= 8, ties at 16, loses at 32 (its per-step scan is amortised over 64/(F/4) entries)
-    return 'xs' if (a.shape[0] == a.shape[1] and F <= 8 and a.shape[1] * F * 4 > (3 << 20)) else 'csr'
+    # measured (profiles/): at ml1m(s=64) XS beats the row-streaming form 1.28x at F=8 and 1.24x at F=16 and loses at F=32
+    # (its per-step scan is amortised over only 64/(F/4) entries); at s=16 (table 4.7-9.4 MB) the row form still wins
+    return 'xs' if (a.shape[0] == a.shape[1] and F <= 16 and a.shape[1] * F * 4 >= (16 << 20)) else 'csr'
 
 
 def _csr_sliced(self, F):

@@ -20,6 +20,7 @@
 // f32 MFMA is an exact k-ordered fmaf chain, so results do not depend on tiling; the k order
 // differs from a plain dot product only by the fixed interleave (4g + r), well inside 1e-6.
 #include "amar_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -240,25 +241,26 @@ int amar_chain_f32(const float *A, int64_t lda, int32_t Da, const int32_t *ids_a
     if (P == 0) return AMAR_OK;
     const size_t lds_bytes = (size_t)off * sizeof(float);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (maxw <= 64) {
-        constexpr int PT = 4;
-        int64_t blocks = (P + 4 * 16 * PT - 1) / (4 * 16 * PT);
-        if (blocks > 2048) blocks = 2048;
-        auto kern = chain_kernel<4, PT>;
-        if (lds_bytes > 64 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
-            return amar_check_launch() == AMAR_OK ? AMAR_ELAUNCH : AMAR_ELAUNCH;
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
-    } else {
-        constexpr int PT = 2;
-        int64_t blocks = (P + 4 * 16 * PT - 1) / (4 * 16 * PT);
-        if (blocks > 2048) blocks = 2048;
-        auto kern = chain_kernel<8, PT>;
-        if (lds_bytes > 64 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
-            return AMAR_ELAUNCH;
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);
-    }
+    // tile budget: MAXT = widest layer / 16 rounded up to {3, 4, 8}; PT pair tiles per wave (register budget ~ MAXT * PT)
+    static const int force_pt = getenv("AMAR_CHAIN_PT") ? atoi(getenv("AMAR_CHAIN_PT")) : 0;
+    const int maxt = maxw <= 48 ? 3 : (maxw <= 64 ? 4 : 8);
+    int pt = maxt == 8 ? 2 : 4;
+    if (force_pt == 1 || force_pt == 2 || (force_pt == 4 && maxt != 8)) pt = force_pt;
+#define AMAR_CHAIN_LAUNCH(MT, PTT)                                                                                      \
+    do {                                                                                                                \
+        int64_t blocks = (P + 4 * 16 * PTT - 1) / (4 * 16 * PTT);                                                       \
+        if (blocks > 4096) blocks = 4096;                                                                               \
+        auto kern = chain_kernel<MT, PTT>;                                                                              \
+        if (lds_bytes > 64 * 1024 &&                                                                                    \
+            hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                (int)lds_bytes) != hipSuccess)                                                          \
+            return AMAR_ELAUNCH;                                                                                        \
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);                                  \
+    } while (0)
+    if (maxt == 3) { if (pt == 1) AMAR_CHAIN_LAUNCH(3, 1); else if (pt == 2) AMAR_CHAIN_LAUNCH(3, 2); else AMAR_CHAIN_LAUNCH(3, 4); }
+    else if (maxt == 4) { if (pt == 1) AMAR_CHAIN_LAUNCH(4, 1); else if (pt == 2) AMAR_CHAIN_LAUNCH(4, 2); else AMAR_CHAIN_LAUNCH(4, 4); }
+    else { if (pt == 1) AMAR_CHAIN_LAUNCH(8, 1); else AMAR_CHAIN_LAUNCH(8, 2); }
+#undef AMAR_CHAIN_LAUNCH
     return amar_check_launch();
 }
 

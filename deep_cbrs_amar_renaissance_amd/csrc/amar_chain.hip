@@ -244,7 +244,7 @@ int amar_chain_f32(const float *A, int64_t lda, int32_t Da, const int32_t *ids_a
     // tile budget: MAXT = widest layer / 16 rounded up to {3, 4, 8}; PT pair tiles per wave (register budget ~ MAXT * PT)
     static const int force_pt = getenv("AMAR_CHAIN_PT") ? atoi(getenv("AMAR_CHAIN_PT")) : 0;
     const int maxt = maxw <= 48 ? 3 : (maxw <= 64 ? 4 : 8);
-    int pt = maxt == 8 ? 2 : 4;
+    int pt = 2;                                                   // measured best on grid1/grid2/grid6 shapes (tools/exp_chain.py)
     if (force_pt == 1 || force_pt == 2 || (force_pt == 4 && maxt != 8)) pt = force_pt;
 #define AMAR_CHAIN_LAUNCH(MT, PTT)                                                                                      \
     do {                                                                                                                \

@@ -46,7 +46,9 @@ __device__ __forceinline__ float chain_act(float v, int act) {
     return v;
 }
 
-template <int MAXT, int PT>
+// FULL: every MFMA layer has exactly MAXT input and MAXT output tiles (e.g. grid1's 48 -> 48 -> 48 classifier with
+// MAXT = 3): the tile guards fold away and the layer bodies become straight-line MFMA code.
+template <int MAXT, int PT, bool FULL>
 __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float w_lds[];
     for (int i = threadIdx.x * 4; i < a.wpack_floats; i += blockDim.x * 4)
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
             for (int t = 0; t < MAXT; ++t) {
                 const int f = 16 * t + 4 * g;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (t < a.kt[0] && ok) {
+                if ((FULL || t < a.kt[0]) && ok) {
                     if (f < a.Da) v = *reinterpret_cast<const f32x4 *>(a.A + ra * a.lda + f);
                     else if (f < a.Da + a.Db) v = *reinterpret_cast<const f32x4 *>(a.B + rb * a.ldb + (f - a.Da));
                 }
@@ -80,19 +82,19 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
         }
         // ---- dense layers on MFMA, activations stay in registers
         for (int l = 0; l < a.n_layers; ++l) {
-            const int KT = a.kt[l], NT = a.nt[l];
+            const int KT = FULL ? MAXT : a.kt[l], NT = FULL ? MAXT : a.nt[l];
             const float *wl = w_lds + a.w_off[l];
             const float *bl = w_lds + a.b_off[l];
             f32x4 y[MAXT][PT];
 #pragma unroll
             for (int m = 0; m < MAXT; ++m) {
-                if (m < NT) {
+                if (FULL || m < NT) {
                     const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bl + 16 * m + 4 * g);
 #pragma unroll
                     for (int pt = 0; pt < PT; ++pt) y[m][pt] = b4;
 #pragma unroll
                     for (int t = 0; t < MAXT; ++t) {
-                        if (t < KT) {
+                        if (FULL || t < KT) {
                             const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wl + ((m * KT + t) * 64 + lane) * 4);
 #pragma unroll
                             for (int r = 0; r < 4; ++r)
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
 #pragma unroll
                 for (int pt = 0; pt < PT; ++pt) {
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (m < NT) {
+                    if (FULL || m < NT) {
                         v = y[m][pt];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = chain_act(v[r], act);
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
                 float s = 0.f;
 #pragma unroll
                 for (int t = 0; t < MAXT; ++t) {
-                    if (t < a.dot_kt) {
+                    if (FULL || t < a.dot_kt) {
                         const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wd + 16 * t + 4 * g);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) s = fmaf(x[t][pt][r], w4[r], s);
@@ -244,13 +246,15 @@ int amar_chain_f32(const float *A, int64_t lda, int32_t Da, const int32_t *ids_a
     // tile budget: MAXT = widest layer / 16 rounded up to {3, 4, 8}; PT pair tiles per wave (register budget ~ MAXT * PT)
     static const int force_pt = getenv("AMAR_CHAIN_PT") ? atoi(getenv("AMAR_CHAIN_PT")) : 0;
     const int maxt = maxw <= 48 ? 3 : (maxw <= 64 ? 4 : 8);
+    bool full = (dims[0] + 15) / 16 == maxt && (!a.has_dot || a.dot_kt == maxt);
+    for (int l = 0; l < a.n_layers; ++l) full = full && a.kt[l] == maxt && a.nt[l] == maxt;
     int pt = 2;                                                   // measured best on grid1/grid2/grid6 shapes (tools/exp_chain.py)
     if (force_pt == 1 || force_pt == 2 || (force_pt == 4 && maxt != 8)) pt = force_pt;
 #define AMAR_CHAIN_LAUNCH(MT, PTT)                                                                                      \
     do {                                                                                                                \
         int64_t blocks = (P + 4 * 16 * PTT - 1) / (4 * 16 * PTT);                                                       \
         if (blocks > 4096) blocks = 4096;                                                                               \
-        auto kern = chain_kernel<MT, PTT>;                                                                              \
+        auto kern = full ? chain_kernel<MT, PTT, true> : chain_kernel<MT, PTT, false>;                                  \
         if (lds_bytes > 64 * 1024 &&                                                                                    \
             hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,       \
                                 (int)lds_bytes) != hipSuccess)                                                          \

@@ -38,7 +38,7 @@ SIGNATURES = {
     'amar_dense_f32': (ctypes.c_int, [_P, _I64, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _P]),
     'amar_chain_pack_floats': (ctypes.c_int64, [_P, _I32]),
     'amar_chain_pack_f32': (ctypes.c_int, [_P, _P, _P, _I32, _P]),
-    'amar_chain_f32': (ctypes.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _I32, _P, _I32, _P, _P, _P, _I32, _P, _I64, _I64, _P]),
+    'amar_chain_f32': (ctypes.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _I32, _P, _I32, _I32, _I32, _P, _P, _P, _I32, _P, _I64, _I64, _P]),
     'amar_copy_columns_f32': (ctypes.c_int, [_P, _I64, _P, _I32, _P, _I64, _I64, _I32, _P]),
     'amar_reduce_layers_f32': (ctypes.c_int, [_P, _I64, _I32, _I32, _P, _I64, _I64, _I32, _P]),
     'amar_topk_segmented_f32': (ctypes.c_int, [_P, _P, _P, _I32, _I32, _P, _P, _P]),
@@ -268,10 +268,12 @@ def dense(X, W, bias, Y, act='relu', ids=None):
 CHAIN_MAX_WIDTH, CHAIN_MAX_LAYERS = 128, 8
 
 
-def chain_supported(dims, in_a, in_b=0):
+def chain_supported(dims, in_a, in_b=0, sum_inputs=False):
     """True when amar_chain_f32 can run a dense stack with these widths (else use dense() per layer)."""
+    width_in = in_a if sum_inputs else in_a + in_b
     return (1 <= len(dims) - 1 <= CHAIN_MAX_LAYERS and max(dims) <= CHAIN_MAX_WIDTH and in_a % 4 == 0 and in_a >= 4
-            and in_b % 4 == 0 and dims[0] == in_a + in_b and (dims[-1] % 4 == 0 or (dims[-1] == 1 and len(dims) > 2)))
+            and in_b % 4 == 0 and dims[0] == width_in and (not sum_inputs or in_a == in_b)
+            and (dims[-1] % 4 == 0 or (dims[-1] == 1 and len(dims) > 2)))
 
 
 def chain_pack(kernels, biases):
@@ -295,8 +297,9 @@ def chain_pack(kernels, biases):
     return out, dims
 
 
-def chain(A, wpack, dims, acts, out, ids_a=None, base_a=0, B=None, ids_b=None, base_b=0):
-    """out = DenseStack([A[ids_a - base_a] || B[ids_b - base_b]]); see amar_chain_f32 in include/amar_hip.h."""
+def chain(A, wpack, dims, acts, out, ids_a=None, base_a=0, B=None, ids_b=None, base_b=0, sum_inputs=False, in_act=None):
+    """out = DenseStack([A[ids_a - base_a] || B[ids_b - base_b]]), or DenseStack(in_act(A[..] + B[..])) with
+    sum_inputs; see amar_chain_f32 in include/amar_hip.h."""
     P = out.shape[0]
     Da, Db = A.shape[1], (B.shape[1] if B is not None else 0)
     for ids, nm in ((ids_a, 'ids_a'), (ids_b, 'ids_b')):
@@ -309,6 +312,7 @@ def chain(A, wpack, dims, acts, out, ids_a=None, base_a=0, B=None, ids_b=None, b
     code = load().amar_chain_f32(
         _ptr(A, torch.float32, 'A'), _ld(A, 'A'), Da, _ptr(ids_a, torch.int32, 'ids_a'), int(base_a),
         _ptr(B, torch.float32, 'B'), _ld(B, 'B') if B is not None else 0, Db, _ptr(ids_b, torch.int32, 'ids_b'), int(base_b),
+        1 if sum_inputs else 0, ACT_CODES[in_act],
         _ptr(wpack, torch.float32, 'wpack'), dims_c, acts_c, len(acts),
         _ptr(out, torch.float32, 'out'), _ld(out, 'out'), P, _stream())
     _check(code, 'amar_chain_f32')

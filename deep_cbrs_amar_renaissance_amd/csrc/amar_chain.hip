@@ -32,6 +32,7 @@ struct ChainArgs {
     const float *A; int64_t lda; int Da; const int32_t *ids_a; int base_a;
     const float *B; int64_t ldb; int Db; const int32_t *ids_b; int base_b;
     const float *wpack; int wpack_floats;
+    int sum_inputs, in_act;             // x = in_act(A[ida] + B[idb]) instead of [A[ida] || B[idb]]
     int n_layers;                       // MFMA layers (a trailing 1-unit layer is the VALU `dot` stage)
     int kt[CHAIN_MAX_LAYERS], nt[CHAIN_MAX_LAYERS], act[CHAIN_MAX_LAYERS];
     int w_off[CHAIN_MAX_LAYERS], b_off[CHAIN_MAX_LAYERS];
@@ -74,7 +75,15 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
                 const int f = 16 * t + 4 * g;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if ((FULL || t < a.kt[0]) && ok) {
-                    if (f < a.Da) v = *reinterpret_cast<const f32x4 *>(a.A + ra * a.lda + f);
+                    if (a.sum_inputs) {
+                        if (f < a.Da) {
+                            const f32x4 va = *reinterpret_cast<const f32x4 *>(a.A + ra * a.lda + f);
+                            const f32x4 vb = *reinterpret_cast<const f32x4 *>(a.B + rb * a.ldb + f);
+                            v = va + vb;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = chain_act(v[r], a.in_act);
+                        }
+                    } else if (f < a.Da) v = *reinterpret_cast<const f32x4 *>(a.A + ra * a.lda + f);
                     else if (f < a.Da + a.Db) v = *reinterpret_cast<const f32x4 *>(a.B + rb * a.ldb + (f - a.Da));
                 }
                 x[t][pt] = v;
@@ -204,16 +213,19 @@ int amar_chain_pack_f32(const float *const *kernels, const float *const *biases,
 
 int amar_chain_f32(const float *A, int64_t lda, int32_t Da, const int32_t *ids_a, int32_t base_a,
                    const float *B, int64_t ldb, int32_t Db, const int32_t *ids_b, int32_t base_b,
+                   int32_t sum_inputs, int32_t in_act,
                    const float *wpack, const int32_t *dims, const int32_t *acts, int32_t n_layers,
                    float *out, int64_t ldo, int64_t P, amar_stream_t stream) {
     if (P < 0 || !A || !wpack || !dims || !acts || !out || Da < 4 || Db < 0) return AMAR_EINVAL;
+    if (sum_inputs && (Db != Da || !B)) return AMAR_EINVAL;
+    if (in_act != AMAR_ACT_NONE && in_act != AMAR_ACT_RELU && in_act != AMAR_ACT_SIGMOID) return AMAR_EINVAL;
     if ((Da & 3) || (Db & 3) || (lda & 3) || lda < Da || !amar_aligned16(A) || !amar_aligned16(wpack)) return AMAR_EINVAL;
     if (Db && (!B || (ldb & 3) || ldb < Db || !amar_aligned16(B))) return AMAR_EINVAL;
-    if (n_layers < 1 || n_layers > CHAIN_MAX_LAYERS || dims[0] != Da + Db) return AMAR_EINVAL;
+    if (n_layers < 1 || n_layers > CHAIN_MAX_LAYERS || dims[0] != (sum_inputs ? Da : Da + Db)) return AMAR_EINVAL;
     ChainArgs a{};
     a.A = A; a.lda = lda; a.Da = Da; a.ids_a = ids_a; a.base_a = base_a;
     a.B = B; a.ldb = ldb; a.Db = Db; a.ids_b = ids_b; a.base_b = base_b;
-    a.wpack = wpack; a.out = out; a.ldo = ldo; a.P = P;
+    a.wpack = wpack; a.out = out; a.ldo = ldo; a.P = P; a.sum_inputs = sum_inputs ? 1 : 0; a.in_act = in_act;
     int maxw = 0, off = 0;
     for (int l = 0; l < n_layers; ++l) {
         const int K = dims[l], N = dims[l + 1], act = acts[l];

@@ -14,6 +14,7 @@ import abc
 import numpy as np
 import torch
 
+from deep_cbrs_amar_renaissance_amd import capi
 from deep_cbrs_amar_renaissance_amd.engine import Model, ids_to_device, to_device_tensor
 from deep_cbrs_amar_renaissance_amd.models.dense import build_dense_network, build_dense_classifier
 from deep_cbrs_amar_renaissance_amd.models.gnn import GCN, GAT, GraphSage, LightGCN, DGCF
@@ -57,17 +58,69 @@ class BasicRS(Model):
             raise NotImplementedError("BasicRS needs at least one tower layer")
         if not self.built:
             self.build_head(u.shape[1], i.shape[1])
-        tu = self.unet.apply2(u, ids_a=u_ids)
-        ti = self.inet.apply2(i, ids_a=i_ids)
-        return self.clf.apply2(tu, ti)                      # Concatenate([u, i]) happens in the kernel's gather
+        towers = self.towers(u, i, u_ids=u_ids, i_ids=i_ids)
+        return self.score_towers(towers, None, None)
 
-    def towers(self, u_table, i_table):
-        """Per-ENTITY tower outputs: Dense stacks act row by row, so unet/inet can run once per user/item
-        instead of once per pair; `score_towers` then only gathers and classifies."""
-        return self.unet.apply2(u_table), self.inet.apply2(i_table)
+    # The classifier's first Dense layer is linear in its concatenated input, [u || i] . W1 = u . W1[:d] + i . W1[d:],
+    # so its two halves ride at the end of the towers (per entity when hoisted) and the pair stage starts at
+    # act(T'u[u] + T'i[i] (+ b1, folded into T'i)): half the per-pair MFMA work of the classifier's first two layers.
+    def _split_plan(self, u_dim, i_dim):
+        """Packed stacks for the split formulation, or None when the fused chain cannot run these shapes."""
+        version = self.weights_version
+        cache = getattr(self, '_split_cache', None)
+        if cache is not None and cache[0] == (version, u_dim, i_dim):
+            return cache[1]
+        plan = None
+        clf, d = list(self.clf.layers), self.dense_units[-1]
+        if len(clf) >= 3:
+            c1 = clf[0].units
+            udims = [u_dim] + [l.units for l in self.unet.layers] + [c1]
+            idims = [i_dim] + [l.units for l in self.inet.layers] + [c1]
+            rdims = [c1] + [l.units for l in clf[1:]]
+            if (capi.chain_supported(udims, u_dim) and capi.chain_supported(idims, i_dim)
+                    and capi.chain_supported(rdims, c1, c1, sum_inputs=True)):
+                w1 = clf[0].kernel.detach().cpu().numpy()
+                b1 = clf[0].bias.detach().cpu().numpy()
+                dev = clf[0].kernel.device
+                np_ = lambda p: p.detach().cpu().numpy()
+                ub, _ = capi.chain_pack([np_(l.kernel) for l in self.unet.layers] + [w1[:d]],
+                                        [np_(l.bias) for l in self.unet.layers] + [0 * b1])
+                ib, _ = capi.chain_pack([np_(l.kernel) for l in self.inet.layers] + [w1[d:]],
+                                        [np_(l.bias) for l in self.inet.layers] + [b1])
+                rb, _ = capi.chain_pack([np_(l.kernel) for l in clf[1:]], [np_(l.bias) for l in clf[1:]])
+                to = lambda x: torch.from_numpy(x).to(dev)
+                plan = {'u': (to(ub), udims, [l.activation for l in self.unet.layers] + [None]),
+                        'i': (to(ib), idims, [l.activation for l in self.inet.layers] + [None]),
+                        'rest': (to(rb), rdims, [l.activation for l in clf[1:]]), 'in_act': clf[0].activation}
+        self._split_cache = ((version, u_dim, i_dim), plan)
+        return plan
 
-    def score_towers(self, tu, ti, u_ids, i_ids, u_base=0, i_base=0):
-        return self.clf.apply2(tu, ti, ids_a=u_ids, base_a=u_base, ids_b=i_ids, base_b=i_base)
+    def towers(self, u_table, i_table, u_ids=None, i_ids=None):
+        """Tower outputs for the given rows (all rows of the tables, or the gathered ids): Dense stacks act row by
+        row, so in hoisted mode unet/inet run once per user/item instead of once per pair."""
+        plan = self._split_plan(u_table.shape[1], i_table.shape[1])
+        if plan is None:
+            return (self.unet.apply2(u_table, ids_a=u_ids), self.inet.apply2(i_table, ids_a=i_ids), False)
+        out = []
+        for key, table, ids in (('u', u_table, u_ids), ('i', i_table, i_ids)):
+            blob, dims, acts = plan[key]
+            m = ids.numel() if ids is not None else table.shape[0]
+            t = torch.empty((m, dims[-1]), dtype=torch.float32, device=table.device)
+            capi.chain(table, blob, dims, acts, t, ids_a=ids)
+            out.append(t)
+        return (out[0], out[1], True)
+
+    def score_towers(self, towers, u_ids, i_ids, u_base=0, i_base=0):
+        tu, ti, split = towers
+        if not split:
+            return self.clf.apply2(tu, ti, ids_a=u_ids, base_a=u_base, ids_b=i_ids, base_b=i_base)
+        plan = self._split_cache[1]
+        blob, dims, acts = plan['rest']
+        m = u_ids.numel() if u_ids is not None else tu.shape[0]
+        out = torch.empty((m, 1), dtype=torch.float32, device=tu.device)
+        capi.chain(tu, blob, dims, acts, out, ids_a=u_ids, base_a=u_base, B=ti, ids_b=i_ids, base_b=i_base,
+                   sum_inputs=True, in_act=plan['in_act'])
+        return out
 
 
 class BasicGNN(Model, abc.ABC):
@@ -102,10 +155,9 @@ class BasicGNN(Model, abc.ABC):
             nu = self.n_users if self.n_users is not None else n
             lo = nu if self.n_users is not None else 0
             hi = nu + self.n_items if (self.n_users is not None and self.n_items is not None) else n
-            tu, ti = self.rs.towers(embeddings[:nu], embeddings[lo:hi])
-            self._towers = (key, tu, ti, lo)
-        _, tu, ti, lo = self._towers
-        return self.rs.score_towers(tu, ti, u, i, 0, lo)
+            self._towers = (key, self.rs.towers(embeddings[:nu], embeddings[lo:hi]), lo)
+        _, towers, lo = self._towers
+        return self.rs.score_towers(towers, u, i, 0, lo)
 
     def _hoist_begin(self, hoist):
         self.gnn.hoist = bool(hoist)

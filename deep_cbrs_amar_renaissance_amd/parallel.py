@@ -99,10 +99,8 @@ class SingleRunner:
         # per-entity towers, then gather + classifier per pair (nothing is cached across steps)
         nu, ni = self.model.n_users, self.model.n_items
         if nu is None or ni is None:
-            tu, ti = self.model.rs.towers(emb, emb)
-            return self.model.rs.score_towers(tu, ti, self.u_ids, self.i_ids)
-        tu, ti = self.model.rs.towers(emb[:nu], emb[nu:nu + ni])
-        return self.model.rs.score_towers(tu, ti, self.u_ids, self.i_ids, 0, nu)
+            return self.model.rs.score_towers(self.model.rs.towers(emb, emb), self.u_ids, self.i_ids)
+        return self.model.rs.score_towers(self.model.rs.towers(emb[:nu], emb[nu:nu + ni]), self.u_ids, self.i_ids, 0, nu)
 
     def last_propagation_ms(self):
         e0, e1 = self._events
@@ -179,8 +177,8 @@ class PartitionedGCNRunner:
         if self.timing:
             e1.record()
             self._events = (e0, e1)
-        tu, ti = self.model.rs.towers(emb, emb)           # replicated per-entity towers over the padded table
-        return self.model.rs.score_towers(tu, ti, self.u_ids, self.i_ids)
+        towers = self.model.rs.towers(emb, emb)           # replicated per-entity towers over the padded table
+        return self.model.rs.score_towers(towers, self.u_ids, self.i_ids)
 
     def last_propagation_ms(self):
         if not self._events:

@@ -158,7 +158,9 @@ int amar_dense_f32(const float *X, int64_t ldx, const int32_t *ids,
  * src/models/basic.py:31-37,72-75, src/models/hybrid.py:72-89, src/models/dense.py:4-17).
  * For every row p < P:
  *     x = [ A[ida(p), 0:Da] || B[idb(p), 0:Db] ],  ida(p) = ids_a ? ids_a[p] - base_a : p   (same for B)
- *     x = act_l( x . W_l + b_l )  for l = 0 .. n_layers-1      dims[0] = Da + Db, dims[l+1] = units of layer l
+ *         or, with sum_inputs != 0 (Da == Db):  x = in_act( A[ida(p)] + B[idb(p)] ) — the form a Dense layer over a
+ *         concatenation takes once its two halves have been applied per entity (x.W = u.W[:d] + i.W[d:])
+ *     x = act_l( x . W_l + b_l )  for l = 0 .. n_layers-1      dims[0] = Da + Db (Da if sum_inputs), dims[l+1] = units of layer l
  * out[p, 0:dims[n_layers]] = x.  A trailing 1-unit layer (the sigmoid scorer) is evaluated as a
  * dot product and written to out[p * ldo].  Activations stay in registers between layers
  * (fp32 MFMA 16x16x4); weights come pre-packed in fragment order from amar_chain_pack_f32 and
@@ -173,6 +175,7 @@ int amar_chain_pack_f32(const float *const *kernels, const float *const *biases,
                         int32_t n_layers, float *out);
 int amar_chain_f32(const float *A, int64_t lda, int32_t Da, const int32_t *ids_a, int32_t base_a,
                    const float *B, int64_t ldb, int32_t Db, const int32_t *ids_b, int32_t base_b,
+                   int32_t sum_inputs, int32_t in_act,
                    const float *wpack, const int32_t *dims, const int32_t *acts, int32_t n_layers,
                    float *out, int64_t ldo, int64_t P, amar_stream_t stream);
 

@@ -385,3 +385,25 @@ def test_spmm_xcd_sliced(hip, F, n):
     hip.spmm_xs(xs, y, None, acc_in=s1, acc_out=e, acc_div=3)
     x1 = A @ x.astype(np.float64)
     assert rel_err(e.cpu().numpy(), (x + x1 + A @ x1) / 3) < 3e-6
+
+
+@pytest.mark.parametrize('D,units', [(48, [48, 1]), (64, [64, 1]), (16, [24, 8]), (128, [64, 64, 1])])
+def test_chain_sum_inputs(hip, D, units):
+    """x = relu(A[ids_a] + B[ids_b]) as the chain's input: a Dense layer over a concatenation, split per entity."""
+    rng = np.random.default_rng(D)
+    P = 3001
+    A = rng.standard_normal((200, D)).astype(np.float32)
+    B = rng.standard_normal((150, D)).astype(np.float32)
+    ia, ib = rng.integers(0, 200, P).astype(np.int32), rng.integers(0, 150, P).astype(np.int32)
+    dims = [D] + units
+    ks = [rng.uniform(-0.4, 0.4, (dims[k], dims[k + 1])).astype(np.float32) for k in range(len(units))]
+    bs = [rng.uniform(-0.2, 0.2, dims[k + 1]).astype(np.float32) for k in range(len(units))]
+    acts = ['relu'] * (len(units) - 1) + ['sigmoid' if units[-1] == 1 else 'relu']
+    assert hip.chain_supported(dims, D, D, sum_inputs=True)
+    blob, _ = hip.chain_pack(ks, bs)
+    out = torch.empty((P, units[-1]), device=DEV)
+    hip.chain(_t(A), _t(blob), dims, acts, out, ids_a=_t(ia), B=_t(B), ids_b=_t(ib), sum_inputs=True, in_act='relu')
+    x = np.maximum(A[ia].astype(np.float64) + B[ib].astype(np.float64), 0)
+    for k, b, a in zip(ks, bs, acts):
+        x = ol.dense(x, k.astype(np.float64), b.astype(np.float64), a)
+    assert rel_err(out.cpu().numpy(), x) < 5e-6

@@ -24,13 +24,13 @@ def main():
         emb = torch.randn((nu + ni, F), device=dev)
         u = torch.randint(0, nu, (P,), device=dev, generator=g).to(torch.int32)
         i = (torch.randint(0, ni, (P,), device=dev, generator=g) + nu).to(torch.int32)
-        tu, ti = rs.towers(emb[:nu], emb[nu:])
+        tw = rs.towers(emb[:nu], emb[nu:])
         med_t, _ = timeit(lambda: rs.towers(emb[:nu], emb[nu:]), reps=10)
-        med_c, _ = timeit(lambda: rs.score_towers(tu, ti, u, i, 0, nu), reps=10)
+        med_c, _ = timeit(lambda: rs.score_towers(tw, u, i, 0, nu), reps=10)
         d = dense[-1]
         flops = P * (2 * d * clf[0] + clf[0] * clf[1]) * 2.0
         us = torch.sort(u).values
-        med_s, _ = timeit(lambda: rs.score_towers(tu, ti, us, i, 0, nu), reps=10)
+        med_s, _ = timeit(lambda: rs.score_towers(tw, us, i, 0, nu), reps=10)
         print('{} PT={}: towers {:.3f} ms, pair clf {:.3f} ms ({:.2f} G pairs/s, {:.1f} TFLOP/s), user-sorted pairs {:.3f} ms'.format(
             cfg_name, os.environ.get('AMAR_CHAIN_PT', 'default'), med_t, med_c, P / med_c / 1e6, flops / med_c / 1e9, med_s), flush=True)
 

@@ -83,12 +83,11 @@ def main():
         emb = model.gnn(None)
         nu, ni = data['n_users'], data['n_items']
         def head():
-            tu, ti = model.rs.towers(emb[:nu], emb[nu:nu + ni])
-            return model.rs.score_towers(tu, ti, u, i, 0, nu)
+            return model.rs.score_towers(model.rs.towers(emb[:nu], emb[nu:nu + ni]), u, i, 0, nu)
         med, _ = timeit(head, reps=5)
-        tu, ti = model.rs.towers(emb[:nu], emb[nu:nu + ni])
+        tw = model.rs.towers(emb[:nu], emb[nu:nu + ni])
         med_t, _ = timeit(lambda: model.rs.towers(emb[:nu], emb[nu:nu + ni]), reps=5)
-        med_c, _ = timeit(lambda: model.rs.score_towers(tu, ti, u, i, 0, nu), reps=5)
+        med_c, _ = timeit(lambda: model.rs.score_towers(tw, u, i, 0, nu), reps=5)
         print('  towers (per entity): {:8.3f} ms   pair clf (gather + 48-48-48-1): {:8.3f} ms -> {:6.2f} G pairs/s'.format(med_t, med_c, P / med_c / 1e6))
         med_f, _ = timeit(lambda: model.rs([emb, emb], u_ids=u, i_ids=i), reps=5)
         print('  per-pair towers + clf (faithful form): {:8.3f} ms'.format(med_f))

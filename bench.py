@@ -73,7 +73,8 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    force_dist = bool(os.environ.get('AMAR_FORCE_DIST'))      # rehearse the RCCL path with a single rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         dist.init_process_group('nccl')
     assert world == args.gpus, "--gpus {} but WORLD_SIZE={}".format(args.gpus, world)
@@ -104,7 +105,8 @@ def main():
     del data
     torch.cuda.empty_cache()
 
-    runner = parallel.make_runner(model, u_all, i_all, rank, world)
+    runner = parallel.make_runner(model, u_all, i_all, rank, world) if not force_dist else \
+        parallel.PartitionedGCNRunner(model, u_all, i_all, rank, world)
 
     spmm_events = []
     raw_gcn_layer, raw_spmm_sj, raw_spmm_xs = capi.gcn_layer, capi.spmm_sj, capi.spmm_xs
@@ -120,7 +122,7 @@ def main():
     capi.gcn_layer, capi.spmm_sj, capi.spmm_xs = timed(raw_gcn_layer), timed(raw_spmm_sj), timed(raw_spmm_xs)   # whichever form the layer dispatches to
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_dist:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -134,7 +136,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     capi.gcn_layer, capi.spmm_sj, capi.spmm_xs = raw_gcn_layer, raw_spmm_sj, raw_spmm_xs
-    if world > 1:
+    if world > 1 or force_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -144,7 +146,7 @@ def main():
     nnz_local = runner.local_nnz
     f = GRID1['n_hiddens'][0]
     from deep_cbrs_amar_renaissance_amd.utilities.math import spmm_kind
-    kind = spmm_kind(model.gnn.gnn_layers.adj_matrix, f) if world == 1 else 'csr'
+    kind = spmm_kind(model.gnn.gnn_layers.adj_matrix, f) if (world == 1 and not force_dist) else 'csr'
     alg_bytes = nnz_local * 8 + (rows_local + 1) * 4 + (n_nodes + rows_local) * f * 4
     avg_ms = float(np.mean(spmm_ms)) if spmm_ms else float('nan')
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
@@ -178,7 +180,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         torch.distributed.destroy_process_group()
 
 

@@ -421,19 +421,29 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void spmm_xs_partial_k
         }
     };
 
-    for (int base = beg; base < end; base += 2 * EPS) {              // two steps in flight: both index loads, then both gathers
-        const int i0 = base + s, i1 = base + EPS + s;
-        const bool ok0 = i0 < end, ok1 = i1 < end;
-        int cw0 = 0, cw1 = 0;
-        float v0 = 0.f, v1 = 0.f;
-        if (ok0) { cw0 = a.colidx[i0]; v0 = a.vals[i0]; }
-        if (ok1) { cw1 = a.colidx[i1]; v1 = a.vals[i1]; }
-        float4 x0 = f4_zero(), x1 = f4_zero();
-        if (ok0) x0 = *reinterpret_cast<const float4 *>(a.X + (int64_t)(cw0 & 0x3ffffff) * a.ldx + 4 * q);
-        if (ok1) x1 = *reinterpret_cast<const float4 *>(a.X + (int64_t)(cw1 & 0x3ffffff) * a.ldx + 4 * q);
-        reduce_step(ok0 ? (int)((unsigned)cw0 >> 26) : 0x7fffffff, make_float4(v0 * x0.x, v0 * x0.y, v0 * x0.z, v0 * x0.w), ok0);
-        if (base + EPS < end)
-            reduce_step(ok1 ? (int)((unsigned)cw1 >> 26) : 0x7fffffff, make_float4(v1 * x1.x, v1 * x1.y, v1 * x1.z, v1 * x1.w), ok1);
+    constexpr int UNR = 4;                                           // steps in flight: all index loads, then all gathers
+    for (int base = beg; base < end; base += UNR * EPS) {
+        int cw[UNR];
+        float v[UNR];
+        bool ok[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int i = base + u * EPS + s;
+            ok[u] = i < end;
+            cw[u] = 0; v[u] = 0.f;
+            if (ok[u]) { cw[u] = a.colidx[i]; v[u] = a.vals[i]; }
+        }
+        float4 x[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            x[u] = f4_zero();
+            if (ok[u]) x[u] = *reinterpret_cast<const float4 *>(a.X + (int64_t)(cw[u] & 0x3ffffff) * a.ldx + 4 * q);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            if (base + u * EPS < end)                                 // wave-uniform
+                reduce_step(ok[u] ? (int)((unsigned)cw[u] >> 26) : 0x7fffffff,
+                            make_float4(v[u] * x[u].x, v[u] * x[u].y, v[u] * x[u].z, v[u] * x[u].w), ok[u]);
     }
     if (lane < nr) {
         float *out = a.P + ((int64_t)k * a.n_rows + r0 + lane) * F;

@@ -95,3 +95,26 @@ def hybrid_head_to_oracle(rs):
 
 def rel_err(got, want):
     return float(np.abs(np.asarray(got, dtype=np.float64) - want).max() / max(1e-30, np.abs(want).max()))
+
+
+def load_oracle_weights(model, gnn, head):
+    """Copy an oracle weight dict (oracle/models.py layout) into a product Basic* model in place."""
+    import torch
+
+    def put(param, value):
+        with torch.no_grad():
+            param.copy_(torch.from_numpy(np.ascontiguousarray(value, dtype=np.float32)).reshape(param.shape))
+
+    seq = model.gnn.gnn_layers
+    put(seq.embeddings, gnn['embeddings'])
+    for layer, lw in zip(seq.seq_layers, gnn['layers']):
+        if 'kernel' in lw:
+            put(layer.kernel, lw['kernel'])
+            put(layer.bias, lw['bias'])
+        if 'attn_self' in lw:
+            put(layer.attn_kernel_self, lw['attn_self'])
+            put(layer.attn_kernel_neighs, lw['attn_neigh'])
+    for name in ('unet', 'inet', 'clf'):
+        for layer, (w, b) in zip(getattr(model.rs, name).layers, head[name]):
+            put(layer.kernel, w)
+            put(layer.bias, b)

@@ -407,3 +407,15 @@ def test_chain_sum_inputs(hip, D, units):
     for k, b, a in zip(ks, bs, acts):
         x = ol.dense(x, k.astype(np.float64), b.astype(np.float64), a)
     assert rel_err(out.cpu().numpy(), x) < 5e-6
+
+
+def test_spmm_xcd_sliced_is_reproducible(hip):
+    """LDS float adds inside the XS partial kernel follow a fixed order: two launches give the same bits."""
+    from deep_cbrs_amar_renaissance_amd.utilities.math import XcdSliced
+    m = (_rand_csr(3000, 40, seed=3, dup=True) + sparse.identity(3000, dtype=np.float32, format='coo')).tocoo()
+    xs = XcdSliced.from_csr(_dev_csr(m))
+    x = _t(np.random.default_rng(0).standard_normal((3000, 8)).astype(np.float32))
+    y1, y2 = torch.empty((3000, 8), device=DEV), torch.empty((3000, 8), device=DEV)
+    hip.spmm_xs(xs, x, y1)
+    hip.spmm_xs(xs, x, y2)
+    assert torch.equal(y1, y2)

@@ -347,8 +347,25 @@ struct XsArgs {
 // Lanes take CONSECUTIVE entries of the wave's (64-row block, slice) range: lane = q * EPS + s handles feature
 // quad q of entry s of the current step (EPS = 64 / (F/4) entries per step), so colidx/vals loads are coalesced
 // and every lane gathers.  The row of an entry rides in bits 26..31 of its column word (row & 63); since entries
-// are sorted by row, aligned groups of 8 lanes mostly hold one row: see reduce_step below.  Sums land in the
-// wave's LDS accumulator [F][64 rows] and leave as one coalesced [64, F] block of partial rows.
+// are sorted by row, a DPP segmented inclusive scan over s (add the value d lanes back iff its key is equal)
+// leaves each row-run's sum in the run's last lane, which adds it to the wave's LDS accumulator [64 rows][F].
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_pull(float v) {     // lanes outside ROW_MASK / without a source get 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_pull_key(int k) {     // ... and key -1 (matches no row)
+    return __builtin_amdgcn_update_dpp(-1, k, CTRL, ROW_MASK, 0xF, false);
+}
+
+template <int CTRL, int ROW_MASK, int DIST, int EPS>
+__device__ __forceinline__ void seg_scan_step(float4 &p, int key, int s) {
+    const int kprev = dpp_pull_key<CTRL, ROW_MASK>(key);
+    const float m = (kprev == key && (DIST == 0 || s >= DIST)) ? 1.f : 0.f;
+    p.x = fmaf(m, dpp_pull<CTRL, ROW_MASK>(p.x), p.x); p.y = fmaf(m, dpp_pull<CTRL, ROW_MASK>(p.y), p.y);
+    p.z = fmaf(m, dpp_pull<CTRL, ROW_MASK>(p.z), p.z); p.w = fmaf(m, dpp_pull<CTRL, ROW_MASK>(p.w), p.w);
+}
+
 template <int F>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void spmm_xs_partial_kernel(const XsArgs a) {
     constexpr int LPN = F / 4, EPS = AMAR_WAVE / LPN;
@@ -367,30 +384,40 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void spmm_xs_partial_k
     for (int c = 0; c < F; ++c) acc[c * AMAR_WAVE + lane] = 0.f;     // wave-private region; LDS ops of a wave stay in order
     const int q = lane / EPS, s = lane % EPS;
 
-    // Reduce-by-row of one step.  Entries are sorted by row and a row's run in a slice is ~24-34 entries long, so most
-    // aligned groups of G = 8 lanes hold ONE row: those are summed with three DPP adds (quad_perm xor 1, xor 2, then
-    // row_shl:4) and only the group's first lane adds to the wave's LDS accumulator; lanes of the few groups that
-    // contain a row boundary add individually.  Same-address LDS adds inside one instruction come from at most
-    // EPS/8 group leaders (or the <= 8 lanes of a mixed group).
-    constexpr int G = EPS >= 8 ? 8 : EPS;
     auto reduce_step = [&](int key, float4 p, bool ok) {
-        int kq = __builtin_amdgcn_update_dpp(0, key, 0x00, 0xF, 0xF, true);           // quad_perm [0,0,0,0]: quad's first key
-        if (G == 8) {
-            const int kprev = __builtin_amdgcn_update_dpp(0, kq, 0x114, 0xF, 0xF, true);   // row_shr:4
-            kq = (lane & 4) ? kprev : kq;                                            // the 8-group's first key
+        // whole step one row-run (the common case for long rows): a plain strided wave sum, result in every lane
+        const int kfirst = __builtin_amdgcn_readfirstlane(key);
+        if (EPS >= 16 && __all(key == kfirst || !ok) && kfirst != 0x7fffffff) {   // (EPS < 16: a 16-lane DPP row spans several q groups)
+            // lanes = q * EPS + s: sum over s inside each group of EPS lanes
+            if (EPS >= 2) { p.x += dpp_mov<0x121>(p.x); p.y += dpp_mov<0x121>(p.y); p.z += dpp_mov<0x121>(p.z); p.w += dpp_mov<0x121>(p.w); }
+            if (EPS >= 4) { p.x += dpp_mov<0x122>(p.x); p.y += dpp_mov<0x122>(p.y); p.z += dpp_mov<0x122>(p.z); p.w += dpp_mov<0x122>(p.w); }
+            if (EPS >= 8) { p.x += dpp_mov<0x124>(p.x); p.y += dpp_mov<0x124>(p.y); p.z += dpp_mov<0x124>(p.z); p.w += dpp_mov<0x124>(p.w); }
+            if (EPS >= 16) { p.x += dpp_mov<0x128>(p.x); p.y += dpp_mov<0x128>(p.y); p.z += dpp_mov<0x128>(p.z); p.w += dpp_mov<0x128>(p.w); }
+            if (EPS >= 32) { float o, w; w = swap16_other(p.x, o); p.x = o + w; w = swap16_other(p.y, o); p.y = o + w;
+                             w = swap16_other(p.z, o); p.z = o + w; w = swap16_other(p.w, o); p.w = o + w; }
+            if (EPS >= 64) { float o, w; w = swap32_other(p.x, o); p.x = o + w; w = swap32_other(p.y, o); p.y = o + w;
+                             w = swap32_other(p.z, o); p.z = o + w; w = swap32_other(p.w, o); p.w = o + w; }
+            if (s == 0) {
+                float *dst = acc + kfirst;
+                atomicAdd(dst + (4 * q + 0) * AMAR_WAVE, p.x); atomicAdd(dst + (4 * q + 1) * AMAR_WAVE, p.y);
+                atomicAdd(dst + (4 * q + 2) * AMAR_WAVE, p.z); atomicAdd(dst + (4 * q + 3) * AMAR_WAVE, p.w);
+            }
+            return;
         }
-        const unsigned long long same = __ballot(key == kq);
-        const bool uniform = ((same >> (lane & ~(G - 1))) & ((1ull << G) - 1)) == ((1ull << G) - 1);
-        float4 r = p;
-        r.x += dpp_mov<0xB1>(r.x); r.y += dpp_mov<0xB1>(r.y); r.z += dpp_mov<0xB1>(r.z); r.w += dpp_mov<0xB1>(r.w);   // xor 1
-        r.x += dpp_mov<0x4E>(r.x); r.y += dpp_mov<0x4E>(r.y); r.z += dpp_mov<0x4E>(r.z); r.w += dpp_mov<0x4E>(r.w);   // xor 2
-        if (G == 8) { r.x += dpp_mov<0x104>(r.x); r.y += dpp_mov<0x104>(r.y); r.z += dpp_mov<0x104>(r.z); r.w += dpp_mov<0x104>(r.w); }
-        const bool leader = uniform && (lane & (G - 1)) == 0;
-        if (ok && (leader || !uniform)) {
-            const float4 t = leader ? r : p;
-            float *dst = acc + key;                                   // acc[feature][row]
-            atomicAdd(dst + (4 * q + 0) * AMAR_WAVE, t.x); atomicAdd(dst + (4 * q + 1) * AMAR_WAVE, t.y);
-            atomicAdd(dst + (4 * q + 2) * AMAR_WAVE, t.z); atomicAdd(dst + (4 * q + 3) * AMAR_WAVE, t.w);
+        // segmented inclusive scan over s (row_shr:d = 0x110 + d; row_bcast15 = 0x142; row_bcast31 = 0x143)
+        if (EPS >= 2) seg_scan_step<0x111, 0xF, (EPS < 16 ? 1 : 0), EPS>(p, key, s);
+        if (EPS >= 4) seg_scan_step<0x112, 0xF, (EPS < 16 ? 2 : 0), EPS>(p, key, s);
+        if (EPS >= 8) seg_scan_step<0x114, 0xF, (EPS < 16 ? 4 : 0), EPS>(p, key, s);
+        if (EPS >= 16) seg_scan_step<0x118, 0xF, 0, EPS>(p, key, s);
+        if (EPS >= 32) seg_scan_step<0x142, 0xA, 0, EPS>(p, key, s);
+        if (EPS >= 64) seg_scan_step<0x143, 0xC, 0, EPS>(p, key, s);
+        // a run ends where the next entry has another key (or the step ends)
+        const int knext = __shfl_down(key, 1, 64);
+        const bool run_end = ok && (s == EPS - 1 || knext != key);
+        if (run_end) {
+            float *dst = acc + key;                                   // acc[feature][row]: lanes of one instruction hit distinct rows
+            atomicAdd(dst + (4 * q + 0) * AMAR_WAVE, p.x); atomicAdd(dst + (4 * q + 1) * AMAR_WAVE, p.y);
+            atomicAdd(dst + (4 * q + 2) * AMAR_WAVE, p.z); atomicAdd(dst + (4 * q + 3) * AMAR_WAVE, p.w);
         }
     };
 

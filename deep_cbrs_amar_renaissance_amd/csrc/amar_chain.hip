@@ -61,31 +61,15 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t stride = (int64_t)gridDim.x * 4 * pairs_per_wave;
 
-    // Row ids of the NEXT iteration are fetched while the current one computes, so an iteration exposes one load
-    // latency (the row gather) instead of two dependent ones (ids, then rows).
-    int64_t ra_n[PT], rb_n[PT];
-    auto fetch_ids = [&](int64_t base_n) {
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) {
-            const int64_t p = base_n + 16 * pt + col;
-            const bool ok = p < a.P;
-            ra_n[pt] = ok ? (a.ids_a ? (int64_t)a.ids_a[p] - a.base_a : p) : 0;
-            rb_n[pt] = (ok && a.Db) ? (a.ids_b ? (int64_t)a.ids_b[p] - a.base_b : p) : 0;
-        }
-    };
-    fetch_ids(wave0 * pairs_per_wave);
-
     for (int64_t base = wave0 * pairs_per_wave; base < a.P; base += stride) {
         f32x4 x[MAXT][PT];
         // ---- gather + concatenate: lane (g, col) holds features 16t+4g .. +3 of pair base + 16*pt + col
-        int64_t ra_c[PT], rb_c[PT];
-#pragma unroll
-        for (int pt = 0; pt < PT; ++pt) { ra_c[pt] = ra_n[pt]; rb_c[pt] = rb_n[pt]; }
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
             const int64_t p = base + 16 * pt + col;
             const bool ok = p < a.P;
-            const int64_t ra = ra_c[pt], rb = rb_c[pt];
+            const int64_t ra = ok ? (a.ids_a ? (int64_t)a.ids_a[p] - a.base_a : p) : 0;
+            const int64_t rb = (ok && a.Db) ? (a.ids_b ? (int64_t)a.ids_b[p] - a.base_b : p) : 0;
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
                 const int f = 16 * t + 4 * g;
@@ -105,7 +89,6 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
                 x[t][pt] = v;
             }
         }
-        if (base + stride < a.P) fetch_ids(base + stride);
         // ---- dense layers on MFMA, activations stay in registers
         for (int l = 0; l < a.n_layers; ++l) {
             const int KT = FULL ? MAXT : a.kt[l], NT = FULL ? MAXT : a.nt[l];

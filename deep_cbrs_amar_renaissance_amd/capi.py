@@ -41,6 +41,14 @@ SIGNATURES = {
     'amar_chain_f32': (ctypes.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _I32, _P, _I32, _I32, _I32, _P, _P, _P, _I32, _P, _I64, _I64, _P]),
     'amar_copy_columns_f32': (ctypes.c_int, [_P, _I64, _P, _I32, _P, _I64, _I64, _I32, _P]),
     'amar_reduce_layers_f32': (ctypes.c_int, [_P, _I64, _I32, _I32, _P, _I64, _I64, _I32, _P]),
+    'amar_act_bwd_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I32, _I32, _P]),
+    'amar_wgrad_scratch_floats': (ctypes.c_int64, [_I64, _I32, _I32]),
+    'amar_wgrad_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I32, _I32, _P, _P, _P, _P]),
+    'amar_bce_grad_f32': (ctypes.c_int, [_P, _I64, _P, _P, _P, _I64, _P]),
+    'amar_scatter_add_rows_f32': (ctypes.c_int, [_P, _I64, _P, _I32, _P, _I64, _I64, _I32, _P]),
+    'amar_add_inplace_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I32, _F32, _P]),
+    'amar_transpose_f32': (ctypes.c_int, [_P, _I32, _I32, _P, _P]),
+    'amar_adam_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _F32, _F32, _F32, _F32, _F32, _P]),
     'amar_topk_segmented_f32': (ctypes.c_int, [_P, _P, _P, _I32, _I32, _P, _P, _P]),
 }
 
@@ -348,3 +356,72 @@ def topk_segmented(seg_ptr, item_ids, scores, k):
         _ptr(scores, torch.float32, 'scores'), n_users, k, _ptr(out_items), _ptr(out_scores), _stream())
     _check(code, 'amar_topk_segmented_f32')
     return out_items, out_scores
+
+
+# ---- training step ----------------------------------------------------------------------------------------------
+def act_bwd(dY, Y, dZ, act):
+    """dZ = dY * act'(Y) with Y the layer output (dZ may alias dY)."""
+    if tuple(dY.shape) != tuple(Y.shape) or tuple(dZ.shape) != tuple(Y.shape):
+        raise ValueError("act_bwd: shapes differ")
+    code = load().amar_act_bwd_f32(_ptr(dY, torch.float32, 'dY'), _ld(dY, 'dY'), _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y'),
+                                   _ptr(dZ, torch.float32, 'dZ'), _ld(dZ, 'dZ'), Y.shape[0], Y.shape[1], ACT_CODES[act], _stream())
+    _check(code, 'amar_act_bwd_f32')
+
+
+def wgrad(X, dZ, dW=None, db=None):
+    """dW = X^T . dZ and / or db = column sums of dZ (deterministic two-stage reduction)."""
+    M, N = dZ.shape
+    K = X.shape[1] if X is not None else 0
+    if dW is not None and (X is None or X.shape[0] != M or tuple(dW.shape) != (K, N) or not dW.is_contiguous()):
+        raise ValueError("wgrad: X [M, K], dZ [M, N], dW [K, N] contiguous expected")
+    if db is not None and (db.numel() != N or not db.is_contiguous()):
+        raise ValueError("wgrad: db must be a contiguous [N] vector")
+    lib = load()
+    n_scratch = lib.amar_wgrad_scratch_floats(M, K if dW is not None else 0, N)
+    scratch = torch.empty(max(int(n_scratch), 1), dtype=torch.float32, device=dZ.device)
+    code = lib.amar_wgrad_f32(_ptr(X if dW is not None else None, torch.float32, 'X'), _ld(X, 'X') if dW is not None else 0,
+                              _ptr(dZ, torch.float32, 'dZ'), _ld(dZ, 'dZ'), M, K, N,
+                              _ptr(dW, torch.float32, 'dW'), _ptr(db, torch.float32, 'db'), _ptr(scratch), _stream())
+    _check(code, 'amar_wgrad_f32')
+
+
+def bce_grad(p, y, dz, loss_terms):
+    B = y.numel()
+    code = load().amar_bce_grad_f32(_ptr(p, torch.float32, 'p'), _ld(p, 'p') if p.dim() == 2 else 1, _ptr(y, torch.float32, 'y'),
+                                    _ptr(dz, torch.float32, 'dz'), _ptr(loss_terms, torch.float32, 'loss_terms'), B, _stream())
+    _check(code, 'amar_bce_grad_f32')
+
+
+def scatter_add_rows(src, ids, dst, base=0):
+    if src.shape[0] != ids.numel() or src.shape[1] != dst.shape[1]:
+        raise ValueError("scatter_add_rows: src [M, W], ids [M], dst [*, W] expected")
+    code = load().amar_scatter_add_rows_f32(_ptr(src, torch.float32, 'src'), _ld(src, 'src'), _ptr(ids, torch.int32, 'ids'), int(base),
+                                            _ptr(dst, torch.float32, 'dst'), _ld(dst, 'dst'), src.shape[0], src.shape[1], _stream())
+    _check(code, 'amar_scatter_add_rows_f32')
+
+
+def add_inplace(dst, src, scale=1.0):
+    if tuple(dst.shape) != tuple(src.shape):
+        raise ValueError("add_inplace: shapes differ")
+    code = load().amar_add_inplace_f32(_ptr(dst, torch.float32, 'dst'), _ld(dst, 'dst'), _ptr(src, torch.float32, 'src'), _ld(src, 'src'),
+                                       dst.shape[0], dst.shape[1], float(scale), _stream())
+    _check(code, 'amar_add_inplace_f32')
+
+
+def transpose(src):
+    K, N = src.shape
+    if not src.is_contiguous():
+        raise ValueError("transpose: contiguous [K, N] expected")
+    dst = torch.empty((N, K), dtype=torch.float32, device=src.device)
+    _check(load().amar_transpose_f32(_ptr(src, torch.float32, 'src'), K, N, _ptr(dst), _stream()), 'amar_transpose_f32')
+    return dst
+
+
+def adam(w, g, m, v, lr_t, beta_1, beta_2, epsilon, l2=0.0):
+    if not (w.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()) or \
+            not (w.numel() == g.numel() == m.numel() == v.numel()):
+        raise ValueError("adam: contiguous tensors of equal size expected")
+    code = load().amar_adam_f32(_ptr(w, torch.float32, 'w'), _ptr(g, torch.float32, 'g'), _ptr(m, torch.float32, 'm'),
+                                _ptr(v, torch.float32, 'v'), w.numel(), float(lr_t), float(beta_1), float(beta_2), float(epsilon),
+                                float(l2), _stream())
+    _check(code, 'amar_adam_f32')

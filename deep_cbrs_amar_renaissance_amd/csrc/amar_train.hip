@@ -1,0 +1,199 @@
+// Training-step kernels: what Keras' fit() adds around the forward hot path.
+// Reference semantics: binary_crossentropy + L2 regularisers + Adam as configured in
+// config.yaml:50-58 and applied by experiment.py:155-188; reverse-mode derivatives of the Dense /
+// GCNConv / LightGCNConv / embedding_lookup operations of src/models/{basic,gnn}.py.
+// All element-wise or small-reduction work: HBM-bound, one float (or a few) per lane, fixed
+// summation orders (the weight gradient is reduced in two stages, never with float atomics).
+#include "amar_common.h"
+
+namespace {
+
+constexpr int WG_ROWS = 512;      // rows per partial block of the weight-gradient kernel
+
+__device__ __forceinline__ float act_grad(float dy, float y, int act) {
+    if (act == AMAR_ACT_RELU) return y > 0.f ? dy : 0.f;
+    if (act == AMAR_ACT_SIGMOID) return dy * y * (1.f - y);
+    return dy;
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ dY, int64_t ldd, const float *__restrict__ Y,
+                                                      int64_t ldy, float *__restrict__ dZ, int64_t ldz, int64_t M, int N, int act) {
+    const int64_t total = M * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / N;
+        const int c = (int)(i - r * N);
+        dZ[r * ldz + c] = act_grad(dY[r * ldd + c], Y[r * ldy + c], act);
+    }
+}
+
+// partial[chunk][k][n] = sum over the chunk's rows of X[m][k] * dZ[m][n]; partial_b[chunk][n] = sum dZ[m][n]
+// block = 16 x 16 threads = one 16x16 tile of dW; grid = (row chunks, K tiles, N tiles)
+__global__ __launch_bounds__(256) void wgrad_partial_kernel(const float *__restrict__ X, int64_t ldx, const float *__restrict__ dZ,
+                                                            int64_t ldz, int64_t M, int K, int N, float *__restrict__ part_w,
+                                                            float *__restrict__ part_b) {
+    __shared__ float xs[64][17], zs[64][17];
+    const int tk = threadIdx.x >> 4, tn = threadIdx.x & 15;
+    const int k0 = blockIdx.y * 16, n0 = blockIdx.z * 16;
+    const int64_t m_beg = (int64_t)blockIdx.x * WG_ROWS, m_end = min(M, m_beg + WG_ROWS);
+    float acc = 0.f, accb = 0.f;
+    for (int64_t m0 = m_beg; m0 < m_end; m0 += 64) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+            const int r = e >> 4, c = e & 15;
+            const int64_t m = m0 + r;
+            xs[r][c] = (X && m < m_end && k0 + c < K) ? X[m * ldx + k0 + c] : 0.f;
+            zs[r][c] = (m < m_end && n0 + c < N) ? dZ[m * ldz + n0 + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) {
+            acc = fmaf(xs[r][tk], zs[r][tn], acc);
+            accb += zs[r][tn];
+        }
+    }
+    if (part_w && k0 + tk < K && n0 + tn < N) part_w[((int64_t)blockIdx.x * K + k0 + tk) * N + n0 + tn] = acc;
+    if (part_b && blockIdx.y == 0 && tk == 0 && n0 + tn < N) part_b[(int64_t)blockIdx.x * N + n0 + tn] = accb;
+}
+
+// out[e] = part[0][e] + part[1][e] + ... in chunk order (fixed order -> reproducible), optionally accumulated into out
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ part, int n_chunks, int64_t size,
+                                                              float *__restrict__ out) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < size; e += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int c = 0; c < n_chunks; ++c) s += part[(int64_t)c * size + e];
+        out[e] = s;
+    }
+}
+
+// Keras backend binary_crossentropy on probabilities: p clipped to [eps, 1-eps], log(p + eps); mean over the batch.
+__global__ __launch_bounds__(256) void bce_grad_kernel(const float *__restrict__ p, int64_t ldp, const float *__restrict__ y,
+                                                       float *__restrict__ dz, float *__restrict__ loss_terms, int64_t B) {
+    const float eps = 1e-7f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < B; i += (int64_t)gridDim.x * blockDim.x) {
+        const float pi = p[i * ldp], yi = y[i];
+        const float pc = fminf(fmaxf(pi, eps), 1.f - eps);
+        loss_terms[i] = -(yi * logf(pc + eps) + (1.f - yi) * logf(1.f - pc + eps));
+        const bool inside = pi >= eps && pi <= 1.f - eps;
+        const float dp = inside ? -(yi / (pc + eps) - (1.f - yi) / (1.f - pc + eps)) / (float)B : 0.f;
+        dz[i] = dp * pi * (1.f - pi);                                // through the sigmoid of the last Dense layer
+    }
+}
+
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float *__restrict__ src, int64_t lds, const int32_t *__restrict__ ids,
+                                                               int base, float *__restrict__ dst, int64_t ldd, int64_t M, int W) {
+    const int64_t total = M * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / W;
+        const int c = (int)(i - r * W);
+        atomicAdd(dst + ((int64_t)ids[r] - base) * ldd + c, src[r * lds + c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void add_inplace_kernel(float *__restrict__ dst, int64_t ldd, const float *__restrict__ src, int64_t lds,
+                                                          int64_t M, int W, float scale) {
+    const int64_t total = M * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / W;
+        const int c = (int)(i - r * W);
+        dst[r * ldd + c] += scale * src[r * lds + c];
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ src, int K, int N, float *__restrict__ dst) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < K * N; e += gridDim.x * blockDim.x) {
+        const int k = e / N, n = e - k * N;
+        dst[n * K + k] = src[e];
+    }
+}
+
+// keras.optimizers.Adam: m, v moments; lr_t carries the bias correction; the L2 regulariser's gradient 2*l2*w is folded in
+__global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m,
+                                                   float *__restrict__ v, int64_t n, float lr_t, float b1, float b2, float eps,
+                                                   float l2x2) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float wi = w[i];
+        const float gi = g[i] + l2x2 * wi;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        w[i] = wi - lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+unsigned grid1d(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+int amar_act_bwd_f32(const float *dY, int64_t ldd, const float *Y, int64_t ldy, float *dZ, int64_t ldz,
+                     int64_t M, int32_t N, int32_t act, amar_stream_t stream) {
+    if (M < 0 || N < 1 || !dY || !Y || !dZ || ldd < N || ldy < N || ldz < N) return AMAR_EINVAL;
+    if (act != AMAR_ACT_NONE && act != AMAR_ACT_RELU && act != AMAR_ACT_SIGMOID) return AMAR_EINVAL;
+    if (M == 0) return AMAR_OK;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(grid1d(M * N)), dim3(256), 0, static_cast<hipStream_t>(stream), dY, ldd, Y, ldy, dZ, ldz, M, N, act);
+    return amar_check_launch();
+}
+
+int64_t amar_wgrad_scratch_floats(int64_t M, int32_t K, int32_t N) {
+    if (M < 0 || K < 0 || N < 1) return AMAR_EINVAL;
+    const int64_t chunks = (M + WG_ROWS - 1) / WG_ROWS;
+    return chunks * ((int64_t)K * N + N);
+}
+
+int amar_wgrad_f32(const float *X, int64_t ldx, const float *dZ, int64_t ldz, int64_t M, int32_t K, int32_t N,
+                   float *dW, float *db, float *scratch, amar_stream_t stream) {
+    if (M < 1 || N < 1 || !dZ || ldz < N || !scratch || (!dW && !db)) return AMAR_EINVAL;
+    if (dW && (!X || K < 1 || ldx < K)) return AMAR_EINVAL;
+    const int Kk = dW ? K : 0;
+    const int64_t chunks = (M + WG_ROWS - 1) / WG_ROWS;
+    if (chunks > 0x7fffffff) return AMAR_EUNSUPPORTED;
+    float *part_w = dW ? scratch : nullptr;
+    float *part_b = db ? scratch + chunks * (int64_t)Kk * N : nullptr;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid((unsigned)chunks, (unsigned)(dW ? (K + 15) / 16 : 1), (unsigned)((N + 15) / 16));
+    hipLaunchKernelGGL(wgrad_partial_kernel, grid, dim3(256), 0, st, dW ? X : nullptr, ldx, dZ, ldz, M, Kk ? Kk : 1, N, part_w, part_b);
+    if (dW) hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid1d((int64_t)K * N)), dim3(256), 0, st, part_w, (int)chunks, (int64_t)K * N, dW);
+    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid1d(N)), dim3(256), 0, st, part_b, (int)chunks, (int64_t)N, db);
+    return amar_check_launch();
+}
+
+int amar_bce_grad_f32(const float *p, int64_t ldp, const float *y, float *dz, float *loss_terms, int64_t B, amar_stream_t stream) {
+    if (B < 1 || !p || !y || !dz || !loss_terms || ldp < 1) return AMAR_EINVAL;
+    hipLaunchKernelGGL(bce_grad_kernel, dim3(grid1d(B)), dim3(256), 0, static_cast<hipStream_t>(stream), p, ldp, y, dz, loss_terms, B);
+    return amar_check_launch();
+}
+
+int amar_scatter_add_rows_f32(const float *src, int64_t lds, const int32_t *ids, int32_t base, float *dst, int64_t ldd,
+                              int64_t M, int32_t W, amar_stream_t stream) {
+    if (M < 0 || W < 1 || !src || !ids || !dst || lds < W || ldd < W) return AMAR_EINVAL;
+    if (M == 0) return AMAR_OK;
+    hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid1d(M * W)), dim3(256), 0, static_cast<hipStream_t>(stream), src, lds, ids, base, dst, ldd, M, W);
+    return amar_check_launch();
+}
+
+int amar_add_inplace_f32(float *dst, int64_t ldd, const float *src, int64_t lds, int64_t M, int32_t W, float scale, amar_stream_t stream) {
+    if (M < 0 || W < 1 || !src || !dst || lds < W || ldd < W) return AMAR_EINVAL;
+    if (M == 0) return AMAR_OK;
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(grid1d(M * W)), dim3(256), 0, static_cast<hipStream_t>(stream), dst, ldd, src, lds, M, W, scale);
+    return amar_check_launch();
+}
+
+int amar_transpose_f32(const float *src, int32_t K, int32_t N, float *dst, amar_stream_t stream) {
+    if (K < 1 || N < 1 || !src || !dst) return AMAR_EINVAL;
+    hipLaunchKernelGGL(transpose_kernel, dim3(grid1d((int64_t)K * N)), dim3(256), 0, static_cast<hipStream_t>(stream), src, K, N, dst);
+    return amar_check_launch();
+}
+
+int amar_adam_f32(float *w, const float *g, float *m, float *v, int64_t n, float lr_t, float beta_1, float beta_2,
+                  float epsilon, float l2, amar_stream_t stream) {
+    if (n < 0 || !w || !g || !m || !v) return AMAR_EINVAL;
+    if (n == 0) return AMAR_OK;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n)), dim3(256), 0, static_cast<hipStream_t>(stream), w, g, m, v, n, lr_t, beta_1, beta_2, epsilon, 2.f * l2);
+    return amar_check_launch();
+}
+
+}  // extern "C"

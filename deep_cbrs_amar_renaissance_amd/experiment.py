@@ -6,8 +6,8 @@ sections), same resolution of model / loader classes from name strings, same per
 catch-and-continue.  Differences, all forced by scope:
 
 * tracking goes to a JSON-lines run log instead of MLflow (not installed);
-* ``Model.fit`` is not implemented yet (training is the next scope row), so ``train()``
-  builds dataset + model and evaluates the seed-initialised weights;
+* ``Model.fit`` is implemented for the GCN and LightGCN recommenders (training.py); for the other stacks
+  ``fit`` raises NotImplementedError and ``train()`` goes on to evaluate the seed-initialised weights;
 * Precision/Recall/F1@k come from a host-side evaluator instead of ``binaries/mimir.jar``.
 
 Run from the directory that holds ``config.yaml`` and the ``datasets/`` tree:

@@ -159,6 +159,11 @@ class BasicGNN(Model, abc.ABC):
         _, towers, lo = self._towers
         return self.rs.score_towers(towers, u, i, 0, lo)
 
+    def fit(self, sequence, epochs=1, **kwargs):
+        """Keras ``fit``: BCE + L2 + Adam over the batches of `sequence` (training.py; GCN and LightGCN stacks)."""
+        from deep_cbrs_amar_renaissance_amd import training
+        return training.fit(self, sequence, epochs=epochs, **kwargs)
+
     def _hoist_begin(self, hoist):
         self.gnn.hoist = bool(hoist)
 

@@ -1,0 +1,217 @@
+"""Training step for the Basic GNN recommenders — what ``model.fit`` runs per batch.
+
+Mirrors what Keras does under `Experimenter.train` (`/root/reference/src/experiment.py:155-188`):
+binary cross-entropy (`config.yaml:58`) on the sigmoid scores of `BasicGNN.call` (full-graph
+propagation re-run for EVERY batch, `basic.py:61-63`), plus the L2 regularisers carried by the
+node table and the GCN kernels/biases (`gnn.py:45, 293-294`), differentiated and applied with
+Adam (`config.yaml:52-56`; Keras defaults beta_2 = 0.999, epsilon = 1e-7).
+
+Forward activations come from the same HIP kernels as inference; the reverse pass uses the
+training kernels of `csrc/amar_train.hip` (activation backward, two-stage deterministic weight
+gradients, row scatter-add for the embedding lookup, Adam) and reuses the forward SpMM for
+A_hat^T . dZ (A_hat is symmetric) and the forward GEMM for dX = dZ . W^T.
+
+Implemented for GCN stacks with 'concatenation' and LightGCN stacks ('mean'); GraphSAGE / GAT
+reverse passes and the hybrid head are not implemented yet and raise.
+"""
+import numpy as np
+import torch
+
+from deep_cbrs_amar_renaissance_amd import capi
+from deep_cbrs_amar_renaissance_amd.engine import ids_to_device, to_device_tensor
+from deep_cbrs_amar_renaissance_amd.layers.gcn_conv import GCNConv
+from deep_cbrs_amar_renaissance_amd.layers.lightgcn_conv import LightGCNConv
+from deep_cbrs_amar_renaissance_amd.utilities.math import spmm_kind
+
+
+def _spmm(a, x, out):
+    """out = A_hat . x with whichever image of A_hat the forward pass uses for this width."""
+    kind = spmm_kind(a, x.shape[1])
+    if kind == 'xs':
+        capi.spmm_xs(a.xcd_sliced(), x, out)
+    elif kind == 'sj':
+        capi.spmm_sj(a.sliced(x.shape[1]), x, out)
+    else:
+        capi.spmm_csr(a.rowptr, a.colidx, a.vals, x, out)
+    return out
+
+
+class _DenseTape:
+    """Forward of a Dense stack that keeps every layer's input and output, and its reverse pass."""
+
+    def __init__(self, stack):
+        self.layers = list(stack.layers)
+        self.inputs, self.outputs = [], []
+
+    def forward(self, x):
+        self.inputs, self.outputs = [], []
+        for layer in self.layers:
+            y = torch.empty((x.shape[0], layer.units), dtype=torch.float32, device=x.device)
+            capi.dense(x, layer.kernel, layer.bias, y, act=layer.activation)
+            self.inputs.append(x)
+            self.outputs.append(y)
+            x = y
+        return x
+
+    def backward(self, dy, grads, last_is_dz=False):
+        """dy: gradient w.r.t. the stack's output (or, with last_is_dz, already w.r.t. the last pre-activation).
+        Fills grads[param] for every kernel/bias; returns the gradient w.r.t. the stack's input."""
+        for k in range(len(self.layers) - 1, -1, -1):
+            layer, x, y = self.layers[k], self.inputs[k], self.outputs[k]
+            if last_is_dz and k == len(self.layers) - 1:
+                dz = dy
+            else:
+                dz = torch.empty_like(y)
+                capi.act_bwd(dy, y, dz, layer.activation)
+            dw, db = torch.empty_like(layer.kernel), torch.empty_like(layer.bias)
+            capi.wgrad(x, dz, dw, db)
+            grads[layer.kernel], grads[layer.bias] = dw, db
+            dx = torch.empty((x.shape[0], layer.kernel.shape[0]), dtype=torch.float32, device=x.device)
+            capi.dense(dz, capi.transpose(layer.kernel.detach()), None, dx, act=None)
+            dy = dx
+        return dy
+
+
+class Trainer:
+    """Holds the Adam state of a Basic{GCN,LightGCN} model and performs training batches."""
+
+    def __init__(self, model, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        seq = model.gnn.gnn_layers
+        layers = list(seq.seq_layers)
+        if layers and all(isinstance(l, GCNConv) for l in layers) and seq.final_node == 'concatenation':
+            self.kind = 'gcn'
+        elif layers and all(isinstance(l, LightGCNConv) for l in layers) and seq.final_node == 'mean':
+            self.kind = 'lightgcn'
+        else:
+            raise NotImplementedError("training is implemented for GCN ('concatenation') and LightGCN stacks; "
+                                      "GraphSAGE / GAT reverse passes are not built yet")
+        if not model.rs.built:
+            model.rs.build_head(model.gnn.output_dim(), model.gnn.output_dim())
+        self.model, self.seq = model, seq
+        self.lr, self.b1, self.b2, self.eps = float(learning_rate), float(beta_1), float(beta_2), float(epsilon)
+        self.t = 0
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.m = {p: torch.zeros_like(p) for p in self.params}
+        self.v = {p: torch.zeros_like(p) for p in self.params}
+        self.unet, self.inet, self.clf = _DenseTape(model.rs.unet), _DenseTape(model.rs.inet), _DenseTape(model.rs.clf)
+
+    @staticmethod
+    def _l2(param):
+        reg = getattr(param, 'regularizer', None)
+        return float(reg.l2) if reg is not None else 0.0
+
+    # -- one batch ------------------------------------------------------------------------------------------------
+    def loss_and_grads(self, u_ids, i_ids, y):
+        """Forward + reverse pass of one batch. Returns (data loss + regularisation loss, {param: gradient})."""
+        model, seq = self.model, self.seq
+        u, i = ids_to_device(u_ids), ids_to_device(i_ids)
+        yv = to_device_tensor(np.asarray(y, dtype=np.float32) if not isinstance(y, torch.Tensor) else y)
+        b = u.numel()
+        dev = seq.embeddings.device
+        with torch.no_grad():
+            e = seq(None)                                            # full-graph propagation, every batch (basic.py:61-63)
+            f = e.shape[1]
+            gu = torch.empty((b, f), dtype=torch.float32, device=dev)
+            gi = torch.empty((b, f), dtype=torch.float32, device=dev)
+            capi.copy_columns(e, gu, ids=u)
+            capi.copy_columns(e, gi, ids=i)
+            tu, ti = self.unet.forward(gu), self.inet.forward(gi)
+            d = tu.shape[1]
+            cat = torch.empty((b, 2 * d), dtype=torch.float32, device=dev)
+            capi.copy_columns(tu, cat[:, :d])
+            capi.copy_columns(ti, cat[:, d:])
+            p = self.clf.forward(cat)
+            # ---- loss and its gradient through the final sigmoid
+            dz = torch.empty((b, 1), dtype=torch.float32, device=dev)
+            terms = torch.empty(b, dtype=torch.float32, device=dev)
+            capi.bce_grad(p, yv, dz, terms)
+            grads = {}
+            dcat = self.clf.backward(dz, grads, last_is_dz=True)
+            dgu = self.unet.backward(dcat[:, :d], grads)
+            dgi = self.inet.backward(dcat[:, d:], grads)
+            de = torch.zeros((e.shape[0], f), dtype=torch.float32, device=dev)
+            capi.scatter_add_rows(dgu, u, de)
+            capi.scatter_add_rows(dgi, i, de)
+            self._propagation_backward(e, de, grads)
+            loss = float(terms.sum().item()) / b
+            for prm in self.params:
+                l2 = self._l2(prm)
+                if l2:
+                    loss += l2 * float((prm.detach().double() ** 2).sum().item())
+        return loss, grads
+
+    def _propagation_backward(self, e, de, grads):
+        seq, a = self.seq, self.seq.adj_matrix
+        layers = list(seq.seq_layers)
+        n, dev = e.shape[0], e.device
+        emb = seq.embeddings
+        if self.kind == 'gcn':
+            widths = seq.layer_widths()
+            offs = np.cumsum([0] + widths)
+            sl = lambda t, k: t[:, offs[k]:offs[k + 1]]
+            for k in range(len(layers) - 1, -1, -1):
+                layer = layers[k]
+                c = widths[k + 1]
+                dzk = torch.empty((n, c), dtype=torch.float32, device=dev)
+                capi.act_bwd(sl(de, k + 1), sl(e, k + 1), dzk, 'relu')
+                dh = torch.empty((n, c), dtype=torch.float32, device=dev)
+                _spmm(a, dzk, dh)                                     # A_hat^T = A_hat
+                dw, db = torch.empty_like(layer.kernel), torch.empty_like(layer.bias)
+                capi.wgrad(sl(e, k), dh, dw, None)
+                capi.wgrad(None, dzk, None, db)
+                grads[layer.kernel], grads[layer.bias] = dw, db
+                back = torch.empty((n, widths[k]), dtype=torch.float32, device=dev)
+                capi.rowwise_xw(dh, capi.transpose(layer.kernel.detach()), back)
+                capi.add_inplace(sl(de, k), back)
+            g0 = torch.empty_like(emb)
+            capi.copy_columns(sl(de, 0), g0)
+            grads[emb] = g0
+        else:
+            n_terms = len(layers) + 1
+            g0 = torch.zeros_like(emb)
+            capi.add_inplace(g0, de, 1.0 / n_terms)
+            acc = g0.clone()
+            for _ in layers:
+                nxt = torch.empty_like(acc)
+                _spmm(a, acc, nxt)
+                capi.add_inplace(g0, nxt)
+                acc = nxt
+            grads[emb] = g0
+
+    def apply_gradients(self, grads):
+        self.t += 1
+        lr_t = self.lr * np.sqrt(1.0 - self.b2 ** self.t) / (1.0 - self.b1 ** self.t)
+        with torch.no_grad():
+            for prm in self.params:
+                g = grads[prm]
+                capi.adam(prm.data.view(-1), g.contiguous().view(-1), self.m[prm].view(-1), self.v[prm].view(-1),
+                          lr_t, self.b1, self.b2, self.eps, l2=self._l2(prm))
+                prm._version  # noqa: B018  (data-level update; bump below keeps hoisting caches honest)
+                prm.add_(0)                                            # bumps the autograd version counter
+
+    def train_batch(self, u_ids, i_ids, y):
+        loss, grads = self.loss_and_grads(u_ids, i_ids, y)
+        self.apply_gradients(grads)
+        return loss
+
+
+def fit(model, sequence, epochs=1, callbacks=None, verbose=True, **kwargs):
+    """Keras-style ``fit`` over a batch Sequence: ``epochs`` passes, ``on_epoch_end`` reshuffles (datasets.py:205-213)."""
+    opt = getattr(model, 'optimizer', None)
+    hp = {k: getattr(opt, k) for k in ('learning_rate', 'beta_1', 'beta_2', 'epsilon') if hasattr(opt, k)}
+    trainer = getattr(model, '_trainer', None)
+    if trainer is None:
+        trainer = model._trainer = Trainer(model, **hp)
+    history = []
+    for epoch in range(int(epochs)):
+        total, count = 0.0, 0
+        for b in range(len(sequence)):
+            (u, i), y = sequence[b]
+            total += trainer.train_batch(u, i, y) * len(y)
+            count += len(y)
+        history.append(total / max(count, 1))
+        if verbose:
+            print("Epoch {}/{} - loss: {:.4f}".format(epoch + 1, epochs, history[-1]))
+        if hasattr(sequence, 'on_epoch_end'):
+            sequence.on_epoch_end()
+    return {'loss': history}

@@ -190,6 +190,36 @@ int amar_copy_columns_f32(const float *src, int64_t lds, const int32_t *ids, int
 int amar_reduce_layers_f32(const float *cat, int64_t ld, int32_t n_layers, int32_t width, float *out, int64_t ldo,
                            int64_t n_rows, int32_t mean, amar_stream_t stream);
 
+/* ---- training step -------------------------------------------------------
+ * What Keras' fit() adds around the forward path for one batch (src/experiment.py:155-188, config.yaml:50-58):
+ * reverse-mode derivatives of Dense / GCNConv / LightGCNConv / embedding_lookup, binary cross-entropy,
+ * L2 regularisers (src/models/gnn.py:45,293-294) and the Adam update.  The forward kernels above are reused
+ * (A_hat is symmetric, so the SpMM is its own transpose; dX = dZ . W^T is amar_dense_f32 on the transposed kernel).
+ *
+ * amar_act_bwd_f32          dZ = dY * act'(Y)        (Y = the layer's OUTPUT; relu / sigmoid / none)
+ * amar_wgrad_f32            dW[K,N] = X^T . dZ and/or db[N] = column sums of dZ, reduced in two stages in a fixed
+ *                           order (no float atomics); scratch must hold amar_wgrad_scratch_floats(M, K, N) floats
+ * amar_bce_grad_f32         Keras backend binary_crossentropy on probabilities (epsilon 1e-7, mean over B):
+ *                           loss_terms[i] and dz[i] = dL/dlogit_i through the final sigmoid
+ * amar_scatter_add_rows_f32 dst[ids[m] - base, :] += src[m, :]   (gradient of embedding_lookup; float atomics)
+ * amar_add_inplace_f32      dst += scale * src on strided [M, W] blocks
+ * amar_transpose_f32        dst[N,K] = src[K,N]^T
+ * amar_adam_f32             keras.optimizers.Adam on a flat parameter: g' = g + 2*l2*w; m, v moments; lr_t = the
+ *                           bias-corrected step lr * sqrt(1 - b2^t) / (1 - b1^t);  w -= lr_t * m / (sqrt(v) + epsilon)
+ */
+int amar_act_bwd_f32(const float *dY, int64_t ldd, const float *Y, int64_t ldy, float *dZ, int64_t ldz,
+                     int64_t M, int32_t N, int32_t act, amar_stream_t stream);
+int64_t amar_wgrad_scratch_floats(int64_t M, int32_t K, int32_t N);
+int amar_wgrad_f32(const float *X, int64_t ldx, const float *dZ, int64_t ldz, int64_t M, int32_t K, int32_t N,
+                   float *dW, float *db, float *scratch, amar_stream_t stream);
+int amar_bce_grad_f32(const float *p, int64_t ldp, const float *y, float *dz, float *loss_terms, int64_t B, amar_stream_t stream);
+int amar_scatter_add_rows_f32(const float *src, int64_t lds, const int32_t *ids, int32_t base, float *dst, int64_t ldd,
+                              int64_t M, int32_t W, amar_stream_t stream);
+int amar_add_inplace_f32(float *dst, int64_t ldd, const float *src, int64_t lds, int64_t M, int32_t W, float scale, amar_stream_t stream);
+int amar_transpose_f32(const float *src, int32_t K, int32_t N, float *dst, amar_stream_t stream);
+int amar_adam_f32(float *w, const float *g, float *m, float *v, int64_t n, float lr_t, float beta_1, float beta_2,
+                  float epsilon, float l2, amar_stream_t stream);
+
 /* ---- ranking ------------------------------------------------------------------------------
  * Per-user top-k over that user's own test pairs (src/utilities/metrics.py:11-34):
  * pairs are grouped by user (seg_ptr[n_users+1] into item_ids/scores); for each user the k

@@ -1,0 +1,156 @@
+"""Oracle for the training step.  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Restates what Keras does for one batch of `Experimenter.train` (experiment.py:155-188, config.yaml:50-58):
+
+    forward   BasicGNN.call (basic.py:61-75): full-graph propagation, lookup, BasicRS
+    loss      binary_crossentropy (Keras backend form, epsilon 1e-7, mean over the batch)
+              + L2 regularisers l2 * sum(w^2) on the node table and the conv kernels / biases
+                (gnn.py:45, 293-294; Dense layers of the head carry none)
+    backward  manual reverse pass below; `torch_grads` is an independent torch-autograd check
+    update    Adam(learning_rate, beta_1, beta_2=0.999, epsilon=1e-7) as keras.optimizers.Adam applies it:
+              lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t);  w -= lr_t * m / (sqrt(v) + eps)
+
+Covers the GCN and LightGCN stacks with the 'concatenation' / 'mean' reductions of the BASELINE configs.
+"""
+import numpy as np
+
+from oracle import graph as ograph
+
+EPS = 1e-7
+
+
+def _dense_fwd(x, net, acts):
+    cache = []
+    for (w, b), act in zip(net, acts):
+        z = x @ w + b
+        y = np.maximum(z, 0) if act == 'relu' else (1.0 / (1.0 + np.exp(-z)) if act == 'sigmoid' else z)
+        cache.append((x, y))
+        x = y
+    return x, cache
+
+
+def _dense_bwd(dy, net, acts, cache):
+    grads = []
+    for (w, b), act, (x, y) in zip(reversed(net), reversed(acts), reversed(cache)):
+        dz = dy * (y > 0) if act == 'relu' else (dy * y * (1 - y) if act == 'sigmoid' else dy)
+        grads.append((x.T @ dz, dz.sum(0)))
+        dy = dz @ w.T
+    return dy, list(reversed(grads))
+
+
+def loss_and_grads(adj, gnn, head, u_ids, i_ids, y, l2=0.0, dtype=np.float64):
+    """Returns (loss, grads) with grads shaped like the weight containers of oracle/models.py."""
+    kind = gnn['kind']
+    a_hat = ograph.gcn_filter(adj).astype(dtype)
+    x0 = gnn['embeddings'].astype(dtype)
+    cast = lambda net: [(w.astype(dtype), b.astype(dtype)) for w, b in net]
+    unet, inet, clf = cast(head['unet']), cast(head['inet']), cast(head['clf'])
+    # ---- forward
+    hs, pre = [x0], []
+    x = x0
+    for lw in gnn['layers']:
+        if kind == 'gcn':
+            h = x @ lw['kernel'].astype(dtype)
+            x_new = np.maximum(a_hat @ h + lw['bias'].astype(dtype), 0)
+            pre.append(x)
+        else:
+            x_new = a_hat @ x
+        hs.append(x_new)
+        x = x_new
+    if kind == 'gcn':
+        e = np.concatenate(hs, axis=1)
+    else:
+        e = sum(hs) / len(hs)
+    tower_acts = ['relu'] * len(unet)
+    clf_acts = ['relu'] * (len(clf) - 1) + ['sigmoid']
+    tu, cu = _dense_fwd(e[u_ids], unet, tower_acts)
+    ti, ci = _dense_fwd(e[i_ids], inet, tower_acts)
+    p, cc = _dense_fwd(np.concatenate([tu, ti], axis=1), clf, clf_acts)
+    p = p[:, 0]
+    yv = np.asarray(y, dtype=dtype)
+    pc = np.clip(p, EPS, 1 - EPS)
+    bce = -np.mean(yv * np.log(pc + EPS) + (1 - yv) * np.log(1 - pc + EPS))
+    reg = l2 * np.sum(x0 * x0)
+    if kind == 'gcn':
+        for lw in gnn['layers']:
+            reg += l2 * (np.sum(lw['kernel'].astype(dtype) ** 2) + np.sum(lw['bias'].astype(dtype) ** 2))
+    loss = bce + reg
+    # ---- backward
+    inside = (p >= EPS) & (p <= 1 - EPS)
+    dp = -(yv / (pc + EPS) - (1 - yv) / (1 - pc + EPS)) / len(p) * inside
+    dcat, g_clf = _dense_bwd(dp[:, None], clf, clf_acts, cc)
+    d = tu.shape[1]
+    dgu, g_unet = _dense_bwd(dcat[:, :d], unet, tower_acts, cu)
+    dgi, g_inet = _dense_bwd(dcat[:, d:], inet, tower_acts, ci)
+    de = np.zeros_like(e)
+    np.add.at(de, u_ids, dgu)
+    np.add.at(de, i_ids, dgi)
+    g_layers = []
+    if kind == 'gcn':
+        widths = [h.shape[1] for h in hs]
+        offs = np.cumsum([0] + widths)
+        dxs = [de[:, offs[k]:offs[k + 1]].copy() for k in range(len(hs))]
+        for k in range(len(gnn['layers']) - 1, -1, -1):
+            lw = gnn['layers'][k]
+            dz = dxs[k + 1] * (hs[k + 1] > 0)
+            dh = a_hat.T @ dz
+            g_layers.append({'kernel': pre[k].T @ dh + 2 * l2 * lw['kernel'].astype(dtype),
+                             'bias': dz.sum(0) + 2 * l2 * lw['bias'].astype(dtype)})
+            dxs[k] = dxs[k] + dh @ lw['kernel'].astype(dtype).T
+        g_layers.reverse()
+        dx0 = dxs[0]
+    else:
+        g = de / len(hs)
+        dx0 = g.copy()
+        acc = g
+        for _ in gnn['layers']:
+            acc = a_hat.T @ acc
+            dx0 = dx0 + acc
+        # d/dX0 of (X0 + A X0 + A^2 X0 + ...)/n summed term by term: g + A^T g + (A^T)^2 g + ...
+        g_layers = [{} for _ in gnn['layers']]
+    grads = {'gnn': {'embeddings': dx0 + 2 * l2 * x0, 'layers': g_layers},
+             'head': {'unet': g_unet, 'inet': g_inet, 'clf': g_clf}}
+    return float(loss), grads, p
+
+
+def adam_update(w, g, m, v, t, lr=1e-3, b1=0.9, b2=0.999, eps=1e-7):
+    """One keras.optimizers.Adam step (t = 1 for the first step); returns (w, m, v)."""
+    m = b1 * m + (1 - b1) * g
+    v = b2 * v + (1 - b2) * g * g
+    lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+    return w - lr_t * m / (np.sqrt(v) + eps), m, v
+
+
+def torch_grads(adj, gnn, head, u_ids, i_ids, y, l2=0.0):
+    """Independent check: the same loss written with torch ops (float64, CPU) and differentiated by autograd."""
+    import torch
+    a = ograph.gcn_filter(adj).tocoo()
+    a_t = torch.sparse_coo_tensor(np.stack([a.row, a.col]), a.data.astype(np.float64), a.shape).coalesce()
+    T = lambda arr: torch.tensor(np.asarray(arr, dtype=np.float64), requires_grad=True)
+    x0 = T(gnn['embeddings'])
+    layers = [{k: T(v) for k, v in lw.items()} for lw in gnn['layers']]
+    nets = {name: [(T(w), T(b)) for w, b in head[name]] for name in ('unet', 'inet', 'clf')}
+    hs, x = [x0], x0
+    for lw in layers:
+        x = torch.relu(torch.sparse.mm(a_t, x @ lw['kernel']) + lw['bias']) if gnn['kind'] == 'gcn' else torch.sparse.mm(a_t, x)
+        hs.append(x)
+    e = torch.cat(hs, 1) if gnn['kind'] == 'gcn' else sum(hs) / len(hs)
+
+    def run(net, v, last_sigmoid=False):
+        for k, (w, b) in enumerate(net):
+            v = v @ w + b
+            v = torch.sigmoid(v) if (last_sigmoid and k == len(net) - 1) else torch.relu(v)
+        return v
+    u = torch.as_tensor(np.asarray(u_ids), dtype=torch.long)
+    i = torch.as_tensor(np.asarray(i_ids), dtype=torch.long)
+    p = run(nets['clf'], torch.cat([run(nets['unet'], e[u]), run(nets['inet'], e[i])], 1), True)[:, 0]
+    yv = torch.tensor(np.asarray(y, dtype=np.float64))
+    pc = torch.clamp(p, EPS, 1 - EPS)
+    loss = -torch.mean(yv * torch.log(pc + EPS) + (1 - yv) * torch.log(1 - pc + EPS)) + l2 * (x0 ** 2).sum()
+    if gnn['kind'] == 'gcn':
+        for lw in layers:
+            loss = loss + l2 * ((lw['kernel'] ** 2).sum() + (lw['bias'] ** 2).sum())
+    loss.backward()
+    g = lambda t: t.grad.numpy() if t.grad is not None else np.zeros(tuple(t.shape))
+    return float(loss), {'gnn': {'embeddings': g(x0), 'layers': [{k: g(v) for k, v in lw.items()} for lw in layers]},
+                         'head': {name: [(g(w), g(b)) for w, b in nets[name]] for name in nets}}

@@ -1,0 +1,163 @@
+"""GPU parity of the training step against oracle/train.py (pytest -m gpu)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import train as otrain
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+CFG = dict(embedding_dim=8, n_hiddens=[8, 8], n_layers=2, dense_units=[24, 24], clf_units=[48, 48], l2_regularizer=1e-4)
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def test_training_kernels(hip):
+    rng = np.random.default_rng(0)
+    M, K, N = 1300, 40, 24
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    yv = np.maximum(rng.standard_normal((M, N)), 0).astype(np.float32)
+    dy = rng.standard_normal((M, N)).astype(np.float32)
+    dz = torch.empty((M, N), device=DEV)
+    hip.act_bwd(_t(dy), _t(yv), dz, 'relu')
+    assert np.array_equal(dz.cpu().numpy(), dy * (yv > 0))
+    s = 1 / (1 + np.exp(-yv))
+    hip.act_bwd(_t(dy), _t(s.astype(np.float32)), dz, 'sigmoid')
+    assert helpers.rel_err(dz.cpu().numpy(), dy * s * (1 - s)) < 1e-6
+    dw, db = torch.empty((K, N), device=DEV), torch.empty(N, device=DEV)
+    hip.wgrad(_t(x), _t(dy), dw, db)
+    assert helpers.rel_err(dw.cpu().numpy(), x.astype(np.float64).T @ dy) < 2e-6
+    assert helpers.rel_err(db.cpu().numpy(), dy.astype(np.float64).sum(0)) < 2e-6
+    db2 = torch.empty(N, device=DEV)
+    hip.wgrad(None, _t(dy), None, db2)
+    assert torch.equal(db, db2)
+    dw2 = torch.empty((K, N), device=DEV)
+    hip.wgrad(_t(x), _t(dy), dw2, None)
+    assert torch.equal(dw, dw2), "two-stage reduction: reproducible bits"
+    # BCE gradient
+    p = rng.uniform(0, 1, 500).astype(np.float32); p[:3] = [0.0, 1.0, 5e-8]
+    lab = rng.integers(0, 2, 500).astype(np.float32)
+    dzb, terms = torch.empty((500, 1), device=DEV), torch.empty(500, device=DEV)
+    hip.bce_grad(_t(p.reshape(-1, 1)), _t(lab), dzb, terms)
+    pc = np.clip(p.astype(np.float64), 1e-7, 1 - 1e-7)
+    want_terms = -(lab * np.log(pc + 1e-7) + (1 - lab) * np.log(1 - pc + 1e-7))
+    inside = (p >= 1e-7) & (p <= 1 - 1e-7)
+    want_dz = -(lab / (pc + 1e-7) - (1 - lab) / (1 - pc + 1e-7)) / 500 * inside * p * (1 - p)
+    assert helpers.rel_err(terms.cpu().numpy(), want_terms) < 1e-5 and helpers.rel_err(dzb.cpu().numpy()[:, 0], want_dz) < 1e-5
+    # scatter-add, in-place add, transpose, Adam
+    ids = rng.integers(5, 60, 2000).astype(np.int32)
+    src = rng.standard_normal((2000, 12)).astype(np.float32)
+    dst = torch.zeros((55, 20), device=DEV)
+    hip.scatter_add_rows(_t(src), _t(ids), dst[:, 4:16], base=5)
+    want = np.zeros((55, 12)); np.add.at(want, ids - 5, src)
+    assert helpers.rel_err(dst.cpu().numpy()[:, 4:16], want) < 1e-5 and float(dst[:, :4].abs().max()) == 0
+    a, b = _t(src[:50]), _t(src[50:100])
+    hip.add_inplace(a, b, 0.5)
+    assert helpers.rel_err(a.cpu().numpy(), src[:50] + 0.5 * src[50:100]) < 1e-6
+    assert np.array_equal(hip.transpose(_t(x)).cpu().numpy(), x.T)
+    w, g = rng.standard_normal(1000).astype(np.float32), rng.standard_normal(1000).astype(np.float32)
+    m, v = rng.standard_normal(1000).astype(np.float32) * 0.1, rng.uniform(0, 1, 1000).astype(np.float32)
+    wd, md, vd = _t(w), _t(m), _t(v)
+    lr_t = 1e-3 * np.sqrt(1 - 0.999 ** 3) / (1 - 0.9 ** 3)
+    hip.adam(wd, _t(g), md, vd, lr_t, 0.9, 0.999, 1e-7, l2=1e-3)
+    g2 = g.astype(np.float64) + 2e-3 * w
+    m2, v2 = 0.9 * m + 0.1 * g2, 0.999 * v + 0.001 * g2 * g2
+    assert helpers.rel_err(wd.cpu().numpy(), w - lr_t * m2 / (np.sqrt(v2) + 1e-7)) < 1e-6
+    assert helpers.rel_err(md.cpu().numpy(), m2) < 1e-6 and helpers.rel_err(vd.cpu().numpy(), v2) < 1e-6
+
+
+def _flatten_oracle_grads(model, grads):
+    """Oracle gradient containers -> {product parameter: ndarray}."""
+    out = {}
+    seq = model.gnn.gnn_layers
+    out[seq.embeddings] = grads['gnn']['embeddings']
+    for layer, gl in zip(seq.seq_layers, grads['gnn']['layers']):
+        if gl:
+            out[layer.kernel], out[layer.bias] = gl['kernel'], gl['bias']
+    for name in ('unet', 'inet', 'clf'):
+        for layer, (gw, gb) in zip(getattr(model.rs, name).layers, grads['head'][name]):
+            out[layer.kernel], out[layer.bias] = gw, gb
+    return out
+
+
+@pytest.mark.parametrize('cls', ['BasicGCN', 'BasicLightGCN'])
+@pytest.mark.parametrize('graph', ['ui', 'uip'])
+def test_gradients_match_oracle(hip, cls, graph):
+    from deep_cbrs_amar_renaissance_amd import engine, training
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    engine.set_seed(5)
+    g = helpers.tiny_graph(n_users=80, n_items=60, n_ratings=1500, seed=9,
+                           n_props=30 if graph == 'uip' else 0, n_links=90 if graph == 'uip' else 0)
+    model = getattr(basic, cls)(g['adj'], **CFG)
+    helpers.randomize_biases(model, seed=6)
+    rng = np.random.default_rng(2)
+    y = rng.integers(0, 2, len(g['u_ids']))
+    trainer = training.Trainer(model)
+    loss, grads = trainer.loss_and_grads(g['u_ids'], g['i_ids'], y)
+    want_loss, want, _ = otrain.loss_and_grads(g['adj'], helpers.gnn_to_oracle(model.gnn), helpers.basic_head_to_oracle(model.rs),
+                                               g['u_ids'], g['i_ids'], y, l2=1e-4)
+    assert abs(loss - want_loss) < 1e-5
+    flat = _flatten_oracle_grads(model, want)
+    assert set(flat) == set(grads)
+    for prm, gw in flat.items():
+        assert helpers.rel_err(grads[prm].cpu().numpy().reshape(gw.shape), gw) < 2e-4, tuple(prm.shape)
+
+
+def test_adam_steps_match_oracle(hip):
+    """Three optimizer steps on one batch: weights follow the oracle's Adam to fp32 rounding."""
+    from deep_cbrs_amar_renaissance_amd import engine, training
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    engine.set_seed(8)
+    g = helpers.tiny_graph(n_users=80, n_items=60, n_ratings=1500, seed=3)
+    model = basic.BasicGCN(g['adj'], **CFG)
+    helpers.randomize_biases(model, seed=1)
+    y = np.random.default_rng(4).integers(0, 2, len(g['u_ids']))
+    gnn, head = helpers.gnn_to_oracle(model.gnn), helpers.basic_head_to_oracle(model.rs)
+    gnn = {k: (v.astype(np.float64) if isinstance(v, np.ndarray) else v) for k, v in gnn.items()}
+    gnn['layers'] = [{k: v.astype(np.float64) for k, v in lw.items()} for lw in gnn['layers']]
+    head = {k: [(w.astype(np.float64), b.astype(np.float64)) for w, b in net] for k, net in head.items()}
+    state = {}
+    trainer = training.Trainer(model)
+    for t in range(1, 4):
+        trainer.train_batch(g['u_ids'], g['i_ids'], y)
+        _, og, _ = otrain.loss_and_grads(g['adj'], gnn, head, g['u_ids'], g['i_ids'], y, l2=1e-4)
+
+        def upd(key, w, gr):
+            m, v = state.get(key, (np.zeros_like(w), np.zeros_like(w)))
+            w2, m, v = otrain.adam_update(w, gr, m, v, t)
+            state[key] = (m, v)
+            return w2
+        gnn['embeddings'] = upd('emb', gnn['embeddings'], og['gnn']['embeddings'])
+        for k, lw in enumerate(gnn['layers']):
+            for nm in ('kernel', 'bias'):
+                lw[nm] = upd(('l', k, nm), lw[nm], og['gnn']['layers'][k][nm])
+        for name in head:
+            head[name] = [(upd((name, k, 'w'), w, og['head'][name][k][0]), upd((name, k, 'b'), b, og['head'][name][k][1]))
+                          for k, (w, b) in enumerate(head[name])]
+    got = helpers.gnn_to_oracle(model.gnn)
+    assert np.abs(got['embeddings'] - gnn['embeddings']).max() < 2e-5          # three steps of ~1e-3 each
+    assert np.abs(got['layers'][0]['kernel'] - gnn['layers'][0]['kernel']).max() < 2e-5
+    gh = helpers.basic_head_to_oracle(model.rs)
+    assert np.abs(gh['clf'][-1][0] - head['clf'][-1][0]).max() < 2e-5
+
+
+def test_fit_learns_a_separable_task(hip):
+    """fit() over a Sequence: the loss falls and training accuracy rises on labels a GCN can represent."""
+    from deep_cbrs_amar_renaissance_amd import engine
+    from deep_cbrs_amar_renaissance_amd.experiment import Adam
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    from deep_cbrs_amar_renaissance_amd.data.datasets import UserItemGraph
+    engine.set_seed(11)
+    g = helpers.tiny_graph(n_users=100, n_items=80, n_ratings=4000, seed=5)
+    ratings = g['ratings']
+    model = basic.BasicGCN(g['adj'], **dict(CFG, l2_regularizer=1e-6))
+    model.compile(loss='binary_crossentropy', optimizer=Adam(learning_rate=0.01), metrics=['accuracy'])
+    seq = UserItemGraph(ratings, g['users'], g['items'], g['adj'], batch_size=512, shuffle=True)
+    before = model.evaluate(seq)
+    hist = model.fit(seq, epochs=12, verbose=False)
+    after = model.evaluate(seq)
+    assert hist['loss'][-1] < hist['loss'][0] - 0.02
+    assert after[0] < before[0] and after[1] > max(before[1], 0.6)

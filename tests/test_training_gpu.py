@@ -42,11 +42,14 @@ def test_training_kernels(hip):
     lab = rng.integers(0, 2, 500).astype(np.float32)
     dzb, terms = torch.empty((500, 1), device=DEV), torch.empty(500, device=DEV)
     hip.bce_grad(_t(p.reshape(-1, 1)), _t(lab), dzb, terms)
-    pc = np.clip(p.astype(np.float64), 1e-7, 1 - 1e-7)
-    want_terms = -(lab * np.log(pc + 1e-7) + (1 - lab) * np.log(1 - pc + 1e-7))
-    inside = (p >= 1e-7) & (p <= 1 - 1e-7)
-    want_dz = -(lab / (pc + 1e-7) - (1 - lab) / (1 - pc + 1e-7)) / 500 * inside * p * (1 - p)
-    assert helpers.rel_err(terms.cpu().numpy(), want_terms) < 1e-5 and helpers.rel_err(dzb.cpu().numpy()[:, 0], want_dz) < 1e-5
+    # Keras evaluates this in float32: so does the expectation (1 - 1e-7 is not representable, the clip lands on 1 - 1.19e-7)
+    e32, one = np.float32(1e-7), np.float32(1)
+    pc = np.clip(p, e32, one - e32)
+    want_terms = -(lab * np.log(pc + e32) + (one - lab) * np.log(one - pc + e32))
+    inside = (p >= e32) & (p <= one - e32)
+    want_dz = -(lab / (pc + e32) - (one - lab) / (one - pc + e32)) / np.float32(500) * inside * p * (one - p)
+    assert helpers.rel_err(terms.cpu().numpy(), want_terms.astype(np.float64)) < 1e-5
+    assert helpers.rel_err(dzb.cpu().numpy()[:, 0], want_dz.astype(np.float64)) < 1e-5
     # scatter-add, in-place add, transpose, Adam
     ids = rng.integers(5, 60, 2000).astype(np.int32)
     src = rng.standard_normal((2000, 12)).astype(np.float32)

@@ -106,7 +106,9 @@ def test_gradients_match_oracle(hip, cls, graph):
     flat = _flatten_oracle_grads(model, want)
     assert set(flat) == set(grads)
     for prm, gw in flat.items():
-        assert helpers.rel_err(grads[prm].cpu().numpy().reshape(gw.shape), gw) < 2e-4, tuple(prm.shape)
+        got = grads[prm].cpu().numpy().reshape(gw.shape).astype(np.float64)
+        got += 2 * trainer._l2(prm) * prm.detach().cpu().numpy().reshape(gw.shape)      # the trainer folds the L2 term into amar_adam_f32
+        assert helpers.rel_err(got, gw) < 2e-4, tuple(prm.shape)
 
 
 def test_adam_steps_match_oracle(hip):

@@ -19,7 +19,7 @@ BASE_CONFIG = {
     'dataset': {'load_function_name': 'load_graph_embeddings', 'type_adjacency': 'unary', 'sparse_adjacency': True,
                 'symmetric_adjacency': True, 'props_triples_filepath': None,
                 'train_batch_size': 1024, 'test_batch_size': 2048, 'shuffle': True},
-    'parameters': {'epochs': 25, 'optimizer': {'name': 'Adam', 'learning_rate': 0.001, 'beta_1': 0.9},
+    'parameters': {'epochs': 2, 'optimizer': {'name': 'Adam', 'learning_rate': 0.001, 'beta_1': 0.9},
                    'metrics': ['accuracy'], 'loss': 'binary_crossentropy'},
 }
 

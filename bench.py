@@ -66,6 +66,45 @@ def cpu_baseline():
                       .format(len(u), reps, dt)}
 
 
+def ml1m_true_size(dev):
+    """configs[1] at its real size, ml1m(s=1) (launch-latency-bound): hoisted and faithful pairs/s."""
+    from deep_cbrs_amar_renaissance_amd import engine
+    from deep_cbrs_amar_renaissance_amd.data import synthetic
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter_device
+    data = synthetic.ml1m_device(1, device=dev)
+    n = data['n_users'] + data['n_items']
+    a_hat = gcn_filter_device(data['train_pos'][:, 0], data['train_pos'][:, 1], n)
+    engine.set_seed(42)
+    model = basic.BasicGCN(a_hat, **GRID1)
+    model.n_users, model.n_items = data['n_users'], data['n_items']
+    u = data['test'][:, 0].to(torch.int32).contiguous()
+    i = data['test'][:, 1].to(torch.int32).contiguous()
+    p = int(u.numel())
+
+    def hoisted():
+        emb = model.gnn(None)
+        return model.rs.score_towers(model.rs.towers(emb[:model.n_users], emb[model.n_users:]), u, i, 0, model.n_users)
+
+    def faithful():                                          # basic.py:61-63: propagation + scoring per 2048-pair batch
+        for lo in range(0, p, 2048):
+            model((u[lo:lo + 2048], i[lo:lo + 2048]))
+
+    out = {}
+    for name, fn, reps in (('hoisted', hoisted, 20), ('faithful', faithful, 3)):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        out[name + '_pairs_per_s'] = p / dt
+        out[name + '_ms'] = 1e3 * dt
+    out.update({'pairs': p, 'nodes': n, 'nnz': a_hat.nnz, 'note': 'latency / launch-bound at this size'})
+    return out
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get('RANK', 0))
@@ -178,6 +217,7 @@ def main():
             'propagation_ms': runner.last_propagation_ms(),
         }
         if world == 1 and not args.no_cpu_baseline:
+            out['ml1m_s1'] = ml1m_true_size(dev)
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
     if world > 1 or force_dist:

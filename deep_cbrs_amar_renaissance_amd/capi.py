@@ -39,6 +39,7 @@ SIGNATURES = {
     'amar_chain_pack_floats': (ctypes.c_int64, [_P, _I32]),
     'amar_chain_pack_f32': (ctypes.c_int, [_P, _P, _P, _I32, _P]),
     'amar_chain_f32': (ctypes.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _I32, _P, _I32, _I32, _I32, _P, _P, _P, _I32, _P, _I64, _I64, _P]),
+    'amar_dual_chain_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _I32, _P, _P, _I64, _I64, _P]),
     'amar_copy_columns_f32': (ctypes.c_int, [_P, _I64, _P, _I32, _P, _I64, _I64, _I32, _P]),
     'amar_reduce_layers_f32': (ctypes.c_int, [_P, _I64, _I32, _I32, _P, _I64, _I64, _I32, _P]),
     'amar_act_bwd_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I32, _I32, _P]),
@@ -324,6 +325,34 @@ def chain(A, wpack, dims, acts, out, ids_a=None, base_a=0, B=None, ids_b=None, b
         _ptr(wpack, torch.float32, 'wpack'), dims_c, acts_c, len(acts),
         _ptr(out, torch.float32, 'out'), _ld(out, 'out'), P, _stream())
     _check(code, 'amar_chain_f32')
+
+
+def dual_chain_supported(D, n_branch_dims_equal, trunk_dims):
+    return (D % 16 == 0 and D <= 64 and n_branch_dims_equal and len(trunk_dims) >= 3 and trunk_dims[0] == 2 * D
+            and trunk_dims[-1] == 1 and len(set(trunk_dims[1:-1])) == 1 and trunk_dims[1] <= 64 and trunk_dims[1] % 4 == 0)
+
+
+def dual_chain(tables_a, tables_b, ids_a, ids_b, bases_a, bases_b, D, in_act, branch_acts, trunk_dims, trunk_acts, wpack, out):
+    """Fused two-branch head: see amar_dual_chain_f32. tables_* / ids_* / bases_* are 2-element sequences."""
+    P = out.shape[0]
+    arr = lambda vals, ctype: (ctype * 2)(*vals)
+    A = arr([_ptr(t, torch.float32, 'A') for t in tables_a], ctypes.c_void_p)
+    B = arr([_ptr(t, torch.float32, 'B') for t in tables_b], ctypes.c_void_p)
+    IA = arr([_ptr(t, torch.int32, 'ida') for t in ids_a], ctypes.c_void_p)
+    IB = arr([_ptr(t, torch.int32, 'idb') for t in ids_b], ctypes.c_void_p)
+    for ids in list(ids_a) + list(ids_b):
+        if ids is not None and ids.numel() != P:
+            raise ValueError("dual_chain: one id per output row expected")
+    lda = arr([_ld(t, 'A') for t in tables_a], ctypes.c_int64)
+    ldb = arr([_ld(t, 'B') for t in tables_b], ctypes.c_int64)
+    ba, bb = arr([int(b) for b in bases_a], ctypes.c_int32), arr([int(b) for b in bases_b], ctypes.c_int32)
+    bacts = (ctypes.c_int32 * max(1, len(branch_acts)))(*[ACT_CODES[a] for a in branch_acts])
+    tdims = (ctypes.c_int32 * len(trunk_dims))(*trunk_dims)
+    tacts = (ctypes.c_int32 * len(trunk_acts))(*[ACT_CODES[a] for a in trunk_acts])
+    code = load().amar_dual_chain_f32(A, lda, IA, ba, B, ldb, IB, bb, D, ACT_CODES[in_act], len(branch_acts), bacts,
+                                      tdims, tacts, len(trunk_acts), _ptr(wpack, torch.float32, 'wpack'),
+                                      _ptr(out, torch.float32, 'out'), _ld(out, 'out'), P, _stream())
+    _check(code, 'amar_dual_chain_f32')
 
 
 def copy_columns(src, dst, ids=None, base=0):

@@ -162,6 +162,158 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
     }
 }
 
+// Two-branch form for the hybrid head (src/models/hybrid.py:72-89 with the first layers of dense3a / dense3b folded
+// into the per-entity tables):  xa = act(A1[.] + B1[.]) -> branch-1 layers;  xb = act(A2[.] + B2[.]) -> branch-2 layers;
+// trunk = classifier over [xa || xb].  Everything stays in registers; up to 4 tiles (64 features) per branch and
+// per trunk layer.  Tile counts are runtime values <= 4 (guards fold for the common 4/4 case only at run time).
+struct DualArgs {
+    const float *A[2]; int64_t lda[2]; const int32_t *ida[2]; int base_a[2];
+    const float *B[2]; int64_t ldb[2]; const int32_t *idb[2]; int base_b[2];
+    int D, tb, in_act;                    // branch width, its tile count, activation of the summed inputs
+    int n_branch; int bw_off[2][CHAIN_MAX_LAYERS], bb_off[2][CHAIN_MAX_LAYERS], b_act[CHAIN_MAX_LAYERS];
+    int n_trunk, tt; int tw_off[CHAIN_MAX_LAYERS], tbias_off[CHAIN_MAX_LAYERS], t_act[CHAIN_MAX_LAYERS];
+    int dot_off, dot_bias_off, dot_act;
+    const float *wpack; int wpack_floats;
+    float *out; int64_t ldo; int64_t P;
+};
+
+template <int PT>
+__global__ __launch_bounds__(256) void dual_chain_kernel(const DualArgs a) {
+    constexpr int T = 4;
+    extern __shared__ __attribute__((aligned(16))) float w_lds[];
+    for (int i = threadIdx.x * 4; i < a.wpack_floats; i += blockDim.x * 4)
+        *reinterpret_cast<float4 *>(&w_lds[i]) = *reinterpret_cast<const float4 *>(a.wpack + i);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, g = lane >> 4, col = lane & 15;
+    const int64_t pairs_per_wave = 16 * PT;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * 4 * pairs_per_wave;
+    const int TB = a.tb, TT = a.tt;
+
+    for (int64_t base = wave0 * pairs_per_wave; base < a.P; base += stride) {
+        f32x4 xb[2][T][PT];                               // branch activations
+#pragma unroll
+        for (int br = 0; br < 2; ++br) {
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int64_t p = base + 16 * pt + col;
+                const bool ok = p < a.P;
+                const int64_t ra = ok ? (a.ida[br] ? (int64_t)a.ida[br][p] - a.base_a[br] : p) : 0;
+                const int64_t rb = ok ? (a.idb[br] ? (int64_t)a.idb[br][p] - a.base_b[br] : p) : 0;
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const int f = 16 * t + 4 * g;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (t < TB && ok && f < a.D) {
+                        const f32x4 va = *reinterpret_cast<const f32x4 *>(a.A[br] + ra * a.lda[br] + f);
+                        const f32x4 vb = *reinterpret_cast<const f32x4 *>(a.B[br] + rb * a.ldb[br] + f);
+                        v = va + vb;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = chain_act(v[r], a.in_act);
+                    }
+                    xb[br][t][pt] = v;
+                }
+            }
+            for (int l = 0; l < a.n_branch; ++l) {
+                const float *wl = w_lds + a.bw_off[br][l], *bl = w_lds + a.bb_off[br][l];
+                f32x4 y[T][PT];
+#pragma unroll
+                for (int m = 0; m < T; ++m) {
+                    if (m < TB) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bl + 16 * m + 4 * g);
+#pragma unroll
+                        for (int pt = 0; pt < PT; ++pt) y[m][pt] = b4;
+#pragma unroll
+                        for (int t = 0; t < T; ++t)
+                            if (t < TB) {
+                                const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wl + ((m * TB + t) * 64 + lane) * 4);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                                    for (int pt = 0; pt < PT; ++pt)
+                                        y[m][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[r], xb[br][t][pt][r], y[m][pt], 0, 0, 0);
+                            }
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < T; ++m)
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) {
+                        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                        if (m < TB) {
+                            v = y[m][pt];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = chain_act(v[r], a.b_act[l]);
+                        }
+                        xb[br][m][pt] = v;
+                    }
+            }
+        }
+        // ---- trunk: first layer reads [xa || xb] (2*TB k-tiles), later layers TT x TT
+        f32x4 x[T][PT];
+        for (int l = 0; l < a.n_trunk; ++l) {
+            const float *wl = w_lds + a.tw_off[l], *bl = w_lds + a.tbias_off[l];
+            const int KT = l == 0 ? 2 * TB : TT;
+            f32x4 y[T][PT];
+#pragma unroll
+            for (int m = 0; m < T; ++m) {
+                if (m < TT) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bl + 16 * m + 4 * g);
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) y[m][pt] = b4;
+#pragma unroll
+                    for (int t = 0; t < 2 * T; ++t) {
+                        const bool first = l == 0;
+                        // k-tile t of the first trunk layer: branch 0 tiles 0..TB-1, then branch 1 tiles
+                        const int br = t >= T ? 1 : 0, tl = t >= T ? t - T : t;
+                        const bool active = first ? (tl < TB) : (t < TT);
+                        if (active) {
+                            const int kt_idx = first ? (br * TB + tl) : t;
+                            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wl + ((m * KT + kt_idx) * 64 + lane) * 4);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                                for (int pt = 0; pt < PT; ++pt) {
+                                    const float bv = first ? xb[br][tl][pt][r] : (t < T ? x[t < T ? t : 0][pt][r] : 0.f);
+                                    y[m][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[r], bv, y[m][pt], 0, 0, 0);
+                                }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < T; ++m)
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (m < TT) {
+                        v = y[m][pt];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = chain_act(v[r], a.t_act[l]);
+                    }
+                    x[m][pt] = v;
+                }
+        }
+        const float *wd = w_lds + a.dot_off;
+        const float bd = w_lds[a.dot_bias_off];
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                if (t < TT) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wd + 16 * t + 4 * g);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) sacc = fmaf(x[t][pt][r], w4[r], sacc);
+                }
+            sacc += __shfl_xor(sacc, 16, 64);
+            sacc += __shfl_xor(sacc, 32, 64);
+            const int64_t p = base + 16 * pt + col;
+            if (g == 0 && p < a.P) a.out[p * a.ldo] = chain_act(sacc + bd, a.dot_act);
+        }
+    }
+}
+
 inline int tiles16(int n) { return (n + 15) / 16; }
 
 }  // namespace
@@ -277,6 +429,65 @@ int amar_chain_f32(const float *A, int64_t lda, int32_t Da, const int32_t *ids_a
     else if (maxt == 4) { if (pt == 1) AMAR_CHAIN_LAUNCH(4, 1); else if (pt == 2) AMAR_CHAIN_LAUNCH(4, 2); else AMAR_CHAIN_LAUNCH(4, 4); }
     else { if (pt == 1) AMAR_CHAIN_LAUNCH(8, 1); else AMAR_CHAIN_LAUNCH(8, 2); }
 #undef AMAR_CHAIN_LAUNCH
+    return amar_check_launch();
+}
+
+// Fused two-branch head.  Each branch b in {0,1}: x_b = in_act(A_b[ida_b] + B_b[idb_b]) ([P, D]), then n_branch Dense
+// layers D -> D (packed with amar_chain_pack_f32, dims [D, D, ...], one blob per branch); trunk: Dense stack over
+// [x_0 || x_1] with dims trunk_dims[0] = 2D, equal hidden widths <= 64 and a final 1-unit layer (packed the same way).
+// D and the trunk widths must be multiples of 4 and <= 64.  wpack = branch-0 blob, branch-1 blob, trunk blob, contiguous.
+int amar_dual_chain_f32(const float *const *A, const int64_t *lda, const int32_t *const *ida, const int32_t *base_a,
+                        const float *const *B, const int64_t *ldb, const int32_t *const *idb, const int32_t *base_b,
+                        int32_t D, int32_t in_act, int32_t n_branch, const int32_t *branch_acts,
+                        const int32_t *trunk_dims, const int32_t *trunk_acts, int32_t n_trunk,
+                        const float *wpack, float *out, int64_t ldo, int64_t P, amar_stream_t stream) {
+    if (P < 0 || !A || !B || !lda || !ldb || !ida || !idb || !base_a || !base_b || !wpack || !out || !trunk_dims || !trunk_acts)
+        return AMAR_EINVAL;
+    if (D < 4 || (D & 3) || n_branch < 0 || n_branch > CHAIN_MAX_LAYERS || (n_branch && !branch_acts)) return AMAR_EINVAL;
+    if (n_trunk < 2 || n_trunk > CHAIN_MAX_LAYERS || trunk_dims[0] != 2 * D || trunk_dims[n_trunk] != 1 || ldo < 1) return AMAR_EINVAL;
+    if (D > 64) return AMAR_EUNSUPPORTED;
+    DualArgs a{};
+    for (int b = 0; b < 2; ++b) {
+        if (!A[b] || !B[b] || lda[b] < D || ldb[b] < D || (lda[b] & 3) || (ldb[b] & 3) || !amar_aligned16(A[b]) || !amar_aligned16(B[b]))
+            return AMAR_EINVAL;
+        a.A[b] = A[b]; a.lda[b] = lda[b]; a.ida[b] = ida[b]; a.base_a[b] = base_a[b];
+        a.B[b] = B[b]; a.ldb[b] = ldb[b]; a.idb[b] = idb[b]; a.base_b[b] = base_b[b];
+    }
+    a.D = D; a.tb = tiles16(D); a.in_act = in_act; a.n_branch = n_branch;
+    int off = 0;
+    for (int b = 0; b < 2; ++b)
+        for (int l = 0; l < n_branch; ++l) {
+            a.bw_off[b][l] = off; off += a.tb * a.tb * 256;
+            a.bb_off[b][l] = off; off += 16 * a.tb;
+            a.b_act[l] = branch_acts[l];
+        }
+    const int W = trunk_dims[1];
+    if (W < 4 || (W & 3) || W > 64) return AMAR_EUNSUPPORTED;
+    a.tt = tiles16(W); a.n_trunk = n_trunk - 1;
+    for (int l = 0; l < n_trunk - 1; ++l) {
+        if (trunk_dims[l + 1] != W) return AMAR_EUNSUPPORTED;
+        const int KT = l == 0 ? 2 * a.tb : a.tt;
+        // the trunk's first layer is packed for a 2D-wide input: its k-tiles are those of [x_0 || x_1] only if D % 16 == 0
+        if (l == 0 && (D & 15)) return AMAR_EUNSUPPORTED;
+        a.tw_off[l] = off; off += a.tt * KT * 256;
+        a.tbias_off[l] = off; off += 16 * a.tt;
+        a.t_act[l] = trunk_acts[l];
+    }
+    a.dot_off = off; off += 16 * a.tt;
+    a.dot_bias_off = off; off += 4;
+    a.dot_act = trunk_acts[n_trunk - 1];
+    a.wpack = wpack; a.wpack_floats = off; a.out = out; a.ldo = ldo; a.P = P;
+    if ((size_t)off * sizeof(float) > 150 * 1024) return AMAR_EUNSUPPORTED;
+    if (P == 0) return AMAR_OK;
+    const size_t lds_bytes = (size_t)off * sizeof(float);
+    constexpr int PT = 2;
+    int64_t blocks = (P + 4 * 16 * PT - 1) / (4 * 16 * PT);
+    if (blocks > 4096) blocks = 4096;
+    auto kern = dual_chain_kernel<PT>;
+    if (lds_bytes > 64 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
+        return AMAR_ELAUNCH;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, static_cast<hipStream_t>(stream), a);
     return amar_check_launch();
 }
 

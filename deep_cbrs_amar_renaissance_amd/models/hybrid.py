@@ -137,6 +137,32 @@ class HybridCBRS(Model):
                               net.layers[0].activation)
         return cache[id(net)]
 
+    def _dual_plan(self):
+        """Blob + shapes for the fused two-branch kernel (rest of dense3a, rest of dense3b, classifier), or None."""
+        key = self.weights_version
+        cache = self.__dict__.get('_dual_cache')
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        plan = None
+        ra, rb, clf = list(self.dense3a.layers[1:]), list(self.dense3b.layers[1:]), list(self.clf.layers)
+        D = self.dense3a.layers[0].units
+        same = all(l.units == D for l in ra + rb) and self.dense3b.layers[0].units == D and len(ra) == len(rb) and \
+            self.dense3a.layers[0].activation == self.dense3b.layers[0].activation and \
+            all(x.activation == y.activation for x, y in zip(ra, rb))
+        trunk_dims = [2 * D] + [l.units for l in clf]
+        if capi.dual_chain_supported(D, same, trunk_dims):
+            np_ = lambda prm: prm.detach().cpu().numpy()
+            blobs = []
+            for layers in (ra, rb, clf):
+                if layers:
+                    blob, _ = capi.chain_pack([np_(l.kernel) for l in layers], [np_(l.bias) for l in layers])
+                    blobs.append(torch.from_numpy(blob))
+            plan = {'D': D, 'in_act': self.dense3a.layers[0].activation, 'branch_acts': [l.activation for l in ra],
+                    'trunk_dims': trunk_dims, 'trunk_acts': [l.activation for l in clf],
+                    'wpack': torch.cat(blobs).to(clf[0].kernel.device)}
+        self.__dict__['_dual_cache'] = (key, plan)
+        return plan
+
     def score_towers(self, towers, u_ids, i_ids, u_base=0, i_base=0):
         """dense3a / dense3b over the fused (concatenated) tower rows of each pair, then the classifier."""
         tug, tig, tub, tib, folded = towers
@@ -152,6 +178,14 @@ class HybridCBRS(Model):
             x1 = self.dense3a.apply2(in1[0], in1[1], **args1)
             x2 = self.dense3b.apply2(in2[0], in2[1], **args2)
             return self.clf.apply2(x1, x2)
+        plan = self._dual_plan()
+        if plan is not None:
+            m = args1['ids_a'].numel() if args1['ids_a'] is not None else in1[0].shape[0]
+            out = torch.empty((m, 1), dtype=torch.float32, device=in1[0].device)
+            capi.dual_chain((in1[0], in2[0]), (in1[1], in2[1]), (args1['ids_a'], args2['ids_a']), (args1['ids_b'], args2['ids_b']),
+                            (args1['base_a'], args2['base_a']), (args1['base_b'], args2['base_b']),
+                            plan['D'], plan['in_act'], plan['branch_acts'], plan['trunk_dims'], plan['trunk_acts'], plan['wpack'], out)
+            return out
         outs = []
         for net, (ta, tb), args in ((self.dense3a, in1, args1), (self.dense3b, in2, args2)):
             blob, dims, acts, in_act = self._rest(net)

@@ -179,6 +179,21 @@ int amar_chain_f32(const float *A, int64_t lda, int32_t Da, const int32_t *ids_a
                    const float *wpack, const int32_t *dims, const int32_t *acts, int32_t n_layers,
                    float *out, int64_t ldo, int64_t P, amar_stream_t stream);
 
+/* Fused two-branch scorer for the hybrid head (src/models/hybrid.py:72-89) once the first Dense layers of
+ * dense3a / dense3b have been folded into the per-entity tables:
+ *     x_b  = in_act( A[b][ida_b(p)] + B[b][idb_b(p)] )            b = 0, 1;  [P, D]
+ *     x_b  = act_l( x_b . W_bl + b_bl )                            n_branch layers D -> D per branch
+ *     out  = trunk( [x_0 || x_1] )                                 Dense stack trunk_dims[0] = 2D, equal hidden widths, last = 1 unit
+ * A, lda, ida, base_a (and B, ...) are HOST arrays of two entries (device pointers inside).  wpack = the
+ * amar_chain_pack_f32 blobs of branch 0 (dims [D, D, ..]), branch 1 and the trunk, concatenated on the device.
+ * D % 16 == 0, D <= 64, trunk hidden widths <= 64; other shapes return AMAR_EUNSUPPORTED (use amar_chain_f32).
+ */
+int amar_dual_chain_f32(const float *const *A, const int64_t *lda, const int32_t *const *ida, const int32_t *base_a,
+                        const float *const *B, const int64_t *ldb, const int32_t *const *idb, const int32_t *base_b,
+                        int32_t D, int32_t in_act, int32_t n_branch, const int32_t *branch_acts,
+                        const int32_t *trunk_dims, const int32_t *trunk_acts, int32_t n_trunk,
+                        const float *wpack, float *out, int64_t ldo, int64_t P, amar_stream_t stream);
+
 /* Concatenate / ReductionLayer as layout operations (src/layers/reduction.py:15-33,
  * src/layers/fusion.py:51-53): copy a [n_rows, width] block between two strided matrices
  * (row r of dst reads row ids[r] - base of src when ids != NULL: tf.nn.embedding_lookup), and

@@ -273,3 +273,41 @@ def test_hip_path_reproduces_golden_vectors(hip, kind, cls, graph):
         # fp32-cast golden scores can tie where the fp64 ones do not: compare as sets per user when a tie was created
         if len(np.unique(z['scores_f64'].astype(np.float32))) == len(np.unique(z['scores_f64'])):
             assert np.array_equal(got_i, z['top{}_items'.format(kk)])
+
+
+@pytest.mark.parametrize('feature_based', [True, False])
+def test_hybrid_hoisted_fused_head(hip, ml1m_s1, feature_based):
+    """predict() on a hybrid model: per-entity towers with folded first layers + the fused two-branch kernel,
+    against the oracle's straight HybridCBRS.call."""
+    from deep_cbrs_amar_renaissance_amd.models import hybrid
+    from deep_cbrs_amar_renaissance_amd.data import synthetic
+    from deep_cbrs_amar_renaissance_amd.data.datasets import UserItemGraphEmbeddings
+    from oracle import layers as ol
+    cfg = dict(GRID1, dense_units=[[24, 24], [256, 64], [64, 64]], clf_units=[64, 64], feature_based=feature_based)
+    n_ent = len(ml1m_s1['users']) + len(ml1m_s1['items'])
+    bert = synthetic.entity_embeddings(n_ent, 768, 'bert')
+    data = ml1m_s1['test'][:7000]
+    model = hybrid.HybridBertGCN(ml1m_s1['adj_ui'], **cfg)
+    model.n_users, model.n_items = len(ml1m_s1['users']), len(ml1m_s1['items'])
+    model.rs.build_head(model.gnn.output_dim(), 768)
+    helpers.randomize_biases(model, seed=23)
+    model.set_bert_table(bert)
+    assert model.rs._dual_plan() is not None
+    u, i = torch.from_numpy(data[:, 0]).cuda(), torch.from_numpy(data[:, 1]).cuda()
+    model._hoist_begin(True)
+    try:
+        got = model((u, i, None, None)).cpu().numpy()
+    finally:
+        model._hoist_end()
+    e = om.propagate(ml1m_s1['adj_ui'], helpers.gnn_to_oracle(model.gnn), np.float64)
+    h = helpers.hybrid_head_to_oracle(model.rs)
+    net = lambda k, x: ol.dense_network(x, [(w.astype(np.float64), b.astype(np.float64)) for w, b in h[k]])
+    ui, ii = data[:, 0], data[:, 1]
+    ug, ig = net('dense1a', e[ui]), net('dense1b', e[ii])
+    ub, ib = net('dense2a', bert[ui].astype(np.float64)), net('dense2b', bert[ii].astype(np.float64))
+    if feature_based:
+        x1, x2 = net('dense3a', np.concatenate([ug, ig], 1)), net('dense3b', np.concatenate([ub, ib], 1))
+    else:
+        x1, x2 = net('dense3a', np.concatenate([ug, ub], 1)), net('dense3b', np.concatenate([ig, ib], 1))
+    want = ol.dense_classifier(np.concatenate([x1, x2], 1), [(w.astype(np.float64), b.astype(np.float64)) for w, b in h['clf']])
+    assert np.abs(got - want).max() < 1e-4

@@ -480,7 +480,7 @@ int amar_dual_chain_f32(const float *const *A, const int64_t *lda, const int32_t
     if ((size_t)off * sizeof(float) > 150 * 1024) return AMAR_EUNSUPPORTED;
     if (P == 0) return AMAR_OK;
     const size_t lds_bytes = (size_t)off * sizeof(float);
-    constexpr int PT = 2;
+    constexpr int PT = 1;
     int64_t blocks = (P + 4 * 16 * PT - 1) / (4 * 16 * PT);
     if (blocks > 4096) blocks = 4096;
     auto kern = dual_chain_kernel<PT>;

@@ -178,7 +178,7 @@ struct DualArgs {
 };
 
 template <int PT>
-__global__ __launch_bounds__(256) void dual_chain_kernel(const DualArgs a) {
+__global__ __launch_bounds__(1024) void dual_chain_kernel(const DualArgs a) {
     constexpr int T = 4;
     extern __shared__ __attribute__((aligned(16))) float w_lds[];
     for (int i = threadIdx.x * 4; i < a.wpack_floats; i += blockDim.x * 4)
@@ -186,8 +186,9 @@ __global__ __launch_bounds__(256) void dual_chain_kernel(const DualArgs a) {
     __syncthreads();
     const int lane = threadIdx.x & 63, g = lane >> 4, col = lane & 15;
     const int64_t pairs_per_wave = 16 * PT;
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t stride = (int64_t)gridDim.x * 4 * pairs_per_wave;
+    const int wpb = blockDim.x >> 6;                      // 16 waves share one LDS copy of the weights
+    const int64_t wave0 = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * wpb * pairs_per_wave;
     const int TB = a.tb, TT = a.tt;
 
     for (int64_t base = wave0 * pairs_per_wave; base < a.P; base += stride) {
@@ -481,13 +482,14 @@ int amar_dual_chain_f32(const float *const *A, const int64_t *lda, const int32_t
     if (P == 0) return AMAR_OK;
     const size_t lds_bytes = (size_t)off * sizeof(float);
     constexpr int PT = 1;
-    int64_t blocks = (P + 4 * 16 * PT - 1) / (4 * 16 * PT);
-    if (blocks > 4096) blocks = 4096;
+    constexpr int THREADS = 1024;                          // the blob (~84 KB for 64-wide stacks) allows one workgroup per CU
+    int64_t blocks = (P + (THREADS / 64) * 16 * PT - 1) / ((THREADS / 64) * 16 * PT);
+    if (blocks > 1024) blocks = 1024;
     auto kern = dual_chain_kernel<PT>;
     if (lds_bytes > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
         return AMAR_ELAUNCH;
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, static_cast<hipStream_t>(stream), a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(THREADS), lds_bytes, static_cast<hipStream_t>(stream), a);
     return amar_check_launch();
 }
 

@@ -68,3 +68,32 @@ def test_experiment_grid_runs_and_ranks_like_the_oracle(hip, tmp_path, monkeypat
     assert top[0].is_monotonic_increasing
     assert set(top[0]).issubset(set(ds.train[:, 0])) and set(top[1]).issubset(set(ds.train[:, 1]))
     assert all(g[2].is_monotonic_decreasing for _, g in top.groupby(0))
+
+
+def test_cli_entry_point_like_the_reference(hip, tmp_path):
+    """`python src/experiment.py -c config.yaml -e exps.yaml --exp_name X` run from the data directory (experiment.py:314-318)."""
+    import subprocess
+    import sys
+    from deep_cbrs_amar_renaissance_amd.data import synthetic
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ds = synthetic.ml1m(1)
+    ds.train = ds.train[:40000]
+    ds.test = ds.test[np.isin(ds.test[:, 0], ds.train[:, 0]) & np.isin(ds.test[:, 1], ds.train[:, 1])][:4000]
+    ds.props = None
+    paths = synthetic.write_dataset(ds, str(tmp_path / 'datasets' / 'movielens'))
+    cfg = json.loads(json.dumps(BASE_CONFIG))
+    cfg['parameters']['epochs'] = 1
+    cfg['dataset'].update({'train_ratings_filepath': 'datasets/movielens/train2id.tsv',
+                           'test_ratings_filepath': 'datasets/movielens/test2id.tsv',
+                           'graph_filepath': 'unused.json', 'bert_user_filepath': 'unused.json', 'bert_item_filepath': 'unused.json'})
+    (tmp_path / 'config.yaml').write_text(yaml.safe_dump(cfg))
+    (tmp_path / 'exps.yaml').write_text(
+        "linear:\n  lightgcn:\n    model:\n      name: basic.BasicLightGCN\n      embedding_dim: 8\n      n_layers: 2\n"
+        "      dense_units: [24, 24]\n      clf_units: [48, 48]\n      l2_regularizer: 1e-5\n"
+        "    dataset:\n      load_function_name: load_user_item_graph\n")
+    proc = subprocess.run([sys.executable, os.path.join(root, 'src', 'experiment.py'), '-c', 'config.yaml', '-e', 'exps.yaml',
+                           '--exp_name', 'cli test'], cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    assert 'Retrieved experiments: 1' in proc.stdout and 'precision_at' in proc.stdout
+    assert 'Epoch 1/1' in proc.stdout                      # fit() really ran (LightGCN has a reverse pass)
+    assert glob.glob(str(tmp_path / 'mlruns' / 'cli_test' / '*' / 'artifacts' / 'predictions' / 'top_10' / 'results.tsv'))

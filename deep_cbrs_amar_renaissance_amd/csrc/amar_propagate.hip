@@ -342,6 +342,7 @@ int launch_spmm_sj(const SjArgs &a, int F, hipStream_t st) {
 struct XsArgs {
     const int32_t *rowptr; const int32_t *colidx; const float *vals;     // XS image
     const float *X; int64_t ldx; float *P; int n_rows; int n_slices; int blocks_per_slice;
+    bool off32;                                                          // every byte offset into X < 2^32
 };
 
 // Lanes take CONSECUTIVE entries of the wave's (64-row block, slice) range: lane = q * EPS + s handles feature
@@ -366,14 +367,62 @@ __device__ __forceinline__ void seg_scan_step(float4 &p, int key, int s) {
     p.z = fmaf(m, dpp_pull<CTRL, ROW_MASK>(p.z), p.z); p.w = fmaf(m, dpp_pull<CTRL, ROW_MASK>(p.w), p.w);
 }
 
-template <int F>
-__global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void spmm_xs_partial_kernel(const XsArgs a) {
-    constexpr int LPN = F / 4, EPS = AMAR_WAVE / LPN;
-    __shared__ float lds_acc[WAVES_PER_BLOCK][AMAR_WAVE * F];
+// The same scan for EPS >= 16 in hand-scheduled ISA.  hipcc turns `fmaf(m, dpp(p), p)` into v_mov 0 + v_mov_dpp +
+// v_pk_fma (VOP3P has no DPP form): 14 VALU per level.  v_fmac_f32_dpp pulls and accumulates in one instruction and
+// leaves a lane without a DPP source untouched, which is exactly the scan's "no left neighbour" case: 7 per level.
+// Hazards (cdna_hip_programming.md 5.7): a DPP read needs 2 wait states after the VALU write of its source: the
+// leading s_nop covers whatever the compiler put in front; inside the block 3+ instructions separate every pair.
+#define AMAR_SEG_LEVEL(SHIFT)                                              \
+    "v_mov_b32_dpp %4, %6 " SHIFT " bank_mask:0xf bound_ctrl:1\n\t"        \
+    "v_cmp_eq_u32_e32 vcc, %4, %6\n\t"                                     \
+    "v_cndmask_b32_e64 %5, 0, 1.0, vcc\n\t"                                \
+    "v_fmac_f32_dpp %0, %0, %5 " SHIFT " bank_mask:0xf\n\t"                \
+    "v_fmac_f32_dpp %1, %1, %5 " SHIFT " bank_mask:0xf\n\t"                \
+    "v_fmac_f32_dpp %2, %2, %5 " SHIFT " bank_mask:0xf\n\t"                \
+    "v_fmac_f32_dpp %3, %3, %5 " SHIFT " bank_mask:0xf\n\t"
+template <int EPS>
+__device__ __forceinline__ void seg_scan_isa(float4 &p, int key) {
+    static_assert(EPS >= 16, "a 16-lane DPP row must not span several feature groups");
+    int kprev; float m;
+    asm volatile("s_nop 1\n\t"
+                 AMAR_SEG_LEVEL("row_shr:1 row_mask:0xf") AMAR_SEG_LEVEL("row_shr:2 row_mask:0xf")
+                 AMAR_SEG_LEVEL("row_shr:4 row_mask:0xf") AMAR_SEG_LEVEL("row_shr:8 row_mask:0xf")
+                 : "+v"(p.x), "+v"(p.y), "+v"(p.z), "+v"(p.w), "=&v"(kprev), "=&v"(m) : "v"(key) : "vcc");
+    if (EPS >= 32)      // lane 15 of rows 0 / 2 into every lane of rows 1 / 3 (rows 0 / 2 are not written: their m is moot)
+        asm volatile("s_nop 1\n\t" AMAR_SEG_LEVEL("row_bcast:15 row_mask:0xa")
+                     : "+v"(p.x), "+v"(p.y), "+v"(p.z), "+v"(p.w), "=&v"(kprev), "=&v"(m) : "v"(key) : "vcc");
+    if (EPS >= 64)
+        asm volatile("s_nop 1\n\t" AMAR_SEG_LEVEL("row_bcast:31 row_mask:0xc")
+                     : "+v"(p.x), "+v"(p.y), "+v"(p.z), "+v"(p.w), "=&v"(kprev), "=&v"(m) : "v"(key) : "vcc");
+}
+#undef AMAR_SEG_LEVEL
+
+// OFF32: every byte offset into X fits 32 bits, so the gathers take the `saddr + voffset` form and the per-lane
+// address arithmetic is one multiply-add instead of a 64-bit chain.
+//
+// Work split inside a wave (v4.2).  A "super-step" is EPS * EPL consecutive entries of the tile; lane = q * EPS + s
+// (q = feature quad, EPS = 64 / (F/4) lanes per quad) owns the EPL CONSECUTIVE entries s*EPL .. s*EPL+EPL-1:
+//   1. 16-byte non-temporal loads of its EPL column words and values (the read-once stream), then EPL 16-byte gathers;
+//   2. an in-lane serial segmented sum over those entries: whenever the row key changes, the finished run goes to
+//      the wave's LDS accumulator with ds_add_f32; the lane keeps its LAST run;
+//   3. ONE cross-lane segmented scan (seg_scan_isa) over the lanes' last runs, keyed by the last key: since the entries
+//      are sorted by row, "key of lane s-d == key of lane s" still means every entry in between belongs to that row;
+//   4. the last lane of every cross-lane run adds the result to the LDS accumulator.
+// What bounds it (tools/exp_xs_floor.py, tools/exp_gather.py): a 32-byte row costs a whole 128-byte
+// line fill into the CU's L1, and a CU sustains 0.43-0.45 line fills per clock from its XCD's L2 whatever the lane
+// layout (= 0.21 ms for the 55.9 M gathers of ml1m(s=64)); the index stream adds its HBM time on top.  VALU work
+// (3.5x less than the one-entry-per-lane v4.1) and the LDS adds are hidden behind that.
+
+constexpr int XS_WAVES = 4;                     // waves per workgroup of the partial kernel: one tile each (1 or 4: same time)
+template <int F, bool OFF32, int EPL>
+__global__ __launch_bounds__(XS_WAVES * AMAR_WAVE) void spmm_xs_partial_kernel(const XsArgs a) {
+    constexpr int LPN = F / 4, EPS = AMAR_WAVE / LPN, SUPER = EPS * EPL;
+    constexpr int PAD_KEY = AMAR_WAVE;                               // key of an entry past the end: equals no row, never flushed
+    __shared__ float lds_acc[XS_WAVES][AMAR_WAVE * F];
     const int lane = threadIdx.x & (AMAR_WAVE - 1);
     const int k = blockIdx.x % a.n_slices;                           // slice <-> XCD affinity
     const int chunk = blockIdx.x / a.n_slices;
-    const int r0 = __builtin_amdgcn_readfirstlane((chunk * WAVES_PER_BLOCK + (threadIdx.x >> 6)) * AMAR_WAVE);
+    const int r0 = __builtin_amdgcn_readfirstlane((chunk * XS_WAVES + (threadIdx.x >> 6)) * AMAR_WAVE);
     if (r0 >= a.n_rows) return;
     const int nr = min(AMAR_WAVE, a.n_rows - r0);
     const int32_t *rp = a.rowptr + (int64_t)k * a.n_rows + r0;
@@ -383,67 +432,80 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void spmm_xs_partial_k
 #pragma unroll
     for (int c = 0; c < F; ++c) acc[c * AMAR_WAVE + lane] = 0.f;     // wave-private region; LDS ops of a wave stay in order
     const int q = lane / EPS, s = lane % EPS;
+    const int n_tile = end - beg;
+    const char *cbase = reinterpret_cast<const char *>(a.colidx + beg);   // scalar bases + 32-bit lane offsets
+    const char *vbase = reinterpret_cast<const char *>(a.vals + beg);
 
-    auto reduce_step = [&](int key, float4 p, bool ok) {
-        // whole step one row-run (the common case for long rows): a plain strided wave sum, result in every lane
-        const int kfirst = __builtin_amdgcn_readfirstlane(key);
-        if (EPS >= 16 && __all(key == kfirst || !ok) && kfirst != 0x7fffffff) {   // (EPS < 16: a 16-lane DPP row spans several q groups)
-            // lanes = q * EPS + s: sum over s inside each group of EPS lanes
-            if (EPS >= 2) { p.x += dpp_mov<0x121>(p.x); p.y += dpp_mov<0x121>(p.y); p.z += dpp_mov<0x121>(p.z); p.w += dpp_mov<0x121>(p.w); }
-            if (EPS >= 4) { p.x += dpp_mov<0x122>(p.x); p.y += dpp_mov<0x122>(p.y); p.z += dpp_mov<0x122>(p.z); p.w += dpp_mov<0x122>(p.w); }
-            if (EPS >= 8) { p.x += dpp_mov<0x124>(p.x); p.y += dpp_mov<0x124>(p.y); p.z += dpp_mov<0x124>(p.z); p.w += dpp_mov<0x124>(p.w); }
-            if (EPS >= 16) { p.x += dpp_mov<0x128>(p.x); p.y += dpp_mov<0x128>(p.y); p.z += dpp_mov<0x128>(p.z); p.w += dpp_mov<0x128>(p.w); }
-            if (EPS >= 32) { float o, w; w = swap16_other(p.x, o); p.x = o + w; w = swap16_other(p.y, o); p.y = o + w;
-                             w = swap16_other(p.z, o); p.z = o + w; w = swap16_other(p.w, o); p.w = o + w; }
-            if (EPS >= 64) { float o, w; w = swap32_other(p.x, o); p.x = o + w; w = swap32_other(p.y, o); p.y = o + w;
-                             w = swap32_other(p.z, o); p.z = o + w; w = swap32_other(p.w, o); p.w = o + w; }
-            if (s == 0) {
-                float *dst = acc + kfirst;
-                atomicAdd(dst + (4 * q + 0) * AMAR_WAVE, p.x); atomicAdd(dst + (4 * q + 1) * AMAR_WAVE, p.y);
-                atomicAdd(dst + (4 * q + 2) * AMAR_WAVE, p.z); atomicAdd(dst + (4 * q + 3) * AMAR_WAVE, p.w);
+    auto flush = [&](int key, const float4 &p) {                     // acc[feature][row]: lanes of one instruction hit distinct rows
+        float *dst = acc + key;
+        atomicAdd(dst + (4 * q + 0) * AMAR_WAVE, p.x); atomicAdd(dst + (4 * q + 1) * AMAR_WAVE, p.y);
+        atomicAdd(dst + (4 * q + 2) * AMAR_WAVE, p.z); atomicAdd(dst + (4 * q + 3) * AMAR_WAVE, p.w);
+    };
+    auto gather = [&](int cw) {
+        const unsigned col = (unsigned)cw & 0x3ffffffu;
+        if (OFF32) return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.X) + (col * (unsigned)a.ldx + 4u * q) * 4u);
+        return *reinterpret_cast<const float4 *>(a.X + (int64_t)col * a.ldx + 4 * q);
+    };
+    // the lane's EPL column words and values of the super-step that starts at t0 (entries past the end re-read the last one)
+    auto load_words = [&](int t0, int (&cw)[EPL], float (&v)[EPL]) {
+        const int first = t0 + s * EPL;
+        if (t0 + SUPER <= n_tile) {                                  // wave-uniform: a full super-step, 16-byte loads
+#pragma unroll
+            for (int j4 = 0; j4 < EPL; j4 += 4) {
+                // read-once stream: non-temporal, so that it does not push the X slice out of the XCD's L2
+                // (hipcc merges the four dword loads into one global_load_dwordx4 nt; 4-byte alignment is enough)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    cw[j4 + j] = __builtin_nontemporal_load(reinterpret_cast<const int32_t *>(cbase + (unsigned)(first + j4 + j) * 4u));
+                    v[j4 + j] = __builtin_nontemporal_load(reinterpret_cast<const float *>(vbase + (unsigned)(first + j4 + j) * 4u));
+                }
             }
-            return;
-        }
-        // segmented inclusive scan over s (row_shr:d = 0x110 + d; row_bcast15 = 0x142; row_bcast31 = 0x143)
-        if (EPS >= 2) seg_scan_step<0x111, 0xF, (EPS < 16 ? 1 : 0), EPS>(p, key, s);
-        if (EPS >= 4) seg_scan_step<0x112, 0xF, (EPS < 16 ? 2 : 0), EPS>(p, key, s);
-        if (EPS >= 8) seg_scan_step<0x114, 0xF, (EPS < 16 ? 4 : 0), EPS>(p, key, s);
-        if (EPS >= 16) seg_scan_step<0x118, 0xF, 0, EPS>(p, key, s);
-        if (EPS >= 32) seg_scan_step<0x142, 0xA, 0, EPS>(p, key, s);
-        if (EPS >= 64) seg_scan_step<0x143, 0xC, 0, EPS>(p, key, s);
-        // a run ends where the next entry has another key (or the step ends)
-        const int knext = __shfl_down(key, 1, 64);
-        const bool run_end = ok && (s == EPS - 1 || knext != key);
-        if (run_end) {
-            float *dst = acc + key;                                   // acc[feature][row]: lanes of one instruction hit distinct rows
-            atomicAdd(dst + (4 * q + 0) * AMAR_WAVE, p.x); atomicAdd(dst + (4 * q + 1) * AMAR_WAVE, p.y);
-            atomicAdd(dst + (4 * q + 2) * AMAR_WAVE, p.z); atomicAdd(dst + (4 * q + 3) * AMAR_WAVE, p.w);
+        } else {
+#pragma unroll
+            for (int j = 0; j < EPL; ++j) {
+                const unsigned off = (unsigned)max(min(first + j, n_tile - 1), 0) * 4u;
+                cw[j] = *reinterpret_cast<const int32_t *>(cbase + off);
+                v[j] = *reinterpret_cast<const float *>(vbase + off);
+            }
         }
     };
 
-    constexpr int UNR = 4;                                           // steps in flight: all index loads, then all gathers
-    for (int base = beg; base < end; base += UNR * EPS) {
-        int cw[UNR];
-        float v[UNR];
-        bool ok[UNR];
+    int cw[EPL];
+    float v[EPL];
+    load_words(0, cw, v);
+    for (int t0 = 0; t0 < n_tile; t0 += SUPER) {
+        const int first = t0 + s * EPL;                              // the lane's first entry, relative to the tile
+        float4 x[EPL];
+        int key[EPL];
+        float vv[EPL];
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int i = base + u * EPS + s;
-            ok[u] = i < end;
-            cw[u] = 0; v[u] = 0.f;
-            if (ok[u]) { cw[u] = a.colidx[i]; v[u] = a.vals[i]; }
+        for (int j = 0; j < EPL; ++j) {
+            x[j] = gather(cw[j]);
+            key[j] = first + j < n_tile ? (int)((unsigned)cw[j] >> 26) : PAD_KEY;
+            vv[j] = v[j];
         }
-        float4 x[UNR];
+
+        float4 cur = make_float4(vv[0] * x[0].x, vv[0] * x[0].y, vv[0] * x[0].z, vv[0] * x[0].w);
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            x[u] = f4_zero();
-            if (ok[u]) x[u] = *reinterpret_cast<const float4 *>(a.X + (int64_t)(cw[u] & 0x3ffffff) * a.ldx + 4 * q);
+        for (int j = 1; j < EPL; ++j) {
+            const bool same = key[j] == key[j - 1];
+            if (!same) flush(key[j - 1], cur);                       // key[j-1] is a real row: padding only follows padding
+            const float keep = same ? 1.f : 0.f;
+            cur = make_float4(fmaf(vv[j], x[j].x, keep * cur.x), fmaf(vv[j], x[j].y, keep * cur.y),
+                              fmaf(vv[j], x[j].z, keep * cur.z), fmaf(vv[j], x[j].w, keep * cur.w));
         }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u)
-            if (base + u * EPS < end)                                 // wave-uniform
-                reduce_step(ok[u] ? (int)((unsigned)cw[u] >> 26) : 0x7fffffff,
-                            make_float4(v[u] * x[u].x, v[u] * x[u].y, v[u] * x[u].z, v[u] * x[u].w), ok[u]);
+        const int kl = key[EPL - 1];
+        if constexpr (EPS >= 16) {
+            seg_scan_isa<EPS>(cur, kl);
+        } else {                                                     // a 16-lane DPP row spans several feature groups: guarded C++ form
+            seg_scan_step<0x111, 0xF, 1, EPS>(cur, kl, s);
+            if (EPS >= 4) seg_scan_step<0x112, 0xF, 2, EPS>(cur, kl, s);
+            if (EPS >= 8) seg_scan_step<0x114, 0xF, 4, EPS>(cur, kl, s);
+        }
+        // a cross-lane run ends where the next lane's last key differs (or the group ends); wave_shl:1 = 0x130: lane l reads l + 1
+        const int knext = __builtin_amdgcn_mov_dpp(kl, 0x130, 0xF, 0xF, true);
+        if (kl != PAD_KEY && (s == EPS - 1 || knext != kl)) flush(kl, cur);
+        if (t0 + SUPER < n_tile) load_words(t0 + SUPER, cw, v);
     }
     if (lane < nr) {
         float *out = a.P + ((int64_t)k * a.n_rows + r0 + lane) * F;
@@ -484,8 +546,11 @@ __global__ __launch_bounds__(256) void spmm_xs_combine_kernel(const XsCombineArg
 
 template <int F>
 int launch_spmm_xs(const XsArgs &pa, const XsCombineArgs &ca, bool fuse, hipStream_t st) {
-    const dim3 block(WAVES_PER_BLOCK * AMAR_WAVE);
-    hipLaunchKernelGGL((spmm_xs_partial_kernel<F>), dim3((unsigned)(pa.blocks_per_slice * pa.n_slices)), block, 0, st, pa);
+    const dim3 block(XS_WAVES * AMAR_WAVE);
+    const dim3 pgrid((unsigned)(pa.blocks_per_slice * pa.n_slices));
+    constexpr int EPL = F >= 8 ? 8 : 4;
+    if (pa.off32) hipLaunchKernelGGL((spmm_xs_partial_kernel<F, true, EPL>), pgrid, block, 0, st, pa);
+    else hipLaunchKernelGGL((spmm_xs_partial_kernel<F, false, EPL>), pgrid, block, 0, st, pa);
     const dim3 cgrid((ca.e.n_rows + 255) / 256);
     if (fuse) hipLaunchKernelGGL((spmm_xs_combine_kernel<F, true>), cgrid, dim3(256), 0, st, ca);
     else hipLaunchKernelGGL((spmm_xs_combine_kernel<F, false>), cgrid, dim3(256), 0, st, ca);
@@ -788,7 +853,8 @@ int amar_spmm_xs_f32(const float *diag, const int32_t *rowptr, const int32_t *co
     if (Wnext && (!Hnext || Cn < 1 || ldhn < Cn)) return AMAR_EINVAL;
     if (Wnext && Cn > 64) return AMAR_EUNSUPPORTED;
     XsArgs pa{rowptr, colidx, vals, X, ldx, partials, n_rows, n_slices,
-              (n_rows + WAVES_PER_BLOCK * AMAR_WAVE - 1) / (WAVES_PER_BLOCK * AMAR_WAVE)};
+              (n_rows + XS_WAVES * AMAR_WAVE - 1) / (XS_WAVES * AMAR_WAVE),
+              (int64_t)n_rows * ldx * 4 < (int64_t(1) << 32)};
     XsCombineArgs ca{};
     ca.diag = diag; ca.P = partials; ca.rowptr = rowptr; ca.n_slices = n_slices;
     ca.e.X = X; ca.e.ldx = ldx; ca.e.Y = Y; ca.e.ldy = ldy;

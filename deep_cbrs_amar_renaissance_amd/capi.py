@@ -48,6 +48,9 @@ SIGNATURES = {
     'amar_bce_grad_f32': (ctypes.c_int, [_P, _I64, _P, _P, _P, _I64, _P]),
     'amar_scatter_add_rows_f32': (ctypes.c_int, [_P, _I64, _P, _I32, _P, _I64, _I64, _I32, _P]),
     'amar_add_inplace_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I32, _F32, _P]),
+    'amar_row_affine_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I32, _P]),
+    'amar_l2norm_fwd_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _P]),
+    'amar_l2norm_bwd_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _P]),
     'amar_transpose_f32': (ctypes.c_int, [_P, _I32, _I32, _P, _P]),
     'amar_adam_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _F32, _F32, _F32, _F32, _F32, _P]),
     'amar_topk_segmented_f32': (ctypes.c_int, [_P, _P, _P, _I32, _I32, _P, _P, _P]),
@@ -435,6 +438,38 @@ def add_inplace(dst, src, scale=1.0):
     code = load().amar_add_inplace_f32(_ptr(dst, torch.float32, 'dst'), _ld(dst, 'dst'), _ptr(src, torch.float32, 'src'), _ld(src, 'src'),
                                        dst.shape[0], dst.shape[1], float(scale), _stream())
     _check(code, 'amar_add_inplace_f32')
+
+
+def row_affine(a, scale, out, b=None):
+    """out = (a + b) * scale[row] on strided [M, W] blocks (b optional)."""
+    M, W = a.shape
+    if tuple(out.shape) != (M, W) or scale.numel() != M or (b is not None and tuple(b.shape) != (M, W)):
+        raise ValueError("row_affine: a, b, out [M, W] and scale [M] expected")
+    code = load().amar_row_affine_f32(_ptr(a, torch.float32, 'a'), _ld(a, 'a'), _ptr(b, torch.float32, 'b'),
+                                      _ld(b, 'b') if b is not None else 0, _ptr(scale, torch.float32, 'scale'),
+                                      _ptr(out, torch.float32, 'out'), _ld(out, 'out'), M, W, _stream())
+    _check(code, 'amar_row_affine_f32')
+
+
+def l2norm_fwd(z, nrm, inv, y, act='relu'):
+    """nrm = l2_normalize(z) per row, inv = the row scale, y = act(nrm)  (GraphSageConv's tail)."""
+    M, C = z.shape
+    if tuple(nrm.shape) != (M, C) or tuple(y.shape) != (M, C) or inv.numel() != M:
+        raise ValueError("l2norm_fwd: z, nrm, y [M, C] and inv [M] expected")
+    code = load().amar_l2norm_fwd_f32(_ptr(z, torch.float32, 'z'), _ld(z, 'z'), _ptr(nrm, torch.float32, 'nrm'), _ld(nrm, 'nrm'),
+                                      _ptr(inv, torch.float32, 'inv'), _ptr(y, torch.float32, 'y'), _ld(y, 'y'), M, C,
+                                      ACT_CODES[act], _stream())
+    _check(code, 'amar_l2norm_fwd_f32')
+
+
+def l2norm_bwd(dy, nrm, inv, dz, act='relu'):
+    M, C = dy.shape
+    if tuple(nrm.shape) != (M, C) or tuple(dz.shape) != (M, C) or inv.numel() != M:
+        raise ValueError("l2norm_bwd: dy, nrm, dz [M, C] and inv [M] expected")
+    code = load().amar_l2norm_bwd_f32(_ptr(dy, torch.float32, 'dy'), _ld(dy, 'dy'), _ptr(nrm, torch.float32, 'nrm'), _ld(nrm, 'nrm'),
+                                      _ptr(inv, torch.float32, 'inv'), _ptr(dz, torch.float32, 'dz'), _ld(dz, 'dz'), M, C,
+                                      ACT_CODES[act], _stream())
+    _check(code, 'amar_l2norm_bwd_f32')
 
 
 def transpose(src):

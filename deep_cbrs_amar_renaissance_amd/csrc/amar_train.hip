@@ -120,6 +120,60 @@ __global__ __launch_bounds__(256) void adam_kernel(float *__restrict__ w, const 
     }
 }
 
+// out = (A + B) * scale[row]   (B optional): GraphSAGE's mean aggregate (s + x) / count and its reverse
+__global__ __launch_bounds__(256) void row_affine_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
+                                                         int64_t ldb, const float *__restrict__ scale, float *__restrict__ out,
+                                                         int64_t ldo, int64_t M, int W) {
+    const int64_t total = M * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / W;
+        const int c = (int)(i - r * W);
+        float v = A[r * lda + c];
+        if (B) v += B[r * ldb + c];
+        out[r * ldo + c] = v * scale[r];
+    }
+}
+
+// tf.nn.l2_normalize(axis=-1) followed by the activation (GraphSageConv): inv = rsqrt(max(sum z^2, 1e-12)),
+// n = z * inv (kept for the reverse pass), y = relu(n).  One thread per row: rows are a few dozen floats.
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float *__restrict__ Z, int64_t ldz, float *__restrict__ Nrm,
+                                                         int64_t ldn, float *__restrict__ inv, float *__restrict__ Y,
+                                                         int64_t ldy, int64_t M, int C, int relu) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < M; r += (int64_t)gridDim.x * blockDim.x) {
+        const float *z = Z + r * ldz;
+        float sq = 0.f;
+        for (int c = 0; c < C; ++c) sq = fmaf(z[c], z[c], sq);
+        const float iv = rsqrtf(fmaxf(sq, 1e-12f));
+        inv[r] = iv;
+        for (int c = 0; c < C; ++c) {
+            const float n = z[c] * iv;
+            Nrm[r * ldn + c] = n;
+            Y[r * ldy + c] = relu ? fmaxf(n, 0.f) : n;
+        }
+    }
+}
+
+// reverse of the above: dn = dy * [n > 0];  dz = inv * (dn - n * (n . dn)); where the norm was clamped (inv = 1e6)
+// z * inv is linear in z and dz = inv * dn.
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float *__restrict__ dY, int64_t ldd, const float *__restrict__ Nrm,
+                                                         int64_t ldn, const float *__restrict__ inv, float *__restrict__ dZ,
+                                                         int64_t ldz, int64_t M, int C, int relu) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < M; r += (int64_t)gridDim.x * blockDim.x) {
+        const float *n = Nrm + r * ldn, *dy = dY + r * ldd;
+        const float iv = inv[r];
+        float dot = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float dn = (!relu || n[c] > 0.f) ? dy[c] : 0.f;
+            dot = fmaf(n[c], dn, dot);
+        }
+        if (!(iv < 1e6f)) dot = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float dn = (!relu || n[c] > 0.f) ? dy[c] : 0.f;
+            dZ[r * ldz + c] = iv * (dn - n[c] * dot);
+        }
+    }
+}
+
 unsigned grid1d(int64_t total) {
     int64_t b = (total + 255) / 256;
     return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
@@ -179,6 +233,32 @@ int amar_add_inplace_f32(float *dst, int64_t ldd, const float *src, int64_t lds,
     if (M < 0 || W < 1 || !src || !dst || lds < W || ldd < W) return AMAR_EINVAL;
     if (M == 0) return AMAR_OK;
     hipLaunchKernelGGL(add_inplace_kernel, dim3(grid1d(M * W)), dim3(256), 0, static_cast<hipStream_t>(stream), dst, ldd, src, lds, M, W, scale);
+    return amar_check_launch();
+}
+
+int amar_row_affine_f32(const float *A, int64_t lda, const float *B, int64_t ldb, const float *scale, float *out, int64_t ldo,
+                        int64_t M, int32_t W, amar_stream_t stream) {
+    if (M < 0 || W < 1 || !A || !scale || !out || lda < W || ldo < W || (B && ldb < W)) return AMAR_EINVAL;
+    if (M == 0) return AMAR_OK;
+    hipLaunchKernelGGL(row_affine_kernel, dim3(grid1d(M * W)), dim3(256), 0, static_cast<hipStream_t>(stream), A, lda, B, ldb, scale, out, ldo, M, W);
+    return amar_check_launch();
+}
+
+int amar_l2norm_fwd_f32(const float *Z, int64_t ldz, float *Nrm, int64_t ldn, float *inv, float *Y, int64_t ldy,
+                        int64_t M, int32_t C, int32_t act, amar_stream_t stream) {
+    if (M < 0 || C < 1 || !Z || !Nrm || !inv || !Y || ldz < C || ldn < C || ldy < C) return AMAR_EINVAL;
+    if (act != AMAR_ACT_NONE && act != AMAR_ACT_RELU) return AMAR_EUNSUPPORTED;
+    if (M == 0) return AMAR_OK;
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(grid1d(M)), dim3(256), 0, static_cast<hipStream_t>(stream), Z, ldz, Nrm, ldn, inv, Y, ldy, M, C, act == AMAR_ACT_RELU);
+    return amar_check_launch();
+}
+
+int amar_l2norm_bwd_f32(const float *dY, int64_t ldd, const float *Nrm, int64_t ldn, const float *inv, float *dZ, int64_t ldz,
+                        int64_t M, int32_t C, int32_t act, amar_stream_t stream) {
+    if (M < 0 || C < 1 || !dY || !Nrm || !inv || !dZ || ldd < C || ldn < C || ldz < C) return AMAR_EINVAL;
+    if (act != AMAR_ACT_NONE && act != AMAR_ACT_RELU) return AMAR_EUNSUPPORTED;
+    if (M == 0) return AMAR_OK;
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(grid1d(M)), dim3(256), 0, static_cast<hipStream_t>(stream), dY, ldd, Nrm, ldn, inv, dZ, ldz, M, C, act == AMAR_ACT_RELU);
     return amar_check_launch();
 }
 

@@ -11,8 +11,10 @@ training kernels of `csrc/amar_train.hip` (activation backward, two-stage determ
 gradients, row scatter-add for the embedding lookup, Adam) and reuses the forward SpMM for
 A_hat^T . dZ (A_hat is symmetric) and the forward GEMM for dX = dZ . W^T.
 
-Implemented for GCN stacks with 'concatenation' and LightGCN stacks ('mean'); GraphSAGE / GAT
-reverse passes and the hybrid head are not implemented yet and raise.
+Implemented for GCN, GraphSAGE (both 'concatenation') and LightGCN ('mean') stacks.  GraphSAGE trains on an
+unfused forward that keeps what the reverse pass needs ([x || mean] and the normalised pre-activation); its
+aggregate (A + I) / count is symmetric up to the row scale, so the reverse aggregate is the same value-free SpMM.
+GAT reverse passes and the hybrid head are not implemented yet and raise.
 """
 import numpy as np
 import torch
@@ -20,6 +22,7 @@ import torch
 from deep_cbrs_amar_renaissance_amd import capi
 from deep_cbrs_amar_renaissance_amd.engine import ids_to_device, to_device_tensor
 from deep_cbrs_amar_renaissance_amd.layers.gcn_conv import GCNConv
+from deep_cbrs_amar_renaissance_amd.layers.graphsage_conv import GraphSageConv
 from deep_cbrs_amar_renaissance_amd.layers.lightgcn_conv import LightGCNConv
 from deep_cbrs_amar_renaissance_amd.utilities.math import spmm_kind
 
@@ -73,7 +76,7 @@ class _DenseTape:
 
 
 class Trainer:
-    """Holds the Adam state of a Basic{GCN,LightGCN} model and performs training batches."""
+    """Holds the Adam state of a Basic{GCN,GraphSage,LightGCN} model and performs training batches."""
 
     def __init__(self, model, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
         seq = model.gnn.gnn_layers
@@ -82,9 +85,19 @@ class Trainer:
             self.kind = 'gcn'
         elif layers and all(isinstance(l, LightGCNConv) for l in layers) and seq.final_node == 'mean':
             self.kind = 'lightgcn'
+        elif layers and all(isinstance(l, GraphSageConv) for l in layers) and seq.final_node == 'concatenation':
+            self.kind = 'sage'
+            a = seq.adj_matrix
+            deg = (a.rowptr[1:] - a.rowptr[:-1]).to(torch.float32)
+            if len({bool(l.self_loops) for l in layers}) != 1:
+                raise NotImplementedError("GraphSAGE layers with mixed self_loops settings")
+            self.self_loops = bool(layers[0].self_loops)
+            # unsorted_segment_mean: sum / count, 0 for an empty segment
+            self.inv_cnt = (1.0 / (deg + 1.0)) if self.self_loops else torch.where(deg > 0, 1.0 / deg.clamp(min=1.0), torch.zeros_like(deg))
+            self.inv_cnt = self.inv_cnt.contiguous()
         else:
-            raise NotImplementedError("training is implemented for GCN ('concatenation') and LightGCN stacks; "
-                                      "GraphSAGE / GAT reverse passes are not built yet")
+            raise NotImplementedError("training is implemented for GCN / GraphSAGE ('concatenation') and LightGCN stacks; "
+                                      "the GAT reverse pass is not built yet")
         if not model.rs.built:
             model.rs.build_head(model.gnn.output_dim(), model.gnn.output_dim())
         self.model, self.seq = model, seq
@@ -109,7 +122,7 @@ class Trainer:
         b = u.numel()
         dev = seq.embeddings.device
         with torch.no_grad():
-            e = seq(None)                                            # full-graph propagation, every batch (basic.py:61-63)
+            e = self._propagation_forward()                          # full-graph propagation, every batch (basic.py:61-63)
             f = e.shape[1]
             gu = torch.empty((b, f), dtype=torch.float32, device=dev)
             gi = torch.empty((b, f), dtype=torch.float32, device=dev)
@@ -140,12 +153,69 @@ class Trainer:
                     loss += l2 * float((prm.detach().double() ** 2).sum().item())
         return loss, grads
 
+    def _propagation_forward(self):
+        """E = gnn(None).  GCN / LightGCN: the inference kernels (their outputs are all the reverse pass needs);
+        GraphSAGE: layer by layer, keeping [x || mean(x)] and the l2-normalised pre-activation."""
+        seq = self.seq
+        if self.kind != 'sage':
+            return seq(None)
+        a = seq.adj_matrix
+        widths = seq.layer_widths()
+        seq._build_layers(widths)
+        n, dev = a.shape[0], seq.embeddings.device
+        offs = np.cumsum([0] + widths)
+        cat = torch.empty((n, int(offs[-1])), dtype=torch.float32, device=dev)
+        sl = lambda k: cat[:, offs[k]:offs[k + 1]]
+        capi.copy_columns(seq.embeddings, sl(0))
+        self._tape = []
+        for k, layer in enumerate(seq.seq_layers):
+            f, c = widths[k], widths[k + 1]
+            xa = torch.empty((n, 2 * f), dtype=torch.float32, device=dev)
+            capi.copy_columns(sl(k), xa[:, :f])
+            ssum = torch.empty((n, f), dtype=torch.float32, device=dev)
+            capi.spmm_csr(a.rowptr, a.colidx, None, sl(k), ssum)
+            capi.row_affine(ssum, self.inv_cnt, xa[:, f:], b=sl(k) if self.self_loops else None)
+            z = torch.empty((n, c), dtype=torch.float32, device=dev)
+            capi.dense(xa, layer.kernel, layer.bias, z, act=None)
+            nrm = torch.empty((n, c), dtype=torch.float32, device=dev)
+            inv = torch.empty(n, dtype=torch.float32, device=dev)
+            capi.l2norm_fwd(z, nrm, inv, sl(k + 1), act='relu')
+            self._tape.append((xa, nrm, inv))
+        return cat
+
     def _propagation_backward(self, e, de, grads):
         seq, a = self.seq, self.seq.adj_matrix
         layers = list(seq.seq_layers)
         n, dev = e.shape[0], e.device
         emb = seq.embeddings
-        if self.kind == 'gcn':
+        if self.kind == 'sage':
+            widths = seq.layer_widths()
+            offs = np.cumsum([0] + widths)
+            sl = lambda t, k: t[:, offs[k]:offs[k + 1]]
+            for k in range(len(layers) - 1, -1, -1):
+                layer = layers[k]
+                f, c = widths[k], widths[k + 1]
+                xa, nrm, inv = self._tape[k]
+                dz = torch.empty((n, c), dtype=torch.float32, device=dev)
+                capi.l2norm_bwd(sl(de, k + 1), nrm, inv, dz, act='relu')
+                dw, db = torch.empty_like(layer.kernel), torch.empty_like(layer.bias)
+                capi.wgrad(xa, dz, dw, db)
+                grads[layer.kernel], grads[layer.bias] = dw, db
+                dxa = torch.empty((n, 2 * f), dtype=torch.float32, device=dev)
+                capi.dense(dz, capi.transpose(layer.kernel.detach()), None, dxa, act=None)
+                capi.add_inplace(sl(de, k), dxa[:, :f])
+                g = torch.empty((n, f), dtype=torch.float32, device=dev)
+                capi.row_affine(dxa[:, f:], self.inv_cnt, g)               # d(mean)/d(sum)
+                back = torch.empty((n, f), dtype=torch.float32, device=dev)
+                capi.spmm_csr(a.rowptr, a.colidx, None, g, back)           # the edge multiset is symmetric
+                capi.add_inplace(sl(de, k), back)
+                if self.self_loops:
+                    capi.add_inplace(sl(de, k), g)
+            g0 = torch.empty_like(emb)
+            capi.copy_columns(sl(de, 0), g0)
+            grads[emb] = g0
+            self._tape = None
+        elif self.kind == 'gcn':
             widths = seq.layer_widths()
             offs = np.cumsum([0] + widths)
             sl = lambda t, k: t[:, offs[k]:offs[k + 1]]

@@ -218,6 +218,12 @@ int amar_reduce_layers_f32(const float *cat, int64_t ld, int32_t n_layers, int32
  *                           loss_terms[i] and dz[i] = dL/dlogit_i through the final sigmoid
  * amar_scatter_add_rows_f32 dst[ids[m] - base, :] += src[m, :]   (gradient of embedding_lookup; float atomics)
  * amar_add_inplace_f32      dst += scale * src on strided [M, W] blocks
+ * amar_row_affine_f32       out = (A + B) * scale[row], B optional: GraphSAGE's mean aggregate (sum + self) / count
+ *                           (Spektral GraphSageConv, built at src/models/gnn.py:354-361) and its reverse
+ * amar_l2norm_fwd_f32       tf.nn.l2_normalize(axis=-1) + activation as GraphSageConv applies them: inv[r] =
+ *                           rsqrt(max(sum z^2, 1e-12)), Nrm = z * inv (kept for the reverse pass), Y = act(Nrm)
+ * amar_l2norm_bwd_f32       dZ = inv * (dn - Nrm * (Nrm . dn)) with dn = dY * act'(Nrm); dZ = inv * dn where the norm
+ *                           was clamped
  * amar_transpose_f32        dst[N,K] = src[K,N]^T
  * amar_adam_f32             keras.optimizers.Adam on a flat parameter: g' = g + 2*l2*w; m, v moments; lr_t = the
  *                           bias-corrected step lr * sqrt(1 - b2^t) / (1 - b1^t);  w -= lr_t * m / (sqrt(v) + epsilon)
@@ -231,6 +237,12 @@ int amar_bce_grad_f32(const float *p, int64_t ldp, const float *y, float *dz, fl
 int amar_scatter_add_rows_f32(const float *src, int64_t lds, const int32_t *ids, int32_t base, float *dst, int64_t ldd,
                               int64_t M, int32_t W, amar_stream_t stream);
 int amar_add_inplace_f32(float *dst, int64_t ldd, const float *src, int64_t lds, int64_t M, int32_t W, float scale, amar_stream_t stream);
+int amar_row_affine_f32(const float *A, int64_t lda, const float *B, int64_t ldb, const float *scale, float *out, int64_t ldo,
+                        int64_t M, int32_t W, amar_stream_t stream);
+int amar_l2norm_fwd_f32(const float *Z, int64_t ldz, float *Nrm, int64_t ldn, float *inv, float *Y, int64_t ldy,
+                        int64_t M, int32_t C, int32_t act, amar_stream_t stream);
+int amar_l2norm_bwd_f32(const float *dY, int64_t ldd, const float *Nrm, int64_t ldn, const float *inv, float *dZ, int64_t ldz,
+                        int64_t M, int32_t C, int32_t act, amar_stream_t stream);
 int amar_transpose_f32(const float *src, int32_t K, int32_t N, float *dst, amar_stream_t stream);
 int amar_adam_f32(float *w, const float *g, float *m, float *v, int64_t n, float lr_t, float beta_1, float beta_2,
                   float epsilon, float l2, amar_stream_t stream);

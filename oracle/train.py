@@ -154,3 +154,86 @@ def torch_grads(adj, gnn, head, u_ids, i_ids, y, l2=0.0):
     g = lambda t: t.grad.numpy() if t.grad is not None else np.zeros(tuple(t.shape))
     return float(loss), {'gnn': {'embeddings': g(x0), 'layers': [{k: g(v) for k, v in lw.items()} for lw in layers]},
                          'head': {name: [(g(w), g(b)) for w, b in nets[name]] for name in nets}}
+
+
+def torch_model_grads(adj, gnn, head, u_ids, i_ids, y, l2=0.0, self_loops=True, bert=None):
+    """Loss and gradients of ANY model on the path by torch autograd (float64, CPU): the four GNN kinds of
+    oracle/models.py:propagate under the Basic head (keys unet/inet/clf) or the Hybrid head (dense1a..dense3b, clf;
+    `bert` = (user rows [B, D], item rows [B, D]) as the batch Sequence delivers them, hybrid.py:119-140).
+
+    The forward below restates oracle/layers.py op by op with differentiable torch ops (tests check that its scores
+    equal the numpy oracle's); what Keras adds is autodiff of exactly this graph plus the L2 terms of the node table
+    and of the conv kernels / biases (gnn.py:45, 293-294, 324-327, 357-360; attention vectors carry none).
+    """
+    import torch
+    kind = gnn['kind']
+    T = lambda arr: torch.tensor(np.asarray(arr, dtype=np.float64), requires_grad=True)
+    x0 = T(gnn['embeddings'])
+    layers = [{k: T(v) for k, v in lw.items()} for lw in gnn['layers']]
+    nets = {name: [(T(w), T(b)) for w, b in head[name]] for name in head}
+    n = x0.shape[0]
+    hs, x = [x0], x0
+    if kind in ('gcn', 'lightgcn'):
+        a = ograph.gcn_filter(adj).tocoo()
+        a_t = torch.sparse_coo_tensor(np.stack([a.row, a.col]), a.data.astype(np.float64), a.shape).coalesce()
+        for lw in layers:
+            x = torch.relu(torch.sparse.mm(a_t, x @ lw['kernel']) + lw['bias']) if kind == 'gcn' else torch.sparse.mm(a_t, x)
+            hs.append(x)
+    else:
+        row, col, _ = ograph.reordered_coo(adj)
+        if self_loops:
+            row, col = ograph.add_self_loops_edges(row, col, n)
+        src = torch.as_tensor(np.asarray(row), dtype=torch.long)
+        tgt = torch.as_tensor(np.asarray(col), dtype=torch.long)
+        count = torch.bincount(tgt, minlength=n).double().clamp(min=1.0)
+        for lw in layers:
+            if kind == 'sage':
+                agg = torch.zeros_like(x).index_add(0, tgt, x[src]) / count[:, None]
+                z = torch.cat([x, agg], 1) @ lw['kernel'] + lw['bias']
+                z = z * torch.rsqrt(torch.clamp((z * z).sum(1, keepdim=True), min=1e-12))
+                x = torch.relu(z)
+            else:
+                h = x @ lw['kernel']
+                e = (h @ lw['attn_self'])[tgt] + (h @ lw['attn_neigh'])[src]
+                e = torch.where(e > 0, e, 0.2 * e)
+                seg_max = torch.full((n,), -float('inf'), dtype=torch.float64).scatter_reduce(0, tgt, e.detach(), 'amax')
+                ex = torch.exp(e - seg_max[tgt])
+                denom = torch.zeros(n, dtype=torch.float64).index_add(0, tgt, ex) + 1e-9
+                alpha = ex / denom[tgt]
+                x = torch.relu(torch.zeros_like(h).index_add(0, tgt, alpha[:, None] * h[src]) + lw['bias'])
+            hs.append(x)
+    final_node = 'mean' if kind == 'lightgcn' else gnn.get('final_node', 'concatenation')
+    if final_node == 'concatenation':
+        e_all = torch.cat(hs, 1)
+    elif final_node == 'last':
+        e_all = hs[-1]
+    else:
+        e_all = sum(hs) / (len(hs) if final_node == 'mean' else 1)
+
+    def run(net, v, last_sigmoid=False):
+        for k, (w, b) in enumerate(net):
+            v = v @ w + b
+            v = torch.sigmoid(v) if (last_sigmoid and k == len(net) - 1) else torch.relu(v)
+        return v
+    u = torch.as_tensor(np.asarray(u_ids), dtype=torch.long)
+    i = torch.as_tensor(np.asarray(i_ids), dtype=torch.long)
+    if 'unet' in nets:
+        p = run(nets['clf'], torch.cat([run(nets['unet'], e_all[u]), run(nets['inet'], e_all[i])], 1), True)[:, 0]
+    else:
+        ub = torch.tensor(np.asarray(bert[0], dtype=np.float64))
+        ib = torch.tensor(np.asarray(bert[1], dtype=np.float64))
+        x1 = run(nets['dense3a'], torch.cat([run(nets['dense1a'], e_all[u]), run(nets['dense1b'], e_all[i])], 1))
+        x2 = run(nets['dense3b'], torch.cat([run(nets['dense2a'], ub), run(nets['dense2b'], ib)], 1))
+        p = run(nets['clf'], torch.cat([x1, x2], 1), True)[:, 0]
+    yv = torch.tensor(np.asarray(y, dtype=np.float64))
+    pc = torch.clamp(p, EPS, 1 - EPS)
+    loss = -torch.mean(yv * torch.log(pc + EPS) + (1 - yv) * torch.log(1 - pc + EPS)) + l2 * (x0 ** 2).sum()
+    for lw in layers:
+        for name in ('kernel', 'bias'):
+            if name in lw:
+                loss = loss + l2 * (lw[name] ** 2).sum()
+    loss.backward()
+    g = lambda t: t.grad.numpy() if t.grad is not None else np.zeros(tuple(t.shape))
+    grads = {'gnn': {'embeddings': g(x0), 'layers': [{k: g(v) for k, v in lw.items()} for lw in layers]},
+             'head': {name: [(g(w), g(b)) for w, b in nets[name]] for name in nets}}
+    return float(loss.detach()), grads, p.detach().numpy()

@@ -153,8 +153,8 @@ def test_model_classes_resolve_and_param_counts():
         basic.BasicGCN(adj, **dict(cfg, final_node='bogus'))
     with pytest.raises(ValueError):
         hybrid.HybridCBRS(fusion_method='bogus')
-    with pytest.raises(NotImplementedError):                  # reverse passes exist for GCN / LightGCN stacks only
-        basic.BasicGraphSage(adj, **cfg).fit(None)
+    with pytest.raises(NotImplementedError):                  # no reverse pass for this reduction
+        basic.BasicGCN(adj, **dict(cfg, final_node='last')).fit(None)
 
 
 def test_seed_reproducibility_and_glorot_limits():

@@ -72,14 +72,43 @@ def test_training_kernels(hip):
     assert helpers.rel_err(md.cpu().numpy(), m2) < 1e-6 and helpers.rel_err(vd.cpu().numpy(), v2) < 1e-6
 
 
+def test_sage_training_kernels(hip):
+    rng = np.random.default_rng(1)
+    M, W = 777, 12
+    a, b = rng.standard_normal((M, W)).astype(np.float32), rng.standard_normal((M, W)).astype(np.float32)
+    sc = rng.uniform(0.1, 1, M).astype(np.float32)
+    out = torch.zeros((M, 2 * W), device=DEV)
+    hip.row_affine(_t(a), _t(sc), out[:, W:], b=_t(b))
+    assert helpers.rel_err(out.cpu().numpy()[:, W:], (a + b) * sc[:, None]) < 1e-6 and float(out[:, :W].abs().max()) == 0
+    hip.row_affine(_t(a), _t(sc), out[:, :W])
+    assert helpers.rel_err(out.cpu().numpy()[:, :W], a * sc[:, None]) < 1e-6
+    z = rng.standard_normal((M, W)).astype(np.float32)
+    z[5] = 0                                           # clamped row: inv = 1e6
+    z[6] *= 1e-8
+    nrm, inv, y = torch.empty((M, W), device=DEV), torch.empty(M, device=DEV), torch.empty((M, W), device=DEV)
+    hip.l2norm_fwd(_t(z), nrm, inv, y, act='relu')
+    z64 = z.astype(np.float64)
+    want_inv = 1 / np.sqrt(np.maximum((z64 * z64).sum(1), 1e-12))
+    assert helpers.rel_err(inv.cpu().numpy(), want_inv) < 1e-6
+    assert helpers.rel_err(nrm.cpu().numpy(), z64 * want_inv[:, None]) < 1e-6
+    assert np.array_equal(y.cpu().numpy(), np.maximum(nrm.cpu().numpy(), 0))
+    dy = rng.standard_normal((M, W)).astype(np.float32)
+    dz = torch.empty((M, W), device=DEV)
+    hip.l2norm_bwd(_t(dy), nrm, inv, dz, act='relu')
+    zt = torch.tensor(z64, requires_grad=True)
+    nt = zt * torch.rsqrt(torch.clamp((zt * zt).sum(1, keepdim=True), min=1e-12))
+    (torch.relu(nt) * torch.tensor(dy.astype(np.float64))).sum().backward()
+    assert helpers.rel_err(dz.cpu().numpy(), zt.grad.numpy()) < 1e-5
+
+
 def _flatten_oracle_grads(model, grads):
     """Oracle gradient containers -> {product parameter: ndarray}."""
     out = {}
     seq = model.gnn.gnn_layers
     out[seq.embeddings] = grads['gnn']['embeddings']
     for layer, gl in zip(seq.seq_layers, grads['gnn']['layers']):
-        if gl:
-            out[layer.kernel], out[layer.bias] = gl['kernel'], gl['bias']
+        for name, arr in gl.items():
+            out[getattr(layer, name)] = arr
     for name in ('unet', 'inet', 'clf'):
         for layer, (gw, gb) in zip(getattr(model.rs, name).layers, grads['head'][name]):
             out[layer.kernel], out[layer.bias] = gw, gb
@@ -108,6 +137,36 @@ def test_gradients_match_oracle(hip, cls, graph):
     for prm, gw in flat.items():
         got = grads[prm].cpu().numpy().reshape(gw.shape).astype(np.float64)
         got += 2 * trainer._l2(prm) * prm.detach().cpu().numpy().reshape(gw.shape)      # the trainer folds the L2 term into amar_adam_f32
+        assert helpers.rel_err(got, gw) < 2e-4, tuple(prm.shape)
+
+
+@pytest.mark.parametrize('cls', ['BasicGraphSage'])
+@pytest.mark.parametrize('graph', ['ui', 'uip'])
+def test_gradients_match_autograd_oracle(hip, cls, graph):
+    """Model kinds without a manual numpy reverse pass: oracle = torch autograd of the restated forward (float64)."""
+    from deep_cbrs_amar_renaissance_amd import engine, training
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    engine.set_seed(5)
+    g = helpers.tiny_graph(n_users=80, n_items=60, n_ratings=1500, seed=9,
+                           n_props=30 if graph == 'uip' else 0, n_links=90 if graph == 'uip' else 0)
+    model = getattr(basic, cls)(g['adj'], **CFG)
+    helpers.randomize_biases(model, seed=6)
+    y = np.random.default_rng(2).integers(0, 2, len(g['u_ids']))
+    trainer = training.Trainer(model)
+    loss, grads = trainer.loss_and_grads(g['u_ids'], g['i_ids'], y)
+    # the training forward (unfused, keeps intermediates) scores like the fused inference forward
+    with torch.no_grad():
+        e_inf = model.gnn.gnn_layers(None)
+        e_trn = trainer._propagation_forward()
+    assert float((e_inf - e_trn).abs().max()) < 2e-6
+    want_loss, want, _ = otrain.torch_model_grads(g['adj'], helpers.gnn_to_oracle(model.gnn), helpers.basic_head_to_oracle(model.rs),
+                                                  g['u_ids'], g['i_ids'], y, l2=1e-4)
+    assert abs(loss - want_loss) < 1e-5
+    flat = _flatten_oracle_grads(model, want)
+    assert set(flat) == set(grads)
+    for prm, gw in flat.items():
+        got = grads[prm].cpu().numpy().reshape(gw.shape).astype(np.float64)
+        got += 2 * trainer._l2(prm) * prm.detach().cpu().numpy().reshape(gw.shape)
         assert helpers.rel_err(got, gw) < 2e-4, tuple(prm.shape)
 
 

@@ -160,7 +160,7 @@ class BasicGNN(Model, abc.ABC):
         return self.rs.score_towers(towers, u, i, 0, lo)
 
     def fit(self, sequence, epochs=1, **kwargs):
-        """Keras ``fit``: BCE + L2 + Adam over the batches of `sequence` (training.py; GCN and LightGCN stacks)."""
+        """Keras ``fit``: BCE + L2 + Adam over the batches of `sequence` (training.py)."""
         from deep_cbrs_amar_renaissance_amd import training
         return training.fit(self, sequence, epochs=epochs, **kwargs)
 

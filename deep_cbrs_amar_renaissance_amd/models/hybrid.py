@@ -253,6 +253,11 @@ class HybridBertGNN(Model, abc.ABC):
             return self.rs.score_towers(self._towers[1], u, i, 0, self._towers[2])
         return self.rs([embeddings, embeddings, ub, ib], g_ids=(u, i))
 
+    def fit(self, sequence, epochs=1, **kwargs):
+        """Keras ``fit``: BCE + L2 + Adam over the batches of `sequence` (training.py)."""
+        from deep_cbrs_amar_renaissance_amd import training
+        return training.fit(self, sequence, epochs=epochs, **kwargs)
+
     def _hoist_begin(self, hoist):
         self.gnn.hoist = bool(hoist)
 

@@ -14,7 +14,8 @@ A_hat^T . dZ (A_hat is symmetric) and the forward GEMM for dX = dZ . W^T.
 Implemented for GCN, GraphSAGE (both 'concatenation') and LightGCN ('mean') stacks.  GraphSAGE trains on an
 unfused forward that keeps what the reverse pass needs ([x || mean] and the normalised pre-activation); its
 aggregate (A + I) / count is symmetric up to the row scale, so the reverse aggregate is the same value-free SpMM.
-GAT reverse passes and the hybrid head are not implemented yet and raise.
+The hybrid head (HybridCBRS, 'concatenate' fusion, both feature_based settings) trains on the same Dense tapes; its
+BERT inputs are constants.  The GAT reverse pass is not implemented yet and raises.
 """
 import numpy as np
 import torch
@@ -56,9 +57,10 @@ class _DenseTape:
             x = y
         return x
 
-    def backward(self, dy, grads, last_is_dz=False):
+    def backward(self, dy, grads, last_is_dz=False, need_input_grad=True):
         """dy: gradient w.r.t. the stack's output (or, with last_is_dz, already w.r.t. the last pre-activation).
-        Fills grads[param] for every kernel/bias; returns the gradient w.r.t. the stack's input."""
+        Fills grads[param] for every kernel/bias; returns the gradient w.r.t. the stack's input (None when
+        need_input_grad is False: constant inputs such as the BERT rows)."""
         for k in range(len(self.layers) - 1, -1, -1):
             layer, x, y = self.layers[k], self.inputs[k], self.outputs[k]
             if last_is_dz and k == len(self.layers) - 1:
@@ -69,16 +71,74 @@ class _DenseTape:
             dw, db = torch.empty_like(layer.kernel), torch.empty_like(layer.bias)
             capi.wgrad(x, dz, dw, db)
             grads[layer.kernel], grads[layer.bias] = dw, db
+            if k == 0 and not need_input_grad:
+                return None
             dx = torch.empty((x.shape[0], layer.kernel.shape[0]), dtype=torch.float32, device=x.device)
             capi.dense(dz, capi.transpose(layer.kernel.detach()), None, dx, act=None)
             dy = dx
         return dy
 
 
+def _concat(a, b):
+    out = torch.empty((a.shape[0], a.shape[1] + b.shape[1]), dtype=torch.float32, device=a.device)
+    capi.copy_columns(a, out[:, :a.shape[1]])
+    capi.copy_columns(b, out[:, a.shape[1]:])
+    return out
+
+
+class _BasicHead:
+    """BasicRS (basic.py:11-37) with saved activations: towers on E[u], E[i]; classifier on their concatenation."""
+
+    def __init__(self, rs):
+        self.unet, self.inet, self.clf = _DenseTape(rs.unet), _DenseTape(rs.inet), _DenseTape(rs.clf)
+
+    def forward(self, gu, gi, bert):
+        tu, ti = self.unet.forward(gu), self.inet.forward(gi)
+        self.d = tu.shape[1]
+        return self.clf.forward(_concat(tu, ti))
+
+    def backward(self, dz, grads):
+        """dz = dL/d(last pre-activation). Returns (dL/dE[u], dL/dE[i])."""
+        dcat = self.clf.backward(dz, grads, last_is_dz=True)
+        return self.unet.backward(dcat[:, :self.d], grads), self.inet.backward(dcat[:, self.d:], grads)
+
+
+class _HybridHead:
+    """HybridCBRS (hybrid.py:13-89), fusion 'concatenate', with saved activations.  The BERT rows are constants."""
+
+    def __init__(self, rs):
+        self.fb = bool(rs.feature_based)
+        self.t = {name: _DenseTape(getattr(rs, name)) for name in ('dense1a', 'dense1b', 'dense2a', 'dense2b', 'dense3a', 'dense3b', 'clf')}
+
+    def forward(self, gu, gi, bert):
+        ub, ib = bert
+        t = self.t
+        g1, g2 = t['dense1a'].forward(gu), t['dense1b'].forward(gi)
+        b1, b2 = t['dense2a'].forward(ub), t['dense2b'].forward(ib)
+        self.d1, self.d2 = g1.shape[1], b1.shape[1]
+        # feature based: (graph user, graph item) | (bert user, bert item); else per entity (hybrid.py:72-84)
+        x1 = t['dense3a'].forward(_concat(g1, g2) if self.fb else _concat(g1, b1))
+        x2 = t['dense3b'].forward(_concat(b1, b2) if self.fb else _concat(g2, b2))
+        self.d3 = x1.shape[1]
+        return t['clf'].forward(_concat(x1, x2))
+
+    def backward(self, dz, grads):
+        t, d1, d2 = self.t, self.d1, self.d2
+        dcat = t['clf'].backward(dz, grads, last_is_dz=True)
+        da, db = t['dense3a'].backward(dcat[:, :self.d3], grads), t['dense3b'].backward(dcat[:, self.d3:], grads)
+        if self.fb:
+            dg1, dg2, db1, db2 = da[:, :d1], da[:, d1:], db[:, :d2], db[:, d2:]
+        else:
+            dg1, db1, dg2, db2 = da[:, :d1], da[:, d1:], db[:, :d1], db[:, d1:]
+        t['dense2a'].backward(db1, grads, need_input_grad=False)
+        t['dense2b'].backward(db2, grads, need_input_grad=False)
+        return t['dense1a'].backward(dg1, grads), t['dense1b'].backward(dg2, grads)
+
+
 class Trainer:
     """Holds the Adam state of a Basic{GCN,GraphSage,LightGCN} model and performs training batches."""
 
-    def __init__(self, model, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+    def __init__(self, model, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, bert_dim=None):
         seq = model.gnn.gnn_layers
         layers = list(seq.seq_layers)
         if layers and all(isinstance(l, GCNConv) for l in layers) and seq.final_node == 'concatenation':
@@ -98,15 +158,21 @@ class Trainer:
         else:
             raise NotImplementedError("training is implemented for GCN / GraphSAGE ('concatenation') and LightGCN stacks; "
                                       "the GAT reverse pass is not built yet")
+        self.hybrid = hasattr(model.rs, 'dense1a')
         if not model.rs.built:
-            model.rs.build_head(model.gnn.output_dim(), model.gnn.output_dim())
+            if self.hybrid:
+                if getattr(model, 'bert_table', None) is None and bert_dim is None:
+                    raise ValueError("the hybrid head is not built yet: register the BERT table or pass bert_dim")
+                model.rs.build_head(model.gnn.output_dim(), bert_dim if bert_dim is not None else model.bert_table.shape[1])
+            else:
+                model.rs.build_head(model.gnn.output_dim(), model.gnn.output_dim())
         self.model, self.seq = model, seq
         self.lr, self.b1, self.b2, self.eps = float(learning_rate), float(beta_1), float(beta_2), float(epsilon)
         self.t = 0
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.m = {p: torch.zeros_like(p) for p in self.params}
         self.v = {p: torch.zeros_like(p) for p in self.params}
-        self.unet, self.inet, self.clf = _DenseTape(model.rs.unet), _DenseTape(model.rs.inet), _DenseTape(model.rs.clf)
+        self.head = _HybridHead(model.rs) if self.hybrid else _BasicHead(model.rs)
 
     @staticmethod
     def _l2(param):
@@ -114,8 +180,19 @@ class Trainer:
         return float(reg.l2) if reg is not None else 0.0
 
     # -- one batch ------------------------------------------------------------------------------------------------
-    def loss_and_grads(self, u_ids, i_ids, y):
-        """Forward + reverse pass of one batch. Returns (data loss + regularisation loss, {param: gradient})."""
+    def _bert_rows(self, ids, block):
+        if block is not None:
+            return to_device_tensor(block)
+        table = getattr(self.model, 'bert_table', None)
+        if table is None:
+            raise ValueError("no BERT block in the batch and no resident table registered")
+        rows = torch.empty((ids.numel(), table.shape[1]), dtype=torch.float32, device=table.device)
+        capi.copy_columns(table, rows, ids=ids)
+        return rows
+
+    def loss_and_grads(self, u_ids, i_ids, y, bert=None):
+        """Forward + reverse pass of one batch. Returns (data loss + regularisation loss, {param: gradient}).
+        `bert` = (user block, item block) for the hybrid head (None: rows of the resident table)."""
         model, seq = self.model, self.seq
         u, i = ids_to_device(u_ids), ids_to_device(i_ids)
         yv = to_device_tensor(np.asarray(y, dtype=np.float32) if not isinstance(y, torch.Tensor) else y)
@@ -128,20 +205,17 @@ class Trainer:
             gi = torch.empty((b, f), dtype=torch.float32, device=dev)
             capi.copy_columns(e, gu, ids=u)
             capi.copy_columns(e, gi, ids=i)
-            tu, ti = self.unet.forward(gu), self.inet.forward(gi)
-            d = tu.shape[1]
-            cat = torch.empty((b, 2 * d), dtype=torch.float32, device=dev)
-            capi.copy_columns(tu, cat[:, :d])
-            capi.copy_columns(ti, cat[:, d:])
-            p = self.clf.forward(cat)
+            rows = None
+            if self.hybrid:
+                ub, ib = bert if bert is not None else (None, None)
+                rows = (self._bert_rows(u, ub), self._bert_rows(i, ib))
+            p = self.head.forward(gu, gi, rows)
             # ---- loss and its gradient through the final sigmoid
             dz = torch.empty((b, 1), dtype=torch.float32, device=dev)
             terms = torch.empty(b, dtype=torch.float32, device=dev)
             capi.bce_grad(p, yv, dz, terms)
             grads = {}
-            dcat = self.clf.backward(dz, grads, last_is_dz=True)
-            dgu = self.unet.backward(dcat[:, :d], grads)
-            dgi = self.inet.backward(dcat[:, d:], grads)
+            dgu, dgi = self.head.backward(dz, grads)
             de = torch.zeros((e.shape[0], f), dtype=torch.float32, device=dev)
             capi.scatter_add_rows(dgu, u, de)
             capi.scatter_add_rows(dgi, i, de)
@@ -259,8 +333,8 @@ class Trainer:
                 prm._version  # noqa: B018  (data-level update; bump below keeps hoisting caches honest)
                 prm.add_(0)                                            # bumps the autograd version counter
 
-    def train_batch(self, u_ids, i_ids, y):
-        loss, grads = self.loss_and_grads(u_ids, i_ids, y)
+    def train_batch(self, u_ids, i_ids, y, bert=None):
+        loss, grads = self.loss_and_grads(u_ids, i_ids, y, bert=bert)
         self.apply_gradients(grads)
         return loss
 
@@ -271,13 +345,19 @@ def fit(model, sequence, epochs=1, callbacks=None, verbose=True, **kwargs):
     hp = {k: getattr(opt, k) for k in ('learning_rate', 'beta_1', 'beta_2', 'epsilon') if hasattr(opt, k)}
     trainer = getattr(model, '_trainer', None)
     if trainer is None:
+        if hasattr(model.rs, 'dense1a') and not model.rs.built and len(sequence):
+            first = sequence[0][0]
+            if len(first) >= 4 and first[2] is not None:
+                hp['bert_dim'] = int(np.asarray(first[2]).shape[1])
         trainer = model._trainer = Trainer(model, **hp)
     history = []
     for epoch in range(int(epochs)):
         total, count = 0.0, 0
         for b in range(len(sequence)):
-            (u, i), y = sequence[b]
-            total += trainer.train_batch(u, i, y) * len(y)
+            inputs, y = sequence[b]
+            u, i = inputs[0], inputs[1]
+            bert = (inputs[2], inputs[3]) if len(inputs) >= 4 else None     # hybrid batches carry the BERT blocks (datasets.py:112-115)
+            total += trainer.train_batch(u, i, y, bert=bert) * len(y)
             count += len(y)
         history.append(total / max(count, 1))
         if verbose:

@@ -156,7 +156,7 @@ def torch_grads(adj, gnn, head, u_ids, i_ids, y, l2=0.0):
                          'head': {name: [(g(w), g(b)) for w, b in nets[name]] for name in nets}}
 
 
-def torch_model_grads(adj, gnn, head, u_ids, i_ids, y, l2=0.0, self_loops=True, bert=None):
+def torch_model_grads(adj, gnn, head, u_ids, i_ids, y, l2=0.0, self_loops=True, bert=None, feature_based=True):
     """Loss and gradients of ANY model on the path by torch autograd (float64, CPU): the four GNN kinds of
     oracle/models.py:propagate under the Basic head (keys unet/inet/clf) or the Hybrid head (dense1a..dense3b, clf;
     `bert` = (user rows [B, D], item rows [B, D]) as the batch Sequence delivers them, hybrid.py:119-140).
@@ -222,8 +222,10 @@ def torch_model_grads(adj, gnn, head, u_ids, i_ids, y, l2=0.0, self_loops=True, 
     else:
         ub = torch.tensor(np.asarray(bert[0], dtype=np.float64))
         ib = torch.tensor(np.asarray(bert[1], dtype=np.float64))
-        x1 = run(nets['dense3a'], torch.cat([run(nets['dense1a'], e_all[u]), run(nets['dense1b'], e_all[i])], 1))
-        x2 = run(nets['dense3b'], torch.cat([run(nets['dense2a'], ub), run(nets['dense2b'], ib)], 1))
+        g1, g2, b1, b2 = run(nets['dense1a'], e_all[u]), run(nets['dense1b'], e_all[i]), run(nets['dense2a'], ub), run(nets['dense2b'], ib)
+        # hybrid.py:72-84: feature based = (graph user, graph item) | (bert user, bert item); otherwise one branch per entity
+        x1 = run(nets['dense3a'], torch.cat([g1, g2] if feature_based else [g1, b1], 1))
+        x2 = run(nets['dense3b'], torch.cat([b1, b2] if feature_based else [g2, b2], 1))
         p = run(nets['clf'], torch.cat([x1, x2], 1), True)[:, 0]
     yv = torch.tensor(np.asarray(y, dtype=np.float64))
     pc = torch.clamp(p, EPS, 1 - EPS)

@@ -109,7 +109,7 @@ def _flatten_oracle_grads(model, grads):
     for layer, gl in zip(seq.seq_layers, grads['gnn']['layers']):
         for name, arr in gl.items():
             out[getattr(layer, name)] = arr
-    for name in ('unet', 'inet', 'clf'):
+    for name in grads['head']:
         for layer, (gw, gb) in zip(getattr(model.rs, name).layers, grads['head'][name]):
             out[layer.kernel], out[layer.bias] = gw, gb
     return out
@@ -168,6 +168,67 @@ def test_gradients_match_autograd_oracle(hip, cls, graph):
         got = grads[prm].cpu().numpy().reshape(gw.shape).astype(np.float64)
         got += 2 * trainer._l2(prm) * prm.detach().cpu().numpy().reshape(gw.shape)
         assert helpers.rel_err(got, gw) < 2e-4, tuple(prm.shape)
+
+
+@pytest.mark.parametrize('cls,feature_based', [('HybridBertGCN', True), ('HybridBertGCN', False), ('HybridBertGraphSage', True),
+                                                ('HybridBertLightGCN', True)])
+def test_hybrid_gradients_match_autograd_oracle(hip, cls, feature_based):
+    """HybridBertGNN (hybrid.py:92-140): GNN + four-input head; BERT rows from the batch or from the resident table."""
+    from deep_cbrs_amar_renaissance_amd import engine, training
+    from deep_cbrs_amar_renaissance_amd.models import hybrid
+    engine.set_seed(11)
+    g = helpers.tiny_graph(n_users=80, n_items=60, n_ratings=1500, seed=4)
+    cfg = dict(embedding_dim=8, n_hiddens=[8, 8], n_layers=2, dense_units=[[24, 16], [32, 16], [16, 16]], clf_units=[24, 24],
+               l2_regularizer=1e-4, feature_based=feature_based)
+    model = getattr(hybrid, cls)(g['adj'], **cfg)
+    rng = np.random.default_rng(3)
+    table = rng.standard_normal((g['adj'].shape[0], 40)).astype(np.float32) * 0.5
+    model.set_bert_table(table)
+    y = rng.integers(0, 2, len(g['u_ids']))
+    trainer = training.Trainer(model)
+    helpers.randomize_biases(model, seed=7)
+    u, i = g['u_ids'], g['i_ids']
+    loss, grads = trainer.loss_and_grads(u, i, y)                                  # rows of the resident table
+    loss_b, grads_b = trainer.loss_and_grads(u, i, y, bert=(table[u], table[i]))   # blocks delivered by the Sequence
+    # (the embedding-row scatter uses float atomics: sums may differ in the last bits between runs)
+    assert loss == loss_b and all(torch.allclose(grads[k], grads_b[k], rtol=1e-5, atol=1e-9) for k in grads)
+    want_loss, want, p = otrain.torch_model_grads(g['adj'], helpers.gnn_to_oracle(model.gnn), helpers.hybrid_head_to_oracle(model.rs),
+                                                  u, i, y, l2=1e-4, bert=(table[u], table[i]), feature_based=feature_based)
+    with torch.no_grad():
+        got_p = model((u, i, None, None)).cpu().numpy()[:, 0]
+    assert np.abs(got_p - p).max() < 1e-5
+    assert abs(loss - want_loss) < 1e-5
+    flat = _flatten_oracle_grads(model, want)
+    assert set(flat) == set(grads)
+    for prm, gw in flat.items():
+        got = grads[prm].cpu().numpy().reshape(gw.shape).astype(np.float64)
+        got += 2 * trainer._l2(prm) * prm.detach().cpu().numpy().reshape(gw.shape)
+        assert helpers.rel_err(got, gw) < 2e-4, tuple(prm.shape)
+
+
+def test_hybrid_fit_reduces_loss(hip):
+    from deep_cbrs_amar_renaissance_amd import engine
+    from deep_cbrs_amar_renaissance_amd.models import hybrid
+    engine.set_seed(2)
+    g = helpers.tiny_graph(n_users=60, n_items=50, n_ratings=1200, seed=1)
+    model = hybrid.HybridBertGCN(g['adj'], embedding_dim=8, n_hiddens=[8, 8], dense_units=[[16], [16], [16]], clf_units=[16],
+                                 feature_based=True, l2_regularizer=1e-5)
+    rng = np.random.default_rng(0)
+    table = rng.standard_normal((g['adj'].shape[0], 24)).astype(np.float32)
+    u, i = g['u_ids'], g['i_ids']
+    y = ((table[u, 0] + table[i, 1]) > 0).astype(np.float32)          # learnable from the BERT rows alone
+
+    class Seq:
+        def __len__(self):
+            return 3
+
+        def __getitem__(self, b):
+            s = slice(b * 100, (b + 1) * 100)
+            return (u[s], i[s], table[u[s]], table[i[s]]), y[s]
+    import types
+    model.compile(optimizer=types.SimpleNamespace(learning_rate=5e-3, beta_1=0.9))
+    hist = model.fit(Seq(), epochs=30, verbose=False)['loss']
+    assert hist[-1] < 0.6 * hist[0], hist[::6]
 
 
 def test_adam_steps_match_oracle(hip):

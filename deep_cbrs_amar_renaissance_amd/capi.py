@@ -51,6 +51,8 @@ SIGNATURES = {
     'amar_row_affine_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I32, _P]),
     'amar_l2norm_fwd_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _P]),
     'amar_l2norm_bwd_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _P]),
+    'amar_gat_bwd_f32': (ctypes.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I64,
+                                        _I32, _I32, _P]),
     'amar_transpose_f32': (ctypes.c_int, [_P, _I32, _I32, _P, _P]),
     'amar_adam_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _F32, _F32, _F32, _F32, _F32, _P]),
     'amar_topk_segmented_f32': (ctypes.c_int, [_P, _P, _P, _I32, _I32, _P, _P, _P]),
@@ -470,6 +472,28 @@ def l2norm_bwd(dy, nrm, inv, dz, act='relu'):
                                       _ptr(inv, torch.float32, 'inv'), _ptr(dz, torch.float32, 'dz'), _ld(dz, 'dz'), M, C,
                                       ACT_CODES[act], _stream())
     _check(code, 'amar_l2norm_bwd_f32')
+
+
+def gat_bwd(rowptr, colidx, H, s_self, s_neigh, Y, dY, bias, a_self, a_neigh, self_loop=True):
+    """Reverse of gat_layer. Returns (dout [n, C], ds [n], dt [n], dH [n, C])."""
+    n = rowptr.numel() - 1
+    C = H.shape[1]
+    if tuple(Y.shape) != (n, C) or tuple(dY.shape) != (n, C) or H.shape[0] != n or bias.numel() != C or \
+            a_self.numel() != C or a_neigh.numel() != C:
+        raise ValueError("gat_bwd: H, Y, dY [n, C]; bias, a_self, a_neigh [C] expected")
+    dev = H.device
+    dout = torch.empty((n, C), dtype=torch.float32, device=dev)
+    scratch = torch.empty(3 * n, dtype=torch.float32, device=dev)
+    ds, dt = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
+    dH = torch.empty((n, C), dtype=torch.float32, device=dev)
+    code = load().amar_gat_bwd_f32(
+        _ptr(rowptr, torch.int32, 'rowptr'), _ptr(colidx, torch.int32, 'colidx'), _ptr(H, torch.float32, 'H'), _ld(H, 'H'), C,
+        _ptr(s_self, torch.float32, 's_self'), _ptr(s_neigh, torch.float32, 's_neigh'), _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y'),
+        _ptr(dY, torch.float32, 'dY'), _ld(dY, 'dY'), _ptr(bias, torch.float32, 'bias'), _ptr(a_self, torch.float32, 'a_self'),
+        _ptr(a_neigh, torch.float32, 'a_neigh'), _ptr(dout), _ptr(scratch), _ptr(ds), _ptr(dt), _ptr(dH), C,
+        1 if self_loop else 0, n, _stream())
+    _check(code, 'amar_gat_bwd_f32')
+    return dout, ds, dt, dH
 
 
 def transpose(src):

@@ -174,6 +174,113 @@ __global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float *__restrict
     }
 }
 
+// ---- GAT reverse pass (Spektral GATConv._call_single, 1 head; forward: amar_gat_layer_f32) ----------------
+// With out_i = sum_j alpha_ij h_j + b, alpha = softmax_j(LeakyReLU(s_i + t_j)) (s = h.a_self, t = h.a_neigh) and
+// g_i = dL/dout_i (ReLU mask applied):   d alpha_ij = g_i . h_j,   sum_k alpha_ik d alpha_ik = g_i . (out_i - b) =: c_i,
+//   d e_ij = alpha_ij (d alpha_ij - c_i),  d pre_ij = d e_ij * LeakyReLU'(s_i + t_j),
+//   ds_i = sum_j d pre_ij,   dt_j = sum_i d pre_ij,   dh_j = sum_i alpha_ij g_i + ds_j a_self + dt_j a_neigh.
+// The edge multiset is symmetric, so "targets i that have j as a source" is CSR row j: both sums run row-wise, one
+// wavefront per node, without float atomics.  Kernel 1 (node as target) recomputes the softmax statistics.
+struct GatBwdArgs {
+    const int32_t *rowptr; const int32_t *colidx; const float *H; int64_t ldh; const float *s_self; const float *s_neigh;
+    const float *Y; int64_t ldy; const float *dY; int64_t ldd; const float *bias; const float *a_self; const float *a_neigh;
+    float *dout; float *row_max; float *row_inv; float *row_c; float *ds; float *dt; float *dH; int64_t lddh;
+    int self_loop; int n_rows;
+};
+
+__device__ __forceinline__ float leaky02(float x) { return x > 0.f ? x : 0.2f * x; }
+__device__ __forceinline__ float dot4(const float4 &a, const float4 &b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+template <int LPN>
+__device__ __forceinline__ float group_sum(float v) {               // over the LPN consecutive lanes of a slot
+#pragma unroll
+    for (int m = 1; m < LPN; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void gat_bwd_target_kernel(const GatBwdArgs a) {
+    constexpr int LPN = C / 4, NS = AMAR_WAVE / LPN;
+    const int lane = threadIdx.x & (AMAR_WAVE - 1);
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.n_rows) return;
+    const int q = lane % LPN, slot = lane / LPN;
+    const int beg = a.rowptr[row], end = a.rowptr[row + 1];
+    const float si = a.s_self[row];
+    const float4 y = *reinterpret_cast<const float4 *>(a.Y + (int64_t)row * a.ldy + 4 * q);
+    const float4 dy = *reinterpret_cast<const float4 *>(a.dY + (int64_t)row * a.ldd + 4 * q);
+    const float4 b = *reinterpret_cast<const float4 *>(a.bias + 4 * q);
+    const float4 g = make_float4(y.x > 0.f ? dy.x : 0.f, y.y > 0.f ? dy.y : 0.f, y.z > 0.f ? dy.z : 0.f, y.w > 0.f ? dy.w : 0.f);
+    if (slot == 0) *reinterpret_cast<float4 *>(a.dout + (int64_t)row * C + 4 * q) = g;
+    const float ci = wave_sum_stride<1>(slot == 0 ? dot4(g, make_float4(y.x - b.x, y.y - b.y, y.z - b.z, y.w - b.w)) : 0.f);
+    // softmax statistics as in the forward kernel
+    float mn = a.self_loop ? a.s_neigh[row] : -INFINITY;
+    for (int p = beg + lane; p < end; p += AMAR_WAVE) mn = fmaxf(mn, a.s_neigh[a.colidx[p]]);
+    mn = wave_max_all(mn);
+    const float emax = leaky02(si + mn);
+    float den = 0.f;
+    for (int p = beg + lane; p < end; p += AMAR_WAVE) den += expf(leaky02(si + a.s_neigh[a.colidx[p]]) - emax);
+    if (a.self_loop && lane == 0) den += expf(leaky02(si + a.s_neigh[row]) - emax);
+    den = wave_sum_stride<1>(den);
+    const float inv = 1.f / (den + 1e-9f);
+    float ds = 0.f;
+    auto edge = [&](int j) {
+        const float pre = si + a.s_neigh[j];
+        const float alpha = expf(leaky02(pre) - emax) * inv;
+        const float4 h = *reinterpret_cast<const float4 *>(a.H + (int64_t)j * a.ldh + 4 * q);
+        const float dalpha = group_sum<LPN>(dot4(g, h));
+        const float dpre = alpha * (dalpha - ci) * (pre > 0.f ? 1.f : 0.2f);
+        if (q == 0) ds += dpre;
+    };
+    // every lane of a slot group takes part in the shuffles: the loop bound is uniform per group
+    for (int p = beg + slot; p < end; p += NS) edge(a.colidx[p]);
+    if (a.self_loop && slot == 0) edge(row);
+    ds = wave_sum_stride<1>(ds);
+    if (lane == 0) { a.ds[row] = ds; a.row_max[row] = emax; a.row_inv[row] = inv; a.row_c[row] = ci; }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void gat_bwd_source_kernel(const GatBwdArgs a) {
+    constexpr int LPN = C / 4, NS = AMAR_WAVE / LPN;
+    const int lane = threadIdx.x & (AMAR_WAVE - 1);
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.n_rows) return;
+    const int q = lane % LPN, slot = lane / LPN;
+    const int beg = a.rowptr[row], end = a.rowptr[row + 1];
+    const float tj = a.s_neigh[row];
+    const float4 h = *reinterpret_cast<const float4 *>(a.H + (int64_t)row * a.ldh + 4 * q);
+    float4 acc = f4_zero();
+    float dt = 0.f;
+    auto edge = [&](int i) {
+        const float pre = a.s_self[i] + tj;
+        const float alpha = expf(leaky02(pre) - a.row_max[i]) * a.row_inv[i];
+        const float4 g = *reinterpret_cast<const float4 *>(a.dout + (int64_t)i * C + 4 * q);
+        acc = f4_fma(alpha, g, acc);
+        const float dalpha = group_sum<LPN>(dot4(g, h));
+        const float dpre = alpha * (dalpha - a.row_c[i]) * (pre > 0.f ? 1.f : 0.2f);
+        if (q == 0) dt += dpre;
+    };
+    for (int p = beg + slot; p < end; p += NS) edge(a.colidx[p]);
+    if (a.self_loop && slot == 0) edge(row);
+    acc = f4_wave_sum_stride<LPN>(acc);
+    dt = wave_sum_stride<1>(dt);
+    if (slot == 0) {
+        const float ds = a.ds[row];
+        const float4 as = *reinterpret_cast<const float4 *>(a.a_self + 4 * q);
+        const float4 an = *reinterpret_cast<const float4 *>(a.a_neigh + 4 * q);
+        *reinterpret_cast<float4 *>(a.dH + (int64_t)row * a.lddh + 4 * q) =
+            make_float4(acc.x + ds * as.x + dt * an.x, acc.y + ds * as.y + dt * an.y,
+                        acc.z + ds * as.z + dt * an.z, acc.w + ds * as.w + dt * an.w);
+    }
+    if (lane == 0) a.dt[row] = dt;
+}
+
+template <int C>
+void launch_gat_bwd(const GatBwdArgs &a, hipStream_t st) {
+    const dim3 grid((a.n_rows + 3) / 4), block(256);
+    hipLaunchKernelGGL(gat_bwd_target_kernel<C>, grid, block, 0, st, a);
+    hipLaunchKernelGGL(gat_bwd_source_kernel<C>, grid, block, 0, st, a);
+}
+
 unsigned grid1d(int64_t total) {
     int64_t b = (total + 255) / 256;
     return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
@@ -259,6 +366,32 @@ int amar_l2norm_bwd_f32(const float *dY, int64_t ldd, const float *Nrm, int64_t 
     if (act != AMAR_ACT_NONE && act != AMAR_ACT_RELU) return AMAR_EUNSUPPORTED;
     if (M == 0) return AMAR_OK;
     hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(grid1d(M)), dim3(256), 0, static_cast<hipStream_t>(stream), dY, ldd, Nrm, ldn, inv, dZ, ldz, M, C, act == AMAR_ACT_RELU);
+    return amar_check_launch();
+}
+
+int amar_gat_bwd_f32(const int32_t *rowptr, const int32_t *colidx, const float *H, int64_t ldh, int32_t C,
+                     const float *s_self, const float *s_neigh, const float *Y, int64_t ldy, const float *dY, int64_t ldd,
+                     const float *bias, const float *a_self, const float *a_neigh,
+                     float *dout, float *row_scratch, float *ds, float *dt, float *dH, int64_t lddh,
+                     int32_t self_loop, int32_t n_rows, amar_stream_t stream) {
+    if (n_rows < 0 || !rowptr || !H || !s_self || !s_neigh || !Y || !dY || !bias || !a_self || !a_neigh || !dout ||
+        !row_scratch || !ds || !dt || !dH) return AMAR_EINVAL;
+    if (ldh < C || ldy < C || ldd < C || lddh < C || (ldh & 3) || (ldy & 3) || (ldd & 3) || (lddh & 3)) return AMAR_EINVAL;
+    if (!amar_aligned16(H) || !amar_aligned16(Y) || !amar_aligned16(dY) || !amar_aligned16(bias) || !amar_aligned16(a_self) ||
+        !amar_aligned16(a_neigh) || !amar_aligned16(dout) || !amar_aligned16(dH)) return AMAR_EINVAL;
+    if (n_rows == 0) return AMAR_OK;
+    if (!colidx) return AMAR_EINVAL;
+    GatBwdArgs a{rowptr, colidx, H, ldh, s_self, s_neigh, Y, ldy, dY, ldd, bias, a_self, a_neigh, dout,
+                 row_scratch, row_scratch + n_rows, row_scratch + 2 * (int64_t)n_rows, ds, dt, dH, lddh, self_loop ? 1 : 0, n_rows};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (C) {
+    case 4:  launch_gat_bwd<4>(a, st); break;
+    case 8:  launch_gat_bwd<8>(a, st); break;
+    case 16: launch_gat_bwd<16>(a, st); break;
+    case 32: launch_gat_bwd<32>(a, st); break;
+    case 64: launch_gat_bwd<64>(a, st); break;
+    default: return AMAR_EUNSUPPORTED;
+    }
     return amar_check_launch();
 }
 

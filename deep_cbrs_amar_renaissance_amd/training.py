@@ -15,13 +15,15 @@ Implemented for GCN, GraphSAGE (both 'concatenation') and LightGCN ('mean') stac
 unfused forward that keeps what the reverse pass needs ([x || mean] and the normalised pre-activation); its
 aggregate (A + I) / count is symmetric up to the row scale, so the reverse aggregate is the same value-free SpMM.
 The hybrid head (HybridCBRS, 'concatenate' fusion, both feature_based settings) trains on the same Dense tapes; its
-BERT inputs are constants.  The GAT reverse pass is not implemented yet and raises.
+BERT inputs are constants.  GAT (1 head) trains on the inference kernels plus `amar_gat_bwd_f32`, which forms the
+softmax / attention-scalar gradients row-wise for both edge directions (symmetric edge multiset, no float atomics).
 """
 import numpy as np
 import torch
 
 from deep_cbrs_amar_renaissance_amd import capi
 from deep_cbrs_amar_renaissance_amd.engine import ids_to_device, to_device_tensor
+from deep_cbrs_amar_renaissance_amd.layers.gat_conv import GATConv
 from deep_cbrs_amar_renaissance_amd.layers.gcn_conv import GCNConv
 from deep_cbrs_amar_renaissance_amd.layers.graphsage_conv import GraphSageConv
 from deep_cbrs_amar_renaissance_amd.layers.lightgcn_conv import LightGCNConv
@@ -136,7 +138,7 @@ class _HybridHead:
 
 
 class Trainer:
-    """Holds the Adam state of a Basic{GCN,GraphSage,LightGCN} model and performs training batches."""
+    """Holds the Adam state of a Basic* / HybridBert* {GCN, GraphSage, GAT, LightGCN} model and performs training batches."""
 
     def __init__(self, model, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, bert_dim=None):
         seq = model.gnn.gnn_layers
@@ -155,9 +157,11 @@ class Trainer:
             # unsorted_segment_mean: sum / count, 0 for an empty segment
             self.inv_cnt = (1.0 / (deg + 1.0)) if self.self_loops else torch.where(deg > 0, 1.0 / deg.clamp(min=1.0), torch.zeros_like(deg))
             self.inv_cnt = self.inv_cnt.contiguous()
+        elif layers and all(isinstance(l, GATConv) for l in layers) and seq.final_node == 'concatenation':
+            self.kind = 'gat'
         else:
-            raise NotImplementedError("training is implemented for GCN / GraphSAGE ('concatenation') and LightGCN stacks; "
-                                      "the GAT reverse pass is not built yet")
+            raise NotImplementedError("training is implemented for GCN / GraphSAGE / GAT stacks with 'concatenation' "
+                                      "and for LightGCN ('mean')")
         self.hybrid = hasattr(model.rs, 'dense1a')
         if not model.rs.built:
             if self.hybrid:
@@ -231,8 +235,10 @@ class Trainer:
         """E = gnn(None).  GCN / LightGCN: the inference kernels (their outputs are all the reverse pass needs);
         GraphSAGE: layer by layer, keeping [x || mean(x)] and the l2-normalised pre-activation."""
         seq = self.seq
-        if self.kind != 'sage':
+        if self.kind in ('gcn', 'lightgcn'):
             return seq(None)
+        if self.kind == 'gat':
+            return self._gat_forward()
         a = seq.adj_matrix
         widths = seq.layer_widths()
         seq._build_layers(widths)
@@ -257,7 +263,64 @@ class Trainer:
             self._tape.append((xa, nrm, inv))
         return cat
 
+    def _gat_forward(self):
+        """GATConv.call layer by layer (same kernels as inference), keeping H and the two attention scalars."""
+        seq = self.seq
+        a = seq.adj_matrix
+        widths = seq.layer_widths()
+        seq._build_layers(widths)
+        n, dev = a.shape[0], seq.embeddings.device
+        offs = np.cumsum([0] + widths)
+        cat = torch.empty((n, int(offs[-1])), dtype=torch.float32, device=dev)
+        sl = lambda k: cat[:, offs[k]:offs[k + 1]]
+        capi.copy_columns(seq.embeddings, sl(0))
+        self._tape = []
+        for k, layer in enumerate(seq.seq_layers):
+            c = widths[k + 1]
+            h = torch.empty((n, c), dtype=torch.float32, device=dev)
+            s_self = torch.empty(n, dtype=torch.float32, device=dev)
+            s_neigh = torch.empty(n, dtype=torch.float32, device=dev)
+            capi.rowwise_xw(sl(k), layer.kernel.view(-1, c), h, a_self=layer.attn_kernel_self.view(c),
+                            a_neigh=layer.attn_kernel_neighs.view(c), s_self=s_self, s_neigh=s_neigh)
+            capi.gat_layer(a.rowptr, a.colidx, h, s_self, s_neigh, layer.bias, sl(k + 1), self_loop=layer.add_self_loops)
+            self._tape.append((h, s_self, s_neigh))
+        return cat
+
+    def _gat_backward(self, e, de, grads):
+        seq, a = self.seq, self.seq.adj_matrix
+        layers = list(seq.seq_layers)
+        n, dev = e.shape[0], e.device
+        widths = seq.layer_widths()
+        offs = np.cumsum([0] + widths)
+        sl = lambda t, k: t[:, offs[k]:offs[k + 1]]
+        for k in range(len(layers) - 1, -1, -1):
+            layer = layers[k]
+            f, c = widths[k], widths[k + 1]
+            h, s_self, s_neigh = self._tape[k]
+            w2d = layer.kernel.detach().view(f, c)
+            dout, ds, dt, dh = capi.gat_bwd(a.rowptr, a.colidx, h, s_self, s_neigh, sl(e, k + 1), sl(de, k + 1), layer.bias,
+                                            layer.attn_kernel_self.detach().view(c), layer.attn_kernel_neighs.detach().view(c),
+                                            self_loop=layer.add_self_loops)
+            db = torch.empty_like(layer.bias)
+            capi.wgrad(None, dout, None, db)
+            das, dan = torch.empty((c, 1), dtype=torch.float32, device=dev), torch.empty((c, 1), dtype=torch.float32, device=dev)
+            capi.wgrad(h, ds.view(n, 1), das, None)
+            capi.wgrad(h, dt.view(n, 1), dan, None)
+            dw = torch.empty((f, c), dtype=torch.float32, device=dev)
+            capi.wgrad(sl(e, k), dh, dw, None)
+            grads[layer.kernel], grads[layer.bias] = dw.view_as(layer.kernel), db
+            grads[layer.attn_kernel_self], grads[layer.attn_kernel_neighs] = das.view_as(layer.attn_kernel_self), dan.view_as(layer.attn_kernel_neighs)
+            back = torch.empty((n, f), dtype=torch.float32, device=dev)
+            capi.dense(dh, capi.transpose(w2d.contiguous()), None, back, act=None)
+            capi.add_inplace(sl(de, k), back)
+        g0 = torch.empty_like(seq.embeddings)
+        capi.copy_columns(sl(de, 0), g0)
+        grads[seq.embeddings] = g0
+        self._tape = None
+
     def _propagation_backward(self, e, de, grads):
+        if self.kind == 'gat':
+            return self._gat_backward(e, de, grads)
         seq, a = self.seq, self.seq.adj_matrix
         layers = list(seq.seq_layers)
         n, dev = e.shape[0], e.device

@@ -224,6 +224,12 @@ int amar_reduce_layers_f32(const float *cat, int64_t ld, int32_t n_layers, int32
  *                           rsqrt(max(sum z^2, 1e-12)), Nrm = z * inv (kept for the reverse pass), Y = act(Nrm)
  * amar_l2norm_bwd_f32       dZ = inv * (dn - Nrm * (Nrm . dn)) with dn = dY * act'(Nrm); dZ = inv * dn where the norm
  *                           was clamped
+ * amar_gat_bwd_f32          reverse of amar_gat_layer_f32 (Spektral GATConv, src/models/gnn.py:321-328) given dY = dL/dY:
+ *                           dout = dY * [Y > 0] ([n, C] contiguous, also the source of the bias gradient), ds / dt = the
+ *                           gradients of the two attention scalars per node, dH = dL/dH including their ds (x) a_self +
+ *                           dt (x) a_neigh terms.  row_scratch: 3 * n_rows floats.  Row-wise sums only (no float atomics):
+ *                           relies on the edge multiset being symmetric, as build_adjacency_matrix + symmetrize_matrix
+ *                           produce it (src/data/preprocess.py:44-170, src/utilities/math.py:6-21).  C in {4,8,16,32,64}.
  * amar_transpose_f32        dst[N,K] = src[K,N]^T
  * amar_adam_f32             keras.optimizers.Adam on a flat parameter: g' = g + 2*l2*w; m, v moments; lr_t = the
  *                           bias-corrected step lr * sqrt(1 - b2^t) / (1 - b1^t);  w -= lr_t * m / (sqrt(v) + epsilon)
@@ -243,6 +249,11 @@ int amar_l2norm_fwd_f32(const float *Z, int64_t ldz, float *Nrm, int64_t ldn, fl
                         int64_t M, int32_t C, int32_t act, amar_stream_t stream);
 int amar_l2norm_bwd_f32(const float *dY, int64_t ldd, const float *Nrm, int64_t ldn, const float *inv, float *dZ, int64_t ldz,
                         int64_t M, int32_t C, int32_t act, amar_stream_t stream);
+int amar_gat_bwd_f32(const int32_t *rowptr, const int32_t *colidx, const float *H, int64_t ldh, int32_t C,
+                     const float *s_self, const float *s_neigh, const float *Y, int64_t ldy, const float *dY, int64_t ldd,
+                     const float *bias, const float *a_self, const float *a_neigh,
+                     float *dout, float *row_scratch, float *ds, float *dt, float *dH, int64_t lddh,
+                     int32_t self_loop, int32_t n_rows, amar_stream_t stream);
 int amar_transpose_f32(const float *src, int32_t K, int32_t N, float *dst, amar_stream_t stream);
 int amar_adam_f32(float *w, const float *g, float *m, float *v, int64_t n, float lr_t, float beta_1, float beta_2,
                   float epsilon, float l2, amar_stream_t stream);

@@ -55,6 +55,8 @@ SIGNATURES = {
                                         _I32, _I32, _P]),
     'amar_transpose_f32': (ctypes.c_int, [_P, _I32, _I32, _P, _P]),
     'amar_adam_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _F32, _F32, _F32, _F32, _F32, _P]),
+    'amar_adam_advance_f32': (ctypes.c_int, [_P, _F32, _F32, _F32, _P]),
+    'amar_adam_dev_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _P, _F32, _F32, _F32, _F32, _P]),
     'amar_topk_segmented_f32': (ctypes.c_int, [_P, _P, _P, _I32, _I32, _P, _P, _P]),
 }
 
@@ -379,6 +381,23 @@ def reduce_layers(cat, n_layers, width, out, mean=False):
                                          _ptr(out, torch.float32, 'out'), _ld(out, 'out'), cat.shape[0],
                                          1 if mean else 0, _stream())
     _check(code, 'amar_reduce_layers_f32')
+
+
+def adam_advance(state, learning_rate, beta_1, beta_2):
+    if state.numel() != 2 or not state.is_contiguous():
+        raise ValueError("adam_advance: state must be 2 contiguous floats (t, lr_t)")
+    _check(load().amar_adam_advance_f32(_ptr(state, torch.float32, 'state'), float(learning_rate), float(beta_1), float(beta_2),
+                                        _stream()), 'amar_adam_advance_f32')
+
+
+def adam_dev(w, g, m, v, state, beta_1, beta_2, epsilon, l2=0.0):
+    if not (w.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()) or \
+            not (w.numel() == g.numel() == m.numel() == v.numel()):
+        raise ValueError("adam_dev: contiguous tensors of equal size expected")
+    code = load().amar_adam_dev_f32(_ptr(w, torch.float32, 'w'), _ptr(g, torch.float32, 'g'), _ptr(m, torch.float32, 'm'),
+                                    _ptr(v, torch.float32, 'v'), w.numel(), _ptr(state, torch.float32, 'state'), float(beta_1),
+                                    float(beta_2), float(epsilon), float(l2), _stream())
+    _check(code, 'amar_adam_dev_f32')
 
 
 def topk_segmented(seg_ptr, item_ids, scores, k):

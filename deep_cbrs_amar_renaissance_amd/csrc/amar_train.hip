@@ -281,6 +281,29 @@ void launch_gat_bwd(const GatBwdArgs &a, hipStream_t st) {
     hipLaunchKernelGGL(gat_bwd_source_kernel<C>, grid, block, 0, st, a);
 }
 
+// The same update with the step size read from device memory, and the one-thread kernel that advances it:
+// state[0] = t (as float), state[1] = lr * sqrt(1 - b2^t) / (1 - b1^t).  Lets a whole training batch, optimizer
+// included, replay as one hipGraph with nothing baked in that changes from step to step.
+__global__ void adam_advance_kernel(float *__restrict__ state, float lr, float b1, float b2) {
+    const double t = (double)state[0] + 1.0;
+    state[0] = (float)t;
+    state[1] = (float)((double)lr * sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+}
+
+__global__ __launch_bounds__(256) void adam_dev_kernel(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ m,
+                                                       float *__restrict__ v, int64_t n, const float *__restrict__ state, float b1,
+                                                       float b2, float eps, float l2x2) {
+    const float lr_t = state[1];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float wi = w[i];
+        const float gi = g[i] + l2x2 * wi;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        w[i] = wi - lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
 unsigned grid1d(int64_t total) {
     int64_t b = (total + 255) / 256;
     return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
@@ -406,6 +429,20 @@ int amar_adam_f32(float *w, const float *g, float *m, float *v, int64_t n, float
     if (n < 0 || !w || !g || !m || !v) return AMAR_EINVAL;
     if (n == 0) return AMAR_OK;
     hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n)), dim3(256), 0, static_cast<hipStream_t>(stream), w, g, m, v, n, lr_t, beta_1, beta_2, epsilon, 2.f * l2);
+    return amar_check_launch();
+}
+
+int amar_adam_advance_f32(float *state, float learning_rate, float beta_1, float beta_2, amar_stream_t stream) {
+    if (!state) return AMAR_EINVAL;
+    hipLaunchKernelGGL(adam_advance_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream), state, learning_rate, beta_1, beta_2);
+    return amar_check_launch();
+}
+
+int amar_adam_dev_f32(float *w, const float *g, float *m, float *v, int64_t n, const float *state, float beta_1, float beta_2,
+                      float epsilon, float l2, amar_stream_t stream) {
+    if (n < 0 || !w || !g || !m || !v || !state) return AMAR_EINVAL;
+    if (n == 0) return AMAR_OK;
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(grid1d(n)), dim3(256), 0, static_cast<hipStream_t>(stream), w, g, m, v, n, state, beta_1, beta_2, epsilon, 2.f * l2);
     return amar_check_launch();
 }
 

@@ -18,6 +18,8 @@ The hybrid head (HybridCBRS, 'concatenate' fusion, both feature_based settings) 
 BERT inputs are constants.  GAT (1 head) trains on the inference kernels plus `amar_gat_bwd_f32`, which forms the
 softmax / attention-scalar gradients row-wise for both edge directions (symmetric edge multiset, no float atomics).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -186,7 +188,7 @@ class Trainer:
     # -- one batch ------------------------------------------------------------------------------------------------
     def _bert_rows(self, ids, block):
         if block is not None:
-            return to_device_tensor(block)
+            return block if isinstance(block, torch.Tensor) and block.is_cuda else to_device_tensor(block)
         table = getattr(self.model, 'bert_table', None)
         if table is None:
             raise ValueError("no BERT block in the batch and no resident table registered")
@@ -194,42 +196,118 @@ class Trainer:
         capi.copy_columns(table, rows, ids=ids)
         return rows
 
+    def _forward_backward(self, u, i, yv, rows):
+        """Device-only body of a batch (no host synchronisation, fixed shapes -> capturable as a hipGraph):
+        returns (per-pair loss terms [B], {param: gradient})."""
+        seq = self.seq
+        b = u.numel()
+        dev = seq.embeddings.device
+        e = self._propagation_forward()                              # full-graph propagation, every batch (basic.py:61-63)
+        f = e.shape[1]
+        gu = torch.empty((b, f), dtype=torch.float32, device=dev)
+        gi = torch.empty((b, f), dtype=torch.float32, device=dev)
+        capi.copy_columns(e, gu, ids=u)
+        capi.copy_columns(e, gi, ids=i)
+        if self.hybrid:
+            rows = (self._bert_rows(u, rows[0] if rows else None), self._bert_rows(i, rows[1] if rows else None))
+        p = self.head.forward(gu, gi, rows)
+        # ---- loss and its gradient through the final sigmoid
+        dz = torch.empty((b, 1), dtype=torch.float32, device=dev)
+        terms = torch.empty(b, dtype=torch.float32, device=dev)
+        capi.bce_grad(p, yv, dz, terms)
+        grads = {}
+        dgu, dgi = self.head.backward(dz, grads)
+        de = torch.zeros((e.shape[0], f), dtype=torch.float32, device=dev)
+        capi.scatter_add_rows(dgu, u, de)
+        capi.scatter_add_rows(dgi, i, de)
+        self._propagation_backward(e, de, grads)
+        return terms, grads
+
     def loss_and_grads(self, u_ids, i_ids, y, bert=None):
         """Forward + reverse pass of one batch. Returns (data loss + regularisation loss, {param: gradient}).
         `bert` = (user block, item block) for the hybrid head (None: rows of the resident table)."""
-        model, seq = self.model, self.seq
         u, i = ids_to_device(u_ids), ids_to_device(i_ids)
         yv = to_device_tensor(np.asarray(y, dtype=np.float32) if not isinstance(y, torch.Tensor) else y)
-        b = u.numel()
-        dev = seq.embeddings.device
         with torch.no_grad():
-            e = self._propagation_forward()                          # full-graph propagation, every batch (basic.py:61-63)
-            f = e.shape[1]
-            gu = torch.empty((b, f), dtype=torch.float32, device=dev)
-            gi = torch.empty((b, f), dtype=torch.float32, device=dev)
-            capi.copy_columns(e, gu, ids=u)
-            capi.copy_columns(e, gi, ids=i)
-            rows = None
-            if self.hybrid:
-                ub, ib = bert if bert is not None else (None, None)
-                rows = (self._bert_rows(u, ub), self._bert_rows(i, ib))
-            p = self.head.forward(gu, gi, rows)
-            # ---- loss and its gradient through the final sigmoid
-            dz = torch.empty((b, 1), dtype=torch.float32, device=dev)
-            terms = torch.empty(b, dtype=torch.float32, device=dev)
-            capi.bce_grad(p, yv, dz, terms)
-            grads = {}
-            dgu, dgi = self.head.backward(dz, grads)
-            de = torch.zeros((e.shape[0], f), dtype=torch.float32, device=dev)
-            capi.scatter_add_rows(dgu, u, de)
-            capi.scatter_add_rows(dgi, i, de)
-            self._propagation_backward(e, de, grads)
-            loss = float(terms.sum().item()) / b
+            terms, grads = self._forward_backward(u, i, yv, bert)
+            loss = float(terms.sum().item()) / u.numel()
             for prm in self.params:
                 l2 = self._l2(prm)
                 if l2:
                     loss += l2 * float((prm.detach().double() ** 2).sum().item())
         return loss, grads
+
+    # -- one batch as a hipGraph ------------------------------------------------------------------------------------
+    def _graph_body(self):
+        g = self._g
+        terms, grads = self._forward_backward(g['u'], g['i'], g['y'], (g['ub'], g['ib']) if g['ub'] is not None else None)
+        capi.adam_advance(self._adam_state, self.lr, self.b1, self.b2)
+        for prm in self.params:
+            capi.adam_dev(prm.data.view(-1), grads[prm].contiguous().view(-1), self.m[prm].view(-1), self.v[prm].view(-1),
+                          self._adam_state, self.b1, self.b2, self.eps, l2=self._l2(prm))
+        loss = terms.sum() / float(g['u'].numel())
+        for prm in self.params:
+            l2 = self._l2(prm)
+            if l2:
+                loss = loss + l2 * (prm.detach() * prm.detach()).sum()
+        self._loss_sum += loss * float(g['u'].numel())
+
+    def train_batch_graphed(self, u_ids, i_ids, y, bert=None):
+        """One training batch replayed from a hipGraph: the forward, the reverse pass and the Adam update are ~100
+        small launches that are otherwise bound by host launch time.  The graph is captured at the second batch of a
+        given size (the first one runs eagerly and warms every lazily built buffer); the running loss stays on the
+        device (`pop_loss_sum`).  Batches of another size run eagerly."""
+        b = len(y)
+        dev = self.seq.embeddings.device
+        with_blocks = bert is not None and bert[0] is not None
+        key = (b, with_blocks)
+        if not hasattr(self, '_graphs'):
+            self._graphs, self._seen, self._eager_loss, self._dev_t = {}, set(), 0.0, None
+            self._adam_state = torch.zeros(2, dtype=torch.float32, device=dev)
+            self._loss_sum = torch.zeros((), dtype=torch.float32, device=dev)
+        g = self._graphs.get(key)
+        if g is None:
+            if key not in self._seen:                               # first batch of this shape: eager (real) step
+                self._seen.add(key)
+                self._eager_loss += self.train_batch(u_ids, i_ids, y, bert=bert) * b
+                return
+            d = int(np.asarray(bert[0]).shape[1]) if with_blocks else 0
+            g = self._g = {'u': torch.zeros(b, dtype=torch.int32, device=dev), 'i': torch.zeros(b, dtype=torch.int32, device=dev),
+                           'y': torch.zeros(b, dtype=torch.float32, device=dev),
+                           'ub': torch.zeros((b, d), dtype=torch.float32, device=dev) if with_blocks else None,
+                           'ib': torch.zeros((b, d), dtype=torch.float32, device=dev) if with_blocks else None}
+            torch.cuda.synchronize()
+            g['graph'] = torch.cuda.CUDAGraph()
+            with torch.no_grad(), torch.cuda.graph(g['graph']):
+                self._graph_body()
+            self._graphs[key] = g
+        self._g = g
+        g['u'].copy_(ids_to_device(u_ids))
+        g['i'].copy_(ids_to_device(i_ids))
+        g['y'].copy_(to_device_tensor(np.asarray(y, dtype=np.float32) if not isinstance(y, torch.Tensor) else y))
+        if with_blocks:
+            g['ub'].copy_(to_device_tensor(bert[0]))
+            g['ib'].copy_(to_device_tensor(bert[1]))
+        if self._dev_t != self.t:                                    # eager steps happened in between: resynchronise the counter
+            self._adam_state[0] = float(self.t)
+        g['graph'].replay()
+        self.t += 1
+        self._dev_t = self.t
+
+    def pop_loss_sum(self):
+        """Sum over the batches since the last call of (batch loss x batch size); one host synchronisation."""
+        if not hasattr(self, '_graphs'):
+            return 0.0
+        total = self._eager_loss + float(self._loss_sum.item())
+        self._eager_loss = 0.0
+        self._loss_sum.zero_()
+        return total
+
+    def touch_parameters(self):
+        """Bump the autograd version counters after graph replays (hoisting caches key on them)."""
+        with torch.no_grad():
+            for prm in self.params:
+                prm.add_(0)
 
     def _propagation_forward(self):
         """E = gnn(None).  GCN / LightGCN: the inference kernels (their outputs are all the reverse pass needs);
@@ -413,6 +491,7 @@ def fit(model, sequence, epochs=1, callbacks=None, verbose=True, **kwargs):
             if len(first) >= 4 and first[2] is not None:
                 hp['bert_dim'] = int(np.asarray(first[2]).shape[1])
         trainer = model._trainer = Trainer(model, **hp)
+    use_graph = os.environ.get('AMAR_TRAIN_GRAPH', '1') != '0'
     history = []
     for epoch in range(int(epochs)):
         total, count = 0.0, 0
@@ -420,8 +499,14 @@ def fit(model, sequence, epochs=1, callbacks=None, verbose=True, **kwargs):
             inputs, y = sequence[b]
             u, i = inputs[0], inputs[1]
             bert = (inputs[2], inputs[3]) if len(inputs) >= 4 else None     # hybrid batches carry the BERT blocks (datasets.py:112-115)
-            total += trainer.train_batch(u, i, y, bert=bert) * len(y)
+            if use_graph:
+                trainer.train_batch_graphed(u, i, y, bert=bert)
+            else:
+                total += trainer.train_batch(u, i, y, bert=bert) * len(y)
             count += len(y)
+        if use_graph:
+            total = trainer.pop_loss_sum()
+            trainer.touch_parameters()
         history.append(total / max(count, 1))
         if verbose:
             print("Epoch {}/{} - loss: {:.4f}".format(epoch + 1, epochs, history[-1]))

@@ -233,6 +233,10 @@ int amar_reduce_layers_f32(const float *cat, int64_t ld, int32_t n_layers, int32
  * amar_transpose_f32        dst[N,K] = src[K,N]^T
  * amar_adam_f32             keras.optimizers.Adam on a flat parameter: g' = g + 2*l2*w; m, v moments; lr_t = the
  *                           bias-corrected step lr * sqrt(1 - b2^t) / (1 - b1^t);  w -= lr_t * m / (sqrt(v) + epsilon)
+ * amar_adam_advance_f32     state[0] = t + 1, state[1] = lr_t for that t (device memory, 2 floats): the step counter of
+ *                           keras.optimizers.Adam (`iterations`) kept on the device ...
+ * amar_adam_dev_f32         ... and the same update as amar_adam_f32 reading lr_t from state[1], so that a whole batch
+ *                           (forward, reverse pass, optimizer) can be captured once as a hipGraph and replayed
  */
 int amar_act_bwd_f32(const float *dY, int64_t ldd, const float *Y, int64_t ldy, float *dZ, int64_t ldz,
                      int64_t M, int32_t N, int32_t act, amar_stream_t stream);
@@ -257,6 +261,9 @@ int amar_gat_bwd_f32(const int32_t *rowptr, const int32_t *colidx, const float *
 int amar_transpose_f32(const float *src, int32_t K, int32_t N, float *dst, amar_stream_t stream);
 int amar_adam_f32(float *w, const float *g, float *m, float *v, int64_t n, float lr_t, float beta_1, float beta_2,
                   float epsilon, float l2, amar_stream_t stream);
+int amar_adam_advance_f32(float *state, float learning_rate, float beta_1, float beta_2, amar_stream_t stream);
+int amar_adam_dev_f32(float *w, const float *g, float *m, float *v, int64_t n, const float *state, float beta_1, float beta_2,
+                      float epsilon, float l2, amar_stream_t stream);
 
 /* ---- ranking ------------------------------------------------------------------------------
  * Per-user top-k over that user's own test pairs (src/utilities/metrics.py:11-34):

@@ -331,3 +331,30 @@ def test_fit_learns_a_separable_task(hip):
     after = model.evaluate(seq)
     assert hist['loss'][-1] < hist['loss'][0] - 0.02
     assert after[0] < before[0] and after[1] > max(before[1], 0.6)
+
+
+@pytest.mark.parametrize('cls', ['BasicGCN', 'BasicGraphSage', 'BasicGAT', 'BasicLightGCN'])
+def test_graph_replayed_batches_equal_eager_batches(hip, cls):
+    """train_batch_graphed (hipGraph replay incl. the device-side Adam counter) == train_batch, step for step."""
+    from deep_cbrs_amar_renaissance_amd import engine, training
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    g = helpers.tiny_graph(n_users=80, n_items=60, n_ratings=1500, seed=3)
+    rng = np.random.default_rng(4)
+    batches = [(g['u_ids'][k * 64:(k + 1) * 64], g['i_ids'][k * 64:(k + 1) * 64], rng.integers(0, 2, 64)) for k in range(4)]
+    models = []
+    for _ in range(2):
+        engine.set_seed(8)
+        m = getattr(basic, cls)(g['adj'], **CFG)
+        helpers.randomize_biases(m, seed=1)
+        models.append(m)
+    eager, graphed = training.Trainer(models[0]), training.Trainer(models[1])
+    loss_eager = 0.0
+    for epoch in range(3):
+        for u, i, y in batches:
+            loss_eager += eager.train_batch(u, i, y) * len(y)
+            graphed.train_batch_graphed(u, i, y)
+    assert graphed._g is not None and graphed.t == eager.t == 12
+    assert abs(graphed.pop_loss_sum() - loss_eager) < 1e-3 * abs(loss_eager)
+    for pa, pb in zip(models[0].parameters(), models[1].parameters()):
+        # identical kernels, identical order; only the float atomics of the embedding scatter may differ in the last bits
+        assert torch.allclose(pa, pb, rtol=1e-4, atol=1e-6), tuple(pa.shape)

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'libamar_hip.so')
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 ACT_CODES = {None: ACT_NONE, 'linear': ACT_NONE, 'relu': ACT_RELU, 'sigmoid': ACT_SIGMOID}
-SPMM_BIAS, SPMM_RELU, SPMM_ACCUM, SPMM_ACCUM_DIV = 1, 2, 4, 8
+SPMM_BIAS, SPMM_RELU, SPMM_ACCUM, SPMM_ACCUM_DIV, SPMM_SCALE_NEXT = 1, 2, 4, 8, 16
 
 _P = ctypes.c_void_p
 _I32, _I64, _U32, _F32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_float
@@ -29,7 +29,7 @@ SIGNATURES = {
                                          _P, _I64, _P, _I64, _F32, _P]),
     'amar_spmm_sj_f32': (ctypes.c_int, [_P, _P, _P, _I32, _P, _I64, _P, _I64, _I32, _I32, _U32, _P,
                                         _P, _I64, _P, _I64, _F32, _P, _I32, _P, _I64, _P]),
-    'amar_spmm_xs_f32': (ctypes.c_int, [_P, _P, _P, _P, _I32, _P, _I64, _P, _P, _I64, _I32, _I32, _U32, _P,
+    'amar_spmm_xs_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, _I32, _P, _I64, _P, _P, _I64, _I32, _I32, _U32, _P,
                                         _P, _I64, _P, _I64, _F32, _P, _I32, _P, _I64, _P]),
     'amar_gcn_layer_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _I64, _P, _I32, _P, _I64, _I32, _P]),
     'amar_rowwise_xw_f32': (ctypes.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _P, _I64, _P, _P, _P, _P, _I32, _P]),
@@ -169,9 +169,13 @@ def spmm_sj(sj, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc
     _check(code, 'amar_spmm_sj_f32')
 
 
-def spmm_xs(xs, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc_div=None, Wnext=None, Hnext=None):
+def spmm_xs(xs, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc_div=None, Wnext=None, Hnext=None,
+            prescaled=False, scale_next=False):
     """Y = A.X on the XCD-sliced image `xs` of A (utilities.math.XcdSliced): per-slice partial products with
-    XCD <-> L2 affinity, then the combine kernel with the epilogues of spmm_csr / gcn_layer."""
+    XCD <-> L2 affinity, then the combine kernel with the epilogues of spmm_csr / gcn_layer.
+
+    A value-free image (xs.row_scale is set: A = S C S) gathers from S.X: `prescaled=True` says X already is that
+    table (the fused GCN chain keeps it so with `scale_next`), otherwise one row_affine pass makes it here."""
     n_rows = xs.shape[0]
     F = X.shape[1]
     flags = (SPMM_BIAS if bias is not None else 0) | (SPMM_RELU if relu else 0)
@@ -189,9 +193,18 @@ def spmm_xs(xs, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc
             raise ValueError("spmm_xs: Wnext [F, Cn] contiguous and Hnext [n_rows, Cn] expected")
         Cn = Wnext.shape[1]
     P = xs.partials(F)
+    row_scale = getattr(xs, 'row_scale', None)
+    if row_scale is None and (prescaled or scale_next):
+        raise ValueError("spmm_xs: prescaled / scale_next need a value-free image")
+    if row_scale is not None and not prescaled:
+        Xs = torch.empty((n_rows, F), dtype=torch.float32, device=X.device)
+        row_affine(X, row_scale, Xs)
+        X = Xs
+    if scale_next:
+        flags |= SPMM_SCALE_NEXT
     code = load().amar_spmm_xs_f32(
         _ptr(xs.diag, torch.float32, 'diag'), _ptr(xs.rowptr, torch.int32, 'rowptr'), _ptr(xs.colidx, torch.int32, 'colidx'),
-        _ptr(xs.vals, torch.float32, 'vals'), xs.n_slices,
+        _ptr(xs.vals, torch.float32, 'vals'), _ptr(row_scale, torch.float32, 'row_scale'), xs.n_slices,
         _ptr(X, torch.float32, 'X'), _ld(X, 'X'), _ptr(P, torch.float32, 'partials'),
         _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y') if Y is not None else 0,
         n_rows, F, flags, _ptr(bias, torch.float32, 'bias'),

@@ -64,6 +64,7 @@ struct SpmmArgs {
     const float *acc_in; int64_t ld_acc_in; float *acc_out; int64_t ld_acc_out; float acc_div; int accum; int accum_div;
     const float *Wn; int Cn; float *Hn; int64_t ldhn;
     int n_rows;
+    const float *next_scale;                     // Hn rows are multiplied by next_scale[row] (value-free XS image), or NULL
 };
 
 // Bias / ReLU / store / running layer sum / next layer's dense product for one reduced row.
@@ -245,6 +246,7 @@ __device__ __forceinline__ void lane_row_epilogue(const SpmmArgs &e, int row, fl
                     for (int t = 0; t < 4; ++t)
                         if (j0 + t < e.Cn) h[t] = fmaf(yk, w[t], h[t]);
                 }
+            if (e.next_scale) { const float sc = e.next_scale[row]; h[0] *= sc; h[1] *= sc; h[2] *= sc; h[3] *= sc; }
             float *dst = e.Hn + (int64_t)row * e.ldhn + j0;
             if (j0 + 3 < e.Cn && (e.ldhn & 3) == 0) *reinterpret_cast<float4 *>(dst) = make_float4(h[0], h[1], h[2], h[3]);
             else for (int t = 0; t < 4 && j0 + t < e.Cn; ++t) dst[t] = h[t];
@@ -414,7 +416,7 @@ __device__ __forceinline__ void seg_scan_isa(float4 &p, int key) {
 // (3.5x less than the one-entry-per-lane v4.1) and the LDS adds are hidden behind that.
 
 constexpr int XS_WAVES = 4;                     // waves per workgroup of the partial kernel: one tile each (1 or 4: same time)
-template <int F, bool OFF32, int EPL>
+template <int F, bool OFF32, int EPL, bool VALS>
 __global__ __launch_bounds__(XS_WAVES * AMAR_WAVE) void spmm_xs_partial_kernel(const XsArgs a) {
     constexpr int LPN = F / 4, EPS = AMAR_WAVE / LPN, SUPER = EPS * EPL;
     constexpr int PAD_KEY = AMAR_WAVE;                               // key of an entry past the end: equals no row, never flushed
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(XS_WAVES * AMAR_WAVE) void spmm_xs_partial_kernel(c
     const int q = lane / EPS, s = lane % EPS;
     const int n_tile = end - beg;
     const char *cbase = reinterpret_cast<const char *>(a.colidx + beg);   // scalar bases + 32-bit lane offsets
-    const char *vbase = reinterpret_cast<const char *>(a.vals + beg);
+    const char *vbase = VALS ? reinterpret_cast<const char *>(a.vals + beg) : nullptr;   // value-free image: every entry weighs 1
 
     auto flush = [&](int key, const float4 &p) {                     // acc[feature][row]: lanes of one instruction hit distinct rows
         float *dst = acc + key;
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(XS_WAVES * AMAR_WAVE) void spmm_xs_partial_kernel(c
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     cw[j4 + j] = __builtin_nontemporal_load(reinterpret_cast<const int32_t *>(cbase + (unsigned)(first + j4 + j) * 4u));
-                    v[j4 + j] = __builtin_nontemporal_load(reinterpret_cast<const float *>(vbase + (unsigned)(first + j4 + j) * 4u));
+                    v[j4 + j] = VALS ? __builtin_nontemporal_load(reinterpret_cast<const float *>(vbase + (unsigned)(first + j4 + j) * 4u)) : 1.f;
                 }
             }
         } else {
@@ -465,7 +467,7 @@ __global__ __launch_bounds__(XS_WAVES * AMAR_WAVE) void spmm_xs_partial_kernel(c
             for (int j = 0; j < EPL; ++j) {
                 const unsigned off = (unsigned)max(min(first + j, n_tile - 1), 0) * 4u;
                 cw[j] = *reinterpret_cast<const int32_t *>(cbase + off);
-                v[j] = *reinterpret_cast<const float *>(vbase + off);
+                v[j] = VALS ? *reinterpret_cast<const float *>(vbase + off) : 1.f;
             }
         }
     };
@@ -517,7 +519,7 @@ __global__ __launch_bounds__(XS_WAVES * AMAR_WAVE) void spmm_xs_partial_kernel(c
     }
 }
 
-struct XsCombineArgs { const float *diag; const float *P; const int32_t *rowptr; int n_slices; SpmmArgs e; };
+struct XsCombineArgs { const float *diag; const float *P; const int32_t *rowptr; int n_slices; const float *row_scale; SpmmArgs e; };
 
 template <int F, bool FUSE_NEXT>
 __global__ __launch_bounds__(256) void spmm_xs_combine_kernel(const XsCombineArgs a) {
@@ -541,6 +543,11 @@ __global__ __launch_bounds__(256) void spmm_xs_combine_kernel(const XsCombineArg
 #pragma unroll
         for (int q = 0; q < LPN; ++q) acc[q] = f4_add(acc[q], *reinterpret_cast<const float4 *>(p + 4 * q));
     }
+    if (a.row_scale) {                                               // value-free image: y_i = d_i^-1/2 * sum_j c_ij x'_j
+        const float sc = a.row_scale[row];
+#pragma unroll
+        for (int q = 0; q < LPN; ++q) { acc[q].x *= sc; acc[q].y *= sc; acc[q].z *= sc; acc[q].w *= sc; }
+    }
     lane_row_epilogue<F, FUSE_NEXT>(e, row, acc);
 }
 
@@ -549,8 +556,13 @@ int launch_spmm_xs(const XsArgs &pa, const XsCombineArgs &ca, bool fuse, hipStre
     const dim3 block(XS_WAVES * AMAR_WAVE);
     const dim3 pgrid((unsigned)(pa.blocks_per_slice * pa.n_slices));
     constexpr int EPL = F >= 8 ? 8 : 4;
-    if (pa.off32) hipLaunchKernelGGL((spmm_xs_partial_kernel<F, true, EPL>), pgrid, block, 0, st, pa);
-    else hipLaunchKernelGGL((spmm_xs_partial_kernel<F, false, EPL>), pgrid, block, 0, st, pa);
+    if (pa.vals) {
+        if (pa.off32) hipLaunchKernelGGL((spmm_xs_partial_kernel<F, true, EPL, true>), pgrid, block, 0, st, pa);
+        else hipLaunchKernelGGL((spmm_xs_partial_kernel<F, false, EPL, true>), pgrid, block, 0, st, pa);
+    } else {
+        if (pa.off32) hipLaunchKernelGGL((spmm_xs_partial_kernel<F, true, EPL, false>), pgrid, block, 0, st, pa);
+        else hipLaunchKernelGGL((spmm_xs_partial_kernel<F, false, EPL, false>), pgrid, block, 0, st, pa);
+    }
     const dim3 cgrid((ca.e.n_rows + 255) / 256);
     if (fuse) hipLaunchKernelGGL((spmm_xs_combine_kernel<F, true>), cgrid, dim3(256), 0, st, ca);
     else hipLaunchKernelGGL((spmm_xs_combine_kernel<F, false>), cgrid, dim3(256), 0, st, ca);
@@ -834,8 +846,8 @@ int amar_spmm_sj_f32(const int32_t *entries, const int16_t *counts, const int32_
     return Wnext ? launch_spmm_sj<true>(a, F, st) : launch_spmm_sj<false>(a, F, st);
 }
 
-int amar_spmm_xs_f32(const float *diag, const int32_t *rowptr, const int32_t *colidx, const float *vals, int32_t n_slices,
-                     const float *X, int64_t ldx, float *partials, float *Y, int64_t ldy,
+int amar_spmm_xs_f32(const float *diag, const int32_t *rowptr, const int32_t *colidx, const float *vals, const float *row_scale,
+                     int32_t n_slices, const float *X, int64_t ldx, float *partials, float *Y, int64_t ldy,
                      int32_t n_rows, int32_t F, uint32_t flags, const float *bias,
                      const float *acc_in, int64_t ld_acc_in, float *acc_out, int64_t ld_acc_out, float acc_div,
                      const float *Wnext, int32_t Cn, float *Hnext, int64_t ldhn, amar_stream_t stream) {
@@ -852,11 +864,14 @@ int amar_spmm_xs_f32(const float *diag, const int32_t *rowptr, const int32_t *co
     if ((flags & AMAR_SPMM_ACCUM_DIV) && !(acc_div != 0.f)) return AMAR_EINVAL;
     if (Wnext && (!Hnext || Cn < 1 || ldhn < Cn)) return AMAR_EINVAL;
     if (Wnext && Cn > 64) return AMAR_EUNSUPPORTED;
+    if ((flags & AMAR_SPMM_SCALE_NEXT) && (!row_scale || !Wnext)) return AMAR_EINVAL;
+    if ((vals != nullptr) == (row_scale != nullptr) && colidx) return AMAR_EINVAL;   // exactly one of them (unless there are no entries)
     XsArgs pa{rowptr, colidx, vals, X, ldx, partials, n_rows, n_slices,
               (n_rows + XS_WAVES * AMAR_WAVE - 1) / (XS_WAVES * AMAR_WAVE),
               (int64_t)n_rows * ldx * 4 < (int64_t(1) << 32)};
     XsCombineArgs ca{};
-    ca.diag = diag; ca.P = partials; ca.rowptr = rowptr; ca.n_slices = n_slices;
+    ca.diag = diag; ca.P = partials; ca.rowptr = rowptr; ca.n_slices = n_slices; ca.row_scale = row_scale;
+    ca.e.next_scale = (flags & AMAR_SPMM_SCALE_NEXT) ? row_scale : nullptr;
     ca.e.X = X; ca.e.ldx = ldx; ca.e.Y = Y; ca.e.ldy = ldy;
     ca.e.bias = (flags & AMAR_SPMM_BIAS) ? bias : nullptr; ca.e.relu = (flags & AMAR_SPMM_RELU) ? 1 : 0;
     ca.e.acc_in = acc_in; ca.e.ld_acc_in = ld_acc_in; ca.e.acc_out = acc_out; ca.e.ld_acc_out = ld_acc_out;

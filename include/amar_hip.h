@@ -39,6 +39,7 @@ extern "C" {
 #define AMAR_SPMM_RELU      2u   /* y = max(y, 0) after bias                                  */
 #define AMAR_SPMM_ACCUM     4u   /* acc_out = acc_in + y (LightGCN running layer sum)         */
 #define AMAR_SPMM_ACCUM_DIV 8u   /* ... and acc_out /= acc_div (ReductionLayer 'mean')        */
+#define AMAR_SPMM_SCALE_NEXT 16u /* amar_spmm_xs_f32, value-free image: Hnext[i] *= row_scale[i] */
 
 typedef void *amar_stream_t;
 
@@ -89,9 +90,16 @@ int amar_spmm_sj_f32(const int32_t *entries, const int16_t *counts, const int32_
  * slice b % n_slices only (XCD <-> L2 affinity under round-robin dispatch); then
  *   Y[i] = epilogue( diag[i] . X[i] + sum_k partials[k][i] )   in slice order, epilogue as amar_spmm_sj_f32.
  * The matrix must be square and X must be the same table the rows index (X[i] is row i's own features).
+ *
+ * Value-free form (vals == NULL, row_scale != NULL) for A = S (C) S with S = diag(row_scale) and C a matrix of small
+ * non-negative integers — exactly gcn_filter's D^-1/2 (A + I) D^-1/2 (Spektral, called at src/models/gnn.py:283,381):
+ * every entry weighs 1 (an entry of C equal to c is stored c times), diag[i] = C_ii, X must already hold S . X
+ * (row i scaled by row_scale[i]) and Y[i] = epilogue( row_scale[i] * (diag[i] . X[i] + sum_k partials[k][i]) ).
+ * This halves the read-once index stream.  AMAR_SPMM_SCALE_NEXT also scales Hnext[i] by row_scale[i], so that a
+ * chain of GCN layers stays in the pre-scaled form.  With vals != NULL row_scale must be NULL.
  */
-int amar_spmm_xs_f32(const float *diag, const int32_t *rowptr, const int32_t *colidx, const float *vals, int32_t n_slices,
-                     const float *X, int64_t ldx, float *partials, float *Y, int64_t ldy,
+int amar_spmm_xs_f32(const float *diag, const int32_t *rowptr, const int32_t *colidx, const float *vals, const float *row_scale,
+                     int32_t n_slices, const float *X, int64_t ldx, float *partials, float *Y, int64_t ldy,
                      int32_t n_rows, int32_t F, uint32_t flags, const float *bias,
                      const float *acc_in, int64_t ld_acc_in, float *acc_out, int64_t ld_acc_out, float acc_div,
                      const float *Wnext, int32_t Cn, float *Hnext, int64_t ldhn, amar_stream_t stream);

@@ -10,6 +10,7 @@ import torch
 from scipy import sparse
 
 from oracle import layers as ol
+from tests import helpers
 from tests.helpers import rel_err
 
 pytestmark = pytest.mark.gpu
@@ -352,6 +353,20 @@ def test_spmm_kinds_agree_on_models(hip, monkeypatch):
             monkeypatch.setenv('AMAR_SPMM_KIND', kind)
             e_k = model.gnn(None).cpu().numpy()
             assert rel_err(e_k, e_csr.astype(np.float64)) < 2e-6
+    # a device-built adjacency (factors known) takes the value-free XS image and the pre-scaled fused GCN chain
+    from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter_device
+    coo = g['adj'].tocoo()
+    keep = coo.row < coo.col
+    a = gcn_filter_device(torch.from_numpy(coo.row[keep].astype(np.int64)).to(DEV), torch.from_numpy(coo.col[keep].astype(np.int64)).to(DEV), coo.shape[0])
+    for name in ('BasicGCN', 'BasicLightGCN'):
+        model = getattr(basic, name)(a, embedding_dim=8, n_hiddens=[8, 16], n_layers=2, dense_units=[24, 24], clf_units=[48])
+        helpers.randomize_biases(model, seed=2)
+        monkeypatch.setenv('AMAR_SPMM_KIND', 'csr')
+        e_csr = model.gnn(None).cpu().numpy()
+        monkeypatch.setenv('AMAR_SPMM_KIND', 'xs')
+        e_xs = model.gnn(None).cpu().numpy()
+        assert model.gnn.gnn_layers.adj_matrix.xcd_sliced().row_scale is not None
+        assert rel_err(e_xs, e_csr.astype(np.float64)) < 2e-6
 
 
 @pytest.mark.parametrize('F', [4, 8, 16, 32, 64])
@@ -407,6 +422,47 @@ def test_chain_sum_inputs(hip, D, units):
     for k, b, a in zip(ks, bs, acts):
         x = ol.dense(x, k.astype(np.float64), b.astype(np.float64), a)
     assert rel_err(out.cpu().numpy(), x) < 5e-6
+
+
+@pytest.mark.parametrize('F', [4, 8, 16])
+@pytest.mark.parametrize('uip', [False, True])
+def test_spmm_xcd_sliced_value_free(hip, F, uip, monkeypatch):
+    """The value-free XS image of a gcn-filtered matrix (A_hat = S (A + I) S, entries weigh 1, multiplicities
+    repeated) against the valued CSR product and the valued XS image, plain and as a pre-scaled fused GCN chain."""
+    from deep_cbrs_amar_renaissance_amd.utilities.math import XcdSliced, gcn_filter_device
+    g = helpers.tiny_graph(n_users=300, n_items=200, n_ratings=9000, seed=F, n_props=60 if uip else 0, n_links=400 if uip else 0)
+    coo = g['adj'].tocoo()
+    keep = coo.row < coo.col                                    # the un-symmetrised edges, duplicates (multi-relation links) kept
+    rows, cols = torch.from_numpy(coo.row[keep].astype(np.int64)).to(DEV), torch.from_numpy(coo.col[keep].astype(np.int64)).to(DEV)
+    n = coo.shape[0]
+    a = gcn_filter_device(rows, cols, n)
+    assert a.dinv is not None and (not uip or int(a.mult.max()) > 1)
+    xs = XcdSliced.from_csr(a)
+    assert xs.vals is None and xs.row_scale is not None
+    monkeypatch.setenv('AMAR_XS_VALUES', '1')
+    xs_valued = XcdSliced.from_csr(a)
+    monkeypatch.delenv('AMAR_XS_VALUES')
+    assert xs_valued.vals is not None and xs.colidx.numel() >= xs_valued.colidx.numel()
+    A = a.to_scipy().astype(np.float64)
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((n, F)).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, F).astype(np.float32)
+    w2 = rng.uniform(-0.5, 0.5, (F, F)).astype(np.float32)
+    y, yv = torch.empty((n, F), device=DEV), torch.empty((n, F), device=DEV)
+    hip.spmm_xs(xs, _t(x), y)                                   # un-scaled input: the wrapper pre-scales
+    hip.spmm_xs(xs_valued, _t(x), yv)
+    want = A @ x.astype(np.float64)
+    assert rel_err(y.cpu().numpy(), want) < 2e-6 and rel_err(yv.cpu().numpy(), want) < 2e-6
+    # two chained GCN layers kept in the pre-scaled form: H1' = S (relu(A H0 + b) W2), then A_hat H1
+    h0 = torch.empty((n, F), device=DEV)
+    hip.row_affine(_t(x), xs.row_scale, h0)
+    y1, h1 = torch.empty((n, F), device=DEV), torch.empty((n, F), device=DEV)
+    hip.spmm_xs(xs, h0, y1, bias=_t(b), relu=True, Wnext=_t(w2), Hnext=h1, prescaled=True, scale_next=True)
+    y2 = torch.empty((n, F), device=DEV)
+    hip.spmm_xs(xs, h1, y2, bias=_t(b), relu=True, prescaled=True)
+    w1 = np.maximum(want + b, 0)
+    want2 = np.maximum(A @ (w1 @ w2.astype(np.float64)) + b, 0)
+    assert rel_err(y1.cpu().numpy(), w1) < 2e-6 and rel_err(y2.cpu().numpy(), want2) < 3e-6
 
 
 def test_spmm_xcd_sliced_is_reproducible(hip):

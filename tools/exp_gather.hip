@@ -12,7 +12,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const float *X, unsigned ro
     const int lane = threadIdx.x & 63;
     unsigned state = (blockIdx.x * 256 + threadIdx.x) * 2654435761u + 12345u;
     int grp, sub;
-    if (MODE == 0) { grp = lane & 31; sub = lane >> 5; }
+    if (MODE == 0 || MODE >= 5) { grp = lane & 31; sub = lane >> 5; }
     else if (MODE == 1) { grp = lane >> 1; sub = lane & 1; }
     else if (MODE == 2) { grp = lane >> 2; sub = lane & 3; }
     else if (MODE == 3) { grp = lane >> 3; sub = lane & 7; }
@@ -31,8 +31,17 @@ __global__ __launch_bounds__(256) void gather_kernel(const float *X, unsigned ro
             if (MODE == 0 || MODE == 1) r[u] = *reinterpret_cast<const float4 *>(p + sub * 16);
             else if (MODE == 2) { const float2 t = *reinterpret_cast<const float2 *>(p + sub * 8); r[u] = make_float4(t.x, t.y, 0.f, 0.f); }
             else if (MODE == 3) { r[u] = make_float4(*reinterpret_cast<const float *>(p + sub * 4), 0.f, 0.f, 0.f); }
-            else r[u] = *reinterpret_cast<const float4 *>(p);
+            else if (MODE == 4) r[u] = *reinterpret_cast<const float4 *>(p);
+            else {
+                const unsigned off = row * 32u + (lane >> 5) * 16u;
+                if (MODE == 5) asm volatile("global_load_dwordx4 %0, %1, %2 sc0" : "=v"(r[u]) : "v"(off), "s"(X) : "memory");
+                if (MODE == 6) asm volatile("global_load_dwordx4 %0, %1, %2 sc1" : "=v"(r[u]) : "v"(off), "s"(X) : "memory");
+                if (MODE == 7) asm volatile("global_load_dwordx4 %0, %1, %2 sc0 sc1" : "=v"(r[u]) : "v"(off), "s"(X) : "memory");
+                if (MODE == 8) asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(r[u]) : "v"(off), "s"(X) : "memory");
+                if (MODE == 9) asm volatile("global_load_dwordx4 %0, %1, %2 sc0 sc1 nt" : "=v"(r[u]) : "v"(off), "s"(X) : "memory");
+            }
         }
+        if (MODE >= 5) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc += r[u].x + r[u].y + r[u].z + r[u].w;
     }
@@ -48,7 +57,12 @@ extern "C" float run_gather(int mode, const float *X, unsigned row_mask, int ite
         case 1: hipLaunchKernelGGL(gather_kernel<1>, dim3(blocks), dim3(256), 0, 0, X, row_mask, iters, out); break;
         case 2: hipLaunchKernelGGL(gather_kernel<2>, dim3(blocks), dim3(256), 0, 0, X, row_mask, iters, out); break;
         case 3: hipLaunchKernelGGL(gather_kernel<3>, dim3(blocks), dim3(256), 0, 0, X, row_mask, iters, out); break;
-        default: hipLaunchKernelGGL(gather_kernel<4>, dim3(blocks), dim3(256), 0, 0, X, row_mask, iters, out); break;
+        case 4: hipLaunchKernelGGL(gather_kernel<4>, dim3(blocks), dim3(256), 0, 0, X, row_mask, iters, out); break;
+        case 5: hipLaunchKernelGGL(gather_kernel<5>, dim3(blocks), dim3(256), 0, 0, X, row_mask, iters, out); break;
+        case 6: hipLaunchKernelGGL(gather_kernel<6>, dim3(blocks), dim3(256), 0, 0, X, row_mask, iters, out); break;
+        case 7: hipLaunchKernelGGL(gather_kernel<7>, dim3(blocks), dim3(256), 0, 0, X, row_mask, iters, out); break;
+        case 8: hipLaunchKernelGGL(gather_kernel<8>, dim3(blocks), dim3(256), 0, 0, X, row_mask, iters, out); break;
+        default: hipLaunchKernelGGL(gather_kernel<9>, dim3(blocks), dim3(256), 0, 0, X, row_mask, iters, out); break;
         }
     };
     launch();

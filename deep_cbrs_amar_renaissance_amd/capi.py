@@ -53,6 +53,9 @@ SIGNATURES = {
     'amar_l2norm_bwd_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _I64, _I32, _I32, _P]),
     'amar_gat_bwd_f32': (ctypes.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _I64,
                                         _I32, _I32, _P]),
+    'amar_attention_mix_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I32, _P]),
+    'amar_attention_mix_bwd_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64, _I32, _P]),
+    'amar_add3_act_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I32, _I32, _P]),
     'amar_transpose_f32': (ctypes.c_int, [_P, _I32, _I32, _P, _P]),
     'amar_adam_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _F32, _F32, _F32, _F32, _F32, _P]),
     'amar_adam_advance_f32': (ctypes.c_int, [_P, _F32, _F32, _F32, _P]),
@@ -526,6 +529,41 @@ def gat_bwd(rowptr, colidx, H, s_self, s_neigh, Y, dY, bias, a_self, a_neigh, se
         1 if self_loop else 0, n, _stream())
     _check(code, 'amar_gat_bwd_f32')
     return dout, ds, dt, dH
+
+
+def attention_mix(a, b, ta, tb, out):
+    """out = wa * a + (1 - wa) * b with wa = sigmoid(tanh(ta) - tanh(tb)) per feature (FusionLayer 'attention')."""
+    M, D = a.shape
+    if any(tuple(t.shape) != (M, D) for t in (b, ta, tb, out)):
+        raise ValueError("attention_mix: five [M, D] blocks expected")
+    code = load().amar_attention_mix_f32(_ptr(a, torch.float32, 'a'), _ld(a, 'a'), _ptr(b, torch.float32, 'b'), _ld(b, 'b'),
+                                         _ptr(ta, torch.float32, 'ta'), _ld(ta, 'ta'), _ptr(tb, torch.float32, 'tb'), _ld(tb, 'tb'),
+                                         _ptr(out, torch.float32, 'out'), _ld(out, 'out'), M, D, _stream())
+    _check(code, 'amar_attention_mix_f32')
+
+
+def attention_mix_bwd(dout, a, b, ta, tb):
+    """Returns (dA, dB, dTA, dTB), contiguous [M, D]."""
+    M, D = a.shape
+    if any(tuple(t.shape) != (M, D) for t in (dout, b, ta, tb)):
+        raise ValueError("attention_mix_bwd: five [M, D] blocks expected")
+    outs = [torch.empty((M, D), dtype=torch.float32, device=a.device) for _ in range(4)]
+    code = load().amar_attention_mix_bwd_f32(_ptr(dout, torch.float32, 'dout'), _ld(dout, 'dout'), _ptr(a, torch.float32, 'a'), _ld(a, 'a'),
+                                             _ptr(b, torch.float32, 'b'), _ld(b, 'b'), _ptr(ta, torch.float32, 'ta'), _ld(ta, 'ta'),
+                                             _ptr(tb, torch.float32, 'tb'), _ld(tb, 'tb'), _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]),
+                                             _ptr(outs[3]), M, D, _stream())
+    _check(code, 'amar_attention_mix_bwd_f32')
+    return outs
+
+
+def add3_act(a, b, c, out, act='relu'):
+    M, W = a.shape
+    if any(tuple(t.shape) != (M, W) for t in (b, c, out)):
+        raise ValueError("add3_act: four [M, W] blocks expected")
+    code = load().amar_add3_act_f32(_ptr(a, torch.float32, 'a'), _ld(a, 'a'), _ptr(b, torch.float32, 'b'), _ld(b, 'b'),
+                                    _ptr(c, torch.float32, 'c'), _ld(c, 'c'), _ptr(out, torch.float32, 'out'), _ld(out, 'out'),
+                                    M, W, ACT_CODES[act], _stream())
+    _check(code, 'amar_add3_act_f32')
 
 
 def transpose(src):

@@ -304,6 +304,58 @@ __global__ __launch_bounds__(256) void adam_dev_kernel(float *__restrict__ w, co
     }
 }
 
+// ---- FusionLayer('attention') (src/layers/fusion.py:54-68) and the residual head's sum (src/models/hybrid.py:89) ----
+// With ta = a . W_att, tb = b . W_att (two Dense products done by the caller):  the softmax over the two stacked
+// sources is, per feature, wa = sigmoid(tanh(ta) - tanh(tb)), wb = 1 - wa, and out = wa * a + wb * b.
+__global__ __launch_bounds__(256) void attention_mix_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B,
+                                                            int64_t ldb, const float *__restrict__ TA, int64_t ldta,
+                                                            const float *__restrict__ TB, int64_t ldtb, float *__restrict__ out,
+                                                            int64_t ldo, int64_t M, int D) {
+    const int64_t total = M * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / D;
+        const int c = (int)(i - r * D);
+        const float a = A[r * lda + c], b = B[r * ldb + c];
+        const float wa = 1.f / (1.f + expf(tanhf(TB[r * ldtb + c]) - tanhf(TA[r * ldta + c])));
+        out[r * ldo + c] = wa * a + (1.f - wa) * b;
+    }
+}
+
+// reverse: dA = dOut * wa, dB = dOut * wb (the direct paths), dTA = g * (1 - tanh(ta)^2), dTB = -g * (1 - tanh(tb)^2)
+// with g = dOut * (a - b) * wa * wb; the caller adds dTA . W^T / dTB . W^T to dA / dB and forms dW.
+__global__ __launch_bounds__(256) void attention_mix_bwd_kernel(const float *__restrict__ dOut, int64_t ldd, const float *__restrict__ A,
+                                                                int64_t lda, const float *__restrict__ B, int64_t ldb,
+                                                                const float *__restrict__ TA, int64_t ldta, const float *__restrict__ TB,
+                                                                int64_t ldtb, float *__restrict__ dA, float *__restrict__ dB,
+                                                                float *__restrict__ dTA, float *__restrict__ dTB, int64_t M, int D) {
+    const int64_t total = M * D;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / D;
+        const int c = (int)(i - r * D);
+        const float a = A[r * lda + c], b = B[r * ldb + c], d = dOut[r * ldd + c];
+        const float ca = tanhf(TA[r * ldta + c]), cb = tanhf(TB[r * ldtb + c]);
+        const float wa = 1.f / (1.f + expf(cb - ca)), wb = 1.f - wa;
+        const float g = d * (a - b) * wa * wb;
+        dA[i] = d * wa; dB[i] = d * wb;                                 // contiguous [M, D] outputs
+        dTA[i] = g * (1.f - ca * ca); dTB[i] = -g * (1.f - cb * cb);
+    }
+}
+
+// out = act(a + b + c): the residual head's activation(residual(x) + x1 + x2)
+__global__ __launch_bounds__(256) void add3_act_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
+                                                       const float *__restrict__ C, int64_t ldc, float *__restrict__ out, int64_t ldo,
+                                                       int64_t M, int W, int act) {
+    const int64_t total = M * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / W;
+        const int c = (int)(i - r * W);
+        float v = A[r * lda + c] + B[r * ldb + c] + C[r * ldc + c];
+        if (act == AMAR_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (act == AMAR_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+        out[r * ldo + c] = v;
+    }
+}
+
 unsigned grid1d(int64_t total) {
     int64_t b = (total + 255) / 256;
     return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
@@ -415,6 +467,33 @@ int amar_gat_bwd_f32(const int32_t *rowptr, const int32_t *colidx, const float *
     case 64: launch_gat_bwd<64>(a, st); break;
     default: return AMAR_EUNSUPPORTED;
     }
+    return amar_check_launch();
+}
+
+int amar_attention_mix_f32(const float *A, int64_t lda, const float *B, int64_t ldb, const float *TA, int64_t ldta,
+                           const float *TB, int64_t ldtb, float *out, int64_t ldo, int64_t M, int32_t D, amar_stream_t stream) {
+    if (M < 0 || D < 1 || !A || !B || !TA || !TB || !out || lda < D || ldb < D || ldta < D || ldtb < D || ldo < D) return AMAR_EINVAL;
+    if (M == 0) return AMAR_OK;
+    hipLaunchKernelGGL(attention_mix_kernel, dim3(grid1d(M * D)), dim3(256), 0, static_cast<hipStream_t>(stream), A, lda, B, ldb, TA, ldta, TB, ldtb, out, ldo, M, D);
+    return amar_check_launch();
+}
+
+int amar_attention_mix_bwd_f32(const float *dOut, int64_t ldd, const float *A, int64_t lda, const float *B, int64_t ldb,
+                               const float *TA, int64_t ldta, const float *TB, int64_t ldtb,
+                               float *dA, float *dB, float *dTA, float *dTB, int64_t M, int32_t D, amar_stream_t stream) {
+    if (M < 0 || D < 1 || !dOut || !A || !B || !TA || !TB || !dA || !dB || !dTA || !dTB || ldd < D || lda < D || ldb < D ||
+        ldta < D || ldtb < D) return AMAR_EINVAL;
+    if (M == 0) return AMAR_OK;
+    hipLaunchKernelGGL(attention_mix_bwd_kernel, dim3(grid1d(M * D)), dim3(256), 0, static_cast<hipStream_t>(stream), dOut, ldd, A, lda, B, ldb, TA, ldta, TB, ldtb, dA, dB, dTA, dTB, M, D);
+    return amar_check_launch();
+}
+
+int amar_add3_act_f32(const float *A, int64_t lda, const float *B, int64_t ldb, const float *C, int64_t ldc, float *out, int64_t ldo,
+                      int64_t M, int32_t W, int32_t act, amar_stream_t stream) {
+    if (M < 0 || W < 1 || !A || !B || !C || !out || lda < W || ldb < W || ldc < W || ldo < W) return AMAR_EINVAL;
+    if (act != AMAR_ACT_NONE && act != AMAR_ACT_RELU && act != AMAR_ACT_SIGMOID) return AMAR_EINVAL;
+    if (M == 0) return AMAR_OK;
+    hipLaunchKernelGGL(add3_act_kernel, dim3(grid1d(M * W)), dim3(256), 0, static_cast<hipStream_t>(stream), A, lda, B, ldb, C, ldc, out, ldo, M, W, act);
     return amar_check_launch();
 }
 

@@ -122,4 +122,7 @@ def build_dense_classifier(units, n_classes, **kwargs):
 
 
 def build_residual_dense_network(units, **kwargs):
-    raise NotImplementedError("residual heads (hybrid-gnn-tweaks) are out of scope for the HIP path (SURVEY.md §8f N4)")
+    """dense.py:20-27: like build_dense_network, but the last layer has no activation (it is added to the skip paths)."""
+    last_kwargs = dict(kwargs)
+    last_kwargs['activation'] = None
+    return Sequential([Dense(u, **kwargs) for u in units[:-1]] + [Dense(units[-1], **last_kwargs)])

@@ -22,7 +22,7 @@ import torch
 from deep_cbrs_amar_renaissance_amd import capi
 from deep_cbrs_amar_renaissance_amd.engine import Model, ids_to_device, to_device_tensor
 from deep_cbrs_amar_renaissance_amd.layers.fusion import FusionLayer
-from deep_cbrs_amar_renaissance_amd.models.dense import build_dense_network, build_dense_classifier
+from deep_cbrs_amar_renaissance_amd.models.dense import build_dense_classifier, build_dense_network, build_residual_dense_network
 from deep_cbrs_amar_renaissance_amd.models.gnn import GCN, GAT, GraphSage, LightGCN, DGCF
 from deep_cbrs_amar_renaissance_amd.models.basic import _out_of_scope, _TWO_STEP, _TWO_WAY
 
@@ -46,11 +46,9 @@ class HybridCBRS(Model):
             self.fuse1a, self.fuse1b, self.fuse2 = FusionLayer('concatenate'), FusionLayer('concatenate'), FusionLayer(fusion_method)
         else:
             self.fuse1a, self.fuse1b, self.fuse2 = FusionLayer(fusion_method), FusionLayer(fusion_method), FusionLayer('concatenate')
-        if residual:
-            if dense_units[2][-1] != clf_units[-1]:
-                raise ValueError("The last dense units before the last fusion layer "
-                                 "must be equal to the last classifier units for residual connections")
-            raise NotImplementedError("residual heads are out of scope for the HIP path (SURVEY.md §8f N4)")
+        if residual and dense_units[2][-1] != clf_units[-1]:
+            raise ValueError("The last dense units before the last fusion layer "
+                             "must be equal to the last classifier units for residual connections")
         self.dense_units = [list(d) for d in dense_units]
         if any(len(d) == 0 for d in self.dense_units):
             raise NotImplementedError("every hybrid branch needs at least one layer")
@@ -60,8 +58,14 @@ class HybridCBRS(Model):
         self.dense2b = build_dense_network(dense_units[1], activation=activation)
         self.dense3a = build_dense_network(dense_units[2], activation=activation)
         self.dense3b = build_dense_network(dense_units[2], activation=activation)
-        self.residual = self.activation = None
-        self.clf = build_dense_classifier(clf_units, n_classes=1, activation=activation)
+        if residual:                                          # hybrid.py:61-65
+            self.residual = build_residual_dense_network(clf_units, activation=activation)
+            self.activation = activation
+            self.clf = build_dense_classifier([], n_classes=1)
+        else:
+            self.residual = self.activation = None
+            self.clf = build_dense_classifier(clf_units, n_classes=1, activation=activation)
+        self.fusion_method = fusion_method
 
     def build(self, input_shape):
         self.build_head(input_shape[0][-1], input_shape[2][-1])
@@ -72,9 +76,21 @@ class HybridCBRS(Model):
         self.dense1b.build_chain(g_dim)
         d2 = self.dense2a.build_chain(b_dim)
         self.dense2b.build_chain(b_dim)
-        d3 = self.dense3a.build_chain(2 * d1 if self.feature_based else d1 + d2)
-        self.dense3b.build_chain(2 * d2 if self.feature_based else d1 + d2)
-        self.clf.build_chain(2 * d3)
+        ins = ((d1, d1), (d2, d2)) if self.feature_based else ((d1, d2), (d1, d2))
+        for fuse, (da, db) in zip((self.fuse1a, self.fuse1b), ins):
+            if not fuse.built:
+                fuse.build([(None, da), (None, db)])
+                fuse.built = True
+        d3 = self.dense3a.build_chain(self.fuse1a.output_dim(*ins[0]))
+        self.dense3b.build_chain(self.fuse1b.output_dim(*ins[1]))
+        if not self.fuse2.built:
+            self.fuse2.build([(None, d3), (None, d3)])
+            self.fuse2.built = True
+        d_fused = self.fuse2.output_dim(d3, d3)
+        if self.residual is not None:
+            self.clf.build_chain(self.residual.build_chain(d_fused))
+        else:
+            self.clf.build_chain(d_fused)
         self.built = True
 
     def call(self, inputs, g_ids=None, b_ids=None, **kwargs):
@@ -100,6 +116,8 @@ class HybridCBRS(Model):
 
     def _can_fold(self):
         d3 = [l.units for l in self.dense3a.layers]
+        if self.fuse1a.method != 'concatenate':              # the first Dense of dense3a/3b then sees a mixed block, not a concatenation
+            return False
         return (len(self.dense3a.layers) >= 2 and len(self.dense3b.layers) >= 2 and max(d3) <= capi.CHAIN_MAX_WIDTH
                 and all(u % 4 == 0 for u in d3))
 
@@ -174,11 +192,19 @@ class HybridCBRS(Model):
             args1 = dict(ids_a=u_ids, base_a=u_base, ids_b=u_ids, base_b=u_base)
             args2 = dict(ids_a=i_ids, base_a=i_base, ids_b=i_ids, base_b=i_base)
             in1, in2 = (tug, tub), (tig, tib)
+        plain = self.fuse2.method == 'concatenate' and self.residual is None
         if not folded:
-            x1 = self.dense3a.apply2(in1[0], in1[1], **args1)
-            x2 = self.dense3b.apply2(in2[0], in2[1], **args2)
-            return self.clf.apply2(x1, x2)
-        plan = self._dual_plan()
+            if self.fuse1a.method == 'concatenate':
+                x1 = self.dense3a.apply2(in1[0], in1[1], **args1)
+                x2 = self.dense3b.apply2(in2[0], in2[1], **args2)
+            else:                                             # attention over the gathered rows of each pair
+                xs = []
+                for fuse, net, (ta, tb), args in ((self.fuse1a, self.dense3a, in1, args1), (self.fuse1b, self.dense3b, in2, args2)):
+                    ga, gb = self._rows(ta, args['ids_a'], args['base_a']), self._rows(tb, args['ids_b'], args['base_b'])
+                    xs.append(net.apply2(fuse([ga, gb])))
+                x1, x2 = xs
+            return self.clf.apply2(x1, x2) if plain else self._tail(x1, x2)
+        plan = self._dual_plan() if plain else None
         if plan is not None:
             m = args1['ids_a'].numel() if args1['ids_a'] is not None else in1[0].shape[0]
             out = torch.empty((m, 1), dtype=torch.float32, device=in1[0].device)
@@ -193,7 +219,26 @@ class HybridCBRS(Model):
             x = torch.empty((m, dims[-1]), dtype=torch.float32, device=ta.device)
             capi.chain(ta, blob, dims, acts, x, B=tb, sum_inputs=True, in_act=in_act, **args)
             outs.append(x)
-        return self.clf.apply2(outs[0], outs[1])
+        return self.clf.apply2(outs[0], outs[1]) if plain else self._tail(outs[0], outs[1])
+
+    @staticmethod
+    def _rows(table, ids, base):
+        if ids is None:
+            return table
+        rows = torch.empty((ids.numel(), table.shape[1]), dtype=torch.float32, device=table.device)
+        capi.copy_columns(table, rows, ids=ids, base=base)
+        return rows
+
+    def _tail(self, x1, x2):
+        """hybrid.py:85-89 for the tweak configs: x = fuse2([x1, x2]) (attention or concatenation), then either the
+        classifier, or clf(activation(residual(x) + x1 + x2))."""
+        x = self.fuse2([x1, x2])
+        if self.residual is None:
+            return self.clf.apply2(x)
+        r = self.residual.apply2(x)
+        s = torch.empty_like(r)
+        capi.add3_act(r, x1, x2, s, act=self.activation)
+        return self.clf.apply2(s)
 
 
 class HybridBertGNN(Model, abc.ABC):

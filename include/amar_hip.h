@@ -213,6 +213,23 @@ int amar_copy_columns_f32(const float *src, int64_t lds, const int32_t *ids, int
 int amar_reduce_layers_f32(const float *cat, int64_t ld, int32_t n_layers, int32_t width, float *out, int64_t ldo,
                            int64_t n_rows, int32_t mean, amar_stream_t stream);
 
+/* ---- hybrid-head variants of econfigs/hybrid-gnn-tweaks*.yaml -----------------------
+ * amar_attention_mix_f32      FusionLayer('attention') (src/layers/fusion.py:54-68) after the two products
+ *                             TA = A . att_weight, TB = B . att_weight (amar_dense_f32, no bias): the softmax over the two
+ *                             stacked sources is per feature wa = sigmoid(tanh(TA) - tanh(TB)); out = wa*A + (1-wa)*B
+ * amar_attention_mix_bwd_f32  its reverse: dA, dB = the direct paths, dTA, dTB = gradients of the two products
+ *                             (all four contiguous [M, D])
+ * amar_add3_act_f32           out = act(A + B + C): the residual head, activation(residual(x) + x1 + x2)
+ *                             (src/models/hybrid.py:86-89)
+ */
+int amar_attention_mix_f32(const float *A, int64_t lda, const float *B, int64_t ldb, const float *TA, int64_t ldta,
+                           const float *TB, int64_t ldtb, float *out, int64_t ldo, int64_t M, int32_t D, amar_stream_t stream);
+int amar_attention_mix_bwd_f32(const float *dOut, int64_t ldd, const float *A, int64_t lda, const float *B, int64_t ldb,
+                               const float *TA, int64_t ldta, const float *TB, int64_t ldtb,
+                               float *dA, float *dB, float *dTA, float *dTB, int64_t M, int32_t D, amar_stream_t stream);
+int amar_add3_act_f32(const float *A, int64_t lda, const float *B, int64_t ldb, const float *C, int64_t ldc, float *out, int64_t ldo,
+                      int64_t M, int32_t W, int32_t act, amar_stream_t stream);
+
 /* ---- training step -------------------------------------------------------
  * What Keras' fit() adds around the forward path for one batch (src/experiment.py:155-188, config.yaml:50-58):
  * reverse-mode derivatives of Dense / GCNConv / LightGCNConv / embedding_lookup, binary cross-entropy,

@@ -62,14 +62,40 @@ def basic_rs(u, i, head, activation='relu'):
     return olayers.dense_classifier(np.concatenate([u, i], axis=1), _cast_net(head['clf'], dtype), activation)
 
 
-def hybrid_cbrs(ug, ig, ub, ib, head, activation='relu'):
-    """HybridCBRS.call (hybrid.py:72-89), feature_based=True, fusion 'concatenate', residual=False."""
+def attention_fuse(a, b, fw):
+    """FusionLayer('attention') (fusion.py:54-68): project the narrower block, stack, per-feature two-way softmax
+    of tanh(x . att_weight), weighted sum.  fw = {'att_weight': [D, D], optional 'proj_weight': [d_small, D]}."""
+    if 'proj_weight' in fw:
+        if a.shape[1] < b.shape[1]:
+            a = a @ fw['proj_weight'].astype(a.dtype)
+        else:
+            b = b @ fw['proj_weight'].astype(a.dtype)
+    x = np.stack([a, b], axis=1)                                   # [B, 2, D]
+    att = np.tanh(x @ fw['att_weight'].astype(a.dtype))
+    att = np.exp(att - att.max(axis=1, keepdims=True))
+    att = att / att.sum(axis=1, keepdims=True)
+    return (att * x).sum(axis=1)
+
+
+def hybrid_cbrs(ug, ig, ub, ib, head, activation='relu', feature_based=True):
+    """HybridCBRS.call (hybrid.py:72-89).  Fusion layers present in `head` ('fuse1a', 'fuse1b', 'fuse2') are attention
+    fusions, absent ones concatenate; head['residual'] (a Dense stack whose last layer is linear) selects
+    clf(activation(residual(x) + x1 + x2)) (hybrid.py:86-89)."""
     dtype = ug.dtype
     net = lambda name, x: olayers.dense_network(x, _cast_net(head[name], dtype), activation)
+    fuse = lambda name, a, b: attention_fuse(a, b, head[name]) if name in head else np.concatenate([a, b], axis=1)
     ug, ig, ub, ib = net('dense1a', ug), net('dense1b', ig), net('dense2a', ub), net('dense2b', ib)
-    x1 = net('dense3a', np.concatenate([ug, ig], axis=1))
-    x2 = net('dense3b', np.concatenate([ub, ib], axis=1))
-    return olayers.dense_classifier(np.concatenate([x1, x2], axis=1), _cast_net(head['clf'], dtype), activation)
+    if feature_based:
+        x1, x2 = net('dense3a', fuse('fuse1a', ug, ig)), net('dense3b', fuse('fuse1b', ub, ib))
+    else:
+        x1, x2 = net('dense3a', fuse('fuse1a', ug, ub)), net('dense3b', fuse('fuse1b', ig, ib))
+    x = fuse('fuse2', x1, x2)
+    if 'residual' in head:
+        res = _cast_net(head['residual'], dtype)
+        r = olayers.dense_network(x, res[:-1], activation)
+        r = olayers.dense(r, res[-1][0], res[-1][1], None)
+        x = olayers._act(r + x1 + x2, activation)
+    return olayers.dense_classifier(x, _cast_net(head['clf'], dtype), activation)
 
 
 def basic_gnn_scores(adj, gnn, head, u_ids, i_ids, dtype=np.float32, batch=None):
@@ -88,11 +114,11 @@ def basic_gnn_scores(adj, gnn, head, u_ids, i_ids, dtype=np.float32, batch=None)
     return np.concatenate(outs, axis=0)
 
 
-def hybrid_gnn_scores(adj, gnn, head, u_ids, i_ids, bert, dtype=np.float32):
+def hybrid_gnn_scores(adj, gnn, head, u_ids, i_ids, bert, dtype=np.float32, feature_based=True):
     """HybridBertGNN.call (hybrid.py:126-140) with host-side BERT row gather (datasets.py:65-66)."""
     e = propagate(adj, gnn, dtype)
     bert = bert.astype(dtype)
-    return hybrid_cbrs(e[u_ids], e[i_ids], bert[u_ids], bert[i_ids], head)
+    return hybrid_cbrs(e[u_ids], e[i_ids], bert[u_ids], bert[i_ids], head, feature_based=feature_based)
 
 
 def top_k(u_idx, i_idx, scores, users, items, k):

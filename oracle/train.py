@@ -170,7 +170,8 @@ def torch_model_grads(adj, gnn, head, u_ids, i_ids, y, l2=0.0, self_loops=True, 
     T = lambda arr: torch.tensor(np.asarray(arr, dtype=np.float64), requires_grad=True)
     x0 = T(gnn['embeddings'])
     layers = [{k: T(v) for k, v in lw.items()} for lw in gnn['layers']]
-    nets = {name: [(T(w), T(b)) for w, b in head[name]] for name in head}
+    fusers = {name: {k: T(v) for k, v in head[name].items()} for name in head if name.startswith('fuse')}
+    nets = {name: [(T(w), T(b)) for w, b in head[name]] for name in head if not name.startswith('fuse')}
     n = x0.shape[0]
     hs, x = [x0], x0
     if kind in ('gcn', 'lightgcn'):
@@ -223,10 +224,24 @@ def torch_model_grads(adj, gnn, head, u_ids, i_ids, y, l2=0.0, self_loops=True, 
         ub = torch.tensor(np.asarray(bert[0], dtype=np.float64))
         ib = torch.tensor(np.asarray(bert[1], dtype=np.float64))
         g1, g2, b1, b2 = run(nets['dense1a'], e_all[u]), run(nets['dense1b'], e_all[i]), run(nets['dense2a'], ub), run(nets['dense2b'], ib)
+
+        def fuse(name, a, b):                                        # fusion.py:51-68
+            if name not in fusers:
+                return torch.cat([a, b], 1)
+            fw = fusers[name]
+            if 'proj_weight' in fw:
+                a, b = (a @ fw['proj_weight'], b) if a.shape[1] < b.shape[1] else (a, b @ fw['proj_weight'])
+            x = torch.stack([a, b], 1)
+            return (torch.softmax(torch.tanh(x @ fw['att_weight']), 1) * x).sum(1)
         # hybrid.py:72-84: feature based = (graph user, graph item) | (bert user, bert item); otherwise one branch per entity
-        x1 = run(nets['dense3a'], torch.cat([g1, g2] if feature_based else [g1, b1], 1))
-        x2 = run(nets['dense3b'], torch.cat([b1, b2] if feature_based else [g2, b2], 1))
-        p = run(nets['clf'], torch.cat([x1, x2], 1), True)[:, 0]
+        x1 = run(nets['dense3a'], fuse('fuse1a', g1, g2) if feature_based else fuse('fuse1a', g1, b1))
+        x2 = run(nets['dense3b'], fuse('fuse1b', b1, b2) if feature_based else fuse('fuse1b', g2, b2))
+        x = fuse('fuse2', x1, x2)
+        if 'residual' in nets:                                       # hybrid.py:86-89
+            res = nets['residual']
+            r = run(res[:-1], x) if len(res) > 1 else x
+            x = torch.relu(r @ res[-1][0] + res[-1][1] + x1 + x2)
+        p = run(nets['clf'], x, True)[:, 0]
     yv = torch.tensor(np.asarray(y, dtype=np.float64))
     pc = torch.clamp(p, EPS, 1 - EPS)
     loss = -torch.mean(yv * torch.log(pc + EPS) + (1 - yv) * torch.log(1 - pc + EPS)) + l2 * (x0 ** 2).sum()
@@ -238,4 +253,5 @@ def torch_model_grads(adj, gnn, head, u_ids, i_ids, y, l2=0.0, self_loops=True, 
     g = lambda t: t.grad.numpy() if t.grad is not None else np.zeros(tuple(t.shape))
     grads = {'gnn': {'embeddings': g(x0), 'layers': [{k: g(v) for k, v in lw.items()} for lw in layers]},
              'head': {name: [(g(w), g(b)) for w, b in nets[name]] for name in nets}}
+    grads['head'].update({name: {k: g(v) for k, v in fw.items()} for name, fw in fusers.items()})
     return float(loss.detach()), grads, p.detach().numpy()

@@ -82,3 +82,41 @@ def hybrid_head(rng, g_dim, b_dim, dense_units, clf_units, bias_range=0.0):
             'dense2a': dense_net(rng, b_dim, d2, bias_range), 'dense2b': dense_net(rng, b_dim, d2, bias_range),
             'dense3a': dense_net(rng, 2 * d1[-1], d3, bias_range), 'dense3b': dense_net(rng, 2 * d2[-1], d3, bias_range),
             'clf': dense_net(rng, 2 * d3[-1], list(clf_units) + [1], bias_range)}
+
+
+def attention_fuser(rng, da, db):
+    """FusionLayer('attention') weights (fusion.py:19-47): att_weight [D, D], D = max(da, db); proj_weight when da != db."""
+    d = max(da, db)
+    fw = {'att_weight': glorot_uniform(rng, (d, d))}
+    if da != db:
+        fw['proj_weight'] = glorot_uniform(rng, (min(da, db), d))
+    return fw
+
+
+def hybrid_head_tweaked(rng, g_dim, b_dim, dense_units, clf_units, bias_range=0.0, fusion_method='attention', residual=False,
+                        feature_based=True):
+    """Heads of econfigs/hybrid-gnn-tweaks*.yaml: attention fusion and / or the residual classifier (hybrid.py:42-67)."""
+    d1, d2, d3 = dense_units
+    head = {'dense1a': dense_net(rng, g_dim, d1, bias_range), 'dense1b': dense_net(rng, g_dim, d1, bias_range),
+            'dense2a': dense_net(rng, b_dim, d2, bias_range), 'dense2b': dense_net(rng, b_dim, d2, bias_range)}
+    att = fusion_method == 'attention'
+    if feature_based:
+        ins = ((d1[-1], d1[-1]), (d2[-1], d2[-1]))
+        first_att, last_att = False, att
+    else:
+        ins = ((d1[-1], d2[-1]), (d1[-1], d2[-1]))
+        first_att, last_att = att, False
+    for name, (da, db) in zip(('fuse1a', 'fuse1b'), ins):
+        if first_att:
+            head[name] = attention_fuser(rng, da, db)
+    w3 = [max(a, b) if first_att else a + b for a, b in ins]
+    head['dense3a'], head['dense3b'] = dense_net(rng, w3[0], d3, bias_range), dense_net(rng, w3[1], d3, bias_range)
+    if last_att:
+        head['fuse2'] = attention_fuser(rng, d3[-1], d3[-1])
+    fused = d3[-1] if last_att else 2 * d3[-1]
+    if residual:
+        head['residual'] = dense_net(rng, fused, list(clf_units), bias_range)
+        head['clf'] = dense_net(rng, clf_units[-1], [1], bias_range)
+    else:
+        head['clf'] = dense_net(rng, fused, list(clf_units) + [1], bias_range)
+    return head

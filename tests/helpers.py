@@ -90,7 +90,16 @@ def basic_head_to_oracle(rs):
 
 
 def hybrid_head_to_oracle(rs):
-    return {k: _net(getattr(rs, k)) for k in ('dense1a', 'dense1b', 'dense2a', 'dense2b', 'dense3a', 'dense3b', 'clf')}
+    head = {k: _net(getattr(rs, k)) for k in ('dense1a', 'dense1b', 'dense2a', 'dense2b', 'dense3a', 'dense3b', 'clf')}
+    for name in ('fuse1a', 'fuse1b', 'fuse2'):                      # attention fusions carry weights (fusion.py:19-47)
+        fuse = getattr(rs, name)
+        if fuse.method == 'attention':
+            head[name] = {'att_weight': _np(fuse.att_weight)}
+            if fuse.proj_weight is not None:
+                head[name]['proj_weight'] = _np(fuse.proj_weight)
+    if getattr(rs, 'residual', None) is not None:
+        head['residual'] = _net(rs.residual)
+    return head
 
 
 def rel_err(got, want):

@@ -135,6 +135,39 @@ def test_hybrid_bert_gcn(hip, ml1m_s1):
         assert np.abs(got_batch - want).max() < 1e-4
 
 
+@pytest.mark.parametrize('feature_based,fusion,residual', [(True, 'attention', False), (True, 'concatenate', True),
+                                                           (False, 'attention', False), (False, 'concatenate', True)])
+def test_hybrid_tweaked_heads(hip, ml1m_s1, feature_based, fusion, residual):
+    """econfigs/hybrid-gnn-tweaks*.yaml: attention fusion (fusion.py:54-68) and the residual classifier
+    (hybrid.py:61-65, 86-89); batch call, resident table + ids, and hoisted predict against the oracle."""
+    from deep_cbrs_amar_renaissance_amd.models import hybrid
+    from deep_cbrs_amar_renaissance_amd.data import synthetic
+    cfg = dict(GRID1, dense_units=[[24, 24], [256, 64], [64, 64]], clf_units=[64, 64], feature_based=feature_based,
+               fusion_method=fusion, residual=residual)
+    n_ent = len(ml1m_s1['users']) + len(ml1m_s1['items'])
+    bert = synthetic.entity_embeddings(n_ent, 768, 'bert')
+    data = ml1m_s1['test'][:5000]
+    u, i = data[:, 0], data[:, 1]
+    model = hybrid.HybridBertGCN(ml1m_s1['adj_ui'], **cfg)
+    model.n_users, model.n_items = len(ml1m_s1['users']), len(ml1m_s1['items'])
+    model.rs.build_head(model.gnn.output_dim(), 768)
+    helpers.randomize_biases(model, seed=29)
+    head = helpers.hybrid_head_to_oracle(model.rs)
+    assert ('residual' in head) == residual and any(k.startswith('fuse') for k in head) == (fusion == 'attention')
+    want = om.hybrid_gnn_scores(ml1m_s1['adj_ui'], helpers.gnn_to_oracle(model.gnn), head, u, i, bert, dtype=np.float64,
+                                feature_based=feature_based)
+    got_batch = model((u, i, bert[u], bert[i])).cpu().numpy()
+    model.set_bert_table(bert)
+    got_table = model((u, i, None, None)).cpu().numpy()
+    model._hoist_begin(True)
+    try:
+        got_hoisted = model((u, i, None, None)).cpu().numpy()
+    finally:
+        model._hoist_end()
+    for got in (got_batch, got_table, got_hoisted):
+        assert np.abs(got - want).max() < 1e-4
+
+
 def test_hybrid_entity_based(hip):
     from deep_cbrs_amar_renaissance_amd.models import hybrid
     from oracle import layers as ol

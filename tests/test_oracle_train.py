@@ -39,6 +39,42 @@ def test_autograd_forward_equals_numpy_oracle(kind, hybrid):
     np.testing.assert_allclose(p, want, rtol=0, atol=1e-12)
 
 
+@pytest.mark.parametrize('feature_based,fusion,residual', [(True, 'attention', False), (True, 'concatenate', True),
+                                                           (False, 'attention', False), (True, 'attention', True)])
+def test_tweaked_heads_forward_and_finite_differences(feature_based, fusion, residual):
+    """Attention fusion / residual classifier (econfigs/hybrid-gnn-tweaks*.yaml): autograd forward == numpy oracle, and a
+    few gradient entries of the fusion / residual weights == central finite differences."""
+    g = helpers.tiny_graph(n_users=14, n_items=11, n_ratings=70, seed=0)
+    rng = np.random.default_rng(1)
+    n = g['adj'].shape[0]
+    gnn = ow.gnn(rng, 'gcn', n, embedding_dim=4, n_hiddens=(4, 4), bias_range=0.05)
+    head = ow.hybrid_head_tweaked(rng, ow.gnn_out_dim(gnn), 6, ([6], [5], [6]), [7, 6], bias_range=0.05, fusion_method=fusion,
+                                  residual=residual, feature_based=feature_based)
+    b = 20
+    u, i = g['u_ids'][:b], g['i_ids'][:b]
+    y = (rng.random(b) < 0.5).astype(np.float32)
+    bert = (rng.normal(size=(b, 6)).astype(np.float32), rng.normal(size=(b, 6)).astype(np.float32))
+    run = lambda: otrain.torch_model_grads(g['adj'], gnn, head, u, i, y, bert=bert, feature_based=feature_based)
+    _, grads, p = run()
+    e = om.propagate(g['adj'], gnn, dtype=np.float64)
+    want = om.hybrid_cbrs(e[u], e[i], bert[0].astype(np.float64), bert[1].astype(np.float64), head, feature_based=feature_based)[:, 0]
+    np.testing.assert_allclose(p, want, rtol=0, atol=1e-12)
+    probes = [(head[name], key, grads['head'][name][key]) for name in head if name.startswith('fuse') for key in head[name]]
+    for container, key, grad in probes:
+        orig = container[key]
+        arr = orig.astype(np.float64)
+        container[key] = arr
+        idx = tuple(int(rng.integers(0, s)) for s in arr.shape)
+        keep, h = arr[idx], 1e-5
+        arr[idx] = keep + h
+        up = run()[0]
+        arr[idx] = keep - h
+        dn = run()[0]
+        container[key] = orig
+        fd = (up - dn) / (2 * h)
+        assert abs(fd - grad[idx]) <= 1e-6 * max(1.0, abs(fd)) + 1e-8, (key, fd, grad[idx])
+
+
 @pytest.mark.parametrize('kind', ['gcn', 'lightgcn'])
 def test_manual_reverse_pass_equals_autograd(kind):
     g, gnn, head, u, i, y, _ = _case(kind, n_props=5)

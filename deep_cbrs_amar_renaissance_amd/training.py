@@ -107,33 +107,106 @@ class _BasicHead:
         return self.unet.backward(dcat[:, :self.d], grads), self.inet.backward(dcat[:, self.d:], grads)
 
 
+class _FusionTape:
+    """FusionLayer (fusion.py:5-68) with saved operands: concatenation, or the attention mix with its two weights."""
+
+    def __init__(self, fuse):
+        self.fuse = fuse
+
+    def forward(self, a, b):
+        f = self.fuse
+        self.da, self.db = a.shape[1], b.shape[1]
+        if f.method == 'concatenate':
+            return _concat(a, b)
+        pa, pb = f.project(a, b)
+        ta, tb = torch.empty_like(pa), torch.empty_like(pb)
+        capi.dense(pa, f.att_weight, None, ta, act=None)
+        capi.dense(pb, f.att_weight, None, tb, act=None)
+        out = torch.empty_like(pa)
+        capi.attention_mix(pa, pb, ta, tb, out)
+        self.saved = (a, b, pa, pb, ta, tb)
+        return out
+
+    def backward(self, dout, grads):
+        """Returns (dL/da, dL/db); fills grads for att_weight / proj_weight."""
+        f = self.fuse
+        if f.method == 'concatenate':
+            return dout[:, :self.da], dout[:, self.da:]
+        a, b, pa, pb, ta, tb = self.saved
+        d_a, d_b, d_ta, d_tb = capi.attention_mix_bwd(dout, pa, pb, ta, tb)
+        w = f.att_weight.detach()
+        dw, dw2 = torch.empty_like(w), torch.empty_like(w)
+        capi.wgrad(pa, d_ta, dw, None)
+        capi.wgrad(pb, d_tb, dw2, None)
+        capi.add_inplace(dw, dw2)
+        grads[f.att_weight] = dw
+        wt = capi.transpose(w)
+        back = torch.empty_like(d_a)
+        capi.dense(d_ta, wt, None, back, act=None)
+        capi.add_inplace(d_a, back)
+        capi.dense(d_tb, wt, None, back, act=None)
+        capi.add_inplace(d_b, back)
+        if f.proj_first is not None:                                 # the narrower block went through proj_weight first
+            src, d_proj = (a, d_a) if f.proj_first else (b, d_b)
+            dp = torch.empty_like(f.proj_weight)
+            capi.wgrad(src, d_proj, dp, None)
+            grads[f.proj_weight] = dp
+            d_src = torch.empty((src.shape[0], src.shape[1]), dtype=torch.float32, device=src.device)
+            capi.dense(d_proj, capi.transpose(f.proj_weight.detach()), None, d_src, act=None)
+            if f.proj_first:
+                d_a = d_src
+            else:
+                d_b = d_src
+        return d_a, d_b
+
+
 class _HybridHead:
-    """HybridCBRS (hybrid.py:13-89), fusion 'concatenate', with saved activations.  The BERT rows are constants."""
+    """HybridCBRS (hybrid.py:13-89) with saved activations: both feature_based settings, 'concatenate' / 'attention'
+    fusion, optional residual classifier.  The BERT rows are constants."""
 
     def __init__(self, rs):
+        self.rs = rs
         self.fb = bool(rs.feature_based)
-        self.t = {name: _DenseTape(getattr(rs, name)) for name in ('dense1a', 'dense1b', 'dense2a', 'dense2b', 'dense3a', 'dense3b', 'clf')}
+        names = ['dense1a', 'dense1b', 'dense2a', 'dense2b', 'dense3a', 'dense3b', 'clf'] + (['residual'] if rs.residual is not None else [])
+        self.t = {name: _DenseTape(getattr(rs, name)) for name in names}
+        self.f1a, self.f1b, self.f2 = _FusionTape(rs.fuse1a), _FusionTape(rs.fuse1b), _FusionTape(rs.fuse2)
 
     def forward(self, gu, gi, bert):
         ub, ib = bert
         t = self.t
         g1, g2 = t['dense1a'].forward(gu), t['dense1b'].forward(gi)
         b1, b2 = t['dense2a'].forward(ub), t['dense2b'].forward(ib)
-        self.d1, self.d2 = g1.shape[1], b1.shape[1]
         # feature based: (graph user, graph item) | (bert user, bert item); else per entity (hybrid.py:72-84)
-        x1 = t['dense3a'].forward(_concat(g1, g2) if self.fb else _concat(g1, b1))
-        x2 = t['dense3b'].forward(_concat(b1, b2) if self.fb else _concat(g2, b2))
-        self.d3 = x1.shape[1]
-        return t['clf'].forward(_concat(x1, x2))
+        ins = ((g1, g2), (b1, b2)) if self.fb else ((g1, b1), (g2, b2))
+        x1 = t['dense3a'].forward(self.f1a.forward(*ins[0]))
+        x2 = t['dense3b'].forward(self.f1b.forward(*ins[1]))
+        x = self.f2.forward(x1, x2)
+        if 'residual' in t:                                          # hybrid.py:86-89
+            r = t['residual'].forward(x)
+            self.s = torch.empty_like(r)
+            capi.add3_act(r, x1, x2, self.s, act=self.rs.activation)
+            x = self.s
+        return t['clf'].forward(x)
 
     def backward(self, dz, grads):
-        t, d1, d2 = self.t, self.d1, self.d2
-        dcat = t['clf'].backward(dz, grads, last_is_dz=True)
-        da, db = t['dense3a'].backward(dcat[:, :self.d3], grads), t['dense3b'].backward(dcat[:, self.d3:], grads)
+        t = self.t
+        dx = t['clf'].backward(dz, grads, last_is_dz=True)
+        skip = None
+        if 'residual' in t:
+            skip = torch.empty_like(dx)
+            capi.act_bwd(dx, self.s, skip, self.rs.activation)       # d(residual(x) + x1 + x2): the same for all three terms
+            dx = t['residual'].backward(skip, grads, last_is_dz=True)
+        dx1, dx2 = self.f2.backward(dx, grads)
+        if skip is not None:
+            dx1, dx2 = dx1.contiguous().clone(), dx2.contiguous().clone()
+            capi.add_inplace(dx1, skip)
+            capi.add_inplace(dx2, skip)
+        da = self.f1a.backward(t['dense3a'].backward(dx1, grads), grads)
+        db = self.f1b.backward(t['dense3b'].backward(dx2, grads), grads)
         if self.fb:
-            dg1, dg2, db1, db2 = da[:, :d1], da[:, d1:], db[:, :d2], db[:, d2:]
+            (dg1, dg2), (db1, db2) = da, db
         else:
-            dg1, db1, dg2, db2 = da[:, :d1], da[:, d1:], db[:, :d1], db[:, d1:]
+            (dg1, db1), (dg2, db2) = da, db
         t['dense2a'].backward(db1, grads, need_input_grad=False)
         t['dense2b'].backward(db2, grads, need_input_grad=False)
         return t['dense1a'].backward(dg1, grads), t['dense1b'].backward(dg2, grads)

@@ -152,6 +152,10 @@ def _flatten_oracle_grads(model, grads):
         for name, arr in gl.items():
             out[getattr(layer, {'attn_self': 'attn_kernel_self', 'attn_neigh': 'attn_kernel_neighs'}.get(name, name))] = arr
     for name in grads['head']:
+        if name.startswith('fuse'):                                  # attention fusion weights
+            for key, arr in grads['head'][name].items():
+                out[getattr(getattr(model.rs, name), key)] = arr
+            continue
         for layer, (gw, gb) in zip(getattr(model.rs, name).layers, grads['head'][name]):
             out[layer.kernel], out[layer.bias] = gw, gb
     return out
@@ -214,16 +218,20 @@ def test_gradients_match_autograd_oracle(hip, cls, graph):
         assert np.abs(got - gw).max() <= 2e-4 * np.abs(gw).max() + 1e-10, tuple(prm.shape)
 
 
-@pytest.mark.parametrize('cls,feature_based', [('HybridBertGCN', True), ('HybridBertGCN', False), ('HybridBertGraphSage', True),
-                                                ('HybridBertLightGCN', True), ('HybridBertGAT', True)])
-def test_hybrid_gradients_match_autograd_oracle(hip, cls, feature_based):
+@pytest.mark.parametrize('cls,feature_based,fusion,residual', [
+    ('HybridBertGCN', True, 'concatenate', False), ('HybridBertGCN', False, 'concatenate', False),
+    ('HybridBertGraphSage', True, 'concatenate', False), ('HybridBertLightGCN', True, 'concatenate', False),
+    ('HybridBertGAT', True, 'concatenate', False),
+    ('HybridBertGCN', True, 'attention', False), ('HybridBertGCN', True, 'concatenate', True),        # hybrid-gnn-tweaks*.yaml
+    ('HybridBertGCN', False, 'attention', False), ('HybridBertLightGCN', True, 'attention', True)])
+def test_hybrid_gradients_match_autograd_oracle(hip, cls, feature_based, fusion, residual):
     """HybridBertGNN (hybrid.py:92-140): GNN + four-input head; BERT rows from the batch or from the resident table."""
     from deep_cbrs_amar_renaissance_amd import engine, training
     from deep_cbrs_amar_renaissance_amd.models import hybrid
     engine.set_seed(11)
     g = helpers.tiny_graph(n_users=80, n_items=60, n_ratings=1500, seed=4)
-    cfg = dict(embedding_dim=8, n_hiddens=[8, 8], n_layers=2, dense_units=[[24, 16], [32, 16], [16, 16]], clf_units=[24, 24],
-               l2_regularizer=1e-4, feature_based=feature_based)
+    cfg = dict(embedding_dim=8, n_hiddens=[8, 8], n_layers=2, dense_units=[[24, 16], [32, 24], [16, 16]], clf_units=[24, 16],
+               l2_regularizer=1e-4, feature_based=feature_based, fusion_method=fusion, residual=residual)
     model = getattr(hybrid, cls)(g['adj'], **cfg)
     rng = np.random.default_rng(3)
     table = rng.standard_normal((g['adj'].shape[0], 40)).astype(np.float32) * 0.5

@@ -56,6 +56,8 @@ SIGNATURES = {
     'amar_attention_mix_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I32, _P]),
     'amar_attention_mix_bwd_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _P, _P, _P, _I64, _I32, _P]),
     'amar_add3_act_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I64, _I32, _I32, _P]),
+    'amar_locality_scale_f32': (ctypes.c_int, [_P, _I64, _P, _P, _I64, _I64, _I32, _P]),
+    'amar_locality_scale_bwd_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _P]),
     'amar_transpose_f32': (ctypes.c_int, [_P, _I32, _I32, _P, _P]),
     'amar_adam_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _F32, _F32, _F32, _F32, _F32, _P]),
     'amar_adam_advance_f32': (ctypes.c_int, [_P, _F32, _F32, _F32, _P]),
@@ -564,6 +566,26 @@ def add3_act(a, b, c, out, act='relu'):
                                     _ptr(c, torch.float32, 'c'), _ld(c, 'c'), _ptr(out, torch.float32, 'out'), _ld(out, 'out'),
                                     M, W, ACT_CODES[act], _stream())
     _check(code, 'amar_add3_act_f32')
+
+
+def locality_scale(x, w, out):
+    """out = x * sigmoid(w[row])  (DGCFConv's LocalityAdaptive)."""
+    M, W = x.shape
+    if tuple(out.shape) != (M, W) or w.numel() != M or not w.is_contiguous():
+        raise ValueError("locality_scale: x, out [M, W] and contiguous w [M] expected")
+    code = load().amar_locality_scale_f32(_ptr(x, torch.float32, 'x'), _ld(x, 'x'), _ptr(w, torch.float32, 'w'),
+                                          _ptr(out, torch.float32, 'out'), _ld(out, 'out'), M, W, _stream())
+    _check(code, 'amar_locality_scale_f32')
+
+
+def locality_scale_bwd(dout, x, w, dx, dw, accumulate=False):
+    M, W = x.shape
+    if tuple(dout.shape) != (M, W) or tuple(dx.shape) != (M, W) or w.numel() != M or dw.numel() != M:
+        raise ValueError("locality_scale_bwd: dout, x, dx [M, W]; w, dw [M] expected")
+    code = load().amar_locality_scale_bwd_f32(_ptr(dout, torch.float32, 'dout'), _ld(dout, 'dout'), _ptr(x, torch.float32, 'x'), _ld(x, 'x'),
+                                              _ptr(w, torch.float32, 'w'), _ptr(dx, torch.float32, 'dx'), _ld(dx, 'dx'),
+                                              _ptr(dw, torch.float32, 'dw'), M, W, 1 if accumulate else 0, _stream())
+    _check(code, 'amar_locality_scale_bwd_f32')
 
 
 def transpose(src):

@@ -341,6 +341,34 @@ __global__ __launch_bounds__(256) void attention_mix_bwd_kernel(const float *__r
     }
 }
 
+// LocalityAdaptive of DGCFConv (src/layers/dgcf_conv.py:83-102): out = X * sigmoid(w[row]), w [n, 1] trainable
+__global__ __launch_bounds__(256) void locality_scale_kernel(const float *__restrict__ X, int64_t ldx, const float *__restrict__ w,
+                                                             float *__restrict__ out, int64_t ldo, int64_t M, int W) {
+    const int64_t total = M * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / W;
+        const int c = (int)(i - r * W);
+        out[r * ldo + c] = X[r * ldx + c] / (1.f + expf(-w[r]));
+    }
+}
+
+// reverse: dX (+)= dOut * s, dw[row] = s (1 - s) * sum_c dOut[row, c] X[row, c], s = sigmoid(w[row]); one thread per row
+__global__ __launch_bounds__(256) void locality_scale_bwd_kernel(const float *__restrict__ dOut, int64_t ldd, const float *__restrict__ X,
+                                                                 int64_t ldx, const float *__restrict__ w, float *__restrict__ dX,
+                                                                 int64_t lddx, float *__restrict__ dw, int64_t M, int W, int accumulate) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < M; r += (int64_t)gridDim.x * blockDim.x) {
+        const float s = 1.f / (1.f + expf(-w[r]));
+        float dot = 0.f;
+        for (int c = 0; c < W; ++c) {
+            const float d = dOut[r * ldd + c];
+            dot = fmaf(d, X[r * ldx + c], dot);
+            const float v = d * s;
+            dX[r * lddx + c] = accumulate ? dX[r * lddx + c] + v : v;
+        }
+        dw[r] = s * (1.f - s) * dot;
+    }
+}
+
 // out = act(a + b + c): the residual head's activation(residual(x) + x1 + x2)
 __global__ __launch_bounds__(256) void add3_act_kernel(const float *__restrict__ A, int64_t lda, const float *__restrict__ B, int64_t ldb,
                                                        const float *__restrict__ C, int64_t ldc, float *__restrict__ out, int64_t ldo,
@@ -485,6 +513,22 @@ int amar_attention_mix_bwd_f32(const float *dOut, int64_t ldd, const float *A, i
         ldta < D || ldtb < D) return AMAR_EINVAL;
     if (M == 0) return AMAR_OK;
     hipLaunchKernelGGL(attention_mix_bwd_kernel, dim3(grid1d(M * D)), dim3(256), 0, static_cast<hipStream_t>(stream), dOut, ldd, A, lda, B, ldb, TA, ldta, TB, ldtb, dA, dB, dTA, dTB, M, D);
+    return amar_check_launch();
+}
+
+int amar_locality_scale_f32(const float *X, int64_t ldx, const float *w, float *out, int64_t ldo, int64_t M, int32_t W,
+                            amar_stream_t stream) {
+    if (M < 0 || W < 1 || !X || !w || !out || ldx < W || ldo < W) return AMAR_EINVAL;
+    if (M == 0) return AMAR_OK;
+    hipLaunchKernelGGL(locality_scale_kernel, dim3(grid1d(M * W)), dim3(256), 0, static_cast<hipStream_t>(stream), X, ldx, w, out, ldo, M, W);
+    return amar_check_launch();
+}
+
+int amar_locality_scale_bwd_f32(const float *dOut, int64_t ldd, const float *X, int64_t ldx, const float *w, float *dX, int64_t lddx,
+                                float *dw, int64_t M, int32_t W, int32_t accumulate, amar_stream_t stream) {
+    if (M < 0 || W < 1 || !dOut || !X || !w || !dX || !dw || ldd < W || ldx < W || lddx < W) return AMAR_EINVAL;
+    if (M == 0) return AMAR_OK;
+    hipLaunchKernelGGL(locality_scale_bwd_kernel, dim3(grid1d(M)), dim3(256), 0, static_cast<hipStream_t>(stream), dOut, ldd, X, ldx, w, dX, lddx, dw, M, W, accumulate ? 1 : 0);
     return amar_check_launch();
 }
 

@@ -12,7 +12,7 @@ the SpMM epilogue ('mean' reduction).  GraphSAGE / GAT consume the raw edge list
 kept, `utilities/math.py`), exactly as the reference hands Spektral an un-normalised matrix
 (`gnn.py:316-319, 349-352`).
 
-DGCF and the Half/FullInput variants are out of scope.
+The Half/FullInput variants (TwoStep / TwoWay models only) are out of scope.
 """
 import abc
 
@@ -22,6 +22,7 @@ from deep_cbrs_amar_renaissance_amd import capi
 from deep_cbrs_amar_renaissance_amd.engine import Layer, Model, L2
 from deep_cbrs_amar_renaissance_amd.layers.gat_conv import GATConv
 from deep_cbrs_amar_renaissance_amd.layers.gcn_conv import GCNConv
+from deep_cbrs_amar_renaissance_amd.layers.dgcf_conv import DGCFConv
 from deep_cbrs_amar_renaissance_amd.layers.graphsage_conv import GraphSageConv
 from deep_cbrs_amar_renaissance_amd.layers.lightgcn_conv import LightGCNConv
 from deep_cbrs_amar_renaissance_amd.layers.reduction import ReductionLayer
@@ -256,8 +257,10 @@ class LightGCN(GNN):
 
 
 class DGCF(GNN):
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError("DGCF is out of scope for the HIP path (SURVEY.md §8f N4)")
+    def __init__(self, adj_matrix, n_layers=3, **kwargs):
+        kwargs['final_node'] = 'mean'                          # gnn.py:405
+        crosshop_matrix = DGCFConv.preprocess(adj_matrix)      # gnn.py:408
+        super().__init__(crosshop_matrix, n_layers, **kwargs)
 
-    def build_gnn_layer(self, i, **kwargs):
-        raise NotImplementedError
+    def build_gnn_layer(self, i, regularizer=None, **kwargs):
+        return DGCFConv(regularizer)

@@ -25,6 +25,7 @@ import torch
 
 from deep_cbrs_amar_renaissance_amd import capi
 from deep_cbrs_amar_renaissance_amd.engine import ids_to_device, to_device_tensor
+from deep_cbrs_amar_renaissance_amd.layers.dgcf_conv import DGCFConv
 from deep_cbrs_amar_renaissance_amd.layers.gat_conv import GATConv
 from deep_cbrs_amar_renaissance_amd.layers.gcn_conv import GCNConv
 from deep_cbrs_amar_renaissance_amd.layers.graphsage_conv import GraphSageConv
@@ -232,11 +233,13 @@ class Trainer:
             # unsorted_segment_mean: sum / count, 0 for an empty segment
             self.inv_cnt = (1.0 / (deg + 1.0)) if self.self_loops else torch.where(deg > 0, 1.0 / deg.clamp(min=1.0), torch.zeros_like(deg))
             self.inv_cnt = self.inv_cnt.contiguous()
+        elif layers and all(isinstance(l, DGCFConv) for l in layers) and seq.final_node == 'mean':
+            self.kind = 'dgcf'
         elif layers and all(isinstance(l, GATConv) for l in layers) and seq.final_node == 'concatenation':
             self.kind = 'gat'
         else:
             raise NotImplementedError("training is implemented for GCN / GraphSAGE / GAT stacks with 'concatenation' "
-                                      "and for LightGCN ('mean')")
+                                      "and for LightGCN / DGCF ('mean')")
         self.hybrid = hasattr(model.rs, 'dense1a')
         if not model.rs.built:
             if self.hybrid:
@@ -390,6 +393,8 @@ class Trainer:
             return seq(None)
         if self.kind == 'gat':
             return self._gat_forward()
+        if self.kind == 'dgcf':
+            return self._dgcf_forward()
         a = seq.adj_matrix
         widths = seq.layer_widths()
         seq._build_layers(widths)
@@ -413,6 +418,42 @@ class Trainer:
             capi.l2norm_fwd(z, nrm, inv, sl(k + 1), act='relu')
             self._tape.append((xa, nrm, inv))
         return cat
+
+    def _dgcf_forward(self):
+        """DGCFConv.call layer by layer, keeping every layer's input (the gate's gradient needs it); E = mean of all."""
+        seq = self.seq
+        a = seq.adj_matrix
+        widths = seq.layer_widths()
+        seq._build_layers(widths)
+        n, dev, d = a.shape[0], seq.embeddings.device, widths[0]
+        cat = torch.empty((n, d * len(widths)), dtype=torch.float32, device=dev)
+        capi.copy_columns(seq.embeddings, cat[:, :d])
+        for k, layer in enumerate(seq.seq_layers):
+            layer([cat[:, k * d:(k + 1) * d], a], out=cat[:, (k + 1) * d:(k + 2) * d])
+        self._tape = cat
+        out = torch.empty((n, d), dtype=torch.float32, device=dev)
+        capi.reduce_layers(cat, len(widths), d, out, mean=True)
+        return out
+
+    def _dgcf_backward(self, e, de, grads):
+        seq, a = self.seq, self.seq.adj_matrix
+        layers = list(seq.seq_layers)
+        n, dev, d = e.shape[0], e.device, e.shape[1]
+        cat = self._tape
+        n_terms = len(layers) + 1
+        dxs = []                                                     # dL/dX_k: de / (L + 1) for every term of the mean
+        for _ in range(n_terms):
+            g = torch.zeros((n, d), dtype=torch.float32, device=dev)
+            capi.add_inplace(g, de, 1.0 / n_terms)
+            dxs.append(g)
+        for k in range(len(layers) - 1, -1, -1):
+            back = torch.empty((n, d), dtype=torch.float32, device=dev)
+            _spmm(a, dxs[k + 1], back)                               # A_dgcf is symmetric
+            dw = torch.empty(n, dtype=torch.float32, device=dev)
+            capi.locality_scale_bwd(back, cat[:, k * d:(k + 1) * d], layers[k].w.detach().view(-1), dxs[k], dw, accumulate=True)
+            grads[layers[k].w] = dw.view_as(layers[k].w)
+        grads[seq.embeddings] = dxs[0]
+        self._tape = None
 
     def _gat_forward(self):
         """GATConv.call layer by layer (same kernels as inference), keeping H and the two attention scalars."""
@@ -472,6 +513,8 @@ class Trainer:
     def _propagation_backward(self, e, de, grads):
         if self.kind == 'gat':
             return self._gat_backward(e, de, grads)
+        if self.kind == 'dgcf':
+            return self._dgcf_backward(e, de, grads)
         seq, a = self.seq, self.seq.adj_matrix
         layers = list(seq.seq_layers)
         n, dev = e.shape[0], e.device

@@ -221,6 +221,9 @@ int amar_reduce_layers_f32(const float *cat, int64_t ld, int32_t n_layers, int32
  *                             (all four contiguous [M, D])
  * amar_add3_act_f32           out = act(A + B + C): the residual head, activation(residual(x) + x1 + x2)
  *                             (src/models/hybrid.py:86-89)
+ * amar_locality_scale_f32     DGCFConv's LocalityAdaptive (src/layers/dgcf_conv.py:83-102): out = X * sigmoid(w[row]);
+ *                             the layer is then amar_spmm_* on the DGCF adjacency (dgcf_conv.py:32-36)
+ * amar_locality_scale_bwd_f32 dX (+)= dOut * sigmoid(w), dw[row] = sigmoid'(w[row]) * (dOut[row] . X[row])
  */
 int amar_attention_mix_f32(const float *A, int64_t lda, const float *B, int64_t ldb, const float *TA, int64_t ldta,
                            const float *TB, int64_t ldtb, float *out, int64_t ldo, int64_t M, int32_t D, amar_stream_t stream);
@@ -229,6 +232,10 @@ int amar_attention_mix_bwd_f32(const float *dOut, int64_t ldd, const float *A, i
                                float *dA, float *dB, float *dTA, float *dTB, int64_t M, int32_t D, amar_stream_t stream);
 int amar_add3_act_f32(const float *A, int64_t lda, const float *B, int64_t ldb, const float *C, int64_t ldc, float *out, int64_t ldo,
                       int64_t M, int32_t W, int32_t act, amar_stream_t stream);
+int amar_locality_scale_f32(const float *X, int64_t ldx, const float *w, float *out, int64_t ldo, int64_t M, int32_t W,
+                            amar_stream_t stream);
+int amar_locality_scale_bwd_f32(const float *dOut, int64_t ldd, const float *X, int64_t ldx, const float *w, float *dX, int64_t lddx,
+                                float *dw, int64_t M, int32_t W, int32_t accumulate, amar_stream_t stream);
 
 /* ---- training step -------------------------------------------------------
  * What Keras' fit() adds around the forward path for one batch (src/experiment.py:155-188, config.yaml:50-58):

@@ -98,3 +98,24 @@ def add_self_loops_edges(row, col, n):
     c = np.concatenate([col[keep], np.arange(n)])
     order = np.lexsort((c, r))
     return r[order], c[order]
+
+
+def dgcf_adjacency(a):
+    """DGCFConv.preprocess (dgcf_conv.py:38-48) with its high-pass filter (dgcf_conv.py:50-80).
+
+    crosshop = A . A (duplicates of A summed by the product); both A and the crosshop matrix go through gcn_filter;
+    the crosshop filter keeps the entries > eps for the eps in (1e-1, 1e-2, 1e-3, 5e-4) whose kept-entry count is
+    closest in ratio to nnz(gcn_filter(A)) (first minimum); result = A_hat + filtered + I, float32 CSR.
+    An eps that keeps nothing has an infinite ratio here (the reference would divide by zero).
+    """
+    a = sparse.csr_matrix(a)
+    crosshop = a.dot(a)
+    a_hat, cross_hat = gcn_filter(a), gcn_filter(crosshop)
+    edges = len(a_hat.data)
+    filtered = [cross_hat.multiply(cross_hat > eps).tocsr() for eps in (1e-1, 1e-2, 1e-3, 5e-4)]
+    counts = [len(m.data) for m in filtered]
+    ratios = [np.inf if c == 0 else (edges / c if edges > c else c / edges) for c in counts]
+    best = int(np.argmin(ratios))
+    out = (a_hat + filtered[best] + sparse.eye(a.shape[0], dtype=np.float32)).tocsr().astype(np.float32)
+    out.sum_duplicates()
+    return out

@@ -48,6 +48,12 @@ def lightgcn_conv(x, a_hat):
     return a_hat.astype(x.dtype) @ x
 
 
+def dgcf_conv(x, a_dgcf, w):
+    """DGCFConv.call (dgcf_conv.py:32-36): LocalityAdaptive x * sigmoid(w) (w [N, 1], dgcf_conv.py:83-102), then A . x."""
+    gate = 1.0 / (1.0 + np.exp(-w.astype(x.dtype)))
+    return a_dgcf.astype(x.dtype) @ (x * gate)
+
+
 def _segment_sum(values, targets, n):
     m = sparse.csr_matrix((np.ones(len(targets), dtype=values.dtype), (targets, np.arange(len(targets)))),
                           shape=(n, len(targets)))

@@ -4,8 +4,8 @@ TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
 
 Weights travel as plain dicts of numpy arrays:
 
-    gnn     {'kind': 'gcn'|'lightgcn'|'sage'|'gat', 'embeddings': [N,d],
-             'layers': [ {'kernel','bias'} | {} | {'kernel','bias'} | {'kernel','attn_self','attn_neigh','bias'} ],
+    gnn     {'kind': 'gcn'|'lightgcn'|'sage'|'gat'|'dgcf', 'embeddings': [N,d],
+             'layers': [ {'kernel','bias'} | {} | {'kernel','bias'} | {'kernel','attn_self','attn_neigh','bias'} | {'w'} ],
              'final_node': 'concatenation'|'mean'|'sum'|'last'}
     basic   {'unet': [(W,b)..], 'inet': [(W,b)..], 'clf': [(W,b).., (W_out,b_out)]}
     hybrid  {'dense1a','dense1b','dense2a','dense2b','dense3a','dense3b': [(W,b)..], 'clf': [...]}
@@ -33,6 +33,11 @@ def propagate(adj, gnn, dtype=np.float32, self_loops=True):
             else:
                 x = olayers.lightgcn_conv(x, a_hat)
             hs.append(x)
+    elif kind == 'dgcf':
+        a_dgcf = ograph.dgcf_adjacency(adj)                          # gnn.py:408
+        for lw in gnn['layers']:
+            x = olayers.dgcf_conv(x, a_dgcf, lw['w'].astype(dtype))
+            hs.append(x)
     elif kind in ('sage', 'gat'):
         row, col, _ = ograph.reordered_coo(adj)
         for lw in gnn['layers']:
@@ -46,7 +51,7 @@ def propagate(adj, gnn, dtype=np.float32, self_loops=True):
             hs.append(x)
     else:
         raise ValueError("Unknown GNN kind {}".format(kind))
-    final_node = 'mean' if kind == 'lightgcn' else gnn.get('final_node', 'concatenation')   # gnn.py:378
+    final_node = 'mean' if kind in ('lightgcn', 'dgcf') else gnn.get('final_node', 'concatenation')   # gnn.py:378, 405
     return olayers.reduce_layers(hs, final_node)
 
 

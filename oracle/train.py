@@ -180,6 +180,12 @@ def torch_model_grads(adj, gnn, head, u_ids, i_ids, y, l2=0.0, self_loops=True, 
         for lw in layers:
             x = torch.relu(torch.sparse.mm(a_t, x @ lw['kernel']) + lw['bias']) if kind == 'gcn' else torch.sparse.mm(a_t, x)
             hs.append(x)
+    elif kind == 'dgcf':
+        a = ograph.dgcf_adjacency(adj).tocoo()
+        a_t = torch.sparse_coo_tensor(np.stack([a.row, a.col]), a.data.astype(np.float64), a.shape).coalesce()
+        for lw in layers:
+            x = torch.sparse.mm(a_t, x * torch.sigmoid(lw['w']))
+            hs.append(x)
     else:
         row, col, _ = ograph.reordered_coo(adj)
         if self_loops:
@@ -203,7 +209,7 @@ def torch_model_grads(adj, gnn, head, u_ids, i_ids, y, l2=0.0, self_loops=True, 
                 alpha = ex / denom[tgt]
                 x = torch.relu(torch.zeros_like(h).index_add(0, tgt, alpha[:, None] * h[src]) + lw['bias'])
             hs.append(x)
-    final_node = 'mean' if kind == 'lightgcn' else gnn.get('final_node', 'concatenation')
+    final_node = 'mean' if kind in ('lightgcn', 'dgcf') else gnn.get('final_node', 'concatenation')
     if final_node == 'concatenation':
         e_all = torch.cat(hs, 1)
     elif final_node == 'last':
@@ -246,7 +252,7 @@ def torch_model_grads(adj, gnn, head, u_ids, i_ids, y, l2=0.0, self_loops=True, 
     pc = torch.clamp(p, EPS, 1 - EPS)
     loss = -torch.mean(yv * torch.log(pc + EPS) + (1 - yv) * torch.log(1 - pc + EPS)) + l2 * (x0 ** 2).sum()
     for lw in layers:
-        for name in ('kernel', 'bias'):
+        for name in ('kernel', 'bias', 'w'):                         # LocalityAdaptive's w carries the regulariser too (dgcf_conv.py:97)
             if name in lw:
                 loss = loss + l2 * (lw[name] ** 2).sum()
     loss.backward()

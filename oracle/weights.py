@@ -44,6 +44,11 @@ def gnn(rng, kind, n_nodes, embedding_dim=8, n_hiddens=(8, 8), n_layers=2, final
         w['layers'] = [{} for _ in range(n_layers)]
         w['final_node'] = 'mean'
         return w
+    if kind == 'dgcf':                                   # LocalityAdaptive: ones [N, 1] (dgcf_conv.py:93-99); fixtures perturb them
+        w['layers'] = [{'w': (1.0 + (rng.uniform(-bias_range, bias_range, size=(n_nodes, 1)) if bias_range else 0.0)
+                              * 10).astype(np.float32) * np.ones((n_nodes, 1), dtype=np.float32)} for _ in range(n_layers)]
+        w['final_node'] = 'mean'
+        return w
     for c in n_hiddens:
         if kind == 'gcn':
             lw = {'kernel': glorot_uniform(rng, (f_in, c)), 'bias': _bias(rng, c, bias_range)}

@@ -66,12 +66,15 @@ def gnn_to_oracle(gnn):
     from deep_cbrs_amar_renaissance_amd.layers.gat_conv import GATConv
     from deep_cbrs_amar_renaissance_amd.layers.lightgcn_conv import LightGCNConv
     seq = gnn.gnn_layers
-    kinds = {GCNConv: 'gcn', GraphSageConv: 'sage', GATConv: 'gat', LightGCNConv: 'lightgcn'}
+    from deep_cbrs_amar_renaissance_amd.layers.dgcf_conv import DGCFConv
+    kinds = {GCNConv: 'gcn', GraphSageConv: 'sage', GATConv: 'gat', LightGCNConv: 'lightgcn', DGCFConv: 'dgcf'}
     kind = kinds[type(seq.seq_layers[0])]
     layers = []
     for l in seq.seq_layers:
         if kind == 'lightgcn':
             layers.append({})
+        elif kind == 'dgcf':
+            layers.append({'w': _np(l.w)})
         elif kind == 'gat':
             c = l.channels
             layers.append({'kernel': _np(l.kernel).reshape(-1, c), 'attn_self': _np(l.attn_kernel_self).reshape(c),

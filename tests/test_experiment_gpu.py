@@ -38,7 +38,7 @@ def test_experiment_grid_runs_and_ranks_like_the_oracle(hip, tmp_path, monkeypat
     cfg['dataset'].update({k: v for k, v in paths.items() if k != 'props_triples_filepath'})
     (tmp_path / 'config.yaml').write_text(yaml.safe_dump(cfg))
     grid = {'grid': {
-        'g1': {'model': {'name': ['basic.BasicGCN', 'basic.BasicLightGCN', 'basic.BasicDGCF'], 'l2_regularizer': [1e-4],
+        'g1': {'model': {'name': ['basic.BasicGCN', 'basic.BasicLightGCN', 'basic.BasicDGCF', 'basic.BasicTSGCN'], 'l2_regularizer': [1e-4],
                          'dense_units': [[24, 24]], 'clf_units': [[48, 48]], 'embedding_dim': [8], 'n_hiddens': [[8, 8]],
                          'n_layers': [2]},
                'dataset': {'load_function_name': ['load_user_item_graph'], 'type_adjacency': ['unary-uip'],
@@ -59,16 +59,16 @@ def test_experiment_grid_runs_and_ranks_like_the_oracle(hip, tmp_path, monkeypat
     monkeypatch.chdir(tmp_path)
     run_log = setup_mlflow('test group', str(tmp_path / 'mlruns'))
     multi = experiment.MultiExperimenter(str(tmp_path / 'config.yaml'), str(tmp_path / 'exps.yaml'), run_log)
-    assert len(multi.experiments) == 7
+    assert len(multi.experiments) == 8
     results = multi.run()
     done = [k for k, v in results.items() if v is not None]
     failed = [k for k, v in results.items() if v is None]
-    assert len(done) == 6 and len(failed) == 1 and 'BasicDGCF' in failed[0]      # catch-and-continue (experiment.py:295-302)
+    assert len(done) == 7 and len(failed) == 1 and 'BasicTSGCN' in failed[0]      # catch-and-continue (experiment.py:295-302)
     for metrics in (results[k] for k in done):
         assert list(metrics.index) == ['precision_at', 'recall_at', 'f1_at'] and list(metrics.columns) == [5, 10]
         assert ((metrics.values >= 0) & (metrics.values <= 1)).all()
     tsvs = glob.glob(str(tmp_path / 'mlruns' / '*' / '*' / 'artifacts' / 'predictions' / 'top_5' / 'predictions_1.tsv'))
-    assert len(tsvs) == 6
+    assert len(tsvs) == 7
     top = pd.read_csv(tsvs[0], sep='\t', header=None)
     assert top.shape[1] == 3 and top.groupby(0).size().max() <= 5
     # raw identifiers, user ascending then score descending

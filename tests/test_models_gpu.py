@@ -168,6 +168,34 @@ def test_hybrid_tweaked_heads(hip, ml1m_s1, feature_based, fusion, residual):
         assert np.abs(got - want).max() < 1e-4
 
 
+@pytest.mark.parametrize('graph', ['adj_ui', 'adj_uip'])
+def test_basic_dgcf(hip, ml1m_s1, graph):
+    """BasicDGCF (gnn.py:391-415, dgcf_conv.py): host preprocess (cross-hop product, high-pass filter) equals the oracle's
+    matrix entry for entry; scores match with non-trivial gates."""
+    from deep_cbrs_amar_renaissance_amd.layers.dgcf_conv import DGCFConv
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    from oracle import graph as og
+    tr = ml1m_s1['train'][:60000]                                        # the cross-hop product of the full graph is ~45 M entries
+    users, items = ml1m_s1['users'], ml1m_s1['items']
+    from deep_cbrs_amar_renaissance_amd.data.preprocess import build_adjacency_matrix
+    if graph == 'adj_uip':
+        adj = build_adjacency_matrix(tr, users, items, ml1m_s1['triples'][:3000], ml1m_s1['props'], 'unary-uip')
+    else:
+        adj = build_adjacency_matrix(tr, users, items)
+    got_a, want_a = DGCFConv.preprocess(adj), og.dgcf_adjacency(adj)
+    assert got_a.nnz == want_a.nnz and abs(got_a - want_a).max() < 1e-7
+    model = basic.BasicDGCF(adj, **dict(GRID1, n_layers=2))
+    helpers.randomize_biases(model, seed=31)
+    with torch.no_grad():
+        for layer in model.gnn.gnn_layers.seq_layers:
+            layer.w.add_(torch.from_numpy(np.random.default_rng(5).uniform(-1.5, 1.5, tuple(layer.w.shape)).astype(np.float32)).to(layer.w.device))
+    data = ml1m_s1['test'][:5000]
+    u, i = data[:, 0], data[:, 1]
+    got = model((u, i)).cpu().numpy()
+    want = om.basic_gnn_scores(adj, helpers.gnn_to_oracle(model.gnn), helpers.basic_head_to_oracle(model.rs), u, i, dtype=np.float64)
+    assert np.abs(got - want).max() < 1e-4
+
+
 def test_hybrid_entity_based(hip):
     from deep_cbrs_amar_renaissance_amd.models import hybrid
     from oracle import layers as ol

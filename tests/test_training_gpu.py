@@ -187,7 +187,7 @@ def test_gradients_match_oracle(hip, cls, graph):
         assert np.abs(got - gw).max() <= 2e-4 * np.abs(gw).max() + 1e-10, tuple(prm.shape)
 
 
-@pytest.mark.parametrize('cls', ['BasicGraphSage', 'BasicGAT'])
+@pytest.mark.parametrize('cls', ['BasicGraphSage', 'BasicGAT', 'BasicDGCF'])
 @pytest.mark.parametrize('graph', ['ui', 'uip'])
 def test_gradients_match_autograd_oracle(hip, cls, graph):
     """Model kinds without a manual numpy reverse pass: oracle = torch autograd of the restated forward (float64)."""
@@ -201,6 +201,11 @@ def test_gradients_match_autograd_oracle(hip, cls, graph):
     y = np.random.default_rng(2).integers(0, 2, len(g['u_ids']))
     trainer = training.Trainer(model)
     loss, grads = trainer.loss_and_grads(g['u_ids'], g['i_ids'], y)
+    if cls == 'BasicDGCF':                                    # gates away from their all-ones start
+        with torch.no_grad():
+            for layer in model.gnn.gnn_layers.seq_layers:
+                layer.w.add_(torch.from_numpy(np.random.default_rng(3).uniform(-1, 1, tuple(layer.w.shape)).astype(np.float32)).to(layer.w.device))
+        loss, grads = trainer.loss_and_grads(g['u_ids'], g['i_ids'], y)
     # the training forward (unfused, keeps intermediates) scores like the fused inference forward
     with torch.no_grad():
         e_inf = model.gnn.gnn_layers(None)
@@ -341,7 +346,7 @@ def test_fit_learns_a_separable_task(hip):
     assert after[0] < before[0] and after[1] > max(before[1], 0.6)
 
 
-@pytest.mark.parametrize('cls', ['BasicGCN', 'BasicGraphSage', 'BasicGAT', 'BasicLightGCN'])
+@pytest.mark.parametrize('cls', ['BasicGCN', 'BasicGraphSage', 'BasicGAT', 'BasicLightGCN', 'BasicDGCF'])
 def test_graph_replayed_batches_equal_eager_batches(hip, cls):
     """train_batch_graphed (hipGraph replay incl. the device-side Adam counter) == train_batch, step for step."""
     from deep_cbrs_amar_renaissance_amd import engine, training

@@ -159,6 +159,17 @@ def main():
             spmm_events.append((e0, e1))
         return wrapper
     capi.gcn_layer, capi.spmm_sj, capi.spmm_xs = timed(raw_gcn_layer), timed(raw_spmm_sj), timed(raw_spmm_xs)   # whichever form the layer dispatches to
+    pair_events, raw_chain = [], capi.chain
+
+    def timed_chain(*a, **k):                                  # the pair stage = the sum-input chain launch
+        if not k.get('sum_inputs'):
+            return raw_chain(*a, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        raw_chain(*a, **k)
+        e1.record()
+        pair_events.append((e0, e1))
+    capi.chain = timed_chain
 
     def barrier():
         if world > 1 or force_dist:
@@ -169,12 +180,14 @@ def main():
         runner.step()
     barrier()
     spmm_events.clear()
+    pair_events.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         runner.step()
     barrier()
     dt = time.perf_counter() - t0
     capi.gcn_layer, capi.spmm_sj, capi.spmm_xs = raw_gcn_layer, raw_spmm_sj, raw_spmm_xs
+    capi.chain = raw_chain
     if world > 1 or force_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -196,7 +209,7 @@ def main():
         # HBM/fabric bytes per launch from a separate rocprofv3 --pmc run of this same command (tools/profile_bench.sh),
         # corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 on gfx950) — only valid for the profiled scale
         pmc = json.load(open(pmc_path))
-        if pmc.get('scale') == args.scale:
+        if pmc.get('scale') == args.scale and kind == 'xs':
             traffic = pmc['traffic_bytes_per_launch']
 
     if rank == 0:
@@ -216,6 +229,23 @@ def main():
                          'launches_timed': len(spmm_ms)},
             'propagation_ms': runner.last_propagation_ms(),
         }
+        pair_ms = [e0.elapsed_time(e1) for e0, e1 in pair_events]
+        if pair_ms:
+            # the other large kernel of a step: chain_kernel (sum-input form) gathers two 48-float per-entity rows per pair
+            c1 = GRID1['clf_units'][0]
+            pairs_local = int(runner.u_ids.numel())
+            pair_alg = pairs_local * (2 * c1 * 4 + 2 * 4 + 4)
+            pms = float(np.mean(pair_ms))
+            pair_traffic = None
+            if world == 1 and os.path.exists(pmc_path) and json.load(open(pmc_path)).get('scale') == args.scale and \
+                    'pair_stage_traffic_bytes_per_launch' in json.load(open(pmc_path)):
+                pmc = json.load(open(pmc_path))
+                pair_traffic = pmc['pair_stage_traffic_bytes_per_launch']
+            out['pair_stage'] = {'kernel': 'chain_kernel<3,2,true> (relu(T_u[u] + T_i[i]) -> Dense 48 -> Dense 1, sigmoid)',
+                                 'avg_launch_ms': pms, 'pairs_per_launch': pairs_local, 'bound': 'hbm',
+                                 'algorithmic_bytes_per_launch': pair_alg, 'achieved': pair_alg / (pms * 1e-3) / 1e9,
+                                 'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': pair_alg / (pms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                 'traffic': pair_traffic}
         if world == 1 and not args.no_cpu_baseline:
             out['ml1m_s1'] = ml1m_true_size(dev)
             out['cpu_baseline'] = cpu_baseline()

@@ -25,6 +25,7 @@ import torch
 
 from deep_cbrs_amar_renaissance_amd import capi
 from deep_cbrs_amar_renaissance_amd.layers.gcn_conv import GCNConv
+from deep_cbrs_amar_renaissance_amd.layers.lightgcn_conv import LightGCNConv
 from deep_cbrs_amar_renaissance_amd.utilities.math import DeviceCSR
 
 
@@ -113,14 +114,21 @@ class SingleRunner:
 
 
 class PartitionedGCNRunner:
-    """BasicGCN over `world` ranks: row-range SpMM + per-layer all-gather, pair-sharded scoring."""
+    """Basic* / HybridBert* models with a GCN ('concatenation') or LightGCN ('mean') stack over `world` ranks:
+    row-range SpMM + per-layer all-gather, replicated per-entity towers, pair-sharded scoring."""
 
     def __init__(self, model, u_ids, i_ids, rank, world, ops=capi, dist=None, timing=True):
         self.ops, self.rank, self.world, self.timing = ops, rank, world, timing
         self.dist = dist if dist is not None else torch.distributed
         seq = model.gnn.gnn_layers
-        if not all(isinstance(l, GCNConv) for l in seq.seq_layers) or seq.final_node != 'concatenation':
-            raise NotImplementedError("the partitioned runner covers GCN stacks with the 'concatenation' reduction")
+        layers = list(seq.seq_layers)
+        if layers and all(isinstance(l, GCNConv) for l in layers) and seq.final_node == 'concatenation':
+            self.kind = 'gcn'
+        elif layers and all(isinstance(l, LightGCNConv) for l in layers) and seq.final_node == 'mean':
+            self.kind = 'lightgcn'
+        else:
+            raise NotImplementedError("the partitioned runner covers GCN ('concatenation') and LightGCN ('mean') stacks")
+        self.hybrid = hasattr(model.rs, 'dense1a')
         self.model, self.seq = model, seq
         a = seq.adj_matrix
         self.part = RowPartition(partition_rows_by_nnz(a.rowptr, world))
@@ -136,6 +144,16 @@ class PartitionedGCNRunner:
         self.i_ids = self.part.padded_index(i_ids[lo:hi]).to(torch.int32).contiguous()
         self.pair_range = (lo, hi)
         self._events = None
+        # users are the first n_users global ids, items the next n_items (loaders.py:43-56): in the padded layout they
+        # occupy two row ranges that overlap by at most one rank's block, so each tower runs on its own range only
+        if getattr(model, 'n_users', None) is None or getattr(model, 'n_items', None) is None:
+            self.u_rows = self.i_rows = (0, self.world * self.part.R)        # unknown split: both towers over every row
+        else:
+            nu, ni = int(model.n_users), int(model.n_items)
+            last = torch.tensor([nu - 1, nu, nu + ni - 1], device=u_ids.device)
+            pu_end, pi_beg, pi_end = [int(v) for v in self.part.padded_index(last).cpu()]
+            self.u_rows, self.i_rows = (0, pu_end + 1), (pi_beg, pi_end + 1)
+        self._bert_version, self._bert_pad = None, None
 
     def _x0_padded(self):
         emb = self.seq.embeddings
@@ -155,6 +173,19 @@ class PartitionedGCNRunner:
         layers, widths = list(self.seq.seq_layers), self.widths
         rows = self.local_rows
         x0p = self._x0_padded()
+        if self.kind == 'lightgcn':
+            # X_{l+1} = A_hat X_l on the local rows, gathered; the mean over layers accumulates on the full table
+            acc = x0p.clone()
+            x = x0p
+            for _ in layers:
+                y_local = torch.zeros((R, widths[0]), dtype=torch.float32, device=dev)
+                ops.spmm_csr(self.csr.rowptr, self.csr.colidx, self.csr.vals, x, y_local[:rows])
+                x = torch.empty((self.world * R, widths[0]), dtype=torch.float32, device=dev)
+                self.dist.all_gather_into_tensor(x, y_local)
+                ops.add_inplace(acc, x)
+            out = torch.empty_like(acc)
+            ops.row_affine(acc, self._mean_scale(acc.shape[0], len(layers) + 1, dev), out)
+            return out
         f_cat = sum(widths)
         offs = np.cumsum([0] + widths)
         e_all = torch.empty((self.world * R, f_cat), dtype=torch.float32, device=dev)
@@ -180,8 +211,33 @@ class PartitionedGCNRunner:
         if self.timing:
             e1.record()
             self._events = (e0, e1)
-        towers = self.model.rs.towers(emb, emb)           # replicated per-entity towers over the padded table
-        return self.model.rs.score_towers(towers, self.u_ids, self.i_ids)
+        # replicated per-entity towers, each over its own row range of the padded table
+        (u0, u1), (i0, i1) = self.u_rows, self.i_rows
+        if self.hybrid:
+            bert = self._bert_padded()
+            towers = self.model.rs.towers(emb[u0:u1], emb[i0:i1], bert[u0:u1], bert[i0:i1])
+        else:
+            towers = self.model.rs.towers(emb[u0:u1], emb[i0:i1])
+        return self.model.rs.score_towers(towers, self.u_ids, self.i_ids, u0, i0)
+
+    def _mean_scale(self, n_rows, n_terms, dev):
+        if getattr(self, '_mean', None) is None or self._mean.numel() != n_rows:
+            self._mean = torch.full((n_rows,), 1.0 / n_terms, dtype=torch.float32, device=dev)
+        return self._mean
+
+    def _bert_padded(self):
+        """The resident BERT table (rows = users then items) in the padded layout; property nodes get zero rows."""
+        table = self.model.bert_table
+        if table is None:
+            raise ValueError("the hybrid model needs its BERT table registered (set_bert_table) for the partitioned run")
+        key = (table.data_ptr(), table._version)
+        if self._bert_version != key:
+            full = torch.zeros((self.part.n, table.shape[1]), dtype=torch.float32, device=table.device)
+            full[:min(self.part.n, table.shape[0])] = table[:self.part.n]
+            self._bert_pad, self._bert_version = self.part.pad_table(full), key
+            if not self.model.rs.built:
+                self.model.rs.build_head(self.model.gnn.output_dim(), table.shape[1])
+        return self._bert_pad
 
     def last_propagation_ms(self):
         if not self._events:

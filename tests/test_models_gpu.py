@@ -263,22 +263,35 @@ class _LockstepGather:
 
 
 @pytest.mark.parametrize('world', [1, 2, 4])
-def test_partitioned_runner_with_real_kernels(hip, world):
+@pytest.mark.parametrize('case', ['BasicGCN', 'BasicGCN-ranges', 'BasicLightGCN', 'HybridBertGCN-uip'])
+def test_partitioned_runner_with_real_kernels(hip, world, case):
     """parallel.PartitionedGCNRunner (node-range partition, padded index space, per-layer gather) driving the real HIP
     kernels: `world` rank threads on one GPU, the collective replaced by an in-process copy.  Scores of every rank's
-    pair shard must match the single-GPU model."""
+    pair shard must match the single-GPU model.  'HybridBertGCN-uip' is the shape of BASELINE config 4
+    (hybrid-gnn-uip-2relconf, node-partitioned): properties extend the graph, the BERT table covers users + items."""
     import threading
     from deep_cbrs_amar_renaissance_amd import engine, parallel
-    from deep_cbrs_amar_renaissance_amd.models import basic
+    from deep_cbrs_amar_renaissance_amd.models import basic, hybrid
     engine.set_seed(3)
-    g = helpers.tiny_graph(n_users=300, n_items=200, n_ratings=9000, seed=12)
-    model = basic.BasicGCN(g['adj'], **GRID1)
-    helpers.randomize_biases(model, seed=4)
-    helpers.spread_scores(model)
+    uip = case.endswith('-uip')
+    g = helpers.tiny_graph(n_users=300, n_items=200, n_ratings=9000, seed=12, n_props=90 if uip else 0, n_links=500 if uip else 0)
     rng = np.random.default_rng(0)
     u = torch.from_numpy(rng.integers(0, 300, 5000)).cuda()
     i = torch.from_numpy(rng.integers(300, 500, 5000)).cuda()
-    want = model((u, i)).cpu().numpy()
+    if case.startswith('Hybrid'):
+        model = hybrid.HybridBertGCN(g['adj'], **dict(GRID1, dense_units=[[24, 24], [32, 16], [16, 16]], clf_units=[16, 16], feature_based=True))
+        model.n_users, model.n_items = 300, 200
+        model.set_bert_table(rng.standard_normal((500, 40)).astype(np.float32))
+        model.rs.build_head(model.gnn.output_dim(), 40)
+        inputs = (u, i, None, None)
+    else:
+        model = getattr(basic, case.split('-')[0])(g['adj'], **GRID1)
+        if case.endswith('-ranges'):
+            model.n_users, model.n_items = 300, 200
+        inputs = (u, i)
+    helpers.randomize_biases(model, seed=4)
+    helpers.spread_scores(model)
+    want = model(inputs).cpu().numpy()
     e_want = model.gnn(None).cpu().numpy()
     fake = _LockstepGather(world)
     results, errors = [None] * world, []

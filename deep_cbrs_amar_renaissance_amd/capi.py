@@ -29,7 +29,7 @@ SIGNATURES = {
                                          _P, _I64, _P, _I64, _F32, _P]),
     'amar_spmm_sj_f32': (ctypes.c_int, [_P, _P, _P, _I32, _P, _I64, _P, _I64, _I32, _I32, _U32, _P,
                                         _P, _I64, _P, _I64, _F32, _P, _I32, _P, _I64, _P]),
-    'amar_spmm_xs_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, _I32, _P, _I64, _P, _P, _I64, _I32, _I32, _U32, _P,
+    'amar_spmm_xs_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _P, _P, _P, _I64, _I32, _I32, _U32, _P,
                                         _P, _I64, _P, _I64, _F32, _P, _I32, _P, _I64, _P]),
     'amar_gcn_layer_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _I64, _P, _I32, _P, _I64, _I32, _P]),
     'amar_rowwise_xw_f32': (ctypes.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _P, _I64, _P, _P, _P, _P, _I32, _P]),
@@ -190,8 +190,9 @@ def spmm_xs(xs, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc
             raise ValueError("acc_in/acc_out must be [n_rows, F]")
     if Y is not None and tuple(Y.shape) != (n_rows, F):
         raise ValueError("Y must be [n_rows, F]")
-    if X.shape[0] != n_rows:
-        raise ValueError("X must have one row per node")
+    diag_offset = int(getattr(xs, 'diag_offset', 0))
+    if X.shape[0] != xs.shape[1] or diag_offset + n_rows > X.shape[0]:
+        raise ValueError("X must have one row per column of the matrix")
     Cn = 0
     if Wnext is not None:
         if Wnext.shape[0] != F or not Wnext.is_contiguous() or Hnext is None or tuple(Hnext.shape) != (n_rows, Wnext.shape[1]):
@@ -202,15 +203,17 @@ def spmm_xs(xs, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc
     if row_scale is None and (prescaled or scale_next):
         raise ValueError("spmm_xs: prescaled / scale_next need a value-free image")
     if row_scale is not None and not prescaled:
-        Xs = torch.empty((n_rows, F), dtype=torch.float32, device=X.device)
-        row_affine(X, row_scale, Xs)
+        col_scale = getattr(xs, 'col_scale', None)
+        Xs = torch.empty((X.shape[0], F), dtype=torch.float32, device=X.device)
+        row_affine(X, col_scale if col_scale is not None else row_scale, Xs)
         X = Xs
     if scale_next:
         flags |= SPMM_SCALE_NEXT
     code = load().amar_spmm_xs_f32(
         _ptr(xs.diag, torch.float32, 'diag'), _ptr(xs.rowptr, torch.int32, 'rowptr'), _ptr(xs.colidx, torch.int32, 'colidx'),
         _ptr(xs.vals, torch.float32, 'vals'), _ptr(row_scale, torch.float32, 'row_scale'), xs.n_slices,
-        _ptr(X, torch.float32, 'X'), _ld(X, 'X'), _ptr(P, torch.float32, 'partials'),
+        _ptr(X, torch.float32, 'X'), _ld(X, 'X'), X.shape[0], _ptr(X[diag_offset:], torch.float32, 'X') if diag_offset else None,
+        _ptr(P, torch.float32, 'partials'),
         _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y') if Y is not None else 0,
         n_rows, F, flags, _ptr(bias, torch.float32, 'bias'),
         _ptr(acc_in, torch.float32, 'acc_in'), _ld(acc_in, 'acc_in') if acc_in is not None else 0,

@@ -519,7 +519,7 @@ __global__ __launch_bounds__(XS_WAVES * AMAR_WAVE) void spmm_xs_partial_kernel(c
     }
 }
 
-struct XsCombineArgs { const float *diag; const float *P; const int32_t *rowptr; int n_slices; const float *row_scale; SpmmArgs e; };
+struct XsCombineArgs { const float *diag; const float *P; const int32_t *rowptr; int n_slices; const float *row_scale; const float *Xself; SpmmArgs e; };
 
 template <int F, bool FUSE_NEXT>
 __global__ __launch_bounds__(256) void spmm_xs_combine_kernel(const XsCombineArgs a) {
@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256) void spmm_xs_combine_kernel(const XsCombineArg
     const float d = a.diag[row];
 #pragma unroll
     for (int q = 0; q < LPN; ++q) {
-        const float4 x = *reinterpret_cast<const float4 *>(e.X + (int64_t)row * e.ldx + 4 * q);
+        const float4 x = *reinterpret_cast<const float4 *>(a.Xself + (int64_t)row * e.ldx + 4 * q);   // the row's own features
         acc[q] = make_float4(d * x.x, d * x.y, d * x.z, d * x.w);
     }
     const int w0 = __builtin_amdgcn_readfirstlane(row & ~(AMAR_WAVE - 1));      // the partial kernel's 64-row block
@@ -847,12 +847,14 @@ int amar_spmm_sj_f32(const int32_t *entries, const int16_t *counts, const int32_
 }
 
 int amar_spmm_xs_f32(const float *diag, const int32_t *rowptr, const int32_t *colidx, const float *vals, const float *row_scale,
-                     int32_t n_slices, const float *X, int64_t ldx, float *partials, float *Y, int64_t ldy,
-                     int32_t n_rows, int32_t F, uint32_t flags, const float *bias,
+                     int32_t n_slices, const float *X, int64_t ldx, int32_t n_cols, const float *Xself, float *partials,
+                     float *Y, int64_t ldy, int32_t n_rows, int32_t F, uint32_t flags, const float *bias,
                      const float *acc_in, int64_t ld_acc_in, float *acc_out, int64_t ld_acc_out, float acc_div,
                      const float *Wnext, int32_t Cn, float *Hnext, int64_t ldhn, amar_stream_t stream) {
-    if (n_rows < 0 || n_slices < 1 || !diag || !rowptr || !X || !partials) return AMAR_EINVAL;
+    if (n_rows < 0 || n_cols < 0 || n_slices < 1 || !diag || !rowptr || !X || !partials) return AMAR_EINVAL;
     if (n_rows == 0) return AMAR_OK;
+    if (!Xself) { if (n_cols < n_rows) return AMAR_EINVAL; Xself = X; }   // square: row i's own features are X[i]
+    if (!amar_aligned16(Xself)) return AMAR_EINVAL;
     // colidx / vals may be NULL when the matrix has no off-diagonal entry (every segment is then empty)
     const bool accum = flags & AMAR_SPMM_ACCUM;
     if (!Y && !accum) return AMAR_EINVAL;
@@ -868,9 +870,9 @@ int amar_spmm_xs_f32(const float *diag, const int32_t *rowptr, const int32_t *co
     if ((vals != nullptr) == (row_scale != nullptr) && colidx) return AMAR_EINVAL;   // exactly one of them (unless there are no entries)
     XsArgs pa{rowptr, colidx, vals, X, ldx, partials, n_rows, n_slices,
               (n_rows + XS_WAVES * AMAR_WAVE - 1) / (XS_WAVES * AMAR_WAVE),
-              (int64_t)n_rows * ldx * 4 < (int64_t(1) << 32)};
+              (int64_t)n_cols * ldx * 4 < (int64_t(1) << 32)};
     XsCombineArgs ca{};
-    ca.diag = diag; ca.P = partials; ca.rowptr = rowptr; ca.n_slices = n_slices; ca.row_scale = row_scale;
+    ca.diag = diag; ca.P = partials; ca.rowptr = rowptr; ca.n_slices = n_slices; ca.row_scale = row_scale; ca.Xself = Xself;
     ca.e.next_scale = (flags & AMAR_SPMM_SCALE_NEXT) ? row_scale : nullptr;
     ca.e.X = X; ca.e.ldx = ldx; ca.e.Y = Y; ca.e.ldy = ldy;
     ca.e.bias = (flags & AMAR_SPMM_BIAS) ? bias : nullptr; ca.e.relu = (flags & AMAR_SPMM_RELU) ? 1 : 0;

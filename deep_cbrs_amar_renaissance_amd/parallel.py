@@ -20,6 +20,8 @@ is row-separable, the scoring head is pair-separable:
 ``ops`` is the kernel provider (the ctypes binding by default); tests inject a CPU stand-in to
 exercise the partition / exchange logic under ``gloo`` without a GPU.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -76,8 +78,13 @@ class RowPartition:
         p0, p1 = int(rp[0]), int(rp[-1])
         colidx = self.padded_index(a.colidx[p0:p1]).to(torch.int32).contiguous()
         vals = a.vals[p0:p1].contiguous() if a.vals is not None else None
-        return DeviceCSR((rp - p0).to(torch.int32).contiguous(), colidx, vals, (hi - lo, self.world * self.R),
-                         gcn_filtered=a.gcn_filtered)
+        local = DeviceCSR((rp - p0).to(torch.int32).contiguous(), colidx, vals, (hi - lo, self.world * self.R),
+                          gcn_filtered=a.gcn_filtered)
+        local.diag_offset = rank * self.R                            # padded column of local row 0's own entry
+        if getattr(a, 'dinv', None) is not None and getattr(a, 'mult', None) is not None:
+            local.dinv = self.pad_table(a.dinv.view(-1, 1)).view(-1).contiguous()      # over the padded columns
+            local.mult = a.mult[p0:p1].contiguous()
+        return local
 
 
 class SingleRunner:
@@ -194,7 +201,15 @@ class PartitionedGCNRunner:
         ops.rowwise_xw(x0p, layers[0].kernel, h)
         for k, layer in enumerate(layers):
             y_local = torch.zeros((R, widths[k + 1]), dtype=torch.float32, device=dev)
-            ops.gcn_layer(self.csr.rowptr, self.csr.colidx, self.csr.vals, h, layer.bias, y_local[:rows])
+            if self._use_xs(widths[k + 1]):
+                # the rank's row block on the XCD-sliced image (value-free when A_hat's factors are known): same kernels
+                # as the single-GPU path, the block's own rows sit at column offset rank * R of the padded table
+                xs = self.csr.xcd_sliced()
+                if xs.row_scale is not None:
+                    ops.row_affine(h, xs.col_scale, h)
+                ops.spmm_xs(xs, h, y_local[:rows], bias=layer.bias, relu=True, prescaled=xs.row_scale is not None)
+            else:
+                ops.gcn_layer(self.csr.rowptr, self.csr.colidx, self.csr.vals, h, layer.bias, y_local[:rows])
             x_full = torch.empty((self.world * R, widths[k + 1]), dtype=torch.float32, device=dev)
             self.dist.all_gather_into_tensor(x_full, y_local)
             ops.copy_columns(x_full, e_all[:, offs[k + 1]:offs[k + 2]])
@@ -219,6 +234,16 @@ class PartitionedGCNRunner:
         else:
             towers = self.model.rs.towers(emb[u0:u1], emb[i0:i1])
         return self.model.rs.score_towers(towers, self.u_ids, self.i_ids, u0, i0)
+
+    def _use_xs(self, width):
+        """XCD-sliced local SpMM when the gathered table exceeds the per-XCD L2s (as utilities.math.spmm_kind decides
+        for the single-GPU path); AMAR_SPMM_KIND=csr|xs overrides."""
+        if self.ops is not capi or not hasattr(self.csr, 'diag_offset') or width > 16 or width % 4:
+            return False
+        forced = os.environ.get('AMAR_SPMM_KIND')
+        if forced in ('csr', 'xs'):
+            return forced == 'xs'
+        return self.world * self.part.R * width * 4 >= (16 << 20)
 
     def _mean_scale(self, n_rows, n_terms, dev):
         if getattr(self, '_mean', None) is None or self._mean.numel() != n_rows:

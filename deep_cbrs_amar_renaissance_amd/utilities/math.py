@@ -254,9 +254,11 @@ class XcdSliced:
 
     N_SLICES = 8
 
-    def __init__(self, diag, rowptr, colidx, vals, bounds, shape, row_scale=None):
+    def __init__(self, diag, rowptr, colidx, vals, bounds, shape, row_scale=None, col_scale=None, diag_offset=0):
         self.diag, self.rowptr, self.colidx, self.vals, self.bounds, self.shape = diag, rowptr, colidx, vals, bounds, tuple(shape)
-        self.row_scale = row_scale
+        # value-free form: row_scale [n_rows] scales the row sums, col_scale [n_cols] pre-scales the gathered table
+        # (the same vector for a square matrix); diag_offset: column of row 0's own entry (row block of a larger matrix)
+        self.row_scale, self.col_scale, self.diag_offset = row_scale, col_scale, int(diag_offset)
         self.n_slices = len(bounds) - 1
         self._partials = {}
 
@@ -268,10 +270,13 @@ class XcdSliced:
 
     @classmethod
     def from_csr(cls, a, n_slices=N_SLICES):
+        """`a`: a square DeviceCSR, or a row block of one (multi-GPU partition) carrying `diag_offset` = the column of
+        its first row's own entry, and for the value-free form `dinv` over its COLUMNS plus `mult`."""
         dev = a.rowptr.device
-        n = a.shape[0]
-        if a.shape[0] != a.shape[1]:
-            raise ValueError("the XS image is defined for square matrices")
+        n, n_cols = a.shape
+        diag_offset = int(getattr(a, 'diag_offset', 0))
+        if n != n_cols and not hasattr(a, 'diag_offset'):
+            raise ValueError("the XS image is defined for square matrices and for row blocks that say where their diagonal is")
         deg = (a.rowptr[1:] - a.rowptr[:-1]).long()
         rows = torch.repeat_interleave(torch.arange(n, device=dev), deg)
         cols = a.colidx.long()
@@ -281,7 +286,7 @@ class XcdSliced:
             vals = a.mult.to(torch.float32)                      # C = A + I: the integer multiplicities
         else:
             vals = a.vals if a.vals is not None else torch.ones(a.nnz, dtype=torch.float32, device=dev)
-        on_diag = rows == cols
+        on_diag = cols == rows + diag_offset
         diag = torch.zeros(n, dtype=torch.float32, device=dev).index_add_(0, rows[on_diag], vals[on_diag])
         rows, cols, vals = rows[~on_diag], cols[~on_diag], vals[~on_diag]
         if value_free and cols.numel() and int(vals.max()) > 1:  # an entry c > 1 becomes c unit entries
@@ -292,25 +297,26 @@ class XcdSliced:
             sc = torch.sort(cols).values
             cuts = [int(sc[(m * k) // n_slices]) for k in range(1, n_slices)]
         else:
-            cuts = [(n * k) // n_slices for k in range(1, n_slices)]
-        bounds = [0] + cuts + [n]
+            cuts = [(n_cols * k) // n_slices for k in range(1, n_slices)]
+        bounds = [0] + cuts + [n_cols]
         for k in range(1, len(bounds)):
             bounds[k] = max(bounds[k], bounds[k - 1])
         b = torch.tensor(bounds, dtype=torch.int64, device=dev)
         sl = (torch.searchsorted(b, cols, right=True) - 1).clamp_(0, n_slices - 1)
         seg = sl * n + rows
-        order = torch.argsort(seg * n + cols)
+        order = torch.argsort(seg * n_cols + cols)
         rowptr = torch.zeros(n_slices * n + 1, dtype=torch.int64, device=dev)
         rowptr[1:] = torch.cumsum(torch.bincount(seg, minlength=n_slices * n), 0)
-        if n > (1 << 26):
+        if n_cols > (1 << 26):
             raise ValueError("the XS image packs the row (6 bits) above a 26-bit column: n must be <= 2^26")
         packed = ((rows[order] & 63) << 26) | cols[order]
         packed = torch.where(packed >= (1 << 31), packed - (1 << 32), packed)      # two's-complement int32
         if value_free:
+            col_scale = a.dinv.to(torch.float32).contiguous()                   # over the columns
             return cls(diag, rowptr.to(torch.int32), packed.to(torch.int32).contiguous(), None, bounds, a.shape,
-                       row_scale=a.dinv.to(torch.float32).contiguous())
+                       row_scale=col_scale[diag_offset:diag_offset + n].contiguous(), col_scale=col_scale, diag_offset=diag_offset)
         return cls(diag, rowptr.to(torch.int32), packed.to(torch.int32).contiguous(), vals[order].contiguous(),
-                   bounds, a.shape)
+                   bounds, a.shape, diag_offset=diag_offset)
 
 
 def _csr_xcd_sliced(self):

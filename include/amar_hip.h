@@ -89,7 +89,8 @@ int amar_spmm_sj_f32(const int32_t *entries, const int16_t *counts, const int32_
  * Two launches: per-slice partial rows -> partials[n_slices, n, F] (caller-provided scratch), workgroup b touching
  * slice b % n_slices only (XCD <-> L2 affinity under round-robin dispatch); then
  *   Y[i] = epilogue( diag[i] . X[i] + sum_k partials[k][i] )   in slice order, epilogue as amar_spmm_sj_f32.
- * The matrix must be square and X must be the same table the rows index (X[i] is row i's own features).
+ * X has n_cols rows (the columns of A).  Xself[i] is row i's own feature row for the diag term: NULL means X (square A,
+ * the rows index the same table); a row block of a larger matrix (multi-GPU node-range partition) passes X + offset.
  *
  * Value-free form (vals == NULL, row_scale != NULL) for A = S (C) S with S = diag(row_scale) and C a matrix of small
  * non-negative integers — exactly gcn_filter's D^-1/2 (A + I) D^-1/2 (Spektral, called at src/models/gnn.py:283,381):
@@ -99,7 +100,7 @@ int amar_spmm_sj_f32(const int32_t *entries, const int16_t *counts, const int32_
  * chain of GCN layers stays in the pre-scaled form.  With vals != NULL row_scale must be NULL.
  */
 int amar_spmm_xs_f32(const float *diag, const int32_t *rowptr, const int32_t *colidx, const float *vals, const float *row_scale,
-                     int32_t n_slices, const float *X, int64_t ldx, float *partials, float *Y, int64_t ldy,
+                     int32_t n_slices, const float *X, int64_t ldx, int32_t n_cols, const float *Xself, float *partials, float *Y, int64_t ldy,
                      int32_t n_rows, int32_t F, uint32_t flags, const float *bias,
                      const float *acc_in, int64_t ld_acc_in, float *acc_out, int64_t ld_acc_out, float acc_div,
                      const float *Wnext, int32_t Cn, float *Hnext, int64_t ldhn, amar_stream_t stream);

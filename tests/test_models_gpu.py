@@ -263,8 +263,8 @@ class _LockstepGather:
 
 
 @pytest.mark.parametrize('world', [1, 2, 4])
-@pytest.mark.parametrize('case', ['BasicGCN', 'BasicGCN-ranges', 'BasicLightGCN', 'HybridBertGCN-uip'])
-def test_partitioned_runner_with_real_kernels(hip, world, case):
+@pytest.mark.parametrize('case', ['BasicGCN', 'BasicGCN-ranges', 'BasicLightGCN', 'HybridBertGCN-uip', 'BasicGCN-xs', 'BasicGCN-xs-valuefree'])
+def test_partitioned_runner_with_real_kernels(hip, world, case, monkeypatch):
     """parallel.PartitionedGCNRunner (node-range partition, padded index space, per-layer gather) driving the real HIP
     kernels: `world` rank threads on one GPU, the collective replaced by an in-process copy.  Scores of every rank's
     pair shard must match the single-GPU model.  'HybridBertGCN-uip' is the shape of BASELINE config 4
@@ -285,7 +285,13 @@ def test_partitioned_runner_with_real_kernels(hip, world, case):
         model.rs.build_head(model.gnn.output_dim(), 40)
         inputs = (u, i, None, None)
     else:
-        model = getattr(basic, case.split('-')[0])(g['adj'], **GRID1)
+        adj = g['adj']
+        if case.endswith('-valuefree'):                        # device-built A_hat carries its factors: value-free row blocks
+            from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter_device
+            coo = g['adj'].tocoo()
+            keep = coo.row < coo.col
+            adj = gcn_filter_device(torch.from_numpy(coo.row[keep].astype(np.int64)).cuda(), torch.from_numpy(coo.col[keep].astype(np.int64)).cuda(), coo.shape[0])
+        model = getattr(basic, case.split('-')[0])(adj, **GRID1)
         if case.endswith('-ranges'):
             model.n_users, model.n_items = 300, 200
         inputs = (u, i)
@@ -293,6 +299,8 @@ def test_partitioned_runner_with_real_kernels(hip, world, case):
     helpers.spread_scores(model)
     want = model(inputs).cpu().numpy()
     e_want = model.gnn(None).cpu().numpy()
+    if '-xs' in case:
+        monkeypatch.setenv('AMAR_SPMM_KIND', 'xs')             # the ranks' row blocks on the XCD-sliced kernels
     fake = _LockstepGather(world)
     results, errors = [None] * world, []
 
@@ -305,6 +313,8 @@ def test_partitioned_runner_with_real_kernels(hip, world, case):
             idx = runner.part.padded_index(torch.arange(e_want.shape[0], device='cuda'))
             scores = runner.step()
             torch.cuda.synchronize()
+            if '-xs' in case:
+                assert runner._use_xs(8) and (runner.csr.xcd_sliced().row_scale is not None) == case.endswith('-valuefree')
             results[rank] = (e_pad[idx].cpu().numpy(), scores.cpu().numpy(), runner.pair_range)
         except Exception as exc:                              # surface thread failures in the main thread
             errors.append(exc)

@@ -198,7 +198,10 @@ def main():
     nnz_local = runner.local_nnz
     f = GRID1['n_hiddens'][0]
     from deep_cbrs_amar_renaissance_amd.utilities.math import spmm_kind
-    kind = spmm_kind(model.gnn.gnn_layers.adj_matrix, f) if (world == 1 and not force_dist) else 'csr'
+    if world == 1 and not force_dist:
+        kind = spmm_kind(model.gnn.gnn_layers.adj_matrix, f)
+    else:
+        kind = 'xs' if runner._use_xs(f) else 'csr'
     alg_bytes = nnz_local * 8 + (rows_local + 1) * 4 + (n_nodes + rows_local) * f * 4
     avg_ms = float(np.mean(spmm_ms)) if spmm_ms else float('nan')
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
@@ -209,7 +212,7 @@ def main():
         # HBM/fabric bytes per launch from a separate rocprofv3 --pmc run of this same command (tools/profile_bench.sh),
         # corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 on gfx950) — only valid for the profiled scale
         pmc = json.load(open(pmc_path))
-        if pmc.get('scale') == args.scale and kind == 'xs':
+        if pmc.get('scale') == args.scale and kind == 'xs' and not force_dist:
             traffic = pmc['traffic_bytes_per_launch']
 
     if rank == 0:

@@ -186,10 +186,10 @@ int amar_dense_f32(const float *X, int64_t ldx, const int32_t *ids,
 int amar_topk_segmented_f32(const int32_t *seg_ptr, const int32_t *item_ids, const float *scores,
                             int32_t n_users, int32_t k, int32_t *out_items, float *out_scores,
                             amar_stream_t stream) {
-    if (n_users < 0 || k < 1 || !seg_ptr || !out_items || !out_scores) return AMAR_EINVAL;
+    if (n_users < 0 || k < 1 || !seg_ptr) return AMAR_EINVAL;
     if (k > 64) return AMAR_EUNSUPPORTED;
-    if (n_users == 0) return AMAR_OK;
-    if (!item_ids || !scores) return AMAR_EINVAL;
+    if (n_users == 0) return AMAR_OK;                                    // nothing to rank: the outputs may be empty (NULL)
+    if (!item_ids || !scores || !out_items || !out_scores) return AMAR_EINVAL;
     hipLaunchKernelGGL(topk_segmented_kernel, dim3((n_users + 3) / 4), dim3(256), 0,
                        static_cast<hipStream_t>(stream), seg_ptr, item_ids, scores, n_users, k, out_items, out_scores);
     return amar_check_launch();

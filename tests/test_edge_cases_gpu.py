@@ -1,0 +1,91 @@
+"""GPU edge cases of the hot path (pytest -m gpu): empty and one-element inputs, isolated nodes, edgeless graphs,
+users with fewer than k scored items — the degenerate shapes a drop-in has to survive."""
+import numpy as np
+import pytest
+import torch
+from scipy import sparse
+
+from oracle import models as om
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+CFG = dict(embedding_dim=8, n_hiddens=[8, 8], n_layers=2, dense_units=[24, 24], clf_units=[48, 48], l2_regularizer=1e-4)
+
+
+class _Seq:
+    def __init__(self, batches):
+        self.batches = batches
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __getitem__(self, b):
+        return self.batches[b]
+
+
+@pytest.mark.parametrize('cls', ['BasicGCN', 'BasicGraphSage', 'BasicGAT', 'BasicLightGCN'])
+def test_isolated_nodes_and_single_pairs(hip, cls):
+    """Nodes without any edge (degree 0: only the filter's self loop / the layers' own self loop), batches of one pair,
+    ragged last batch, hoisted and faithful predict."""
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    n_users, n_items = 37, 29
+    rng = np.random.default_rng(1)
+    u = rng.integers(0, n_users - 5, 150)                      # the last 5 users and 4 items never appear: isolated nodes
+    i = rng.integers(0, n_items - 4, 150) + n_users
+    n = n_users + n_items
+    adj = sparse.coo_matrix((np.ones(300, dtype=np.float32), (np.concatenate([u, i]), np.concatenate([i, u]))), shape=(n, n))
+    model = getattr(basic, cls)(adj, **CFG)
+    helpers.randomize_biases(model, seed=2)
+    pu = np.arange(n_users, dtype=np.int64)
+    pi = (np.arange(n_users) % n_items + n_users).astype(np.int64)          # touches the isolated items and users too
+    want = om.basic_gnn_scores(adj, helpers.gnn_to_oracle(model.gnn), helpers.basic_head_to_oracle(model.rs), pu, pi, dtype=np.float64)
+    seq = _Seq([((pu[:1], pi[:1]), None), ((pu[1:20], pi[1:20]), None), ((pu[20:], pi[20:]), None)])     # 1, 19, 17 pairs
+    for hoist in (True, False):
+        got = model.predict(seq, hoist=hoist)
+        assert got.shape == (n_users, 1) and np.isfinite(got).all()
+        assert np.abs(got - want).max() < 1e-5
+
+
+def test_empty_inputs(hip):
+    """No batches, and a graph without any edge (A_hat = I): predict returns [0, 1] / finite scores; top-k of nothing."""
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    from deep_cbrs_amar_renaissance_amd.utilities import metrics
+    n = 12
+    adj = sparse.coo_matrix((n, n), dtype=np.float32)
+    model = basic.BasicGCN(adj, **CFG)
+    helpers.randomize_biases(model, seed=3)
+    assert model.predict(_Seq([])).shape == (0, 1)
+    pu, pi = np.array([0, 1, 2], dtype=np.int64), np.array([6, 7, 8], dtype=np.int64)
+    got = model.predict(_Seq([((pu, pi), None)]))
+    want = om.basic_gnn_scores(adj, helpers.gnn_to_oracle(model.gnn), helpers.basic_head_to_oracle(model.rs), pu, pi, dtype=np.float64)
+    assert np.abs(got - want).max() < 1e-5
+    empty = metrics.top_k_predictions(np.zeros((0, 3)), np.arange(6), np.arange(6), k=5)
+    assert len(empty) == 0
+
+
+def test_topk_with_fewer_than_k_items_and_ties(hip):
+    """metrics.py:11-34: users with fewer than k scored items keep what they have; equal scores break on the item id."""
+    from deep_cbrs_amar_renaissance_amd.utilities import metrics
+    users, items = np.array([10, 20, 30]), np.array([7, 8, 9, 11])
+    pred = np.array([[0, 3, 0.5], [0, 4, 0.9], [0, 5, 0.5], [0, 6, 0.1],        # user 10: 4 items, a tie
+                     [1, 3, 0.2],                                                # user 20: one item
+                     [2, 6, 0.7], [2, 5, 0.7]])                                  # user 30: two tied items
+    top = metrics.top_k_predictions(pred, users, items, k=3)
+    got = [(int(a), int(b)) for a, b, _ in top.to_numpy().tolist()]
+    assert got == [(10, 8), (10, 7), (10, 9), (20, 7), (30, 9), (30, 11)]
+    assert np.allclose(top['scores'].to_numpy(), [0.9, 0.5, 0.5, 0.2, 0.7, 0.7], atol=1e-7)       # scores travel as fp32
+    ou, oi, _ = om.top_k(pred[:, 0].astype(int), pred[:, 1].astype(int), pred[:, 2], users, items, 3)
+    assert [(int(a), int(b)) for a, b in zip(ou, oi)] == got
+
+
+def test_training_batch_of_one_and_all_negative_labels(hip):
+    """fit() shapes the reference can produce: a last batch of a single rating, a batch whose labels are all 0."""
+    from deep_cbrs_amar_renaissance_amd import training
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    g = helpers.tiny_graph(n_users=30, n_items=20, n_ratings=300, seed=5)
+    model = basic.BasicGCN(g['adj'], **CFG)
+    trainer = training.Trainer(model)
+    loss1 = trainer.train_batch(g['u_ids'][:1], g['i_ids'][:1], np.array([1.0]))
+    loss0 = trainer.train_batch(g['u_ids'][:50], g['i_ids'][:50], np.zeros(50))
+    assert np.isfinite(loss1) and np.isfinite(loss0)
+    assert all(torch.isfinite(p).all() for p in model.parameters())

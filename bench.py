@@ -248,7 +248,13 @@ def main():
                                  'avg_launch_ms': pms, 'pairs_per_launch': pairs_local, 'bound': 'hbm',
                                  'algorithmic_bytes_per_launch': pair_alg, 'achieved': pair_alg / (pms * 1e-3) / 1e9,
                                  'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': pair_alg / (pms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                 'traffic': pair_traffic}
+                                 'traffic': pair_traffic,
+                                 # the same launch against the fp32 MFMA peak (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s dense)
+                                 'mfma': {'flop_per_pair': 2 * (c1 * GRID1['clf_units'][1] + GRID1['clf_units'][1]),
+                                          'achieved_tflops': pairs_local * 2 * (c1 * GRID1['clf_units'][1] + GRID1['clf_units'][1]) / (pms * 1e-3) / 1e12,
+                                          'peak_tflops': 157.3,
+                                          'frac': pairs_local * 2 * (c1 * GRID1['clf_units'][1] + GRID1['clf_units'][1]) / (pms * 1e-3) / 1e12 / 157.3,
+                                          'pmc_busy_frac': pmc.get('pair_stage_mfma_busy_frac') if pair_traffic is not None else None}}
         if world == 1 and not args.no_cpu_baseline:
             out['ml1m_s1'] = ml1m_true_size(dev)
             out['cpu_baseline'] = cpu_baseline()

@@ -325,4 +325,25 @@ def _csr_xcd_sliced(self):
     return self.__dict__['_xs_cache']
 
 
+def _csr_xcd_sliced_mean(self, self_loops=True):
+    """XS image of an edge-list CSR (no values, duplicates kept, no diagonal) as GraphSAGE's mean aggregate:
+    value-free entries, diag = 1 for the added self loop, row_scale = 1 / count (0 for an empty segment); the gathered
+    table is NOT pre-scaled (call capi.spmm_xs with prescaled=True)."""
+    key = '_xs_mean_cache_{}'.format(int(bool(self_loops)))
+    if key not in self.__dict__:
+        if self.vals is not None:
+            raise ValueError("the mean-aggregate image is built from an edge-list CSR (vals None)")
+        xs = XcdSliced.from_csr(self)                              # valued image of ones, zero diagonal
+        deg = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.float32)
+        if self_loops:
+            xs.diag = xs.diag + 1.0
+            inv = 1.0 / (deg + 1.0)
+        else:
+            inv = torch.where(deg > 0, 1.0 / deg.clamp(min=1.0), torch.zeros_like(deg))
+        xs.vals, xs.row_scale, xs.col_scale = None, inv.contiguous(), None
+        self.__dict__[key] = xs
+    return self.__dict__[key]
+
+
 DeviceCSR.xcd_sliced = _csr_xcd_sliced
+DeviceCSR.xcd_sliced_mean = _csr_xcd_sliced_mean

@@ -353,6 +353,17 @@ def test_spmm_kinds_agree_on_models(hip, monkeypatch):
             monkeypatch.setenv('AMAR_SPMM_KIND', kind)
             e_k = model.gnn(None).cpu().numpy()
             assert rel_err(e_k, e_csr.astype(np.float64)) < 2e-6
+    # GraphSAGE: fused row kernel vs mean aggregate on the XCD-sliced value-free image + dense + l2-normalise
+    for loops in (True, False):
+        model = basic.BasicGraphSage(g['adj'], embedding_dim=8, n_hiddens=[8, 16], n_layers=2, dense_units=[24, 24], clf_units=[48])
+        for layer in model.gnn.gnn_layers.seq_layers:
+            layer.self_loops = loops
+        helpers.randomize_biases(model, seed=2)
+        monkeypatch.setenv('AMAR_SPMM_KIND', 'csr')
+        e_row = model.gnn(None).cpu().numpy()
+        monkeypatch.setenv('AMAR_SPMM_KIND', 'xs')
+        e_xs = model.gnn(None).cpu().numpy()
+        assert rel_err(e_xs, e_row.astype(np.float64)) < 3e-6
     # a device-built adjacency (factors known) takes the value-free XS image and the pre-scaled fused GCN chain
     from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter_device
     coo = g['adj'].tocoo()

@@ -243,7 +243,7 @@ class PartitionedGCNRunner:
         forced = os.environ.get('AMAR_SPMM_KIND')
         if forced in ('csr', 'xs'):
             return forced == 'xs'
-        return self.world * self.part.R * width * 4 >= (16 << 20)
+        return self.world * self.part.R * width * 4 >= ((8 << 20) if width <= 8 else (16 << 20))
 
     def _mean_scale(self, n_rows, n_terms, dev):
         if getattr(self, '_mean', None) is None or self._mean.numel() != n_rows:

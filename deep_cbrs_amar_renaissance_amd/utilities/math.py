@@ -213,9 +213,12 @@ def spmm_kind(a, F):
     forced = os.environ.get('AMAR_SPMM_KIND')
     if forced in ('csr', 'sj', 'xs'):
         return forced
-    # measured (profiles/): at ml1m(s=64) XS beats the row-streaming form 1.28x at F=8 and 1.24x at F=16 and loses at F=32
-    # (its per-step scan is amortised over only 64/(F/4) entries); at s=16 (table 4.7-9.4 MB) the row form still wins
-    return 'xs' if (a.shape[0] == a.shape[1] and F <= 16 and a.shape[1] * F * 4 >= (16 << 20)) else 'csr'
+    # measured (tools/profile_step.py, value-free image): F=8: row form 0.094 / XS 0.117 ms at s=16 (4.7 MB table), 0.224 / 0.192 ms
+    # at s=32 (9.4 MB), 0.62 / 0.38 ms at s=64; F=16: 0.127 / 0.169 ms at 9.4 MB, 0.319 / 0.281 ms at 18.9 MB; XS loses at F=32
+    # (its scan is amortised over only 64/(F/4) lanes' worth of entries)
+    table_bytes = a.shape[1] * F * 4
+    big = table_bytes >= ((8 << 20) if F <= 8 else (16 << 20))
+    return 'xs' if (a.shape[0] == a.shape[1] and F <= 16 and big) else 'csr'
 
 
 def _csr_sliced(self, F):

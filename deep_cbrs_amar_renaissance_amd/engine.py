@@ -42,7 +42,7 @@ def glorot_uniform(shape, rng=None):
 
 
 class L2:
-    """keras.regularizers.l2 stand-in: only carries the factor (training is out of scope)."""
+    """keras.regularizers.l2 stand-in: carries the factor; training.py adds l2 * sum(w^2) to the loss / 2 l2 w to the gradient."""
     def __init__(self, l2=0.01):
         self.l2 = float(l2)
 
@@ -140,8 +140,8 @@ class Model(Layer):
 
     def fit(self, *args, **kwargs):
         raise NotImplementedError(
-            "training (BCE + Adam backward pass) is the next scope row (SURVEY.md §8f N1); "
-            "this build implements the forward / scoring path")
+            "fit() is implemented by the Basic* / HybridBert* GNN models (training.py: BCE + L2 + Adam reverse pass); "
+            "{} has no training path".format(type(self).__name__))
 
     # -- inference ---------------------------------------------------------------------------
     def _predict_batches(self, sequence):

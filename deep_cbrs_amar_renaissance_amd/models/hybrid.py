@@ -5,11 +5,13 @@
     ug -> dense1a, ig -> dense1b, ub -> dense2a, ib -> dense2b
     feature_based:  x1 = dense3a([ug || ig]),  x2 = dense3b([ub || ib])
     entity based:   x1 = dense3a([ug || ub]),  x2 = dense3b([ig || ib])
-    out = clf([x1 || x2])
+    x = fuse2([x1, x2]);  out = clf(x)   or, with residual=True,   clf(act(residual(x) + x1 + x2))
 
-with FusionLayer('concatenate') everywhere (the only setting of the BASELINE configs);
-'attention' fusion and residual heads are out of scope.  ``HybridBertGNN`` = propagation ->
-lookup -> HybridCBRS; the factory generates ``HybridBert{GCN,GAT,GraphSage,LightGCN}``.
+FusionLayer('concatenate') everywhere is the setting of the BASELINE configs and the one with the fused pair-stage
+kernels (folded first layers, `amar_dual_chain_f32`); 'attention' fusion (fuse2 when feature based, fuse1a/1b
+otherwise) and the residual classifier (`hybrid-gnn-tweaks*.yaml`) run on per-branch chains + the mix / add
+kernels.  ``HybridBertGNN`` = propagation -> lookup -> HybridCBRS; the factory generates
+``HybridBert{GCN,GAT,GraphSage,LightGCN,DGCF}``.
 
 The BERT blocks may be given per batch ([B, 768] host arrays, as the reference's Sequence
 does, `datasets.py:65-66`) or as a resident table + ids (``bert_table``), which removes the

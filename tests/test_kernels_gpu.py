@@ -476,6 +476,27 @@ def test_spmm_xcd_sliced_value_free(hip, F, uip, monkeypatch):
     assert rel_err(y1.cpu().numpy(), w1) < 2e-6 and rel_err(y2.cpu().numpy(), want2) < 3e-6
 
 
+@pytest.mark.parametrize('F', [4, 8, 16, 32])
+@pytest.mark.parametrize('n,avg_deg,seed', [(300, 160, 1), (513, 260, 2), (200, 40, 3), (1030, 520, 4)])
+def test_spmm_xcd_sliced_dense_tiles(hip, F, n, avg_deg, seed):
+    """Tiles far longer than one super-step (64 lanes x 8 entries), tile lengths on and around its multiples, rows that are
+    empty in some slices and very long in others: the full-step path, the clamped last step and the run bookkeeping."""
+    from deep_cbrs_amar_renaissance_amd.utilities.math import XcdSliced
+    m = _rand_csr(n, avg_deg, seed=seed, dup=(seed == 3)).tocoo()
+    a = _dev_csr(m)
+    xs = XcdSliced.from_csr(a)
+    tile = (xs.rowptr[64::64].long() - xs.rowptr[:-64:64].long())
+    assert int(tile.max()) > 256, "this case is meant to exceed one super-step"
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((n, F)).astype(np.float32)
+    y = torch.full((n, F), float('nan'), device=DEV)
+    hip.spmm_xs(xs, _t(x), y)
+    assert rel_err(y.cpu().numpy(), m.tocsr().astype(np.float64) @ x.astype(np.float64)) < 3e-6
+    ycsr = torch.empty((n, F), device=DEV)
+    hip.spmm_csr(a.rowptr, a.colidx, a.vals, _t(x), ycsr)
+    assert rel_err(y.cpu().numpy(), ycsr.cpu().numpy().astype(np.float64)) < 3e-6
+
+
 def test_spmm_xcd_sliced_is_reproducible(hip):
     """LDS float adds inside the XS partial kernel follow a fixed order: two launches give the same bits."""
     from deep_cbrs_amar_renaissance_amd.utilities.math import XcdSliced

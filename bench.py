@@ -184,6 +184,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         runner.step()
+    host_dt = time.perf_counter() - t0                        # time to ENQUEUE the steps (host-side launch cost)
     barrier()
     dt = time.perf_counter() - t0
     capi.gcn_layer, capi.spmm_sj, capi.spmm_xs = raw_gcn_layer, raw_spmm_sj, raw_spmm_xs
@@ -231,6 +232,7 @@ def main():
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': avg_ms,
                          'launches_timed': len(spmm_ms)},
             'propagation_ms': runner.last_propagation_ms(),
+            'host_enqueue_ms_per_step': 1e3 * host_dt / args.steps,
         }
         pair_ms = [e0.elapsed_time(e1) for e0, e1 in pair_events]
         if pair_ms:

@@ -698,6 +698,188 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void gat_row_kernel(co
     }
 }
 
+
+// ---- GAT on the XCD-sliced image (large graphs) ----------------------------------------------------------------
+// Same tiling as spmm_xs_*: workgroup b works on column slice b % S, a wave on one (64-row block, slice) tile, a lane on
+// EPL consecutive entries.  The gathered table is G = C + 4 floats wide per node: [ h_j (C) | s_neigh_j | 0 0 0 ] (48-byte
+// rows for C = 8: the 28 MB table of ml1m(s=64) still fits the eight L2s slice by slice), so one L2 request serves the row
+// AND the neighbour scalar (a quarter of the rows straddle two lines).  The softmax is kept exact with the "online" form: every partial
+// result is a triple (m, l, o) = (running max of e, sum exp(e - m), sum exp(e - m) h_j), and two triples of one row merge as
+//     M = max(m1, m2);  l = l1 exp(m1 - M) + l2 exp(m2 - M);  o = o1 exp(m1 - M) + o2 exp(m2 - M).
+// In-lane serial merge over the lane's entries, ONE cross-lane segmented scan with that operator (EPS = 16: one DPP row),
+// then the run-end lane merges into the wave's LDS accumulator (plain read-modify-write: a row is touched by at most one
+// lane group per LDS instruction, and LDS instructions of a wave stay in order).  Per (slice, row) the kernel leaves
+// (o, m, l); the combine kernel merges the slices with the self loop, divides by (l + 1e-9), adds the bias, applies ReLU.
+struct GatXsArgs {
+    const int32_t *rowptr; const int32_t *colidx; const float *HT; const float *s_self; float *P;
+    int n_rows; int n_slices; int blocks_per_slice; bool off32;
+};
+
+struct Soft4 { float m; float l; float4 o; };
+
+// One of the two rescale factors is always exp(0) = 1: a single exp(-|m1 - m2|) serves the merge (v_exp_f32 form; both
+// maxima -inf means both sides are empty and the factor is moot).
+__device__ __forceinline__ void soft_merge(Soft4 &a, float m2, float l2, const float4 &o2) {    // a <- a (+) (m2, l2, o2)
+    const float M = fmaxf(a.m, m2);
+    const float t = (a.m == m2) ? 1.f : __expf(-fabsf(a.m - m2));
+    const float ea = a.m >= m2 ? 1.f : t, eb = a.m >= m2 ? t : 1.f;
+    a.l = a.l * ea + l2 * eb;
+    a.o = make_float4(a.o.x * ea + o2.x * eb, a.o.y * ea + o2.y * eb, a.o.z * ea + o2.z * eb, a.o.w * ea + o2.w * eb);
+    a.m = M;
+}
+
+template <int CTRL>
+__device__ __forceinline__ void soft_scan_level(Soft4 &st, int key) {
+    const int kprev = __builtin_amdgcn_update_dpp(-1, key, CTRL, 0xF, 0xF, false);
+    const float mp = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, st.m), CTRL, 0xF, 0xF, false));
+    const float lp = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, st.l), CTRL, 0xF, 0xF, false));
+    float4 op;
+    op.x = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, st.o.x), CTRL, 0xF, 0xF, false));
+    op.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, st.o.y), CTRL, 0xF, 0xF, false));
+    op.z = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, st.o.z), CTRL, 0xF, 0xF, false));
+    op.w = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, st.o.w), CTRL, 0xF, 0xF, false));
+    if (kprev == key) soft_merge(st, mp, lp, op);          // lanes without a source got key -1: no merge
+}
+
+template <int C, bool OFF32>
+__global__ __launch_bounds__(XS_WAVES * AMAR_WAVE) void gat_xs_partial_kernel(const GatXsArgs a) {
+    constexpr int G = C + 4, EPS = 16, EPL = 8, SUPER = EPS * EPL, QH = C / 4;   // QH quads carry h, quad QH carries s_neigh; lanes of quad 3 idle
+    static_assert(C == 8 && EPS == 16, "the cross-lane scan below covers exactly one 16-lane DPP row per feature quad (C = 8)");
+    constexpr int PAD_KEY = AMAR_WAVE;
+    __shared__ float lds_o[XS_WAVES][C * AMAR_WAVE];
+    __shared__ float lds_ml[XS_WAVES][3 * AMAR_WAVE];              // m, l, and the tile's s_self
+    const int lane = threadIdx.x & (AMAR_WAVE - 1), wv = threadIdx.x >> 6;
+    const int k = blockIdx.x % a.n_slices;
+    const int chunk = blockIdx.x / a.n_slices;
+    const int r0 = __builtin_amdgcn_readfirstlane((chunk * XS_WAVES + wv) * AMAR_WAVE);
+    if (r0 >= a.n_rows) return;
+    const int nr = min(AMAR_WAVE, a.n_rows - r0);
+    const int32_t *rp = a.rowptr + (int64_t)k * a.n_rows + r0;
+    const int beg = rp[0], end = rp[nr];
+    if (beg == end) return;
+    float *acc_o = lds_o[wv], *acc_m = lds_ml[wv], *acc_l = lds_ml[wv] + AMAR_WAVE, *srow = lds_ml[wv] + 2 * AMAR_WAVE;
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc_o[c * AMAR_WAVE + lane] = 0.f;
+    acc_m[lane] = -INFINITY; acc_l[lane] = 0.f;
+    srow[lane] = lane < nr ? a.s_self[r0 + lane] : 0.f;
+    const int q = lane / EPS, s = lane % EPS;
+    const int n_tile = end - beg;
+    const char *cbase = reinterpret_cast<const char *>(a.colidx + beg);
+
+    auto flush = [&](int key, const Soft4 &st) {                     // merge a finished run into the wave's accumulator row
+        if (q >= QH) return;                                         // the scalar / padding quads carry no output features
+        Soft4 cur;
+        cur.m = acc_m[key]; cur.l = acc_l[key];
+        cur.o = make_float4(acc_o[(4 * q + 0) * AMAR_WAVE + key], acc_o[(4 * q + 1) * AMAR_WAVE + key],
+                            acc_o[(4 * q + 2) * AMAR_WAVE + key], acc_o[(4 * q + 3) * AMAR_WAVE + key]);
+        soft_merge(cur, st.m, st.l, st.o);
+        acc_o[(4 * q + 0) * AMAR_WAVE + key] = cur.o.x; acc_o[(4 * q + 1) * AMAR_WAVE + key] = cur.o.y;
+        acc_o[(4 * q + 2) * AMAR_WAVE + key] = cur.o.z; acc_o[(4 * q + 3) * AMAR_WAVE + key] = cur.o.w;
+        if (q == QH - 1) { acc_m[key] = cur.m; acc_l[key] = cur.l; }  // after every quad of this entry read the old (m, l): same instruction order for all
+    };
+
+    for (int t0 = 0; t0 < n_tile; t0 += SUPER) {
+        const int first = t0 + s * EPL;
+        int cw[EPL], key[EPL];
+        float4 x[EPL];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const unsigned off = (unsigned)max(min(first + j, n_tile - 1), 0) * 4u;
+            cw[j] = __builtin_nontemporal_load(reinterpret_cast<const int32_t *>(cbase + off));
+            key[j] = first + j < n_tile ? (int)((unsigned)cw[j] >> 26) : PAD_KEY;
+        }
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            const unsigned col = (unsigned)cw[j] & 0x3ffffffu;
+            x[j] = f4_zero();
+            if (q <= QH) {
+                if (OFF32) x[j] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.HT) + (col * (unsigned)G + 4u * q) * 4u);
+                else x[j] = *reinterpret_cast<const float4 *>(a.HT + (int64_t)col * G + 4 * q);
+            }
+        }
+        Soft4 st;
+        int kcur = PAD_KEY;
+        st.m = -INFINITY; st.l = 0.f; st.o = f4_zero();
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) {
+            // the neighbour scalar sits in quad QH's first float: lanes (q, s) read it from lane (QH, s)
+            const float tj = __shfl(x[j].x, QH * EPS + s, AMAR_WAVE);
+            const int kj = key[j];
+            if (j > 0 && kj != kcur && kcur != PAD_KEY) flush(kcur, st);
+            if (kj != kcur) { st.m = -INFINITY; st.l = 0.f; st.o = f4_zero(); kcur = kj; }
+            if (kj != PAD_KEY) {
+                const float pre = srow[kj] + tj;
+                const float e = pre > 0.f ? pre : 0.2f * pre;
+                soft_merge(st, e, 1.f, x[j]);
+            }
+        }
+        // one segmented scan over the 16 lanes of the quad's DPP row (row_shr:1, 2, 4, 8), keyed by the lane's last key
+        soft_scan_level<0x111>(st, kcur); soft_scan_level<0x112>(st, kcur);
+        soft_scan_level<0x114>(st, kcur); soft_scan_level<0x118>(st, kcur);
+        const int knext = __builtin_amdgcn_mov_dpp(kcur, 0x130, 0xF, 0xF, true);
+        if (kcur != PAD_KEY && (s == EPS - 1 || knext != kcur)) flush(kcur, st);
+    }
+    if (lane < nr) {                                                  // P[slice][row] = (o[0..C), m, l, unused...)
+        float *out = a.P + ((int64_t)k * a.n_rows + r0 + lane) * G;
+#pragma unroll
+        for (int c = 0; c < C; ++c) out[c] = acc_o[c * AMAR_WAVE + lane];
+        out[C] = acc_m[lane]; out[C + 1] = acc_l[lane];
+    }
+}
+
+struct GatXsCombineArgs {
+    const float *P; const int32_t *rowptr; const float *HT; const float *s_self; const float *bias; float *Y; int64_t ldy;
+    int n_rows; int n_slices; int self_loop;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void gat_xs_combine_kernel(const GatXsCombineArgs a) {
+    constexpr int G = C + 4;
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    if (row >= a.n_rows) return;
+    float m = -INFINITY, l = 0.f, o[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) o[c] = 0.f;
+    auto merge = [&](float m2, float l2, const float *o2) {
+        const float M = fmaxf(m, m2);
+        const float t = (m == m2) ? 1.f : __expf(-fabsf(m - m2));
+        const float ea = m >= m2 ? 1.f : t, eb = m >= m2 ? t : 1.f;
+        l = l * ea + l2 * eb;
+#pragma unroll
+        for (int c = 0; c < C; ++c) o[c] = o[c] * ea + o2[c] * eb;
+        m = M;
+    };
+    const float *own = a.HT + (int64_t)row * G;
+    if (a.self_loop) {
+        const float pre = a.s_self[row] + own[C];
+        merge(pre > 0.f ? pre : 0.2f * pre, 1.f, own);
+    }
+    const int w0 = __builtin_amdgcn_readfirstlane(row & ~(AMAR_WAVE - 1));
+    const int w1 = min(w0 + AMAR_WAVE, a.n_rows);
+    for (int k = 0; k < a.n_slices; ++k) {
+        const int32_t *rp = a.rowptr + (int64_t)k * a.n_rows;
+        if (rp[w0] == rp[w1]) continue;                              // the partial kernel wrote nothing for this (block, slice)
+        const float *p = a.P + ((int64_t)k * a.n_rows + row) * G;
+        if (p[C + 1] > 0.f) merge(p[C], p[C + 1], p);
+    }
+    const float inv = 1.f / (l + 1e-9f);
+    float *y = a.Y + (int64_t)row * a.ldy;
+#pragma unroll
+    for (int c = 0; c < C; ++c) y[c] = fmaxf(o[c] * inv + a.bias[c], 0.f);
+}
+
+// [ H (C) | s_neigh | 0 0 0 ] rows of C + 4 floats: what the partial kernel gathers
+__global__ __launch_bounds__(256) void gat_pack_kernel(const float *__restrict__ H, int64_t ldh, const float *__restrict__ s_neigh,
+                                                       float *__restrict__ HT, int n, int C) {
+    const int G = C + 4;
+    const int64_t total = (int64_t)n * G;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / G;
+        const int c = (int)(i - r * G);
+        HT[i] = c < C ? H[r * ldh + c] : (c == C ? s_neigh[r] : 0.f);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -813,6 +995,28 @@ int amar_gat_layer_f32(const int32_t *rowptr, const int32_t *colidx,
     case 64: hipLaunchKernelGGL(gat_row_kernel<64>, grid, block, 0, st, a); break;
     default: return AMAR_EUNSUPPORTED;
     }
+    return amar_check_launch();
+}
+
+int amar_gat_xs_f32(const int32_t *rowptr, const int32_t *colidx, int32_t n_slices,
+                    const float *H, int64_t ldh, int32_t C, const float *s_self, const float *s_neigh, const float *bias,
+                    float *packed, float *partials, float *Y, int64_t ldy, int32_t self_loop, int32_t n_rows,
+                    amar_stream_t stream) {
+    if (n_rows < 0 || n_slices < 1 || !rowptr || !H || !s_self || !s_neigh || !bias || !packed || !partials || !Y) return AMAR_EINVAL;
+    if (ldh < C || ldy < C || !amar_aligned16(packed) || !amar_aligned16(partials)) return AMAR_EINVAL;
+    if (C != 8) return AMAR_EUNSUPPORTED;                               // 16 lanes per feature quad = one DPP row
+    if (n_rows == 0) return AMAR_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)n_rows * (C + 4);
+    hipLaunchKernelGGL(gat_pack_kernel, dim3((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256)), dim3(256), 0, st,
+                       H, ldh, s_neigh, packed, n_rows, C);
+    GatXsArgs pa{rowptr, colidx, packed, s_self, partials, n_rows, n_slices,
+                 (n_rows + XS_WAVES * AMAR_WAVE - 1) / (XS_WAVES * AMAR_WAVE), (int64_t)n_rows * (C + 4) * 4 < (int64_t(1) << 32)};
+    const dim3 pgrid((unsigned)(pa.blocks_per_slice * pa.n_slices)), block(XS_WAVES * AMAR_WAVE);
+    if (pa.off32) hipLaunchKernelGGL((gat_xs_partial_kernel<8, true>), pgrid, block, 0, st, pa);
+    else hipLaunchKernelGGL((gat_xs_partial_kernel<8, false>), pgrid, block, 0, st, pa);
+    GatXsCombineArgs ca{partials, rowptr, packed, s_self, bias, Y, ldy, n_rows, n_slices, self_loop ? 1 : 0};
+    hipLaunchKernelGGL((gat_xs_combine_kernel<8>), dim3((n_rows + 255) / 256), dim3(256), 0, st, ca);
     return amar_check_launch();
 }
 

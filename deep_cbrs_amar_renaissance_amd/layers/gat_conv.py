@@ -9,12 +9,15 @@ dropout_rate=0.0, add_self_loops=True:
     X'_i  = act( sum_j alpha_ij H_j + b )
 
 On the device: `amar_rowwise_xw_f32` (H and the two attention scalars per node) followed by
-`amar_gat_layer_f32` (two passes over the row: max of the neighbour scalars, then the weighted sum).
+`amar_gat_layer_f32` (two passes over the row: max of the neighbour scalars, then the weighted sum); on graphs whose
+node table exceeds the per-XCD L2s, `amar_gat_xs_f32` (XCD-sliced image, exact online softmax over (max, sum, weighted
+sum) triples).
 """
 import torch
 
 from deep_cbrs_amar_renaissance_amd import capi
 from deep_cbrs_amar_renaissance_amd.engine import Layer
+from deep_cbrs_amar_renaissance_amd.utilities.math import spmm_kind
 
 
 class GATConv(Layer):
@@ -51,5 +54,8 @@ class GATConv(Layer):
                         a_neigh=self.attn_kernel_neighs.view(c), s_self=s_self, s_neigh=s_neigh)
         if out is None:
             out = torch.empty((n, c), dtype=torch.float32, device=x.device)
-        capi.gat_layer(a.rowptr, a.colidx, h, s_self, s_neigh, self.bias, out, self_loop=self.add_self_loops)
+        if c == 8 and spmm_kind(a, c) == 'xs':                 # large graphs: XCD-sliced form, exact online softmax
+            capi.gat_xs(a.xcd_sliced(), h, s_self, s_neigh, self.bias, out, self_loop=self.add_self_loops)
+        else:
+            capi.gat_layer(a.rowptr, a.colidx, h, s_self, s_neigh, self.bias, out, self_loop=self.add_self_loops)
         return out

@@ -214,6 +214,17 @@ int amar_copy_columns_f32(const float *src, int64_t lds, const int32_t *ids, int
 int amar_reduce_layers_f32(const float *cat, int64_t ld, int32_t n_layers, int32_t width, float *out, int64_t ldo,
                            int64_t n_rows, int32_t mean, amar_stream_t stream);
 
+/* The same GAT layer on the XCD-sliced image of the (square) edge-list adjacency, for graphs whose node table exceeds the
+ * per-XCD L2s: rowptr / colidx as in amar_spmm_xs_f32 (values unused).  `packed` is scratch [n, C + 4] floats that the call
+ * fills with [ H | s_neigh | 0 0 0 ] rows (one L2 request then serves the neighbour's features and its scalar), `partials`
+ * scratch [n_slices, n, C + 4].  The segment softmax stays exact through (max, sum, weighted sum) triples merged per
+ * (row, slice) and across slices.  C = 8.
+ */
+int amar_gat_xs_f32(const int32_t *rowptr, const int32_t *colidx, int32_t n_slices,
+                    const float *H, int64_t ldh, int32_t C, const float *s_self, const float *s_neigh, const float *bias,
+                    float *packed, float *partials, float *Y, int64_t ldy, int32_t self_loop, int32_t n_rows,
+                    amar_stream_t stream);
+
 /* ---- hybrid-head variants of econfigs/hybrid-gnn-tweaks*.yaml -----------------------
  * amar_attention_mix_f32      FusionLayer('attention') (src/layers/fusion.py:54-68) after the two products
  *                             TA = A . att_weight, TB = B . att_weight (amar_dense_f32, no bias): the softmax over the two

@@ -364,6 +364,14 @@ def test_spmm_kinds_agree_on_models(hip, monkeypatch):
         monkeypatch.setenv('AMAR_SPMM_KIND', 'xs')
         e_xs = model.gnn(None).cpu().numpy()
         assert rel_err(e_xs, e_row.astype(np.float64)) < 3e-6
+    # GAT: row kernel vs XCD-sliced online-softmax form
+    model = basic.BasicGAT(g['adj'], embedding_dim=8, n_hiddens=[8, 8], n_layers=2, dense_units=[24, 24], clf_units=[48])
+    helpers.randomize_biases(model, seed=2)
+    monkeypatch.setenv('AMAR_SPMM_KIND', 'csr')
+    e_row = model.gnn(None).cpu().numpy()
+    monkeypatch.setenv('AMAR_SPMM_KIND', 'xs')
+    e_xs = model.gnn(None).cpu().numpy()
+    assert rel_err(e_xs, e_row.astype(np.float64)) < 3e-6
     # a device-built adjacency (factors known) takes the value-free XS image and the pre-scaled fused GCN chain
     from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter_device
     coo = g['adj'].tocoo()
@@ -495,6 +503,43 @@ def test_spmm_xcd_sliced_dense_tiles(hip, F, n, avg_deg, seed):
     ycsr = torch.empty((n, F), device=DEV)
     hip.spmm_csr(a.rowptr, a.colidx, a.vals, _t(x), ycsr)
     assert rel_err(y.cpu().numpy(), ycsr.cpu().numpy().astype(np.float64)) < 3e-6
+
+
+@pytest.mark.parametrize('n,avg_deg,seed,dup', [(67, 9, 1, False), (1000, 9, 2, True), (300, 160, 3, False), (1030, 400, 4, True), (4097, 20, 5, False)])
+@pytest.mark.parametrize('self_loop', [True, False])
+def test_gat_xcd_sliced(hip, n, avg_deg, seed, dup, self_loop):
+    """amar_gat_xs_f32 (XCD-sliced image, online softmax) against the row kernel and the dense float64 softmax, incl. tiles
+    longer than a super-step, duplicate edges, empty rows and widely spread attention scalars."""
+    from deep_cbrs_amar_renaissance_amd.utilities.math import XcdSliced
+    m = _rand_csr(n, avg_deg, seed=seed, dup=dup).tocoo()
+    keep = m.row != m.col
+    m = sparse.coo_matrix((m.data[keep], (m.row[keep], m.col[keep])), shape=m.shape)
+    a = _dev_csr(m, with_values=False)
+    xs = XcdSliced.from_csr(a)
+    rng = np.random.default_rng(seed)
+    C = 8
+    h = rng.standard_normal((n, C)).astype(np.float32)
+    ss = (rng.standard_normal(n) * 4).astype(np.float32)            # spread: exp() ranges over many decades
+    sn = (rng.standard_normal(n) * 4).astype(np.float32)
+    b = rng.uniform(-0.3, 0.3, C).astype(np.float32)
+    y_row, y_xs = torch.empty((n, C), device=DEV), torch.full((n, C), float('nan'), device=DEV)
+    hip.gat_layer(a.rowptr, a.colidx, _t(h), _t(ss), _t(sn), _t(b), y_row, self_loop=self_loop)
+    hip.gat_xs(xs, _t(h), _t(ss), _t(sn), _t(b), y_xs, self_loop=self_loop)
+    got = y_xs.cpu().numpy()
+    assert np.isfinite(got).all()
+    # dense float64 reference of the layer
+    rows, cols = m.row, m.col
+    if self_loop:
+        rows, cols = np.concatenate([rows, np.arange(n)]), np.concatenate([cols, np.arange(n)])
+    e = ss.astype(np.float64)[rows] + sn.astype(np.float64)[cols]
+    e = np.where(e > 0, e, 0.2 * e)
+    mx = np.full(n, -np.inf); np.maximum.at(mx, rows, e)
+    ex = np.exp(e - mx[rows])
+    den = np.zeros(n); np.add.at(den, rows, ex)
+    num = np.zeros((n, C)); np.add.at(num, rows, ex[:, None] * h.astype(np.float64)[cols])
+    want = np.maximum(num / (den + 1e-9)[:, None] + b, 0)
+    assert np.abs(got - want).max() < 2e-5 * max(1.0, np.abs(want).max())
+    assert np.abs(got - y_row.cpu().numpy()).max() < 2e-5 * max(1.0, np.abs(want).max())
 
 
 def test_spmm_xcd_sliced_is_reproducible(hip):

@@ -53,6 +53,12 @@ def main():
     t = timeit(lambda: capi.gat_layer(a.rowptr, a.colidx, h, ss, sn, b, y, self_loop=True))
     alg += nnz * 4
     print('gat_row_kernel<8>:  %.3f ms, %.0f MB algorithmic -> %.0f GB/s (%.1f %% of 8 TB/s)' % (t, alg / 1e6, alg / t / 1e6, alg / t / 1e6 / 80), flush=True)
+    y_row = y.clone()
+    xs_e = a.xcd_sliced()
+    capi.gat_xs(xs_e, h, ss, sn, b, y, self_loop=True)
+    print('  GAT XS form max |diff| vs row kernel: %.2e' % float((y - y_row).abs().max()))
+    t = timeit(lambda: capi.gat_xs(xs_e, h, ss, sn, b, y, self_loop=True))
+    print('gat on XS (pack + partial + combine): %.3f ms -> %.0f GB/s (%.1f %% of 8 TB/s)' % (t, alg / t / 1e6, alg / t / 1e6 / 80), flush=True)
     t = timeit(lambda: capi.spmm_csr(a.rowptr, a.colidx, None, x, y))
     print('value-free spmm_csr (stream kernel): %.3f ms' % t, flush=True)
 

@@ -126,7 +126,13 @@ def load_oracle_weights(model, gnn, head):
         if 'attn_self' in lw:
             put(layer.attn_kernel_self, lw['attn_self'])
             put(layer.attn_kernel_neighs, lw['attn_neigh'])
-    for name in ('unet', 'inet', 'clf'):
+        if 'w' in lw:
+            put(layer.w, lw['w'])
+    for name in head:
+        if name.startswith('fuse'):
+            for key, value in head[name].items():
+                put(getattr(getattr(model.rs, name), key), value)
+            continue
         for layer, (w, b) in zip(getattr(model.rs, name).layers, head[name]):
             put(layer.kernel, w)
             put(layer.bias, b)

@@ -359,6 +359,31 @@ def test_hip_path_reproduces_golden_vectors(hip, kind, cls, graph):
             assert np.array_equal(got_i, z['top{}_items'.format(kk)])
 
 
+@pytest.mark.parametrize('name', ['dgcf_uip', 'hybrid_attention', 'hybrid_residual', 'hybrid_entity-attention'])
+def test_hip_path_reproduces_extra_golden_vectors(hip, name):
+    """Committed fixtures of DGCF and the hybrid-gnn-tweaks heads through the HIP path."""
+    import os
+    from deep_cbrs_amar_renaissance_amd.models import basic, hybrid
+    from tests.test_oracle import load_extra_golden, GOLDEN
+    z, adj, gnn, head = load_extra_golden(os.path.join(GOLDEN, 'extra_{}.npz'.format(name)))
+    if name.startswith('dgcf'):
+        model = basic.BasicDGCF(adj, embedding_dim=8, n_layers=2, dense_units=[24, 24], clf_units=[48, 48])
+        model.rs.build_head(8, 8)
+        inputs = (z['u_ids'], z['i_ids'])
+    else:
+        model = hybrid.HybridBertGCN(adj, embedding_dim=8, n_hiddens=[8, 8], n_layers=2, dense_units=[[24, 16], [32, 24], [16, 16]],
+                                     clf_units=[24, 16], feature_based=bool(z['feature_based']),
+                                     fusion_method='attention' if 'attention' in name else 'concatenate', residual='residual' in name)
+        model.rs.build_head(model.gnn.output_dim(), 40)
+        model.set_bert_table(z['bert'])
+        inputs = (z['u_ids'], z['i_ids'], None, None)
+    helpers.load_oracle_weights(model, gnn, head)
+    scores = model(inputs).cpu().numpy()
+    assert np.abs(scores - z['scores_f64']).max() < 1e-5
+    if name.startswith('dgcf'):
+        assert helpers.rel_err(model.gnn(None).cpu().numpy(), z['emb_f64']) < 1e-5
+
+
 @pytest.mark.parametrize('feature_based', [True, False])
 def test_hybrid_hoisted_fused_head(hip, ml1m_s1, feature_based):
     """predict() on a hybrid model: per-entity towers with folded first layers + the fused two-branch kernel,

@@ -142,6 +142,35 @@ def _unflatten_net(z, prefix):
     return out
 
 
+def load_extra_golden(path):
+    """Fixtures of the families added later (DGCF, hybrid-gnn-tweaks heads): (z, adj, gnn weights, head weights)."""
+    z = np.load(path)
+    n = int(z['n'])
+    adj = sparse.coo_matrix((z['adj_data'], (z['adj_row'], z['adj_col'])), shape=(n, n))
+    kind = 'dgcf' if 'dgcf' in os.path.basename(path) else 'gcn'
+    gnn = _unflatten_gnn(z, kind)
+    if kind == 'dgcf':
+        gnn['final_node'] = 'mean'
+    head = {}
+    for name in sorted({key.split('.')[1] for key in z.files if key.startswith('head.')}):
+        if name.startswith('fuse'):
+            head[name] = {key.split('.')[-1]: z[key] for key in z.files if key.startswith('head.{}.'.format(name))}
+        else:
+            head[name] = _unflatten_net(z, 'head.' + name)
+    return z, adj, gnn, head
+
+
+@pytest.mark.parametrize('path', sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'extra_*.npz'))))
+def test_oracle_reproduces_extra_golden(path):
+    z, adj, gnn, head = load_extra_golden(path)
+    if gnn['kind'] == 'dgcf':
+        assert np.allclose(om.propagate(adj, gnn, np.float64), z['emb_f64'], rtol=0, atol=1e-15)
+        got = om.basic_gnn_scores(adj, gnn, head, z['u_ids'], z['i_ids'], np.float64)
+    else:
+        got = om.hybrid_gnn_scores(adj, gnn, head, z['u_ids'], z['i_ids'], z['bert'], np.float64, feature_based=bool(z['feature_based']))
+    assert np.allclose(got, z['scores_f64'], rtol=0, atol=1e-15)
+
+
 def load_golden(path):
     z = np.load(path)
     kind = os.path.basename(path).split('_')[1]

@@ -782,11 +782,19 @@ __global__ __launch_bounds__(XS_WAVES * AMAR_WAVE) void gat_xs_partial_kernel(co
         const int first = t0 + s * EPL;
         int cw[EPL], key[EPL];
         float4 x[EPL];
+        if (t0 + SUPER <= n_tile) {                                  // wave-uniform: a full super-step, the lane's words as 16-byte loads
+#pragma unroll                                                       // (8 separate clamped dword loads cost as much TA time as the gathers)
+            for (int j = 0; j < EPL; ++j) {
+                cw[j] = __builtin_nontemporal_load(reinterpret_cast<const int32_t *>(cbase + (unsigned)(first + j) * 4u));
+                key[j] = (int)((unsigned)cw[j] >> 26);
+            }
+        } else {
 #pragma unroll
-        for (int j = 0; j < EPL; ++j) {
-            const unsigned off = (unsigned)max(min(first + j, n_tile - 1), 0) * 4u;
-            cw[j] = __builtin_nontemporal_load(reinterpret_cast<const int32_t *>(cbase + off));
-            key[j] = first + j < n_tile ? (int)((unsigned)cw[j] >> 26) : PAD_KEY;
+            for (int j = 0; j < EPL; ++j) {
+                const unsigned off = (unsigned)max(min(first + j, n_tile - 1), 0) * 4u;
+                cw[j] = __builtin_nontemporal_load(reinterpret_cast<const int32_t *>(cbase + off));
+                key[j] = first + j < n_tile ? (int)((unsigned)cw[j] >> 26) : PAD_KEY;
+            }
         }
 #pragma unroll
         for (int j = 0; j < EPL; ++j) {

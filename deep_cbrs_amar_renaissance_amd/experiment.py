@@ -18,7 +18,6 @@ import argparse
 import copy
 import inspect
 import io
-import logging
 import os
 import re
 import traceback

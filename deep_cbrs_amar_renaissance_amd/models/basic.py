@@ -11,7 +11,6 @@ Device mapping: the lookup is fused into the first tower layer's load (`amar_den
 """
 import abc
 
-import numpy as np
 import torch
 
 from deep_cbrs_amar_renaissance_amd import capi

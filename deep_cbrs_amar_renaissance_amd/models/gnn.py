@@ -19,7 +19,7 @@ import abc
 import torch
 
 from deep_cbrs_amar_renaissance_amd import capi
-from deep_cbrs_amar_renaissance_amd.engine import Layer, Model, L2
+from deep_cbrs_amar_renaissance_amd.engine import Model, L2
 from deep_cbrs_amar_renaissance_amd.layers.gat_conv import GATConv
 from deep_cbrs_amar_renaissance_amd.layers.gcn_conv import GCNConv
 from deep_cbrs_amar_renaissance_amd.layers.dgcf_conv import DGCFConv

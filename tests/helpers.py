@@ -1,6 +1,5 @@
 """Shared test plumbing: synthetic graphs, and product-model -> oracle weight export."""
 import numpy as np
-from scipy import sparse
 
 
 def tiny_graph(n_users=40, n_items=30, n_ratings=400, seed=0, n_props=0, n_links=0):

@@ -9,11 +9,10 @@ KGE JSON ``{"ent_embeddings": [[...]]}`` indexed by raw id, BERT JSON
 Raw ids become contiguous indices in ascending raw-id order of the TRAIN file
 (``np.unique``), items offset by |U|, properties by |U|+|I| (`loaders.py:43-68`).
 """
-import json
-
 import numpy as np
 import pandas as pd
 
+from deep_cbrs_amar_renaissance_amd.data import jsonstream
 from deep_cbrs_amar_renaissance_amd.data.datasets import UserItemEmbeddings, HybridUserItemEmbeddings
 from deep_cbrs_amar_renaissance_amd.data.datasets import UserItemGraph, UserItemGraphEmbeddings
 from deep_cbrs_amar_renaissance_amd.data.preprocess import build_adjacency_matrix
@@ -81,26 +80,27 @@ def load_train_test_ratings(
 
 
 def json_load_graph_embeddings(filepath):
-    with open(filepath) as fp:
-        return json.load(fp)['ent_embeddings']
+    """The 'ent_embeddings' rows (loaders.py:85-95) as a float32 array, streamed (the files reach 5.5 GB of JSON text)."""
+    return jsonstream.stream_ent_embeddings(filepath)
 
 
 def json_load_bert_embeddings(filepath):
+    """DataFrame sorted by ID_OpenKE like the reference's (loaders.py:98-105); the loaders below stream instead."""
     return pd.read_json(filepath).sort_values(by=['ID_OpenKE'])
 
 
 def load_graph_user_item_embeddings(filepath, users, items):
     """[|U|+|I|, D] fp32: KGE rows of the users followed by those of the items (rows indexed by raw id)."""
-    table = np.array(json_load_graph_embeddings(filepath), dtype=np.float32)
+    table = json_load_graph_embeddings(filepath)
     return np.concatenate([table[users], table[items]], axis=0)
 
 
 def load_bert_user_item_embeddings(user_filepath, item_filepath, users, items):
     """[|U|+|I|, D] fp32: BERT rows of the users followed by those of the items (matched on ID_OpenKE)."""
     def rows(filepath, column, ids):
-        df = json_load_bert_embeddings(filepath)
-        known = df['ID_OpenKE'].to_numpy()
-        table = np.array(df[column].tolist(), dtype=np.float32)
+        known, table = jsonstream.stream_bert_records(filepath, column)
+        order = np.argsort(known, kind='stable')
+        known, table = known[order], table[order]
         return table[_lookup(known, ids, "BERT file " + filepath)]
     return np.concatenate([rows(user_filepath, 'profile_embedding', users),
                            rows(item_filepath, 'embedding', items)], axis=0)

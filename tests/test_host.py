@@ -172,3 +172,47 @@ def test_seed_reproducibility_and_glorot_limits():
     emb = a.gnn.gnn_layers.embeddings
     assert float(emb.abs().max()) <= np.sqrt(6 / (500 + 8)) and float(emb.abs().max()) > 0.9 * np.sqrt(6 / 508)
     assert all(float(p.abs().max()) == 0 for n, p in a.named_parameters() if n.endswith('bias'))
+
+
+def test_streaming_embedding_readers(tmp_path):
+    """data/jsonstream.py against json.load on the reference's two file formats (loaders.py:85-105), with chunk sizes small
+    enough that keys, rows and records straddle chunk boundaries."""
+    import json
+    from deep_cbrs_amar_renaissance_amd.data import jsonstream, loaders
+    rng = np.random.default_rng(0)
+    kge = rng.standard_normal((37, 12)).astype(np.float32)
+    kge[3, 4] = 1e-9
+    kge[5, 0] = -123456.75
+    doc = {'rel_embeddings': [[0.5, 1.5], [2.5, 3.5]], 'ent_embeddings': kge.astype(np.float64).tolist(), 'zz_after': [[9.0]]}
+    p_kge = tmp_path / 'kge.json'
+    p_kge.write_text(json.dumps(doc, indent=1))                       # newlines / indentation inside the rows
+    for chunk in (7, 64, 1000, 1 << 20):
+        got = jsonstream.stream_ent_embeddings(str(p_kge), chunk=chunk)
+        assert got.dtype == np.float32 and np.array_equal(got, kge)
+    (tmp_path / 'compact.json').write_text(json.dumps(doc, separators=(',', ':')))
+    assert np.array_equal(jsonstream.stream_ent_embeddings(str(tmp_path / 'compact.json'), chunk=13), kge)
+    with pytest.raises(KeyError):
+        jsonstream.stream_ent_embeddings(str(p_kge), key='missing')
+    (tmp_path / 'cut.json').write_text(json.dumps(doc)[:400])
+    with pytest.raises(ValueError):
+        jsonstream.stream_ent_embeddings(str(tmp_path / 'cut.json'))
+    # BERT records: unordered ids, extra fields, both column names
+    ids = rng.permutation(50)[:20] * 3 + 1
+    emb = rng.standard_normal((20, 9)).astype(np.float32)
+    records = [{'title': 'x [y] {z}', 'ID_OpenKE': int(i), 'embedding': e.astype(np.float64).tolist(), 'n': 1} for i, e in zip(ids, emb)]
+    p_bert = tmp_path / 'items.json'
+    p_bert.write_text(json.dumps(records, indent=2))
+    for chunk in (11, 300, 1 << 20):
+        got_ids, got = jsonstream.stream_bert_records(str(p_bert), 'embedding', chunk=chunk)
+        assert np.array_equal(got_ids, ids) and np.array_equal(got, emb)
+    users = [{'ID_OpenKE': int(i), 'profile_embedding': e.astype(np.float64).tolist()} for i, e in zip(ids, emb[::-1])]
+    (tmp_path / 'users.json').write_text(json.dumps(users))
+    want_ids = np.sort(ids)[:5]
+    table = loaders.load_bert_user_item_embeddings(str(tmp_path / 'users.json'), str(p_bert), want_ids, want_ids)
+    lookup = {int(i): k for k, i in enumerate(ids)}
+    assert np.array_equal(table[:5], emb[::-1][[lookup[int(i)] for i in want_ids]])
+    assert np.array_equal(table[5:], emb[[lookup[int(i)] for i in want_ids]])
+    assert np.array_equal(loaders.load_graph_user_item_embeddings(str(p_kge), [1, 2], [30, 36]), kge[[1, 2, 30, 36]])
+    (tmp_path / 'empty.json').write_text('[]')
+    e_ids, e_tab = jsonstream.stream_bert_records(str(tmp_path / 'empty.json'), 'embedding')
+    assert e_ids.size == 0 and e_tab.size == 0

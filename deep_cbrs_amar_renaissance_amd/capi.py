@@ -63,6 +63,8 @@ SIGNATURES = {
     'amar_adam_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _F32, _F32, _F32, _F32, _F32, _P]),
     'amar_adam_advance_f32': (ctypes.c_int, [_P, _F32, _F32, _F32, _P]),
     'amar_adam_dev_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _P, _F32, _F32, _F32, _F32, _P]),
+    'amar_adam_multi_f32': (ctypes.c_int, [_P, _I32, _I64, _P, _F32, _F32, _F32, _F32, _P, _P]),
+    'amar_sum_into_f32': (ctypes.c_int, [_P, _I64, _F32, _P, _P]),
     'amar_topk_segmented_f32': (ctypes.c_int, [_P, _P, _P, _I32, _I32, _P, _P, _P]),
 }
 
@@ -308,9 +310,13 @@ def gat_xs(xs, H, s_self, s_neigh, bias, Y, self_loop=True):
     _check(code, 'amar_gat_xs_f32')
 
 
-def dense(X, W, bias, Y, act='relu', ids=None):
-    """Y = act(X[ids] . W + bias). Y may be a column slice of a wider buffer (concatenation)."""
-    K, N = W.shape
+DENSE_WT = 0x100
+
+
+def dense(X, W, bias, Y, act='relu', ids=None, w_transposed=False):
+    """Y = act(X[ids] . W + bias). Y may be a column slice of a wider buffer (concatenation).
+    w_transposed: W holds the transpose ([N, K]), i.e. Y = X . W^T — the reverse pass' dX = dZ . W^T without a transpose launch."""
+    K, N = (W.shape[1], W.shape[0]) if w_transposed else W.shape
     M = ids.numel() if ids is not None else X.shape[0]
     if X.shape[1] != K or not W.is_contiguous() or tuple(Y.shape) != (M, N):
         raise ValueError("dense: X [*, K], W [K, N] contiguous, Y [M, N] expected")
@@ -319,7 +325,7 @@ def dense(X, W, bias, Y, act='relu', ids=None):
     code = load().amar_dense_f32(
         _ptr(X, torch.float32, 'X'), _ld(X, 'X'), _ptr(ids, torch.int32, 'ids'),
         _ptr(W, torch.float32, 'W'), _ptr(bias, torch.float32, 'bias'), _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y'),
-        M, K, N, ACT_CODES[act], _stream())
+        M, K, N, ACT_CODES[act] | (DENSE_WT if w_transposed else 0), _stream())
     _check(code, 'amar_dense_f32')
 
 
@@ -440,6 +446,38 @@ def adam_dev(w, g, m, v, state, beta_1, beta_2, epsilon, l2=0.0):
                                     _ptr(v, torch.float32, 'v'), w.numel(), _ptr(state, torch.float32, 'state'), float(beta_1),
                                     float(beta_2), float(epsilon), float(l2), _stream())
     _check(code, 'amar_adam_dev_f32')
+
+
+class AdamSlot(ctypes.Structure):
+    """include/amar_hip.h: amar_adam_slot"""
+    _fields_ = [('w', ctypes.c_void_p), ('g', ctypes.c_void_p), ('m', ctypes.c_void_p), ('v', ctypes.c_void_p),
+                ('n', ctypes.c_int64), ('first_block', ctypes.c_int64), ('l2', ctypes.c_float), ('pad_', ctypes.c_float)]
+
+
+def adam_slot_table(entries):
+    """entries: [(w, g, m, v, l2)] contiguous fp32 tensors -> (host uint8 tensor holding the slot table, total blocks)."""
+    table = (AdamSlot * len(entries))()
+    block = 0
+    for k, (w, g, m, v, l2) in enumerate(entries):
+        if not (w.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()) or \
+                not (w.numel() == g.numel() == m.numel() == v.numel()):
+            raise ValueError("adam_slot_table: contiguous tensors of equal size expected")
+        table[k] = AdamSlot(w.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), w.numel(), block, float(l2), 0.0)
+        block += (w.numel() + 1023) // 1024
+    host = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).clone()
+    return host, block
+
+
+def adam_multi(table_dev, n_slots, total_blocks, state, beta_1, beta_2, epsilon, reg_scale=0.0, loss_acc=None):
+    code = load().amar_adam_multi_f32(ctypes.c_void_p(table_dev.data_ptr()), n_slots, total_blocks, _ptr(state, torch.float32, 'state'),
+                                      float(beta_1), float(beta_2), float(epsilon), float(reg_scale),
+                                      _ptr(loss_acc, torch.float32, 'loss_acc'), _stream())
+    _check(code, 'amar_adam_multi_f32')
+
+
+def sum_into(x, acc, scale=1.0):
+    _check(load().amar_sum_into_f32(_ptr(x, torch.float32, 'x'), x.numel(), float(scale), _ptr(acc, torch.float32, 'acc'), _stream()),
+           'amar_sum_into_f32')
 
 
 def topk_segmented(seg_ptr, item_ids, scores, k):

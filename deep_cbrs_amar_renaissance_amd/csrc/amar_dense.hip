@@ -23,6 +23,7 @@ struct DenseArgs {
     const float *X; int64_t ldx; const int32_t *ids;
     const float *W; const float *bias; float *Y; int64_t ldy;
     int64_t M; int K; int N; int act;
+    int w_trans;                                   // W holds the transpose: element (k, n) of the product's B sits at W[n * K + k]
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -71,7 +72,10 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const DenseArgs a) {
         float wb[4];
         {
             const int k = k0 + wk, n = n0 + 4 * wq;
-            if (k < a.K && VEC_W && n + 3 < a.N) {
+            if (a.w_trans) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) wb[i] = (k < a.K && n + i < a.N) ? a.W[(int64_t)(n + i) * a.K + k] : 0.f;
+            } else if (k < a.K && VEC_W && n + 3 < a.N) {
                 const float4 v = *reinterpret_cast<const float4 *>(a.W + (int64_t)k * a.N + n);
                 wb[0] = v.x; wb[1] = v.y; wb[2] = v.z; wb[3] = v.w;
             } else {
@@ -167,11 +171,13 @@ int amar_dense_f32(const float *X, int64_t ldx, const int32_t *ids,
                    const float *W, const float *bias, float *Y, int64_t ldy,
                    int64_t M, int32_t K, int32_t N, int32_t act, amar_stream_t stream) {
     if (M < 0 || K < 1 || N < 1 || !X || !W || !Y || ldx < K || ldy < N) return AMAR_EINVAL;
+    const int w_trans = (act & AMAR_DENSE_WT) ? 1 : 0;
+    act &= ~AMAR_DENSE_WT;
     if (act != AMAR_ACT_NONE && act != AMAR_ACT_RELU && act != AMAR_ACT_SIGMOID) return AMAR_EINVAL;
     if (M == 0) return AMAR_OK;
     const int64_t gx = (M + BM - 1) / BM;
     if (gx > 0x7fffffffLL) return AMAR_EUNSUPPORTED;
-    DenseArgs a{X, ldx, ids, W, bias, Y, ldy, M, K, N, act};
+    DenseArgs a{X, ldx, ids, W, bias, Y, ldy, M, K, N, act, w_trans};
     const dim3 grid((unsigned)gx, (unsigned)((N + BN - 1) / BN)), block(256);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool vx = (ldx & 3) == 0 && amar_aligned16(X);

@@ -65,6 +65,21 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__res
     }
 }
 
+// the same for the weight and the bias partials of one wgrad call in ONE launch (elements [0, size_w) and [size_w, size_w + size_b))
+__global__ __launch_bounds__(256) void reduce_partials2_kernel(const float *__restrict__ part_w, int64_t size_w, float *__restrict__ out_w,
+                                                               const float *__restrict__ part_b, int64_t size_b, float *__restrict__ out_b,
+                                                               int n_chunks) {
+    const int64_t total = size_w + size_b;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const bool is_w = e < size_w;
+        const float *part = is_w ? part_w : part_b;
+        const int64_t size = is_w ? size_w : size_b, idx = is_w ? e : e - size_w;
+        float s = 0.f;
+        for (int c = 0; c < n_chunks; ++c) s += part[(int64_t)c * size + idx];
+        (is_w ? out_w : out_b)[idx] = s;
+    }
+}
+
 // Keras backend binary_crossentropy on probabilities: p clipped to [eps, 1-eps], log(p + eps); mean over the batch.
 __global__ __launch_bounds__(256) void bce_grad_kernel(const float *__restrict__ p, int64_t ldp, const float *__restrict__ y,
                                                        float *__restrict__ dz, float *__restrict__ loss_terms, int64_t B) {
@@ -384,6 +399,51 @@ __global__ __launch_bounds__(256) void add3_act_kernel(const float *__restrict__
     }
 }
 
+// Every parameter of a model in ONE launch: block b works on 1024 elements of the slot that owns it (slots carry their
+// first block).  Also adds reg_scale * l2 * sum(w^2) of the PRE-update weights to *loss_acc (the regularisation part of the
+// batch loss Keras reports), so no separate reduction launches are needed.
+__global__ __launch_bounds__(256) void adam_multi_kernel(const amar_adam_slot *__restrict__ slots, int n_slots,
+                                                         const float *__restrict__ state, float b1, float b2, float eps,
+                                                         float reg_scale, float *__restrict__ loss_acc) {
+    int sidx = 0;
+    while (sidx + 1 < n_slots && (int64_t)blockIdx.x >= slots[sidx + 1].first_block) ++sidx;
+    const amar_adam_slot sl = slots[sidx];
+    const float lr_t = state[1], l2x2 = 2.f * sl.l2;
+    const int64_t base = ((int64_t)blockIdx.x - sl.first_block) * 1024;
+    float sq = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int64_t i = base + r * 256 + threadIdx.x;
+        if (i < sl.n) {
+            const float wi = sl.w[i];
+            const float gi = sl.g[i] + l2x2 * wi;
+            const float mi = b1 * sl.m[i] + (1.f - b1) * gi;
+            const float vi = b2 * sl.v[i] + (1.f - b2) * gi * gi;
+            sl.m[i] = mi; sl.v[i] = vi;
+            sl.w[i] = wi - lr_t * mi / (sqrtf(vi) + eps);
+            sq = fmaf(wi, wi, sq);
+        }
+    }
+    if (loss_acc && sl.l2 != 0.f) {                                  // block sum, one atomic per block
+        __shared__ float red[4];
+        sq = wave_sum_stride<1>(sq);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(loss_acc, reg_scale * sl.l2 * (red[0] + red[1] + red[2] + red[3]));
+    }
+}
+
+// *acc += scale * sum(x[0..n))  — the batch's data loss into the running loss, one block
+__global__ __launch_bounds__(256) void sum_into_kernel(const float *__restrict__ x, int64_t n, float scale, float *__restrict__ acc) {
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += x[i];
+    __shared__ float red[4];
+    s = wave_sum_stride<1>(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) *acc += scale * (red[0] + red[1] + red[2] + red[3]);
+}
+
 unsigned grid1d(int64_t total) {
     int64_t b = (total + 255) / 256;
     return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
@@ -420,8 +480,10 @@ int amar_wgrad_f32(const float *X, int64_t ldx, const float *dZ, int64_t ldz, in
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)chunks, (unsigned)(dW ? (K + 15) / 16 : 1), (unsigned)((N + 15) / 16));
     hipLaunchKernelGGL(wgrad_partial_kernel, grid, dim3(256), 0, st, dW ? X : nullptr, ldx, dZ, ldz, M, Kk ? Kk : 1, N, part_w, part_b);
-    if (dW) hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid1d((int64_t)K * N)), dim3(256), 0, st, part_w, (int)chunks, (int64_t)K * N, dW);
-    if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid1d(N)), dim3(256), 0, st, part_b, (int)chunks, (int64_t)N, db);
+    if (dW && db) hipLaunchKernelGGL(reduce_partials2_kernel, dim3(grid1d((int64_t)K * N + N)), dim3(256), 0, st, part_w, (int64_t)K * N, dW,
+                                     part_b, (int64_t)N, db, (int)chunks);
+    else if (dW) hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid1d((int64_t)K * N)), dim3(256), 0, st, part_w, (int)chunks, (int64_t)K * N, dW);
+    else hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid1d(N)), dim3(256), 0, st, part_b, (int)chunks, (int64_t)N, db);
     return amar_check_launch();
 }
 
@@ -566,6 +628,21 @@ int amar_adam_dev_f32(float *w, const float *g, float *m, float *v, int64_t n, c
     if (n < 0 || !w || !g || !m || !v || !state) return AMAR_EINVAL;
     if (n == 0) return AMAR_OK;
     hipLaunchKernelGGL(adam_dev_kernel, dim3(grid1d(n)), dim3(256), 0, static_cast<hipStream_t>(stream), w, g, m, v, n, state, beta_1, beta_2, epsilon, 2.f * l2);
+    return amar_check_launch();
+}
+
+int amar_adam_multi_f32(const amar_adam_slot *slots, int32_t n_slots, int64_t total_blocks, const float *state, float beta_1,
+                        float beta_2, float epsilon, float reg_scale, float *loss_acc, amar_stream_t stream) {
+    if (!slots || n_slots < 1 || total_blocks < 1 || total_blocks > 0x7fffffff || !state) return AMAR_EINVAL;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream), slots, n_slots, state,
+                       beta_1, beta_2, epsilon, reg_scale, loss_acc);
+    return amar_check_launch();
+}
+
+int amar_sum_into_f32(const float *x, int64_t n, float scale, float *acc, amar_stream_t stream) {
+    if (n < 0 || !acc || (n > 0 && !x)) return AMAR_EINVAL;
+    if (n == 0) return AMAR_OK;
+    hipLaunchKernelGGL(sum_into_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), x, n, scale, acc);
     return amar_check_launch();
 }
 

@@ -79,7 +79,7 @@ class _DenseTape:
             if k == 0 and not need_input_grad:
                 return None
             dx = torch.empty((x.shape[0], layer.kernel.shape[0]), dtype=torch.float32, device=x.device)
-            capi.dense(dz, capi.transpose(layer.kernel.detach()), None, dx, act=None)
+            capi.dense(dz, layer.kernel.detach(), None, dx, act=None, w_transposed=True)
             dy = dx
         return dy
 
@@ -141,11 +141,10 @@ class _FusionTape:
         capi.wgrad(pb, d_tb, dw2, None)
         capi.add_inplace(dw, dw2)
         grads[f.att_weight] = dw
-        wt = capi.transpose(w)
         back = torch.empty_like(d_a)
-        capi.dense(d_ta, wt, None, back, act=None)
+        capi.dense(d_ta, w, None, back, act=None, w_transposed=True)
         capi.add_inplace(d_a, back)
-        capi.dense(d_tb, wt, None, back, act=None)
+        capi.dense(d_tb, w, None, back, act=None, w_transposed=True)
         capi.add_inplace(d_b, back)
         if f.proj_first is not None:                                 # the narrower block went through proj_weight first
             src, d_proj = (a, d_a) if f.proj_first else (b, d_b)
@@ -153,7 +152,7 @@ class _FusionTape:
             capi.wgrad(src, d_proj, dp, None)
             grads[f.proj_weight] = dp
             d_src = torch.empty((src.shape[0], src.shape[1]), dtype=torch.float32, device=src.device)
-            capi.dense(d_proj, capi.transpose(f.proj_weight.detach()), None, d_src, act=None)
+            capi.dense(d_proj, f.proj_weight.detach(), None, d_src, act=None, w_transposed=True)
             if f.proj_first:
                 d_a = d_src
             else:
@@ -318,15 +317,19 @@ class Trainer:
         g = self._g
         terms, grads = self._forward_backward(g['u'], g['i'], g['y'], (g['ub'], g['ib']) if g['ub'] is not None else None)
         capi.adam_advance(self._adam_state, self.lr, self.b1, self.b2)
-        for prm in self.params:
-            capi.adam_dev(prm.data.view(-1), grads[prm].contiguous().view(-1), self.m[prm].view(-1), self.v[prm].view(-1),
-                          self._adam_state, self.b1, self.b2, self.eps, l2=self._l2(prm))
-        loss = terms.sum() / float(g['u'].numel())
-        for prm in self.params:
-            l2 = self._l2(prm)
-            if l2:
-                loss = loss + l2 * (prm.detach() * prm.detach()).sum()
-        self._loss_sum += loss * float(g['u'].numel())
+        # one launch updates every parameter (a table of slots, uploaded by a captured copy from pinned memory: the
+        # gradient buffers of this graph have fixed addresses) and adds the regularisation loss; one more adds the data loss
+        entries = [(prm.data.view(-1), grads[prm].contiguous().view(-1), self.m[prm].view(-1), self.v[prm].view(-1), self._l2(prm))
+                   for prm in self.params]
+        host, blocks = capi.adam_slot_table(entries)
+        g['slot_host'][:host.numel()].copy_(host)                    # pinned buffer allocated before the capture began
+        g['slot_dev'] = torch.empty(host.numel(), dtype=torch.uint8, device=self._adam_state.device)
+        g['slot_dev'].copy_(g['slot_host'][:host.numel()], non_blocking=True)
+        g['keep'] = entries                                          # the slots point into these tensors
+        batch = float(g['u'].numel())
+        capi.sum_into(terms, self._loss_sum)                         # sum of the per-pair terms = data loss x batch size
+        capi.adam_multi(g['slot_dev'], len(entries), blocks, self._adam_state, self.b1, self.b2, self.eps,
+                        reg_scale=batch, loss_acc=self._loss_sum)
 
     def train_batch_graphed(self, u_ids, i_ids, y, bert=None):
         """One training batch replayed from a hipGraph: the forward, the reverse pass and the Adam update are ~100
@@ -352,6 +355,7 @@ class Trainer:
                            'y': torch.zeros(b, dtype=torch.float32, device=dev),
                            'ub': torch.zeros((b, d), dtype=torch.float32, device=dev) if with_blocks else None,
                            'ib': torch.zeros((b, d), dtype=torch.float32, device=dev) if with_blocks else None}
+            g['slot_host'] = torch.empty(64 * len(self.params) + 64, dtype=torch.uint8).pin_memory()   # >= sizeof(amar_adam_slot) per parameter
             torch.cuda.synchronize()
             g['graph'] = torch.cuda.CUDAGraph()
             with torch.no_grad(), torch.cuda.graph(g['graph']):
@@ -503,7 +507,7 @@ class Trainer:
             grads[layer.kernel], grads[layer.bias] = dw.view_as(layer.kernel), db
             grads[layer.attn_kernel_self], grads[layer.attn_kernel_neighs] = das.view_as(layer.attn_kernel_self), dan.view_as(layer.attn_kernel_neighs)
             back = torch.empty((n, f), dtype=torch.float32, device=dev)
-            capi.dense(dh, capi.transpose(w2d.contiguous()), None, back, act=None)
+            capi.dense(dh, w2d.contiguous(), None, back, act=None, w_transposed=True)
             capi.add_inplace(sl(de, k), back)
         g0 = torch.empty_like(seq.embeddings)
         capi.copy_columns(sl(de, 0), g0)
@@ -533,7 +537,7 @@ class Trainer:
                 capi.wgrad(xa, dz, dw, db)
                 grads[layer.kernel], grads[layer.bias] = dw, db
                 dxa = torch.empty((n, 2 * f), dtype=torch.float32, device=dev)
-                capi.dense(dz, capi.transpose(layer.kernel.detach()), None, dxa, act=None)
+                capi.dense(dz, layer.kernel.detach(), None, dxa, act=None, w_transposed=True)
                 capi.add_inplace(sl(de, k), dxa[:, :f])
                 g = torch.empty((n, f), dtype=torch.float32, device=dev)
                 capi.row_affine(dxa[:, f:], self.inv_cnt, g)               # d(mean)/d(sum)
@@ -562,7 +566,7 @@ class Trainer:
                 capi.wgrad(None, dzk, None, db)
                 grads[layer.kernel], grads[layer.bias] = dw, db
                 back = torch.empty((n, widths[k]), dtype=torch.float32, device=dev)
-                capi.rowwise_xw(dh, capi.transpose(layer.kernel.detach()), back)
+                capi.dense(dh, layer.kernel.detach(), None, back, act=None, w_transposed=True)
                 capi.add_inplace(sl(de, k), back)
             g0 = torch.empty_like(emb)
             capi.copy_columns(sl(de, 0), g0)

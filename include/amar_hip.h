@@ -33,6 +33,7 @@ extern "C" {
 #define AMAR_ACT_NONE     0
 #define AMAR_ACT_RELU     1
 #define AMAR_ACT_SIGMOID  2
+#define AMAR_DENSE_WT 0x100    /* amar_dense_f32, OR-ed into `act`: W is given transposed ([N, K] row-major), for dX = dZ . W^T */
 
 /* flags of amar_spmm_csr_f32 */
 #define AMAR_SPMM_BIAS      1u   /* y += bias[F]                                              */
@@ -306,6 +307,14 @@ int amar_transpose_f32(const float *src, int32_t K, int32_t N, float *dst, amar_
 int amar_adam_f32(float *w, const float *g, float *m, float *v, int64_t n, float lr_t, float beta_1, float beta_2,
                   float epsilon, float l2, amar_stream_t stream);
 int amar_adam_advance_f32(float *state, float learning_rate, float beta_1, float beta_2, amar_stream_t stream);
+/* All parameters of a model in one launch (a table of slots in device memory; slot k owns blocks [first_block_k,
+ * first_block_{k+1}) of 1024 elements each, first_block_0 = 0, total_blocks = sum of ceil(n / 1024)); the update of
+ * amar_adam_dev_f32.  If loss_acc != NULL, reg_scale * l2 * sum(w^2) of the pre-update weights is added to *loss_acc (the
+ * regularisation part of the loss Keras reports).  amar_sum_into_f32: *acc += scale * sum(x) (the data part). */
+typedef struct amar_adam_slot { float *w; const float *g; float *m; float *v; int64_t n; int64_t first_block; float l2; float pad_; } amar_adam_slot;
+int amar_adam_multi_f32(const amar_adam_slot *slots, int32_t n_slots, int64_t total_blocks, const float *state, float beta_1,
+                        float beta_2, float epsilon, float reg_scale, float *loss_acc, amar_stream_t stream);
+int amar_sum_into_f32(const float *x, int64_t n, float scale, float *acc, amar_stream_t stream);
 int amar_adam_dev_f32(float *w, const float *g, float *m, float *v, int64_t n, const float *state, float beta_1, float beta_2,
                       float epsilon, float l2, amar_stream_t stream);
 

@@ -60,6 +60,11 @@ class BasicRS(Model):
         towers = self.towers(u, i, u_ids=u_ids, i_ids=i_ids)
         return self.score_towers(towers, None, None)
 
+    def fit(self, sequence, epochs=1, **kwargs):
+        """Keras ``fit`` on pre-computed embedding rows (basic-kge / hybrid-kge configs): BCE + Adam on the Dense stacks."""
+        from deep_cbrs_amar_renaissance_amd import training
+        return training.fit(self, sequence, epochs=epochs, **kwargs)
+
     # The classifier's first Dense layer is linear in its concatenated input, [u || i] . W1 = u . W1[:d] + i . W1[d:],
     # so its two halves ride at the end of the towers (per entity when hoisted) and the pair stage starts at
     # act(T'u[u] + T'i[i] (+ b1, folded into T'i)): half the per-pair MFMA work of the classifier's first two layers.

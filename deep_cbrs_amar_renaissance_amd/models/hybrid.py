@@ -107,6 +107,11 @@ class HybridCBRS(Model):
                   self.dense2a.apply2(ub, ids_a=bu), self.dense2b.apply2(ib, ids_a=bi), False)
         return self.score_towers(towers, None, None)
 
+    def fit(self, sequence, epochs=1, **kwargs):
+        """Keras ``fit`` on pre-computed embedding rows (basic-kge / hybrid-kge configs): BCE + Adam on the Dense stacks."""
+        from deep_cbrs_amar_renaissance_amd import training
+        return training.fit(self, sequence, epochs=epochs, **kwargs)
+
     # As in BasicRS: dense3a / dense3b start with a Dense layer over a concatenation, which is linear in its two
     # halves — [a || b] . W = a . W[:da] + b . W[da:] — so each half is applied once per ENTITY at the end of the
     # corresponding first-stage network and the pair stage starts at act(A'[x] + B'[y]) (sum-input chain).

@@ -102,10 +102,11 @@ class _BasicHead:
         self.d = tu.shape[1]
         return self.clf.forward(_concat(tu, ti))
 
-    def backward(self, dz, grads):
-        """dz = dL/d(last pre-activation). Returns (dL/dE[u], dL/dE[i])."""
+    def backward(self, dz, grads, need_input_grad=True):
+        """dz = dL/d(last pre-activation). Returns (dL/dE[u], dL/dE[i]) (None, None when the inputs are constants)."""
         dcat = self.clf.backward(dz, grads, last_is_dz=True)
-        return self.unet.backward(dcat[:, :self.d], grads), self.inet.backward(dcat[:, self.d:], grads)
+        return (self.unet.backward(dcat[:, :self.d], grads, need_input_grad=need_input_grad),
+                self.inet.backward(dcat[:, self.d:], grads, need_input_grad=need_input_grad))
 
 
 class _FusionTape:
@@ -188,7 +189,7 @@ class _HybridHead:
             x = self.s
         return t['clf'].forward(x)
 
-    def backward(self, dz, grads):
+    def backward(self, dz, grads, need_input_grad=True):
         t = self.t
         dx = t['clf'].backward(dz, grads, last_is_dz=True)
         skip = None
@@ -209,7 +210,8 @@ class _HybridHead:
             (dg1, db1), (dg2, db2) = da, db
         t['dense2a'].backward(db1, grads, need_input_grad=False)
         t['dense2b'].backward(db2, grads, need_input_grad=False)
-        return t['dense1a'].backward(dg1, grads), t['dense1b'].backward(dg2, grads)
+        return (t['dense1a'].backward(dg1, grads, need_input_grad=need_input_grad),
+                t['dense1b'].backward(dg2, grads, need_input_grad=need_input_grad))
 
 
 class Trainer:
@@ -600,10 +602,66 @@ class Trainer:
         return loss
 
 
+class HeadTrainer(Trainer):
+    """BasicRS / HybridCBRS on pre-computed embedding rows (econfigs/basic-kge.yaml, hybrid-kge.yaml): the batch Sequence
+    delivers the rows themselves (datasets.py:43-77), so only the Dense stacks (and fusion weights) train."""
+
+    def __init__(self, model, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, **unused):
+        if not model.built:
+            raise ValueError("build the head first (one forward call, as Experimenter.build_model does)")
+        self.model = model
+        self.hybrid = hasattr(model, 'dense1a')
+        self.lr, self.b1, self.b2, self.eps = float(learning_rate), float(beta_1), float(beta_2), float(epsilon)
+        self.t = 0
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.m = {p: torch.zeros_like(p) for p in self.params}
+        self.v = {p: torch.zeros_like(p) for p in self.params}
+        self.head = _HybridHead(model) if self.hybrid else _BasicHead(model)
+
+    def loss_and_grads(self, blocks, y):
+        """blocks = (user rows, item rows) or (user graph, item graph, user BERT, item BERT), each [B, D]."""
+        rows = [to_device_tensor(b) for b in blocks]
+        yv = to_device_tensor(np.asarray(y, dtype=np.float32) if not isinstance(y, torch.Tensor) else y)
+        b = rows[0].shape[0]
+        with torch.no_grad():
+            p = self.head.forward(rows[0], rows[1], (rows[2], rows[3]) if self.hybrid else None)
+            dz = torch.empty((b, 1), dtype=torch.float32, device=p.device)
+            terms = torch.empty(b, dtype=torch.float32, device=p.device)
+            capi.bce_grad(p, yv, dz, terms)
+            grads = {}
+            self.head.backward(dz, grads, need_input_grad=False)
+            loss = float(terms.sum().item()) / b
+        return loss, grads
+
+    def train_batch(self, blocks, y):
+        loss, grads = self.loss_and_grads(blocks, y)
+        self.apply_gradients(grads)
+        return loss
+
+
 def fit(model, sequence, epochs=1, callbacks=None, verbose=True, **kwargs):
     """Keras-style ``fit`` over a batch Sequence: ``epochs`` passes, ``on_epoch_end`` reshuffles (datasets.py:205-213)."""
     opt = getattr(model, 'optimizer', None)
     hp = {k: getattr(opt, k) for k in ('learning_rate', 'beta_1', 'beta_2', 'epsilon') if hasattr(opt, k)}
+    if not hasattr(model, 'gnn'):                              # BasicRS / HybridCBRS on pre-computed rows: head-only training
+        trainer = getattr(model, '_trainer', None)
+        if trainer is None:
+            if not model.built and len(sequence):
+                model(sequence[0][0])                          # one forward call builds every weight (as Keras does)
+            trainer = model._trainer = HeadTrainer(model, **hp)
+        history = []
+        for epoch in range(int(epochs)):
+            total, count = 0.0, 0
+            for b in range(len(sequence)):
+                blocks, y = sequence[b]
+                total += trainer.train_batch(blocks, y) * len(y)
+                count += len(y)
+            history.append(total / max(count, 1))
+            if verbose:
+                print("Epoch {}/{} - loss: {:.4f}".format(epoch + 1, epochs, history[-1]))
+            if hasattr(sequence, 'on_epoch_end'):
+                sequence.on_epoch_end()
+        return {'loss': history}
     trainer = getattr(model, '_trainer', None)
     if trainer is None:
         if hasattr(model.rs, 'dense1a') and not model.rs.built and len(sequence):

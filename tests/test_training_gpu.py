@@ -3,6 +3,8 @@ import numpy as np
 import pytest
 import torch
 
+from scipy import sparse
+
 from oracle import train as otrain
 from tests import helpers
 
@@ -371,3 +373,60 @@ def test_graph_replayed_batches_equal_eager_batches(hip, cls):
     for pa, pb in zip(models[0].parameters(), models[1].parameters()):
         # identical kernels, identical order; only the float atomics of the embedding scatter may differ in the last bits
         assert torch.allclose(pa, pb, rtol=1e-4, atol=1e-6), tuple(pa.shape)
+
+
+@pytest.mark.parametrize('kind', ['BasicRS', 'HybridCBRS', 'HybridCBRS-attention'])
+def test_head_only_training(hip, kind):
+    """basic-kge.yaml / hybrid-kge.yaml: BasicRS / HybridCBRS train on pre-computed embedding rows (datasets.py:43-77).
+    Gradients against the autograd oracle (the embeddings enter as a zero-layer 'GNN'), then fit() on a separable task."""
+    import types
+    from deep_cbrs_amar_renaissance_amd import engine, training
+    from deep_cbrs_amar_renaissance_amd.models import basic, hybrid
+    engine.set_seed(4)
+    rng = np.random.default_rng(6)
+    n, d, b = 90, 32, 200
+    table = rng.standard_normal((n, d)).astype(np.float32) * 0.5
+    bert = rng.standard_normal((n, 24)).astype(np.float32) * 0.5
+    u, i = rng.integers(0, 50, b), rng.integers(50, 90, b)
+    y = rng.integers(0, 2, b)
+    if kind == 'BasicRS':
+        model = basic.BasicRS(dense_units=[24, 16], clf_units=[16])
+        blocks = (table[u], table[i])
+    else:
+        model = hybrid.HybridCBRS(feature_based=True, dense_units=[[24, 16], [24, 16], [16, 16]], clf_units=[16],
+                                  fusion_method='attention' if kind.endswith('attention') else 'concatenate')
+        blocks = (table[u], table[i], bert[u], bert[i])
+    model(blocks)                                             # builds the weights
+    helpers.randomize_biases(model, seed=8)
+    trainer = training.HeadTrainer(model)
+    loss, grads = trainer.loss_and_grads(blocks, y)
+    head = helpers.basic_head_to_oracle(model) if kind == 'BasicRS' else helpers.hybrid_head_to_oracle(model)
+    gnn = {'kind': 'lightgcn', 'embeddings': table, 'layers': []}            # E = the table itself
+    adj = sparse.coo_matrix((n, n), dtype=np.float32)
+    want_loss, want, _ = otrain.torch_model_grads(adj, gnn, head, u, i, y, bert=(bert[u], bert[i]) if kind != 'BasicRS' else None)
+    assert abs(loss - want_loss) < 1e-5
+    flat = {}
+    for name, val in want['head'].items():
+        if name.startswith('fuse'):
+            for key, arr in val.items():
+                flat[getattr(getattr(model, name), key)] = arr
+        else:
+            for layer, (gw, gb) in zip(getattr(model, name).layers, val):
+                flat[layer.kernel], flat[layer.bias] = gw, gb
+    assert set(flat) == set(grads)
+    for prm, gw in flat.items():
+        got = grads[prm].cpu().numpy().reshape(gw.shape).astype(np.float64)
+        assert np.abs(got - gw).max() <= 2e-4 * np.abs(gw).max() + 1e-10, tuple(prm.shape)
+    # fit() through the Keras protocol: labels readable from the rows
+    yy = ((table[u, 0] + table[i, 1]) > 0).astype(np.float32)
+
+    class Seq:
+        def __len__(self):
+            return 2
+
+        def __getitem__(self, k):
+            s = slice(k * 100, (k + 1) * 100)
+            return tuple(blk[s] for blk in blocks), yy[s]
+    model.compile(optimizer=types.SimpleNamespace(learning_rate=5e-3, beta_1=0.9))
+    hist = model.fit(Seq(), epochs=40, verbose=False)['loss']
+    assert hist[-1] < 0.6 * hist[0], hist[::8]

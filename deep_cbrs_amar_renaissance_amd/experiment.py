@@ -20,6 +20,7 @@ import inspect
 import io
 import os
 import re
+import time
 import traceback
 from os.path import join as path_join
 from time import strftime
@@ -176,10 +177,13 @@ class Experimenter:
         self.build_optimizer()
         self.build_model()
         self.logger.info('Training:')
+        t0 = time.perf_counter()
         try:
             self.model.fit(self.trainset, epochs=self.parameters.epochs, workers=self.config.n_workers)
         except NotImplementedError as e:
             self.logger.warning("fit() skipped: {}".format(e))
+        # the reference's LogCallback reports the fit wall time as 'training_time' (utilities/keras.py:43-51, 69-85)
+        self.run_log.log_metrics({'training_time': time.perf_counter() - t0})
 
     def evaluate(self):
         loss_acc = self.model.evaluate(self.testset)

@@ -40,6 +40,20 @@ class NumpyOps:
         if Wnext is not None:
             Hnext.copy_(torch.from_numpy(y @ Wnext.detach().numpy()))
 
+    @staticmethod
+    def spmm_csr(rowptr, colidx, vals, X, Y, **kw):
+        n = rowptr.numel() - 1
+        a = sparse.csr_matrix((vals.numpy(), colidx.numpy(), rowptr.numpy()), shape=(n, X.shape[0]))
+        Y.copy_(torch.from_numpy(a @ X.detach().numpy()))
+
+    @staticmethod
+    def add_inplace(dst, src, scale=1.0):
+        dst.add_(src, alpha=scale)
+
+    @staticmethod
+    def row_affine(a, scale, out, b=None):
+        out.copy_((a if b is None else a + b) * scale[:, None])
+
 
 def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
@@ -57,9 +71,14 @@ def _worker(rank, world, port, out_dir):
         e_pad = runner.propagate()
         n = g['adj'].shape[0]
         idx = runner.part.padded_index(torch.arange(n))
+        # LightGCN stack ('mean' reduction accumulated on the gathered table) through the same partition
+        light = basic.BasicLightGCN(g['adj'], **dict(GRID1, n_layers=3))
+        lrun = parallel.PartitionedGCNRunner(light, u, i, rank, world, ops=NumpyOps, dist=dist, timing=False)
+        e_light = lrun.propagate()
         np.savez(os.path.join(out_dir, 'rank{}.npz'.format(rank)), e=e_pad[idx].numpy(),
                  bounds=np.array(runner.part.bounds), pair_range=np.array(runner.pair_range),
-                 u_back=e_pad[runner.u_ids.long()].numpy(), nnz=np.array(runner.local_nnz))
+                 u_back=e_pad[runner.u_ids.long()].numpy(), nnz=np.array(runner.local_nnz),
+                 e_light=e_light[lrun.part.padded_index(torch.arange(n))].detach().numpy())
     finally:
         dist.destroy_process_group()
 
@@ -84,10 +103,13 @@ def test_partitioned_propagation_matches_oracle_world2(tmp_path):
     model = basic.BasicGCN(g['adj'], **GRID1)
     helpers.randomize_biases(model, seed=3)
     want = om.propagate(g['adj'], helpers.gnn_to_oracle(model.gnn), np.float64)
+    light = basic.BasicLightGCN(g['adj'], **dict(GRID1, n_layers=3))          # same seed order as in the workers
+    want_light = om.propagate(g['adj'], helpers.gnn_to_oracle(light.gnn), np.float64)
     total_nnz, covered = 0, []
     for r in range(world):
         z = np.load(os.path.join(str(tmp_path), 'rank{}.npz'.format(r)))
         assert helpers.rel_err(z['e'], want) < 1e-5, "rank {} holds a wrong node table".format(r)
+        assert helpers.rel_err(z['e_light'], want_light) < 1e-5, "rank {} holds a wrong LightGCN table".format(r)
         lo, hi = z['pair_range']
         assert helpers.rel_err(z['u_back'], want[g['u_ids'][lo:hi]]) < 1e-5     # padded pair ids hit the right rows
         total_nnz += int(z['nnz'])

@@ -299,8 +299,8 @@ def gat_xs(xs, H, s_self, s_neigh, bias, Y, self_loop=True):
         raise ValueError("gat_xs: square image, H / Y [n, C], bias [C], s_self / s_neigh [n] expected")
     scratch = xs.__dict__.setdefault('_gat_scratch', {})
     if C not in scratch:
-        scratch[C] = (torch.empty((n, C + 4), dtype=torch.float32, device=H.device),
-                      torch.empty((xs.n_slices, n, C + 4), dtype=torch.float32, device=H.device))
+        scratch[C] = (torch.empty((n, 2 * C), dtype=torch.float32, device=H.device),
+                      torch.empty((xs.n_slices, n, 2 * C), dtype=torch.float32, device=H.device))
     packed, partials = scratch[C]
     code = load().amar_gat_xs_f32(
         _ptr(xs.rowptr, torch.int32, 'rowptr'), _ptr(xs.colidx, torch.int32, 'colidx'), xs.n_slices,

@@ -701,9 +701,9 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void gat_row_kernel(co
 
 // ---- GAT on the XCD-sliced image (large graphs) ----------------------------------------------------------------
 // Same tiling as spmm_xs_*: workgroup b works on column slice b % S, a wave on one (64-row block, slice) tile, a lane on
-// EPL consecutive entries.  The gathered table is G = C + 4 floats wide per node: [ h_j (C) | s_neigh_j | 0 0 0 ] (48-byte
-// rows for C = 8: the 28 MB table of ml1m(s=64) still fits the eight L2s slice by slice), so one L2 request serves the row
-// AND the neighbour scalar (a quarter of the rows straddle two lines).  The softmax is kept exact with the "online" form: every partial
+// EPL consecutive entries.  The gathered table is G = 2C floats wide per node: [ h_j (C) | s_neigh_j | 0 .. ] (64-byte rows
+// for C = 8: never straddling a 128-byte line; 48-byte rows fit the L2s better but a quarter of them straddle: measured
+// 0.55-0.59 ms against 0.54 ms per layer), so one L2 request serves the row AND the neighbour scalar.  The softmax is kept exact with the "online" form: every partial
 // result is a triple (m, l, o) = (running max of e, sum exp(e - m), sum exp(e - m) h_j), and two triples of one row merge as
 //     M = max(m1, m2);  l = l1 exp(m1 - M) + l2 exp(m2 - M);  o = o1 exp(m1 - M) + o2 exp(m2 - M).
 // In-lane serial merge over the lane's entries, ONE cross-lane segmented scan with that operator (EPS = 16: one DPP row),
@@ -743,7 +743,7 @@ __device__ __forceinline__ void soft_scan_level(Soft4 &st, int key) {
 
 template <int C, bool OFF32>
 __global__ __launch_bounds__(XS_WAVES * AMAR_WAVE) void gat_xs_partial_kernel(const GatXsArgs a) {
-    constexpr int G = C + 4, EPS = 16, EPL = 8, SUPER = EPS * EPL, QH = C / 4;   // QH quads carry h, quad QH carries s_neigh; lanes of quad 3 idle
+    constexpr int G = 2 * C, EPS = 16, EPL = 8, SUPER = EPS * EPL, QH = C / 4;   // QH quads carry h, quad QH carries s_neigh; lanes of quad 3 idle
     static_assert(C == 8 && EPS == 16, "the cross-lane scan below covers exactly one 16-lane DPP row per feature quad (C = 8)");
     constexpr int PAD_KEY = AMAR_WAVE;
     __shared__ float lds_o[XS_WAVES][C * AMAR_WAVE];
@@ -842,7 +842,7 @@ struct GatXsCombineArgs {
 
 template <int C>
 __global__ __launch_bounds__(256) void gat_xs_combine_kernel(const GatXsCombineArgs a) {
-    constexpr int G = C + 4;
+    constexpr int G = 2 * C;
     const int row = blockIdx.x * 256 + threadIdx.x;
     if (row >= a.n_rows) return;
     float m = -INFINITY, l = 0.f, o[C];
@@ -876,10 +876,10 @@ __global__ __launch_bounds__(256) void gat_xs_combine_kernel(const GatXsCombineA
     for (int c = 0; c < C; ++c) y[c] = fmaxf(o[c] * inv + a.bias[c], 0.f);
 }
 
-// [ H (C) | s_neigh | 0 0 0 ] rows of C + 4 floats: what the partial kernel gathers
+// [ H (C) | s_neigh | 0 .. ] rows of 2C floats: what the partial kernel gathers
 __global__ __launch_bounds__(256) void gat_pack_kernel(const float *__restrict__ H, int64_t ldh, const float *__restrict__ s_neigh,
                                                        float *__restrict__ HT, int n, int C) {
-    const int G = C + 4;
+    const int G = 2 * C;
     const int64_t total = (int64_t)n * G;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = i / G;
@@ -1015,11 +1015,11 @@ int amar_gat_xs_f32(const int32_t *rowptr, const int32_t *colidx, int32_t n_slic
     if (C != 8) return AMAR_EUNSUPPORTED;                               // 16 lanes per feature quad = one DPP row
     if (n_rows == 0) return AMAR_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int64_t total = (int64_t)n_rows * (C + 4);
+    const int64_t total = (int64_t)n_rows * (2 * C);
     hipLaunchKernelGGL(gat_pack_kernel, dim3((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256)), dim3(256), 0, st,
                        H, ldh, s_neigh, packed, n_rows, C);
     GatXsArgs pa{rowptr, colidx, packed, s_self, partials, n_rows, n_slices,
-                 (n_rows + XS_WAVES * AMAR_WAVE - 1) / (XS_WAVES * AMAR_WAVE), (int64_t)n_rows * (C + 4) * 4 < (int64_t(1) << 32)};
+                 (n_rows + XS_WAVES * AMAR_WAVE - 1) / (XS_WAVES * AMAR_WAVE), (int64_t)n_rows * (2 * C) * 4 < (int64_t(1) << 32)};
     const dim3 pgrid((unsigned)(pa.blocks_per_slice * pa.n_slices)), block(XS_WAVES * AMAR_WAVE);
     if (pa.off32) hipLaunchKernelGGL((gat_xs_partial_kernel<8, true>), pgrid, block, 0, st, pa);
     else hipLaunchKernelGGL((gat_xs_partial_kernel<8, false>), pgrid, block, 0, st, pa);

@@ -216,9 +216,9 @@ int amar_reduce_layers_f32(const float *cat, int64_t ld, int32_t n_layers, int32
                            int64_t n_rows, int32_t mean, amar_stream_t stream);
 
 /* The same GAT layer on the XCD-sliced image of the (square) edge-list adjacency, for graphs whose node table exceeds the
- * per-XCD L2s: rowptr / colidx as in amar_spmm_xs_f32 (values unused).  `packed` is scratch [n, C + 4] floats that the call
- * fills with [ H | s_neigh | 0 0 0 ] rows (one L2 request then serves the neighbour's features and its scalar), `partials`
- * scratch [n_slices, n, C + 4].  The segment softmax stays exact through (max, sum, weighted sum) triples merged per
+ * per-XCD L2s: rowptr / colidx as in amar_spmm_xs_f32 (values unused).  `packed` is scratch [n, 2C] floats that the call
+ * fills with [ H | s_neigh | 0 .. ] rows (one L2 request then serves the neighbour's features and its scalar), `partials`
+ * scratch [n_slices, n, 2C].  The segment softmax stays exact through (max, sum, weighted sum) triples merged per
  * (row, slice) and across slices.  C = 8.
  */
 int amar_gat_xs_f32(const int32_t *rowptr, const int32_t *colidx, int32_t n_slices,

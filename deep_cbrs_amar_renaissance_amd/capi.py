@@ -31,7 +31,7 @@ SIGNATURES = {
                                         _P, _I64, _P, _I64, _F32, _P, _I32, _P, _I64, _P]),
     'amar_spmm_xs_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _P, _P, _P, _I64, _I32, _I32, _U32, _P,
                                         _P, _I64, _P, _I64, _F32, _P, _I32, _P, _I64, _P]),
-    'amar_gat_xs_f32': (ctypes.c_int, [_P, _P, _I32, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P]),
+    'amar_gat_xs_f32': (ctypes.c_int, [_P, _P, _I32, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P]),
     'amar_gcn_layer_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _I64, _P, _I32, _P, _I64, _I32, _P]),
     'amar_rowwise_xw_f32': (ctypes.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _P, _I64, _P, _P, _P, _P, _I32, _P]),
     'amar_sage_layer_f32': (ctypes.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _I32, _P, _I64, _I32, _I32, _P]),
@@ -291,22 +291,23 @@ def gat_layer(rowptr, colidx, H, s_self, s_neigh, bias, Y, self_loop=True):
 
 
 def gat_xs(xs, H, s_self, s_neigh, bias, Y, self_loop=True):
-    """gat_layer on the XCD-sliced image `xs` of the edge-list adjacency (utilities.math.XcdSliced; values unused)."""
-    n = xs.shape[0]
+    """gat_layer on the XCD-sliced image `xs` of the edge-list adjacency (utilities.math.XcdSliced; values unused).
+    `xs` may be a row block (multi-GPU partition): H / s_self / s_neigh then cover all of its columns."""
+    n, n_cols = xs.shape
+    row_offset = int(getattr(xs, 'diag_offset', 0))
     C = H.shape[1]
-    if xs.shape[0] != xs.shape[1] or tuple(Y.shape) != (n, C) or H.shape[0] != n or bias.numel() != C or \
-            s_self.numel() != n or s_neigh.numel() != n:
-        raise ValueError("gat_xs: square image, H / Y [n, C], bias [C], s_self / s_neigh [n] expected")
+    if tuple(Y.shape) != (n, C) or H.shape[0] != n_cols or bias.numel() != C or s_self.numel() != n_cols or s_neigh.numel() != n_cols:
+        raise ValueError("gat_xs: H [n_cols, C], Y [n_rows, C], bias [C], s_self / s_neigh [n_cols] expected")
     scratch = xs.__dict__.setdefault('_gat_scratch', {})
     if C not in scratch:
-        scratch[C] = (torch.empty((n, 2 * C), dtype=torch.float32, device=H.device),
+        scratch[C] = (torch.empty((n_cols, 2 * C), dtype=torch.float32, device=H.device),
                       torch.empty((xs.n_slices, n, 2 * C), dtype=torch.float32, device=H.device))
     packed, partials = scratch[C]
     code = load().amar_gat_xs_f32(
         _ptr(xs.rowptr, torch.int32, 'rowptr'), _ptr(xs.colidx, torch.int32, 'colidx'), xs.n_slices,
         _ptr(H, torch.float32, 'H'), _ld(H, 'H'), C, _ptr(s_self, torch.float32, 's_self'), _ptr(s_neigh, torch.float32, 's_neigh'),
         _ptr(bias, torch.float32, 'bias'), _ptr(packed), _ptr(partials), _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y'),
-        1 if self_loop else 0, n, _stream())
+        1 if self_loop else 0, n, n_cols, row_offset, _stream())
     _check(code, 'amar_gat_xs_f32')
 
 

@@ -713,6 +713,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void gat_row_kernel(co
 struct GatXsArgs {
     const int32_t *rowptr; const int32_t *colidx; const float *HT; const float *s_self; float *P;
     int n_rows; int n_slices; int blocks_per_slice; bool off32;
+    int row_offset;                              // row i of this block is node row_offset + i of s_self / the packed table
 };
 
 struct Soft4 { float m; float l; float4 o; };
@@ -761,7 +762,7 @@ __global__ __launch_bounds__(XS_WAVES * AMAR_WAVE) void gat_xs_partial_kernel(co
 #pragma unroll
     for (int c = 0; c < C; ++c) acc_o[c * AMAR_WAVE + lane] = 0.f;
     acc_m[lane] = -INFINITY; acc_l[lane] = 0.f;
-    srow[lane] = lane < nr ? a.s_self[r0 + lane] : 0.f;
+    srow[lane] = lane < nr ? a.s_self[a.row_offset + r0 + lane] : 0.f;
     const int q = lane / EPS, s = lane % EPS;
     const int n_tile = end - beg;
     const char *cbase = reinterpret_cast<const char *>(a.colidx + beg);
@@ -837,7 +838,7 @@ __global__ __launch_bounds__(XS_WAVES * AMAR_WAVE) void gat_xs_partial_kernel(co
 
 struct GatXsCombineArgs {
     const float *P; const int32_t *rowptr; const float *HT; const float *s_self; const float *bias; float *Y; int64_t ldy;
-    int n_rows; int n_slices; int self_loop;
+    int n_rows; int n_slices; int self_loop; int row_offset;
 };
 
 template <int C>
@@ -857,9 +858,9 @@ __global__ __launch_bounds__(256) void gat_xs_combine_kernel(const GatXsCombineA
         for (int c = 0; c < C; ++c) o[c] = o[c] * ea + o2[c] * eb;
         m = M;
     };
-    const float *own = a.HT + (int64_t)row * G;
+    const float *own = a.HT + (int64_t)(a.row_offset + row) * G;
     if (a.self_loop) {
-        const float pre = a.s_self[row] + own[C];
+        const float pre = a.s_self[a.row_offset + row] + own[C];
         merge(pre > 0.f ? pre : 0.2f * pre, 1.f, own);
     }
     const int w0 = __builtin_amdgcn_readfirstlane(row & ~(AMAR_WAVE - 1));
@@ -1009,21 +1010,22 @@ int amar_gat_layer_f32(const int32_t *rowptr, const int32_t *colidx,
 int amar_gat_xs_f32(const int32_t *rowptr, const int32_t *colidx, int32_t n_slices,
                     const float *H, int64_t ldh, int32_t C, const float *s_self, const float *s_neigh, const float *bias,
                     float *packed, float *partials, float *Y, int64_t ldy, int32_t self_loop, int32_t n_rows,
-                    amar_stream_t stream) {
+                    int32_t n_cols, int32_t row_offset, amar_stream_t stream) {
     if (n_rows < 0 || n_slices < 1 || !rowptr || !H || !s_self || !s_neigh || !bias || !packed || !partials || !Y) return AMAR_EINVAL;
+    if (n_cols < n_rows || row_offset < 0 || row_offset + n_rows > n_cols) return AMAR_EINVAL;
     if (ldh < C || ldy < C || !amar_aligned16(packed) || !amar_aligned16(partials)) return AMAR_EINVAL;
     if (C != 8) return AMAR_EUNSUPPORTED;                               // 16 lanes per feature quad = one DPP row
     if (n_rows == 0) return AMAR_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int64_t total = (int64_t)n_rows * (2 * C);
+    const int64_t total = (int64_t)n_cols * (2 * C);
     hipLaunchKernelGGL(gat_pack_kernel, dim3((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256)), dim3(256), 0, st,
-                       H, ldh, s_neigh, packed, n_rows, C);
+                       H, ldh, s_neigh, packed, n_cols, C);
     GatXsArgs pa{rowptr, colidx, packed, s_self, partials, n_rows, n_slices,
-                 (n_rows + XS_WAVES * AMAR_WAVE - 1) / (XS_WAVES * AMAR_WAVE), (int64_t)n_rows * (2 * C) * 4 < (int64_t(1) << 32)};
+                 (n_rows + XS_WAVES * AMAR_WAVE - 1) / (XS_WAVES * AMAR_WAVE), (int64_t)n_cols * (2 * C) * 4 < (int64_t(1) << 32), row_offset};
     const dim3 pgrid((unsigned)(pa.blocks_per_slice * pa.n_slices)), block(XS_WAVES * AMAR_WAVE);
     if (pa.off32) hipLaunchKernelGGL((gat_xs_partial_kernel<8, true>), pgrid, block, 0, st, pa);
     else hipLaunchKernelGGL((gat_xs_partial_kernel<8, false>), pgrid, block, 0, st, pa);
-    GatXsCombineArgs ca{partials, rowptr, packed, s_self, bias, Y, ldy, n_rows, n_slices, self_loop ? 1 : 0};
+    GatXsCombineArgs ca{partials, rowptr, packed, s_self, bias, Y, ldy, n_rows, n_slices, self_loop ? 1 : 0, row_offset};
     hipLaunchKernelGGL((gat_xs_combine_kernel<8>), dim3((n_rows + 255) / 256), dim3(256), 0, st, ca);
     return amar_check_launch();
 }

@@ -26,7 +26,10 @@ import numpy as np
 import torch
 
 from deep_cbrs_amar_renaissance_amd import capi
+from deep_cbrs_amar_renaissance_amd.layers.dgcf_conv import DGCFConv
+from deep_cbrs_amar_renaissance_amd.layers.gat_conv import GATConv
 from deep_cbrs_amar_renaissance_amd.layers.gcn_conv import GCNConv
+from deep_cbrs_amar_renaissance_amd.layers.graphsage_conv import GraphSageConv
 from deep_cbrs_amar_renaissance_amd.layers.lightgcn_conv import LightGCNConv
 from deep_cbrs_amar_renaissance_amd.utilities.math import DeviceCSR
 
@@ -133,8 +136,18 @@ class PartitionedGCNRunner:
             self.kind = 'gcn'
         elif layers and all(isinstance(l, LightGCNConv) for l in layers) and seq.final_node == 'mean':
             self.kind = 'lightgcn'
+        elif layers and all(isinstance(l, DGCFConv) for l in layers) and seq.final_node == 'mean':
+            self.kind = 'dgcf'
+        elif layers and all(isinstance(l, GraphSageConv) for l in layers) and seq.final_node == 'concatenation':
+            self.kind = 'sage'
+        elif layers and all(isinstance(l, GATConv) for l in layers) and seq.final_node == 'concatenation' and \
+                all(l.channels == 8 for l in layers):
+            self.kind = 'gat'
         else:
-            raise NotImplementedError("the partitioned runner covers GCN ('concatenation') and LightGCN ('mean') stacks")
+            raise NotImplementedError("the partitioned runner covers GCN / GraphSAGE / GAT (8 channels) stacks with "
+                                      "'concatenation' and LightGCN / DGCF stacks ('mean')")
+        if self.kind in ('sage', 'gat') and ops is not capi:
+            raise NotImplementedError("partitioned GraphSAGE / GAT run on the XCD-sliced HIP kernels only")
         self.hybrid = hasattr(model.rs, 'dense1a')
         self.model, self.seq = model, seq
         a = seq.adj_matrix
@@ -180,12 +193,17 @@ class PartitionedGCNRunner:
         layers, widths = list(self.seq.seq_layers), self.widths
         rows = self.local_rows
         x0p = self._x0_padded()
-        if self.kind == 'lightgcn':
-            # X_{l+1} = A_hat X_l on the local rows, gathered; the mean over layers accumulates on the full table
+        if self.kind in ('lightgcn', 'dgcf'):
+            # X_{l+1} = A X_l on the local rows (DGCF: A_dgcf (X_l * sigmoid(w_l)), the gate applied to the whole replicated
+            # table), gathered; the mean over layers accumulates on the full table
             acc = x0p.clone()
             x = x0p
-            for _ in layers:
+            for k, layer in enumerate(layers):
                 y_local = torch.zeros((R, widths[0]), dtype=torch.float32, device=dev)
+                if self.kind == 'dgcf':
+                    gated = torch.empty_like(x)
+                    ops.locality_scale(x, self._gate_padded(k, layer), gated)
+                    x = gated
                 ops.spmm_csr(self.csr.rowptr, self.csr.colidx, self.csr.vals, x, y_local[:rows])
                 x = torch.empty((self.world * R, widths[0]), dtype=torch.float32, device=dev)
                 self.dist.all_gather_into_tensor(x, y_local)
@@ -197,6 +215,33 @@ class PartitionedGCNRunner:
         offs = np.cumsum([0] + widths)
         e_all = torch.empty((self.world * R, f_cat), dtype=torch.float32, device=dev)
         ops.copy_columns(x0p, e_all[:, :widths[0]])                         # X_0 is a replicated weight
+        if self.kind in ('sage', 'gat'):
+            # the rank's row block on the XCD-sliced forms (amar_spmm_xs_f32 mean aggregate / amar_gat_xs_f32): both take a
+            # block whose own rows sit at column offset rank * R of the replicated table
+            lo = self.rank * R
+            x_full = x0p
+            for k, layer in enumerate(layers):
+                f, c = widths[k], widths[k + 1]
+                y_local = torch.zeros((R, c), dtype=torch.float32, device=dev)
+                if self.kind == 'sage':
+                    xa = torch.empty((rows, 2 * f), dtype=torch.float32, device=dev)
+                    ops.copy_columns(x_full[lo:lo + rows], xa[:, :f])
+                    ops.spmm_xs(self.csr.xcd_sliced_mean(layer.self_loops), x_full, xa[:, f:], prescaled=True)
+                    z = torch.empty((rows, c), dtype=torch.float32, device=dev)
+                    ops.dense(xa, layer.kernel, layer.bias, z, act=None)
+                    nrm, inv = torch.empty_like(z), torch.empty(rows, dtype=torch.float32, device=dev)
+                    ops.l2norm_fwd(z, nrm, inv, y_local[:rows], act='relu')
+                else:
+                    h = torch.empty((self.world * R, c), dtype=torch.float32, device=dev)
+                    s_self = torch.empty(self.world * R, dtype=torch.float32, device=dev)
+                    s_neigh = torch.empty(self.world * R, dtype=torch.float32, device=dev)
+                    ops.rowwise_xw(x_full, layer.kernel.view(-1, c), h, a_self=layer.attn_kernel_self.view(c),
+                                   a_neigh=layer.attn_kernel_neighs.view(c), s_self=s_self, s_neigh=s_neigh)
+                    ops.gat_xs(self.csr.xcd_sliced(), h, s_self, s_neigh, layer.bias, y_local[:rows], self_loop=layer.add_self_loops)
+                x_full = torch.empty((self.world * R, c), dtype=torch.float32, device=dev)
+                self.dist.all_gather_into_tensor(x_full, y_local)
+                ops.copy_columns(x_full, e_all[:, offs[k + 1]:offs[k + 2]])
+            return e_all
         h = torch.empty((self.world * R, widths[1]), dtype=torch.float32, device=dev)
         ops.rowwise_xw(x0p, layers[0].kernel, h)
         for k, layer in enumerate(layers):
@@ -244,6 +289,14 @@ class PartitionedGCNRunner:
         if forced in ('csr', 'xs'):
             return forced == 'xs'
         return self.world * self.part.R * width * 4 >= ((8 << 20) if width <= 8 else (16 << 20))
+
+    def _gate_padded(self, k, layer):
+        """DGCF's per-node gate weights of layer k in the padded layout (rebuilt when they change)."""
+        cache = self.__dict__.setdefault('_gates', {})
+        version = layer.w._version
+        if cache.get(k, (None, None))[0] != version:
+            cache[k] = (version, self.part.pad_table(layer.w.detach().view(-1, 1)).view(-1).contiguous())
+        return cache[k][1]
 
     def _mean_scale(self, n_rows, n_terms, dev):
         if getattr(self, '_mean', None) is None or self._mean.numel() != n_rows:

@@ -219,12 +219,13 @@ int amar_reduce_layers_f32(const float *cat, int64_t ld, int32_t n_layers, int32
  * per-XCD L2s: rowptr / colidx as in amar_spmm_xs_f32 (values unused).  `packed` is scratch [n, 2C] floats that the call
  * fills with [ H | s_neigh | 0 .. ] rows (one L2 request then serves the neighbour's features and its scalar), `partials`
  * scratch [n_slices, n, 2C].  The segment softmax stays exact through (max, sum, weighted sum) triples merged per
- * (row, slice) and across slices.  C = 8.
+ * (row, slice) and across slices.  C = 8.  H, s_self, s_neigh and `packed` have n_cols rows (the columns of the image);
+ * a row block of a larger graph (multi-GPU partition) has n_rows < n_cols and its row i is node row_offset + i.
  */
 int amar_gat_xs_f32(const int32_t *rowptr, const int32_t *colidx, int32_t n_slices,
                     const float *H, int64_t ldh, int32_t C, const float *s_self, const float *s_neigh, const float *bias,
                     float *packed, float *partials, float *Y, int64_t ldy, int32_t self_loop, int32_t n_rows,
-                    amar_stream_t stream);
+                    int32_t n_cols, int32_t row_offset, amar_stream_t stream);
 
 /* ---- hybrid-head variants of econfigs/hybrid-gnn-tweaks*.yaml -----------------------
  * amar_attention_mix_f32      FusionLayer('attention') (src/layers/fusion.py:54-68) after the two products

@@ -399,6 +399,21 @@ __device__ __forceinline__ void seg_scan_isa(float4 &p, int key) {
 }
 #undef AMAR_SEG_LEVEL
 
+// Workgroup -> (row chunk, slice) with XCD affinity.  n_slices = 8 * phases: workgroup b lands on XCD b % 8 (round-robin
+// dispatch) and works, during phase p = b / (8 * blocks_per_slice), on slice 8 p + b % 8 — so at any time an XCD's L2 holds ONE
+// slice of X, also when the table is several times larger than the aggregate L2.  (n_slices not a multiple of 8: plain b % S.)
+__device__ __forceinline__ void xs_block_to_tile(int b, int n_slices, int blocks_per_slice, int &chunk, int &slice) {
+    if ((n_slices & 7) == 0) {
+        const int per_phase = 8 * blocks_per_slice;
+        const int phase = b / per_phase, r = b - phase * per_phase;
+        chunk = r >> 3;
+        slice = phase * 8 + (r & 7);
+    } else {
+        slice = b % n_slices;
+        chunk = b / n_slices;
+    }
+}
+
 // OFF32: every byte offset into X fits 32 bits, so the gathers take the `saddr + voffset` form and the per-lane
 // address arithmetic is one multiply-add instead of a 64-bit chain.
 //
@@ -422,8 +437,8 @@ __global__ __launch_bounds__(XS_WAVES * AMAR_WAVE) void spmm_xs_partial_kernel(c
     constexpr int PAD_KEY = AMAR_WAVE;                               // key of an entry past the end: equals no row, never flushed
     __shared__ float lds_acc[XS_WAVES][AMAR_WAVE * F];
     const int lane = threadIdx.x & (AMAR_WAVE - 1);
-    const int k = blockIdx.x % a.n_slices;                           // slice <-> XCD affinity
-    const int chunk = blockIdx.x / a.n_slices;
+    int k, chunk;                                                    // slice <-> XCD affinity
+    xs_block_to_tile(blockIdx.x, a.n_slices, a.blocks_per_slice, chunk, k);
     const int r0 = __builtin_amdgcn_readfirstlane((chunk * XS_WAVES + (threadIdx.x >> 6)) * AMAR_WAVE);
     if (r0 >= a.n_rows) return;
     const int nr = min(AMAR_WAVE, a.n_rows - r0);
@@ -750,8 +765,8 @@ __global__ __launch_bounds__(XS_WAVES * AMAR_WAVE) void gat_xs_partial_kernel(co
     __shared__ float lds_o[XS_WAVES][C * AMAR_WAVE];
     __shared__ float lds_ml[XS_WAVES][3 * AMAR_WAVE];              // m, l, and the tile's s_self
     const int lane = threadIdx.x & (AMAR_WAVE - 1), wv = threadIdx.x >> 6;
-    const int k = blockIdx.x % a.n_slices;
-    const int chunk = blockIdx.x / a.n_slices;
+    int k, chunk;
+    xs_block_to_tile(blockIdx.x, a.n_slices, a.blocks_per_slice, chunk, k);
     const int r0 = __builtin_amdgcn_readfirstlane((chunk * XS_WAVES + wv) * AMAR_WAVE);
     if (r0 >= a.n_rows) return;
     const int nr = min(AMAR_WAVE, a.n_rows - r0);

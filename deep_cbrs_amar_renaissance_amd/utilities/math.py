@@ -257,6 +257,14 @@ class XcdSliced:
 
     N_SLICES = 8
 
+    @classmethod
+    def slices_for(cls, n_cols):
+        """8 slices, one per XCD.  AMAR_XS_SLICES=8k makes the kernels work through 8k slices in k phases (one slice per XCD
+        live at a time; supported and tested, but at ml1m(s=256) — a 75 MB table — 32 slices gained only 4 % over 8 and cost
+        4x the partial-sum scratch, so it is not the default)."""
+        forced = os.environ.get('AMAR_XS_SLICES')
+        return int(forced) if forced else cls.N_SLICES
+
     def __init__(self, diag, rowptr, colidx, vals, bounds, shape, row_scale=None, col_scale=None, diag_offset=0):
         self.diag, self.rowptr, self.colidx, self.vals, self.bounds, self.shape = diag, rowptr, colidx, vals, bounds, tuple(shape)
         # value-free form: row_scale [n_rows] scales the row sums, col_scale [n_cols] pre-scales the gathered table
@@ -272,11 +280,13 @@ class XcdSliced:
         return self._partials[F]
 
     @classmethod
-    def from_csr(cls, a, n_slices=N_SLICES):
+    def from_csr(cls, a, n_slices=None):
         """`a`: a square DeviceCSR, or a row block of one (multi-GPU partition) carrying `diag_offset` = the column of
         its first row's own entry, and for the value-free form `dinv` over its COLUMNS plus `mult`."""
         dev = a.rowptr.device
         n, n_cols = a.shape
+        if n_slices is None:
+            n_slices = cls.slices_for(n_cols)
         diag_offset = int(getattr(a, 'diag_offset', 0))
         if n != n_cols and not hasattr(a, 'diag_offset'):
             raise ValueError("the XS image is defined for square matrices and for row blocks that say where their diagonal is")

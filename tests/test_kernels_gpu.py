@@ -542,6 +542,43 @@ def test_gat_xcd_sliced(hip, n, avg_deg, seed, dup, self_loop):
     assert np.abs(got - y_row.cpu().numpy()).max() < 2e-5 * max(1.0, np.abs(want).max())
 
 
+@pytest.mark.parametrize('n_slices', [16, 24, 5])
+def test_xcd_sliced_multi_phase(hip, n_slices, monkeypatch):
+    """8 k slices processed in k phases (tables beyond the aggregate L2), and a slice count that is no multiple of 8: the
+    SpMM (valued and value-free), GraphSAGE's mean aggregate and the GAT form against the row kernels."""
+    from deep_cbrs_amar_renaissance_amd.utilities.math import XcdSliced, gcn_filter_device
+    monkeypatch.setenv('AMAR_XS_SLICES', str(n_slices))
+    g = helpers.tiny_graph(n_users=400, n_items=300, n_ratings=20000, seed=n_slices)
+    coo = g['adj'].tocoo()
+    keep = coo.row < coo.col
+    n = coo.shape[0]
+    a = gcn_filter_device(torch.from_numpy(coo.row[keep].astype(np.int64)).to(DEV), torch.from_numpy(coo.col[keep].astype(np.int64)).to(DEV), n)
+    xs = a.xcd_sliced()
+    assert xs.n_slices == n_slices and xs.row_scale is not None
+    rng = np.random.default_rng(1)
+    x = _t(rng.standard_normal((n, 8)).astype(np.float32))
+    y, ycsr = torch.empty((n, 8), device=DEV), torch.empty((n, 8), device=DEV)
+    hip.spmm_xs(xs, x, y)
+    hip.spmm_csr(a.rowptr, a.colidx, a.vals, x, ycsr)
+    assert rel_err(y.cpu().numpy(), ycsr.cpu().numpy().astype(np.float64)) < 3e-6
+    monkeypatch.setenv('AMAR_XS_VALUES', '1')
+    hip.spmm_xs(XcdSliced.from_csr(a), x, y)
+    assert rel_err(y.cpu().numpy(), ycsr.cpu().numpy().astype(np.float64)) < 3e-6
+    e = _dev_csr(g['adj'], with_values=False, drop_diagonal=True)
+    h = _t(rng.standard_normal((n, 8)).astype(np.float32))
+    ss, sn, b = _t(rng.standard_normal(n).astype(np.float32)), _t(rng.standard_normal(n).astype(np.float32)), _t(rng.uniform(-0.2, 0.2, 8).astype(np.float32))
+    yr, yx = torch.empty((n, 8), device=DEV), torch.empty((n, 8), device=DEV)
+    hip.gat_layer(e.rowptr, e.colidx, h, ss, sn, b, yr, self_loop=True)
+    hip.gat_xs(e.xcd_sliced(), h, ss, sn, b, yx, self_loop=True)
+    assert e.xcd_sliced().n_slices == n_slices and float((yr - yx).abs().max()) < 2e-5
+    agg_x, agg_r = torch.empty((n, 8), device=DEV), torch.empty((n, 8), device=DEV)
+    hip.spmm_xs(e.xcd_sliced_mean(True), x, agg_x, prescaled=True)
+    hip.spmm_csr(e.rowptr, e.colidx, None, x, agg_r)
+    deg = (e.rowptr[1:] - e.rowptr[:-1]).float()
+    want = (agg_r + x) / (deg + 1)[:, None]
+    assert float((agg_x - want).abs().max()) < 1e-5
+
+
 def test_spmm_xcd_sliced_is_reproducible(hip):
     """LDS float adds inside the XS partial kernel follow a fixed order: two launches give the same bits."""
     from deep_cbrs_amar_renaissance_amd.utilities.math import XcdSliced

@@ -6,8 +6,8 @@ sections), same resolution of model / loader classes from name strings, same per
 catch-and-continue.  Differences, all forced by scope:
 
 * tracking goes to a JSON-lines run log instead of MLflow (not installed);
-* ``Model.fit`` is implemented for the GCN and LightGCN recommenders (training.py); for the other stacks
-  ``fit`` raises NotImplementedError and ``train()`` goes on to evaluate the seed-initialised weights;
+* ``Model.fit`` is the HIP training step of training.py (every model class named in ``econfigs/``); a model without
+  one (TwoStep / TwoWay names) raises NotImplementedError at construction and the grid goes on with the next experiment;
 * Precision/Recall/F1@k come from a host-side evaluator instead of ``binaries/mimir.jar``.
 
 Run from the directory that holds ``config.yaml`` and the ``datasets/`` tree:

@@ -109,6 +109,22 @@ def _ptr(t, dtype=None, name='tensor'):
     return t.data_ptr()
 
 
+_EMPTY_STANDINS = {}
+
+
+def _ptr_entries(t, dtype, name):
+    """Pointer of a per-non-zero array (colidx / vals).  A matrix without any non-zero has empty arrays whose data pointer
+    is NULL; the C entry points reject NULL (a NULL with non-zeros behind it would fault the GPU), so an empty array is
+    replaced by a one-element stand-in that the kernels never read (every row range is empty)."""
+    if t is None or t.numel() > 0:
+        return _ptr(t, dtype, name)
+    _ptr(t, dtype, name)                                             # same device / dtype checks
+    key = (t.device, dtype)
+    if key not in _EMPTY_STANDINS:
+        _EMPTY_STANDINS[key] = torch.zeros(4, dtype=dtype, device=t.device)
+    return _EMPTY_STANDINS[key].data_ptr()
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -136,7 +152,7 @@ def spmm_csr(rowptr, colidx, vals, X, Y=None, bias=None, relu=False, acc_in=None
     if vals is not None and vals.numel() != colidx.numel():
         raise ValueError("vals and colidx differ in length")
     code = load().amar_spmm_csr_f32(
-        _ptr(rowptr, torch.int32, 'rowptr'), _ptr(colidx, torch.int32, 'colidx'), _ptr(vals, torch.float32, 'vals'),
+        _ptr(rowptr, torch.int32, 'rowptr'), _ptr_entries(colidx, torch.int32, 'colidx'), _ptr_entries(vals, torch.float32, 'vals'),
         _ptr(X, torch.float32, 'X'), _ld(X, 'X'), _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y') if Y is not None else 0,
         n_rows, F, flags, _ptr(bias, torch.float32, 'bias'),
         _ptr(acc_in, torch.float32, 'acc_in'), _ld(acc_in, 'acc_in') if acc_in is not None else 0,
@@ -238,7 +254,7 @@ def gcn_layer(rowptr, colidx, vals, H, bias, Y, Wnext=None, Hnext=None):
             raise ValueError("gcn_layer: Wnext [C, Cn] contiguous and Hnext [n_rows, Cn] expected")
         Cn = Wnext.shape[1]
     code = load().amar_gcn_layer_f32(
-        _ptr(rowptr, torch.int32, 'rowptr'), _ptr(colidx, torch.int32, 'colidx'), _ptr(vals, torch.float32, 'vals'),
+        _ptr(rowptr, torch.int32, 'rowptr'), _ptr_entries(colidx, torch.int32, 'colidx'), _ptr_entries(vals, torch.float32, 'vals'),
         _ptr(H, torch.float32, 'H'), _ld(H, 'H'), C, _ptr(bias, torch.float32, 'bias'),
         _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y'),
         _ptr(Wnext, torch.float32, 'Wnext'), Cn, _ptr(Hnext, torch.float32, 'Hnext'),
@@ -271,7 +287,7 @@ def sage_layer(rowptr, colidx, X, W, bias, Y, self_loop=True):
             tuple(Y.shape) != (n_rows, W.shape[1]) or X.shape[0] < n_rows:
         raise ValueError("sage_layer: W [2F, C] contiguous, bias [C], Y [n_rows, C] expected")
     code = load().amar_sage_layer_f32(
-        _ptr(rowptr, torch.int32, 'rowptr'), _ptr(colidx, torch.int32, 'colidx'),
+        _ptr(rowptr, torch.int32, 'rowptr'), _ptr_entries(colidx, torch.int32, 'colidx'),
         _ptr(X, torch.float32, 'X'), _ld(X, 'X'), F, _ptr(W, torch.float32, 'W'), _ptr(bias, torch.float32, 'bias'),
         W.shape[1], _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y'), 1 if self_loop else 0, n_rows, _stream())
     _check(code, 'amar_sage_layer_f32')
@@ -283,7 +299,7 @@ def gat_layer(rowptr, colidx, H, s_self, s_neigh, bias, Y, self_loop=True):
     if tuple(Y.shape) != (n_rows, C) or bias.numel() != C or s_self.numel() < n_rows or s_neigh.numel() < H.shape[0]:
         raise ValueError("gat_layer: bias [C], Y [n_rows, C], s_self/s_neigh [n] expected")
     code = load().amar_gat_layer_f32(
-        _ptr(rowptr, torch.int32, 'rowptr'), _ptr(colidx, torch.int32, 'colidx'),
+        _ptr(rowptr, torch.int32, 'rowptr'), _ptr_entries(colidx, torch.int32, 'colidx'),
         _ptr(H, torch.float32, 'H'), _ld(H, 'H'), C, _ptr(s_self, torch.float32, 's_self'),
         _ptr(s_neigh, torch.float32, 's_neigh'), _ptr(bias, torch.float32, 'bias'),
         _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y'), 1 if self_loop else 0, n_rows, _stream())
@@ -587,7 +603,7 @@ def gat_bwd(rowptr, colidx, H, s_self, s_neigh, Y, dY, bias, a_self, a_neigh, se
     ds, dt = torch.empty(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
     dH = torch.empty((n, C), dtype=torch.float32, device=dev)
     code = load().amar_gat_bwd_f32(
-        _ptr(rowptr, torch.int32, 'rowptr'), _ptr(colidx, torch.int32, 'colidx'), _ptr(H, torch.float32, 'H'), _ld(H, 'H'), C,
+        _ptr(rowptr, torch.int32, 'rowptr'), _ptr_entries(colidx, torch.int32, 'colidx'), _ptr(H, torch.float32, 'H'), _ld(H, 'H'), C,
         _ptr(s_self, torch.float32, 's_self'), _ptr(s_neigh, torch.float32, 's_neigh'), _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y'),
         _ptr(dY, torch.float32, 'dY'), _ld(dY, 'dY'), _ptr(bias, torch.float32, 'bias'), _ptr(a_self, torch.float32, 'a_self'),
         _ptr(a_neigh, torch.float32, 'a_neigh'), _ptr(dout), _ptr(scratch), _ptr(ds), _ptr(dt), _ptr(dH), C,

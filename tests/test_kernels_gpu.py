@@ -589,3 +589,52 @@ def test_spmm_xcd_sliced_is_reproducible(hip):
     hip.spmm_xs(xs, x, y1)
     hip.spmm_xs(xs, x, y2)
     assert torch.equal(y1, y2)
+
+
+def test_xs_randomised_sweep(hip, monkeypatch):
+    """Many random shapes through the XCD-sliced SpMM (valued, value-free, mean-aggregate) and GAT forms against the row
+    kernels: sizes around the 64-row block and 256-entry super-step boundaries, skewed degrees, duplicates, slice counts."""
+    from deep_cbrs_amar_renaissance_amd.utilities.math import XcdSliced, gcn_filter_device
+    rng = np.random.default_rng(2024)
+    for case in range(40):
+        n = int(rng.choice([1, 2, 63, 64, 65, 127, 129, 200, 511, 777, 1500]))
+        avg = float(rng.choice([0.5, 3, 20, 120]))
+        slices = int(rng.choice([8, 8, 8, 16, 3]))
+        F = int(rng.choice([4, 8, 16]))
+        monkeypatch.setenv('AMAR_XS_SLICES', str(slices))
+        m = _rand_csr(n, min(avg, n), seed=1000 + case, dup=bool(case % 3 == 0)).tocoo()
+        a = _dev_csr(m)
+        x = _t(rng.standard_normal((n, F)).astype(np.float32))
+        y, ycsr = torch.full((n, F), float('nan'), device=DEV), torch.empty((n, F), device=DEV)
+        hip.spmm_xs(XcdSliced.from_csr(a), x, y)
+        hip.spmm_csr(a.rowptr, a.colidx, a.vals, x, ycsr)
+        ref = ycsr.cpu().numpy().astype(np.float64)
+        assert np.abs(y.cpu().numpy() - ref).max() <= 3e-6 * max(1.0, np.abs(ref).max()), (case, n, avg, slices, F)
+        # edge-list forms on the off-diagonal structure of the same matrix
+        keep = m.row != m.col
+        e = _dev_csr(sparse.coo_matrix((m.data[keep], (m.row[keep], m.col[keep])), shape=m.shape), with_values=False)
+        agg, raw = torch.full((n, F), float('nan'), device=DEV), torch.empty((n, F), device=DEV)
+        hip.spmm_xs(e.xcd_sliced_mean(True), x, agg, prescaled=True)
+        hip.spmm_csr(e.rowptr, e.colidx, None, x, raw)
+        want = ((raw + x) / ((e.rowptr[1:] - e.rowptr[:-1]).float() + 1)[:, None]).cpu().numpy()
+        assert np.abs(agg.cpu().numpy() - want).max() <= 3e-6 * max(1.0, np.abs(want).max()), (case, 'mean', n, avg, slices, F)
+        if F == 8:
+            ss, sn = _t((rng.standard_normal(n) * 3).astype(np.float32)), _t((rng.standard_normal(n) * 3).astype(np.float32))
+            b = _t(rng.uniform(-0.3, 0.3, 8).astype(np.float32))
+            yr, yx = torch.empty((n, 8), device=DEV), torch.full((n, 8), float('nan'), device=DEV)
+            loop = bool(case % 2)
+            hip.gat_layer(e.rowptr, e.colidx, x, ss, sn, b, yr, self_loop=loop)
+            hip.gat_xs(e.xcd_sliced(), x, ss, sn, b, yx, self_loop=loop)
+            assert float((yr - yx).abs().max()) <= 2e-5 * max(1.0, float(yr.abs().max())), (case, 'gat', n, avg, slices, loop)
+        # value-free image of a device-built gcn filter over the same symmetric structure
+        if n >= 2 and keep.any():
+            lo = m.row[keep] < m.col[keep]
+            if lo.any():
+                r = torch.from_numpy(m.row[keep][lo].astype(np.int64)).to(DEV)
+                c = torch.from_numpy(m.col[keep][lo].astype(np.int64)).to(DEV)
+                ah = gcn_filter_device(r, c, n)
+                yv, yc = torch.full((n, F), float('nan'), device=DEV), torch.empty((n, F), device=DEV)
+                hip.spmm_xs(ah.xcd_sliced(), x, yv)
+                hip.spmm_csr(ah.rowptr, ah.colidx, ah.vals, x, yc)
+                assert ah.xcd_sliced().row_scale is not None
+                assert float((yv - yc).abs().max()) <= 3e-6 * max(1.0, float(yc.abs().max())), (case, 'value-free', n, avg, slices, F)

@@ -89,3 +89,27 @@ def test_training_batch_of_one_and_all_negative_labels(hip):
     loss0 = trainer.train_batch(g['u_ids'][:50], g['i_ids'][:50], np.zeros(50))
     assert np.isfinite(loss1) and np.isfinite(loss0)
     assert all(torch.isfinite(p).all() for p in model.parameters())
+
+
+def test_randomised_model_sweep(hip):
+    """Small random rating sets — down to one user and one item, or no positive rating at all — through every Basic model
+    family against the oracle (scores within 1e-4, as the parity bar asks)."""
+    from deep_cbrs_amar_renaissance_amd.data.preprocess import build_adjacency_matrix
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    rng = np.random.default_rng(77)
+    kinds = ['BasicGCN', 'BasicGraphSage', 'BasicGAT', 'BasicLightGCN', 'BasicDGCF']
+    for case in range(20):
+        n_users, n_items = int(rng.choice([1, 2, 5, 33, 70])), int(rng.choice([1, 3, 17, 64]))
+        n_r = int(rng.integers(1, 4 * (n_users + n_items)))
+        u = rng.integers(0, n_users, n_r)
+        i = rng.integers(0, n_items, n_r) + n_users
+        lab = (rng.random(n_r) < (0.0 if case == 3 else 0.6)).astype(np.int64)          # case 3: no positive rating -> no edge
+        ratings = np.unique(np.stack([u, i, lab], 1), axis=0)
+        adj = build_adjacency_matrix(ratings, np.arange(n_users), np.arange(n_items))
+        cls = kinds[case % len(kinds)]
+        model = getattr(basic, cls)(adj, **CFG)
+        helpers.randomize_biases(model, seed=case)
+        pu, pi = ratings[:, 0], ratings[:, 1]
+        got = model((pu, pi)).cpu().numpy()
+        want = om.basic_gnn_scores(adj, helpers.gnn_to_oracle(model.gnn), helpers.basic_head_to_oracle(model.rs), pu, pi, dtype=np.float64)
+        assert np.isfinite(got).all() and np.abs(got - want).max() < 1e-4, (case, cls, n_users, n_items, len(ratings))

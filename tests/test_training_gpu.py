@@ -430,3 +430,37 @@ def test_head_only_training(hip, kind):
     model.compile(optimizer=types.SimpleNamespace(learning_rate=5e-3, beta_1=0.9))
     hist = model.fit(Seq(), epochs=40, verbose=False)['loss']
     assert hist[-1] < 0.6 * hist[0], hist[::8]
+
+
+def test_randomised_gradient_sweep(hip):
+    """Tiny random graphs (isolated nodes, batches of 1 ... 40 pairs, repeated pairs) through every trainable Basic family:
+    loss and gradients against the autograd oracle."""
+    from deep_cbrs_amar_renaissance_amd import engine, training
+    from deep_cbrs_amar_renaissance_amd.data.preprocess import build_adjacency_matrix
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    rng = np.random.default_rng(31)
+    kinds = ['BasicGCN', 'BasicGraphSage', 'BasicGAT', 'BasicLightGCN', 'BasicDGCF']
+    for case in range(15):
+        engine.set_seed(case)
+        n_users, n_items = int(rng.choice([2, 7, 40])), int(rng.choice([2, 9, 30]))
+        n_r = int(rng.integers(2, 5 * (n_users + n_items)))
+        ratings = np.unique(np.stack([rng.integers(0, n_users, n_r), rng.integers(0, n_items, n_r) + n_users,
+                                      (rng.random(n_r) < 0.6).astype(np.int64)], 1), axis=0)
+        adj = build_adjacency_matrix(ratings, np.arange(n_users), np.arange(n_items))
+        cls = kinds[case % len(kinds)]
+        model = getattr(basic, cls)(adj, **CFG)
+        helpers.randomize_biases(model, seed=case)
+        b = int(rng.choice([1, 2, 17, 40]))
+        pick = rng.integers(0, len(ratings), b)                       # with repetitions
+        u, i, y = ratings[pick, 0], ratings[pick, 1], ratings[pick, 2]
+        trainer = training.Trainer(model)
+        loss, grads = trainer.loss_and_grads(u, i, y)
+        want_loss, want, _ = otrain.torch_model_grads(adj, helpers.gnn_to_oracle(model.gnn), helpers.basic_head_to_oracle(model.rs),
+                                                      u, i, y, l2=1e-4)
+        assert abs(loss - want_loss) < 1e-5, (case, cls)
+        flat = _flatten_oracle_grads(model, want)
+        assert set(flat) == set(grads)
+        for prm, gw in flat.items():
+            got = grads[prm].cpu().numpy().reshape(gw.shape).astype(np.float64)
+            got += 2 * trainer._l2(prm) * prm.detach().cpu().numpy().reshape(gw.shape)
+            assert np.abs(got - gw).max() <= 3e-4 * np.abs(gw).max() + 1e-9, (case, cls, tuple(prm.shape))

@@ -33,7 +33,7 @@ SIGNATURES = {
                                         _P, _I64, _P, _I64, _F32, _P, _I32, _P, _I64, _P]),
     'amar_gat_xs_f32': (ctypes.c_int, [_P, _P, _I32, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P]),
     'amar_gcn_layer_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _I64, _P, _I32, _P, _I64, _I32, _P]),
-    'amar_rowwise_xw_f32': (ctypes.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _P, _I64, _P, _P, _P, _P, _I32, _P]),
+    'amar_rowwise_xw_f32': (ctypes.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I32, _P]),
     'amar_sage_layer_f32': (ctypes.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _I32, _P, _I64, _I32, _I32, _P]),
     'amar_gat_layer_f32': (ctypes.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _P, _I64, _I32, _I32, _P]),
     'amar_dense_f32': (ctypes.c_int, [_P, _I64, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _P]),
@@ -262,12 +262,14 @@ def gcn_layer(rowptr, colidx, vals, H, bias, Y, Wnext=None, Hnext=None):
     _check(code, 'amar_gcn_layer_f32')
 
 
-def rowwise_xw(X, W, H, copy_to=None, a_self=None, a_neigh=None, s_self=None, s_neigh=None):
+def rowwise_xw(X, W, H, copy_to=None, a_self=None, a_neigh=None, s_self=None, s_neigh=None, row_scale=None):
     n_rows, F = X.shape
     if W.shape[0] != F or not W.is_contiguous() or tuple(H.shape) != (n_rows, W.shape[1]):
         raise ValueError("rowwise_xw: W [F, C] contiguous and H [n_rows, C] expected")
     if copy_to is not None and tuple(copy_to.shape) != (n_rows, F):
         raise ValueError("rowwise_xw: copy_to must be [n_rows, F]")
+    if row_scale is not None and (row_scale.numel() != n_rows or not row_scale.is_contiguous()):
+        raise ValueError("rowwise_xw: row_scale must be a contiguous [n_rows] vector")
     for v, nm in ((s_self, 's_self'), (s_neigh, 's_neigh')):
         if v is not None and (v.numel() != n_rows or not v.is_contiguous()):
             raise ValueError("rowwise_xw: {} must be a contiguous [n_rows] vector".format(nm))
@@ -276,7 +278,8 @@ def rowwise_xw(X, W, H, copy_to=None, a_self=None, a_neigh=None, s_self=None, s_
         _ptr(H, torch.float32, 'H'), _ld(H, 'H'),
         _ptr(copy_to, torch.float32, 'copy_to'), _ld(copy_to, 'copy_to') if copy_to is not None else 0,
         _ptr(a_self, torch.float32, 'a_self'), _ptr(a_neigh, torch.float32, 'a_neigh'),
-        _ptr(s_self, torch.float32, 's_self'), _ptr(s_neigh, torch.float32, 's_neigh'), n_rows, _stream())
+        _ptr(s_self, torch.float32, 's_self'), _ptr(s_neigh, torch.float32, 's_neigh'),
+        _ptr(row_scale, torch.float32, 'row_scale'), n_rows, _stream())
     _check(code, 'amar_rowwise_xw_f32')
 
 

@@ -592,6 +592,7 @@ struct XwArgs {
     float *H; int64_t ldh; float *copy_to; int64_t ld_copy;
     const float *a_self; const float *a_neigh; float *s_self; float *s_neigh;
     int n_rows;
+    const float *row_scale;                      // H rows are multiplied by row_scale[row] (value-free XS image), or NULL
 };
 
 // One wave handles 64/CP rows at a time (CP = C rounded up to a power of two): lane = (row slot, out column).
@@ -607,7 +608,7 @@ __global__ __launch_bounds__(256) void rowwise_xw_kernel(const XwArgs a, int CP)
         float h = 0.f;
         if (c < a.C) {
             for (int k = 0; k < a.F; ++k) h = fmaf(x[k], w_lds[k * a.C + c], h);
-            a.H[row * a.ldh + c] = h;
+            a.H[row * a.ldh + c] = a.row_scale ? h * a.row_scale[row] : h;
         }
         if (a.copy_to) for (int k = c; k < a.F; k += CP) a.copy_to[row * a.ld_copy + k] = x[k];
         if (a.s_self) {
@@ -957,7 +958,7 @@ int amar_gcn_layer_f32(const int32_t *rowptr, const int32_t *colidx, const float
 int amar_rowwise_xw_f32(const float *X, int64_t ldx, int32_t F, const float *W, int32_t C,
                         float *H, int64_t ldh, float *copy_to, int64_t ld_copy,
                         const float *a_self, const float *a_neigh, float *s_self, float *s_neigh,
-                        int32_t n_rows, amar_stream_t stream) {
+                        const float *row_scale, int32_t n_rows, amar_stream_t stream) {
     if (n_rows < 0 || !X || !W || !H || F < 1 || C < 1 || ldx < F || ldh < C) return AMAR_EINVAL;
     if (F > 64 || C > 64) return AMAR_EUNSUPPORTED;
     if (copy_to && ld_copy < F) return AMAR_EINVAL;
@@ -966,7 +967,8 @@ int amar_rowwise_xw_f32(const float *X, int64_t ldx, int32_t F, const float *W, 
     if (n_rows == 0) return AMAR_OK;
     int CP = 1;
     while (CP < C) CP <<= 1;
-    XwArgs a{X, ldx, F, W, C, H, ldh, copy_to, ld_copy, a_self, a_neigh, attn ? s_self : nullptr, s_neigh, n_rows};
+    if (attn && row_scale) return AMAR_EINVAL;                       // the attention scalars are defined on the un-scaled product
+    XwArgs a{X, ldx, F, W, C, H, ldh, copy_to, ld_copy, a_self, a_neigh, attn ? s_self : nullptr, s_neigh, n_rows, row_scale};
     const int rows_per_block = 256 / CP;
     int64_t blocks = ((int64_t)n_rows + rows_per_block - 1) / rows_per_block;
     if (blocks > 8192) blocks = 8192;

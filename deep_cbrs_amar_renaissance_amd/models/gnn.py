@@ -123,12 +123,10 @@ class SequentialGNN(Model):
 
         if layers and all(isinstance(l, GCNConv) for l in layers):
             h = torch.empty((n, widths[1]), dtype=torch.float32, device=dev)
-            capi.rowwise_xw(x, layers[0].kernel, h, copy_to=slices[0])
-            # value-free XS image: the chain of gathered tables stays pre-scaled by d^-1/2 (first one here, the
+            # value-free XS image: the chain of gathered tables stays pre-scaled by d^-1/2 (first one in this X.W launch, the
             # following ones in the combine kernel's epilogue)
             pre = all(spmm_kind(a, widths[k + 1]) == 'xs' for k in range(len(layers))) and a.xcd_sliced().row_scale is not None
-            if pre:
-                capi.row_affine(h, a.xcd_sliced().row_scale, h)
+            capi.rowwise_xw(x, layers[0].kernel, h, copy_to=slices[0], row_scale=a.xcd_sliced().row_scale if pre else None)
             for k, layer in enumerate(layers):
                 nxt = layers[k + 1] if k + 1 < len(layers) else None
                 h_next = torch.empty((n, widths[k + 2]), dtype=torch.float32, device=dev) if nxt is not None else None

@@ -214,8 +214,8 @@ class PartitionedGCNRunner:
         f_cat = sum(widths)
         offs = np.cumsum([0] + widths)
         e_all = torch.empty((self.world * R, f_cat), dtype=torch.float32, device=dev)
-        ops.copy_columns(x0p, e_all[:, :widths[0]])                         # X_0 is a replicated weight
         if self.kind in ('sage', 'gat'):
+            ops.copy_columns(x0p, e_all[:, :widths[0]])                     # X_0 is a replicated weight
             # the rank's row block on the XCD-sliced forms (amar_spmm_xs_f32 mean aggregate / amar_gat_xs_f32): both take a
             # block whose own rows sit at column offset rank * R of the replicated table
             lo = self.rank * R
@@ -242,17 +242,22 @@ class PartitionedGCNRunner:
                 self.dist.all_gather_into_tensor(x_full, y_local)
                 ops.copy_columns(x_full, e_all[:, offs[k + 1]:offs[k + 2]])
             return e_all
+        def pre_scale(width):
+            # value-free XCD-sliced image: the gathered table is pre-scaled by d^-1/2 inside the X.W launch
+            if not self._use_xs(width):
+                return None
+            xs = self.csr.xcd_sliced()
+            return xs.col_scale if xs.row_scale is not None else None
+
         h = torch.empty((self.world * R, widths[1]), dtype=torch.float32, device=dev)
-        ops.rowwise_xw(x0p, layers[0].kernel, h)
+        scale = pre_scale(widths[1])
+        ops.rowwise_xw(x0p, layers[0].kernel, h, copy_to=e_all[:, :widths[0]], row_scale=scale)   # X_0 slice rides along
         for k, layer in enumerate(layers):
             y_local = torch.zeros((R, widths[k + 1]), dtype=torch.float32, device=dev)
             if self._use_xs(widths[k + 1]):
                 # the rank's row block on the XCD-sliced image (value-free when A_hat's factors are known): same kernels
                 # as the single-GPU path, the block's own rows sit at column offset rank * R of the padded table
-                xs = self.csr.xcd_sliced()
-                if xs.row_scale is not None:
-                    ops.row_affine(h, xs.col_scale, h)
-                ops.spmm_xs(xs, h, y_local[:rows], bias=layer.bias, relu=True, prescaled=xs.row_scale is not None)
+                ops.spmm_xs(self.csr.xcd_sliced(), h, y_local[:rows], bias=layer.bias, relu=True, prescaled=scale is not None)
             else:
                 ops.gcn_layer(self.csr.rowptr, self.csr.colidx, self.csr.vals, h, layer.bias, y_local[:rows])
             x_full = torch.empty((self.world * R, widths[k + 1]), dtype=torch.float32, device=dev)
@@ -260,7 +265,8 @@ class PartitionedGCNRunner:
             ops.copy_columns(x_full, e_all[:, offs[k + 1]:offs[k + 2]])
             if k + 1 < len(layers):
                 h = torch.empty((self.world * R, widths[k + 2]), dtype=torch.float32, device=dev)
-                ops.rowwise_xw(x_full, layers[k + 1].kernel, h)
+                scale = pre_scale(widths[k + 2])
+                ops.rowwise_xw(x_full, layers[k + 1].kernel, h, row_scale=scale)
         return e_all
 
     def step(self):

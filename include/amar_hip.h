@@ -123,11 +123,13 @@ int amar_gcn_layer_f32(const int32_t *rowptr, const int32_t *colidx, const float
  *     H[i, 0:C] = X[i, 0:F] . W[F, C]                     F, C <= 64
  *     copy_to != NULL:  copy_to[i, 0:F] = X[i, 0:F]       (X_0 slice of the concat buffer)
  *     a_self/a_neigh != NULL (GAT):  s_self[i] = H[i,:].a_self,  s_neigh[i] = H[i,:].a_neigh
+  * row_scale != NULL (not together with the attention scalars): H[i] is multiplied by row_scale[i] — the pre-scaled table
+ * the value-free form of amar_spmm_xs_f32 gathers from.
  */
 int amar_rowwise_xw_f32(const float *X, int64_t ldx, int32_t F, const float *W, int32_t C,
                         float *H, int64_t ldh, float *copy_to, int64_t ld_copy,
                         const float *a_self, const float *a_neigh, float *s_self, float *s_neigh,
-                        int32_t n_rows, amar_stream_t stream);
+                        const float *row_scale, int32_t n_rows, amar_stream_t stream);
 
 /* One GraphSAGE-mean layer (Spektral 1.x GraphSageConv, built at src/models/gnn.py:354-361):
  *     agg_i = ( [self_loop] X_i + sum_{j in N(i)} X_j ) / ( [self_loop] 1 + |N(i)| )

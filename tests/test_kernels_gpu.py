@@ -128,6 +128,25 @@ def test_rowwise_xw(hip, F, C):
     assert rel_err(sn.cpu().numpy(), want @ a_n) < 3e-6
 
 
+@pytest.mark.parametrize('F,C', [(8, 8), (24, 16), (5, 3)])
+def test_rowwise_xw_row_scale(hip, F, C):
+    """The fused d^-1/2 pre-scale of the value-free XS chain: H = diag(s).(X.W), bit-identical to X.W followed by the
+    separate row_affine pass; together with the attention scalars it is refused."""
+    n = 1234
+    rng = np.random.default_rng(F + C)
+    x, w = _t(rng.standard_normal((n, F)).astype(np.float32)), _t(rng.standard_normal((F, C)).astype(np.float32))
+    s = _t(rng.uniform(0.1, 1.0, n).astype(np.float32))
+    h, h2, cp = torch.empty((n, C), device=DEV), torch.empty((n, C), device=DEV), torch.empty((n, F), device=DEV)
+    hip.rowwise_xw(x, w, h, copy_to=cp, row_scale=s)
+    hip.rowwise_xw(x, w, h2)
+    hip.row_affine(h2, s, h2)
+    assert torch.equal(h, h2)
+    assert torch.equal(cp, x)
+    with pytest.raises(Exception):
+        hip.rowwise_xw(x, w, h, a_self=_t(np.ones(C, np.float32)), a_neigh=_t(np.ones(C, np.float32)),
+                       s_self=torch.empty(n, device=DEV), s_neigh=torch.empty(n, device=DEV), row_scale=s)
+
+
 @pytest.mark.parametrize('F,C', [(8, 8), (16, 16), (32, 32), (4, 8), (8, 5)])
 @pytest.mark.parametrize('self_loop', [True, False])
 def test_sage_layer(hip, F, C, self_loop):

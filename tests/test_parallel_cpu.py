@@ -28,8 +28,10 @@ class NumpyOps:
         dst.copy_(src)
 
     @staticmethod
-    def rowwise_xw(X, W, H, **kw):
+    def rowwise_xw(X, W, H, copy_to=None, **kw):
         H.copy_(X @ W.detach())
+        if copy_to is not None:
+            copy_to.copy_(X)
 
     @staticmethod
     def gcn_layer(rowptr, colidx, vals, H, bias, Y, Wnext=None, Hnext=None):

@@ -586,6 +586,15 @@ int launch_spmm_xs(const XsArgs &pa, const XsCombineArgs &ca, bool fuse, hipStre
 
 bool ld_ok(int64_t ld, int F) { return ld >= F && (ld & 3) == 0; }
 
+// The row kernels are instantiated for widths 4, 8, 16, 32, 64.  Every operation below that is separable by feature
+// column (SpMM and its bias / ReLU / running-sum epilogue, the GAT aggregation once the per-node attention scalars
+// exist) runs any other multiple of 4 as a sequence of column chunks of those widths on strided views: 24 = 16 + 8,
+// 48 = 32 + 16, 96 = 64 + 32 (TwoStep / TwoWay stacks with a 'concatenation' hand-over, tsgnn.py:65-75).
+bool native_width(int F) { return F == 4 || F == 8 || F == 16 || F == 32 || F == 64; }
+int chunk_width(int remaining) { return remaining >= 64 ? 64 : remaining >= 32 ? 32 : remaining >= 16 ? 16 : remaining >= 8 ? 8 : 4; }
+const float *at(const float *p, int o) { return p ? p + o : nullptr; }
+float *at(float *p, int o) { return p ? p + o : nullptr; }
+
 // ---- row-wise X.W prologue -------------------------------------------------------------------
 struct XwArgs {
     const float *X; int64_t ldx; int F; const float *W; int C;
@@ -925,6 +934,16 @@ int amar_spmm_csr_f32(const int32_t *rowptr, const int32_t *colidx, const float 
     if (accum && (!acc_in || !acc_out || !ld_ok(ld_acc_in, F) || !ld_ok(ld_acc_out, F) ||
                   !amar_aligned16(acc_in) || !amar_aligned16(acc_out))) return AMAR_EINVAL;
     if ((flags & AMAR_SPMM_ACCUM_DIV) && !(acc_div != 0.f)) return AMAR_EINVAL;
+    if (!native_width(F)) {
+        if (F < 4 || (F & 3)) return AMAR_EUNSUPPORTED;
+        for (int o = 0, w; o < F; o += w) {
+            w = chunk_width(F - o);
+            const int rc = amar_spmm_csr_f32(rowptr, colidx, vals, X + o, ldx, at(Y, o), ldy, n_rows, w, flags, at(bias, o),
+                                             at(acc_in, o), ld_acc_in, at(acc_out, o), ld_acc_out, acc_div, stream);
+            if (rc != AMAR_OK) return rc;
+        }
+        return AMAR_OK;
+    }
     SpmmArgs a{};
     a.rowptr = rowptr; a.colidx = colidx; a.vals = vals; a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy;
     a.bias = (flags & AMAR_SPMM_BIAS) ? bias : nullptr; a.relu = (flags & AMAR_SPMM_RELU) ? 1 : 0;
@@ -947,6 +966,17 @@ int amar_gcn_layer_f32(const int32_t *rowptr, const int32_t *colidx, const float
         return AMAR_EINVAL;
     if (Wnext && (!Hnext || Cn < 1 || ldhn < Cn)) return AMAR_EINVAL;
     if (Wnext && Cn > 64) return AMAR_EUNSUPPORTED;
+    if (!native_width(C)) {
+        // column chunks; the fused next-layer product needs the whole output row in one lane, so it is not offered here
+        if (C < 4 || (C & 3) || Wnext) return AMAR_EUNSUPPORTED;
+        for (int o = 0, w; o < C; o += w) {
+            w = chunk_width(C - o);
+            const int rc = amar_gcn_layer_f32(rowptr, colidx, vals, H + o, ldh, w, bias + o, Y + o, ldy, nullptr, 0, nullptr, 0,
+                                              n_rows, stream);
+            if (rc != AMAR_OK) return rc;
+        }
+        return AMAR_OK;
+    }
     SpmmArgs a{};
     a.rowptr = rowptr; a.colidx = colidx; a.vals = vals; a.X = H; a.ldx = ldh; a.Y = Y; a.ldy = ldy;
     a.bias = bias; a.relu = 1; a.Wn = Wnext; a.Cn = Cn; a.Hn = Hnext; a.ldhn = ldhn; a.n_rows = n_rows;
@@ -1010,6 +1040,17 @@ int amar_gat_layer_f32(const int32_t *rowptr, const int32_t *colidx,
         return AMAR_EINVAL;
     if (n_rows == 0) return AMAR_OK;
     if (!colidx) return AMAR_EINVAL;
+    if (!native_width(C)) {
+        // the attention coefficients only depend on the per-node scalars: each column chunk recomputes the same softmax
+        if (C < 4 || (C & 3)) return AMAR_EUNSUPPORTED;
+        for (int o = 0, w; o < C; o += w) {
+            w = chunk_width(C - o);
+            const int rc = amar_gat_layer_f32(rowptr, colidx, H + o, ldh, w, s_self, s_neigh, bias + o, Y + o, ldy, self_loop,
+                                              n_rows, stream);
+            if (rc != AMAR_OK) return rc;
+        }
+        return AMAR_OK;
+    }
     GatArgs a{rowptr, colidx, H, ldh, s_self, s_neigh, bias, Y, ldy, self_loop ? 1 : 0, n_rows};
     const dim3 grid((n_rows + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK), block(WAVES_PER_BLOCK * AMAR_WAVE);
     hipStream_t st = static_cast<hipStream_t>(stream);

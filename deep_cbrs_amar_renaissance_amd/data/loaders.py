@@ -15,7 +15,7 @@ import pandas as pd
 from deep_cbrs_amar_renaissance_amd.data import jsonstream
 from deep_cbrs_amar_renaissance_amd.data.datasets import UserItemEmbeddings, HybridUserItemEmbeddings
 from deep_cbrs_amar_renaissance_amd.data.datasets import UserItemGraph, UserItemGraphEmbeddings
-from deep_cbrs_amar_renaissance_amd.data.preprocess import build_adjacency_matrix
+from deep_cbrs_amar_renaissance_amd.data.preprocess import build_adjacency_matrix, get_user_properties
 
 
 def _read_tsv(filepath, sep):
@@ -170,11 +170,16 @@ def load_hybrid_embeddings(
 
 def _graph_ratings(train_ratings_filepath, test_ratings_filepath, props_triples_filepath, sep, type_adjacency,
                    sparse_adjacency, symmetric_adjacency, user_properties):
+    ratings, (users, items), adj_matrix = load_train_test_ratings(
+        train_ratings_filepath, test_ratings_filepath, props_triples_filepath,
+        sep=sep, return_adjacency=True, type_adjacency=type_adjacency,
+        sparse_adjacency=sparse_adjacency, symmetric_adjacency=symmetric_adjacency)
     if user_properties and type_adjacency != 'unary-uip':
-        raise NotImplementedError("user-properties matrices only feed TwoWay models, which are out of scope")
-    return load_train_test_ratings(train_ratings_filepath, test_ratings_filepath, props_triples_filepath,
-                                   sep=sep, return_adjacency=True, type_adjacency=type_adjacency,
-                                   sparse_adjacency=sparse_adjacency, symmetric_adjacency=symmetric_adjacency)
+        # loaders.py:318-321: TwoWay models take (user-item, item-property, user-property); like the reference this
+        # needs the 'unary-kg' pair
+        ui_adj, ip_adj = adj_matrix
+        adj_matrix = (ui_adj, ip_adj, get_user_properties(ui_adj, ip_adj, len(users), len(items)))
+    return ratings, (users, items), adj_matrix
 
 
 def load_user_item_graph(

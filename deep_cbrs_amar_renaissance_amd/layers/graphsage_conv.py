@@ -37,6 +37,15 @@ class GraphSageConv(Layer):
         self.kernel = self.add_weight('kernel', (2 * f_in, self.channels), 'glorot_uniform', self.kernel_regularizer)
         self.bias = self.add_weight('bias', (self.channels,), 'zeros', self.bias_regularizer)
 
+    def _inv_count(self, a):
+        """1 / (edges into the node (+1 with the self loop)); 0 for an empty segment, as unsorted_segment_mean yields."""
+        cache = a.__dict__.setdefault('_sage_inv_count', {})
+        if self.self_loops not in cache:
+            deg = (a.rowptr[1:] - a.rowptr[:-1]).to(torch.float32)
+            inv = 1.0 / (deg + 1.0) if self.self_loops else torch.where(deg > 0, 1.0 / deg.clamp(min=1.0), torch.zeros_like(deg))
+            cache[self.self_loops] = inv.contiguous()
+        return cache[self.self_loops]
+
     def call(self, inputs, out=None, **kwargs):
         x, a = inputs
         if a.vals is not None:
@@ -44,12 +53,19 @@ class GraphSageConv(Layer):
         n, f = a.shape[0], x.shape[1]
         if out is None:
             out = torch.empty((n, self.channels), dtype=torch.float32, device=x.device)
-        if spmm_kind(a, f) != 'xs':
+        kind = spmm_kind(a, f)
+        if kind != 'xs' and f in (4, 8, 16, 32) and self.channels <= 64:
             capi.sage_layer(a.rowptr, a.colidx, x, self.kernel, self.bias, out, self_loop=self.self_loops)
             return out
         xa = torch.empty((n, 2 * f), dtype=torch.float32, device=x.device)
         capi.copy_columns(x, xa[:, :f])
-        capi.spmm_xs(a.xcd_sliced_mean(self.self_loops), x, xa[:, f:], prescaled=True)
+        if kind == 'xs':
+            capi.spmm_xs(a.xcd_sliced_mean(self.self_loops), x, xa[:, f:], prescaled=True)
+        else:
+            # widths the fused row kernel is not instantiated for (TwoStep / TwoWay 'concatenation' hand-over, 24 / 48):
+            # neighbour sum as column chunks of the value-free SpMM, then (sum + own row) / count
+            capi.spmm_csr(a.rowptr, a.colidx, None, x, xa[:, f:])
+            capi.row_affine(xa[:, f:], self._inv_count(a), xa[:, f:], b=x if self.self_loops else None)
         z = torch.empty((n, self.channels), dtype=torch.float32, device=x.device)
         capi.dense(xa, self.kernel, self.bias, z, act=None)
         nrm = torch.empty_like(z)

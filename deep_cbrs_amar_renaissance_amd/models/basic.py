@@ -3,8 +3,8 @@
 ``BasicRS``: two dense towers (user, item), Concatenate, dense classifier ending in
 Dense(1, sigmoid).  ``BasicGNN``: full-graph propagation -> embedding lookup of the batch's
 (user, item) ids -> BasicRS.  The class factory at the bottom generates ``BasicGCN``,
-``BasicGAT``, ``BasicGraphSage``, ``BasicLightGCN`` (and the out-of-scope names, which resolve
-but raise on construction) exactly like `basic.py:90-120`.
+``BasicGAT``, ``BasicGraphSage``, ``BasicLightGCN``, ``BasicDGCF``, ``BasicTS*`` and ``BasicTW*`` exactly like
+`basic.py:90-120`.
 
 Device mapping: the lookup is fused into the first tower layer's load (`amar_dense_f32` with
 ``ids``), each tower's last layer writes its half of the concatenation buffer directly.
@@ -17,6 +17,8 @@ from deep_cbrs_amar_renaissance_amd import capi
 from deep_cbrs_amar_renaissance_amd.engine import Model, ids_to_device, to_device_tensor
 from deep_cbrs_amar_renaissance_amd.models.dense import build_dense_network, build_dense_classifier
 from deep_cbrs_amar_renaissance_amd.models.gnn import GCN, GAT, GraphSage, LightGCN, DGCF
+from deep_cbrs_amar_renaissance_amd.models.tsgnn import TwoStepGCN, TwoStepGraphSage, TwoStepGAT, TwoStepLightGCN, TwoStepDGCF
+from deep_cbrs_amar_renaissance_amd.models.twgnn import TwoWayGCN, TwoWayGraphSage, TwoWayGAT, TwoWayLightGCN, TwoWayDGCF
 
 
 class BasicRS(Model):
@@ -189,31 +191,20 @@ class BasicKnowledgeGCN(BasicGNN):
     pass
 
 
-def _out_of_scope(name):
-    class _OutOfScope:
-        def __init__(self, *args, **kwargs):
-            raise NotImplementedError("{} is out of scope for the HIP path (SURVEY.md §2 row 6)".format(name))
-    _OutOfScope.__name__ = name
-    return _OutOfScope
-
-
 def BasicGNNFactory(name, Parent, GNN):
     def __init__(self, *args, **kwargs):
         Parent.__init__(self, **kwargs)
         self.gnn = self.gnn_class(*args, **kwargs)
-        self.gnn.gnn_layers._build_layers(self.gnn.gnn_layers.layer_widths())
+        self.gnn.build_layers()
         self.rs.build_head(self.gnn.output_dim(), self.gnn.output_dim())
 
     return type(name, (Parent,), {"gnn_class": GNN, "__init__": __init__})
 
 
-_TWO_STEP = ['TwoStepGCN', 'TwoStepGraphSage', 'TwoStepGAT', 'TwoStepLightGCN', 'TwoStepDGCF']
-_TWO_WAY = ['TwoWayGCN', 'TwoWayGraphSage', 'TwoWayGAT', 'TwoWayLightGCN', 'TwoWayDGCF']
-
 BASIC_GNNS = [
     (BasicGNN, [GCN, GAT, GraphSage, LightGCN, DGCF], None),
-    (BasicTSGNN, [_out_of_scope(n) for n in _TWO_STEP], lambda name: 'BasicTS' + name[7:]),
-    (BasicTWGNN, [_out_of_scope(n) for n in _TWO_WAY], lambda name: 'BasicTW' + name[6:]),
+    (BasicTSGNN, [TwoStepGCN, TwoStepGraphSage, TwoStepGAT, TwoStepLightGCN, TwoStepDGCF], lambda name: 'BasicTS' + name[7:]),
+    (BasicTWGNN, [TwoWayGCN, TwoWayGraphSage, TwoWayGAT, TwoWayLightGCN, TwoWayDGCF], lambda name: 'BasicTW' + name[6:]),
 ]
 
 

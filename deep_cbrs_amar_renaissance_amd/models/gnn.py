@@ -12,7 +12,8 @@ the SpMM epilogue ('mean' reduction).  GraphSAGE / GAT consume the raw edge list
 kept, `utilities/math.py`), exactly as the reference hands Spektral an un-normalised matrix
 (`gnn.py:316-319, 349-352`).
 
-The Half/FullInput variants (TwoStep / TwoWay models only) are out of scope.
+``HalfInputSequentialGNN`` / ``FullInputSequentialGNN`` (`gnn.py:87-207`, TwoStep / TwoWay stacks) run the same
+propagation on a node table that is (partly) handed in by the caller.
 """
 import abc
 
@@ -50,13 +51,16 @@ class SequentialGNN(Model):
         :param cache_neighbours: must be False (the reference raises NotImplementedError too, gnn.py:52-53).
         """
         super().__init__()
+        self.embeddings = self.add_weight('embeddings', (adj_matrix.shape[0], embedding_dim),
+                                          'glorot_uniform', regularizer)
+        self._init_stack(adj_matrix, seq_layers, final_node, dropout, cache_neighbours)
+
+    def _init_stack(self, adj_matrix, seq_layers, final_node, dropout, cache_neighbours):
         if cache_neighbours:
             raise NotImplementedError("Multi-hops neighbours caching is not yet completely supported!")
         if dropout:
             raise NotImplementedError("dropout is a training-time feature; inference treats it as identity")
         self.cache_neighbours = cache_neighbours
-        self.embeddings = self.add_weight('embeddings', (adj_matrix.shape[0], embedding_dim),
-                                          'glorot_uniform', regularizer)
         # GraphSAGE / GAT ignore edge values and add their own self loop
         edge_list = any(isinstance(l, (GraphSageConv, GATConv)) for l in seq_layers)
         self.adj_matrix = convert_to_tensor(adj_matrix, with_values=not edge_list, drop_diagonal=edge_list)
@@ -73,8 +77,11 @@ class SequentialGNN(Model):
     def __len__(self):
         return self.n_hops
 
+    def input_width(self):
+        return int(self.embeddings.shape[1])
+
     def layer_widths(self):
-        widths = [int(self.embeddings.shape[1])]
+        widths = [self.input_width()]
         for layer in self.seq_layers:
             widths.append(int(layer.channels) if layer.channels is not None else widths[-1])
         return widths
@@ -86,13 +93,21 @@ class SequentialGNN(Model):
     def _build_layers(self, widths):
         for layer, f_in in zip(self.seq_layers, widths[:-1]):
             if not layer.built:
-                layer.build([(self.embeddings.shape[0], f_in), self.adj_matrix.shape])
+                layer.build([(self.adj_matrix.shape[0], f_in), self.adj_matrix.shape])
                 layer.built = True
 
     def call(self, inputs=None, **kwargs):
-        x, a = self.embeddings, self.adj_matrix
+        return self._propagate(self.embeddings)
+
+    def _propagate(self, x):
+        """The convolution stack + reduction over the node table `x` [N, widths[0]] (gnn.py:74-84)."""
+        a = self.adj_matrix
         n = x.shape[0]
+        if n != a.shape[0]:
+            raise ValueError("node table has {} rows, the adjacency matrix {}".format(n, a.shape[0]))
         widths = self.layer_widths()
+        if int(x.shape[1]) != widths[0]:
+            raise ValueError("node table is {} wide, the stack was built for {}".format(int(x.shape[1]), widths[0]))
         self._build_layers(widths)
         dev = x.device
         layers = list(self.seq_layers)
@@ -121,7 +136,8 @@ class SequentialGNN(Model):
         offs = [sum(widths[:k]) for k in range(len(widths) + 1)]
         slices = [cat[:, offs[k]:offs[k + 1]] for k in range(len(widths))]
 
-        if layers and all(isinstance(l, GCNConv) for l in layers):
+        # (widths the kernels are not instantiated for run layer by layer as column chunks, without the fused next X.W)
+        if layers and all(isinstance(l, GCNConv) for l in layers) and all(w in (4, 8, 16, 32, 64) for w in widths[1:]):
             h = torch.empty((n, widths[1]), dtype=torch.float32, device=dev)
             # value-free XS image: the chain of gathered tables stays pre-scaled by d^-1/2 (first one in this X.W launch, the
             # following ones in the combine kernel's epilogue)
@@ -158,7 +174,68 @@ class SequentialGNN(Model):
         return out
 
 
-class GNN(Model, abc.ABC):
+class HalfInputSequentialGNN(SequentialGNN):
+    """`gnn.py:87-150`: the first `n_random_embeddings` rows of the node table are trainable, the remaining rows are
+    handed in by the caller (TwoStep: users are trained here, items come out of the item-property stack)."""
+
+    def __init__(self, adj_matrix, seq_layers, n_random_embeddings, final_node='concatenation', dropout=None,
+                 embedding_dim=8, regularizer=None, cache_neighbours=False):
+        Model.__init__(self)
+        self.embeddings = self.add_weight('embeddings', (n_random_embeddings, embedding_dim), 'glorot_uniform', regularizer)
+        self._init_stack(adj_matrix, seq_layers, final_node, dropout, cache_neighbours)
+
+    def call(self, inputs=None, **kwargs):
+        e = self.embeddings
+        if inputs is None or inputs.shape[1] != e.shape[1] or e.shape[0] + inputs.shape[0] != self.adj_matrix.shape[0]:
+            raise ValueError("HalfInputSequentialGNN: inputs must be [{}, {}]".format(
+                self.adj_matrix.shape[0] - e.shape[0], e.shape[1]))
+        x = torch.empty((self.adj_matrix.shape[0], e.shape[1]), dtype=torch.float32, device=e.device)
+        capi.copy_columns(e.detach(), x[:e.shape[0]])
+        capi.copy_columns(inputs, x[e.shape[0]:])
+        return self._propagate(x)
+
+
+class FullInputSequentialGNN(SequentialGNN):
+    """`gnn.py:153-207`: no table of its own, the whole node table is handed in (TwoWay's user-item stack).  The input
+    width is fixed by the first call, or by `input_dim` when the owner knows it up front."""
+
+    def __init__(self, adj_matrix, seq_layers, final_node='concatenation', dropout=None, cache_neighbours=False,
+                 input_dim=None):
+        Model.__init__(self)
+        self.input_dim = input_dim
+        self._init_stack(adj_matrix, seq_layers, final_node, dropout, cache_neighbours)
+
+    def input_width(self):
+        if self.input_dim is None:
+            raise ValueError("FullInputSequentialGNN: the input width is unknown before the first call")
+        return int(self.input_dim)
+
+    def call(self, x=None, **kwargs):
+        if x is None:
+            raise ValueError("FullInputSequentialGNN needs the node table as its input")
+        if self.input_dim is None:
+            self.input_dim = int(x.shape[1])
+        return self._propagate(x)
+
+
+class _Hoisted:
+    """One propagation per weight state: legal because the node representations do not depend on the batch
+    (gnn.py:263-264 passes None), see BasicGNN.predict."""
+
+    def _init_hoist(self):
+        self._hoisted = None
+        self.hoist = False
+
+    def _maybe_hoisted(self, run):
+        if not self.hoist:
+            return run()
+        version = self.weights_version
+        if self._hoisted is None or self._hoisted[0] != version:
+            self._hoisted = (version, run())
+        return self._hoisted[1]
+
+
+class GNN(Model, _Hoisted, abc.ABC):
     def __init__(
             self,
             adj_matrix,
@@ -191,8 +268,7 @@ class GNN(Model, abc.ABC):
             dropout=dropout, regularizer=regularizer, cache_neighbours=cache_neighbours
         )
         self.built = True
-        self._hoisted = None
-        self.hoist = False
+        self._init_hoist()
 
     @abc.abstractmethod
     def build_gnn_layer(self, i, **kwargs):
@@ -201,14 +277,12 @@ class GNN(Model, abc.ABC):
     def output_dim(self):
         return self.gnn_layers.output_dim()
 
+    def build_layers(self):
+        self.gnn_layers._build_layers(self.gnn_layers.layer_widths())
+
     def call(self, inputs=None, **kwargs):
         """Node representations [N, F_out]; `inputs` is ignored like in the reference (gnn.py:263-264)."""
-        if not self.hoist:
-            return self.gnn_layers(None)
-        version = self.weights_version
-        if self._hoisted is None or self._hoisted[0] != version:
-            self._hoisted = (version, self.gnn_layers(None))
-        return self._hoisted[1]
+        return self._maybe_hoisted(lambda: self.gnn_layers(None))
 
 
 class GCN(GNN):

@@ -26,7 +26,8 @@ from deep_cbrs_amar_renaissance_amd.engine import Model, ids_to_device, to_devic
 from deep_cbrs_amar_renaissance_amd.layers.fusion import FusionLayer
 from deep_cbrs_amar_renaissance_amd.models.dense import build_dense_classifier, build_dense_network, build_residual_dense_network
 from deep_cbrs_amar_renaissance_amd.models.gnn import GCN, GAT, GraphSage, LightGCN, DGCF
-from deep_cbrs_amar_renaissance_amd.models.basic import _out_of_scope, _TWO_STEP, _TWO_WAY
+from deep_cbrs_amar_renaissance_amd.models.tsgnn import TwoStepGCN, TwoStepGraphSage, TwoStepGAT, TwoStepLightGCN, TwoStepDGCF
+from deep_cbrs_amar_renaissance_amd.models.twgnn import TwoWayGCN, TwoWayGraphSage, TwoWayGAT, TwoWayLightGCN, TwoWayDGCF
 
 
 class HybridCBRS(Model):
@@ -323,7 +324,7 @@ def BasicGNNFactory(name, Parent, GNN):
     def __init__(self, *args, **kwargs):
         Parent.__init__(self, **kwargs)
         self.gnn = self.gnn_class(*args, **kwargs)
-        self.gnn.gnn_layers._build_layers(self.gnn.gnn_layers.layer_widths())
+        self.gnn.build_layers()
 
     return type(name, (Parent,), {"gnn_class": GNN, "__init__": __init__})
 
@@ -338,8 +339,8 @@ class HybridBertTWGNN(HybridBertGNN):
 
 HYBRID_GNNS = [
     (HybridBertGNN, [GCN, GAT, GraphSage, LightGCN, DGCF], None),
-    (HybridBertTSGNN, [_out_of_scope(n) for n in _TWO_STEP], lambda name: 'HybridBertTS' + name[7:]),
-    (HybridBertTWGNN, [_out_of_scope(n) for n in _TWO_WAY], lambda name: 'HybridBertTW' + name[6:]),
+    (HybridBertTSGNN, [TwoStepGCN, TwoStepGraphSage, TwoStepGAT, TwoStepLightGCN, TwoStepDGCF], lambda name: 'HybridBertTS' + name[7:]),
+    (HybridBertTWGNN, [TwoWayGCN, TwoWayGraphSage, TwoWayGAT, TwoWayLightGCN, TwoWayDGCF], lambda name: 'HybridBertTW' + name[6:]),
 ]
 
 

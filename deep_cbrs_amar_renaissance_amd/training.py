@@ -218,6 +218,8 @@ class Trainer:
     """Holds the Adam state of a Basic* / HybridBert* {GCN, GraphSage, GAT, LightGCN} model and performs training batches."""
 
     def __init__(self, model, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, bert_dim=None):
+        if not hasattr(model.gnn, 'gnn_layers'):
+            raise NotImplementedError("training of the TwoStep / TwoWay stacks is not implemented (inference only)")
         seq = model.gnn.gnn_layers
         layers = list(seq.seq_layers)
         if layers and all(isinstance(l, GCNConv) for l in layers) and seq.final_node == 'concatenation':

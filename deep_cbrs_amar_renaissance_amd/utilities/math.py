@@ -218,7 +218,7 @@ def spmm_kind(a, F):
     # (its scan is amortised over only 64/(F/4) lanes' worth of entries)
     table_bytes = a.shape[1] * F * 4
     big = table_bytes >= ((8 << 20) if F <= 8 else (16 << 20))
-    return 'xs' if (a.shape[0] == a.shape[1] and F <= 16 and big) else 'csr'
+    return 'xs' if (a.shape[0] == a.shape[1] and F in (4, 8, 16) and big) else 'csr'
 
 
 def _csr_sliced(self, F):

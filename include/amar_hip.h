@@ -49,7 +49,8 @@ const char *amar_error_string(int code);
 int amar_last_hip_error(void);          /* last hipError_t seen by this thread, 0 if none */
 
 /* ---- propagation --------------------------------------------------------------------------
- * Y[n_rows, F] = A . X   (+ bias, ReLU, running sum)        fp32, CSR, F in {4, 8, 16, 32, 64}
+ * Y[n_rows, F] = A . X   (+ bias, ReLU, running sum)        fp32, CSR, F in {4, 8, 16, 32, 64};
+ * any other multiple of 4 runs as column chunks of those widths (24 = 16 + 8), same results column by column
  * Replaces spektral.layers.ops.modal_dot -> tf.sparse.sparse_dense_matmul at
  * src/layers/lightgcn_conv.py:51-54 and inside GCNConv.call (built at src/models/gnn.py:289-295,
  * invoked at src/models/gnn.py:78).  vals == NULL means an all-ones (binary) matrix.
@@ -110,7 +111,8 @@ int amar_spmm_xs_f32(const float *diag, const int32_t *rowptr, const int32_t *co
  *     Y[i, 0:C]      = ReLU( sum_j A_hat[i,j] . H[j, 0:C] + bias )      H = X_prev . W  (pre-multiplied)
  *     Hnext[i, 0:Cn] = Y[i, :] . Wnext[C, Cn]                            (only if Wnext != NULL)
  * so that layer l's epilogue performs layer l+1's dense product and each layer is ONE kernel.
- * C in {4,8,16,32,64}; Cn <= 64.
+ * C in {4,8,16,32,64}; Cn <= 64.  Other multiples of 4 run as column chunks, without the fused next product
+ * (Wnext must be NULL for them: AMAR_EUNSUPPORTED otherwise).
  */
 int amar_gcn_layer_f32(const int32_t *rowptr, const int32_t *colidx, const float *vals,
                        const float *H, int64_t ldh, int32_t C, const float *bias,
@@ -147,7 +149,8 @@ int amar_sage_layer_f32(const int32_t *rowptr, const int32_t *colidx,
  *     e_ij  = LeakyReLU_0.2( s_self[i] + s_neigh[j] ),  j in N(i) (+ i itself if self_loop)
  *     alpha = exp(e_ij - max_j e_ij) / ( sum_j exp(e_ij - max_j e_ij) + 1e-9 )
  *     Y_i   = ReLU( sum_j alpha_ij H_j + bias )
- * H, s_self, s_neigh come from amar_rowwise_xw_f32.  C in {4,8,16,32,64}.
+ * H, s_self, s_neigh come from amar_rowwise_xw_f32.  C in {4,8,16,32,64}; other multiples of 4 run as column chunks
+ * (the attention coefficients only depend on the per-node scalars).
  */
 int amar_gat_layer_f32(const int32_t *rowptr, const int32_t *colidx,
                        const float *H, int64_t ldh, int32_t C,

@@ -63,6 +63,32 @@ def adjacency_unary_uip(train, triples, n_users, n_items, n_props, symmetric=Tru
     return symmetrize(a) if symmetric else a
 
 
+def adjacency_unary_kg(train, triples, n_users, n_items, n_props, symmetric=True):
+    """preprocess.py:120-152 ('unary-kg') — the user-item graph and, separately, the item-property graph (items first)."""
+    pos = train[:, 2] == 1
+    n_ui, n_kg = n_users + n_items, n_items + n_props
+    bi = sparse.coo_matrix((train[pos, 2], (train[pos, 0], train[pos, 1])), shape=[n_ui, n_ui], dtype=np.float32)
+    kg = sparse.coo_matrix((triples[:, 2], (triples[:, 0], triples[:, 1])), shape=[n_kg, n_kg], dtype=np.float32)
+    return (symmetrize(bi), symmetrize(kg)) if symmetric else (bi, kg)
+
+
+def user_properties(ui_adj, ip_adj, n_users, n_items):
+    """get_user_properties (preprocess.py:9-41), followed literally: stack the two graphs into one user-item-property
+    matrix, square it, binarise, and copy the user x property blocks of the DENSE square (small graphs only)."""
+    n_props = ip_adj.shape[0] - n_items
+    n = n_users + n_items + n_props
+    uip = sparse.coo_matrix((np.concatenate([ui_adj.data, ip_adj.data]),
+                             (np.concatenate([ui_adj.row, ip_adj.row + n_users]),
+                              np.concatenate([ui_adj.col, ip_adj.col + n_users]))), shape=(n, n))
+    sq = uip.dot(uip)
+    sq.data = np.ones(len(sq.data))
+    sq = np.asarray(sq.todense())
+    up = np.zeros((n_users + n_props, n_users + n_props))
+    up[n_users:, :n_users] = sq[n_users + n_items:, :n_users]
+    up[:n_users, n_users:] = sq[:n_users, n_users + n_items:]
+    return sparse.coo_matrix(up)
+
+
 def gcn_filter(a):
     """Spektral 1.x utils.convolution.gcn_filter (call sites gnn.py:283,381; lightgcn_conv.py:56-58).
 

@@ -22,8 +22,15 @@ def propagate(adj, gnn, dtype=np.float32, self_loops=True):
     `adj` is the raw symmetric COO adjacency from build_adjacency_matrix; GCN and LightGCN first
     run gcn_filter on it (gnn.py:283,381), GraphSAGE and GAT consume it as is (gnn.py:316-319,349-352).
     """
+    return propagate_from(adj, gnn['embeddings'], gnn, dtype, self_loops)
+
+
+def propagate_from(adj, x0, gnn, dtype=np.float32, self_loops=True, force_mean=True):
+    """The layer loop + reduction of SequentialGNN / HalfInput / FullInputSequentialGNN.call (gnn.py:74-84, 141-150,
+    197-207) over the node table `x0`.  `force_mean`: the single-graph LightGCN / DGCF classes override final_node with
+    'mean' (gnn.py:378, 405); the TwoStep / TwoWay classes override only their LAST stack's (tsgnn.py:222, twgnn.py:227)."""
     kind = gnn['kind']
-    x = gnn['embeddings'].astype(dtype)
+    x = x0.astype(dtype)
     hs = [x]
     if kind in ('gcn', 'lightgcn'):
         a_hat = ograph.gcn_filter(adj)
@@ -51,8 +58,32 @@ def propagate(adj, gnn, dtype=np.float32, self_loops=True):
             hs.append(x)
     else:
         raise ValueError("Unknown GNN kind {}".format(kind))
-    final_node = 'mean' if kind in ('lightgcn', 'dgcf') else gnn.get('final_node', 'concatenation')   # gnn.py:378, 405
+    final_node = gnn.get('final_node', 'concatenation')
+    if force_mean and kind in ('lightgcn', 'dgcf'):
+        final_node = 'mean'
     return olayers.reduce_layers(hs, final_node)
+
+
+def two_step(adjs, ts, n_users, n_items, dtype=np.float32):
+    """TwoStepGNN.call (tsgnn.py:99-101): step one over the item-property graph, its first |I| rows appended to the
+    trainable user rows (HalfInputSequentialGNN.call, gnn.py:141-142), step two over the user-item graph.
+    adjs = (user-item, item-property) RAW adjacencies; ts = {'step_one': gnn dict, 'step_two': gnn dict}."""
+    adj_ui, adj_kg = adjs
+    x = propagate_from(adj_kg, ts['step_one']['embeddings'], ts['step_one'], dtype, force_mean=False)
+    x0 = np.concatenate([ts['step_two']['embeddings'].astype(dtype), x[:n_items]], axis=0)
+    return propagate_from(adj_ui, x0, ts['step_two'], dtype, force_mean=False)
+
+
+def two_way(adjs, tw, n_users, n_items, dtype=np.float32):
+    """TwoWayGNN.call (twgnn.py:98-105): users out of the user-property stack, items out of the item-property stack,
+    stacked and propagated over the user-item graph (FullInputSequentialGNN).
+    adjs = (user-item, item-property, user-property); tw = {'way_one', 'way_two', 'step_two'} gnn dicts (step_two has
+    no 'embeddings')."""
+    adj_ui, adj_ip, adj_up = adjs
+    users = propagate_from(adj_up, tw['way_one']['embeddings'], tw['way_one'], dtype, force_mean=False)
+    items = propagate_from(adj_ip, tw['way_two']['embeddings'], tw['way_two'], dtype, force_mean=False)
+    x0 = np.concatenate([users[:n_users], items[:n_items]], axis=0)
+    return propagate_from(adj_ui, x0, tw['step_two'], dtype, force_mean=False)
 
 
 def _cast_net(net, dtype):

@@ -125,3 +125,48 @@ def hybrid_head_tweaked(rng, g_dim, b_dim, dense_units, clf_units, bias_range=0.
     else:
         head['clf'] = dense_net(rng, fused, list(clf_units) + [1], bias_range)
     return head
+
+
+def _stack(rng, kind, n_rows, embedding_dim, hiddens, n_layers, final_node, bias_range, table=True):
+    """One SequentialGNN-like stack; LightGCN / DGCF keep the caller's final_node (only the single-graph classes force
+    'mean').  `n_rows` sizes the trainable table (None: FullInput stack, no table) — DGCF gates are per graph node."""
+    n_table, n_nodes = n_rows
+    w = gnn(rng, kind, n_nodes, embedding_dim=embedding_dim, n_hiddens=hiddens, n_layers=n_layers, final_node=final_node,
+            bias_range=bias_range)
+    w['final_node'] = final_node
+    if table:
+        w['embeddings'] = glorot_uniform(rng, (n_table, embedding_dim))
+    else:
+        del w['embeddings']
+    return w
+
+
+def two_step(rng, kind, n_users, n_items, n_props, embedding_dim=8, n_hiddens=(8, 8), n_layers=2, item_node='mean',
+             final_node='concatenation', bias_range=0.0):
+    """TwoStepGNN weights (tsgnn.py:53-81): step one [|I|+|P|, d] over the item-property graph; step two trains the
+    [|U|, d2] user rows.  n_hiddens are the widths of step one; step two's continue the list the way tsgnn.py:65-75
+    does (d (L+1) each for item_node 'concatenation', else d)."""
+    hops = len(n_hiddens) if kind in ('gcn', 'sage', 'gat') else n_layers
+    d2 = embedding_dim * (hops + 1) if (item_node == 'concatenation' and kind in ('gcn', 'sage', 'gat')) else embedding_dim
+    if kind in ('lightgcn', 'dgcf'):
+        final_node = 'mean'                                  # tsgnn.py:222, 252
+    one = _stack(rng, kind, (n_items + n_props, n_items + n_props), embedding_dim, list(n_hiddens), hops, item_node, bias_range)
+    two = _stack(rng, kind, (n_users, n_users + n_items), d2, [d2] * hops, hops, final_node, bias_range)
+    return {'step_one': one, 'step_two': two}
+
+
+def two_way(rng, kind, n_users, n_items, n_props, embedding_dim=8, n_hiddens=(8, 8), n_layers=2, user_item_node='mean',
+            final_node='concatenation', bias_range=0.0):
+    """TwoWayGNN weights (twgnn.py:53-85): way one [|U|+|P|, d] over the user-property graph, way two [|I|+|P|, d] over
+    the item-property graph (same layer widths, separate weights), and the table-less user-item stack."""
+    hops = len(n_hiddens) if kind in ('gcn', 'sage', 'gat') else n_layers
+    d2 = embedding_dim * (hops + 1) if (user_item_node == 'concatenation' and kind in ('gcn', 'sage', 'gat')) else embedding_dim
+    if kind in ('lightgcn', 'dgcf'):
+        final_node = 'mean'                                  # twgnn.py:227, 257
+    one = _stack(rng, kind, (n_users + n_props, n_users + n_props), embedding_dim, list(n_hiddens), hops, user_item_node, bias_range)
+    two = _stack(rng, kind, (n_items + n_props, n_items + n_props), embedding_dim, list(n_hiddens), hops, user_item_node, bias_range)
+    # the user-item stack's first layer consumes whatever the ways hand over
+    tmp = dict(one)
+    in_dim = gnn_out_dim(tmp) if kind in ('gcn', 'sage', 'gat') else embedding_dim
+    three = _stack(rng, kind, (0, n_users + n_items), in_dim, [d2] * hops, hops, final_node, bias_range, table=False)
+    return {'way_one': one, 'way_two': two, 'step_two': three}

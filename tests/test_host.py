@@ -148,7 +148,7 @@ def test_model_classes_resolve_and_param_counts():
     for name in ['HybridBertTSGCN', 'HybridBertTWLightGCN', 'HybridBertDGCF', 'HybridCBRS']:
         assert hasattr(hybrid, name)
     assert count(basic.BasicDGCF(adj, **cfg)) == 80209 + 2 * 9228      # LightGCN's table + one gate per node and layer (n_layers=2)
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(TypeError):                            # the TwoStep classes take (n_users, n_items, adjacencies), experiment.py:143-148
         basic.BasicTSGCN(adj, **cfg)
     with pytest.raises(ValueError):
         basic.BasicGCN(adj, **dict(cfg, final_node='bogus'))

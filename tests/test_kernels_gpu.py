@@ -42,7 +42,7 @@ def _t(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 
 
-@pytest.mark.parametrize('F', [4, 8, 16, 32, 64])
+@pytest.mark.parametrize('F', [4, 8, 16, 32, 64, 12, 24, 48, 96])       # 12 / 24 / 48 / 96 run as column chunks
 @pytest.mark.parametrize('n', [1, 67, 1000])
 def test_spmm_plain(hip, F, n):
     m = _rand_csr(n, 9, seed=F + n)
@@ -69,6 +69,35 @@ def test_spmm_binary_bias_relu_strided(hip):
     got = out.cpu().numpy()
     assert rel_err(got[:, 16:24], want) < 2e-6
     assert np.all(got[:, :16] == 0), "wrote outside its column slice"
+
+
+@pytest.mark.parametrize('C', [24, 48, 20])
+def test_column_chunked_widths(hip, C):
+    """Widths the row kernels are not instantiated for (TwoStep / TwoWay 'concatenation' hand-over: 3 d) run as column
+    chunks inside the C-ABI: the GCN layer, and the SpMM with its whole epilogue (bias, ReLU, running mean), on strided
+    views; nothing outside the C columns is touched.  A fused next-layer product is refused for such a width."""
+    n = 400
+    m = _rand_csr(n, 10, seed=C)
+    a = _dev_csr(m)
+    rng = np.random.default_rng(C)
+    hbuf, b = rng.standard_normal((n, C + 8)).astype(np.float32), rng.uniform(-1, 1, C).astype(np.float32)
+    acc = rng.standard_normal((n, C)).astype(np.float32)
+    hd = _t(hbuf)
+    A = m.tocsr().astype(np.float64)
+    want = np.maximum(A @ hbuf[:, 4:4 + C].astype(np.float64) + b, 0)
+    y = torch.zeros((n, C + 8), device=DEV)
+    hip.gcn_layer(a.rowptr, a.colidx, a.vals, hd[:, 4:4 + C], _t(b), y[:, 8:])
+    got = y.cpu().numpy()
+    assert rel_err(got[:, 8:], want) < 2e-6 and np.all(got[:, :8] == 0)
+    y2, e = torch.zeros((n, C), device=DEV), torch.empty((n, C), device=DEV)
+    hip.spmm_csr(a.rowptr, a.colidx, a.vals, hd[:, 4:4 + C], y2, bias=_t(b), relu=True, acc_in=_t(acc), acc_out=e, acc_div=3)
+    assert torch.equal(y2, y[:, 8:]), "chunked SpMM epilogue and chunked GCN layer must agree bit for bit"
+    assert rel_err(e.cpu().numpy(), (acc.astype(np.float64) + want) / 3) < 2e-6
+    with pytest.raises(Exception):
+        hip.gcn_layer(a.rowptr, a.colidx, a.vals, hd[:, 4:4 + C], _t(b), y[:, 8:], Wnext=_t(rng.standard_normal((C, 8)).astype(np.float32)),
+                      Hnext=torch.empty((n, 8), device=DEV))
+    with pytest.raises(Exception):                           # not a multiple of 4
+        hip.spmm_csr(a.rowptr, a.colidx, a.vals, _t(hbuf[:, :6].copy()), torch.empty((n, 6), device=DEV))
 
 
 def test_spmm_running_mean(hip):
@@ -166,7 +195,7 @@ def test_sage_layer(hip, F, C, self_loop):
     assert rel_err(y.cpu().numpy(), want) < 5e-6
 
 
-@pytest.mark.parametrize('C', [4, 8, 16, 32, 64])
+@pytest.mark.parametrize('C', [4, 8, 16, 32, 64, 24, 48])
 @pytest.mark.parametrize('self_loop', [True, False])
 def test_gat_layer(hip, C, self_loop):
     n, F = 350, 8
@@ -259,9 +288,9 @@ def test_topk_segmented(hip):
 
 def test_bad_arguments_fail_loudly(hip):
     a = _dev_csr(_rand_csr(10, 3, seed=1))
-    x = torch.zeros((10, 12), device=DEV)
+    x = torch.zeros((10, 10), device=DEV)
     with pytest.raises(Exception):
-        hip.spmm_csr(a.rowptr, a.colidx, a.vals, x, torch.empty((10, 12), device=DEV))      # F = 12 unsupported
+        hip.spmm_csr(a.rowptr, a.colidx, a.vals, x, torch.empty((10, 10), device=DEV))      # F = 10: not a multiple of 4
     with pytest.raises(Exception):
         hip.spmm_csr(a.rowptr, a.colidx, a.vals, torch.zeros((10, 8)), torch.empty((10, 8), device=DEV))  # CPU tensor
 

@@ -1,0 +1,139 @@
+"""CPU: TwoStep / TwoWay (tsgnn.py, twgnn.py) — graph construction against the oracle's literal restatement, the oracle
+against hand-computed tiny graphs, model structure (parameter counts, widths, error behaviour).  No device work."""
+import numpy as np
+import pytest
+from scipy import sparse
+
+from oracle import graph as og
+from oracle import models as om
+from oracle import weights as ow
+from tests import helpers
+
+CFG = dict(embedding_dim=8, n_hiddens=[8, 8], n_layers=2, dense_units=[24, 24], clf_units=[48, 48],
+           l2_regularizer=1e-4, final_node='concatenation', aggregate='mean', dropout_rate=0.0, activation='relu')
+
+
+def _same_coo(a, b):
+    return a.shape == b.shape and a.dtype == b.dtype and np.array_equal(a.row, b.row) and np.array_equal(a.col, b.col) \
+        and np.array_equal(a.data, b.data)
+
+
+@pytest.mark.parametrize('symmetric', [True, False])
+@pytest.mark.parametrize('seed', [0, 1])
+def test_kg_graphs_match_the_literal_restatement(symmetric, seed):
+    """'unary-kg' (preprocess.py:120-152) and get_user_properties (preprocess.py:9-41): the product's sparse block
+    products give the very triplets, order and dtype of the dense construction the oracle follows."""
+    g = helpers.kg_graph(n_users=23, n_items=17, n_props=11, n_ratings=150, n_links=40, seed=seed, symmetric=symmetric)
+    want_ui, want_ip = og.adjacency_unary_kg(g['ratings'], g['triples'], 23, 17, 11, symmetric=symmetric)
+    assert _same_coo(g['adj_ui'], want_ui) and _same_coo(g['adj_ip'], want_ip)
+    want_up = og.user_properties(want_ui, want_ip, 23, 17)
+    assert _same_coo(g['adj_up'], want_up)
+    assert g['adj_up'].dtype == np.float64 and g['adj_up'].shape == (23 + 11, 23 + 11)
+    if symmetric:
+        assert abs(g['adj_up'] - g['adj_up'].T).nnz == 0
+    # a user reaches exactly the properties of the items they liked
+    liked = g['ratings'][g['ratings'][:, 2] == 1]
+    want = {(int(u), int(p) - 17) for u, i, _ in liked for it, p, _ in g['triples'] if it == i - 23}
+    got = {(int(r), int(c) - 23) for r, c in zip(g['adj_up'].row, g['adj_up'].col) if r < 23}
+    assert got == want
+
+
+def test_loader_hands_over_three_graphs(tmp_path):
+    """loaders.load_user_item_graph(type_adjacency='unary-kg', user_properties=True) (loaders.py:305-321)."""
+    from deep_cbrs_amar_renaissance_amd.data import loaders
+    rng = np.random.default_rng(0)
+    keys = rng.choice(12 * 9, size=70, replace=False)
+    rows = np.stack([keys // 9 * 7 + 3, keys % 9 * 11 + 5, rng.integers(0, 2, 70)], axis=1)
+    np.savetxt(tmp_path / 'train.tsv', rows, fmt='%d', delimiter='\t')
+    np.savetxt(tmp_path / 'test.tsv', rows[:20], fmt='%d', delimiter='\t')
+    items = np.unique(rows[:, 1])
+    props = np.stack([rng.choice(items, 25), rng.integers(100, 106, 25), rng.integers(0, 2, 25)], axis=1)
+    np.savetxt(tmp_path / 'props.tsv', props, fmt='%d', delimiter='\t')
+    args = (str(tmp_path / 'train.tsv'), str(tmp_path / 'test.tsv'), str(tmp_path / 'props.tsv'))
+    train, test = loaders.load_user_item_graph(*args, type_adjacency='unary-kg', user_properties=True)
+    ui, ip, up = train.adj_matrix
+    nu, ni, n_props = len(train.users), len(train.items), len(np.unique(props[:, 1]))
+    assert ui.shape == (nu + ni, nu + ni) and ip.shape == (ni + n_props, ni + n_props) and up.shape == (nu + n_props, nu + n_props)
+    assert _same_coo(up, og.user_properties(ui, ip, nu, ni))
+    assert test.adj_matrix is train.adj_matrix
+    train2, _ = loaders.load_user_item_graph(*args, type_adjacency='unary-kg')
+    assert len(train2.adj_matrix) == 2
+
+
+def test_oracle_two_step_by_hand():
+    """One user, one item, one property, d = 1, one LightGCN layer per step.  Both graphs are a single edge, so
+    A_hat = [[.5, .5], [.5, .5]]:  step one  X1 = (a+b)/2 for both nodes, item = mean(a, (a+b)/2);
+    step two on [u, item]:  X1 = (u+item)/2, output = mean(X0, X1) = [3u/4 + item/4, u/4 + 3 item/4]."""
+    edge = sparse.coo_matrix(([1.0, 1.0], ([0, 1], [1, 0])), shape=(2, 2), dtype=np.float32)
+    a, b, u = 0.8, -0.4, 0.5
+    ts = {'step_one': {'kind': 'lightgcn', 'embeddings': np.array([[a], [b]]), 'layers': [{}], 'final_node': 'mean'},
+          'step_two': {'kind': 'lightgcn', 'embeddings': np.array([[u]]), 'layers': [{}], 'final_node': 'mean'}}
+    got = om.two_step((edge, edge), ts, 1, 1, np.float64)
+    item = (a + (a + b) / 2) / 2
+    assert np.allclose(got, [[0.75 * u + 0.25 * item], [0.25 * u + 0.75 * item]], atol=1e-7)
+
+
+def test_oracle_two_way_by_hand():
+    """Same single-edge graphs, TwoWay: users from the user-property stack (table [u0, p0]), items from the
+    item-property stack (table [i0, p1]); user_item_node 'last' takes X1 = the pair's average; the user-item stack
+    (final 'concatenation') appends its own average."""
+    edge = sparse.coo_matrix(([1.0, 1.0], ([0, 1], [1, 0])), shape=(2, 2), dtype=np.float32)
+    u0, p0, i0, p1 = 0.3, 0.9, -0.7, 0.1
+    tw = {'way_one': {'kind': 'lightgcn', 'embeddings': np.array([[u0], [p0]]), 'layers': [{}], 'final_node': 'last'},
+          'way_two': {'kind': 'lightgcn', 'embeddings': np.array([[i0], [p1]]), 'layers': [{}], 'final_node': 'last'},
+          'step_two': {'kind': 'lightgcn', 'layers': [{}], 'final_node': 'concatenation'}}
+    got = om.two_way((edge, edge, edge), tw, 1, 1, np.float64)
+    user, item = (u0 + p0) / 2, (i0 + p1) / 2
+    assert np.allclose(got, [[user, (user + item) / 2], [item, (user + item) / 2]], atol=1e-7)
+
+
+@pytest.mark.parametrize('node', ['mean', 'concatenation'])
+def test_structure_and_parameter_counts(node):
+    """Widths follow tsgnn.py:65-75 / twgnn.py:74-80; trainable parameters = every table + every layer + the head, and
+    equal the oracle's seeded weight sets (oracle/weights.py) built from the same rules."""
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    g = helpers.kg_graph(seed=2)
+    nu, ni, n_props, d = g['n_users'], g['n_items'], g['n_props'], 8
+    d2 = 24 if node == 'concatenation' else 8
+    gcn = lambda f, c: f * c + c
+    head = lambda f: 2 * (gcn(f, 24) + gcn(24, 24)) + gcn(48, 48) + gcn(48, 48) + 49
+
+    ts = basic.BasicTSGCN(nu, ni, (g['adj_ui'], g['adj_ip']), **dict(CFG, item_node=node))
+    assert ts.gnn.n_hiddens == [8, 8, d2, d2]
+    assert ts.gnn.step_one_gnn_layers.embeddings.shape == (ni + n_props, d)
+    assert ts.gnn.step_two_gnn_layers.embeddings.shape == (nu, d2)
+    assert ts.gnn.output_dim() == 3 * d2
+    want = (ni + n_props) * d + 2 * gcn(8, 8) + nu * d2 + 2 * gcn(d2, d2) + head(3 * d2)
+    assert sum(p.numel() for p in ts.parameters()) == want
+    w = ow.two_step(np.random.default_rng(0), 'gcn', nu, ni, n_props, item_node=node)
+    assert om.count_params(w['step_one'], w['step_two']) == want - head(3 * d2)
+    assert om.two_step((g['adj_ui'], g['adj_ip']), w, nu, ni).shape == (nu + ni, 3 * d2)
+
+    tw = basic.BasicTWGCN(nu, ni, (g['adj_ui'], g['adj_ip'], g['adj_up']), **dict(CFG, user_item_node=node))
+    assert tw.gnn.n_hiddens == [8, 8, d2, d2]
+    assert tw.gnn.way_one_gnn_layers.embeddings.shape == (nu + n_props, d)
+    assert tw.gnn.way_two_gnn_layers.embeddings.shape == (ni + n_props, d)
+    assert not hasattr(tw.gnn.step_two_gnn_layers, 'embeddings')
+    assert tw.gnn.output_dim() == 3 * d2
+    want = (nu + n_props) * d + (ni + n_props) * d + 4 * gcn(8, 8) + 2 * gcn(d2, d2) + head(3 * d2)
+    assert sum(p.numel() for p in tw.parameters()) == want
+    w = ow.two_way(np.random.default_rng(0), 'gcn', nu, ni, n_props, user_item_node=node)
+    assert om.count_params(w['way_one'], w['way_two'], w['step_two']) == want - head(3 * d2)
+    assert om.two_way((g['adj_ui'], g['adj_ip'], g['adj_up']), w, nu, ni).shape == (nu + ni, 3 * d2)
+
+
+@pytest.mark.parametrize('kind', ['GCN', 'GraphSage', 'GAT', 'LightGCN', 'DGCF'])
+def test_every_generated_class_builds(kind):
+    """basic.py:99-120 / hybrid.py:160-181: BasicTS*, BasicTW*, HybridBertTS*, HybridBertTW* resolve and build."""
+    from deep_cbrs_amar_renaissance_amd.models import basic, hybrid
+    g = helpers.kg_graph(seed=1)
+    two, three = (g['adj_ui'], g['adj_ip']), (g['adj_ui'], g['adj_ip'], g['adj_up'])
+    hcfg = dict(CFG, dense_units=[[24, 24], [32, 16], [16, 16]], feature_based=True)
+    for cls, adjs, cfg in ((getattr(basic, 'BasicTS' + kind), two, CFG), (getattr(basic, 'BasicTW' + kind), three, CFG),
+                           (getattr(hybrid, 'HybridBertTS' + kind), two, hcfg), (getattr(hybrid, 'HybridBertTW' + kind), three, hcfg)):
+        model = cls(g['n_users'], g['n_items'], adjs, **cfg)
+        assert issubclass(cls, (basic.BasicTSGNN, basic.BasicTWGNN, hybrid.HybridBertTSGNN, hybrid.HybridBertTWGNN))
+        assert sum(p.numel() for p in model.gnn.parameters()) > 0
+        if kind in ('LightGCN', 'DGCF'):
+            assert model.gnn.step_two_gnn_layers.final_node == 'mean'         # tsgnn.py:222,252 / twgnn.py:227,257
+            assert model.gnn.output_dim() == 8

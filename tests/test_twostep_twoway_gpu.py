@@ -1,0 +1,161 @@
+"""GPU parity of the TwoStep / TwoWay stacks (tsgnn.py, twgnn.py) against the oracle (pytest -m gpu).
+
+Same bar as the single-graph models: node representations within 1e-5 relative, scores within 1e-4 of the fp64 oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import models as om
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(embedding_dim=8, n_hiddens=[8, 8], n_layers=2, dense_units=[24, 24], clf_units=[48, 48],
+           l2_regularizer=1e-4, final_node='concatenation', aggregate='mean', dropout_rate=0.0, activation='relu')
+KINDS = ['GCN', 'GraphSage', 'GAT', 'LightGCN', 'DGCF']
+
+
+def _perturb(model, seed):
+    """Zero biases and unit DGCF gates hide bugs: draw both at random."""
+    helpers.randomize_biases(model, seed=seed)
+    rng = np.random.default_rng(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith('.w'):
+                p.add_(torch.from_numpy(rng.uniform(-1.5, 1.5, tuple(p.shape)).astype(np.float32)).to(p.device))
+
+
+def _ml1m_kg(ml1m_s1, n_train=None, n_links=None):
+    from deep_cbrs_amar_renaissance_amd.data.preprocess import build_adjacency_matrix, get_user_properties
+    tr = ml1m_s1['train'] if n_train is None else ml1m_s1['train'][:n_train]
+    trip = ml1m_s1['triples'] if n_links is None else ml1m_s1['triples'][:n_links]
+    users, items, props = ml1m_s1['users'], ml1m_s1['items'], ml1m_s1['props']
+    ui, ip = build_adjacency_matrix(tr, users, items, trip, props, 'unary-kg')
+    return ui, ip, get_user_properties(ui, ip, len(users), len(items))
+
+
+@pytest.mark.parametrize('kind', KINDS)
+@pytest.mark.parametrize('item_node', ['mean', 'concatenation'])
+def test_two_step_small(hip, kind, item_node):
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    if item_node == 'concatenation' and kind in ('LightGCN', 'DGCF'):
+        pytest.skip("weight-free stacks cannot widen the user table (the reference fails in tf.concat as well)")
+    g = helpers.kg_graph(seed=3)
+    model = getattr(basic, 'BasicTS' + kind)(g['n_users'], g['n_items'], (g['adj_ui'], g['adj_ip']), **dict(CFG, item_node=item_node))
+    _perturb(model, 7)
+    ts = helpers.two_step_to_oracle(model.gnn)
+    want_e = om.two_step((g['adj_ui'], g['adj_ip']), ts, g['n_users'], g['n_items'], np.float64)
+    got_e = model.gnn(None).cpu().numpy()
+    assert got_e.shape == want_e.shape == (g['n_users'] + g['n_items'], model.gnn.output_dim())
+    assert helpers.rel_err(got_e, want_e) < 1e-5
+    got = model((g['u_ids'], g['i_ids'])).cpu().numpy()
+    want = om.basic_rs(want_e[g['u_ids']], want_e[g['i_ids']], {k: [(w.astype(np.float64), b.astype(np.float64)) for w, b in v]
+                                                              for k, v in helpers.basic_head_to_oracle(model.rs).items()})
+    assert np.abs(got - want).max() < 1e-4
+
+
+@pytest.mark.parametrize('kind', KINDS)
+@pytest.mark.parametrize('user_item_node', ['mean', 'concatenation'])
+def test_two_way_small(hip, kind, user_item_node):
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    g = helpers.kg_graph(seed=4)
+    adjs = (g['adj_ui'], g['adj_ip'], g['adj_up'])
+    model = getattr(basic, 'BasicTW' + kind)(g['n_users'], g['n_items'], adjs, **dict(CFG, user_item_node=user_item_node))
+    _perturb(model, 9)
+    tw = helpers.two_way_to_oracle(model.gnn)
+    want_e = om.two_way(adjs, tw, g['n_users'], g['n_items'], np.float64)
+    got_e = model.gnn(None).cpu().numpy()
+    assert got_e.shape == want_e.shape == (g['n_users'] + g['n_items'], model.gnn.output_dim())
+    assert helpers.rel_err(got_e, want_e) < 1e-5
+    got = model((g['u_ids'], g['i_ids'])).cpu().numpy()
+    want = om.basic_rs(want_e[g['u_ids']], want_e[g['i_ids']], {k: [(w.astype(np.float64), b.astype(np.float64)) for w, b in v]
+                                                              for k, v in helpers.basic_head_to_oracle(model.rs).items()})
+    assert np.abs(got - want).max() < 1e-4
+
+
+@pytest.mark.parametrize('kind', ['GCN', 'GraphSage', 'GAT', 'LightGCN'])
+def test_two_step_ml1m(hip, ml1m_s1, kind):
+    """ML-1M-shape graphs (9 228 + 20 746 nodes): hoisted predict over the whole test file equals the oracle."""
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    ui, ip, _ = _ml1m_kg(ml1m_s1)
+    nu, ni = len(ml1m_s1['users']), len(ml1m_s1['items'])
+    model = getattr(basic, 'BasicTS' + kind)(nu, ni, (ui, ip), **CFG)
+    _perturb(model, 11)
+    helpers.spread_scores(model)
+    data = ml1m_s1['test'][:20000]
+    u, i = data[:, 0], data[:, 1]
+    want_e = om.two_step((ui, ip), helpers.two_step_to_oracle(model.gnn), nu, ni, np.float64)
+    assert helpers.rel_err(model.gnn(None).cpu().numpy(), want_e) < 1e-5
+    head = {k: [(w.astype(np.float64), b.astype(np.float64)) for w, b in v] for k, v in helpers.basic_head_to_oracle(model.rs).items()}
+    want = om.basic_rs(want_e[u], want_e[i], head)
+    got = model((u, i)).cpu().numpy()
+    assert np.abs(got - want).max() < 1e-4
+
+
+@pytest.mark.parametrize('kind', ['GCN', 'GraphSage', 'GAT', 'LightGCN'])
+def test_two_way_ml1m(hip, ml1m_s1, kind):
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    ui, ip, up = _ml1m_kg(ml1m_s1)
+    nu, ni = len(ml1m_s1['users']), len(ml1m_s1['items'])
+    model = getattr(basic, 'BasicTW' + kind)(nu, ni, (ui, ip, up), **CFG)
+    _perturb(model, 13)
+    helpers.spread_scores(model)
+    data = ml1m_s1['test'][:20000]
+    u, i = data[:, 0], data[:, 1]
+    want_e = om.two_way((ui, ip, up), helpers.two_way_to_oracle(model.gnn), nu, ni, np.float64)
+    assert helpers.rel_err(model.gnn(None).cpu().numpy(), want_e) < 1e-5
+    head = {k: [(w.astype(np.float64), b.astype(np.float64)) for w, b in v] for k, v in helpers.basic_head_to_oracle(model.rs).items()}
+    want = om.basic_rs(want_e[u], want_e[i], head)
+    got = model((u, i)).cpu().numpy()
+    assert np.abs(got - want).max() < 1e-4
+
+
+def test_two_way_dgcf_subgraph(hip, ml1m_s1):
+    """DGCF's cross-hop product on a sub-sampled ML-1M graph (the full one has ~45 M entries), all three graphs."""
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    ui, ip, up = _ml1m_kg(ml1m_s1, n_train=40000, n_links=3000)
+    nu, ni = len(ml1m_s1['users']), len(ml1m_s1['items'])
+    model = basic.BasicTWDGCF(nu, ni, (ui, ip, up), **CFG)
+    _perturb(model, 17)
+    want_e = om.two_way((ui, ip, up), helpers.two_way_to_oracle(model.gnn), nu, ni, np.float64)
+    assert helpers.rel_err(model.gnn(None).cpu().numpy(), want_e) < 1e-5
+
+
+def test_hybrid_two_step(hip):
+    """HybridBertTSGCN (hybrid.py:160-181): the TwoStep stack under the hybrid head, BERT rows travelling with the batch."""
+    from deep_cbrs_amar_renaissance_amd.models import hybrid
+    g = helpers.kg_graph(seed=5)
+    cfg = dict(CFG, dense_units=[[24, 24], [32, 16], [16, 16]], clf_units=[16, 16], feature_based=True)
+    model = hybrid.HybridBertTSGCN(g['n_users'], g['n_items'], (g['adj_ui'], g['adj_ip']), **cfg)
+    rng = np.random.default_rng(0)
+    bert = (rng.standard_normal((g['n_users'] + g['n_items'], 48)) * 0.5).astype(np.float32)
+    u, i = g['u_ids'], g['i_ids']
+    got = model((u, i, bert[u], bert[i])).cpu().numpy()
+    _perturb(model, 19)
+    got = model((u, i, bert[u], bert[i])).cpu().numpy()
+    want_e = om.two_step((g['adj_ui'], g['adj_ip']), helpers.two_step_to_oracle(model.gnn), g['n_users'], g['n_items'], np.float64)
+    b64 = bert.astype(np.float64)
+    want = om.hybrid_cbrs(want_e[u], want_e[i], b64[u], b64[i], helpers.hybrid_head_to_oracle(model.rs))
+    assert np.abs(got - want).max() < 1e-4
+
+
+def test_hoisted_predict_and_errors(hip):
+    """predict() runs each stack once per weight state; malformed adjacency tuples and width mismatches raise ValueError
+    like the reference (tsgnn.py:50-51, twgnn.py:50-51)."""
+    from deep_cbrs_amar_renaissance_amd.data.datasets import UserItemGraph
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    g = helpers.kg_graph(seed=6)
+    adjs = (g['adj_ui'], g['adj_ip'], g['adj_up'])
+    model = basic.BasicTWGCN(g['n_users'], g['n_items'], adjs, **CFG)
+    ratings = np.stack([g['u_ids'], g['i_ids'], np.zeros_like(g['u_ids'])], axis=1)
+    seq = UserItemGraph(ratings, g['users'], g['items'], adjs, batch_size=64)
+    pred = model.predict(seq)
+    direct = model((g['u_ids'], g['i_ids'])).cpu().numpy()
+    assert pred.shape == (len(ratings), 1) and np.abs(pred - direct).max() < 1e-6
+    with pytest.raises(ValueError):
+        basic.BasicTSGCN(g['n_users'], g['n_items'], adjs, **CFG)
+    with pytest.raises(ValueError):
+        basic.BasicTWGCN(g['n_users'], g['n_items'], adjs[:2], **CFG)
+    with pytest.raises(ValueError):                           # 'last' hands over 4-wide items to an 8-wide user table
+        basic.BasicTSGCN(g['n_users'], g['n_items'], adjs[:2], **dict(CFG, n_hiddens=[8, 4], item_node='last'))

@@ -200,7 +200,7 @@ struct GatBwdArgs {
     const int32_t *rowptr; const int32_t *colidx; const float *H; int64_t ldh; const float *s_self; const float *s_neigh;
     const float *Y; int64_t ldy; const float *dY; int64_t ldd; const float *bias; const float *a_self; const float *a_neigh;
     float *dout; float *row_max; float *row_inv; float *row_c; float *ds; float *dt; float *dH; int64_t lddh;
-    int self_loop; int n_rows;
+    int self_loop; int n_rows; int C;
 };
 
 __device__ __forceinline__ float leaky02(float x) { return x > 0.f ? x : 0.2f * x; }
@@ -212,20 +212,24 @@ __device__ __forceinline__ float group_sum(float v) {               // over the 
     return v;
 }
 
-template <int C>
+// LPN = lanes per node = C / 4 rounded up to a power of two (the group sums are xor-shuffles); for widths in between
+// (C = 24: 6 of 8 lanes) the surplus lanes carry zeros and store nothing.
+template <int LPN>
 __global__ __launch_bounds__(256) void gat_bwd_target_kernel(const GatBwdArgs a) {
-    constexpr int LPN = C / 4, NS = AMAR_WAVE / LPN;
+    constexpr int NS = AMAR_WAVE / LPN;
+    const int C = a.C;
     const int lane = threadIdx.x & (AMAR_WAVE - 1);
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.n_rows) return;
     const int q = lane % LPN, slot = lane / LPN;
+    const bool live = 4 * q < C;
     const int beg = a.rowptr[row], end = a.rowptr[row + 1];
     const float si = a.s_self[row];
-    const float4 y = *reinterpret_cast<const float4 *>(a.Y + (int64_t)row * a.ldy + 4 * q);
-    const float4 dy = *reinterpret_cast<const float4 *>(a.dY + (int64_t)row * a.ldd + 4 * q);
-    const float4 b = *reinterpret_cast<const float4 *>(a.bias + 4 * q);
+    const float4 y = live ? *reinterpret_cast<const float4 *>(a.Y + (int64_t)row * a.ldy + 4 * q) : f4_zero();
+    const float4 dy = live ? *reinterpret_cast<const float4 *>(a.dY + (int64_t)row * a.ldd + 4 * q) : f4_zero();
+    const float4 b = live ? *reinterpret_cast<const float4 *>(a.bias + 4 * q) : f4_zero();
     const float4 g = make_float4(y.x > 0.f ? dy.x : 0.f, y.y > 0.f ? dy.y : 0.f, y.z > 0.f ? dy.z : 0.f, y.w > 0.f ? dy.w : 0.f);
-    if (slot == 0) *reinterpret_cast<float4 *>(a.dout + (int64_t)row * C + 4 * q) = g;
+    if (slot == 0 && live) *reinterpret_cast<float4 *>(a.dout + (int64_t)row * C + 4 * q) = g;
     const float ci = wave_sum_stride<1>(slot == 0 ? dot4(g, make_float4(y.x - b.x, y.y - b.y, y.z - b.z, y.w - b.w)) : 0.f);
     // softmax statistics as in the forward kernel
     float mn = a.self_loop ? a.s_neigh[row] : -INFINITY;
@@ -241,7 +245,7 @@ __global__ __launch_bounds__(256) void gat_bwd_target_kernel(const GatBwdArgs a)
     auto edge = [&](int j) {
         const float pre = si + a.s_neigh[j];
         const float alpha = expf(leaky02(pre) - emax) * inv;
-        const float4 h = *reinterpret_cast<const float4 *>(a.H + (int64_t)j * a.ldh + 4 * q);
+        const float4 h = live ? *reinterpret_cast<const float4 *>(a.H + (int64_t)j * a.ldh + 4 * q) : f4_zero();
         const float dalpha = group_sum<LPN>(dot4(g, h));
         const float dpre = alpha * (dalpha - ci) * (pre > 0.f ? 1.f : 0.2f);
         if (q == 0) ds += dpre;
@@ -253,22 +257,24 @@ __global__ __launch_bounds__(256) void gat_bwd_target_kernel(const GatBwdArgs a)
     if (lane == 0) { a.ds[row] = ds; a.row_max[row] = emax; a.row_inv[row] = inv; a.row_c[row] = ci; }
 }
 
-template <int C>
+template <int LPN>
 __global__ __launch_bounds__(256) void gat_bwd_source_kernel(const GatBwdArgs a) {
-    constexpr int LPN = C / 4, NS = AMAR_WAVE / LPN;
+    constexpr int NS = AMAR_WAVE / LPN;
+    const int C = a.C;
     const int lane = threadIdx.x & (AMAR_WAVE - 1);
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.n_rows) return;
     const int q = lane % LPN, slot = lane / LPN;
+    const bool live = 4 * q < C;
     const int beg = a.rowptr[row], end = a.rowptr[row + 1];
     const float tj = a.s_neigh[row];
-    const float4 h = *reinterpret_cast<const float4 *>(a.H + (int64_t)row * a.ldh + 4 * q);
+    const float4 h = live ? *reinterpret_cast<const float4 *>(a.H + (int64_t)row * a.ldh + 4 * q) : f4_zero();
     float4 acc = f4_zero();
     float dt = 0.f;
     auto edge = [&](int i) {
         const float pre = a.s_self[i] + tj;
         const float alpha = expf(leaky02(pre) - a.row_max[i]) * a.row_inv[i];
-        const float4 g = *reinterpret_cast<const float4 *>(a.dout + (int64_t)i * C + 4 * q);
+        const float4 g = live ? *reinterpret_cast<const float4 *>(a.dout + (int64_t)i * C + 4 * q) : f4_zero();
         acc = f4_fma(alpha, g, acc);
         const float dalpha = group_sum<LPN>(dot4(g, h));
         const float dpre = alpha * (dalpha - a.row_c[i]) * (pre > 0.f ? 1.f : 0.2f);
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(256) void gat_bwd_source_kernel(const GatBwdArgs a)
     if (a.self_loop && slot == 0) edge(row);
     acc = f4_wave_sum_stride<LPN>(acc);
     dt = wave_sum_stride<1>(dt);
-    if (slot == 0) {
+    if (slot == 0 && live) {
         const float ds = a.ds[row];
         const float4 as = *reinterpret_cast<const float4 *>(a.a_self + 4 * q);
         const float4 an = *reinterpret_cast<const float4 *>(a.a_neigh + 4 * q);
@@ -289,11 +295,11 @@ __global__ __launch_bounds__(256) void gat_bwd_source_kernel(const GatBwdArgs a)
     if (lane == 0) a.dt[row] = dt;
 }
 
-template <int C>
+template <int LPN>
 void launch_gat_bwd(const GatBwdArgs &a, hipStream_t st) {
     const dim3 grid((a.n_rows + 3) / 4), block(256);
-    hipLaunchKernelGGL(gat_bwd_target_kernel<C>, grid, block, 0, st, a);
-    hipLaunchKernelGGL(gat_bwd_source_kernel<C>, grid, block, 0, st, a);
+    hipLaunchKernelGGL(gat_bwd_target_kernel<LPN>, grid, block, 0, st, a);
+    hipLaunchKernelGGL(gat_bwd_source_kernel<LPN>, grid, block, 0, st, a);
 }
 
 // The same update with the step size read from device memory, and the one-thread kernel that advances it:
@@ -547,16 +553,14 @@ int amar_gat_bwd_f32(const int32_t *rowptr, const int32_t *colidx, const float *
     if (n_rows == 0) return AMAR_OK;
     if (!colidx) return AMAR_EINVAL;
     GatBwdArgs a{rowptr, colidx, H, ldh, s_self, s_neigh, Y, ldy, dY, ldd, bias, a_self, a_neigh, dout,
-                 row_scratch, row_scratch + n_rows, row_scratch + 2 * (int64_t)n_rows, ds, dt, dH, lddh, self_loop ? 1 : 0, n_rows};
+                 row_scratch, row_scratch + n_rows, row_scratch + 2 * (int64_t)n_rows, ds, dt, dH, lddh, self_loop ? 1 : 0, n_rows, C};
     hipStream_t st = static_cast<hipStream_t>(stream);
-    switch (C) {
-    case 4:  launch_gat_bwd<4>(a, st); break;
-    case 8:  launch_gat_bwd<8>(a, st); break;
-    case 16: launch_gat_bwd<16>(a, st); break;
-    case 32: launch_gat_bwd<32>(a, st); break;
-    case 64: launch_gat_bwd<64>(a, st); break;
-    default: return AMAR_EUNSUPPORTED;
-    }
+    if (C < 4 || C > 64 || (C & 3)) return AMAR_EUNSUPPORTED;
+    if (C <= 4) launch_gat_bwd<1>(a, st);
+    else if (C <= 8) launch_gat_bwd<2>(a, st);
+    else if (C <= 16) launch_gat_bwd<4>(a, st);
+    else if (C <= 32) launch_gat_bwd<8>(a, st);
+    else launch_gat_bwd<16>(a, st);
     return amar_check_launch();
 }
 

@@ -99,8 +99,10 @@ class SequentialGNN(Model):
     def call(self, inputs=None, **kwargs):
         return self._propagate(self.embeddings)
 
-    def _propagate(self, x):
-        """The convolution stack + reduction over the node table `x` [N, widths[0]] (gnn.py:74-84)."""
+    def _propagate(self, x, with_layers=False):
+        """The convolution stack + reduction over the node table `x` [N, widths[0]] (gnn.py:74-84).
+        with_layers: also return the [N, sum(widths)] buffer of every layer's output (None on LightGCN's running-sum
+        route, which never materialises it) — what the reverse pass of training.py reads."""
         a = self.adj_matrix
         n = x.shape[0]
         if n != a.shape[0]:
@@ -130,7 +132,7 @@ class SequentialGNN(Model):
                     capi.spmm_csr(a.rowptr, a.colidx, a.vals, x, nxt, acc_in=acc, acc_out=acc_out,
                                   acc_div=len(layers) + 1 if last else None)
                 x, acc = nxt, acc_out
-            return acc
+            return (acc, None) if with_layers else acc
 
         cat = torch.empty((n, sum(widths)), dtype=torch.float32, device=dev)
         offs = [sum(widths[:k]) for k in range(len(widths) + 1)]
@@ -163,13 +165,18 @@ class SequentialGNN(Model):
             for k, layer in enumerate(layers):
                 layer([slices[k], a], out=slices[k + 1])
 
+        out = self._reduce(cat, slices, widths)
+        return (out, cat) if with_layers else out
+
+    def _reduce(self, cat, slices, widths):
+        """ReductionLayer (reduction.py:9-33) over the column slices of `cat`."""
         if self.final_node == 'concatenation':
             return cat
         if self.final_node == 'last':
             return slices[-1]
         if len(set(widths)) != 1:
             raise ValueError("'{}' needs layers of equal width".format(self.final_node))
-        out = torch.empty((n, widths[0]), dtype=torch.float32, device=dev)
+        out = torch.empty((cat.shape[0], widths[0]), dtype=torch.float32, device=cat.device)
         capi.reduce_layers(cat, len(widths), widths[0], out, mean=self.final_node == 'mean')
         return out
 

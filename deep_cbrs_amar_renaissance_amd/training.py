@@ -11,12 +11,16 @@ training kernels of `csrc/amar_train.hip` (activation backward, two-stage determ
 gradients, row scatter-add for the embedding lookup, Adam) and reuses the forward SpMM for
 A_hat^T . dZ (A_hat is symmetric) and the forward GEMM for dX = dZ . W^T.
 
-Implemented for GCN, GraphSAGE (both 'concatenation') and LightGCN ('mean') stacks.  GraphSAGE trains on an
-unfused forward that keeps what the reverse pass needs ([x || mean] and the normalised pre-activation); its
-aggregate (A + I) / count is symmetric up to the row scale, so the reverse aggregate is the same value-free SpMM.
-The hybrid head (HybridCBRS, 'concatenate' fusion, both feature_based settings) trains on the same Dense tapes; its
-BERT inputs are constants.  GAT (1 head) trains on the inference kernels plus `amar_gat_bwd_f32`, which forms the
-softmax / attention-scalar gradients row-wise for both edge directions (symmetric edge multiset, no float atomics).
+Implemented for GCN, GraphSAGE, GAT, LightGCN and DGCF stacks under every reduction ('concatenation', 'mean', 'sum',
+'last'), alone (models/gnn.py) or chained as TwoStep / TwoWay models (models/tsgnn.py, twgnn.py): `_StackTape` is the
+forward-with-kept-activations + reverse pass of ONE stack, and the Trainer chains the tapes the way the model chains the
+stacks (the gradient of a stack's leading rows is lifted back to its full node table).  GraphSAGE trains on an unfused
+forward that keeps what the reverse pass needs ([x || mean] and the normalised pre-activation); its aggregate
+(A + I) / count is symmetric up to the row scale, so the reverse aggregate is the same value-free SpMM.  The hybrid head
+(HybridCBRS: 'concatenate' / 'attention' fusion, residual classifier, both feature_based settings) trains on the same
+Dense tapes; its BERT inputs are constants.  GAT (1 head) trains on the inference kernels plus `amar_gat_bwd_f32`, which
+forms the softmax / attention-scalar gradients row-wise for both edge directions (symmetric edge multiset, no float
+atomics).
 """
 import os
 
@@ -214,20 +218,26 @@ class _HybridHead:
                 t['dense1b'].backward(dg2, grads, need_input_grad=need_input_grad))
 
 
-class Trainer:
-    """Holds the Adam state of a Basic* / HybridBert* {GCN, GraphSage, GAT, LightGCN} model and performs training batches."""
+class _StackTape:
+    """Forward of ONE convolution stack (SequentialGNN / HalfInput / FullInputSequentialGNN) that keeps what its reverse
+    pass needs, and that reverse pass: d(loss)/d(reduced output) -> weight gradients + d(loss)/d(node table).
 
-    def __init__(self, model, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, bert_dim=None):
-        if not hasattr(model.gnn, 'gnn_layers'):
-            raise NotImplementedError("training of the TwoStep / TwoWay stacks is not implemented (inference only)")
-        seq = model.gnn.gnn_layers
+    Every layer's output lives in a column slice of one [N, sum(widths)] buffer `cat`; the reduction (reduction.py:9-33)
+    is undone first (d_cat = d_out for 'concatenation', d_out / (L+1) per slice for 'mean', ...), then the layers run
+    in reverse on the slices of (cat, d_cat).  All adjacency images are symmetric (config.yaml:36), so A^T . g reuses
+    the forward SpMM."""
+
+    KINDS = ((GCNConv, 'gcn'), (LightGCNConv, 'lightgcn'), (GraphSageConv, 'sage'), (GATConv, 'gat'), (DGCFConv, 'dgcf'))
+
+    def __init__(self, seq):
+        self.seq = seq
         layers = list(seq.seq_layers)
-        if layers and all(isinstance(l, GCNConv) for l in layers) and seq.final_node == 'concatenation':
-            self.kind = 'gcn'
-        elif layers and all(isinstance(l, LightGCNConv) for l in layers) and seq.final_node == 'mean':
-            self.kind = 'lightgcn'
-        elif layers and all(isinstance(l, GraphSageConv) for l in layers) and seq.final_node == 'concatenation':
-            self.kind = 'sage'
+        self.kind = next((name for cls, name in self.KINDS if layers and all(isinstance(l, cls) for l in layers)), None)
+        if self.kind is None:
+            raise NotImplementedError("training needs a stack of one layer type (GCN, GraphSAGE, GAT, LightGCN or DGCF)")
+        if seq.final_node not in ('concatenation', 'mean', 'sum', 'last'):
+            raise NotImplementedError("no reverse pass for the '{}' reduction".format(seq.final_node))
+        if self.kind == 'sage':
             a = seq.adj_matrix
             deg = (a.rowptr[1:] - a.rowptr[:-1]).to(torch.float32)
             if len({bool(l.self_loops) for l in layers}) != 1:
@@ -236,13 +246,176 @@ class Trainer:
             # unsorted_segment_mean: sum / count, 0 for an empty segment
             self.inv_cnt = (1.0 / (deg + 1.0)) if self.self_loops else torch.where(deg > 0, 1.0 / deg.clamp(min=1.0), torch.zeros_like(deg))
             self.inv_cnt = self.inv_cnt.contiguous()
-        elif layers and all(isinstance(l, DGCFConv) for l in layers) and seq.final_node == 'mean':
-            self.kind = 'dgcf'
-        elif layers and all(isinstance(l, GATConv) for l in layers) and seq.final_node == 'concatenation':
-            self.kind = 'gat'
+        self.cat = self.tape = None
+
+    def _slices(self, t):
+        offs = self.offs
+        return lambda k: t[:, offs[k]:offs[k + 1]]
+
+    # -- forward ----------------------------------------------------------------------------------------------------
+    def forward(self, x0=None):
+        """Reduced node representations of the stack over the node table x0 (None: the stack's own table)."""
+        seq = self.seq
+        x0 = seq.embeddings if x0 is None else x0
+        widths = self.widths = seq.layer_widths()
+        seq._build_layers(widths)
+        self.offs = [int(v) for v in np.cumsum([0] + widths)]
+        if self.kind in ('gcn', 'lightgcn'):
+            # the inference kernels: their outputs are all the reverse pass needs
+            out, self.cat = seq._propagate(x0, with_layers=True)
+            return out
+        a = seq.adj_matrix
+        n, dev = a.shape[0], x0.device
+        cat = self.cat = torch.empty((n, self.offs[-1]), dtype=torch.float32, device=dev)
+        sl = self._slices(cat)
+        capi.copy_columns(x0, sl(0))
+        self.tape = []
+        for k, layer in enumerate(seq.seq_layers):
+            f, c = widths[k], widths[k + 1]
+            if self.kind == 'sage':
+                # layer by layer, keeping [x || mean(x)] and the l2-normalised pre-activation
+                xa = torch.empty((n, 2 * f), dtype=torch.float32, device=dev)
+                capi.copy_columns(sl(k), xa[:, :f])
+                ssum = torch.empty((n, f), dtype=torch.float32, device=dev)
+                capi.spmm_csr(a.rowptr, a.colidx, None, sl(k), ssum)
+                capi.row_affine(ssum, self.inv_cnt, xa[:, f:], b=sl(k) if self.self_loops else None)
+                z = torch.empty((n, c), dtype=torch.float32, device=dev)
+                capi.dense(xa, layer.kernel, layer.bias, z, act=None)
+                nrm = torch.empty((n, c), dtype=torch.float32, device=dev)
+                inv = torch.empty(n, dtype=torch.float32, device=dev)
+                capi.l2norm_fwd(z, nrm, inv, sl(k + 1), act='relu')
+                self.tape.append((xa, nrm, inv))
+            elif self.kind == 'gat':
+                # same kernels as inference, keeping H and the two attention scalars
+                h = torch.empty((n, c), dtype=torch.float32, device=dev)
+                s_self = torch.empty(n, dtype=torch.float32, device=dev)
+                s_neigh = torch.empty(n, dtype=torch.float32, device=dev)
+                capi.rowwise_xw(sl(k), layer.kernel.view(-1, c), h, a_self=layer.attn_kernel_self.view(c),
+                                a_neigh=layer.attn_kernel_neighs.view(c), s_self=s_self, s_neigh=s_neigh)
+                capi.gat_layer(a.rowptr, a.colidx, h, s_self, s_neigh, layer.bias, sl(k + 1), self_loop=layer.add_self_loops)
+                self.tape.append((h, s_self, s_neigh))
+            else:                                                    # dgcf: every layer's input stays in `cat` (the gate's gradient needs it)
+                layer([sl(k), a], out=sl(k + 1))
+        return seq._reduce(cat, [sl(k) for k in range(len(widths))], widths)
+
+    # -- reverse ----------------------------------------------------------------------------------------------------
+    def _expand(self, d_out):
+        """d(loss)/d(cat) from d(loss)/d(reduced output)."""
+        final, widths = self.seq.final_node, self.widths
+        n_terms = len(widths)
+        if final == 'concatenation':
+            return d_out
+        d_cat = torch.zeros((d_out.shape[0], self.offs[-1]), dtype=torch.float32, device=d_out.device)
+        sl = self._slices(d_cat)
+        if final == 'last':
+            capi.add_inplace(sl(n_terms - 1), d_out)
         else:
-            raise NotImplementedError("training is implemented for GCN / GraphSAGE / GAT stacks with 'concatenation' "
-                                      "and for LightGCN / DGCF ('mean')")
+            for k in range(n_terms):
+                capi.add_inplace(sl(k), d_out, 1.0 / n_terms if final == 'mean' else 1.0)
+        return d_cat
+
+    def backward(self, d_out, grads):
+        """Fills `grads` for the layers' weights; returns d(loss)/d(node table) [N, widths[0]] (a fresh buffer).
+        `d_out` is consumed (it may be modified in place)."""
+        seq, a = self.seq, self.seq.adj_matrix
+        layers, widths = list(seq.seq_layers), self.widths
+        n, dev = d_out.shape[0], d_out.device
+        if self.kind == 'lightgcn' and self.cat is None:
+            # running-sum route ('mean'): g0 = (I + A + A^2 + ...) d_out / (L + 1)
+            n_terms = len(layers) + 1
+            g0 = torch.zeros((n, widths[0]), dtype=torch.float32, device=dev)
+            capi.add_inplace(g0, d_out, 1.0 / n_terms)
+            acc = g0.clone()
+            for _ in layers:
+                nxt = torch.empty_like(acc)
+                _spmm(a, acc, nxt)
+                capi.add_inplace(g0, nxt)
+                acc = nxt
+            return g0
+        e, de = self.cat, self._expand(d_out)
+        sl, dsl = self._slices(e), self._slices(de)
+        for k in range(len(layers) - 1, -1, -1):
+            layer = layers[k]
+            f, c = widths[k], widths[k + 1]
+            if self.kind == 'gcn':
+                dzk = torch.empty((n, c), dtype=torch.float32, device=dev)
+                capi.act_bwd(dsl(k + 1), sl(k + 1), dzk, 'relu')
+                dh = torch.empty((n, c), dtype=torch.float32, device=dev)
+                _spmm(a, dzk, dh)                                     # A_hat^T = A_hat
+                dw, db = torch.empty_like(layer.kernel), torch.empty_like(layer.bias)
+                capi.wgrad(sl(k), dh, dw, None)
+                capi.wgrad(None, dzk, None, db)
+                grads[layer.kernel], grads[layer.bias] = dw, db
+                back = torch.empty((n, f), dtype=torch.float32, device=dev)
+                capi.dense(dh, layer.kernel.detach(), None, back, act=None, w_transposed=True)
+                capi.add_inplace(dsl(k), back)
+            elif self.kind == 'lightgcn':
+                back = torch.empty((n, f), dtype=torch.float32, device=dev)
+                _spmm(a, dsl(k + 1), back)
+                capi.add_inplace(dsl(k), back)
+            elif self.kind == 'sage':
+                xa, nrm, inv = self.tape[k]
+                dz = torch.empty((n, c), dtype=torch.float32, device=dev)
+                capi.l2norm_bwd(dsl(k + 1), nrm, inv, dz, act='relu')
+                dw, db = torch.empty_like(layer.kernel), torch.empty_like(layer.bias)
+                capi.wgrad(xa, dz, dw, db)
+                grads[layer.kernel], grads[layer.bias] = dw, db
+                dxa = torch.empty((n, 2 * f), dtype=torch.float32, device=dev)
+                capi.dense(dz, layer.kernel.detach(), None, dxa, act=None, w_transposed=True)
+                capi.add_inplace(dsl(k), dxa[:, :f])
+                g = torch.empty((n, f), dtype=torch.float32, device=dev)
+                capi.row_affine(dxa[:, f:], self.inv_cnt, g)               # d(mean)/d(sum)
+                back = torch.empty((n, f), dtype=torch.float32, device=dev)
+                capi.spmm_csr(a.rowptr, a.colidx, None, g, back)           # the edge multiset is symmetric
+                capi.add_inplace(dsl(k), back)
+                if self.self_loops:
+                    capi.add_inplace(dsl(k), g)
+            elif self.kind == 'gat':
+                h, s_self, s_neigh = self.tape[k]
+                w2d = layer.kernel.detach().view(f, c)
+                dout, ds, dt, dh = capi.gat_bwd(a.rowptr, a.colidx, h, s_self, s_neigh, sl(k + 1), dsl(k + 1), layer.bias,
+                                                layer.attn_kernel_self.detach().view(c), layer.attn_kernel_neighs.detach().view(c),
+                                                self_loop=layer.add_self_loops)
+                db = torch.empty_like(layer.bias)
+                capi.wgrad(None, dout, None, db)
+                das, dan = torch.empty((c, 1), dtype=torch.float32, device=dev), torch.empty((c, 1), dtype=torch.float32, device=dev)
+                capi.wgrad(h, ds.view(n, 1), das, None)
+                capi.wgrad(h, dt.view(n, 1), dan, None)
+                dw = torch.empty((f, c), dtype=torch.float32, device=dev)
+                capi.wgrad(sl(k), dh, dw, None)
+                grads[layer.kernel], grads[layer.bias] = dw.view_as(layer.kernel), db
+                grads[layer.attn_kernel_self], grads[layer.attn_kernel_neighs] = das.view_as(layer.attn_kernel_self), dan.view_as(layer.attn_kernel_neighs)
+                back = torch.empty((n, f), dtype=torch.float32, device=dev)
+                capi.dense(dh, w2d.contiguous(), None, back, act=None, w_transposed=True)
+                capi.add_inplace(dsl(k), back)
+            else:                                                    # dgcf
+                back = torch.empty((n, f), dtype=torch.float32, device=dev)
+                _spmm(a, dsl(k + 1), back)                # A_dgcf is symmetric
+                dw = torch.empty(n, dtype=torch.float32, device=dev)
+                capi.locality_scale_bwd(back, sl(k), layer.w.detach().view(-1), dsl(k), dw, accumulate=True)
+                grads[layer.w] = dw.view_as(layer.w)
+        g0 = torch.empty((n, widths[0]), dtype=torch.float32, device=dev)
+        capi.copy_columns(dsl(0), g0)
+        self.tape = self.cat = None
+        return g0
+
+
+class Trainer:
+    """Holds the Adam state of a Basic* / HybridBert* model (single-graph, TwoStep or TwoWay stacks) and performs training batches."""
+
+    def __init__(self, model, learning_rate=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7, bert_dim=None):
+        gnn = model.gnn
+        if hasattr(gnn, 'gnn_layers'):                               # one graph (gnn.py:210-264)
+            self.layout, stacks = 'single', [gnn.gnn_layers]
+        elif hasattr(gnn, 'step_one_gnn_layers'):                    # TwoStep (tsgnn.py:99-101)
+            self.layout, stacks = 'two_step', [gnn.step_one_gnn_layers, gnn.step_two_gnn_layers]
+        elif hasattr(gnn, 'way_one_gnn_layers'):                     # TwoWay (twgnn.py:98-105)
+            self.layout, stacks = 'two_way', [gnn.way_one_gnn_layers, gnn.way_two_gnn_layers, gnn.step_two_gnn_layers]
+        else:
+            raise NotImplementedError("no training recipe for {}".format(type(gnn).__name__))
+        self.tapes = [_StackTape(seq) for seq in stacks]
+        self.kind = self.tapes[-1].kind
+        seq = stacks[-1]
         self.hybrid = hasattr(model.rs, 'dense1a')
         if not model.rs.built:
             if self.hybrid:
@@ -255,6 +428,7 @@ class Trainer:
         self.lr, self.b1, self.b2, self.eps = float(learning_rate), float(beta_1), float(beta_2), float(epsilon)
         self.t = 0
         self.params = [p for p in model.parameters() if p.requires_grad]
+        self.device = self.params[0].device
         self.m = {p: torch.zeros_like(p) for p in self.params}
         self.v = {p: torch.zeros_like(p) for p in self.params}
         self.head = _HybridHead(model.rs) if self.hybrid else _BasicHead(model.rs)
@@ -278,9 +452,8 @@ class Trainer:
     def _forward_backward(self, u, i, yv, rows):
         """Device-only body of a batch (no host synchronisation, fixed shapes -> capturable as a hipGraph):
         returns (per-pair loss terms [B], {param: gradient})."""
-        seq = self.seq
         b = u.numel()
-        dev = seq.embeddings.device
+        dev = self.device
         e = self._propagation_forward()                              # full-graph propagation, every batch (basic.py:61-63)
         f = e.shape[1]
         gu = torch.empty((b, f), dtype=torch.float32, device=dev)
@@ -341,7 +514,7 @@ class Trainer:
         given size (the first one runs eagerly and warms every lazily built buffer); the running loss stays on the
         device (`pop_loss_sum`).  Batches of another size run eagerly."""
         b = len(y)
-        dev = self.seq.embeddings.device
+        dev = self.device
         with_blocks = bert is not None and bert[0] is not None
         key = (b, with_blocks)
         if not hasattr(self, '_graphs'):
@@ -394,198 +567,47 @@ class Trainer:
                 prm.add_(0)
 
     def _propagation_forward(self):
-        """E = gnn(None).  GCN / LightGCN: the inference kernels (their outputs are all the reverse pass needs);
-        GraphSAGE: layer by layer, keeping [x || mean(x)] and the l2-normalised pre-activation."""
-        seq = self.seq
-        if self.kind in ('gcn', 'lightgcn'):
-            return seq(None)
-        if self.kind == 'gat':
-            return self._gat_forward()
-        if self.kind == 'dgcf':
-            return self._dgcf_forward()
-        a = seq.adj_matrix
-        widths = seq.layer_widths()
-        seq._build_layers(widths)
-        n, dev = a.shape[0], seq.embeddings.device
-        offs = np.cumsum([0] + widths)
-        cat = torch.empty((n, int(offs[-1])), dtype=torch.float32, device=dev)
-        sl = lambda k: cat[:, offs[k]:offs[k + 1]]
-        capi.copy_columns(seq.embeddings, sl(0))
-        self._tape = []
-        for k, layer in enumerate(seq.seq_layers):
-            f, c = widths[k], widths[k + 1]
-            xa = torch.empty((n, 2 * f), dtype=torch.float32, device=dev)
-            capi.copy_columns(sl(k), xa[:, :f])
-            ssum = torch.empty((n, f), dtype=torch.float32, device=dev)
-            capi.spmm_csr(a.rowptr, a.colidx, None, sl(k), ssum)
-            capi.row_affine(ssum, self.inv_cnt, xa[:, f:], b=sl(k) if self.self_loops else None)
-            z = torch.empty((n, c), dtype=torch.float32, device=dev)
-            capi.dense(xa, layer.kernel, layer.bias, z, act=None)
-            nrm = torch.empty((n, c), dtype=torch.float32, device=dev)
-            inv = torch.empty(n, dtype=torch.float32, device=dev)
-            capi.l2norm_fwd(z, nrm, inv, sl(k + 1), act='relu')
-            self._tape.append((xa, nrm, inv))
-        return cat
+        """E = gnn(None) with every stack's activations kept on its tape."""
+        gnn, tapes = self.model.gnn, self.tapes
+        if self.layout == 'single':
+            return tapes[0].forward()
+        if self.layout == 'two_step':
+            items = tapes[0].forward()[:gnn.n_embeddings]
+            users = gnn.step_two_gnn_layers.embeddings
+            x0 = torch.empty((users.shape[0] + items.shape[0], users.shape[1]), dtype=torch.float32, device=self.device)
+            capi.copy_columns(users.detach(), x0[:users.shape[0]])
+            capi.copy_columns(items, x0[users.shape[0]:])
+            return tapes[1].forward(x0)
+        users, items = tapes[0].forward()[:gnn.n_users], tapes[1].forward()[:gnn.n_items]
+        x0 = torch.empty((gnn.n_users + gnn.n_items, users.shape[1]), dtype=torch.float32, device=self.device)
+        capi.copy_columns(users, x0[:gnn.n_users])
+        capi.copy_columns(items, x0[gnn.n_users:])
+        return tapes[2].forward(x0)
 
-    def _dgcf_forward(self):
-        """DGCFConv.call layer by layer, keeping every layer's input (the gate's gradient needs it); E = mean of all."""
-        seq = self.seq
-        a = seq.adj_matrix
-        widths = seq.layer_widths()
-        seq._build_layers(widths)
-        n, dev, d = a.shape[0], seq.embeddings.device, widths[0]
-        cat = torch.empty((n, d * len(widths)), dtype=torch.float32, device=dev)
-        capi.copy_columns(seq.embeddings, cat[:, :d])
-        for k, layer in enumerate(seq.seq_layers):
-            layer([cat[:, k * d:(k + 1) * d], a], out=cat[:, (k + 1) * d:(k + 2) * d])
-        self._tape = cat
-        out = torch.empty((n, d), dtype=torch.float32, device=dev)
-        capi.reduce_layers(cat, len(widths), d, out, mean=True)
-        return out
-
-    def _dgcf_backward(self, e, de, grads):
-        seq, a = self.seq, self.seq.adj_matrix
-        layers = list(seq.seq_layers)
-        n, dev, d = e.shape[0], e.device, e.shape[1]
-        cat = self._tape
-        n_terms = len(layers) + 1
-        dxs = []                                                     # dL/dX_k: de / (L + 1) for every term of the mean
-        for _ in range(n_terms):
-            g = torch.zeros((n, d), dtype=torch.float32, device=dev)
-            capi.add_inplace(g, de, 1.0 / n_terms)
-            dxs.append(g)
-        for k in range(len(layers) - 1, -1, -1):
-            back = torch.empty((n, d), dtype=torch.float32, device=dev)
-            _spmm(a, dxs[k + 1], back)                               # A_dgcf is symmetric
-            dw = torch.empty(n, dtype=torch.float32, device=dev)
-            capi.locality_scale_bwd(back, cat[:, k * d:(k + 1) * d], layers[k].w.detach().view(-1), dxs[k], dw, accumulate=True)
-            grads[layers[k].w] = dw.view_as(layers[k].w)
-        grads[seq.embeddings] = dxs[0]
-        self._tape = None
-
-    def _gat_forward(self):
-        """GATConv.call layer by layer (same kernels as inference), keeping H and the two attention scalars."""
-        seq = self.seq
-        a = seq.adj_matrix
-        widths = seq.layer_widths()
-        seq._build_layers(widths)
-        n, dev = a.shape[0], seq.embeddings.device
-        offs = np.cumsum([0] + widths)
-        cat = torch.empty((n, int(offs[-1])), dtype=torch.float32, device=dev)
-        sl = lambda k: cat[:, offs[k]:offs[k + 1]]
-        capi.copy_columns(seq.embeddings, sl(0))
-        self._tape = []
-        for k, layer in enumerate(seq.seq_layers):
-            c = widths[k + 1]
-            h = torch.empty((n, c), dtype=torch.float32, device=dev)
-            s_self = torch.empty(n, dtype=torch.float32, device=dev)
-            s_neigh = torch.empty(n, dtype=torch.float32, device=dev)
-            capi.rowwise_xw(sl(k), layer.kernel.view(-1, c), h, a_self=layer.attn_kernel_self.view(c),
-                            a_neigh=layer.attn_kernel_neighs.view(c), s_self=s_self, s_neigh=s_neigh)
-            capi.gat_layer(a.rowptr, a.colidx, h, s_self, s_neigh, layer.bias, sl(k + 1), self_loop=layer.add_self_loops)
-            self._tape.append((h, s_self, s_neigh))
-        return cat
-
-    def _gat_backward(self, e, de, grads):
-        seq, a = self.seq, self.seq.adj_matrix
-        layers = list(seq.seq_layers)
-        n, dev = e.shape[0], e.device
-        widths = seq.layer_widths()
-        offs = np.cumsum([0] + widths)
-        sl = lambda t, k: t[:, offs[k]:offs[k + 1]]
-        for k in range(len(layers) - 1, -1, -1):
-            layer = layers[k]
-            f, c = widths[k], widths[k + 1]
-            h, s_self, s_neigh = self._tape[k]
-            w2d = layer.kernel.detach().view(f, c)
-            dout, ds, dt, dh = capi.gat_bwd(a.rowptr, a.colidx, h, s_self, s_neigh, sl(e, k + 1), sl(de, k + 1), layer.bias,
-                                            layer.attn_kernel_self.detach().view(c), layer.attn_kernel_neighs.detach().view(c),
-                                            self_loop=layer.add_self_loops)
-            db = torch.empty_like(layer.bias)
-            capi.wgrad(None, dout, None, db)
-            das, dan = torch.empty((c, 1), dtype=torch.float32, device=dev), torch.empty((c, 1), dtype=torch.float32, device=dev)
-            capi.wgrad(h, ds.view(n, 1), das, None)
-            capi.wgrad(h, dt.view(n, 1), dan, None)
-            dw = torch.empty((f, c), dtype=torch.float32, device=dev)
-            capi.wgrad(sl(e, k), dh, dw, None)
-            grads[layer.kernel], grads[layer.bias] = dw.view_as(layer.kernel), db
-            grads[layer.attn_kernel_self], grads[layer.attn_kernel_neighs] = das.view_as(layer.attn_kernel_self), dan.view_as(layer.attn_kernel_neighs)
-            back = torch.empty((n, f), dtype=torch.float32, device=dev)
-            capi.dense(dh, w2d.contiguous(), None, back, act=None, w_transposed=True)
-            capi.add_inplace(sl(de, k), back)
-        g0 = torch.empty_like(seq.embeddings)
-        capi.copy_columns(sl(de, 0), g0)
-        grads[seq.embeddings] = g0
-        self._tape = None
+    def _lift(self, rows, n_nodes):
+        """Gradient of a leading-rows slice: the rows, zero below (a stack hands over only its first |U| or |I| nodes)."""
+        full = torch.zeros((n_nodes, rows.shape[1]), dtype=torch.float32, device=self.device)
+        capi.copy_columns(rows, full[:rows.shape[0]])
+        return full
 
     def _propagation_backward(self, e, de, grads):
-        if self.kind == 'gat':
-            return self._gat_backward(e, de, grads)
-        if self.kind == 'dgcf':
-            return self._dgcf_backward(e, de, grads)
-        seq, a = self.seq, self.seq.adj_matrix
-        layers = list(seq.seq_layers)
-        n, dev = e.shape[0], e.device
-        emb = seq.embeddings
-        if self.kind == 'sage':
-            widths = seq.layer_widths()
-            offs = np.cumsum([0] + widths)
-            sl = lambda t, k: t[:, offs[k]:offs[k + 1]]
-            for k in range(len(layers) - 1, -1, -1):
-                layer = layers[k]
-                f, c = widths[k], widths[k + 1]
-                xa, nrm, inv = self._tape[k]
-                dz = torch.empty((n, c), dtype=torch.float32, device=dev)
-                capi.l2norm_bwd(sl(de, k + 1), nrm, inv, dz, act='relu')
-                dw, db = torch.empty_like(layer.kernel), torch.empty_like(layer.bias)
-                capi.wgrad(xa, dz, dw, db)
-                grads[layer.kernel], grads[layer.bias] = dw, db
-                dxa = torch.empty((n, 2 * f), dtype=torch.float32, device=dev)
-                capi.dense(dz, layer.kernel.detach(), None, dxa, act=None, w_transposed=True)
-                capi.add_inplace(sl(de, k), dxa[:, :f])
-                g = torch.empty((n, f), dtype=torch.float32, device=dev)
-                capi.row_affine(dxa[:, f:], self.inv_cnt, g)               # d(mean)/d(sum)
-                back = torch.empty((n, f), dtype=torch.float32, device=dev)
-                capi.spmm_csr(a.rowptr, a.colidx, None, g, back)           # the edge multiset is symmetric
-                capi.add_inplace(sl(de, k), back)
-                if self.self_loops:
-                    capi.add_inplace(sl(de, k), g)
-            g0 = torch.empty_like(emb)
-            capi.copy_columns(sl(de, 0), g0)
-            grads[emb] = g0
-            self._tape = None
-        elif self.kind == 'gcn':
-            widths = seq.layer_widths()
-            offs = np.cumsum([0] + widths)
-            sl = lambda t, k: t[:, offs[k]:offs[k + 1]]
-            for k in range(len(layers) - 1, -1, -1):
-                layer = layers[k]
-                c = widths[k + 1]
-                dzk = torch.empty((n, c), dtype=torch.float32, device=dev)
-                capi.act_bwd(sl(de, k + 1), sl(e, k + 1), dzk, 'relu')
-                dh = torch.empty((n, c), dtype=torch.float32, device=dev)
-                _spmm(a, dzk, dh)                                     # A_hat^T = A_hat
-                dw, db = torch.empty_like(layer.kernel), torch.empty_like(layer.bias)
-                capi.wgrad(sl(e, k), dh, dw, None)
-                capi.wgrad(None, dzk, None, db)
-                grads[layer.kernel], grads[layer.bias] = dw, db
-                back = torch.empty((n, widths[k]), dtype=torch.float32, device=dev)
-                capi.dense(dh, layer.kernel.detach(), None, back, act=None, w_transposed=True)
-                capi.add_inplace(sl(de, k), back)
-            g0 = torch.empty_like(emb)
-            capi.copy_columns(sl(de, 0), g0)
-            grads[emb] = g0
-        else:
-            n_terms = len(layers) + 1
-            g0 = torch.zeros_like(emb)
-            capi.add_inplace(g0, de, 1.0 / n_terms)
-            acc = g0.clone()
-            for _ in layers:
-                nxt = torch.empty_like(acc)
-                _spmm(a, acc, nxt)
-                capi.add_inplace(g0, nxt)
-                acc = nxt
-            grads[emb] = g0
+        gnn, tapes = self.model.gnn, self.tapes
+        if self.layout == 'single':
+            grads[gnn.gnn_layers.embeddings] = tapes[0].backward(de, grads)
+            return
+        if self.layout == 'two_step':
+            one, two = gnn.step_one_gnn_layers, gnn.step_two_gnn_layers
+            dx0 = tapes[1].backward(de, grads)
+            n_users = two.embeddings.shape[0]
+            g_users = torch.empty_like(two.embeddings)
+            capi.copy_columns(dx0[:n_users], g_users)
+            grads[two.embeddings] = g_users
+            grads[one.embeddings] = tapes[0].backward(self._lift(dx0[n_users:], one.adj_matrix.shape[0]), grads)
+            return
+        one, two = gnn.way_one_gnn_layers, gnn.way_two_gnn_layers
+        dx0 = tapes[2].backward(de, grads)
+        grads[one.embeddings] = tapes[0].backward(self._lift(dx0[:gnn.n_users], one.adj_matrix.shape[0]), grads)
+        grads[two.embeddings] = tapes[1].backward(self._lift(dx0[gnn.n_users:], two.adj_matrix.shape[0]), grads)
 
     def apply_gradients(self, grads):
         self.t += 1

@@ -156,33 +156,23 @@ def torch_grads(adj, gnn, head, u_ids, i_ids, y, l2=0.0):
                          'head': {name: [(g(w), g(b)) for w, b in nets[name]] for name in nets}}
 
 
-def torch_model_grads(adj, gnn, head, u_ids, i_ids, y, l2=0.0, self_loops=True, bert=None, feature_based=True):
-    """Loss and gradients of ANY model on the path by torch autograd (float64, CPU): the four GNN kinds of
-    oracle/models.py:propagate under the Basic head (keys unet/inet/clf) or the Hybrid head (dense1a..dense3b, clf;
-    `bert` = (user rows [B, D], item rows [B, D]) as the batch Sequence delivers them, hybrid.py:119-140).
-
-    The forward below restates oracle/layers.py op by op with differentiable torch ops (tests check that its scores
-    equal the numpy oracle's); what Keras adds is autodiff of exactly this graph plus the L2 terms of the node table
-    and of the conv kernels / biases (gnn.py:45, 293-294, 324-327, 357-360; attention vectors carry none).
-    """
+def _torch_stack(adj, x, st, self_loops=True, force_mean=True):
+    """One convolution stack (the layer loop of gnn.py:74-84 / 141-150 / 197-207) in differentiable float64 torch ops,
+    restating oracle/layers.py op by op.  st = {'kind', 'layers': leaf tensors, 'final_node'}."""
     import torch
-    kind = gnn['kind']
-    T = lambda arr: torch.tensor(np.asarray(arr, dtype=np.float64), requires_grad=True)
-    x0 = T(gnn['embeddings'])
-    layers = [{k: T(v) for k, v in lw.items()} for lw in gnn['layers']]
-    fusers = {name: {k: T(v) for k, v in head[name].items()} for name in head if name.startswith('fuse')}
-    nets = {name: [(T(w), T(b)) for w, b in head[name]] for name in head if not name.startswith('fuse')}
-    n = x0.shape[0]
-    hs, x = [x0], x0
+    kind, layers = st['kind'], st['layers']
+    n = x.shape[0]
+    hs = [x]
+    np_dt = np.float32 if x.dtype == torch.float32 else np.float64   # float64 is the oracle; float32 only sizes the rounding floor
     if kind in ('gcn', 'lightgcn'):
         a = ograph.gcn_filter(adj).tocoo()
-        a_t = torch.sparse_coo_tensor(np.stack([a.row, a.col]), a.data.astype(np.float64), a.shape).coalesce()
+        a_t = torch.sparse_coo_tensor(np.stack([a.row, a.col]), a.data.astype(np_dt), a.shape).coalesce()
         for lw in layers:
             x = torch.relu(torch.sparse.mm(a_t, x @ lw['kernel']) + lw['bias']) if kind == 'gcn' else torch.sparse.mm(a_t, x)
             hs.append(x)
     elif kind == 'dgcf':
         a = ograph.dgcf_adjacency(adj).tocoo()
-        a_t = torch.sparse_coo_tensor(np.stack([a.row, a.col]), a.data.astype(np.float64), a.shape).coalesce()
+        a_t = torch.sparse_coo_tensor(np.stack([a.row, a.col]), a.data.astype(np_dt), a.shape).coalesce()
         for lw in layers:
             x = torch.sparse.mm(a_t, x * torch.sigmoid(lw['w']))
             hs.append(x)
@@ -192,7 +182,7 @@ def torch_model_grads(adj, gnn, head, u_ids, i_ids, y, l2=0.0, self_loops=True, 
             row, col = ograph.add_self_loops_edges(row, col, n)
         src = torch.as_tensor(np.asarray(row), dtype=torch.long)
         tgt = torch.as_tensor(np.asarray(col), dtype=torch.long)
-        count = torch.bincount(tgt, minlength=n).double().clamp(min=1.0)
+        count = torch.bincount(tgt, minlength=n).to(x.dtype).clamp(min=1.0)
         for lw in layers:
             if kind == 'sage':
                 agg = torch.zeros_like(x).index_add(0, tgt, x[src]) / count[:, None]
@@ -203,19 +193,63 @@ def torch_model_grads(adj, gnn, head, u_ids, i_ids, y, l2=0.0, self_loops=True, 
                 h = x @ lw['kernel']
                 e = (h @ lw['attn_self'])[tgt] + (h @ lw['attn_neigh'])[src]
                 e = torch.where(e > 0, e, 0.2 * e)
-                seg_max = torch.full((n,), -float('inf'), dtype=torch.float64).scatter_reduce(0, tgt, e.detach(), 'amax')
+                seg_max = torch.full((n,), -float('inf'), dtype=x.dtype).scatter_reduce(0, tgt, e.detach(), 'amax')
                 ex = torch.exp(e - seg_max[tgt])
-                denom = torch.zeros(n, dtype=torch.float64).index_add(0, tgt, ex) + 1e-9
+                denom = torch.zeros(n, dtype=x.dtype).index_add(0, tgt, ex) + 1e-9
                 alpha = ex / denom[tgt]
                 x = torch.relu(torch.zeros_like(h).index_add(0, tgt, alpha[:, None] * h[src]) + lw['bias'])
             hs.append(x)
-    final_node = 'mean' if kind in ('lightgcn', 'dgcf') else gnn.get('final_node', 'concatenation')
+    final_node = st.get('final_node', 'concatenation')
+    if force_mean and kind in ('lightgcn', 'dgcf'):
+        final_node = 'mean'
     if final_node == 'concatenation':
-        e_all = torch.cat(hs, 1)
-    elif final_node == 'last':
-        e_all = hs[-1]
+        return torch.cat(hs, 1)
+    if final_node == 'last':
+        return hs[-1]
+    return sum(hs) / (len(hs) if final_node == 'mean' else 1)
+
+
+def torch_model_grads(adj, gnn, head, u_ids, i_ids, y, l2=0.0, self_loops=True, bert=None, feature_based=True, n_users=None,
+                      n_items=None, dtype=np.float64):
+    """Loss and gradients of ANY model on the path by torch autograd (float64, CPU): the four GNN kinds of
+    oracle/models.py:propagate under the Basic head (keys unet/inet/clf) or the Hybrid head (dense1a..dense3b, clf;
+    `bert` = (user rows [B, D], item rows [B, D]) as the batch Sequence delivers them, hybrid.py:119-140).
+    Compound layouts: gnn = {'step_one', 'step_two'} with adj = (user-item, item-property) is a TwoStep model, gnn =
+    {'way_one', 'way_two', 'step_two'} with adj = (user-item, item-property, user-property) a TwoWay one (n_users, n_items
+    required); their gradients come back as grads['gnn'][stack name].
+
+    The forward below restates oracle/layers.py op by op with differentiable torch ops (tests check that its scores
+    equal the numpy oracle's); what Keras adds is autodiff of exactly this graph plus the L2 terms of the node table
+    and of the conv kernels / biases (gnn.py:45, 293-294, 324-327, 357-360; attention vectors carry none).
+    """
+    import torch
+    T = lambda arr: torch.tensor(np.asarray(arr, dtype=dtype), requires_grad=True)
+    fusers = {name: {k: T(v) for k, v in head[name].items()} for name in head if name.startswith('fuse')}
+    nets = {name: [(T(w), T(b)) for w, b in head[name]] for name in head if not name.startswith('fuse')}
+    # every stack as a dict of leaf tensors — compound layouts chain them (tsgnn.py:99-101, twgnn.py:98-105)
+    stacks = {}
+
+    def leaf(name, w, table_l2):
+        t = {'kind': w['kind'], 'final_node': w.get('final_node', 'concatenation'),
+             'layers': [{k: T(v) for k, v in lw.items()} for lw in w['layers']], 'table_l2': table_l2}
+        if 'embeddings' in w:
+            t['embeddings'] = T(w['embeddings'])
+        stacks[name] = t
+        return t
+    if 'step_one' in gnn:
+        adj_ui, adj_kg = adj
+        one, two = leaf('step_one', gnn['step_one'], True), leaf('step_two', gnn['step_two'], False)   # tsgnn.py:77-81: no regulariser on the user table
+        x = _torch_stack(adj_kg, one['embeddings'], one, self_loops, False)
+        e_all = _torch_stack(adj_ui, torch.cat([two['embeddings'], x[:n_items]], 0), two, self_loops, False)
+    elif 'way_one' in gnn:
+        adj_ui, adj_ip, adj_up = adj
+        one, two, three = leaf('way_one', gnn['way_one'], True), leaf('way_two', gnn['way_two'], True), leaf('step_two', gnn['step_two'], False)
+        users = _torch_stack(adj_up, one['embeddings'], one, self_loops, False)
+        items = _torch_stack(adj_ip, two['embeddings'], two, self_loops, False)
+        e_all = _torch_stack(adj_ui, torch.cat([users[:n_users], items[:n_items]], 0), three, self_loops, False)
     else:
-        e_all = sum(hs) / (len(hs) if final_node == 'mean' else 1)
+        only = leaf('gnn', gnn, True)
+        e_all = _torch_stack(adj, only['embeddings'], only, self_loops, True)
 
     def run(net, v, last_sigmoid=False):
         for k, (w, b) in enumerate(net):
@@ -227,8 +261,8 @@ def torch_model_grads(adj, gnn, head, u_ids, i_ids, y, l2=0.0, self_loops=True, 
     if 'unet' in nets:
         p = run(nets['clf'], torch.cat([run(nets['unet'], e_all[u]), run(nets['inet'], e_all[i])], 1), True)[:, 0]
     else:
-        ub = torch.tensor(np.asarray(bert[0], dtype=np.float64))
-        ib = torch.tensor(np.asarray(bert[1], dtype=np.float64))
+        ub = torch.tensor(np.asarray(bert[0], dtype=dtype))
+        ib = torch.tensor(np.asarray(bert[1], dtype=dtype))
         g1, g2, b1, b2 = run(nets['dense1a'], e_all[u]), run(nets['dense1b'], e_all[i]), run(nets['dense2a'], ub), run(nets['dense2b'], ib)
 
         def fuse(name, a, b):                                        # fusion.py:51-68
@@ -248,16 +282,25 @@ def torch_model_grads(adj, gnn, head, u_ids, i_ids, y, l2=0.0, self_loops=True, 
             r = run(res[:-1], x) if len(res) > 1 else x
             x = torch.relu(r @ res[-1][0] + res[-1][1] + x1 + x2)
         p = run(nets['clf'], x, True)[:, 0]
-    yv = torch.tensor(np.asarray(y, dtype=np.float64))
+    yv = torch.tensor(np.asarray(y, dtype=dtype))
     pc = torch.clamp(p, EPS, 1 - EPS)
-    loss = -torch.mean(yv * torch.log(pc + EPS) + (1 - yv) * torch.log(1 - pc + EPS)) + l2 * (x0 ** 2).sum()
-    for lw in layers:
-        for name in ('kernel', 'bias', 'w'):                         # LocalityAdaptive's w carries the regulariser too (dgcf_conv.py:97)
-            if name in lw:
-                loss = loss + l2 * (lw[name] ** 2).sum()
+    loss = -torch.mean(yv * torch.log(pc + EPS) + (1 - yv) * torch.log(1 - pc + EPS))
+    for st in stacks.values():
+        if st['table_l2'] and 'embeddings' in st:
+            loss = loss + l2 * (st['embeddings'] ** 2).sum()
+        for lw in st['layers']:
+            for name in ('kernel', 'bias', 'w'):                     # LocalityAdaptive's w carries the regulariser too (dgcf_conv.py:97)
+                if name in lw:
+                    loss = loss + l2 * (lw[name] ** 2).sum()
     loss.backward()
     g = lambda t: t.grad.numpy() if t.grad is not None else np.zeros(tuple(t.shape))
-    grads = {'gnn': {'embeddings': g(x0), 'layers': [{k: g(v) for k, v in lw.items()} for lw in layers]},
+
+    def export(st):
+        out = {'layers': [{k: g(v) for k, v in lw.items()} for lw in st['layers']]}
+        if 'embeddings' in st:
+            out['embeddings'] = g(st['embeddings'])
+        return out
+    grads = {'gnn': export(stacks['gnn']) if 'gnn' in stacks else {name: export(st) for name, st in stacks.items()},
              'head': {name: [(g(w), g(b)) for w, b in nets[name]] for name in nets}}
     grads['head'].update({name: {k: g(v) for k, v in fw.items()} for name, fw in fusers.items()})
     return float(loss.detach()), grads, p.detach().numpy()

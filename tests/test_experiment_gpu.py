@@ -54,21 +54,31 @@ def test_experiment_grid_runs_and_ranks_like_the_oracle(hip, tmp_path, monkeypat
                'dataset': {'load_function_name': ['load_user_item_graph_bert_embeddings']}},
         'g5': {'model': {'name': ['hybrid.HybridBertLightGCN'], 'dense_units': [[[24, 24], [16, 8], [16, 16]]], 'clf_units': [[16, 16]],
                          'embedding_dim': [8], 'n_layers': [2], 'fusion_method': ['concatenate'], 'residual': [True]},
-               'dataset': {'load_function_name': ['load_user_item_graph_bert_embeddings']}}}}
+               'dataset': {'load_function_name': ['load_user_item_graph_bert_embeddings']}},
+        # TwoStep on (user-item, item-property), TwoWay on those plus the two-hop user-property graph (loaders.py:318-321)
+        'g6': {'model': {'name': ['basic.BasicTSGraphSage'], 'dense_units': [[24, 24]], 'clf_units': [[48, 48]], 'embedding_dim': [8],
+                         'n_hiddens': [[8, 8]]},
+               'dataset': {'load_function_name': ['load_user_item_graph'], 'type_adjacency': ['unary-kg'],
+                           'props_triples_filepath': [paths['props_triples_filepath']]}},
+        'g7': {'model': {'name': ['basic.BasicTWGCN'], 'dense_units': [[24, 24]], 'clf_units': [[48, 48]], 'embedding_dim': [8],
+                         'n_hiddens': [[8, 8]], 'user_item_node': ['concatenation']},
+               'dataset': {'load_function_name': ['load_user_item_graph'], 'type_adjacency': ['unary-kg'], 'user_properties': [True],
+                           'props_triples_filepath': [paths['props_triples_filepath']]}}}}
     (tmp_path / 'exps.yaml').write_text(yaml.safe_dump(grid))
     monkeypatch.chdir(tmp_path)
     run_log = setup_mlflow('test group', str(tmp_path / 'mlruns'))
     multi = experiment.MultiExperimenter(str(tmp_path / 'config.yaml'), str(tmp_path / 'exps.yaml'), run_log)
-    assert len(multi.experiments) == 8
+    assert len(multi.experiments) == 10
     results = multi.run()
     done = [k for k, v in results.items() if v is not None]
     failed = [k for k, v in results.items() if v is None]
-    assert len(done) == 7 and len(failed) == 1 and 'BasicTSGCN' in failed[0]      # catch-and-continue (experiment.py:295-302)
+    # catch-and-continue (experiment.py:295-302): a TwoStep model cannot be built on the single 'unary-uip' matrix
+    assert len(done) == 9 and len(failed) == 1 and 'BasicTSGCN' in failed[0]
     for metrics in (results[k] for k in done):
         assert list(metrics.index) == ['precision_at', 'recall_at', 'f1_at'] and list(metrics.columns) == [5, 10]
         assert ((metrics.values >= 0) & (metrics.values <= 1)).all()
     tsvs = glob.glob(str(tmp_path / 'mlruns' / '*' / '*' / 'artifacts' / 'predictions' / 'top_5' / 'predictions_1.tsv'))
-    assert len(tsvs) == 7
+    assert len(tsvs) == 9
     top = pd.read_csv(tsvs[0], sep='\t', header=None)
     assert top.shape[1] == 3 and top.groupby(0).size().max() <= 5
     # raw identifiers, user ascending then score descending

@@ -154,8 +154,8 @@ def test_model_classes_resolve_and_param_counts():
         basic.BasicGCN(adj, **dict(cfg, final_node='bogus'))
     with pytest.raises(ValueError):
         hybrid.HybridCBRS(fusion_method='bogus')
-    with pytest.raises(NotImplementedError):                  # no reverse pass for this reduction
-        basic.BasicGCN(adj, **dict(cfg, final_node='last')).fit(None)
+    from deep_cbrs_amar_renaissance_amd import training
+    assert training.Trainer(basic.BasicGCN(adj, **dict(cfg, final_node='last'))).tapes[0].kind == 'gcn'     # every reduction has a reverse pass
 
 
 def test_seed_reproducibility_and_glorot_limits():

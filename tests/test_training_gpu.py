@@ -103,7 +103,7 @@ def test_sage_training_kernels(hip):
     assert helpers.rel_err(dz.cpu().numpy(), zt.grad.numpy()) < 1e-5
 
 
-@pytest.mark.parametrize('C', [4, 16, 32, 64])
+@pytest.mark.parametrize('C', [4, 16, 32, 64, 24, 48])      # 24 / 48: lane groups padded to the next power of two
 @pytest.mark.parametrize('self_loop', [True, False])
 def test_gat_bwd_kernel(hip, C, self_loop):
     """amar_gat_bwd_f32 for every lane layout (C/4 lanes per edge) against torch autograd of the restated forward."""

@@ -159,3 +159,100 @@ def test_hoisted_predict_and_errors(hip):
         basic.BasicTWGCN(g['n_users'], g['n_items'], adjs[:2], **CFG)
     with pytest.raises(ValueError):                           # 'last' hands over 4-wide items to an 8-wide user table
         basic.BasicTSGCN(g['n_users'], g['n_items'], adjs[:2], **dict(CFG, n_hiddens=[8, 4], item_node='last'))
+
+
+# ---- training (SURVEY.md §8f N1 for the TwoStep / TwoWay stacks) -----------------------------------------------------------------
+
+def _flat_stack(seq, gs, out):
+    if 'embeddings' in gs:
+        out[seq.embeddings] = gs['embeddings']
+    for layer, gl in zip(seq.seq_layers, gs['layers']):
+        for name, arr in gl.items():
+            out[getattr(layer, {'attn_self': 'attn_kernel_self', 'attn_neigh': 'attn_kernel_neighs'}.get(name, name))] = arr
+
+
+def _flatten(model, grads, layout):
+    out = {}
+    names = {'two_step': ('step_one', 'step_two'), 'two_way': ('way_one', 'way_two', 'step_two')}[layout]
+    for name in names:
+        _flat_stack(getattr(model.gnn, name + '_gnn_layers'), grads['gnn'][name], out)
+    for name in grads['head']:
+        for layer, (gw, gb) in zip(getattr(model.rs, name).layers, grads['head'][name]):
+            out[layer.kernel], out[layer.bias] = gw, gb
+    return out
+
+
+@pytest.mark.parametrize('kind', KINDS)
+@pytest.mark.parametrize('layout,node', [('two_step', 'mean'), ('two_step', 'concatenation'), ('two_way', 'mean'),
+                                         ('two_way', 'concatenation'), ('two_way', 'last')])
+def test_gradients_match_autograd_oracle(hip, kind, layout, node):
+    """One training batch: loss and every gradient (all tables, all layers of all stacks, the head) against torch
+    autograd of the oracle's restated forward (float64), including the reductions 'mean' / 'last' between the stacks."""
+    from deep_cbrs_amar_renaissance_amd import engine, training
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    from oracle import train as otrain
+    if layout == 'two_step' and node == 'concatenation' and kind in ('LightGCN', 'DGCF'):
+        pytest.skip("weight-free stacks cannot widen the user table")
+    engine.set_seed(5)
+    g = helpers.kg_graph(n_users=60, n_items=45, n_props=30, n_ratings=900, n_links=120, seed=11)
+    if layout == 'two_step':
+        adjs = (g['adj_ui'], g['adj_ip'])
+        model = getattr(basic, 'BasicTS' + kind)(g['n_users'], g['n_items'], adjs, **dict(CFG, item_node=node))
+        ow = helpers.two_step_to_oracle
+    else:
+        adjs = (g['adj_ui'], g['adj_ip'], g['adj_up'])
+        model = getattr(basic, 'BasicTW' + kind)(g['n_users'], g['n_items'], adjs, **dict(CFG, user_item_node=node))
+        ow = helpers.two_way_to_oracle
+    # (seed 23 puts one classifier pre-activation of the two_way / 'last' / GAT case at +2.5e-9: its ReLU mask then differs
+    # between fp32 and the float64 oracle and moves that unit's gradient by one pair's worth, 8 %)
+    _perturb(model, 29)
+    y = np.random.default_rng(2).integers(0, 2, len(g['u_ids']))
+    trainer = training.Trainer(model)
+    assert trainer.layout == layout
+    loss, grads = trainer.loss_and_grads(g['u_ids'], g['i_ids'], y)
+    with torch.no_grad():                                     # the taped forward scores like the inference forward
+        e_inf = model.gnn(None)
+        assert float((e_inf - trainer._propagation_forward()).abs().max()) <= 2e-6 * float(e_inf.abs().max())
+    want_loss, want, _ = otrain.torch_model_grads(adjs, ow(model.gnn), helpers.basic_head_to_oracle(model.rs), g['u_ids'], g['i_ids'], y,
+                                                  l2=1e-4, n_users=g['n_users'], n_items=g['n_items'])
+    assert abs(loss - want_loss) < 1e-5
+    flat = _flatten(model, want, layout)
+    assert set(flat) == set(grads)
+    for prm, gw in flat.items():
+        got = grads[prm].cpu().numpy().reshape(gw.shape).astype(np.float64)
+        got += 2 * trainer._l2(prm) * prm.detach().cpu().numpy().reshape(gw.shape)      # the trainer folds the L2 term into the Adam kernel
+        assert np.abs(got - gw).max() <= 2e-4 * np.abs(gw).max() + 1e-10, tuple(prm.shape)
+    if layout == 'two_step':                                  # tsgnn.py:77-81: the user table carries no regulariser, step one's does
+        assert trainer._l2(model.gnn.step_two_gnn_layers.embeddings) == 0.0
+        assert trainer._l2(model.gnn.step_one_gnn_layers.embeddings) == 1e-4
+
+
+@pytest.mark.parametrize('cls', ['BasicTSGCN', 'BasicTWGraphSage', 'BasicTWLightGCN'])
+def test_fit_reduces_loss_and_replays_graphs(hip, cls):
+    """model.fit over a Sequence: hipGraph-replayed batches, loss going down, same weights as eager batches."""
+    from deep_cbrs_amar_renaissance_amd import engine, training
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    g = helpers.kg_graph(n_users=60, n_items=45, n_props=30, n_ratings=900, n_links=120, seed=12)
+    adjs = (g['adj_ui'], g['adj_ip']) if 'TS' in cls else (g['adj_ui'], g['adj_ip'], g['adj_up'])
+    rng = np.random.default_rng(4)
+    labels = ((g['u_ids'] + g['i_ids']) % 2).astype(np.int64)
+    batches = [(g['u_ids'][k * 64:(k + 1) * 64], g['i_ids'][k * 64:(k + 1) * 64], labels[k * 64:(k + 1) * 64]) for k in range(4)]
+    models = []
+    for _ in range(2):
+        engine.set_seed(8)
+        m = getattr(basic, cls)(g['n_users'], g['n_items'], adjs, **CFG)
+        helpers.randomize_biases(m, seed=1)
+        models.append(m)
+    eager, graphed = training.Trainer(models[0], learning_rate=1e-2), training.Trainer(models[1], learning_rate=1e-2)
+    epoch_loss = []
+    for epoch in range(6):
+        tot = 0.0
+        for u, i, y in batches:
+            tot += eager.train_batch(u, i, y) * len(y)
+            graphed.train_batch_graphed(u, i, y)
+        epoch_loss.append(tot)
+    assert graphed._g is not None and graphed.t == eager.t == 24
+    assert epoch_loss[-1] < epoch_loss[0]
+    assert abs(graphed.pop_loss_sum() - sum(epoch_loss)) < 1e-3 * sum(epoch_loss)
+    for pa, pb in zip(models[0].parameters(), models[1].parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-3, atol=1e-5), tuple(pa.shape)

@@ -261,7 +261,7 @@ def main():
                     'pair_stage_traffic_bytes_per_launch' in json.load(open(pmc_path)):
                 pmc = json.load(open(pmc_path))
                 pair_traffic = pmc['pair_stage_traffic_bytes_per_launch']
-            out['pair_stage'] = {'kernel': 'chain_kernel<3,2,true> (relu(T_u[u] + T_i[i]) -> Dense 48 -> Dense 1, sigmoid)',
+            out['pair_stage'] = {'kernel': 'chain_pipe_kernel<3,2> (relu(T_u[u] + T_i[i]) -> Dense 48 -> Dense 1, sigmoid)',
                                  'avg_launch_ms': pms, 'pairs_per_launch': pairs_local, 'bound': 'hbm',
                                  'algorithmic_bytes_per_launch': pair_alg, 'achieved': pair_alg / (pms * 1e-3) / 1e9,
                                  'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': pair_alg / (pms * 1e-3) / 1e9 / HBM_PEAK_GBPS,

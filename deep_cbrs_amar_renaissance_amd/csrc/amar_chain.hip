@@ -47,9 +47,17 @@ __device__ __forceinline__ float chain_act(float v, int act) {
     return v;
 }
 
+// RELU (template flag of the kernels below): the summed-input activation and every MFMA layer's activation are ReLU — true
+// for every head of the reference's configs (dense.py:4-17 applies one `activation` throughout, 'relu' in config.yaml:27).
+// With the activation a run-time value every one of the 48 activated registers per 32 pairs went through a chain of
+// scalar branches (3 000 instructions in the loop, the VALU as busy as the matrix pipe); known at compile time the loop
+// body is straight-line code.
+template <bool RELU>
+__device__ __forceinline__ float chain_act_t(float v, int act) { return RELU ? fmaxf(v, 0.f) : chain_act(v, act); }
+
 // FULL: every MFMA layer has exactly MAXT input and MAXT output tiles (e.g. grid1's 48 -> 48 -> 48 classifier with
 // MAXT = 3): the tile guards fold away and the layer bodies become straight-line MFMA code.
-template <int MAXT, int PT, bool FULL>
+template <int MAXT, int PT, bool FULL, bool RELU>
 __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float w_lds[];
     for (int i = threadIdx.x * 4; i < a.wpack_floats; i += blockDim.x * 4)
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
                             const f32x4 vb = *reinterpret_cast<const f32x4 *>(a.B + rb * a.ldb + f);
                             v = va + vb;
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = chain_act(v[r], a.in_act);
+                            for (int r = 0; r < 4; ++r) v[r] = chain_act_t<RELU>(v[r], a.in_act);
                         }
                     } else if (f < a.Da) v = *reinterpret_cast<const f32x4 *>(a.A + ra * a.lda + f);
                     else if (f < a.Da + a.Db) v = *reinterpret_cast<const f32x4 *>(a.B + rb * a.ldb + (f - a.Da));
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
                     if (FULL || m < NT) {
                         v = y[m][pt];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = chain_act(v[r], act);
+                        for (int r = 0; r < 4; ++r) v[r] = chain_act_t<RELU>(v[r], act);
                     }
                     x[m][pt] = v;
                 }
@@ -160,6 +168,148 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
             }
         }
     }
+}
+
+// Pair-stage form of the same chain (x = relu(A[ida] + B[idb]), every layer MAXT x MAXT tiles with ReLU, Da = 16 MAXT).
+//
+// What bounds this stage (tools/micro/mfma_valu_overlap.hip, tools/exp_chain_bound.py): on gfx950 an fp32 MFMA holds the
+// SIMD's VALU port for its whole duration — MFMA cycles and plain VALU cycles ADD UP, also across the waves of a SIMD —
+// so the launch time is (72 MFMAs x 32 cycles) + 4 x (VALU instructions) per 32 pairs, plus whatever memory latency is
+// left exposed.  The generic kernel above spends ~400 VALU instructions per 32 pairs (0.72 ms for 12.1 M pairs with the
+// memory system taken out of the picture, against 0.35 ms of MFMA work) and waits for its gathers six times per
+// iteration.  This kernel therefore
+//   * issues the 12 gathers of iteration k+1 before the MFMA block of iteration k (raw A and B rows in their own
+//     registers: they are consumed — summed, ReLU — right before the next ones are requested) and keeps the ids two
+//     iterations ahead;
+//   * takes ReLU as one integer max on the float's bits (no NaN-quieting pre-pass), forms addresses from 32-bit row
+//     numbers, and evaluates the final activation once per 32 pairs (lane group g finishes pair tile g).
+// Same arithmetic in the same order as the generic kernel: the scores are bit-identical.
+__device__ __forceinline__ float relu_bits(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
+
+template <int MAXT, int PT>
+__global__ __launch_bounds__(256) void chain_pipe_kernel(const ChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float w_lds[];
+    for (int i = threadIdx.x * 4; i < a.wpack_floats; i += blockDim.x * 4)
+        *reinterpret_cast<float4 *>(&w_lds[i]) = *reinterpret_cast<const float4 *>(a.wpack + i);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, g = lane >> 4, col = lane & 15;
+    const int64_t pairs_per_wave = 16 * PT;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * 4 * pairs_per_wave;
+    const float *Ag = a.A + 4 * g, *Bg = a.B + 4 * g;
+    const uint32_t lda = (uint32_t)a.lda, ldb = (uint32_t)a.ldb;   // (the launcher checks that both fit 32 bits)
+
+    auto load_ids = [&](int64_t b, uint32_t (&ra)[PT], uint32_t (&rb)[PT]) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const int64_t p = b + 16 * pt + col;
+            const bool ok = p < a.P;                               // pairs past the end read row 0 and are never stored
+            ra[pt] = ok ? (uint32_t)(a.ids_a[p] - a.base_a) : 0u;
+            rb[pt] = ok ? (uint32_t)(a.ids_b[p] - a.base_b) : 0u;
+        }
+    };
+    auto issue = [&](const uint32_t (&ra)[PT], const uint32_t (&rb)[PT], f32x4 (&va)[MAXT][PT], f32x4 (&vb)[MAXT][PT]) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const float *pa = Ag + (uint64_t)ra[pt] * lda, *pb = Bg + (uint64_t)rb[pt] * ldb;   // one v_mad_u64_u32 each
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                va[t][pt] = *reinterpret_cast<const f32x4 *>(pa + 16 * t);
+                vb[t][pt] = *reinterpret_cast<const f32x4 *>(pb + 16 * t);
+            }
+        }
+    };
+    // one iteration: consume (va, vb), start the next iteration's gathers into (na, nb), run the layers, store
+    auto step = [&](int64_t base, uint32_t (&ra)[PT], uint32_t (&rb)[PT], f32x4 (&va)[MAXT][PT], f32x4 (&vb)[MAXT][PT],
+                    f32x4 (&na)[MAXT][PT], f32x4 (&nb)[MAXT][PT]) {
+        f32x4 x[MAXT][PT];
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                f32x4 v = va[t][pt] + vb[t][pt];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = relu_bits(v[r]);
+                x[t][pt] = v;
+            }
+        if (base + stride < a.P) {                                 // wave-uniform
+            issue(ra, rb, na, nb);
+            load_ids(base + 2 * stride, ra, rb);
+        }
+        for (int l = 0; l < a.n_layers; ++l) {
+            const float *wl = w_lds + a.w_off[l];
+            const float *bl = w_lds + a.b_off[l];
+            f32x4 y[MAXT][PT];
+#pragma unroll
+            for (int m = 0; m < MAXT; ++m) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bl + 16 * m + 4 * g);
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) y[m][pt] = b4;
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wl + ((m * MAXT + t) * 64 + lane) * 4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int pt = 0; pt < PT; ++pt)
+                            y[m][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[r], x[t][pt][r], y[m][pt], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < MAXT; ++m)
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[m][pt][r] = relu_bits(y[m][pt][r]);
+        }
+        if (a.has_dot) {
+            const float *wd = w_lds + a.dot_off;
+            const float bd = w_lds[a.dot_bias_off];
+            f32x4 w4[MAXT];
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) w4[t] = *reinterpret_cast<const f32x4 *>(wd + 16 * t + 4 * g);
+            float s[PT];
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                float acc = 0.f;
+#pragma unroll
+                for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = fmaf(x[t][pt][r], w4[t][r], acc);
+                acc += __shfl_xor(acc, 16, 64);
+                acc += __shfl_xor(acc, 32, 64);                    // every lane of a column now holds the pair's sum
+                s[pt] = acc;
+            }
+            // lane group g finishes pair tile g: one activation pass for all PT tiles
+            float z = s[0];
+#pragma unroll
+            for (int pt = 1; pt < PT; ++pt) z = g == pt ? s[pt] : z;
+            z += bd;
+            z = chain_act(z, a.dot_act);                            // same expression as the generic kernel: bit-identical scores
+            const int64_t p = base + 16 * g + col;
+            if (g < PT && p < a.P) a.out[p * a.ldo] = z;
+        } else {
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int64_t p = base + 16 * pt + col;
+#pragma unroll
+                for (int m = 0; m < MAXT; ++m) {
+                    const int f = 16 * m + 4 * g;
+                    if (p < a.P && f < a.n_out) *reinterpret_cast<f32x4 *>(a.out + p * a.ldo + f) = x[m][pt];
+                }
+            }
+        }
+    };
+
+    int64_t base = wave0 * pairs_per_wave;
+    if (base >= a.P) return;
+    f32x4 va[MAXT][PT], vb[MAXT][PT];
+    uint32_t ra[PT], rb[PT];
+    load_ids(base, ra, rb);
+    issue(ra, rb, va, vb);
+    load_ids(base + stride, ra, rb);
+    for (; base < a.P; base += stride) step(base, ra, rb, va, vb, va, vb);   // the raw rows are consumed before the next ones are requested
 }
 
 // Two-branch form for the hybrid head (src/models/hybrid.py:72-89 with the first layers of dense3a / dense3b folded
@@ -413,19 +563,35 @@ int amar_chain_f32(const float *A, int64_t lda, int32_t Da, const int32_t *ids_a
     const int maxt = maxw <= 48 ? 3 : (maxw <= 64 ? 4 : 8);
     bool full = (dims[0] + 15) / 16 == maxt && (!a.has_dot || a.dot_kt == maxt);
     for (int l = 0; l < a.n_layers; ++l) full = full && a.kt[l] == maxt && a.nt[l] == maxt;
+    bool relu = !a.sum_inputs || a.in_act == AMAR_ACT_RELU;
+    for (int l = 0; l < a.n_layers; ++l) relu = relu && a.act[l] == AMAR_ACT_RELU;
     int pt = 2;                                                   // measured best on grid1/grid2/grid6 shapes (tools/exp_chain.py)
     if (force_pt == 1 || force_pt == 2 || (force_pt == 4 && maxt != 8)) pt = force_pt;
 #define AMAR_CHAIN_LAUNCH(MT, PTT)                                                                                      \
     do {                                                                                                                \
         int64_t blocks = (P + 4 * 16 * PTT - 1) / (4 * 16 * PTT);                                                       \
         if (blocks > 4096) blocks = 4096;                                                                               \
-        auto kern = full ? chain_kernel<MT, PTT, true> : chain_kernel<MT, PTT, false>;                                  \
+        auto kern = full ? (relu ? chain_kernel<MT, PTT, true, true> : chain_kernel<MT, PTT, true, false>)              \
+                         : (relu ? chain_kernel<MT, PTT, false, true> : chain_kernel<MT, PTT, false, false>);           \
         if (lds_bytes > 64 * 1024 &&                                                                                    \
             hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,       \
                                 (int)lds_bytes) != hipSuccess)                                                          \
             return AMAR_ELAUNCH;                                                                                        \
         hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds_bytes, st, a);                                  \
     } while (0)
+    // pair stage (ReLU of the sum of two gathered rows, square ReLU layers): the pipelined kernel; AMAR_CHAIN_PIPE=0 keeps the generic one
+    static const bool no_pipe = getenv("AMAR_CHAIN_PIPE") && atoi(getenv("AMAR_CHAIN_PIPE")) == 0;
+    const bool a_dot_ok = !a.has_dot || a.dot_kt == maxt;
+    const bool small_tables = lda < (1ll << 32) && ldb < (1ll << 32);
+    if (!no_pipe && relu && a.sum_inputs && a.in_act == AMAR_ACT_RELU && full && a_dot_ok && a.ids_a && a.ids_b && a.Da == 16 * maxt &&
+        a.Db == a.Da && maxt <= 4 && pt == 2 && lds_bytes <= 64 * 1024 && small_tables) {
+        int64_t blocks = (P + 4 * 16 * 2 - 1) / (4 * 16 * 2);
+        if (blocks > 4096) blocks = 4096;
+        const dim3 grid((unsigned)blocks), block(256);
+        if (maxt == 3) hipLaunchKernelGGL((chain_pipe_kernel<3, 2>), grid, block, lds_bytes, st, a);
+        else hipLaunchKernelGGL((chain_pipe_kernel<4, 2>), grid, block, lds_bytes, st, a);
+        return amar_check_launch();
+    }
     if (maxt == 3) { if (pt == 1) AMAR_CHAIN_LAUNCH(3, 1); else if (pt == 2) AMAR_CHAIN_LAUNCH(3, 2); else AMAR_CHAIN_LAUNCH(3, 4); }
     else if (maxt == 4) { if (pt == 1) AMAR_CHAIN_LAUNCH(4, 1); else if (pt == 2) AMAR_CHAIN_LAUNCH(4, 2); else AMAR_CHAIN_LAUNCH(4, 4); }
     else { if (pt == 1) AMAR_CHAIN_LAUNCH(8, 1); else AMAR_CHAIN_LAUNCH(8, 2); }

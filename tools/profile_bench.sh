@@ -12,7 +12,7 @@ echo "rc=$?"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_DRAM_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
   name=$(echo $pass | cut -d' ' -f1)
   echo "== pmc $pass"; date
-  timeout -k 10 240 rocprofv3 --pmc $pass --kernel-include-regex "spmm_|chain_kernel" --output-format csv -d "$OUT/pmc_$name" -- python $ARGS > "$OUT/pmc_$name.log" 2>&1
+  timeout -k 10 240 rocprofv3 --pmc $pass --kernel-include-regex "spmm_|chain_" --output-format csv -d "$OUT/pmc_$name" -- python $ARGS > "$OUT/pmc_$name.log" 2>&1
   echo "rc=$?"
 done
 python - "$OUT" <<'PY'

@@ -116,6 +116,22 @@ def ml1m_true_size(dev):
     dt = (time.perf_counter() - t0) / 50
     out['hoisted_graph_pairs_per_s'], out['hoisted_graph_ms'] = p / dt, 1e3 * dt
     assert scores.shape[0] == p
+    # full ranking: every (user, item) combination, P_all = |U| x |I| (SURVEY.md 8d "pair sets"), hoisted
+    nu, ni = model.n_users, model.n_items
+    u_all = torch.arange(nu, device=dev, dtype=torch.int32).repeat_interleave(ni).contiguous()
+    i_all = (torch.arange(ni, device=dev, dtype=torch.int32) + nu).repeat(nu).contiguous()
+
+    def full_ranking():
+        emb = model.gnn(None)
+        return model.rs.score_towers(model.rs.towers(emb[:nu], emb[nu:]), u_all, i_all, 0, nu)
+    full_ranking()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        full_ranking()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 10
+    out['full_ranking_pairs'], out['full_ranking_pairs_per_s'], out['full_ranking_ms'] = nu * ni, nu * ni / dt, 1e3 * dt
     out.update({'pairs': p, 'nodes': n, 'nnz': a_hat.nnz, 'note': 'latency / launch-bound at this size'})
     return out
 

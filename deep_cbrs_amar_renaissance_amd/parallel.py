@@ -213,7 +213,8 @@ class PartitionedGCNRunner:
             return out
         f_cat = sum(widths)
         offs = np.cumsum([0] + widths)
-        e_all = torch.empty((self.world * R, f_cat), dtype=torch.float32, device=dev)
+        e_all = self._buffer(('e',), (self.world * R, f_cat)) if self.kind == 'gcn' else \
+            torch.empty((self.world * R, f_cat), dtype=torch.float32, device=dev)
         if self.kind in ('sage', 'gat'):
             ops.copy_columns(x0p, e_all[:, :widths[0]])                     # X_0 is a replicated weight
             # the rank's row block on the XCD-sliced forms (amar_spmm_xs_f32 mean aggregate / amar_gat_xs_f32): both take a
@@ -249,25 +250,36 @@ class PartitionedGCNRunner:
             xs = self.csr.xcd_sliced()
             return xs.col_scale if xs.row_scale is not None else None
 
-        h = torch.empty((self.world * R, widths[1]), dtype=torch.float32, device=dev)
+        # persistent buffers: at 8 ranks the local kernels take tens of microseconds, so per-step allocations and the
+        # memsets of the padded blocks would show up next to them (the pad rows are written once, here, and never again)
+        h = self._buffer(('h', 0), (self.world * R, widths[1]))
         scale = pre_scale(widths[1])
         ops.rowwise_xw(x0p, layers[0].kernel, h, copy_to=e_all[:, :widths[0]], row_scale=scale)   # X_0 slice rides along
         for k, layer in enumerate(layers):
-            y_local = torch.zeros((R, widths[k + 1]), dtype=torch.float32, device=dev)
+            y_local = self._buffer(('y', k), (R, widths[k + 1]), zero=True)
             if self._use_xs(widths[k + 1]):
                 # the rank's row block on the XCD-sliced image (value-free when A_hat's factors are known): same kernels
                 # as the single-GPU path, the block's own rows sit at column offset rank * R of the padded table
                 ops.spmm_xs(self.csr.xcd_sliced(), h, y_local[:rows], bias=layer.bias, relu=True, prescaled=scale is not None)
             else:
                 ops.gcn_layer(self.csr.rowptr, self.csr.colidx, self.csr.vals, h, layer.bias, y_local[:rows])
-            x_full = torch.empty((self.world * R, widths[k + 1]), dtype=torch.float32, device=dev)
+            x_full = self._buffer(('x', k), (self.world * R, widths[k + 1]))
             self.dist.all_gather_into_tensor(x_full, y_local)
             ops.copy_columns(x_full, e_all[:, offs[k + 1]:offs[k + 2]])
             if k + 1 < len(layers):
-                h = torch.empty((self.world * R, widths[k + 2]), dtype=torch.float32, device=dev)
+                h = self._buffer(('h', k + 1), (self.world * R, widths[k + 2]))
                 scale = pre_scale(widths[k + 2])
                 ops.rowwise_xw(x_full, layers[k + 1].kernel, h, row_scale=scale)
         return e_all
+
+    def _buffer(self, key, shape, zero=False):
+        """A per-runner float32 device buffer, allocated (and zeroed, if asked) on first use and then reused every step."""
+        cache = self.__dict__.setdefault('_buffers', {})
+        buf = cache.get(key)
+        if buf is None or tuple(buf.shape) != tuple(shape):
+            dev = self.seq.embeddings.device
+            buf = cache[key] = (torch.zeros if zero else torch.empty)(tuple(shape), dtype=torch.float32, device=dev)
+        return buf
 
     def step(self):
         if self.timing:

@@ -501,6 +501,9 @@ __global__ __launch_bounds__(XS_WAVES * AMAR_WAVE) void spmm_xs_partial_kernel(c
             key[j] = first + j < n_tile ? (int)((unsigned)cw[j] >> 26) : PAD_KEY;
             vv[j] = v[j];
         }
+        // the next super-step's words are requested as soon as this one's gathers are out: a tile is only ~3 super-steps
+        // long, so the stream's latency would otherwise be paid once per step, in series with the gathers'
+        if (t0 + SUPER < n_tile) load_words(t0 + SUPER, cw, v);
 
         float4 cur = make_float4(vv[0] * x[0].x, vv[0] * x[0].y, vv[0] * x[0].z, vv[0] * x[0].w);
 #pragma unroll
@@ -522,7 +525,6 @@ __global__ __launch_bounds__(XS_WAVES * AMAR_WAVE) void spmm_xs_partial_kernel(c
         // a cross-lane run ends where the next lane's last key differs (or the group ends); wave_shl:1 = 0x130: lane l reads l + 1
         const int knext = __builtin_amdgcn_mov_dpp(kl, 0x130, 0xF, 0xF, true);
         if (kl != PAD_KEY && (s == EPS - 1 || knext != kl)) flush(kl, cur);
-        if (t0 + SUPER < n_tile) load_words(t0 + SUPER, cw, v);
     }
     if (lane < nr) {
         float *out = a.P + ((int64_t)k * a.n_rows + r0 + lane) * F;

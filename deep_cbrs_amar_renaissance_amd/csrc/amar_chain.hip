@@ -465,6 +465,117 @@ __global__ __launch_bounds__(1024) void dual_chain_kernel(const DualArgs a) {
     }
 }
 
+// The hybrid head's common shape — 64-wide branches and trunk (4 tiles everywhere), ids on all four tables, ReLU
+// throughout (econfigs/hybrid-gnn*.yaml) — without tile guards or run-time activation selection, and with ALL sixteen
+// row gathers of an iteration (2 branches x 4 tiles x {A, B}) issued back to back before anything waits on them.  The
+// generic kernel above guards every tile load with the exec mask, which keeps the compiler from batching them: a wave
+// then pays eight memory round trips (~2 us each, the tables live in the Infinity Cache) per 16 pairs against 4.4 us of
+// MFMA work — with four waves per SIMD that alone explains its 63 % MFMA utilisation.  Same arithmetic in the same order:
+// bit-identical scores.
+__global__ __launch_bounds__(1024) void dual_chain_full_kernel(const DualArgs a) {
+    constexpr int T = 4;
+    extern __shared__ __attribute__((aligned(16))) float w_lds[];
+    for (int i = threadIdx.x * 4; i < a.wpack_floats; i += blockDim.x * 4)
+        *reinterpret_cast<float4 *>(&w_lds[i]) = *reinterpret_cast<const float4 *>(a.wpack + i);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, g = lane >> 4, col = lane & 15;
+    const int wpb = blockDim.x >> 6;
+    const int64_t wave0 = (int64_t)blockIdx.x * wpb + (threadIdx.x >> 6);
+    const int64_t stride = (int64_t)gridDim.x * wpb * 16;
+
+    for (int64_t base = wave0 * 16; base < a.P; base += stride) {
+        const int64_t p = base + col;
+        const bool ok = p < a.P;                               // pairs past the end read row 0 and are never stored
+        f32x4 va[2][T], vb[2][T];
+#pragma unroll
+        for (int br = 0; br < 2; ++br) {
+            const uint32_t ra = ok ? (uint32_t)(a.ida[br][p] - a.base_a[br]) : 0u;
+            const uint32_t rb = ok ? (uint32_t)(a.idb[br][p] - a.base_b[br]) : 0u;
+            const float *pa = a.A[br] + (uint64_t)ra * (uint32_t)a.lda[br] + 4 * g;
+            const float *pb = a.B[br] + (uint64_t)rb * (uint32_t)a.ldb[br] + 4 * g;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                va[br][t] = *reinterpret_cast<const f32x4 *>(pa + 16 * t);
+                vb[br][t] = *reinterpret_cast<const f32x4 *>(pb + 16 * t);
+            }
+        }
+        f32x4 xb[2][T];
+#pragma unroll
+        for (int br = 0; br < 2; ++br) {
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                f32x4 v = va[br][t] + vb[br][t];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = relu_bits(v[r]);
+                xb[br][t] = v;
+            }
+            for (int l = 0; l < a.n_branch; ++l) {
+                const float *wl = w_lds + a.bw_off[br][l], *bl = w_lds + a.bb_off[br][l];
+                f32x4 y[T];
+#pragma unroll
+                for (int m = 0; m < T; ++m) {
+                    y[m] = *reinterpret_cast<const f32x4 *>(bl + 16 * m + 4 * g);
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wl + ((m * T + t) * 64 + lane) * 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[r], xb[br][t][r], y[m], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int m = 0; m < T; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xb[br][m][r] = relu_bits(y[m][r]);
+            }
+        }
+        // ---- trunk: the first layer reads [xa || xb] (8 k-tiles), later layers 4 x 4
+        f32x4 x[T];
+        for (int l = 0; l < a.n_trunk; ++l) {
+            const float *wl = w_lds + a.tw_off[l], *bl = w_lds + a.tbias_off[l];
+            f32x4 y[T];
+            if (l == 0) {
+#pragma unroll
+                for (int m = 0; m < T; ++m) {
+                    y[m] = *reinterpret_cast<const f32x4 *>(bl + 16 * m + 4 * g);
+#pragma unroll
+                    for (int t = 0; t < 2 * T; ++t) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wl + ((m * 2 * T + t) * 64 + lane) * 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            y[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[r], xb[t / T][t % T][r], y[m], 0, 0, 0);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < T; ++m) {
+                    y[m] = *reinterpret_cast<const f32x4 *>(bl + 16 * m + 4 * g);
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wl + ((m * T + t) * 64 + lane) * 4);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) y[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[r], x[t][r], y[m], 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < T; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[m][r] = relu_bits(y[m][r]);
+        }
+        const float *wd = w_lds + a.dot_off;
+        float sacc = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wd + 16 * t + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sacc = fmaf(x[t][r], w4[r], sacc);
+        }
+        sacc += __shfl_xor(sacc, 16, 64);
+        sacc += __shfl_xor(sacc, 32, 64);
+        if (g == 0 && ok) a.out[p * a.ldo] = chain_act(sacc + w_lds[a.dot_bias_off], a.dot_act);
+    }
+}
+
 inline int tiles16(int n) { return (n + 15) / 16; }
 
 }  // namespace
@@ -651,7 +762,13 @@ int amar_dual_chain_f32(const float *const *A, const int64_t *lda, const int32_t
     constexpr int THREADS = 1024;                          // the blob (~84 KB for 64-wide stacks) allows one workgroup per CU
     int64_t blocks = (P + (THREADS / 64) * 16 * PT - 1) / ((THREADS / 64) * 16 * PT);
     if (blocks > 1024) blocks = 1024;
-    auto kern = dual_chain_kernel<PT>;
+    // the common shape of the hybrid head (64-wide everywhere, ids on every table, ReLU throughout): guard-free kernel
+    static const bool no_full = getenv("AMAR_DUAL_FULL") && atoi(getenv("AMAR_DUAL_FULL")) == 0;
+    bool full = !no_full && D == 64 && W == 64 && in_act == AMAR_ACT_RELU && n_branch >= 1 && ida[0] && ida[1] && idb[0] && idb[1];
+    for (int b = 0; b < 2; ++b) full = full && lda[b] < (1ll << 32) && ldb[b] < (1ll << 32);
+    for (int l = 0; l < n_branch; ++l) full = full && branch_acts[l] == AMAR_ACT_RELU;
+    for (int l = 0; l < n_trunk - 1; ++l) full = full && trunk_acts[l] == AMAR_ACT_RELU;
+    auto kern = full ? dual_chain_full_kernel : dual_chain_kernel<PT>;
     if (lds_bytes > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)
         return AMAR_ELAUNCH;

@@ -24,6 +24,7 @@ struct DenseArgs {
     const float *W; const float *bias; float *Y; int64_t ldy;
     int64_t M; int K; int N; int act;
     int w_trans;                                   // W holds the transpose: element (k, n) of the product's B sits at W[n * K + k]
+    int n_col_blocks;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -37,8 +38,16 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const DenseArgs a) {
     __shared__ float As[BK * A_LD];
     __shared__ float Bs[BK * B_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // Workgroup -> tile with XCD affinity: workgroup L runs on XCD L % 8; the column blocks of one row tile are consecutive
+    // in ONE XCD's queue, so its X rows (128 x K) are fetched from HBM once and re-read from that XCD's L2 — with (row tile,
+    // column block) on (blockIdx.x, blockIdx.y) every column block swept all of X again (4 passes over 1.2 GB for the
+    // 768 -> 256 BERT tower).
+    const int64_t L = blockIdx.x;
+    const int64_t j = L >> 3;
+    const int64_t m_blk = (j / a.n_col_blocks) * 8 + (L & 7);
+    if (m_blk * BM >= a.M) return;
+    const int64_t m0 = m_blk * BM;
+    const int n0 = (int)(j % a.n_col_blocks) * BN;
 
     // staging assignment: X tile = 128 rows x 4 float4 -> 2 rows per thread; W tile = 16 x 16 float4 -> 1 per thread
     const int xr = tid >> 2, xq = tid & 3;
@@ -54,9 +63,9 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const DenseArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 
-    for (int k0 = 0; k0 < a.K; k0 += BK) {
-        // global -> registers
-        float xa[2][4];
+    // global -> registers for the k-tile that starts at k0
+    float xa[2][4], wb[4];
+    auto fetch = [&](int k0) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int k = k0 + 4 * xq;
@@ -69,20 +78,21 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const DenseArgs a) {
                     xa[h][i] = (src_row[h] >= 0 && k + i < a.K) ? a.X[src_row[h] * a.ldx + k + i] : 0.f;
             }
         }
-        float wb[4];
-        {
-            const int k = k0 + wk, n = n0 + 4 * wq;
-            if (a.w_trans) {
+        const int k = k0 + wk, n = n0 + 4 * wq;
+        if (a.w_trans) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) wb[i] = (k < a.K && n + i < a.N) ? a.W[(int64_t)(n + i) * a.K + k] : 0.f;
-            } else if (k < a.K && VEC_W && n + 3 < a.N) {
-                const float4 v = *reinterpret_cast<const float4 *>(a.W + (int64_t)k * a.N + n);
-                wb[0] = v.x; wb[1] = v.y; wb[2] = v.z; wb[3] = v.w;
-            } else {
+            for (int i = 0; i < 4; ++i) wb[i] = (k < a.K && n + i < a.N) ? a.W[(int64_t)(n + i) * a.K + k] : 0.f;
+        } else if (k < a.K && VEC_W && n + 3 < a.N) {
+            const float4 v = *reinterpret_cast<const float4 *>(a.W + (int64_t)k * a.N + n);
+            wb[0] = v.x; wb[1] = v.y; wb[2] = v.z; wb[3] = v.w;
+        } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) wb[i] = (k < a.K && n + i < a.N) ? a.W[(int64_t)k * a.N + n + i] : 0.f;
-            }
+            for (int i = 0; i < 4; ++i) wb[i] = (k < a.K && n + i < a.N) ? a.W[(int64_t)k * a.N + n + i] : 0.f;
         }
+    };
+
+    fetch(0);
+    for (int k0 = 0; k0 < a.K; k0 += BK) {
         __syncthreads();                                // previous tile fully consumed
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -90,6 +100,8 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const DenseArgs a) {
             for (int i = 0; i < 4; ++i) As[(4 * xq + i) * A_LD + xr + 64 * h] = xa[h][i];
         *reinterpret_cast<float4 *>(&Bs[wk * B_LD + 4 * wq]) = make_float4(wb[0], wb[1], wb[2], wb[3]);
         __syncthreads();
+        // the next k-tile travels from memory while this one is multiplied (on gfx950 nothing else overlaps an fp32 MFMA)
+        if (k0 + BK < a.K) fetch(k0 + BK);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const int k = kk + (lane >> 5);
@@ -177,8 +189,11 @@ int amar_dense_f32(const float *X, int64_t ldx, const int32_t *ids,
     if (M == 0) return AMAR_OK;
     const int64_t gx = (M + BM - 1) / BM;
     if (gx > 0x7fffffffLL) return AMAR_EUNSUPPORTED;
-    DenseArgs a{X, ldx, ids, W, bias, Y, ldy, M, K, N, act, w_trans};
-    const dim3 grid((unsigned)gx, (unsigned)((N + BN - 1) / BN)), block(256);
+    const int ny = (N + BN - 1) / BN;
+    DenseArgs a{X, ldx, ids, W, bias, Y, ldy, M, K, N, act, w_trans, ny};
+    const int64_t total = ((gx + 7) / 8) * 8 * ny;
+    if (total > 0x7fffffffLL) return AMAR_EUNSUPPORTED;
+    const dim3 grid((unsigned)total), block(256);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool vx = (ldx & 3) == 0 && amar_aligned16(X);
     const bool vw = (N & 3) == 0 && amar_aligned16(W);

@@ -130,6 +130,8 @@ class PartitionedGCNRunner:
     def __init__(self, model, u_ids, i_ids, rank, world, ops=capi, dist=None, timing=True):
         self.ops, self.rank, self.world, self.timing = ops, rank, world, timing
         self.dist = dist if dist is not None else torch.distributed
+        if not hasattr(model.gnn, 'gnn_layers'):
+            raise NotImplementedError("the partitioned runner covers single-graph models; TwoStep / TwoWay stacks run on one GPU")
         seq = model.gnn.gnn_layers
         layers = list(seq.seq_layers)
         if layers and all(isinstance(l, GCNConv) for l in layers) and seq.final_node == 'concatenation':

@@ -256,3 +256,75 @@ def test_fit_reduces_loss_and_replays_graphs(hip, cls):
     assert abs(graphed.pop_loss_sum() - sum(epoch_loss)) < 1e-3 * sum(epoch_loss)
     for pa, pb in zip(models[0].parameters(), models[1].parameters()):
         assert torch.allclose(pa, pb, rtol=1e-3, atol=1e-5), tuple(pa.shape)
+
+
+@pytest.mark.parametrize('cls,layout', [('HybridBertTSGCN', 'two_step'), ('HybridBertTWGraphSage', 'two_way')])
+def test_hybrid_gradients_match_autograd_oracle(hip, cls, layout):
+    """HybridBertTS* / HybridBertTW* (hybrid.py:160-181): the chained stacks under the four-input head with attention fusion."""
+    from deep_cbrs_amar_renaissance_amd import engine, training
+    from deep_cbrs_amar_renaissance_amd.models import hybrid
+    from oracle import train as otrain
+    engine.set_seed(11)
+    g = helpers.kg_graph(n_users=60, n_items=45, n_props=30, n_ratings=900, n_links=120, seed=13)
+    adjs = (g['adj_ui'], g['adj_ip']) if layout == 'two_step' else (g['adj_ui'], g['adj_ip'], g['adj_up'])
+    cfg = dict(CFG, dense_units=[[24, 16], [32, 24], [16, 16]], clf_units=[24, 16], feature_based=True, fusion_method='attention')
+    model = getattr(hybrid, cls)(g['n_users'], g['n_items'], adjs, **cfg)
+    rng = np.random.default_rng(3)
+    table = rng.standard_normal((g['n_users'] + g['n_items'], 40)).astype(np.float32) * 0.5
+    model.set_bert_table(table)
+    y = rng.integers(0, 2, len(g['u_ids']))
+    trainer = training.Trainer(model)
+    _perturb(model, 31)
+    u, i = g['u_ids'], g['i_ids']
+    loss, grads = trainer.loss_and_grads(u, i, y)
+    ow = helpers.two_step_to_oracle if layout == 'two_step' else helpers.two_way_to_oracle
+    want_loss, want, p = otrain.torch_model_grads(adjs, ow(model.gnn), helpers.hybrid_head_to_oracle(model.rs), u, i, y, l2=1e-4,
+                                                  bert=(table[u], table[i]), feature_based=True, n_users=g['n_users'], n_items=g['n_items'])
+    with torch.no_grad():
+        assert np.abs(model((u, i, None, None)).cpu().numpy()[:, 0] - p).max() < 1e-5
+    assert abs(loss - want_loss) < 1e-5
+    flat = {}
+    for name in (('step_one', 'step_two') if layout == 'two_step' else ('way_one', 'way_two', 'step_two')):
+        _flat_stack(getattr(model.gnn, name + '_gnn_layers'), want['gnn'][name], flat)
+    for name in want['head']:
+        if name.startswith('fuse'):
+            for key, arr in want['head'][name].items():
+                flat[getattr(getattr(model.rs, name), key)] = arr
+            continue
+        for layer, (gw, gb) in zip(getattr(model.rs, name).layers, want['head'][name]):
+            flat[layer.kernel], flat[layer.bias] = gw, gb
+    assert set(flat) == set(grads)
+    for prm, gw in flat.items():
+        got = grads[prm].cpu().numpy().reshape(gw.shape).astype(np.float64)
+        got += 2 * trainer._l2(prm) * prm.detach().cpu().numpy().reshape(gw.shape)
+        assert np.abs(got - gw).max() <= 2e-4 * np.abs(gw).max() + 1e-10, tuple(prm.shape)
+
+
+def test_randomised_shapes(hip):
+    """Seeded sweep over graph sizes, widths, depths and reductions of both layouts (inference parity with the oracle)."""
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    rng = np.random.default_rng(2024)
+    for trial in range(12):
+        nu, ni, n_props = int(rng.integers(5, 70)), int(rng.integers(5, 60)), int(rng.integers(3, 40))
+        g = helpers.kg_graph(n_users=nu, n_items=ni, n_props=n_props, n_ratings=int(rng.integers(10, 600)), n_links=int(rng.integers(5, 150)),
+                             seed=int(rng.integers(0, 1000)))
+        kind = KINDS[trial % len(KINDS)]
+        d = int(rng.choice([4, 8, 16]))
+        hops = int(rng.integers(1, 4))
+        node = str(rng.choice(['mean', 'sum', 'last'] if kind in ('LightGCN', 'DGCF') else ['mean', 'sum', 'last', 'concatenation']))
+        final = str(rng.choice(['concatenation', 'mean', 'last']))
+        cfg = dict(CFG, embedding_dim=d, n_hiddens=[d] * hops, n_layers=hops, final_node=final)
+        if trial % 2 == 0:
+            adjs = (g['adj_ui'], g['adj_ip'])
+            model = getattr(basic, 'BasicTS' + kind)(nu, ni, adjs, **dict(cfg, item_node=node))
+            want_fn, ow = om.two_step, helpers.two_step_to_oracle
+        else:
+            adjs = (g['adj_ui'], g['adj_ip'], g['adj_up'])
+            model = getattr(basic, 'BasicTW' + kind)(nu, ni, adjs, **dict(cfg, user_item_node=node))
+            want_fn, ow = om.two_way, helpers.two_way_to_oracle
+        _perturb(model, trial)
+        want_e = want_fn(adjs, ow(model.gnn), nu, ni, np.float64)
+        got_e = model.gnn(None).cpu().numpy()
+        label = '{} {} d={} hops={} node={} final={} ({} users, {} items, {} props)'.format(type(model).__name__, kind, d, hops, node, final, nu, ni, n_props)
+        assert got_e.shape == want_e.shape, label
+        assert helpers.rel_err(got_e, want_e) < 1e-5, label

@@ -35,6 +35,7 @@ SIGNATURES = {
     'amar_gcn_layer_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _I64, _P, _I32, _P, _I64, _I32, _P]),
     'amar_rowwise_xw_f32': (ctypes.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I32, _P]),
     'amar_sage_layer_f32': (ctypes.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _I32, _P, _I64, _I32, _I32, _P]),
+    'amar_sage_tail_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I32, _P, _P, _I32, _P, _I64, _I64, _P]),
     'amar_gat_layer_f32': (ctypes.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _P, _I64, _I32, _I32, _P]),
     'amar_dense_f32': (ctypes.c_int, [_P, _I64, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _P]),
     'amar_chain_pack_floats': (ctypes.c_int64, [_P, _I32]),
@@ -294,6 +295,22 @@ def sage_layer(rowptr, colidx, X, W, bias, Y, self_loop=True):
         _ptr(X, torch.float32, 'X'), _ld(X, 'X'), F, _ptr(W, torch.float32, 'W'), _ptr(bias, torch.float32, 'bias'),
         W.shape[1], _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y'), 1 if self_loop else 0, n_rows, _stream())
     _check(code, 'amar_sage_layer_f32')
+
+
+def sage_tail(X, agg, W, bias, Y):
+    """Y = relu(l2_normalize([X || agg] . W + bias)): GraphSageConv after its mean aggregate (see amar_sage_tail_f32)."""
+    n_rows, F = agg.shape
+    if X.shape[1] != F or X.shape[0] < n_rows or W.shape[0] != 2 * F or not W.is_contiguous() or bias.numel() != W.shape[1] or \
+            tuple(Y.shape) != (n_rows, W.shape[1]):
+        raise ValueError("sage_tail: X [>=n_rows, F], agg [n_rows, F], W [2F, C] contiguous, bias [C], Y [n_rows, C] expected")
+    code = load().amar_sage_tail_f32(_ptr(X, torch.float32, 'X'), _ld(X, 'X'), _ptr(agg, torch.float32, 'agg'), _ld(agg, 'agg'), F,
+                                     _ptr(W, torch.float32, 'W'), _ptr(bias, torch.float32, 'bias'), W.shape[1],
+                                     _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y'), n_rows, _stream())
+    _check(code, 'amar_sage_tail_f32')
+
+
+def sage_tail_supported(F, C):
+    return F % 4 == 0 and C % 4 == 0 and 4 <= F <= 64 and 4 <= C <= 64
 
 
 def gat_layer(rowptr, colidx, H, s_self, s_neigh, bias, Y, self_loop=True):

@@ -916,6 +916,55 @@ __global__ __launch_bounds__(256) void gat_pack_kernel(const float *__restrict__
     }
 }
 
+
+// ---- GraphSAGE tail: Y = relu(l2_normalize([X || AGG] . W + b)) ------------------------------------------------------------
+// The part of Spektral's GraphSageConv.call after the aggregation (layer built at src/models/gnn.py:354-361), for the
+// routes that produce the mean aggregate with an SpMM (XCD-sliced image on large graphs, column-chunked widths): one
+// thread per row, the [2F, C] kernel and the bias in LDS (every lane reads the same element: broadcast), the C outputs in
+// registers.  Replaces the copy into [x || agg] + amar_dense_f32 + amar_l2norm_fwd_f32 of the inference path: 96 B per row
+// instead of ~350.
+struct SageTailArgs { const float *X; int64_t ldx; const float *G; int64_t ldg; int F; const float *W; const float *bias; int C;
+                      float *Y; int64_t ldy; int64_t M; };
+
+template <int CP>
+__global__ __launch_bounds__(256) void sage_tail_kernel(const SageTailArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float w_lds[];
+    const int nw = 2 * a.F * a.C;
+    for (int i = threadIdx.x; i < nw; i += blockDim.x) w_lds[i] = a.W[i];
+    for (int i = threadIdx.x; i < a.C; i += blockDim.x) w_lds[nw + i] = a.bias[i];
+    __syncthreads();
+    const int C = a.C;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < a.M; r += (int64_t)gridDim.x * blockDim.x) {
+        float acc[CP];
+#pragma unroll
+        for (int c = 0; c < CP; ++c) acc[c] = 0.f;
+        for (int half = 0; half < 2; ++half) {
+            const float *src = half == 0 ? a.X + r * a.ldx : a.G + r * a.ldg;
+            const float *w = w_lds + half * a.F * C;
+            for (int k4 = 0; k4 < a.F; k4 += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(src + k4);
+                const float xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int c = 0; c < CP; ++c)
+                        if (c < C) acc[c] = fmaf(xs[j], w[(k4 + j) * C + c], acc[c]);
+            }
+        }
+        float sq = 0.f;
+#pragma unroll
+        for (int c = 0; c < CP; ++c)
+            if (c < C) { acc[c] += w_lds[nw + c]; sq = fmaf(acc[c], acc[c], sq); }
+        const float iv = rsqrtf(fmaxf(sq, 1e-12f));              // tf.nn.l2_normalize: x * rsqrt(max(sum x^2, 1e-12))
+        float *y = a.Y + r * a.ldy;
+#pragma unroll
+        for (int c4 = 0; c4 < CP; c4 += 4)
+            if (c4 < C)
+                *reinterpret_cast<float4 *>(y + c4) = make_float4(fmaxf(acc[c4] * iv, 0.f), fmaxf(acc[c4 + 1] * iv, 0.f),
+                                                                  fmaxf(acc[c4 + 2] * iv, 0.f), fmaxf(acc[c4 + 3] * iv, 0.f));
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -1029,6 +1078,28 @@ int amar_sage_layer_f32(const int32_t *rowptr, const int32_t *colidx,
     case 32: hipLaunchKernelGGL(sage_row_kernel<32>, grid, block, 0, st, a); break;
     default: return AMAR_EUNSUPPORTED;
     }
+    return amar_check_launch();
+}
+
+int amar_sage_tail_f32(const float *X, int64_t ldx, const float *AGG, int64_t lda, int32_t F,
+                       const float *W, const float *bias, int32_t C, float *Y, int64_t ldy,
+                       int64_t n_rows, amar_stream_t stream) {
+    if (n_rows < 0 || !X || !AGG || !W || !bias || !Y || F < 4 || C < 4 || (F & 3) || (C & 3)) return AMAR_EINVAL;
+    if (!ld_ok(ldx, F) || !ld_ok(lda, F) || !ld_ok(ldy, C) || !amar_aligned16(X) || !amar_aligned16(AGG) || !amar_aligned16(Y))
+        return AMAR_EINVAL;
+    if (F > 64 || C > 64) return AMAR_EUNSUPPORTED;
+    if (n_rows == 0) return AMAR_OK;
+    SageTailArgs a{X, ldx, AGG, lda, F, W, bias, C, Y, ldy, n_rows};
+    const size_t lds = (size_t)(2 * F * C + C) * sizeof(float);   // <= 33 KB
+    int64_t blocks = (n_rows + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    const dim3 grid((unsigned)blocks), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (C <= 4) hipLaunchKernelGGL(sage_tail_kernel<4>, grid, block, lds, st, a);
+    else if (C <= 8) hipLaunchKernelGGL(sage_tail_kernel<8>, grid, block, lds, st, a);
+    else if (C <= 16) hipLaunchKernelGGL(sage_tail_kernel<16>, grid, block, lds, st, a);
+    else if (C <= 32) hipLaunchKernelGGL(sage_tail_kernel<32>, grid, block, lds, st, a);
+    else hipLaunchKernelGGL(sage_tail_kernel<64>, grid, block, lds, st, a);
     return amar_check_launch();
 }
 

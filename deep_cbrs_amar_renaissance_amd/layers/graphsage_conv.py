@@ -57,15 +57,20 @@ class GraphSageConv(Layer):
         if kind != 'xs' and f in (4, 8, 16, 32) and self.channels <= 64:
             capi.sage_layer(a.rowptr, a.colidx, x, self.kernel, self.bias, out, self_loop=self.self_loops)
             return out
-        xa = torch.empty((n, 2 * f), dtype=torch.float32, device=x.device)
-        capi.copy_columns(x, xa[:, :f])
+        fused_tail = capi.sage_tail_supported(f, self.channels)
+        xa = torch.empty((n, f if fused_tail else 2 * f), dtype=torch.float32, device=x.device)
+        agg = xa if fused_tail else xa[:, f:]
         if kind == 'xs':
-            capi.spmm_xs(a.xcd_sliced_mean(self.self_loops), x, xa[:, f:], prescaled=True)
+            capi.spmm_xs(a.xcd_sliced_mean(self.self_loops), x, agg, prescaled=True)
         else:
             # widths the fused row kernel is not instantiated for (TwoStep / TwoWay 'concatenation' hand-over, 24 / 48):
             # neighbour sum as column chunks of the value-free SpMM, then (sum + own row) / count
-            capi.spmm_csr(a.rowptr, a.colidx, None, x, xa[:, f:])
-            capi.row_affine(xa[:, f:], self._inv_count(a), xa[:, f:], b=x if self.self_loops else None)
+            capi.spmm_csr(a.rowptr, a.colidx, None, x, agg)
+            capi.row_affine(agg, self._inv_count(a), agg, b=x if self.self_loops else None)
+        if fused_tail:
+            capi.sage_tail(x, agg, self.kernel, self.bias, out)    # [x || agg] . W + b, l2-normalise, ReLU in one pass
+            return out
+        capi.copy_columns(x, xa[:, :f])
         z = torch.empty((n, self.channels), dtype=torch.float32, device=x.device)
         capi.dense(xa, self.kernel, self.bias, z, act=None)
         nrm = torch.empty_like(z)

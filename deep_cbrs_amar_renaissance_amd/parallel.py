@@ -227,13 +227,18 @@ class PartitionedGCNRunner:
                 f, c = widths[k], widths[k + 1]
                 y_local = torch.zeros((R, c), dtype=torch.float32, device=dev)
                 if self.kind == 'sage':
-                    xa = torch.empty((rows, 2 * f), dtype=torch.float32, device=dev)
-                    ops.copy_columns(x_full[lo:lo + rows], xa[:, :f])
-                    ops.spmm_xs(self.csr.xcd_sliced_mean(layer.self_loops), x_full, xa[:, f:], prescaled=True)
-                    z = torch.empty((rows, c), dtype=torch.float32, device=dev)
-                    ops.dense(xa, layer.kernel, layer.bias, z, act=None)
-                    nrm, inv = torch.empty_like(z), torch.empty(rows, dtype=torch.float32, device=dev)
-                    ops.l2norm_fwd(z, nrm, inv, y_local[:rows], act='relu')
+                    agg = torch.empty((rows, f), dtype=torch.float32, device=dev)
+                    ops.spmm_xs(self.csr.xcd_sliced_mean(layer.self_loops), x_full, agg, prescaled=True)
+                    if ops.sage_tail_supported(f, c):
+                        ops.sage_tail(x_full[lo:lo + rows], agg, layer.kernel, layer.bias, y_local[:rows])
+                    else:
+                        xa = torch.empty((rows, 2 * f), dtype=torch.float32, device=dev)
+                        ops.copy_columns(x_full[lo:lo + rows], xa[:, :f])
+                        ops.copy_columns(agg, xa[:, f:])
+                        z = torch.empty((rows, c), dtype=torch.float32, device=dev)
+                        ops.dense(xa, layer.kernel, layer.bias, z, act=None)
+                        nrm, inv = torch.empty_like(z), torch.empty(rows, dtype=torch.float32, device=dev)
+                        ops.l2norm_fwd(z, nrm, inv, y_local[:rows], act='relu')
                 else:
                     h = torch.empty((self.world * R, c), dtype=torch.float32, device=dev)
                     s_self = torch.empty(self.world * R, dtype=torch.float32, device=dev)

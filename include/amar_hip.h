@@ -145,6 +145,13 @@ int amar_sage_layer_f32(const int32_t *rowptr, const int32_t *colidx,
                         float *Y, int64_t ldy, int32_t self_loop,
                         int32_t n_rows, amar_stream_t stream);
 
+/* The tail of the same layer when the mean aggregate AGG[n_rows, F] was produced by an SpMM (amar_spmm_xs_f32 on the
+ * XCD-sliced mean image for large graphs; amar_spmm_csr_f32 + amar_row_affine_f32 for widths the fused kernel is not
+ * instantiated for):  Y = relu(l2_normalize([X || AGG] . W + bias)), W [2F, C] row-major.  F, C multiples of 4, <= 64. */
+int amar_sage_tail_f32(const float *X, int64_t ldx, const float *AGG, int64_t lda, int32_t F,
+                       const float *W, const float *bias, int32_t C, float *Y, int64_t ldy,
+                       int64_t n_rows, amar_stream_t stream);
+
 /* One GAT layer, 1 head (Spektral 1.x GATConv._call_single, built at src/models/gnn.py:321-328):
  *     e_ij  = LeakyReLU_0.2( s_self[i] + s_neigh[j] ),  j in N(i) (+ i itself if self_loop)
  *     alpha = exp(e_ij - max_j e_ij) / ( sum_j exp(e_ij - max_j e_ij) + 1e-9 )

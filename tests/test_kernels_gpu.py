@@ -195,6 +195,29 @@ def test_sage_layer(hip, F, C, self_loop):
     assert rel_err(y.cpu().numpy(), want) < 5e-6
 
 
+@pytest.mark.parametrize('F,C', [(8, 8), (16, 16), (24, 24), (4, 32), (32, 12), (64, 64), (48, 20)])
+def test_sage_tail(hip, F, C):
+    """GraphSageConv after its mean aggregate: relu(l2_normalize([x || agg] . W + b)) in one pass, on strided views; a row
+    whose pre-activation is all zero stays zero (the 1e-12 clamp of tf.nn.l2_normalize)."""
+    n = 1000
+    rng = np.random.default_rng(F * 100 + C)
+    xbuf = rng.standard_normal((n + 5, F + 8)).astype(np.float32)
+    g = rng.standard_normal((n, F)).astype(np.float32)
+    w = rng.uniform(-0.5, 0.5, (2 * F, C)).astype(np.float32)
+    b = rng.uniform(-0.1, 0.1, C).astype(np.float32)
+    xbuf[7], g[7], b0 = 0, 0, b.copy()
+    xd, out = _t(xbuf), torch.full((n, C + 4), -7.0, device=DEV)
+    hip.sage_tail(xd[:, 4:4 + F], _t(g), _t(w), _t(b), out[:, :C])
+    z = np.concatenate([xbuf[:n, 4:4 + F], g], 1).astype(np.float64) @ w.astype(np.float64) + b
+    want = np.maximum(z / np.sqrt(np.maximum((z * z).sum(1, keepdims=True), 1e-12)), 0)
+    got = out.cpu().numpy()
+    assert rel_err(got[:, :C], want) < 2e-6 and np.all(got[:, C:] == -7.0)
+    z7 = b0.astype(np.float64)
+    assert np.allclose(got[7, :C], np.maximum(z7 / np.sqrt(max((z7 * z7).sum(), 1e-12)), 0), atol=1e-6)
+    with pytest.raises(Exception):
+        hip.sage_tail(xd[:, 4:4 + F], _t(g), _t(w[:-1].copy()), _t(b), out[:, :C])
+
+
 @pytest.mark.parametrize('C', [4, 8, 16, 32, 64, 24, 48])
 @pytest.mark.parametrize('self_loop', [True, False])
 def test_gat_layer(hip, C, self_loop):

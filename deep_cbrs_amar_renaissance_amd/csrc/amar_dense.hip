@@ -15,7 +15,7 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 64, BK = 16;
+constexpr int BM = 128, BN = 64, BK = 16;   // BK = 32 (half the barriers, 25 KB of LDS per workgroup) measured 12 % slower (tools/exp_dense_ab.py)
 constexpr int A_LD = BM + 4;     // +4 floats: the transposing store is at most 2-way conflicted
 constexpr int B_LD = BN;
 

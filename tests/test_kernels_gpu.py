@@ -139,7 +139,7 @@ def test_gcn_layer_fused_next(hip, C, Cn):
     assert torch.equal(y, y2), "fused and unfused epilogues must agree bit for bit"
 
 
-@pytest.mark.parametrize('F,C', [(8, 8), (24, 8), (5, 3), (64, 64), (16, 32)])
+@pytest.mark.parametrize('F,C', [(8, 8), (24, 8), (5, 3), (64, 64), (16, 32), (16, 16), (8, 4), (12, 12), (32, 16), (8, 6)])   # C <= 16, aligned: one thread per row
 def test_rowwise_xw(hip, F, C):
     n = 777
     rng = np.random.default_rng(F * C)

@@ -316,7 +316,7 @@ def test_partitioned_runner_with_real_kernels(hip, world, case, monkeypatch):
             torch.cuda.synchronize()
             if '-xs' in case and 'GCN' in case:
                 assert runner._use_xs(8) and (runner.csr.xcd_sliced().row_scale is not None) == case.endswith('-valuefree')
-            results[rank] = (e_pad[idx].cpu().numpy(), scores.cpu().numpy(), runner.pair_range)
+            results[rank] = (e_pad[idx].cpu().numpy(), scores.cpu().numpy(), runner.pair_index.cpu().numpy(), runner.u_rows)
         except Exception as exc:                              # surface thread failures in the main thread
             errors.append(exc)
             fake.barrier.abort()
@@ -328,10 +328,15 @@ def test_partitioned_runner_with_real_kernels(hip, world, case, monkeypatch):
         t.join(120)
     assert not errors, errors
     for rank in range(world):
-        e_got, s_got, (lo, hi) = results[rank]
+        e_got, s_got, index, _ = results[rank]
         assert helpers.rel_err(e_got, e_want.astype(np.float64)) < 2e-6
-        assert np.abs(s_got - want[lo:hi]).max() < 1e-5
-    assert results[0][2][0] == 0 and results[-1][2][1] == 5000
+        assert np.abs(s_got - want[index]).max() < 1e-5
+    # every pair is scored exactly once; with the user / item split known the shards are user ranges (each rank's user tower
+    # covers only its own range), otherwise contiguous slices of the list
+    assert np.array_equal(np.sort(np.concatenate([r[2] for r in results])), np.arange(5000))
+    if world > 1 and getattr(model, 'n_users', None) is not None:
+        spans = [r[3][1] - r[3][0] for r in results]
+        assert max(spans) < 0.75 * e_want.shape[0]
 
 
 @pytest.mark.parametrize('kind,cls', [('gcn', 'BasicGCN'), ('lightgcn', 'BasicLightGCN'), ('sage', 'BasicGraphSage'), ('gat', 'BasicGAT')])

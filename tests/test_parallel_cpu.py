@@ -75,11 +75,13 @@ def _worker(rank, world, port, out_dir):
         idx = runner.part.padded_index(torch.arange(n))
         # LightGCN stack ('mean' reduction accumulated on the gathered table) through the same partition
         light = basic.BasicLightGCN(g['adj'], **dict(GRID1, n_layers=3))
+        light.n_users, light.n_items = g['n_users'], g['n_items']         # user / item split known: pairs are sharded by user range
         lrun = parallel.PartitionedGCNRunner(light, u, i, rank, world, ops=NumpyOps, dist=dist, timing=False)
         e_light = lrun.propagate()
         np.savez(os.path.join(out_dir, 'rank{}.npz'.format(rank)), e=e_pad[idx].numpy(),
                  bounds=np.array(runner.part.bounds), pair_range=np.array(runner.pair_range),
                  u_back=e_pad[runner.u_ids.long()].numpy(), nnz=np.array(runner.local_nnz),
+                 light_index=lrun.pair_index.numpy(), light_u_back=e_light[lrun.u_ids.long()].numpy(), light_u_rows=np.array(lrun.u_rows),
                  e_light=e_light[lrun.part.padded_index(torch.arange(n))].detach().numpy())
     finally:
         dist.destroy_process_group()
@@ -107,17 +109,22 @@ def test_partitioned_propagation_matches_oracle_world2(tmp_path):
     want = om.propagate(g['adj'], helpers.gnn_to_oracle(model.gnn), np.float64)
     light = basic.BasicLightGCN(g['adj'], **dict(GRID1, n_layers=3))          # same seed order as in the workers
     want_light = om.propagate(g['adj'], helpers.gnn_to_oracle(light.gnn), np.float64)
-    total_nnz, covered = 0, []
+    total_nnz, covered, shards = 0, [], []
     for r in range(world):
         z = np.load(os.path.join(str(tmp_path), 'rank{}.npz'.format(r)))
         assert helpers.rel_err(z['e'], want) < 1e-5, "rank {} holds a wrong node table".format(r)
         assert helpers.rel_err(z['e_light'], want_light) < 1e-5, "rank {} holds a wrong LightGCN table".format(r)
         lo, hi = z['pair_range']
         assert helpers.rel_err(z['u_back'], want[g['u_ids'][lo:hi]]) < 1e-5     # padded pair ids hit the right rows
+        # user-range sharding (second runner): the shard's padded user ids hit the right rows, inside the rank's own user-row span
+        assert helpers.rel_err(z['light_u_back'], want_light[g['u_ids'][z['light_index']]]) < 1e-5
+        shards.append(z['light_index'])
+        assert z['light_u_rows'][1] - z['light_u_rows'][0] < g['adj'].shape[0]
         total_nnz += int(z['nnz'])
         covered.append((int(lo), int(hi)))
         assert z['bounds'][0] == 0 and z['bounds'][-1] == g['adj'].shape[0]
     from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter
+    assert np.array_equal(np.sort(np.concatenate(shards)), np.arange(len(g['u_ids'])))       # every pair scored exactly once
     assert total_nnz == gcn_filter(g['adj']).nnz
     assert covered[0][0] == 0 and covered[0][1] == covered[1][0] and covered[1][1] == len(g['u_ids'])
 

@@ -249,7 +249,7 @@ def main():
 
     if rank == 0:
         out = {
-            'metric': '(user,item) pairs scored/sec, ML-1M basic-gnn 2-layer',
+            'metric': '(user,item) pairs scored/sec, ML-1M basic-gnn 2-layer, 1/2/4/8 MI355X',
             'value': n_pairs * args.steps / dt, 'unit': 'pairs/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,

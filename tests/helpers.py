@@ -2,6 +2,12 @@
 import numpy as np
 
 
+def seed_offset():
+    """AMAR_TEST_SEED_OFFSET shifts the seeds of the randomised sweeps (stress runs: `AMAR_TEST_SEED_OFFSET=3 pytest -m gpu -k randomised`)."""
+    import os
+    return int(os.environ.get('AMAR_TEST_SEED_OFFSET', '0'))
+
+
 def tiny_graph(n_users=40, n_items=30, n_ratings=400, seed=0, n_props=0, n_links=0):
     """Random bipartite (optionally tripartite) rating graph in contiguous ids + a pair list to score."""
     from deep_cbrs_amar_renaissance_amd.data.preprocess import build_adjacency_matrix

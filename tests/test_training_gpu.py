@@ -438,7 +438,7 @@ def test_randomised_gradient_sweep(hip):
     from deep_cbrs_amar_renaissance_amd import engine, training
     from deep_cbrs_amar_renaissance_amd.data.preprocess import build_adjacency_matrix
     from deep_cbrs_amar_renaissance_amd.models import basic
-    rng = np.random.default_rng(31)
+    rng = np.random.default_rng(31 + helpers.seed_offset())
     kinds = ['BasicGCN', 'BasicGraphSage', 'BasicGAT', 'BasicLightGCN', 'BasicDGCF']
     for case in range(15):
         engine.set_seed(case)
@@ -463,4 +463,6 @@ def test_randomised_gradient_sweep(hip):
         for prm, gw in flat.items():
             got = grads[prm].cpu().numpy().reshape(gw.shape).astype(np.float64)
             got += 2 * trainer._l2(prm) * prm.detach().cpu().numpy().reshape(gw.shape)
-            assert np.abs(got - gw).max() <= 3e-4 * np.abs(gw).max() + 1e-9, (case, cls, tuple(prm.shape))
+            # (absolute floor: a bias gradient is a sum of +-0.5/B terms that may cancel to 1e-4 of their size — seen with
+            # AMAR_TEST_SEED_OFFSET=3: 9.5e-8 off on a value of 2.6e-4, i.e. fp32 rounding of the un-cancelled terms)
+            assert np.abs(got - gw).max() <= 3e-4 * np.abs(gw).max() + 3e-7, (case, cls, tuple(prm.shape))

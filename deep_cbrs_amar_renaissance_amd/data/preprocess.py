@@ -2,7 +2,8 @@
 
 Mirrors `/root/reference/src/data/preprocess.py:9-170`: ``'unary'`` (user-item graph of positive ratings),
 ``'unary-uip'`` (user-item-properties graph), ``'unary-kg'`` (the user-item graph AND the item-property graph, for the
-TwoStep / TwoWay stacks) and ``get_user_properties`` (the two-hop user-property graph).  Output is a scipy COO with the
+TwoStep / TwoWay stacks), ``get_user_properties`` (the two-hop user-property graph) and the offline
+``process_item_properties_graph`` filter that produces the property files.  Output is a scipy COO with the
 same triplets, in the same order, as the reference builds — including duplicate (item, property) links and the
 un-deduplicated symmetric copy.  ``'binary'`` only feeds the BPR sampler, which is out of scope, and raises.
 """
@@ -88,3 +89,26 @@ def build_adjacency_matrix(
         size = n_ui + len(props)
     adj = sparse.coo_matrix((data, (rows, cols)), shape=[size, size], dtype=np.float32)
     return symmetrize_matrix(adj) if symmetric_adjacency else adj
+
+
+def process_item_properties_graph(ratings_filepath, graph_filepath, kg_filepath, sep='\t'):
+    """Offline filter that produces the `props2id-*.tsv` files the loaders expect (`preprocess.py:173-198` of the reference).
+
+    `graph_filepath` holds, after one header line, the training ratings followed by the knowledge-graph triples
+    (item, property, relation).  The triples whose item occurs in the training ratings are written to `kg_filepath`,
+    sorted by (item, property) — stable for equal keys —, without header.  (`loaders.index_props` fails on a property file
+    that names an item absent from the training ratings, exactly like `np.stack` does at `loaders.py:68`.)
+
+    :param ratings_filepath: training ratings `user<sep>item<sep>rating`.
+    :param graph_filepath: ratings + KG interactions, first line skipped.
+    :param kg_filepath: output path.
+    :param sep: column separator.
+    """
+    import pandas as pd
+    ratings = pd.read_csv(ratings_filepath, sep=sep, header=None).to_numpy()
+    items = np.unique(ratings[:, 1])
+    graph = pd.read_csv(graph_filepath, sep=sep, header=None, skiprows=1).to_numpy()
+    kg = graph[len(ratings):]
+    kg = kg[np.isin(kg[:, 0], items)]
+    order = np.lexsort((kg[:, 1], kg[:, 0]))
+    pd.DataFrame(data=kg[order]).to_csv(kg_filepath, sep=sep, header=False, index=False)

@@ -137,3 +137,30 @@ def test_every_generated_class_builds(kind):
         if kind in ('LightGCN', 'DGCF'):
             assert model.gnn.step_two_gnn_layers.final_node == 'mean'         # tsgnn.py:222,252 / twgnn.py:227,257
             assert model.gnn.output_dim() == 8
+
+
+def test_offline_property_filter(tmp_path):
+    """process_item_properties_graph (preprocess.py:173-198): KG triples of training items only, sorted by (item, property);
+    its output is what loaders.load_user_item_graph accepts as props_triples_filepath."""
+    from deep_cbrs_amar_renaissance_amd.data import loaders
+    from deep_cbrs_amar_renaissance_amd.data.preprocess import process_item_properties_graph
+    rng = np.random.default_rng(5)
+    ratings = np.stack([rng.integers(0, 9, 40) * 3 + 1, rng.integers(0, 7, 40) * 5 + 2, rng.integers(0, 2, 40)], axis=1)
+    train_items = np.unique(ratings[:, 1])
+    kg = np.stack([rng.choice(np.arange(0, 12) * 5 + 2, 30), rng.integers(500, 520, 30), rng.integers(0, 2, 30)], axis=1)
+    np.savetxt(tmp_path / 'train.tsv', ratings, fmt='%d', delimiter='\t')
+    with open(tmp_path / 'graph.tsv', 'w') as f:
+        f.write('head\trel\ttail\n')
+        np.savetxt(f, np.concatenate([ratings, kg]), fmt='%d', delimiter='\t')
+    process_item_properties_graph(str(tmp_path / 'train.tsv'), str(tmp_path / 'graph.tsv'), str(tmp_path / 'props.tsv'))
+    out = np.loadtxt(tmp_path / 'props.tsv', dtype=np.int64, delimiter='\t', ndmin=2)
+    want = kg[np.isin(kg[:, 0], train_items)]
+    assert len(out) == len(want) and len(out) < len(kg)
+    assert sorted(map(tuple, out)) == sorted(map(tuple, want))
+    keys = out[:, 0] * 10000 + out[:, 1]
+    assert np.all(np.diff(keys) >= 0)
+    np.savetxt(tmp_path / 'test.tsv', ratings[:10], fmt='%d', delimiter='\t')
+    train, _ = loaders.load_user_item_graph(str(tmp_path / 'train.tsv'), str(tmp_path / 'test.tsv'), str(tmp_path / 'props.tsv'),
+                                            type_adjacency='unary-uip')
+    n = len(train.users) + len(train.items) + len(np.unique(out[:, 1]))
+    assert train.adj_matrix.shape == (n, n)

@@ -200,19 +200,23 @@ __global__ __launch_bounds__(256) void chain_pipe_kernel(const ChainArgs a) {
     const float *Ag = a.A + 4 * g, *Bg = a.B + 4 * g;
     const uint32_t lda = (uint32_t)a.lda, ldb = (uint32_t)a.ldb;   // (the launcher checks that both fit 32 bits)
 
-    auto load_ids = [&](int64_t b, uint32_t (&ra)[PT], uint32_t (&rb)[PT]) {
+    // Ids and gathers are requested UNCONDITIONALLY (positions past the end re-read the last pair, whose rows exist): an
+    // exec-masked load is followed by its own s_waitcnt, which would also wait for every gather still in flight, and a
+    // conditionally overwritten register set costs a copy of all 48 registers per iteration.
+    const int64_t last = a.P - 1;
+    auto load_ids = [&](int64_t b, int32_t (&ra)[PT], int32_t (&rb)[PT]) {
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
-            const int64_t p = b + 16 * pt + col;
-            const bool ok = p < a.P;                               // pairs past the end read row 0 and are never stored
-            ra[pt] = ok ? (uint32_t)(a.ids_a[p] - a.base_a) : 0u;
-            rb[pt] = ok ? (uint32_t)(a.ids_b[p] - a.base_b) : 0u;
+            const int64_t p = min(b + 16 * pt + col, last);
+            ra[pt] = a.ids_a[p];
+            rb[pt] = a.ids_b[p];
         }
     };
-    auto issue = [&](const uint32_t (&ra)[PT], const uint32_t (&rb)[PT], f32x4 (&va)[MAXT][PT], f32x4 (&vb)[MAXT][PT]) {
+    auto issue = [&](const int32_t (&ra)[PT], const int32_t (&rb)[PT], f32x4 (&va)[MAXT][PT], f32x4 (&vb)[MAXT][PT]) {
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
-            const float *pa = Ag + (uint64_t)ra[pt] * lda, *pb = Bg + (uint64_t)rb[pt] * ldb;   // one v_mad_u64_u32 each
+            const float *pa = Ag + (uint64_t)(uint32_t)(ra[pt] - a.base_a) * lda;   // one v_mad_u64_u32 each
+            const float *pb = Bg + (uint64_t)(uint32_t)(rb[pt] - a.base_b) * ldb;
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
                 va[t][pt] = *reinterpret_cast<const f32x4 *>(pa + 16 * t);
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256) void chain_pipe_kernel(const ChainArgs a) {
         }
     };
     // one iteration: consume (va, vb), start the next iteration's gathers into (na, nb), run the layers, store
-    auto step = [&](int64_t base, uint32_t (&ra)[PT], uint32_t (&rb)[PT], f32x4 (&va)[MAXT][PT], f32x4 (&vb)[MAXT][PT],
+    auto step = [&](int64_t base, int32_t (&ra)[PT], int32_t (&rb)[PT], f32x4 (&va)[MAXT][PT], f32x4 (&vb)[MAXT][PT],
                     f32x4 (&na)[MAXT][PT], f32x4 (&nb)[MAXT][PT]) {
         f32x4 x[MAXT][PT];
 #pragma unroll
@@ -233,10 +237,8 @@ __global__ __launch_bounds__(256) void chain_pipe_kernel(const ChainArgs a) {
                 for (int r = 0; r < 4; ++r) v[r] = relu_bits(v[r]);
                 x[t][pt] = v;
             }
-        if (base + stride < a.P) {                                 // wave-uniform
-            issue(ra, rb, na, nb);
-            load_ids(base + 2 * stride, ra, rb);
-        }
+        issue(ra, rb, na, nb);                                     // next iteration's rows (the last pair's again past the end)
+        load_ids(base + 2 * stride, ra, rb);
         for (int l = 0; l < a.n_layers; ++l) {
             const float *wl = w_lds + a.w_off[l];
             const float *bl = w_lds + a.b_off[l];
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(256) void chain_pipe_kernel(const ChainArgs a) {
     int64_t base = wave0 * pairs_per_wave;
     if (base >= a.P) return;
     f32x4 va[MAXT][PT], vb[MAXT][PT];
-    uint32_t ra[PT], rb[PT];
+    int32_t ra[PT], rb[PT];
     load_ids(base, ra, rb);
     issue(ra, rb, va, vb);
     load_ids(base + stride, ra, rb);

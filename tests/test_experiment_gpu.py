@@ -26,7 +26,7 @@ BASE_CONFIG = {
 
 def test_experiment_grid_runs_and_ranks_like_the_oracle(hip, tmp_path, monkeypatch):
     from deep_cbrs_amar_renaissance_amd import experiment
-    from deep_cbrs_amar_renaissance_amd.data import synthetic, loaders
+    from deep_cbrs_amar_renaissance_amd.data import synthetic
     from deep_cbrs_amar_renaissance_amd.utilities.utils import setup_mlflow
     ds = synthetic.ml1m(1)
     keep = 150000

@@ -1,5 +1,4 @@
 """CPU: host-side logic of the drop-in boundary (no kernels run here)."""
-import ctypes
 import os
 import re
 
@@ -9,7 +8,6 @@ import torch
 from scipy import sparse
 
 from oracle import graph as og
-from tests import helpers
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

@@ -396,7 +396,6 @@ def test_hybrid_hoisted_fused_head(hip, ml1m_s1, feature_based):
     against the oracle's straight HybridCBRS.call."""
     from deep_cbrs_amar_renaissance_amd.models import hybrid
     from deep_cbrs_amar_renaissance_amd.data import synthetic
-    from deep_cbrs_amar_renaissance_amd.data.datasets import UserItemGraphEmbeddings
     from oracle import layers as ol
     cfg = dict(GRID1, dense_units=[[24, 24], [256, 64], [64, 64]], clf_units=[64, 64], feature_based=feature_based)
     n_ent = len(ml1m_s1['users']) + len(ml1m_s1['items'])

@@ -2,22 +2,30 @@
 """Headline benchmark: (user, item) pairs scored per second, ML-1M-shape basic-gnn (2-layer GCN).
 
 One step = one pass of the hot path over one batch of synthetic input:
-full-graph propagation (X_0.W_1 prologue + one fused CSR-SpMM kernel per GCN layer) followed by
+full-graph propagation (X_0.W_1 prologue + one fused SpMM kernel per GCN layer) followed by
 scoring every test pair (embedding gather + BasicRS towers + classifier) — the "hoisted" mode of
-SURVEY.md §8d: one propagation per weight state, then all pairs.  Inputs (CSR graph, weights,
+SURVEY.md §8d: one propagation per weight state, then all pairs.  Inputs (graph image, weights,
 pair ids) are resident in HBM before the timed region.
 
 Workload: ml1m(s) graph of MovieLens-1M shape scaled by s (default 64: |U| = 386 304,
 |I| = 204 288, ~56 M non-zeros in A_hat, ~12 M test pairs), econfigs/basic-gnn.yaml grid1 model
 (GCN d=8, n_hiddens [8, 8], concat -> 24, dense [24, 24], clf [48, 48]), fp32.
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` (dominant kernel = the fused GCN
-SpMM layer, algorithmic bytes nnz*8 + (N+1)*4 + 2*N*F*4 per launch over its HIP-event time)
-and `cpu_baseline` (the oracle timed on one host core on a bounded ml1m(s=1) sample).
+`python bench.py --gpus N` with no WORLD_SIZE in the environment starts its own N ranks
+(`python -m torch.distributed.run`, fresh child processes, before this process touches the GPU);
+under torchrun (WORLD_SIZE set) it is one rank.  Rank 0 prints ONE JSON line.  Extra objects:
+`roofline` (dominant kernel = the fused GCN SpMM layer, algorithmic bytes nnz*8 + (N+1)*4 + 2*N*F*4
+per launch over its HIP-event time), `roofline_l2` (the same launch against the XS form's binding
+limit, one L2 line request per gathered row), `pair_stage`, `hybrid_head` (econfigs/hybrid-gnn.yaml
+grid1 head at the same scale: MFMA utilisation), `ml1m_s1` (the reference's real size) and
+`cpu_baseline` (the oracle timed on one host core on the SAME ml1m(s=1) graph, weights and pairs).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,7 +38,11 @@ import torch
 
 GRID1 = dict(embedding_dim=8, n_hiddens=[8, 8], n_layers=2, dense_units=[24, 24], clf_units=[48, 48],
              l2_regularizer=1e-4, final_node='concatenation', activation='relu')
+HYBRID_GRID1 = dict(embedding_dim=8, n_hiddens=[8, 8], dense_units=[[24, 24], [256, 64], [64, 64]], clf_units=[64, 64],
+                    feature_based=True)
 HBM_PEAK_GBPS = 8000.0
+MFMA_F32_PEAK_TFLOPS = 157.3
+L2_REQUESTS_PER_S = 270e9          # 256 CUs x 0.44 line requests per clock at 2.4 GHz (profiles/r1_exp_gather_frontend.txt)
 
 
 def parse_args():
@@ -38,44 +50,104 @@ def parse_args():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--scale', type=int, default=64, help='ml1m(s) scale factor of the synthetic graph')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--scale', type=int, default=64, help='ml1m(s) scale factor of the synthetic graph (64; 256 = the larger scaling workload)')
+    ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the ml1m(s=1), hybrid-head and CPU legs')
     return ap.parse_args()
 
 
-def cpu_baseline():
-    """Oracle (numpy/scipy port of the reference arithmetic) on ml1m(s=1), one host thread, hoisted mode."""
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun: start N ranks as fresh children.  This process has not touched the GPU
+    (importing torch does not initialise HIP) and never will: it only waits for the launcher and passes its exit code on."""
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.run(cmd, env=env).returncode
+
+
+def csrc_sha():
+    """Identity of the kernel sources a PMC profile belongs to: sha256 over csrc/*.hip, *.h (sorted), first 16 hex digits."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, 'deep_cbrs_amar_renaissance_amd', 'csrc')
+    for name in sorted(os.listdir(d)):
+        if name.endswith(('.hip', '.h')):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), 'rb').read())
+    return h.hexdigest()[:16]
+
+
+def pmc_profile(scale, kind):
+    """HBM/fabric bytes per launch from a separate rocprofv3 --pmc run of this same command (tools/profile_bench.sh ->
+    profiles/spmm_pmc_latest.json), corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 on gfx950).  Only valid for
+    the profiled scale, kernel form AND kernel sources: anything else returns None for the numbers and says why."""
+    path = os.path.join(ROOT, 'profiles', 'spmm_pmc_latest.json')
+    if not os.path.exists(path):
+        return None, 'no profile (profiles/spmm_pmc_latest.json missing)'
+    pmc = json.load(open(path))
+    src = 'profiles/spmm_pmc_latest.json @ csrc {}'.format(pmc.get('csrc_sha', 'unrecorded'))
+    if pmc.get('scale') != scale or pmc.get('kind', 'xs') != kind:
+        return None, src + ' (profiled scale/kernel form differs from this run: not applied)'
+    if pmc.get('csrc_sha') != csrc_sha():
+        return None, src + ' (csrc/ changed since: stale, not applied)'
+    return pmc, src
+
+
+def cpu_baseline(s1):
+    """Oracle (numpy/scipy port of the reference arithmetic) on the SAME ml1m(s=1) graph, weights and pair list as the
+    `ml1m_s1` GPU leg, one host thread: hoisted (one propagation, then all pairs) and faithful (propagation re-run per
+    2 048-pair batch as basic.py:61-63 does, batch size config.yaml:47).  gcn_filter is the model-construction
+    preprocess (gnn.py:283) and is outside both timed regions, as it is outside the GPU's."""
     from threadpoolctl import threadpool_limits
-    from oracle import models as om, weights as ow
-    from tests import helpers
-    g = helpers.ml1m_indexed(1)
-    rng = np.random.default_rng(42)
-    n = g['adj_ui'].shape[0]
-    gnn = ow.gnn(rng, 'gcn', n, 8, (8, 8))
-    head = ow.basic_head(rng, 24, [24, 24], [48, 48])
-    u, i = g['test'][:, 0], g['test'][:, 1]
+    from oracle import graph as ograph, layers as olayers, models as om
+    adj, gnn, head, u, i = s1['adj'], s1['gnn'], s1['head'], s1['u'], s1['i']
+    a_hat = ograph.gcn_filter(adj)
+
+    def propagate():
+        x = gnn['embeddings'].astype(np.float32)
+        hs = [x]
+        for lw in gnn['layers']:
+            x = olayers.gcn_conv(x, a_hat, lw['kernel'], lw['bias'])
+            hs.append(x)
+        return olayers.reduce_layers(hs, 'concatenation')
+
+    def hoisted():
+        e = propagate()
+        return om.basic_rs(e[u], e[i], head)
+
+    def faithful():
+        outs = []
+        for lo in range(0, len(u), 2048):
+            e = propagate()
+            outs.append(om.basic_rs(e[u[lo:lo + 2048]], e[i[lo:lo + 2048]], head))
+        return np.concatenate(outs)
+
     with threadpool_limits(limits=1):
-        om.basic_gnn_scores(g['adj_ui'], gnn, head, u[:1000], i[:1000])          # warm
+        scores = hoisted()                                          # warm; also the parity check of the GPU leg
         reps, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < 10.0 or reps < 3:
-            om.basic_gnn_scores(g['adj_ui'], gnn, head, u, i)
+        while time.perf_counter() - t0 < 8.0 or reps < 3:
+            hoisted()
             reps += 1
         dt = (time.perf_counter() - t0) / reps
-    # the same with the BLAS pool on every host core (the sparse products of scipy stay single-threaded)
-    reps_all, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < 5.0 or reps_all < 3:
-        om.basic_gnn_scores(g['adj_ui'], gnn, head, u, i)
-        reps_all += 1
-    dt_all = (time.perf_counter() - t0) / reps_all
+        freps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < 8.0 or freps < 1:
+            faithful()
+            freps += 1
+        fdt = (time.perf_counter() - t0) / freps
+    err = float(np.abs(scores.reshape(-1) - s1['gpu_scores'].reshape(-1)).max())
     return {'value': len(u) / dt, 'unit': 'pairs/s', 'cores': 1, 'kind': 'port',
-            'sample': 'ml1m(s=1): gcn_filter + 2-layer GCN propagation + {} test pairs, hoisted, {} reps of {:.3f} s'
-                      .format(len(u), reps, dt),
-            'all_cores': {'value': len(u) / dt_all, 'unit': 'pairs/s', 'cores': os.cpu_count(),
-                          'sample': '{} reps of {:.3f} s, BLAS threads unrestricted'.format(reps_all, dt_all)}}
+            'sample': 'ml1m(s=1), the graph / weights / {} test pairs of the ml1m_s1 GPU leg: 2-layer GCN propagation + all pairs, '
+                      'hoisted, {} reps of {:.3f} s on one thread'.format(len(u), reps, dt),
+            'faithful': {'value': len(u) / fdt, 'unit': 'pairs/s', 'cores': 1, 'batch': 2048,
+                         'sample': 'propagation re-run per 2048-pair batch (basic.py:61-63), {} passes of {:.2f} s'.format(freps, fdt)},
+            'max_abs_score_diff_vs_gpu': err}
 
 
 def ml1m_true_size(dev):
-    """configs[1] at its real size, ml1m(s=1) (launch-latency-bound): hoisted and faithful pairs/s."""
+    """configs[1] at its real size, ml1m(s=1) (launch-latency-bound): hoisted and faithful pairs/s.
+    Returns the JSON object and what the CPU baseline needs to time the same inputs."""
     from deep_cbrs_amar_renaissance_amd import engine
     from deep_cbrs_amar_renaissance_amd.data import synthetic
     from deep_cbrs_amar_renaissance_amd.models import basic
@@ -141,21 +213,96 @@ def ml1m_true_size(dev):
     dt = (time.perf_counter() - t0) / 10
     out['full_ranking_pairs'], out['full_ranking_pairs_per_s'], out['full_ranking_ms'] = nu * ni, nu * ni / dt, 1e3 * dt
     out.update({'pairs': p, 'nodes': n, 'nnz': a_hat.nnz, 'note': 'latency / launch-bound at this size'})
-    return out
+    # the same inputs for the CPU leg: symmetric unit adjacency (preprocess.py:68-86 + math.py:13-20), weights, pairs
+    from scipy import sparse
+    from tests import helpers
+    tp = data['train_pos'].cpu().numpy()
+    adj = sparse.coo_matrix((np.ones(2 * len(tp), np.float32), (np.concatenate([tp[:, 0], tp[:, 1]]), np.concatenate([tp[:, 1], tp[:, 0]]))),
+                            shape=(n, n))
+    s1 = {'adj': adj, 'gnn': helpers.gnn_to_oracle(model.gnn), 'head': helpers.basic_head_to_oracle(model.rs),
+          'u': u.cpu().numpy().astype(np.int64), 'i': i.cpu().numpy().astype(np.int64), 'gpu_scores': hoisted().cpu().numpy()}
+    return out, s1
+
+
+def hybrid_head(dev, scale):
+    """econfigs/hybrid-gnn.yaml grid1 (HybridBertGCN, 768-d BERT rows, feature_based) at the same ml1m(s): the MLP head on
+    MFMA — per-entity first-stage networks (the 768->256->64 towers on amar_dense_f32 / dense_mfma_kernel) and the pair stage
+    (amar_dual_chain_f32) — timed with HIP events, as TFLOP/s against the fp32 MFMA peak."""
+    from deep_cbrs_amar_renaissance_amd import engine
+    from deep_cbrs_amar_renaissance_amd.data import synthetic
+    from deep_cbrs_amar_renaissance_amd.models import hybrid
+    from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter_device
+    data = synthetic.ml1m_device(scale, device=dev)
+    nu, ni = data['n_users'], data['n_items']
+    n = nu + ni
+    a = gcn_filter_device(data['train_pos'][:, 0], data['train_pos'][:, 1], n)
+    engine.set_seed(42)
+    model = hybrid.HybridBertGCN(a, **HYBRID_GRID1)
+    model.n_users, model.n_items = nu, ni
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    bert = torch.randn((n, 768), device=dev, generator=gen) * 0.5
+    model.set_bert_table(bert)
+    model.rs.build_head(model.gnn.output_dim(), 768)
+    perm = torch.randperm(data['test'].shape[0], device=dev, generator=gen)
+    u = data['test'][perm, 0].to(torch.int32).contiguous()
+    i = data['test'][perm, 1].to(torch.int32).contiguous()
+    p = int(u.numel())
+    del data, perm
+    emb = model.gnn(None)
+    rs = model.rs
+
+    def timed(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    ms_bert_u = timed(lambda: rs.dense2a.apply2(bert[:nu]))
+    flop_bert_u = nu * (768 * 256 + 256 * 64) * 2.0
+    tw = rs.towers(emb[:nu], emb[nu:], bert[:nu], bert[nu:])
+    ms_towers = timed(lambda: rs.towers(emb[:nu], emb[nu:], bert[:nu], bert[nu:]))
+    ms_pairs = timed(lambda: rs.score_towers(tw, u, i, 0, nu))
+    flop_pair = 2 * (2 * 64 * 64 + 128 * 64 + 64 * 64 + 64)            # dense3a/3b second layers + clf 128-64-64-1 per pair
+    del model, bert, tw, emb
+    torch.cuda.empty_cache()
+    return {'config': 'econfigs/hybrid-gnn.yaml grid1: HybridBertGCN d=8 L=2, dense [[24,24],[256,64],[64,64]], clf [64,64], 768-d BERT, ml1m(s={})'.format(scale),
+            'bert_tower': {'kernel': 'dense_mfma_kernel (amar_dense_f32): 768->256->64 over the {} user rows'.format(nu),
+                           'ms': ms_bert_u, 'tflops': flop_bert_u / ms_bert_u / 1e9, 'peak_tflops': MFMA_F32_PEAK_TFLOPS,
+                           'mfma_frac': flop_bert_u / ms_bert_u / 1e9 / MFMA_F32_PEAK_TFLOPS},
+            'entity_towers_ms': ms_towers,
+            'pair_stage': {'kernel': 'dual_chain_full_kernel (amar_dual_chain_f32)', 'pairs': p, 'ms': ms_pairs,
+                           'pairs_per_s': p / ms_pairs * 1e3, 'flop_per_pair': flop_pair,
+                           'tflops': p * flop_pair / ms_pairs / 1e9, 'peak_tflops': MFMA_F32_PEAK_TFLOPS,
+                           'mfma_frac': p * flop_pair / ms_pairs / 1e9 / MFMA_F32_PEAK_TFLOPS}}
 
 
 def main():
     args = parse_args()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus {} but WORLD_SIZE={}: start it as `python bench.py --gpus N` (it launches its own ranks) or "
+                 "under torchrun with --nproc-per-node equal to --gpus".format(args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
     torch.cuda.set_device(local_rank)
     force_dist = bool(os.environ.get('AMAR_FORCE_DIST'))      # rehearse the RCCL path with a single rank
     if world > 1 or force_dist:
         import torch.distributed as dist
+        if force_dist and world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29531')
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl')
-    assert world == args.gpus, "--gpus {} but WORLD_SIZE={}".format(args.gpus, world)
 
     from deep_cbrs_amar_renaissance_amd import capi, engine
     from deep_cbrs_amar_renaissance_amd.data import synthetic
@@ -187,17 +334,21 @@ def main():
         parallel.PartitionedGCNRunner(model, u_all, i_all, rank, world)
 
     spmm_events = []
-    raw_gcn_layer, raw_spmm_sj, raw_spmm_xs = capi.gcn_layer, capi.spmm_sj, capi.spmm_xs
+    spmm_names = ('gcn_layer', 'spmm_sj', 'spmm_xs', 'spmm_lt')
+    raw_spmm = {name: getattr(capi, name) for name in spmm_names}
+    kinds_seen = []
 
-    def timed(fn):
+    def timed(name, fn):
         def wrapper(*a, **k):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             fn(*a, **k)
             e1.record()
             spmm_events.append((e0, e1))
+            kinds_seen.append(name)
         return wrapper
-    capi.gcn_layer, capi.spmm_sj, capi.spmm_xs = timed(raw_gcn_layer), timed(raw_spmm_sj), timed(raw_spmm_xs)   # whichever form the layer dispatches to
+    for name in spmm_names:                                   # whichever form the layer dispatches to
+        setattr(capi, name, timed(name, raw_spmm[name]))
     pair_events, raw_chain = [], capi.chain
 
     def timed_chain(*a, **k):                                  # the pair stage = the sum-input chain launch
@@ -220,13 +371,15 @@ def main():
     barrier()
     spmm_events.clear()
     pair_events.clear()
+    del kinds_seen[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         runner.step()
     host_dt = time.perf_counter() - t0                        # time to ENQUEUE the steps (host-side launch cost)
     barrier()
     dt = time.perf_counter() - t0
-    capi.gcn_layer, capi.spmm_sj, capi.spmm_xs = raw_gcn_layer, raw_spmm_sj, raw_spmm_xs
+    for name in spmm_names:
+        setattr(capi, name, raw_spmm[name])
     capi.chain = raw_chain
     if world > 1 or force_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -237,25 +390,17 @@ def main():
     rows_local = runner.local_rows
     nnz_local = runner.local_nnz
     f = GRID1['n_hiddens'][0]
-    from deep_cbrs_amar_renaissance_amd.utilities.math import spmm_kind
-    if world == 1 and not force_dist:
-        kind = spmm_kind(model.gnn.gnn_layers.adj_matrix, f)
-    else:
-        kind = 'xs' if runner._use_xs(f) else 'csr'
+    kind = {'gcn_layer': 'csr', 'spmm_sj': 'sj', 'spmm_xs': 'xs', 'spmm_lt': 'lt'}[kinds_seen[0]] if kinds_seen else 'none'
     alg_bytes = nnz_local * 8 + (rows_local + 1) * 4 + (n_nodes + rows_local) * f * 4
     avg_ms = float(np.mean(spmm_ms)) if spmm_ms else float('nan')
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-
-    traffic = None
-    pmc_path = os.path.join(ROOT, 'profiles', 'spmm_pmc_latest.json')
-    if world == 1 and os.path.exists(pmc_path):
-        # HBM/fabric bytes per launch from a separate rocprofv3 --pmc run of this same command (tools/profile_bench.sh),
-        # corrected as MI355X_MICROARCH.md prescribes (FETCH_SIZE x2 on gfx950) — only valid for the profiled scale
-        pmc = json.load(open(pmc_path))
-        if pmc.get('scale') == args.scale and kind == 'xs' and not force_dist:
-            traffic = pmc['traffic_bytes_per_launch']
+    pmc, traffic_source = (pmc_profile(args.scale, kind) if world == 1 and not force_dist else (None, 'not profiled for multi-rank runs'))
+    kernel_names = {'sj': 'spmm_sj_kernel<8>', 'xs': 'spmm_xs_partial_kernel<8> + spmm_xs_combine_kernel<8>', 'csr': 'spmm_stream_kernel<8>',
+                    'lt': 'spmm_lt_kernel<8> (LDS-tiled, one launch)', 'none': 'none'}
 
     if rank == 0:
+        # what the dispatched image actually streams per launch (the 8(d) formula counts a canonical 8-byte CSR entry)
+        image_entry_bytes = {'csr': 8, 'sj': 8, 'xs': 4, 'lt': 4, 'none': 0}[kind]
         out = {
             'metric': '(user,item) pairs scored/sec, ML-1M basic-gnn 2-layer, 1/2/4/8 MI355X',
             'value': n_pairs * args.steps / dt, 'unit': 'pairs/s',
@@ -266,39 +411,53 @@ def main():
                                    'econfigs/basic-gnn.yaml grid1 BasicGCN d=8 L=2 concat, dense [24,24], clf [48,48]; '
                                    'one propagation + per-entity towers + all pairs (shuffled order) per step (hoisted)'.format(args.scale, n_nodes, nnz, n_pairs),
                        'scale': args.scale, 'parallelism': runner.describe()},
-            'roofline': {'bound': 'hbm', 'kernel': {'sj': 'spmm_sj_kernel<8>', 'xs': 'spmm_xs_partial_kernel<8> + spmm_xs_combine_kernel<8>', 'csr': 'spmm_stream_kernel<8>'}[kind] + ' (fused GCN layer: SpMM + bias + ReLU + next X.W)', 'achieved': achieved,
-                         'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS, 'traffic': traffic,
+            'roofline': {'bound': 'hbm', 'kernel': kernel_names[kind] + ' (fused GCN layer: SpMM + bias + ReLU + next X.W)', 'achieved': achieved,
+                         'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
+                         'traffic': pmc['traffic_bytes_per_launch'] if pmc else None, 'traffic_source': traffic_source,
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': avg_ms,
-                         'launches_timed': len(spmm_ms)},
+                         'launches_timed': len(spmm_ms),
+                         'note': 'achieved = SURVEY 8(d) bytes (canonical CSR: 8 B per non-zero) / time, i.e. a CSR-equivalent effective '
+                                 'bandwidth; the dispatched image streams {} B per non-zero'.format(image_entry_bytes)},
+            # the limit that bound the XS form: one 128-B L2 line request per gathered row at 0.44 requests / clock / CU
+            'roofline_l2': {'bound': 'l2_line_requests (one per gathered row, XS form)', 'requests_per_s': L2_REQUESTS_PER_S,
+                            'floor_ms': 1e3 * nnz_local / L2_REQUESTS_PER_S,
+                            'frac': (1e3 * nnz_local / L2_REQUESTS_PER_S) / avg_ms,
+                            'note': 'frac > 1 means the dispatched kernel issues fewer than one L2 request per non-zero '
+                                    '(the LDS-tiled form gathers in column order: neighbouring entries share L1 lines)'},
             'propagation_ms': runner.last_propagation_ms(),
             'host_enqueue_ms_per_step': 1e3 * host_dt / args.steps,
         }
         pair_ms = [e0.elapsed_time(e1) for e0, e1 in pair_events]
         if pair_ms:
-            # the other large kernel of a step: chain_kernel (sum-input form) gathers two 48-float per-entity rows per pair
-            c1 = GRID1['clf_units'][0]
+            # the other large kernel of a step: the sum-input chain kernel gathers two 48-float per-entity rows per pair
+            c1, c2 = GRID1['clf_units'][0], GRID1['clf_units'][1]
             pairs_local = int(runner.u_ids.numel())
-            pair_alg = pairs_local * (2 * c1 * 4 + 2 * 4 + 4)
+            pair_alg = pairs_local * (2 * c1 * 4 + 2 * 4 + 4)                 # what the kernel gathers: two folded 192-B rows
+            pair_alg_8d = pairs_local * 204                                    # two 24-float rows + ids + score
             pms = float(np.mean(pair_ms))
-            pair_traffic = None
-            if world == 1 and os.path.exists(pmc_path) and json.load(open(pmc_path)).get('scale') == args.scale and \
-                    'pair_stage_traffic_bytes_per_launch' in json.load(open(pmc_path)):
-                pmc = json.load(open(pmc_path))
-                pair_traffic = pmc['pair_stage_traffic_bytes_per_launch']
+            flop_pair = 2 * (c1 * c2 + c2)
             out['pair_stage'] = {'kernel': 'chain_pipe_kernel<3,2> (relu(T_u[u] + T_i[i]) -> Dense 48 -> Dense 1, sigmoid)',
                                  'avg_launch_ms': pms, 'pairs_per_launch': pairs_local, 'bound': 'hbm',
                                  'algorithmic_bytes_per_launch': pair_alg, 'achieved': pair_alg / (pms * 1e-3) / 1e9,
                                  'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': pair_alg / (pms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                                 'traffic': pair_traffic,
+                                 'frac_label': '396 B/pair: the two 48-float per-entity rows (classifier layer 1 folded into the towers) + ids + score',
+                                 'frac_8d': pair_alg_8d / (pms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                 'frac_8d_label': '204 B/pair as SURVEY 8(d) counts it (two 24-float rows): the fold doubles the gathered bytes to halve the MFMA work',
+                                 'traffic': pmc.get('pair_stage_traffic_bytes_per_launch') if pmc else None, 'traffic_source': traffic_source,
                                  # the same launch against the fp32 MFMA peak (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s dense)
-                                 'mfma': {'flop_per_pair': 2 * (c1 * GRID1['clf_units'][1] + GRID1['clf_units'][1]),
-                                          'achieved_tflops': pairs_local * 2 * (c1 * GRID1['clf_units'][1] + GRID1['clf_units'][1]) / (pms * 1e-3) / 1e12,
-                                          'peak_tflops': 157.3,
-                                          'frac': pairs_local * 2 * (c1 * GRID1['clf_units'][1] + GRID1['clf_units'][1]) / (pms * 1e-3) / 1e12 / 157.3,
-                                          'pmc_busy_frac': pmc.get('pair_stage_mfma_busy_frac') if pair_traffic is not None else None}}
+                                 'mfma': {'flop_per_pair': flop_pair,
+                                          'flop_note': 'per-pair work after hoisting the towers and the first classifier layer per entity '
+                                                       '(SURVEY 8(d) counts 13 920 flop/pair for the un-hoisted head; test_faithful_equals_hoisted_and_predict keeps the two equal)',
+                                          'achieved_tflops': pairs_local * flop_pair / (pms * 1e-3) / 1e12,
+                                          'peak_tflops': MFMA_F32_PEAK_TFLOPS,
+                                          'frac': pairs_local * flop_pair / (pms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                          'pmc_busy_frac': pmc.get('pair_stage_mfma_busy_frac') if pmc else None}}
         if world == 1 and not args.no_cpu_baseline:
-            out['ml1m_s1'] = ml1m_true_size(dev)
-            out['cpu_baseline'] = cpu_baseline()
+            del runner, model, a_hat, u_all, i_all
+            torch.cuda.empty_cache()
+            out['hybrid_head'] = hybrid_head(dev, args.scale)
+            out['ml1m_s1'], s1 = ml1m_true_size(dev)
+            out['cpu_baseline'] = cpu_baseline(s1)
         print(json.dumps(out))
     if world > 1 or force_dist:
         torch.distributed.destroy_process_group()

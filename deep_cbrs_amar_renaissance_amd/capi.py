@@ -31,6 +31,8 @@ SIGNATURES = {
                                         _P, _I64, _P, _I64, _F32, _P, _I32, _P, _I64, _P]),
     'amar_spmm_xs_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _P, _P, _P, _I64, _I32, _I32, _U32, _P,
                                         _P, _I64, _P, _I64, _F32, _P, _I32, _P, _I64, _P]),
+    'amar_spmm_lt_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _P, _P, _P, _I64, _I32, _P, _P, _I64, _I32, _I32, _U32, _P,
+                                        _P, _I64, _P, _I64, _F32, _P, _I32, _P, _I64, _P]),
     'amar_gat_xs_f32': (ctypes.c_int, [_P, _P, _I32, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P]),
     'amar_gcn_layer_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _I64, _P, _I32, _P, _I64, _I32, _P]),
     'amar_rowwise_xw_f32': (ctypes.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I32, _P]),
@@ -242,6 +244,50 @@ def spmm_xs(xs, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc
         _ptr(Wnext, torch.float32, 'Wnext'), Cn, _ptr(Hnext, torch.float32, 'Hnext'),
         _ld(Hnext, 'Hnext') if Hnext is not None else 0, _stream())
     _check(code, 'amar_spmm_xs_f32')
+
+
+def spmm_lt(lt, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc_div=None, Wnext=None, Hnext=None,
+            prescaled=False, scale_next=False):
+    """Y = A.X on the LDS-tiled image `lt` of a value-free A = S C S (utilities.lds_tiled.LdsTiled): one launch, the
+    row tile's sums in LDS, gathers in column order.  Keywords as spmm_xs (`prescaled`: X already holds S.X)."""
+    n_rows, n_cols = lt.shape
+    F = X.shape[1]
+    if F != lt.F:
+        raise ValueError("spmm_lt: the image was built for width {}, X is {} wide".format(lt.F, F))
+    flags = (SPMM_BIAS if bias is not None else 0) | (SPMM_RELU if relu else 0)
+    if acc_out is not None:
+        flags |= SPMM_ACCUM | (SPMM_ACCUM_DIV if acc_div is not None else 0)
+        if acc_in is None or tuple(acc_in.shape) != (n_rows, F) or tuple(acc_out.shape) != (n_rows, F):
+            raise ValueError("acc_in/acc_out must be [n_rows, F]")
+    if Y is not None and tuple(Y.shape) != (n_rows, F):
+        raise ValueError("Y must be [n_rows, F]")
+    if X.shape[0] != n_cols or lt.diag_offset + n_rows > X.shape[0]:
+        raise ValueError("X must have one row per column of the matrix")
+    Cn = 0
+    if Wnext is not None:
+        if Wnext.shape[0] != F or not Wnext.is_contiguous() or Hnext is None or tuple(Hnext.shape) != (n_rows, Wnext.shape[1]):
+            raise ValueError("spmm_lt: Wnext [F, Cn] contiguous and Hnext [n_rows, Cn] expected")
+        Cn = Wnext.shape[1]
+    if not prescaled:
+        Xs = torch.empty((X.shape[0], F), dtype=torch.float32, device=X.device)
+        row_affine(X, lt.col_scale if lt.col_scale is not None else lt.row_scale, Xs)
+        X = Xs
+    if scale_next:
+        flags |= SPMM_SCALE_NEXT
+    off = lt.diag_offset
+    code = load().amar_spmm_lt_f32(
+        _ptr(lt.words, torch.int32, 'words'), _ptr(lt.stream_start, torch.int32, 'stream_start'),
+        _ptr(lt.wsteps, torch.int32, 'wsteps'), _ptr(lt.tile_row0, torch.int32, 'tile_row0'), _ptr(lt.n_win, torch.int32, 'n_win'),
+        lt.n_tiles, lt.maxwin1, _ptr(lt.diag, torch.float32, 'diag'), _ptr(lt.row_scale, torch.float32, 'row_scale'),
+        _ptr(X, torch.float32, 'X'), _ld(X, 'X'), X.shape[0], _ptr(X[off:], torch.float32, 'X') if off else None,
+        _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y') if Y is not None else 0,
+        n_rows, F, flags, _ptr(bias, torch.float32, 'bias'),
+        _ptr(acc_in, torch.float32, 'acc_in'), _ld(acc_in, 'acc_in') if acc_in is not None else 0,
+        _ptr(acc_out, torch.float32, 'acc_out'), _ld(acc_out, 'acc_out') if acc_out is not None else 0,
+        float(acc_div) if acc_div is not None else 1.0,
+        _ptr(Wnext, torch.float32, 'Wnext'), Cn, _ptr(Hnext, torch.float32, 'Hnext'),
+        _ld(Hnext, 'Hnext') if Hnext is not None else 0, _stream())
+    _check(code, 'amar_spmm_lt_f32')
 
 
 def gcn_layer(rowptr, colidx, vals, H, bias, Y, Wnext=None, Hnext=None):

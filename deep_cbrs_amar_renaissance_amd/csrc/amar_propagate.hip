@@ -586,6 +586,192 @@ int launch_spmm_xs(const XsArgs &pa, const XsCombineArgs &ca, bool fuse, hipStre
     return amar_check_launch();
 }
 
+// ---- v5: LDS-tiled (LT) SpMM: column-ordered windows, the Y tile in LDS, one launch -------------------------------
+// Format and rationale: utilities/lds_tiled.py, include/amar_hip.h.  One workgroup (8 waves, one per CU: the tile takes
+// 128 KB of LDS) owns a tile of consecutive rows and walks its entries in COLUMN order, a window of a few hundred
+// neighbouring columns at a time, so that the window's rows of X are fetched into the CU's L1 once and every further
+// entry of the window hits them (2-4 entries share a 128-byte line on ml1m(s=64)) — instead of the one L2 request per
+// gathered 32-byte row that bounds the XS kernels.  Wave w owns rows [w.blk, (w+1).blk) of the tile: its LDS rows are
+// private, so the accumulation is a plain ds_read_b128 / add / ds_write_b128 (LDS float atomics run at ~3 clocks per
+// LANE on gfx950); the image orders each wave's entries so that one step's EPS entries hit distinct rows, and flags
+// the rare exception, which is added with ds_add_f32 after the step.  The waves keep G steps of gathers in flight and
+// meet at one s_barrier per window (pacing only: it is what keeps the window L1-resident, not a data dependency).
+struct LtArgs {
+    const int32_t *words; const int32_t *stream_start; const int32_t *wsteps; const int32_t *tile_row0; const int32_t *n_win;
+    int maxwin1; int cbits;
+    const float *X; int64_t ldx; const float *Xself; const float *diag; const float *row_scale;
+    SpmmArgs e;
+};
+
+constexpr int LT_WAVES = 8;
+constexpr int LT_TILE_BYTES = 128 << 10;
+constexpr int LT_CHUNK = 256;                      // entries per index chunk: 64 lanes x one 16-byte load
+
+// ABL (development, tools/exp_lt.py): 1 = no atomic path, 2 = no LDS read-add-write, 4 = no gathers (timing only: wrong sums)
+template <int F, bool OFF32, bool FUSE_NEXT, int U, bool PACE, int ABL = 0>
+__global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtArgs a) {
+    constexpr int LPN = F / 4, EPS = AMAR_WAVE / LPN, RW = LT_TILE_BYTES / (4 * F * LT_WAVES), CS = LT_CHUNK / EPS;
+    constexpr int G = U - 1;                                          // steps of gathers in flight ahead of the accumulation
+    static_assert(CS % U == 0 && G < CS, "register slots of the in-flight steps must be static inside a chunk");
+    extern __shared__ __attribute__((aligned(16))) float lt_lds[];
+    float *ytile = lt_lds;                                            // [LT_WAVES][RW][F]
+    int32_t *ring_all = reinterpret_cast<int32_t *>(lt_lds + LT_WAVES * RW * F);   // [LT_WAVES][LT_CHUNK]
+    const int t = blockIdx.x;
+    const int lane = threadIdx.x & (AMAR_WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r0 = a.tile_row0[t], nr = a.tile_row0[t + 1] - r0;
+    const int blk = (nr + LT_WAVES - 1) / LT_WAVES;
+    for (int i = threadIdx.x; i < LT_WAVES * RW * F / 4; i += LT_WAVES * AMAR_WAVE)
+        reinterpret_cast<float4 *>(ytile)[i] = f4_zero();
+    __syncthreads();
+
+    const int s = lane / LPN, q = lane % LPN;                         // LPN adjacent lanes share an entry
+    const int32_t *stream = a.words + a.stream_start[t * LT_WAVES + wave];
+    const int32_t *ws = a.wsteps + ((int64_t)t * LT_WAVES + wave) * a.maxwin1;     // the wave's window table [maxwin1]
+    const int nwin = a.n_win[t];
+    const int n_chunks = __builtin_amdgcn_readfirstlane(ws[nwin]) / CS;
+    float *ymine = ytile + (wave * RW) * F + 4 * q;
+    int32_t *ring = ring_all + wave * LT_CHUNK;
+    const unsigned cmask = (1u << a.cbits) - 1u;
+
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    v4i pre = {0, 0, 0, 0};
+    auto load_chunk = [&](int c) {                                    // read-once stream: non-temporal
+        pre = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(stream + (int64_t)c * LT_CHUNK) + lane);
+    };
+    int wd[U], wn[CS];                                                // words of the steps in flight / of the chunk being issued
+    float4 x[U];
+    auto refill = [&]() {                                             // chunk registers -> LDS -> one word per (step, entry slot)
+        *reinterpret_cast<v4i *>(ring + 4 * lane) = pre;
+#pragma unroll
+        for (int j = 0; j < CS; ++j) wn[j] = ring[j * EPS + s];
+    };
+    auto issue = [&](int ks, int slot) {                              // ks, slot: compile-time after unrolling
+        const int w = wn[ks];
+        wd[slot] = w;
+        const unsigned col = (unsigned)w & cmask;
+        if (ABL & 4) { const float v = __builtin_bit_cast(float, col); x[slot] = make_float4(v, v, v, v); }
+        else if (OFF32) x[slot] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.X) + (col * (unsigned)a.ldx + 4u * q) * 4u);
+        else x[slot] = *reinterpret_cast<const float4 *>(a.X + (int64_t)col * a.ldx + 4 * q);
+    };
+    auto accumulate = [&](int slot) {
+        const int w = wd[slot];
+        const int lrow = (int)(((unsigned)w >> a.cbits) & (unsigned)(RW - 1));
+        float *yp = ymine + lrow * F;
+        if (ABL & 2) {                                                // keep the gathers alive without LDS traffic
+            if (x[slot].x == 123.f && x[slot].y == 4.f) *reinterpret_cast<float4 *>(yp) = x[slot];
+            return;
+        }
+        if (w >= 0) {
+            float4 y = *reinterpret_cast<float4 *>(yp);
+            y = f4_add(y, x[slot]);
+            *reinterpret_cast<float4 *>(yp) = y;
+        }
+        if (!(ABL & 1) && w < 0) {                                    // the row occurs earlier in this step: after its plain add
+            atomicAdd(yp + 0, x[slot].x); atomicAdd(yp + 1, x[slot].y); atomicAdd(yp + 2, x[slot].z); atomicAdd(yp + 3, x[slot].w);
+        }
+    };
+
+    // window ends: lane l of `wtab` holds ws[wbase + l]; the end of window `win` is entry win + 1.  The reload (once per
+    // 64 windows) is inline asm with its own wait: a compiler-visible load in this rarely taken branch would make every
+    // later v_readlane wait for vmcnt(0), i.e. drain the gathers in flight at every window.
+    int wbase = 0;
+    int wtab;
+    auto load_wtab = [&]() {
+        const int32_t *p = ws + min(wbase + lane, nwin);
+        asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(wtab) : "v"(p) : "memory");
+    };
+    load_wtab();
+    int win = 0;
+    auto window_end = [&](int w) {                                    // w < nwin, wave-uniform
+        if (w + 1 >= wbase + AMAR_WAVE) { wbase = w + 1; load_wtab(); }
+        return __builtin_amdgcn_readlane(wtab, w + 1 - wbase);
+    };
+    int wend = nwin > 0 ? window_end(0) : 0x7fffffff;
+    auto pace = [&](int done) {                                       // `done` steps finished: leave every window that ends here
+        while (wend <= done) {
+            if (PACE) __builtin_amdgcn_s_barrier();
+            ++win;
+            wend = win < nwin ? window_end(win) : 0x7fffffff;
+        }
+    };
+    pace(0);
+    if (n_chunks > 0) {
+        load_chunk(0);
+        refill();
+        if (n_chunks > 1) load_chunk(1);
+#pragma unroll
+        for (int j = 0; j < G; ++j) issue(j, j);
+    }
+    for (int c = 0; c < n_chunks; ++c) {
+#pragma unroll
+        for (int js = 0; js < CS; ++js) {
+            if (js + G == CS) {                                       // the steps issued from here on belong to the next chunk
+                refill();                                             // (past the last chunk: stale words, valid columns, never added)
+                if (c + 2 < n_chunks) load_chunk(c + 2);
+            }
+            issue((js + G) % CS, (js + G) % U);
+            accumulate(js % U);
+            pace(c * CS + js + 1);
+        }
+    }
+    __syncthreads();
+
+    // epilogue: y_i = row_scale_i . (diag_i . x_i + tile_i), then bias / ReLU / store / running sum / next X.W
+    for (int lr = threadIdx.x; lr < nr; lr += LT_WAVES * AMAR_WAVE) {
+        const int w = lr / blk, lrow = lr - w * blk;
+        const float *yp = ytile + (w * RW + lrow) * F;
+        const int row = r0 + lr;
+        const float d = a.diag[row];
+        const float sc = a.row_scale[row];
+        float4 acc[LPN];
+#pragma unroll
+        for (int qq = 0; qq < LPN; ++qq) {
+            const float4 xs = *reinterpret_cast<const float4 *>(a.Xself + (int64_t)row * a.e.ldx + 4 * qq);
+            const float4 y = *reinterpret_cast<const float4 *>(yp + 4 * qq);
+            acc[qq] = make_float4(sc * fmaf(d, xs.x, y.x), sc * fmaf(d, xs.y, y.y), sc * fmaf(d, xs.z, y.z), sc * fmaf(d, xs.w, y.w));
+        }
+        lane_row_epilogue<F, FUSE_NEXT>(a.e, row, acc);
+    }
+}
+
+template <int F>
+int launch_spmm_lt(const LtArgs &a, int n_tiles, bool off32, bool fuse, int variant, hipStream_t st) {
+    constexpr int RW = LT_TILE_BYTES / (4 * F * LT_WAVES);
+    const size_t lds = (size_t)LT_WAVES * RW * F * 4 + (size_t)LT_WAVES * LT_CHUNK * 4;
+    const dim3 grid((unsigned)n_tiles), block(LT_WAVES * AMAR_WAVE);
+#define AMAR_LT_LAUNCH(OFF, FUSE, UU, PP)                                                                               \
+    do {                                                                                                                 \
+        auto kern = spmm_lt_kernel<F, OFF, FUSE, UU, PP>;                                                                \
+        static bool once = false;                                                                                        \
+        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                               \
+    } while (0)
+    // variant (experiments, AMAR_LT_VARIANT; F = 8, 32-bit offsets, no fused next layer only): see the table below
+    if constexpr (F == 8) {
+        if (variant && off32 && !fuse) {
+            switch (variant) {
+            case 1:  AMAR_LT_LAUNCH(true, false, 2, true); break;                 // 1 step ahead
+            case 2:  AMAR_LT_LAUNCH(true, false, 4, false); break;                // unpaced
+            case 3:  AMAR_LT_LAUNCH(true, false, 8, true); break;                 // 7 steps ahead
+            case 4:  AMAR_LT_LAUNCH(true, false, 8, false); break;
+            case 11: { auto kern = spmm_lt_kernel<8, true, false, 4, false, 1>; (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL(kern, grid, block, lds, st, a); } break;
+            case 12: { auto kern = spmm_lt_kernel<8, true, false, 4, false, 3>; (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL(kern, grid, block, lds, st, a); } break;
+            case 13: { auto kern = spmm_lt_kernel<8, true, false, 4, false, 5>; (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL(kern, grid, block, lds, st, a); } break;
+            case 14: { auto kern = spmm_lt_kernel<8, true, false, 4, false, 7>; (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL(kern, grid, block, lds, st, a); } break;
+            case 15: { auto kern = spmm_lt_kernel<8, true, false, 8, false, 3>; (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL(kern, grid, block, lds, st, a); } break;
+            case 16: { auto kern = spmm_lt_kernel<8, true, false, 4, true, 1>; (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL(kern, grid, block, lds, st, a); } break;
+            default: return AMAR_EINVAL;
+            }
+            return amar_check_launch();
+        }
+    }
+    if (off32) { if (fuse) AMAR_LT_LAUNCH(true, true, 4, true); else AMAR_LT_LAUNCH(true, false, 4, true); }
+    else { if (fuse) AMAR_LT_LAUNCH(false, true, 4, true); else AMAR_LT_LAUNCH(false, false, 4, true); }
+#undef AMAR_LT_LAUNCH
+    return amar_check_launch();
+}
+
 bool ld_ok(int64_t ld, int F) { return ld >= F && (ld & 3) == 0; }
 
 // The row kernels are instantiated for widths 4, 8, 16, 32, 64.  Every operation below that is separable by feature
@@ -1235,4 +1421,56 @@ int amar_spmm_xs_f32(const float *diag, const int32_t *rowptr, const int32_t *co
     }
 }
 
+int amar_spmm_lt_f32(const int32_t *words, const int32_t *stream_start, const int32_t *wsteps, const int32_t *tile_row0,
+                     const int32_t *n_win, int32_t n_tiles, int32_t maxwin1,
+                     const float *diag, const float *row_scale,
+                     const float *X, int64_t ldx, int32_t n_cols, const float *Xself,
+                     float *Y, int64_t ldy, int32_t n_rows, int32_t F, uint32_t flags, const float *bias,
+                     const float *acc_in, int64_t ld_acc_in, float *acc_out, int64_t ld_acc_out, float acc_div,
+                     const float *Wnext, int32_t Cn, float *Hnext, int64_t ldhn, amar_stream_t stream) {
+    if (n_rows < 0 || n_cols < 0 || n_tiles < 0 || maxwin1 < 1) return AMAR_EINVAL;
+    if (n_rows == 0 || n_tiles == 0) return n_rows == 0 ? AMAR_OK : AMAR_EINVAL;
+    if (!words || !stream_start || !wsteps || !tile_row0 || !n_win || !diag || !row_scale || !X) return AMAR_EINVAL;
+    if (F != 4 && F != 8 && F != 16 && F != 32) return AMAR_EUNSUPPORTED;
+    const int rw = LT_TILE_BYTES / (4 * F * LT_WAVES);
+    int lbits = 0;
+    while ((1 << lbits) < rw) ++lbits;
+    const int cbits = 31 - lbits;
+    if ((int64_t)n_cols > (int64_t(1) << cbits)) return AMAR_EUNSUPPORTED;
+    if (!Xself) { if (n_cols < n_rows) return AMAR_EINVAL; Xself = X; }
+    if (!amar_aligned16(Xself) || !amar_aligned16(words)) return AMAR_EINVAL;
+    const bool accum = flags & AMAR_SPMM_ACCUM;
+    if (!Y && !accum) return AMAR_EINVAL;
+    if (!ld_ok(ldx, F) || !amar_aligned16(X)) return AMAR_EINVAL;
+    if (Y && (!ld_ok(ldy, F) || !amar_aligned16(Y))) return AMAR_EINVAL;
+    if ((flags & AMAR_SPMM_BIAS) && (!bias || !amar_aligned16(bias))) return AMAR_EINVAL;
+    if (accum && (!acc_in || !acc_out || !ld_ok(ld_acc_in, F) || !ld_ok(ld_acc_out, F) ||
+                  !amar_aligned16(acc_in) || !amar_aligned16(acc_out))) return AMAR_EINVAL;
+    if ((flags & AMAR_SPMM_ACCUM_DIV) && !(acc_div != 0.f)) return AMAR_EINVAL;
+    if (Wnext && (!Hnext || Cn < 1 || ldhn < Cn)) return AMAR_EINVAL;
+    if (Wnext && Cn > 64) return AMAR_EUNSUPPORTED;
+    if ((flags & AMAR_SPMM_SCALE_NEXT) && !Wnext) return AMAR_EINVAL;
+    LtArgs a{};
+    a.words = words; a.stream_start = stream_start; a.wsteps = wsteps; a.tile_row0 = tile_row0; a.n_win = n_win;
+    a.maxwin1 = maxwin1; a.cbits = cbits;
+    a.X = X; a.ldx = ldx; a.Xself = Xself; a.diag = diag; a.row_scale = row_scale;
+    a.e.next_scale = (flags & AMAR_SPMM_SCALE_NEXT) ? row_scale : nullptr;
+    a.e.X = X; a.e.ldx = ldx; a.e.Y = Y; a.e.ldy = ldy;
+    a.e.bias = (flags & AMAR_SPMM_BIAS) ? bias : nullptr; a.e.relu = (flags & AMAR_SPMM_RELU) ? 1 : 0;
+    a.e.acc_in = acc_in; a.e.ld_acc_in = ld_acc_in; a.e.acc_out = acc_out; a.e.ld_acc_out = ld_acc_out;
+    a.e.acc_div = acc_div; a.e.accum = accum ? 1 : 0; a.e.accum_div = (flags & AMAR_SPMM_ACCUM_DIV) ? 1 : 0;
+    a.e.Wn = Wnext; a.e.Cn = Cn; a.e.Hn = Hnext; a.e.ldhn = ldhn; a.e.n_rows = n_rows;
+    const bool off32 = (int64_t)n_cols * ldx * 4 < (int64_t(1) << 32);
+    const char *venv = getenv("AMAR_LT_VARIANT");               // development switch (tools/exp_lt.py)
+    const int variant = venv ? atoi(venv) : 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (F) {
+    case 4:  return launch_spmm_lt<4>(a, n_tiles, off32, Wnext != nullptr, variant, st);
+    case 8:  return launch_spmm_lt<8>(a, n_tiles, off32, Wnext != nullptr, variant, st);
+    case 16: return launch_spmm_lt<16>(a, n_tiles, off32, Wnext != nullptr, variant, st);
+    default: return launch_spmm_lt<32>(a, n_tiles, off32, Wnext != nullptr, variant, st);
+    }
+}
+
 }  // extern "C"
+

@@ -360,3 +360,42 @@ def _csr_xcd_sliced_mean(self, self_loops=True):
 
 DeviceCSR.xcd_sliced = _csr_xcd_sliced
 DeviceCSR.xcd_sliced_mean = _csr_xcd_sliced_mean
+
+
+def _unit_entries(a, use_mult):
+    """Off-diagonal entries of a DeviceCSR (or a row block carrying `diag_offset`) as unit-weight (row, col) pairs —
+    an entry of integer weight c is repeated c times — plus the summed diagonal.  use_mult: weights are `a.mult`
+    (C = A + I of a gcn-filtered matrix), else 1 per stored entry (edge-list CSR)."""
+    dev = a.rowptr.device
+    n = a.shape[0]
+    diag_offset = int(getattr(a, 'diag_offset', 0))
+    deg = (a.rowptr[1:] - a.rowptr[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), deg)
+    cols = a.colidx.long()
+    w = a.mult.to(torch.float32) if use_mult else torch.ones(a.nnz, dtype=torch.float32, device=dev)
+    on_diag = cols == rows + diag_offset
+    diag = torch.zeros(n, dtype=torch.float32, device=dev).index_add_(0, rows[on_diag], w[on_diag])
+    rows, cols, w = rows[~on_diag], cols[~on_diag], w[~on_diag]
+    if cols.numel() and int(w.max()) > 1:
+        rep = w.long()
+        rows, cols = torch.repeat_interleave(rows, rep), torch.repeat_interleave(cols, rep)
+    return rows, cols, diag, diag_offset
+
+
+def _csr_lds_tiled(self, F):
+    """Cached LDS-tiled image (utilities/lds_tiled.py) of a gcn-filtered matrix with known factors, per width F."""
+    from deep_cbrs_amar_renaissance_amd.utilities.lds_tiled import LdsTiled
+    cache = self.__dict__.setdefault('_lt_cache', {})
+    if F not in cache:
+        if getattr(self, 'dinv', None) is None or getattr(self, 'mult', None) is None:
+            raise ValueError("the LT image needs the factors of a gcn-filtered matrix (gcn_filter_device)")
+        rows, cols, diag, diag_offset = _unit_entries(self, True)
+        col_scale = self.dinv.to(torch.float32).contiguous()
+        n = self.shape[0]
+        cache[F] = LdsTiled.build(rows, cols, n, self.shape[1], F, diag, col_scale[diag_offset:diag_offset + n].contiguous(),
+                                  col_scale, diag_offset,
+                                  window_entries=int(os.environ['AMAR_LT_WINDOW']) if os.environ.get('AMAR_LT_WINDOW') else None)
+    return cache[F]
+
+
+DeviceCSR.lds_tiled = _csr_lds_tiled

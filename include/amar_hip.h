@@ -107,6 +107,29 @@ int amar_spmm_xs_f32(const float *diag, const int32_t *rowptr, const int32_t *co
                      const float *acc_in, int64_t ld_acc_in, float *acc_out, int64_t ld_acc_out, float acc_div,
                      const float *Wnext, int32_t Cn, float *Hnext, int64_t ldhn, amar_stream_t stream);
 
+/* The same value-free product on the LDS-tiled (LT) image (utilities/lds_tiled.py:LdsTiled builds it; any producer
+ * may) — the form the 2-layer basic-gnn propagation (src/models/gnn.py:74-84 with GCNConv / LightGCNConv layers,
+ * gnn.py:289-295, src/layers/lightgcn_conv.py:51-54) runs on when the node table exceeds the per-XCD L2s:
+ * ONE launch, one 512-thread workgroup per tile of consecutive rows, the tile's [rows, F] fp32 sums in 128 KB of LDS.
+ *   tile_row0[n_tiles+1]   row ranges; a tile has at most 8.(RW-1) rows, RW = 128 KB / (4.F.8)
+ *   words                  one int32 per unit entry: flag << 31 | lrow << cbits | column, cbits = 31 - log2(RW)
+ *                          (n_cols <= 2^cbits, else AMAR_EUNSUPPORTED); wave w of a tile owns its rows
+ *                          [w.blk, (w+1).blk), blk = ceil(rows / 8), lrow = row inside that range; every (tile, wave)
+ *                          stream is contiguous, 256-entry aligned and padded with (RW-1) << cbits; the 64/(F/4)
+ *                          entries of a step hit distinct rows except those with flag = 1 (added atomically)
+ *   stream_start[n_tiles*8], wsteps[n_tiles][8][maxwin1], n_win[n_tiles]: see utilities/lds_tiled.py
+ * X (n_cols rows) must hold S.X; Y[i] = epilogue( row_scale[i] . (diag[i] . Xself[i] + sum of the row's entries) ),
+ * flags / bias / acc_* / Wnext / AMAR_SPMM_SCALE_NEXT as amar_spmm_xs_f32.  The summation order of a row is fixed by
+ * the image, so results are bitwise reproducible run to run (they differ from the XS / CSR forms in the last bits).
+ */
+int amar_spmm_lt_f32(const int32_t *words, const int32_t *stream_start, const int32_t *wsteps, const int32_t *tile_row0,
+                     const int32_t *n_win, int32_t n_tiles, int32_t maxwin1,
+                     const float *diag, const float *row_scale,
+                     const float *X, int64_t ldx, int32_t n_cols, const float *Xself,
+                     float *Y, int64_t ldy, int32_t n_rows, int32_t F, uint32_t flags, const float *bias,
+                     const float *acc_in, int64_t ld_acc_in, float *acc_out, int64_t ld_acc_out, float acc_div,
+                     const float *Wnext, int32_t Cn, float *Hnext, int64_t ldhn, amar_stream_t stream);
+
 /* One fused GCN layer (src/models/gnn.py:289-295 + gnn.py:78, Spektral GCNConv.call):
  *     Y[i, 0:C]      = ReLU( sum_j A_hat[i,j] . H[j, 0:C] + bias )      H = X_prev . W  (pre-multiplied)
  *     Hnext[i, 0:Cn] = Y[i, :] . Wnext[C, Cn]                            (only if Wnext != NULL)

@@ -709,3 +709,79 @@ def test_xs_randomised_sweep(hip, monkeypatch):
                 hip.spmm_csr(ah.rowptr, ah.colidx, ah.vals, x, yc)
                 assert ah.xcd_sliced().row_scale is not None
                 assert float((yv - yc).abs().max()) <= 3e-6 * max(1.0, float(yc.abs().max())), (case, 'value-free', n, avg, slices, F)
+
+
+@pytest.mark.parametrize('F', [4, 8, 16, 32])
+@pytest.mark.parametrize('uip,n_cu,window', [(False, 256, None), (True, 3, None), (False, 1, 64), (True, 5, 4096)])
+def test_spmm_lds_tiled(hip, F, uip, n_cu, window):
+    """amar_spmm_lt_f32 (LDS-tiled image: column-ordered windows, tile sums in LDS, one launch) against the float64 product
+    of the gcn-filtered matrix and against the value-free XS image: plain, with the layer epilogue into a concat slice,
+    as a pre-scaled two-layer GCN chain and as LightGCN's running mean; identical bits run to run."""
+    from deep_cbrs_amar_renaissance_amd.utilities import lds_tiled
+    from deep_cbrs_amar_renaissance_amd.utilities.math import XcdSliced, gcn_filter_device, _unit_entries
+    g = helpers.tiny_graph(n_users=900, n_items=500, n_ratings=40000, seed=F, n_props=160 if uip else 0, n_links=1500 if uip else 0)
+    coo = g['adj'].tocoo()
+    keep = coo.row < coo.col
+    rows, cols = torch.from_numpy(coo.row[keep].astype(np.int64)).to(DEV), torch.from_numpy(coo.col[keep].astype(np.int64)).to(DEV)
+    n = coo.shape[0]
+    a = gcn_filter_device(rows, cols, n)
+    r, c, diag, off = _unit_entries(a, True)
+    lt = lds_tiled.LdsTiled.build(r, c, n, n, F, diag, a.dinv, a.dinv, off, window_entries=window, n_cu=n_cu)
+    assert lt.n_tiles >= min(n_cu, 2) or n_cu == 1
+    A = a.to_scipy().astype(np.float64)
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((n, F)).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, F).astype(np.float32)
+    w2 = rng.uniform(-0.5, 0.5, (F, F)).astype(np.float32)
+    y = torch.full((n, F), float('nan'), device=DEV)
+    hip.spmm_lt(lt, _t(x), y)                                   # un-scaled input: the wrapper pre-scales
+    want = A @ x.astype(np.float64)
+    assert rel_err(y.cpu().numpy(), want) < 2e-6
+    y_again = torch.empty_like(y)
+    hip.spmm_lt(lt, _t(x), y_again)
+    assert torch.equal(y, y_again)
+    y_xs = torch.empty_like(y)
+    hip.spmm_xs(XcdSliced.from_csr(a), _t(x), y_xs)
+    assert rel_err(y.cpu().numpy(), y_xs.cpu().numpy().astype(np.float64)) < 2e-6
+    # fused GCN chain in the pre-scaled form, first layer written into a column slice of a wider buffer
+    h0 = torch.empty((n, F), device=DEV)
+    hip.row_affine(_t(x), lt.row_scale, h0)
+    cat = torch.zeros((n, 2 * F + 4), device=DEV)
+    h1 = torch.full((n, F), float('nan'), device=DEV)
+    hip.spmm_lt(lt, h0, cat[:, 4:4 + F], bias=_t(b), relu=True, Wnext=_t(w2), Hnext=h1, prescaled=True, scale_next=True)
+    y2 = torch.empty((n, F), device=DEV)
+    hip.spmm_lt(lt, h1, y2, bias=_t(b), relu=True, prescaled=True)
+    w1 = np.maximum(want + b, 0)
+    want2 = np.maximum(A @ (w1 @ w2.astype(np.float64)) + b, 0)
+    got = cat.cpu().numpy()
+    assert rel_err(got[:, 4:4 + F], w1) < 2e-6 and rel_err(y2.cpu().numpy(), want2) < 3e-6
+    assert np.all(got[:, :4] == 0) and np.all(got[:, 4 + F:] == 0)
+    # LightGCN: running sum, then the mean over 3 terms
+    xd = _t(x)
+    s1, e = torch.empty((n, F), device=DEV), torch.empty((n, F), device=DEV)
+    hip.spmm_lt(lt, xd, y, acc_in=xd, acc_out=s1)
+    hip.spmm_lt(lt, y, None, acc_in=s1, acc_out=e, acc_div=3)
+    assert rel_err(e.cpu().numpy(), (x + want + A @ want) / 3) < 3e-6
+
+
+def test_spmm_lds_tiled_heavy_rows(hip):
+    """Rows holding a large share of all entries (long same-row runs inside a window: ranks, flagged atomic adds) and
+    rows without any entry."""
+    from deep_cbrs_amar_renaissance_amd.utilities import lds_tiled
+    n = 3000
+    rng = np.random.default_rng(11)
+    r = np.concatenate([np.full(20000, 5), np.full(9000, 2100), rng.integers(0, 1500, 60000)])
+    c = np.concatenate([rng.integers(1500, 2900, 29000), rng.integers(1500, 2900, 60000)])
+    rows = torch.from_numpy(np.concatenate([r, c]).astype(np.int64)).to(DEV)
+    cols = torch.from_numpy(np.concatenate([c, r]).astype(np.int64)).to(DEV)
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, n).astype(np.float32)).to(DEV)
+    diag = torch.ones(n, device=DEV)
+    for F, n_cu in ((8, 4), (16, 2)):
+        lt = lds_tiled.LdsTiled.build(rows, cols, n, n, F, diag, scale, scale, 0, n_cu=n_cu)
+        assert lt.n_flagged > 0
+        xs_tab = rng.standard_normal((n, F)).astype(np.float32)
+        y = torch.full((n, F), float('nan'), device=DEV)
+        hip.spmm_lt(lt, _t(xs_tab), y, prescaled=True)
+        A = sparse.coo_matrix((np.ones(rows.numel()), (rows.cpu().numpy(), cols.cpu().numpy())), shape=(n, n)).tocsr()
+        want = scale.cpu().numpy()[:, None].astype(np.float64) * (xs_tab.astype(np.float64) + A @ xs_tab.astype(np.float64))
+        assert rel_err(y.cpu().numpy(), want) < 3e-6

@@ -1,0 +1,79 @@
+#!/usr/bin/env python
+"""LDS-tiled SpMM (amar_spmm_lt_f32) against the XCD-sliced form on ml1m(s): parity and time per launch, by window size
+and kernel variant (development aid).  Variants are selected per process (AMAR_LT_VARIANT is read once by the library):
+run as `python tools/exp_lt.py <scale> <F> <variant> [window ...]`."""
+import os
+import sys
+import time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    scale = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    F = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    variants = (sys.argv[3] if len(sys.argv) > 3 else '0').split(',')
+    windows = [int(w) for w in sys.argv[4:]] or [0]
+    from deep_cbrs_amar_renaissance_amd import capi
+    from deep_cbrs_amar_renaissance_amd.data import synthetic
+    from deep_cbrs_amar_renaissance_amd.utilities import lds_tiled
+    from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter_device, _unit_entries
+    capi.load()
+    dev = torch.device('cuda')
+    data = synthetic.ml1m_device(scale, device=dev)
+    n = data['n_users'] + data['n_items']
+    a = gcn_filter_device(data['train_pos'][:, 0], data['train_pos'][:, 1], n)
+    xs = a.xcd_sliced()
+    x = torch.randn((n, F), device=dev)
+    xs_tab = torch.empty_like(x)
+    capi.row_affine(x, xs.col_scale, xs_tab)
+    bias = torch.randn(F, device=dev) * 0.1
+    y_xs, y_lt = torch.empty((n, F), device=dev), torch.empty((n, F), device=dev)
+    capi.spmm_xs(xs, xs_tab, y_xs, prescaled=True)
+    t_xs = timeit(lambda: capi.spmm_xs(xs, xs_tab, y_xs, prescaled=True))
+    print('scale %d F %d: N %d, nnz %d; XS %.4f ms' % (scale, F, n, a.nnz, t_xs), flush=True)
+    rows, cols, diag, off = _unit_entries(a, True)
+    col_scale = a.dinv.to(torch.float32).contiguous()
+    for w in windows:
+        t0 = time.perf_counter()
+        lt = lds_tiled.LdsTiled.build(rows, cols, n, n, F, diag, col_scale, col_scale, off, window_entries=w or None)
+        torch.cuda.synchronize()
+        t_build = time.perf_counter() - t0
+        for variant in variants:
+            os.environ['AMAR_LT_VARIANT'] = variant
+            y_lt.zero_()
+            capi.spmm_lt(lt, xs_tab, y_lt, prescaled=True)
+            torch.cuda.synchronize()
+            capi.spmm_xs(xs, xs_tab, y_xs, prescaled=True)
+            err = float((y_lt - y_xs).abs().max())
+            rel = err / float(y_xs.abs().max())
+            y2 = torch.empty_like(y_lt)
+            capi.spmm_lt(lt, xs_tab, y2, prescaled=True)
+            same = bool(torch.equal(y2, y_lt))
+            t_lt = timeit(lambda: capi.spmm_lt(lt, xs_tab, y_lt, prescaled=True))
+            rows_t = (lt.tile_row0[1:] - lt.tile_row0[:-1])
+            print('  variant %s window %5d: LT %.4f ms (%.2fx XS)  max|diff| %.2e (rel %.1e) reproducible %s | tiles %d (rows %d..%d) '
+                  'windows/tile %d flagged %.3f%% pad %.2f%% build %.1f s' %
+                  (variant, lt.window_entries, t_lt, t_xs / t_lt, err, rel, same, lt.n_tiles, int(rows_t.min()), int(rows_t.max()),
+                   lt.maxwin1 - 1, 100.0 * lt.n_flagged / max(1, lt.n_entries),
+                   100.0 * (lt.words.numel() - lt.n_entries) / max(1, lt.n_entries), t_build), flush=True)
+        os.environ.pop('AMAR_LT_VARIANT', None)
+        del lt
+
+
+if __name__ == '__main__':
+    main()

@@ -31,7 +31,7 @@ SIGNATURES = {
                                         _P, _I64, _P, _I64, _F32, _P, _I32, _P, _I64, _P]),
     'amar_spmm_xs_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _P, _P, _P, _I64, _I32, _I32, _U32, _P,
                                         _P, _I64, _P, _I64, _F32, _P, _I32, _P, _I64, _P]),
-    'amar_spmm_lt_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, _I32, _I32, _P, _P, _P, _I64, _I32, _P, _P, _I64, _I32, _I32, _U32, _P,
+    'amar_spmm_lt_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _P, _P, _P, _I64, _I32, _P, _P, _I64, _I32, _I32, _U32, _P,
                                         _P, _I64, _P, _I64, _F32, _P, _I32, _P, _I64, _P]),
     'amar_gat_xs_f32': (ctypes.c_int, [_P, _P, _I32, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P]),
     'amar_gcn_layer_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _I64, _P, _I32, _P, _I64, _I32, _P]),
@@ -202,7 +202,13 @@ def spmm_xs(xs, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc
     XCD <-> L2 affinity, then the combine kernel with the epilogues of spmm_csr / gcn_layer.
 
     A value-free image (xs.row_scale is set: A = S C S) gathers from S.X: `prescaled=True` says X already is that
-    table (the fused GCN chain keeps it so with `scale_next`), otherwise one row_affine pass makes it here."""
+    table (the fused GCN chain keeps it so with `scale_next`), otherwise one row_affine pass makes it here.
+
+    `xs` may also be an LDS-tiled image (utilities.lds_tiled.LdsTiled, what DeviceCSR.tiled_image returns where the
+    column-ordered form pays): the call is then amar_spmm_lt_f32, same keywords."""
+    if hasattr(xs, 'words'):
+        return spmm_lt(xs, X, Y, bias=bias, relu=relu, acc_in=acc_in, acc_out=acc_out, acc_div=acc_div, Wnext=Wnext, Hnext=Hnext,
+                       prescaled=prescaled, scale_next=scale_next)
     n_rows = xs.shape[0]
     F = X.shape[1]
     flags = (SPMM_BIAS if bias is not None else 0) | (SPMM_RELU if relu else 0)
@@ -278,7 +284,7 @@ def spmm_lt(lt, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc
     code = load().amar_spmm_lt_f32(
         _ptr(lt.words, torch.int32, 'words'), _ptr(lt.stream_start, torch.int32, 'stream_start'),
         _ptr(lt.wsteps, torch.int32, 'wsteps'), _ptr(lt.tile_row0, torch.int32, 'tile_row0'), _ptr(lt.n_win, torch.int32, 'n_win'),
-        lt.n_tiles, lt.maxwin1, _ptr(lt.diag, torch.float32, 'diag'), _ptr(lt.row_scale, torch.float32, 'row_scale'),
+        _ptr(lt.vstart, torch.int32, 'vstart'), _ptr(lt.vcount, torch.int32, 'vcount'), lt.n_tiles, lt.maxwin1, _ptr(lt.diag, torch.float32, 'diag'), _ptr(lt.row_scale, torch.float32, 'row_scale'),
         _ptr(X, torch.float32, 'X'), _ld(X, 'X'), X.shape[0], _ptr(X[off:], torch.float32, 'X') if off else None,
         _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y') if Y is not None else 0,
         n_rows, F, flags, _ptr(bias, torch.float32, 'bias'),

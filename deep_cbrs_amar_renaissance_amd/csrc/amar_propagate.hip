@@ -587,42 +587,56 @@ int launch_spmm_xs(const XsArgs &pa, const XsCombineArgs &ca, bool fuse, hipStre
 }
 
 // ---- v5: LDS-tiled (LT) SpMM: column-ordered windows, the Y tile in LDS, one launch -------------------------------
-// Format and rationale: utilities/lds_tiled.py, include/amar_hip.h.  One workgroup (8 waves, one per CU: the tile takes
+// Format and rationale: utilities/lds_tiled.py, include/amar_hip.h.  One workgroup (16 waves, one per CU: the tile takes
 // 128 KB of LDS) owns a tile of consecutive rows and walks its entries in COLUMN order, a window of a few hundred
 // neighbouring columns at a time, so that the window's rows of X are fetched into the CU's L1 once and every further
 // entry of the window hits them (2-4 entries share a 128-byte line on ml1m(s=64)) — instead of the one L2 request per
-// gathered 32-byte row that bounds the XS kernels.  Wave w owns rows [w.blk, (w+1).blk) of the tile: its LDS rows are
-// private, so the accumulation is a plain ds_read_b128 / add / ds_write_b128 (LDS float atomics run at ~3 clocks per
-// LANE on gfx950); the image orders each wave's entries so that one step's EPS entries hit distinct rows, and flags
-// the rare exception, which is added with ds_add_f32 after the step.  The waves keep G steps of gathers in flight and
-// meet at one s_barrier per window (pacing only: it is what keeps the window L1-resident, not a data dependency).
+// gathered 32-byte row that bounds the XS kernels.  The unit of ownership is the virtual row (a long row is cut into
+// several): virtual row v belongs to wave v % 16, whose LDS rows are private, so the accumulation is a plain
+// ds_read_b128 / add / ds_write_b128 (LDS float atomics run at ~3 clocks per LANE on gfx950).  The image spreads a
+// wave's entries so that one step's EPS entries hit distinct LDS rows; a repeat in the very next slot is folded into its
+// neighbour's registers with one DPP shift, any other repeat is flagged and added with ds_add_f32 after the step.  The
+// waves keep G steps of gathers in flight and meet at one s_barrier per window (pacing only: it is what keeps the
+// window L1-resident, not a data dependency).
 struct LtArgs {
     const int32_t *words; const int32_t *stream_start; const int32_t *wsteps; const int32_t *tile_row0; const int32_t *n_win;
+    const int32_t *vstart; const int32_t *vcount;
     int maxwin1; int cbits;
     const float *X; int64_t ldx; const float *Xself; const float *diag; const float *row_scale;
+    long long *stamps;                           // development: cycles per tile (tools/exp_lt.py), or NULL
     SpmmArgs e;
 };
 
-constexpr int LT_WAVES = 8;
+constexpr int LT_WAVES = 16;
 constexpr int LT_TILE_BYTES = 128 << 10;
 constexpr int LT_CHUNK = 256;                      // entries per index chunk: 64 lanes x one 16-byte load
 
+__device__ __forceinline__ int lt_lds_row(int v) {                    // virtual row -> row of the LDS tile (see lds_tiled.py)
+    const int w = v & (LT_WAVES - 1), l = v / LT_WAVES;
+    return l * LT_WAVES + ((w + l) & (LT_WAVES - 1));
+}
+
 // ABL (development, tools/exp_lt.py): 1 = no atomic path, 2 = no LDS read-add-write, 4 = no gathers (timing only: wrong sums)
-template <int F, bool OFF32, bool FUSE_NEXT, int U, bool PACE, int ABL = 0>
+// PACE: 0 = waves run free, 1 = one s_barrier per window, 2 = arrival counters in LDS: a wave leaves window w once every
+// wave has left window w - 1 (one window of slack: measured slower than the barrier), 3 = s_barrier every other window
+// OFF32: 0 = 64-bit gather addresses, 1 = 32-bit byte offsets, 2 = 32-bit offsets into a dense table (ldx == F: a shift, no multiply)
+template <int F, int OFF32, bool FUSE_NEXT, int U, int PACE, int ABL = 0>
 __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtArgs a) {
     constexpr int LPN = F / 4, EPS = AMAR_WAVE / LPN, RW = LT_TILE_BYTES / (4 * F * LT_WAVES), CS = LT_CHUNK / EPS;
     constexpr int G = U - 1;                                          // steps of gathers in flight ahead of the accumulation
     static_assert(CS % U == 0 && G < CS, "register slots of the in-flight steps must be static inside a chunk");
     extern __shared__ __attribute__((aligned(16))) float lt_lds[];
-    float *ytile = lt_lds;                                            // [LT_WAVES][RW][F]
+    float *ytile = lt_lds;                                            // [RW * LT_WAVES][F]
     int32_t *ring_all = reinterpret_cast<int32_t *>(lt_lds + LT_WAVES * RW * F);   // [LT_WAVES][LT_CHUNK]
+    unsigned *arrived = reinterpret_cast<unsigned *>(ring_all + LT_WAVES * LT_CHUNK);   // [8] arrival counters (PACE 2)
     const int t = blockIdx.x;
     const int lane = threadIdx.x & (AMAR_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long long t_start = a.stamps ? (long long)__builtin_readcyclecounter() : 0;
     const int r0 = a.tile_row0[t], nr = a.tile_row0[t + 1] - r0;
-    const int blk = (nr + LT_WAVES - 1) / LT_WAVES;
     for (int i = threadIdx.x; i < LT_WAVES * RW * F / 4; i += LT_WAVES * AMAR_WAVE)
         reinterpret_cast<float4 *>(ytile)[i] = f4_zero();
+    if (threadIdx.x < 8) arrived[threadIdx.x] = 0;
     __syncthreads();
 
     const int s = lane / LPN, q = lane % LPN;                         // LPN adjacent lanes share an entry
@@ -630,18 +644,16 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtA
     const int32_t *ws = a.wsteps + ((int64_t)t * LT_WAVES + wave) * a.maxwin1;     // the wave's window table [maxwin1]
     const int nwin = a.n_win[t];
     const int n_chunks = __builtin_amdgcn_readfirstlane(ws[nwin]) / CS;
-    float *ymine = ytile + (wave * RW) * F + 4 * q;
     int32_t *ring = ring_all + wave * LT_CHUNK;
     const unsigned cmask = (1u << a.cbits) - 1u;
 
     typedef int v4i __attribute__((ext_vector_type(4)));
-    v4i pre = {0, 0, 0, 0};
     auto load_chunk = [&](int c) {                                    // read-once stream: non-temporal
-        pre = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(stream + (int64_t)c * LT_CHUNK) + lane);
+        return __builtin_nontemporal_load(reinterpret_cast<const v4i *>(stream + (int64_t)c * LT_CHUNK) + lane);
     };
     int wd[U], wn[CS];                                                // words of the steps in flight / of the chunk being issued
     float4 x[U];
-    auto refill = [&]() {                                             // chunk registers -> LDS -> one word per (step, entry slot)
+    auto refill = [&](const v4i &pre) {                               // chunk registers -> LDS -> one word per (step, entry slot)
         *reinterpret_cast<v4i *>(ring + 4 * lane) = pre;
 #pragma unroll
         for (int j = 0; j < CS; ++j) wn[j] = ring[j * EPS + s];
@@ -651,24 +663,35 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtA
         wd[slot] = w;
         const unsigned col = (unsigned)w & cmask;
         if (ABL & 4) { const float v = __builtin_bit_cast(float, col); x[slot] = make_float4(v, v, v, v); }
-        else if (OFF32) x[slot] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.X) + (col * (unsigned)a.ldx + 4u * q) * 4u);
+        else if (OFF32 == 2) x[slot] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.X) + ((col * (unsigned)F + 4u * q) * 4u));
+        else if (OFF32 == 1) x[slot] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.X) + (col * (unsigned)a.ldx + 4u * q) * 4u);
         else x[slot] = *reinterpret_cast<const float4 *>(a.X + (int64_t)col * a.ldx + 4 * q);
     };
     auto accumulate = [&](int slot) {
         const int w = wd[slot];
         const int lrow = (int)(((unsigned)w >> a.cbits) & (unsigned)(RW - 1));
-        float *yp = ymine + lrow * F;
+        float *yp = ytile + (lrow * LT_WAVES + ((wave + lrow) & (LT_WAVES - 1))) * F + 4 * q;
+        float4 xv = x[slot];
         if (ABL & 2) {                                                // keep the gathers alive without LDS traffic
-            if (x[slot].x == 123.f && x[slot].y == 4.f) *reinterpret_cast<float4 *>(yp) = x[slot];
+            if (xv.x == 123.f && xv.y == 4.f) *reinterpret_cast<float4 *>(yp) = xv;
             return;
         }
-        if (w >= 0) {
+        // implicit pair: same virtual row as the previous slot (row_shr: lane l reads l - LPN inside its 16-lane DPP row;
+        // the first slot of a DPP row keeps -1) and not flagged -> its values go to that slot's registers, no LDS update
+        const int prev = __builtin_amdgcn_update_dpp(-1, lrow, 0x110 + LPN, 0xF, 0xF, false);
+        const bool paired = prev == lrow && w >= 0;
+        const float4 give = paired ? xv : f4_zero();
+        xv.x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.x), 0x100 + LPN, 0xF, 0xF, true));
+        xv.y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.y), 0x100 + LPN, 0xF, 0xF, true));
+        xv.z += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.z), 0x100 + LPN, 0xF, 0xF, true));
+        xv.w += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.w), 0x100 + LPN, 0xF, 0xF, true));
+        if (w >= 0 && !paired) {
             float4 y = *reinterpret_cast<float4 *>(yp);
-            y = f4_add(y, x[slot]);
+            y = f4_add(y, xv);
             *reinterpret_cast<float4 *>(yp) = y;
         }
         if (!(ABL & 1) && w < 0) {                                    // the row occurs earlier in this step: after its plain add
-            atomicAdd(yp + 0, x[slot].x); atomicAdd(yp + 1, x[slot].y); atomicAdd(yp + 2, x[slot].z); atomicAdd(yp + 3, x[slot].w);
+            atomicAdd(yp + 0, xv.x); atomicAdd(yp + 1, xv.y); atomicAdd(yp + 2, xv.z); atomicAdd(yp + 3, xv.w);
         }
     };
 
@@ -690,84 +713,109 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtA
     int wend = nwin > 0 ? window_end(0) : 0x7fffffff;
     auto pace = [&](int done) {                                       // `done` steps finished: leave every window that ends here
         while (wend <= done) {
-            if (PACE) __builtin_amdgcn_s_barrier();
+            if (PACE == 1 || (PACE == 3 && (win & 1))) __builtin_amdgcn_s_barrier();
+            if (PACE == 2) {
+                if (lane == 0) atomicAdd(arrived + (win & 7), 1u);
+                if (win > 0) {
+                    const unsigned need = (unsigned)LT_WAVES * ((unsigned)(win - 1) / 8u + 1u);
+                    volatile unsigned *slot = arrived + ((win - 1) & 7);
+                    while (__builtin_amdgcn_readfirstlane((int)*slot) < (int)need) __builtin_amdgcn_s_sleep(1);
+                }
+            }
             ++win;
             wend = win < nwin ? window_end(win) : 0x7fffffff;
         }
     };
     pace(0);
-    if (n_chunks > 0) {
-        load_chunk(0);
-        refill();
-        if (n_chunks > 1) load_chunk(1);
-#pragma unroll
-        for (int j = 0; j < G; ++j) issue(j, j);
-    }
-    for (int c = 0; c < n_chunks; ++c) {
+    // index chunks are requested two chunks ahead, alternately into two register sets: `next` holds chunk c + 1 when chunk c
+    // reaches the point where it starts issuing that chunk's steps, and is then reloaded with chunk c + 3
+    v4i pre_a = {0, 0, 0, 0}, pre_b = {0, 0, 0, 0};
+    auto chunk_body = [&](int c, v4i &next) {
 #pragma unroll
         for (int js = 0; js < CS; ++js) {
             if (js + G == CS) {                                       // the steps issued from here on belong to the next chunk
-                refill();                                             // (past the last chunk: stale words, valid columns, never added)
-                if (c + 2 < n_chunks) load_chunk(c + 2);
+                refill(next);                                         // (past the last chunk: stale words, valid columns, never added)
+                if (c + 3 < n_chunks) next = load_chunk(c + 3);
             }
             issue((js + G) % CS, (js + G) % U);
             accumulate(js % U);
             pace(c * CS + js + 1);
         }
+    };
+    if (n_chunks > 0) {
+        pre_a = load_chunk(0);
+        refill(pre_a);
+        if (n_chunks > 1) pre_b = load_chunk(1);
+        if (n_chunks > 2) pre_a = load_chunk(2);
+#pragma unroll
+        for (int j = 0; j < G; ++j) issue(j, j);
+    }
+    for (int c = 0; c < n_chunks; c += 2) {
+        chunk_body(c, pre_b);
+        if (c + 1 < n_chunks) chunk_body(c + 1, pre_a);
     }
     __syncthreads();
 
-    // epilogue: y_i = row_scale_i . (diag_i . x_i + tile_i), then bias / ReLU / store / running sum / next X.W
+    // epilogue: y_i = row_scale_i . (diag_i . x_i + the row's virtual rows), then bias / ReLU / store / running sum / next X.W
+    const int vtile = a.vcount[t];
     for (int lr = threadIdx.x; lr < nr; lr += LT_WAVES * AMAR_WAVE) {
-        const int w = lr / blk, lrow = lr - w * blk;
-        const float *yp = ytile + (w * RW + lrow) * F;
         const int row = r0 + lr;
+        const int v0 = a.vstart[row], v1 = lr + 1 < nr ? a.vstart[row + 1] : vtile;
         const float d = a.diag[row];
         const float sc = a.row_scale[row];
         float4 acc[LPN];
 #pragma unroll
         for (int qq = 0; qq < LPN; ++qq) {
             const float4 xs = *reinterpret_cast<const float4 *>(a.Xself + (int64_t)row * a.e.ldx + 4 * qq);
-            const float4 y = *reinterpret_cast<const float4 *>(yp + 4 * qq);
-            acc[qq] = make_float4(sc * fmaf(d, xs.x, y.x), sc * fmaf(d, xs.y, y.y), sc * fmaf(d, xs.z, y.z), sc * fmaf(d, xs.w, y.w));
+            acc[qq] = make_float4(d * xs.x, d * xs.y, d * xs.z, d * xs.w);
         }
+        for (int v = v0; v < v1; ++v) {
+            const float *yp = ytile + lt_lds_row(v) * F;
+#pragma unroll
+            for (int qq = 0; qq < LPN; ++qq) acc[qq] = f4_add(acc[qq], *reinterpret_cast<const float4 *>(yp + 4 * qq));
+        }
+#pragma unroll
+        for (int qq = 0; qq < LPN; ++qq) { acc[qq].x *= sc; acc[qq].y *= sc; acc[qq].z *= sc; acc[qq].w *= sc; }
         lane_row_epilogue<F, FUSE_NEXT>(a.e, row, acc);
     }
+    if (a.stamps && threadIdx.x == 0) a.stamps[t] = (long long)__builtin_readcyclecounter() - t_start;
 }
 
 template <int F>
-int launch_spmm_lt(const LtArgs &a, int n_tiles, bool off32, bool fuse, int variant, hipStream_t st) {
+int launch_spmm_lt(const LtArgs &a, int n_tiles, int off32, bool fuse, int variant, hipStream_t st) {
     constexpr int RW = LT_TILE_BYTES / (4 * F * LT_WAVES);
-    const size_t lds = (size_t)LT_WAVES * RW * F * 4 + (size_t)LT_WAVES * LT_CHUNK * 4;
+    const size_t lds = (size_t)LT_WAVES * RW * F * 4 + (size_t)LT_WAVES * LT_CHUNK * 4 + 32;
     const dim3 grid((unsigned)n_tiles), block(LT_WAVES * AMAR_WAVE);
-#define AMAR_LT_LAUNCH(OFF, FUSE, UU, PP)                                                                               \
+#define AMAR_LT_LAUNCH(OFF, FUSE, UU, PP, AA)                                                                           \
     do {                                                                                                                 \
-        auto kern = spmm_lt_kernel<F, OFF, FUSE, UU, PP>;                                                                \
+        auto kern = spmm_lt_kernel<F, OFF, FUSE, UU, PP, AA>;                                                            \
         static bool once = false;                                                                                        \
         if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } \
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                               \
     } while (0)
-    // variant (experiments, AMAR_LT_VARIANT; F = 8, 32-bit offsets, no fused next layer only): see the table below
+    // variant (development, AMAR_LT_VARIANT; F = 8, dense table, no fused next layer only): see tools/exp_lt.py
     if constexpr (F == 8) {
-        if (variant && off32 && !fuse) {
+        if (variant && off32 == 2 && !fuse) {
             switch (variant) {
-            case 1:  AMAR_LT_LAUNCH(true, false, 2, true); break;                 // 1 step ahead
-            case 2:  AMAR_LT_LAUNCH(true, false, 4, false); break;                // unpaced
-            case 3:  AMAR_LT_LAUNCH(true, false, 8, true); break;                 // 7 steps ahead
-            case 4:  AMAR_LT_LAUNCH(true, false, 8, false); break;
-            case 11: { auto kern = spmm_lt_kernel<8, true, false, 4, false, 1>; (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL(kern, grid, block, lds, st, a); } break;
-            case 12: { auto kern = spmm_lt_kernel<8, true, false, 4, false, 3>; (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL(kern, grid, block, lds, st, a); } break;
-            case 13: { auto kern = spmm_lt_kernel<8, true, false, 4, false, 5>; (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL(kern, grid, block, lds, st, a); } break;
-            case 14: { auto kern = spmm_lt_kernel<8, true, false, 4, false, 7>; (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL(kern, grid, block, lds, st, a); } break;
-            case 15: { auto kern = spmm_lt_kernel<8, true, false, 8, false, 3>; (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL(kern, grid, block, lds, st, a); } break;
-            case 16: { auto kern = spmm_lt_kernel<8, true, false, 4, true, 1>; (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL(kern, grid, block, lds, st, a); } break;
+            case 1:  AMAR_LT_LAUNCH(2, false, 2, 1, 0); break;      // 1 step ahead
+            case 2:  AMAR_LT_LAUNCH(2, false, 4, 0, 0); break;      // unpaced
+            case 3:  AMAR_LT_LAUNCH(2, false, 8, 1, 0); break;      // 7 steps ahead
+            case 5:  AMAR_LT_LAUNCH(2, false, 4, 2, 0); break;      // counter pacing, one window of slack
+            case 7:  AMAR_LT_LAUNCH(2, false, 4, 3, 0); break;      // barrier every other window
+            case 8:  AMAR_LT_LAUNCH(1, false, 4, 1, 0); break;      // multiply-add addressing
+            case 11: AMAR_LT_LAUNCH(2, false, 4, 0, 1); break;      // ablations (wrong sums): no atomics
+            case 12: AMAR_LT_LAUNCH(2, false, 4, 0, 3); break;      //   ... no LDS update
+            case 13: AMAR_LT_LAUNCH(2, false, 4, 0, 5); break;      //   ... no gathers
+            case 14: AMAR_LT_LAUNCH(2, false, 4, 0, 7); break;
+            case 16: AMAR_LT_LAUNCH(2, false, 4, 1, 1); break;
             default: return AMAR_EINVAL;
             }
             return amar_check_launch();
         }
     }
-    if (off32) { if (fuse) AMAR_LT_LAUNCH(true, true, 4, true); else AMAR_LT_LAUNCH(true, false, 4, true); }
-    else { if (fuse) AMAR_LT_LAUNCH(false, true, 4, true); else AMAR_LT_LAUNCH(false, false, 4, true); }
+    if (off32 == 2) { if (fuse) AMAR_LT_LAUNCH(2, true, 4, 1, 0); else AMAR_LT_LAUNCH(2, false, 4, 1, 0); }
+    else if (off32 == 1) { if (fuse) AMAR_LT_LAUNCH(1, true, 4, 1, 0); else AMAR_LT_LAUNCH(1, false, 4, 1, 0); }
+    else { if (fuse) AMAR_LT_LAUNCH(0, true, 4, 1, 0); else AMAR_LT_LAUNCH(0, false, 4, 1, 0); }
 #undef AMAR_LT_LAUNCH
     return amar_check_launch();
 }
@@ -1422,7 +1470,7 @@ int amar_spmm_xs_f32(const float *diag, const int32_t *rowptr, const int32_t *co
 }
 
 int amar_spmm_lt_f32(const int32_t *words, const int32_t *stream_start, const int32_t *wsteps, const int32_t *tile_row0,
-                     const int32_t *n_win, int32_t n_tiles, int32_t maxwin1,
+                     const int32_t *n_win, const int32_t *vstart, const int32_t *vcount, int32_t n_tiles, int32_t maxwin1,
                      const float *diag, const float *row_scale,
                      const float *X, int64_t ldx, int32_t n_cols, const float *Xself,
                      float *Y, int64_t ldy, int32_t n_rows, int32_t F, uint32_t flags, const float *bias,
@@ -1430,7 +1478,7 @@ int amar_spmm_lt_f32(const int32_t *words, const int32_t *stream_start, const in
                      const float *Wnext, int32_t Cn, float *Hnext, int64_t ldhn, amar_stream_t stream) {
     if (n_rows < 0 || n_cols < 0 || n_tiles < 0 || maxwin1 < 1) return AMAR_EINVAL;
     if (n_rows == 0 || n_tiles == 0) return n_rows == 0 ? AMAR_OK : AMAR_EINVAL;
-    if (!words || !stream_start || !wsteps || !tile_row0 || !n_win || !diag || !row_scale || !X) return AMAR_EINVAL;
+    if (!words || !stream_start || !wsteps || !tile_row0 || !n_win || !vstart || !vcount || !diag || !row_scale || !X) return AMAR_EINVAL;
     if (F != 4 && F != 8 && F != 16 && F != 32) return AMAR_EUNSUPPORTED;
     const int rw = LT_TILE_BYTES / (4 * F * LT_WAVES);
     int lbits = 0;
@@ -1452,6 +1500,7 @@ int amar_spmm_lt_f32(const int32_t *words, const int32_t *stream_start, const in
     if ((flags & AMAR_SPMM_SCALE_NEXT) && !Wnext) return AMAR_EINVAL;
     LtArgs a{};
     a.words = words; a.stream_start = stream_start; a.wsteps = wsteps; a.tile_row0 = tile_row0; a.n_win = n_win;
+    a.vstart = vstart; a.vcount = vcount;
     a.maxwin1 = maxwin1; a.cbits = cbits;
     a.X = X; a.ldx = ldx; a.Xself = Xself; a.diag = diag; a.row_scale = row_scale;
     a.e.next_scale = (flags & AMAR_SPMM_SCALE_NEXT) ? row_scale : nullptr;
@@ -1460,9 +1509,11 @@ int amar_spmm_lt_f32(const int32_t *words, const int32_t *stream_start, const in
     a.e.acc_in = acc_in; a.e.ld_acc_in = ld_acc_in; a.e.acc_out = acc_out; a.e.ld_acc_out = ld_acc_out;
     a.e.acc_div = acc_div; a.e.accum = accum ? 1 : 0; a.e.accum_div = (flags & AMAR_SPMM_ACCUM_DIV) ? 1 : 0;
     a.e.Wn = Wnext; a.e.Cn = Cn; a.e.Hn = Hnext; a.e.ldhn = ldhn; a.e.n_rows = n_rows;
-    const bool off32 = (int64_t)n_cols * ldx * 4 < (int64_t(1) << 32);
-    const char *venv = getenv("AMAR_LT_VARIANT");               // development switch (tools/exp_lt.py)
+    const int off32 = (int64_t)n_cols * ldx * 4 < (int64_t(1) << 32) ? (ldx == F ? 2 : 1) : 0;
+    const char *venv = getenv("AMAR_LT_VARIANT");               // development switches (tools/exp_lt.py)
     const int variant = venv ? atoi(venv) : 0;
+    const char *senv = getenv("AMAR_LT_STAMPS");                // device address of a [n_tiles] int64 buffer, decimal
+    a.stamps = senv ? reinterpret_cast<long long *>(strtoull(senv, nullptr, 10)) : nullptr;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (F) {
     case 4:  return launch_spmm_lt<4>(a, n_tiles, off32, Wnext != nullptr, variant, st);

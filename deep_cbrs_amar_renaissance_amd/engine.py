@@ -170,11 +170,17 @@ class Model(Layer):
         pass
 
     def evaluate(self, sequence, **kwargs):
-        """Loss (binary cross-entropy) and accuracy on `sequence` (experiment.py:194)."""
+        """Loss and accuracy on `sequence` (experiment.py:194).  As Keras' evaluate(), 'loss' is the binary cross-entropy plus
+        the regularisation losses of the model (l2 * sum(w^2) for every weight carrying a regulariser: gnn.py:45,293-294),
+        the same sum fit() reports per epoch, so train and test losses of one run are comparable."""
         pred = self.predict(sequence).reshape(-1).astype(np.float64)
         y = np.concatenate([np.asarray(sequence[b][1]).reshape(-1) for b in range(len(sequence))]).astype(np.float64)
         eps = 1e-7                                                   # keras backend epsilon
         p = np.clip(pred, eps, 1 - eps)
         loss = float(-np.mean(y * np.log(p) + (1 - y) * np.log(1 - p))) if len(y) else 0.0
+        for w in self.parameters():
+            reg = getattr(w, 'regularizer', None)
+            if reg is not None and getattr(reg, 'l2', 0.0):
+                loss += float(reg.l2) * float((w.detach().double() ** 2).sum())
         acc = float(np.mean((pred > 0.5) == (y > 0.5))) if len(y) else 0.0
         return [loss, acc]

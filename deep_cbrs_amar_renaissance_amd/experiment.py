@@ -178,10 +178,9 @@ class Experimenter:
         self.build_model()
         self.logger.info('Training:')
         t0 = time.perf_counter()
-        try:
-            self.model.fit(self.trainset, epochs=self.parameters.epochs, workers=self.config.n_workers)
-        except NotImplementedError as e:
-            self.logger.warning("fit() skipped: {}".format(e))
+        # a model or reduction without a training recipe raises here: the experiment fails (MultiExperimenter.run_experiment
+        # logs the traceback, ends the run and goes on with the grid, experiment.py:295-302) instead of evaluating random weights
+        self.model.fit(self.trainset, epochs=self.parameters.epochs, workers=self.config.n_workers)
         # the reference's LogCallback reports the fit wall time as 'training_time' (utilities/keras.py:43-51, 69-85)
         self.run_log.log_metrics({'training_time': time.perf_counter() - t0})
 

@@ -36,7 +36,7 @@ class DGCFConv(Layer):
         if out is None:
             out = torch.empty((a.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
         if spmm_kind(a, x.shape[1]) == 'xs':
-            capi.spmm_xs(a.xcd_sliced(), gated, out)
+            capi.spmm_xs(a.tiled_image(x.shape[1]), gated, out)
         else:
             capi.spmm_csr(a.rowptr, a.colidx, a.vals, gated, out)
         return out

@@ -37,7 +37,7 @@ class GCNConv(Layer):
             out = torch.empty((n, self.channels), dtype=torch.float32, device=x.device)
         kind = spmm_kind(a, self.channels)
         if kind == 'xs':
-            capi.spmm_xs(a.xcd_sliced(), h, out, bias=self.bias, relu=True)
+            capi.spmm_xs(a.tiled_image(self.channels), h, out, bias=self.bias, relu=True)
         elif kind == 'sj':
             capi.spmm_sj(a.sliced(self.channels), h, out, bias=self.bias, relu=True)
         else:

@@ -27,7 +27,7 @@ class LightGCNConv(Layer):
             out = torch.empty((a.shape[0], x.shape[1]), dtype=torch.float32, device=x.device)
         kind = spmm_kind(a, x.shape[1])
         if kind == 'xs':
-            capi.spmm_xs(a.xcd_sliced(), x, out, acc_in=acc_in, acc_out=acc_out, acc_div=acc_div)
+            capi.spmm_xs(a.tiled_image(x.shape[1]), x, out, acc_in=acc_in, acc_out=acc_out, acc_div=acc_div)
         elif kind == 'sj':
             capi.spmm_sj(a.sliced(x.shape[1]), x, out, acc_in=acc_in, acc_out=acc_out, acc_div=acc_div)
         else:

@@ -123,7 +123,7 @@ class SequentialGNN(Model):
                 nxt = None if last else torch.empty((n, widths[0]), dtype=torch.float32, device=dev)
                 kind = spmm_kind(a, widths[0])
                 if kind == 'xs':
-                    capi.spmm_xs(a.xcd_sliced(), x, nxt, acc_in=acc, acc_out=acc_out,
+                    capi.spmm_xs(a.tiled_image(widths[0]), x, nxt, acc_in=acc, acc_out=acc_out,
                                  acc_div=len(layers) + 1 if last else None)
                 elif kind == 'sj':
                     capi.spmm_sj(a.sliced(widths[0]), x, nxt, acc_in=acc, acc_out=acc_out,
@@ -143,14 +143,15 @@ class SequentialGNN(Model):
             h = torch.empty((n, widths[1]), dtype=torch.float32, device=dev)
             # value-free XS image: the chain of gathered tables stays pre-scaled by d^-1/2 (first one in this X.W launch, the
             # following ones in the combine kernel's epilogue)
-            pre = all(spmm_kind(a, widths[k + 1]) == 'xs' for k in range(len(layers))) and a.xcd_sliced().row_scale is not None
-            capi.rowwise_xw(x, layers[0].kernel, h, copy_to=slices[0], row_scale=a.xcd_sliced().row_scale if pre else None)
+            pre = all(spmm_kind(a, widths[k + 1]) == 'xs' for k in range(len(layers))) and \
+                all(a.tiled_image(widths[k + 1]).row_scale is not None for k in range(len(layers)))
+            capi.rowwise_xw(x, layers[0].kernel, h, copy_to=slices[0], row_scale=a.tiled_image(widths[1]).row_scale if pre else None)
             for k, layer in enumerate(layers):
                 nxt = layers[k + 1] if k + 1 < len(layers) else None
                 h_next = torch.empty((n, widths[k + 2]), dtype=torch.float32, device=dev) if nxt is not None else None
                 kind = spmm_kind(a, widths[k + 1])
                 if kind == 'xs':
-                    capi.spmm_xs(a.xcd_sliced(), h, slices[k + 1], bias=layer.bias, relu=True,
+                    capi.spmm_xs(a.tiled_image(widths[k + 1]), h, slices[k + 1], bias=layer.bias, relu=True,
                                  Wnext=nxt.kernel if nxt is not None else None, Hnext=h_next,
                                  prescaled=pre, scale_next=pre and nxt is not None)
                 elif kind == 'sj':

@@ -273,7 +273,7 @@ class PartitionedGCNRunner:
             # value-free XCD-sliced image: the gathered table is pre-scaled by d^-1/2 inside the X.W launch
             if not self._use_xs(width):
                 return None
-            xs = self.csr.xcd_sliced()
+            xs = self.csr.tiled_image(width)
             return xs.col_scale if xs.row_scale is not None else None
 
         # persistent buffers: at 8 ranks the local kernels take tens of microseconds, so per-step allocations and the
@@ -286,7 +286,7 @@ class PartitionedGCNRunner:
             if self._use_xs(widths[k + 1]):
                 # the rank's row block on the XCD-sliced image (value-free when A_hat's factors are known): same kernels
                 # as the single-GPU path, the block's own rows sit at column offset rank * R of the padded table
-                ops.spmm_xs(self.csr.xcd_sliced(), h, y_local[:rows], bias=layer.bias, relu=True, prescaled=scale is not None)
+                ops.spmm_xs(self.csr.tiled_image(widths[k + 1]), h, y_local[:rows], bias=layer.bias, relu=True, prescaled=scale is not None)
             else:
                 ops.gcn_layer(self.csr.rowptr, self.csr.colidx, self.csr.vals, h, layer.bias, y_local[:rows])
             x_full = self._buffer(('x', k), (self.world * R, widths[k + 1]))

@@ -41,7 +41,7 @@ def _spmm(a, x, out):
     """out = A_hat . x with whichever image of A_hat the forward pass uses for this width."""
     kind = spmm_kind(a, x.shape[1])
     if kind == 'xs':
-        capi.spmm_xs(a.xcd_sliced(), x, out)
+        capi.spmm_xs(a.tiled_image(x.shape[1]), x, out)
     elif kind == 'sj':
         capi.spmm_sj(a.sliced(x.shape[1]), x, out)
     else:
@@ -400,6 +400,18 @@ class _StackTape:
         return g0
 
 
+def _require_symmetric(a):
+    """The reverse pass of every stack reuses the forward product (or edge list) as its transpose: A^T = A.  That holds for
+    `dataset.symmetric_adjacency: True` (config.yaml:36, every econfig); with False (preprocess.py:91 returns the
+    un-symmetrised matrix) the gradients would be silently wrong, so such a graph is refused.  One host check per graph."""
+    if getattr(a, '_symmetric_checked', None) is None:
+        m = a.to_scipy()
+        a._symmetric_checked = m.shape[0] == m.shape[1] and abs(m - m.T).max() <= 1e-6 * max(abs(m).max(), 1e-30)
+    if not a._symmetric_checked:
+        raise NotImplementedError("training needs a symmetric adjacency matrix (dataset.symmetric_adjacency: True): the reverse "
+                                  "pass multiplies by A where A^T is due")
+
+
 class Trainer:
     """Holds the Adam state of a Basic* / HybridBert* model (single-graph, TwoStep or TwoWay stacks) and performs training batches."""
 
@@ -413,6 +425,8 @@ class Trainer:
             self.layout, stacks = 'two_way', [gnn.way_one_gnn_layers, gnn.way_two_gnn_layers, gnn.step_two_gnn_layers]
         else:
             raise NotImplementedError("no training recipe for {}".format(type(gnn).__name__))
+        for seq_ in stacks:
+            _require_symmetric(seq_.adj_matrix)
         self.tapes = [_StackTape(seq) for seq in stacks]
         self.kind = self.tapes[-1].kind
         seq = stacks[-1]

@@ -5,38 +5,51 @@ sorted by row, so the columns a wave touches are scattered and a 32-byte row (F 
 fill.  A CU sustains ~0.43 such requests per clock (profiles/r1_exp_gather_frontend.txt): 0.207 ms for the
 55.9 M gathers of one ml1m(s=64) layer, whatever the kernel does around them.
 
-Here a workgroup owns a TILE of up to W.(RW-1) consecutive rows of Y (one tile per CU: the whole [rows, F] fp32
-tile sits in 128 KB of LDS) and walks ALL of the tile's non-zeros in COLUMN order, cut into "windows" of
-`window_entries` consecutive (by column) entries.  The tile's 8 waves own disjoint row ranges of it (so the LDS
-accumulation needs no atomics) and step through the windows together (one s_barrier per window): the few hundred
+Here a workgroup owns a TILE of consecutive rows of Y (one tile per CU: the tile's sums sit in 128 KB of LDS) and
+walks ALL of the tile's non-zeros in COLUMN order, cut into "windows" of `window_entries` consecutive (by column)
+entries.  The tile's W = 16 waves step through the windows together (one s_barrier per window): the few hundred
 neighbouring columns of a window are fetched into the CU's L1 once and then hit by every further entry of the
 window — 2-4 entries share a 128-byte line on ml1m(s=64) — instead of one L2 request per entry.  Each tile is
 finished inside its workgroup (diag term, row scale, bias / ReLU / next X.W epilogue): no partial-sum round trip
 and no second launch.
 
+Accumulation without atomics (LDS float atomics run at ~3 clocks per LANE on gfx950).  The unit of ownership is
+the VIRTUAL ROW: a row with more than `split` entries is cut into ceil(d / split) virtual rows (its entries dealt
+round-robin in column order), virtual row v of a tile belongs to wave v % W and sits in LDS row
+(v // W) * W + (v % W + v // W) % W.  A wave only ever touches its own LDS rows, so it adds with a plain
+ds_read_b128 / add / ds_write_b128.  Within a wave-instruction ("step": EPS = 64/(F/4) entries) the same virtual
+row must not be read-modified-written twice; the image therefore spreads the entries of a (wave, window) list over
+the steps the list covers (same-row entries go to different steps first), and what still collides is either
+    * an implicit PAIR: the entry in the slot right after the row's first entry of the step (same 16-lane DPP row):
+      the kernel recognises it (same lrow as the previous slot, flag clear), adds its gathered values to the first
+      entry's registers with one DPP shift and skips its LDS update; or
+    * FLAGGED (bit 31): added with ds_add_f32 after the step's plain updates (rare: < 1 % on ml1m graphs).
+
 Layout (all int32, device):
-    words         one 32-bit word per entry:  flag << 31 | lrow << cbits | column
-                  (lrow = row inside the owning wave's range, cbits = 31 - log2(RW)); each (tile, wave) stream is
-                  contiguous, starts at a multiple of 256 entries and is padded to one with PAD words
-                  (lrow = RW-1: a scratch row of the LDS tile, column 0).  Inside a (tile, wave, window) list the
-                  entries are ordered (occurrence of the row in the list, row): the EPS = 64/(F/4) entries of one
-                  wave-instruction ("step") then hit distinct LDS rows, and the read-add-write needs no conflict
-                  handling; the rare entry whose row already occurs earlier in its step carries flag = 1 and is
-                  added with an LDS float atomic after the step's plain read-add-write.
+    words         one 32-bit word per entry:  flag << 31 | lrow << cbits | column   (lrow = v // W,
+                  cbits = 31 - log2(RW), RW = rows per wave in the LDS tile); each (tile, wave) stream is contiguous,
+                  starts at a multiple of 256 entries and is padded to one with PAD words (lrow = RW-1, a scratch
+                  row of the wave; column 0)
     stream_start  [T*W]              first word of every (tile, wave) stream
     wsteps        [T, W, maxwin+1]   step index (stream-relative) at which window w of the tile begins for the
                                      wave; entry n_win[t] holds the stream's padded step count
     tile_row0     [T+1]              row range of every tile;  n_win [T]
+    vstart        [n_rows+1]         first virtual row of every row, numbered from 0 inside its tile
+                                     (vstart[tile_row0[t]] = 0; the last row of a tile ends at vstart_end[t])
+    vcount        [T]                virtual rows of every tile
 Entries are value-free (weight 1; an entry of multiplicity c is stored c times): A = S C S exactly as the value-free
 XS image, with `diag`, `row_scale`, `col_scale`, `diag_offset` of the same meaning.
 """
 import numpy as np
 import torch
 
-WAVES = 8                      # waves per workgroup of spmm_lt_kernel (one workgroup per CU)
+WAVES = 16                     # waves per workgroup of spmm_lt_kernel (one workgroup per CU)
 TILE_BYTES = 128 << 10         # LDS bytes of the Y tile
 CHUNK = 256                    # entries per index-stream chunk (64 lanes x 16 bytes)
 N_CU = 256
+SPLIT = 128                    # rows longer than this are cut into virtual rows of at most this many entries
+BALANCE_PASSES = 3
+COST_ENTRY, COST_LINE = 1.68, 1.71   # cycles per entry / per 128-byte line of X a tile touches (fit on ml1m(s=64), F = 8)
 
 
 def geometry(F):
@@ -52,18 +65,22 @@ def supported(F, n_cols):
 
 
 class LdsTiled:
-    def __init__(self, F, words, stream_start, wsteps, tile_row0, n_win, maxwin1, diag, row_scale, col_scale, diag_offset, shape,
-                 window_entries, n_entries, n_flagged):
+    def __init__(self, F, words, stream_start, wsteps, tile_row0, n_win, maxwin1, vstart, vcount, diag, row_scale, col_scale,
+                 diag_offset, shape, window_entries, n_entries, n_flagged, n_pairs):
         self.F, self.words, self.stream_start, self.wsteps = F, words, stream_start, wsteps
         self.tile_row0, self.n_win, self.maxwin1 = tile_row0, n_win, int(maxwin1)
+        self.vstart, self.vcount = vstart, vcount
         self.diag, self.row_scale, self.col_scale, self.diag_offset = diag, row_scale, col_scale, int(diag_offset)
         self.shape = tuple(shape)
         self.n_tiles = int(n_win.numel())
-        self.window_entries, self.n_entries, self.n_flagged = int(window_entries), int(n_entries), int(n_flagged)
+        self.window_entries, self.n_entries, self.n_flagged, self.n_pairs = int(window_entries), int(n_entries), int(n_flagged), int(n_pairs)
 
     @classmethod
-    def build(cls, rows, cols, n_rows, n_cols, F, diag, row_scale, col_scale, diag_offset=0, window_entries=None, n_cu=N_CU):
-        """`rows`/`cols`: int64 device tensors of the unit-weight off-diagonal entries (multiplicities expanded)."""
+    def build(cls, rows, cols, n_rows, n_cols, F, diag, row_scale, col_scale, diag_offset=0, window_entries=None, n_cu=N_CU,
+              split=SPLIT, balance=True, row_breaks=()):
+        """`rows`/`cols`: int64 device tensors of the unit-weight off-diagonal entries (multiplicities expanded).
+        `row_breaks`: rows at which a tile must end (node-type boundaries of a bipartite / tripartite graph with grouped ids:
+        a tile that straddles one walks two column ranges at half the density each and runs ~25 % longer than its peers)."""
         dev = rows.device
         W = WAVES
         eps, rw, cbits = geometry(F)
@@ -71,55 +88,93 @@ class LdsTiled:
             raise ValueError("LT image: F = {} with {} columns is outside the packed word's range".format(F, n_cols))
         if window_entries is None:
             window_entries = 2 * W * eps
-        rmax = W * (rw - 1)
+        vmax = W * (rw - 1)                                           # virtual rows a tile can hold
         m = int(rows.numel())
-        # a. row tiles: contiguous, (nearly) equal entry counts, at most rmax rows
+        idx = torch.arange(m, device=dev)
+        # a. virtual rows per row, then row tiles: contiguous, (nearly) equal COST, at most vmax virtual rows.  Cost of an entry
+        #    = COST_ENTRY + COST_LINE * (128-byte lines of X the tile touches) / (entries of the tile): tiles whose entries share
+        #    fewer lines (item rows of a bipartite rating graph: more columns, fewer entries per column) run longer per entry
+        #    (measured on ml1m(s=64), F = 8: 2.08 vs 2.44 cycles per entry).  First pass: equal entry counts; second pass: row
+        #    weights = entries x the cost per entry of the row's first-pass tile.
         deg = torch.bincount(rows, minlength=n_rows) if m else torch.zeros(n_rows, dtype=torch.int64, device=dev)
-        cum = np.concatenate([[0], np.cumsum(deg.cpu().numpy().astype(np.int64))])
-        n_rounds = max(1, -(-n_rows // (n_cu * rmax)))
-        e_t = max(1, -(-m // (n_cu * n_rounds)))
-        tb = [0]
-        while tb[-1] < n_rows:
-            r0 = tb[-1]
-            r1 = int(np.searchsorted(cum, cum[r0] + e_t, side='right')) - 1
-            tb.append(min(max(r1, r0 + 1), r0 + rmax, n_rows))
+        deg_np = deg.cpu().numpy().astype(np.int64)
+
+        breaks = sorted(int(b) for b in row_breaks if 0 < int(b) < n_rows)
+
+        def make_tiles(weight_cum, split_):
+            k_row_ = np.maximum((deg_np + split_ - 1) // split_, 1)
+            vcum_ = np.concatenate([[0], np.cumsum(k_row_)])
+            n_rounds_ = max(1, -(-int(vcum_[-1]) // (n_cu * vmax)))
+            wanted_ = n_cu * n_rounds_
+            # the segments between forced breaks share the tiles in proportion to their weight (at least one each)
+            edges = [0] + breaks + [n_rows]
+            seg_w = np.array([weight_cum[edges[i + 1]] - weight_cum[edges[i]] for i in range(len(edges) - 1)])
+            share = np.maximum(1, np.floor(seg_w / max(seg_w.sum(), 1e-30) * wanted_)).astype(np.int64)
+            while share.sum() < max(wanted_, len(share)):             # hand the remaining tiles to the segments with the most weight per tile
+                share[int(np.argmax(seg_w / share))] += 1
+            tb_ = [0]
+            for i in range(len(edges) - 1):
+                seg_end, target = edges[i + 1], seg_w[i] / share[i]
+                while tb_[-1] < seg_end:
+                    r0 = tb_[-1]
+                    r1 = int(np.searchsorted(weight_cum, weight_cum[r0] + target * (1 - 1e-9), side='left'))   # first row end reaching the target
+                    rv = int(np.searchsorted(vcum_, vcum_[r0] + vmax, side='right')) - 1  # last row end within the LDS capacity
+                    if rv <= r0:
+                        raise ValueError("LT image: a single row needs more than {} virtual rows".format(vmax))
+                    tb_.append(min(max(r1, r0 + 1), rv, seg_end))
+            return tb_, k_row_, vcum_, max(wanted_, len(share))
+
+        cum = np.concatenate([[0.0], np.cumsum(deg_np.astype(np.float64))])
+        while True:
+            tb, k_row_np, vcum, wanted = make_tiles(cum, split)
+            for _ in range(BALANCE_PASSES if balance and m else 0):
+                tb0 = torch.tensor(tb, dtype=torch.int64, device=dev)
+                tile0 = torch.searchsorted(tb0, rows, right=True) - 1
+                cpl = max(1, 128 // (4 * F))                          # columns per 128-byte line
+                n_lines = (n_cols + cpl - 1) // cpl
+                lines_t = torch.bincount(torch.unique(tile0 * n_lines + cols // cpl) // n_lines, minlength=len(tb) - 1).cpu().numpy()
+                ent_t = torch.bincount(tile0, minlength=len(tb) - 1).cpu().numpy()
+                cost_t = COST_ENTRY + COST_LINE * lines_t / np.maximum(ent_t, 1)
+                row_tile = np.searchsorted(np.asarray(tb), np.arange(n_rows), side='right') - 1
+                wcum = np.concatenate([[0.0], np.cumsum(deg_np * cost_t[row_tile])])
+                tb, k_row_np, vcum, wanted = make_tiles(wcum, split)
+                del tb0, tile0
+            if len(tb) - 1 <= wanted or split >= 4096:                # the LDS capacity forced extra tiles: cut long rows less finely
+                break
+            split *= 2
+        k_row = torch.from_numpy(k_row_np).to(dev)
         T = len(tb) - 1
         tb_t = torch.tensor(tb, dtype=torch.int64, device=dev)
-        nr_t = tb_t[1:] - tb_t[:-1]
-        blk_t = (nr_t + W - 1) // W                                   # rows per wave of each tile (<= rw - 1)
+        vcum_t = torch.from_numpy(vcum).to(dev)
         tile = torch.searchsorted(tb_t, rows, right=True) - 1
-        lr = rows - tb_t[tile]
-        wave = lr // blk_t[tile]
-        lrow = lr - wave * blk_t[tile]
-        # b. windows: position of the entry in its tile's column-sorted list
+        vbase_tile = vcum_t[tb_t[:-1]]                                # first virtual row (global numbering) of each tile
+        vstart = vcum_t[:-1] - vbase_tile[torch.searchsorted(tb_t, torch.arange(n_rows, device=dev), right=True) - 1] \
+            if n_rows else torch.zeros(0, dtype=torch.int64, device=dev)
+        vstart = torch.cat([vstart, torch.zeros(1, dtype=torch.int64, device=dev)])
+        vcount = vcum_t[tb_t[1:]] - vbase_tile
+        # b. windows + the virtual row of every entry: both from the tile's column-sorted order
         order = torch.argsort(tile * n_cols + cols)
         tile_cnt = torch.bincount(tile, minlength=T)
         tile_start = torch.cumsum(tile_cnt, 0) - tile_cnt
         win = torch.empty(m, dtype=torch.int64, device=dev)
-        win[order] = (torch.arange(m, device=dev) - tile_start[tile[order]]) // window_entries
+        win[order] = (idx - tile_start[tile[order]]) // window_entries
         del order
         n_win = (tile_cnt + window_entries - 1) // window_entries
         maxwin = max(1, int(n_win.max())) if T else 1
-        # c. occurrence rank of the entry among the entries of its (tile, window, row)
+        order = torch.argsort(rows * n_cols + cols)                   # j-th entry of its row in column order -> virtual row j % k
+        row_start = torch.cumsum(deg, 0) - deg
+        sub = torch.empty(m, dtype=torch.int64, device=dev)
+        sub[order] = (idx - row_start[rows[order]]) % k_row[rows[order]]
+        del order
+        v = vstart[rows] + sub                                        # virtual row inside the tile
+        wave, lrow = v % W, v // W
+        # c. order inside a (tile, wave, window) list: by virtual row; then deal the list's entries to its stream positions
+        #    slot-major over the steps the list covers, so that neighbours (same virtual row) land in different steps
         tw = tile * W + wave
-        key = (tw * maxwin + win) * rw + lrow
-        order = torch.argsort(key, stable=True)
-        ks = key[order]
-        idx = torch.arange(m, device=dev)
-        first = torch.ones(m, dtype=torch.bool, device=dev)
-        if m > 1:
-            first[1:] = ks[1:] != ks[:-1]
-        run_start = torch.cummax(torch.where(first, idx, torch.zeros_like(idx)), 0).values
-        rank = torch.empty(m, dtype=torch.int64, device=dev)
-        rank[order] = idx - run_start
-        del order, ks, first, run_start
-        max_rank = int(rank.max()) + 1 if m else 1
-        if T * W * maxwin * max_rank * rw >= (1 << 62):
+        lst = tw * maxwin + win
+        if T * W * maxwin * rw >= (1 << 62):
             raise ValueError("LT image: sort key overflow")
-        # d. final order: (tile, wave, window, rank, lrow); streams padded to whole chunks
-        key = ((tw * maxwin + win) * max_rank + rank) * rw + lrow
-        order = torch.argsort(key)
-        del key, rank
+        order = torch.argsort(lst * rw + lrow)
         cnt_tw = torch.bincount(tw, minlength=T * W)
         len_tw = (cnt_tw + CHUNK - 1) // CHUNK * CHUNK
         stream_start = torch.cumsum(len_tw, 0) - len_tw
@@ -128,23 +183,36 @@ class LdsTiled:
             raise ValueError("LT image: more than 2^31 entries")
         cnt_start = torch.cumsum(cnt_tw, 0) - cnt_tw
         tw_s = tw[order]
-        dest = stream_start[tw_s] + (idx - cnt_start[tw_s])
-        word = (lrow[order] << cbits) | cols[order]
-        # e. flag the entries whose LDS row already occurs earlier in their step (the kernel adds them atomically)
+        rel = idx - cnt_start[tw_s]                                   # position inside the (tile, wave) stream, list after list
+        lst_s = lst[order]
+        deal = torch.argsort((lst_s * eps + rel % eps) * (int(len_tw.max()) // eps + 1) + rel // eps)
+        dest = stream_start[tw_s] + rel[deal]                         # i-th entry of the sorted order takes the i-th dealt position
+        del deal, rel
         lrow_s = lrow[order]
-        k4 = (dest // eps) * rw + lrow_s
-        o4 = torch.argsort(k4, stable=True)
-        k4s = k4[o4]
-        dup = torch.zeros(m, dtype=torch.bool, device=dev)
+        word = (lrow_s << cbits) | cols[order]
+        # d. inside every step: the first entry of a virtual row is plain; the one in the next slot (same DPP row) is an implicit
+        #    pair; every other repeat is flagged
+        step, slot = dest // eps, dest % eps
+        spr = max(1, 16 // (F // 4))                                   # entry slots per 16-lane DPP row
+        o4 = torch.argsort((step * rw + lrow_s) * eps + slot)
+        g4 = (step * rw + lrow_s)[o4]
+        s4 = slot[o4]
+        first = torch.ones(m, dtype=torch.bool, device=dev)
         if m > 1:
-            dup[o4[1:]] = k4s[1:] == k4s[:-1]
-        n_flagged = int(dup.sum())
-        word = torch.where(dup, word - (1 << 31), word)              # bit 31 as two's complement
+            first[1:] = g4[1:] != g4[:-1]
+        run_start = torch.cummax(torch.where(first, idx, torch.zeros_like(idx)), 0).values
+        rank = idx - run_start
+        pair = (rank == 1) & (s4 == s4[run_start] + 1) & (s4 % spr != 0)
+        flagged = (rank >= 1) & ~pair
+        n_flagged, n_pairs = int(flagged.sum()), int(pair.sum())
+        flag = torch.zeros(m, dtype=torch.bool, device=dev)
+        flag[o4] = flagged
+        word = torch.where(flag, word - (1 << 31), word)              # bit 31 as two's complement
         words = torch.full((max(total, 1),), (rw - 1) << cbits, dtype=torch.int32, device=dev)
         words[dest] = word.to(torch.int32)
-        del o4, k4, k4s, dup, word, dest, lrow_s, tw_s
-        # f. step at which each window begins for each wave
-        cnt = torch.bincount(tw * maxwin + win, minlength=T * W * maxwin).view(T, W, maxwin)
+        del o4, g4, s4, first, run_start, rank, pair, flagged, flag, word, dest, lrow_s, tw_s, lst_s
+        # e. step at which each window begins for each wave
+        cnt = torch.bincount(lst, minlength=T * W * maxwin).view(T, W, maxwin)
         e0 = torch.cumsum(cnt, 2) - cnt                               # entries of the stream before the window
         wsteps = torch.empty((T, W, maxwin + 1), dtype=torch.int64, device=dev)
         wsteps[:, :, :maxwin] = e0 // eps
@@ -152,5 +220,6 @@ class LdsTiled:
         beyond = torch.arange(maxwin + 1, device=dev).view(1, 1, -1) >= n_win.view(T, 1, 1)
         wsteps = torch.where(beyond, end_steps.expand(T, W, maxwin + 1), wsteps)
         return cls(F, words, stream_start.to(torch.int32), wsteps.to(torch.int32).contiguous(),
-                   tb_t.to(torch.int32), n_win.to(torch.int32), maxwin + 1, diag, row_scale, col_scale, diag_offset,
-                   (n_rows, n_cols), window_entries, m, n_flagged)
+                   tb_t.to(torch.int32), n_win.to(torch.int32), maxwin + 1, vstart.to(torch.int32).contiguous(),
+                   vcount.to(torch.int32).contiguous(), diag, row_scale, col_scale, diag_offset,
+                   (n_rows, n_cols), window_entries, m, n_flagged, n_pairs)

@@ -141,8 +141,11 @@ def gcn_filter_device(rows, cols, n_nodes):
     vals = (dinv[r] * a) * dinv[c]
     rowptr = torch.zeros(n_nodes + 1, dtype=torch.int64, device=dev)
     rowptr[1:] = torch.cumsum(torch.bincount(r, minlength=n_nodes), 0)
-    return DeviceCSR(rowptr.to(torch.int32), c.to(torch.int32), vals, (n_nodes, n_nodes), gcn_filtered=True,
-                     dinv=dinv.contiguous(), mult=counts.to(torch.int32))
+    out = DeviceCSR(rowptr.to(torch.int32), c.to(torch.int32), vals, (n_nodes, n_nodes), gcn_filtered=True,
+                    dinv=dinv.contiguous(), mult=counts.to(torch.int32))
+    if rows.numel() and int(rows.max()) < int(cols.min()):           # bipartite with grouped ids (users, then items): type boundary
+        out.row_breaks = (int(cols.min()),)
+    return out
 
 
 class SlicedJagged:
@@ -392,10 +395,38 @@ def _csr_lds_tiled(self, F):
         rows, cols, diag, diag_offset = _unit_entries(self, True)
         col_scale = self.dinv.to(torch.float32).contiguous()
         n = self.shape[0]
+        breaks = tuple(b - diag_offset for b in getattr(self, 'row_breaks', ()))
         cache[F] = LdsTiled.build(rows, cols, n, self.shape[1], F, diag, col_scale[diag_offset:diag_offset + n].contiguous(),
-                                  col_scale, diag_offset,
+                                  col_scale, diag_offset, row_breaks=breaks,
                                   window_entries=int(os.environ['AMAR_LT_WINDOW']) if os.environ.get('AMAR_LT_WINDOW') else None)
     return cache[F]
 
 
 DeviceCSR.lds_tiled = _csr_lds_tiled
+
+LT_MIN_DENSITY = 0.2       # entries per (tile, column): below this neighbouring entries no longer share L1 lines
+
+
+def lt_eligible(a, F):
+    """Whether the large-graph product of `a` (a DeviceCSR or a row block of one) at width F runs on the LDS-tiled image
+    rather than the XCD-sliced one: the value-free factors must be known, the packed word must hold the column, and a
+    tile must see enough entries per column for the column-ordered walk to pay (measured on ml1m(s=64): -27 % per layer;
+    a row block of an 8-rank partition has 1/8 of the entries per tile over the same columns and stays on XS).
+    AMAR_SPMM_LT=0|1 overrides the density rule."""
+    from deep_cbrs_amar_renaissance_amd.utilities import lds_tiled
+    forced = os.environ.get('AMAR_SPMM_LT')
+    if forced == '0' or os.environ.get('AMAR_XS_VALUES') == '1':
+        return False
+    if getattr(a, 'dinv', None) is None or getattr(a, 'mult', None) is None or not lds_tiled.supported(F, a.shape[1]):
+        return False
+    if forced == '1':
+        return True
+    return F in (8, 16) and a.nnz >= LT_MIN_DENSITY * lds_tiled.N_CU * a.shape[1]
+
+
+def _csr_tiled_image(self, F):
+    """The image the large-graph SpMM of width F runs on: LdsTiled where eligible (capi.spmm_xs accepts both), else XcdSliced."""
+    return self.lds_tiled(F) if lt_eligible(self, F) else self.xcd_sliced()
+
+
+DeviceCSR.tiled_image = _csr_tiled_image

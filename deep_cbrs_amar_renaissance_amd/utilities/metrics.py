@@ -6,9 +6,11 @@ Ordering is (user ascending, score descending); equal scores — left to an unst
 in the reference (`metrics.py:27`) — break on item id ascending here.
 
 ``top_k_metrics`` in the reference shells out to ``java -jar binaries/mimir.jar`` (RiVal
-Precision/Recall, `metrics.py:60-65`); no JVM exists where this runs, so a plain host-side
-Precision/Recall/F1@k over the same files is provided instead.  It is a stand-in for the jar,
-not a bit-exact restatement of it.
+Precision/Recall, `metrics.py:60-65`); no JVM exists where this runs, so the holdout
+Precision/Recall/F1@k is restated on the host from RiVal's ranking-metric semantics
+(``precision_recall_f1_at_k``: hand-computed vectors in tests/test_metrics_cpu.py; the choices the
+jar's behaviour cannot settle here are explicit switches) and writes the same ``results.tsv``
+(label, P, R, F1 — `experiment.py:211-213` reads columns 1..3).
 """
 import logging
 import os
@@ -60,19 +62,49 @@ def top_k_predictions(predictions, users, items, k=5):
     return df
 
 
-def precision_recall_f1_at_k(test_filepath, predictions_filepath, k, sep='\t'):
-    """Macro-averaged Precision/Recall/F1@k over users: relevant = test rating 1, predicted = listed items."""
+def precision_recall_f1_at_k(test_filepath, predictions_filepath, k, sep='\t', short_lists='skip', no_relevant='skip',
+                             relevance_threshold=1.0):
+    """Precision / Recall / F1 @k of a top-k predictions file against the test ratings, as `mimir.jar -holdout -cutoff k`
+    computes them (metrics.py:60-65) — restated from RiVal's ranking metrics, the library inside the jar
+    (net.recommenders.rival.evaluation.metric.ranking.{AbstractRankingMetric,Precision,Recall}; there is no JVM here, so
+    the jar itself cannot be run: what its behaviour cannot settle is an explicit switch below):
+
+    * per TEST user with predictions, items are ranked by predicted score (the file's order inside a user is kept: the
+      reference writes each user's rows best first, metrics.py:27-33) and each carries its test relevance
+      (rating >= relevance_threshold -> relevant; an item absent from the user's test rows is not relevant);
+    * P@k(u) = (relevant among the first k) / k, R@k(u) = (relevant among the first k) / (relevant test items of u);
+    * RiVal records a user's value at cutoff k only when the ranked list REACHES rank k (`if (rank == at)`), so a user with
+      fewer than k predicted items contributes to neither mean: short_lists='skip' (default).  'count' keeps such users
+      with P = hits / k, R = hits / relevant — what an evaluator that pads short lists would report;
+    * a user without any relevant test item has R = 0 / 0 = NaN, which RiVal's getValueAt drops from the recall mean
+      (no_relevant='skip', default; 'zero' counts it as recall 0); its precision is 0 and is counted;
+    * both means are plain averages over the remaining users; F1 = 2 P R / (P + R) of the two MEANS (the jar's f1Measure
+      takes the aggregated precision and recall), 0 when both are 0.
+    `relevance_threshold`: the jar's constant is not recoverable from its call site; with the {0, 1} ratings of every
+    dataset in the reference any threshold in (0, 1] gives the same result.
+    """
+    if short_lists not in ('skip', 'count') or no_relevant not in ('skip', 'zero'):
+        raise ValueError("short_lists must be 'skip' or 'count', no_relevant 'skip' or 'zero'")
     test = pd.read_csv(test_filepath, sep=sep, header=None).to_numpy()
     pred = pd.read_csv(predictions_filepath, sep=sep, header=None).to_numpy()
-    liked = test[test[:, 2] == 1]
+    test_users = set(test[:, 0].astype(np.int64).tolist())
+    liked = test[test[:, 2] >= relevance_threshold]
     liked_keys = set(zip(liked[:, 0].astype(np.int64).tolist(), liked[:, 1].astype(np.int64).tolist()))
     n_liked = pd.Series(liked[:, 0].astype(np.int64)).value_counts().to_dict()
-    hits = {}
+    hits, listed = {}, {}
     for u, i in zip(pred[:, 0].astype(np.int64).tolist(), pred[:, 1].astype(np.int64).tolist()):
-        hits[u] = hits.get(u, 0) + ((u, i) in liked_keys)
-    users = sorted(hits)
-    precision = float(np.mean([hits[u] / k for u in users])) if users else 0.0
-    recall = float(np.mean([hits[u] / n_liked[u] for u in users if n_liked.get(u, 0) > 0])) if users else 0.0
+        if u not in test_users:
+            continue                                              # RiVal walks the test model's users
+        rank = listed.get(u, 0)
+        if rank < k:                                              # only the first k rows of a user count
+            hits[u] = hits.get(u, 0) + ((u, i) in liked_keys)
+        listed[u] = rank + 1
+    users = sorted(u for u in listed if short_lists == 'count' or listed[u] >= k)
+    prec = [hits[u] / k for u in users]
+    rec = [hits[u] / n_liked[u] if n_liked.get(u, 0) > 0 else (0.0 if no_relevant == 'zero' else None) for u in users]
+    rec = [r for r in rec if r is not None]
+    precision = float(np.mean(prec)) if prec else 0.0
+    recall = float(np.mean(rec)) if rec else 0.0
     f1 = 2 * precision * recall / (precision + recall) if precision + recall > 0 else 0.0
     return precision, recall, f1
 

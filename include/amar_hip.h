@@ -110,20 +110,25 @@ int amar_spmm_xs_f32(const float *diag, const int32_t *rowptr, const int32_t *co
 /* The same value-free product on the LDS-tiled (LT) image (utilities/lds_tiled.py:LdsTiled builds it; any producer
  * may) — the form the 2-layer basic-gnn propagation (src/models/gnn.py:74-84 with GCNConv / LightGCNConv layers,
  * gnn.py:289-295, src/layers/lightgcn_conv.py:51-54) runs on when the node table exceeds the per-XCD L2s:
- * ONE launch, one 512-thread workgroup per tile of consecutive rows, the tile's [rows, F] fp32 sums in 128 KB of LDS.
- *   tile_row0[n_tiles+1]   row ranges; a tile has at most 8.(RW-1) rows, RW = 128 KB / (4.F.8)
- *   words                  one int32 per unit entry: flag << 31 | lrow << cbits | column, cbits = 31 - log2(RW)
- *                          (n_cols <= 2^cbits, else AMAR_EUNSUPPORTED); wave w of a tile owns its rows
- *                          [w.blk, (w+1).blk), blk = ceil(rows / 8), lrow = row inside that range; every (tile, wave)
- *                          stream is contiguous, 256-entry aligned and padded with (RW-1) << cbits; the 64/(F/4)
- *                          entries of a step hit distinct rows except those with flag = 1 (added atomically)
- *   stream_start[n_tiles*8], wsteps[n_tiles][8][maxwin1], n_win[n_tiles]: see utilities/lds_tiled.py
+ * ONE launch, one 1024-thread workgroup per tile of consecutive rows, the tile's fp32 sums in 128 KB of LDS, the
+ * tile's entries walked in column order so that neighbouring entries share L1 lines.  W = 16 waves,
+ * RW = 128 KB / (4.F.W) LDS rows per wave, cbits = 31 - log2(RW) (n_cols <= 2^cbits, else AMAR_EUNSUPPORTED).
+ *   tile_row0[n_tiles+1]   row range of every tile
+ *   vstart[n_rows+1], vcount[n_tiles]   a row owns the virtual rows [vstart[i], vstart[i+1]) of its tile (the last row of
+ *                          tile t up to vcount[t]); a tile has at most W.(RW-1) virtual rows.  Virtual row v belongs to
+ *                          wave v % W and accumulates in LDS row (v/W).W + (v%W + v/W) % W.
+ *   words                  one int32 per unit entry: flag << 31 | (v / W) << cbits | column; every (tile, wave) stream is
+ *                          contiguous, 256-entry aligned and padded with (RW-1) << cbits.  Within a step (64/(F/4)
+ *                          consecutive entries) a virtual row is read-modified-written once: a repeat in the next slot
+ *                          (same 16-lane DPP row, flag 0) is folded into its neighbour in registers; any other repeat
+ *                          carries flag = 1 and is added with an LDS atomic after the step.
+ *   stream_start[n_tiles*W], wsteps[n_tiles][W][maxwin1], n_win[n_tiles]: see utilities/lds_tiled.py
  * X (n_cols rows) must hold S.X; Y[i] = epilogue( row_scale[i] . (diag[i] . Xself[i] + sum of the row's entries) ),
  * flags / bias / acc_* / Wnext / AMAR_SPMM_SCALE_NEXT as amar_spmm_xs_f32.  The summation order of a row is fixed by
  * the image, so results are bitwise reproducible run to run (they differ from the XS / CSR forms in the last bits).
  */
 int amar_spmm_lt_f32(const int32_t *words, const int32_t *stream_start, const int32_t *wsteps, const int32_t *tile_row0,
-                     const int32_t *n_win, int32_t n_tiles, int32_t maxwin1,
+                     const int32_t *n_win, const int32_t *vstart, const int32_t *vcount, int32_t n_tiles, int32_t maxwin1,
                      const float *diag, const float *row_scale,
                      const float *X, int64_t ldx, int32_t n_cols, const float *Xself,
                      float *Y, int64_t ldy, int32_t n_rows, int32_t F, uint32_t flags, const float *bias,

@@ -776,12 +776,12 @@ def test_spmm_lds_tiled_heavy_rows(hip):
     cols = torch.from_numpy(np.concatenate([c, r]).astype(np.int64)).to(DEV)
     scale = torch.from_numpy(rng.uniform(0.5, 1.5, n).astype(np.float32)).to(DEV)
     diag = torch.ones(n, device=DEV)
-    for F, n_cu in ((8, 4), (16, 2)):
-        lt = lds_tiled.LdsTiled.build(rows, cols, n, n, F, diag, scale, scale, 0, n_cu=n_cu)
-        assert lt.n_flagged > 0
+    for F, n_cu, split in ((8, 4, 256), (16, 2, 4096), (8, 1, 100000), (32, 3, 64), (4, 2, 100000)):
+        lt = lds_tiled.LdsTiled.build(rows, cols, n, n, F, diag, scale, scale, 0, n_cu=n_cu, split=split)
+        assert split < 20000 or (lt.n_flagged > 0 and lt.n_pairs > 0)       # un-split heavy rows: pairs and flagged repeats
         xs_tab = rng.standard_normal((n, F)).astype(np.float32)
         y = torch.full((n, F), float('nan'), device=DEV)
         hip.spmm_lt(lt, _t(xs_tab), y, prescaled=True)
         A = sparse.coo_matrix((np.ones(rows.numel()), (rows.cpu().numpy(), cols.cpu().numpy())), shape=(n, n)).tocsr()
         want = scale.cpu().numpy()[:, None].astype(np.float64) * (xs_tab.astype(np.float64) + A @ xs_tab.astype(np.float64))
-        assert rel_err(y.cpu().numpy(), want) < 3e-6
+        assert rel_err(y.cpu().numpy(), want) < 1e-5             # rows of 20 000 fp32 terms

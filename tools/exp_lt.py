@@ -7,6 +7,7 @@ import sys
 import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import numpy as np
 import torch
 
 
@@ -50,7 +51,8 @@ def main():
     col_scale = a.dinv.to(torch.float32).contiguous()
     for w in windows:
         t0 = time.perf_counter()
-        lt = lds_tiled.LdsTiled.build(rows, cols, n, n, F, diag, col_scale, col_scale, off, window_entries=w or None)
+        lt = lds_tiled.LdsTiled.build(rows, cols, n, n, F, diag, col_scale, col_scale, off, window_entries=w or None,
+                                      split=int(os.environ.get('LT_SPLIT', lds_tiled.SPLIT)), row_breaks=getattr(a, 'row_breaks', ()))
         torch.cuda.synchronize()
         t_build = time.perf_counter() - t0
         for variant in variants:
@@ -67,11 +69,31 @@ def main():
             t_lt = timeit(lambda: capi.spmm_lt(lt, xs_tab, y_lt, prescaled=True))
             rows_t = (lt.tile_row0[1:] - lt.tile_row0[:-1])
             print('  variant %s window %5d: LT %.4f ms (%.2fx XS)  max|diff| %.2e (rel %.1e) reproducible %s | tiles %d (rows %d..%d) '
-                  'windows/tile %d flagged %.3f%% pad %.2f%% build %.1f s' %
+                  'vrows <= %d windows/tile %d pairs %.3f%% flagged %.3f%% pad %.2f%% build %.1f s' %
                   (variant, lt.window_entries, t_lt, t_xs / t_lt, err, rel, same, lt.n_tiles, int(rows_t.min()), int(rows_t.max()),
-                   lt.maxwin1 - 1, 100.0 * lt.n_flagged / max(1, lt.n_entries),
+                   int(lt.vcount.max()), lt.maxwin1 - 1, 100.0 * lt.n_pairs / max(1, lt.n_entries), 100.0 * lt.n_flagged / max(1, lt.n_entries),
                    100.0 * (lt.words.numel() - lt.n_entries) / max(1, lt.n_entries), t_build), flush=True)
         os.environ.pop('AMAR_LT_VARIANT', None)
+        if os.environ.get('LT_STAMPS'):
+            # cycles per tile (shader clock), user-row tiles vs item-row tiles
+            for variant in variants:
+                os.environ['AMAR_LT_VARIANT'] = variant
+                stamps = torch.zeros(lt.n_tiles, dtype=torch.int64, device=dev)
+                os.environ['AMAR_LT_STAMPS'] = str(stamps.data_ptr())
+                capi.spmm_lt(lt, xs_tab, y_lt, prescaled=True)
+                torch.cuda.synchronize()
+                os.environ.pop('AMAR_LT_STAMPS')
+                st = stamps.cpu().numpy().astype(float)
+                is_user = (lt.tile_row0[:-1] < data['n_users']).cpu().numpy()
+                tc = torch.bincount(torch.searchsorted(lt.tile_row0.long(), rows, right=True) - 1, minlength=lt.n_tiles).cpu().numpy()
+                worst = int(st.argmax())
+                print('    variant %s slowest tile %d: rows [%d, %d) entries %d windows %d cycles %.0f' % (variant, worst, int(lt.tile_row0[worst]), int(lt.tile_row0[worst + 1]), tc[worst], int(lt.n_win[worst]), st[worst]), flush=True)
+                for name, sel in (('user tiles', is_user), ('item tiles', ~is_user)):
+                    if sel.any():
+                        print('    variant %s %s: n %d cycles min %.0f median %.0f max %.0f | entries median %.0f -> %.2f cycles/entry' %
+                              (variant, name, sel.sum(), st[sel].min(), np.median(st[sel]), st[sel].max(), np.median(tc[sel]),
+                               np.median(st[sel]) / max(1.0, np.median(tc[sel]))), flush=True)
+            os.environ.pop('AMAR_LT_VARIANT', None)
         del lt
 
 

@@ -27,12 +27,15 @@ def main():
         a.colidx.zero_()
     sj = a.sliced(F) if kind == 'sj' else None
     xs = a.xcd_sliced() if kind == 'xs' else None
+    lt = a.lds_tiled(F) if kind == 'lt' else None                    # AMAR_LT_WINDOW / AMAR_LT_VARIANT apply
     torch.cuda.synchronize()
     for _ in range(reps):
         if kind == 'sj':
             capi.spmm_sj(sj, x, y)
         elif kind == 'xs':
-            capi.spmm_xs(xs, x, y)
+            capi.spmm_xs(xs, x, y, prescaled=xs.row_scale is not None)
+        elif kind == 'lt':
+            capi.spmm_lt(lt, x, y, prescaled=True)
         else:
             capi.spmm_csr(a.rowptr, a.colidx, a.vals, x, y)
     torch.cuda.synchronize()

@@ -43,6 +43,7 @@ SIGNATURES = {
     'amar_chain_pack_floats': (ctypes.c_int64, [_P, _I32]),
     'amar_chain_pack_f32': (ctypes.c_int, [_P, _P, _P, _I32, _P]),
     'amar_chain_f32': (ctypes.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _I32, _P, _I32, _I32, _I32, _P, _P, _P, _I32, _P, _I64, _I64, _P]),
+    'amar_chain_indexed_f32': (ctypes.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _I32, _P, _I32, _I32, _I32, _P, _P, _P, _I32, _P, _I64, _P, _I64, _P]),
     'amar_dual_chain_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _I32, _P, _P, _I64, _I64, _P]),
     'amar_copy_columns_f32': (ctypes.c_int, [_P, _I64, _P, _I32, _P, _I64, _I64, _I32, _P]),
     'amar_reduce_layers_f32': (ctypes.c_int, [_P, _I64, _I32, _I32, _P, _I64, _I64, _I32, _P]),
@@ -450,9 +451,10 @@ def chain_pack(kernels, biases):
     return out, dims
 
 
-def chain(A, wpack, dims, acts, out, ids_a=None, base_a=0, B=None, ids_b=None, base_b=0, sum_inputs=False, in_act=None):
+def chain(A, wpack, dims, acts, out, ids_a=None, base_a=0, B=None, ids_b=None, base_b=0, sum_inputs=False, in_act=None, out_index=None):
     """out = DenseStack([A[ids_a - base_a] || B[ids_b - base_b]]), or DenseStack(in_act(A[..] + B[..])) with
-    sum_inputs; see amar_chain_f32 in include/amar_hip.h."""
+    sum_inputs; see amar_chain_f32 in include/amar_hip.h.  out_index (int32 [P]): row p goes to out[out_index[p]]
+    (amar_chain_indexed_f32: a pair list kept in XCD-affine order, scores back in the caller's order)."""
     P = out.shape[0]
     Da, Db = A.shape[1], (B.shape[1] if B is not None else 0)
     for ids, nm in ((ids_a, 'ids_a'), (ids_b, 'ids_b')):
@@ -462,13 +464,15 @@ def chain(A, wpack, dims, acts, out, ids_a=None, base_a=0, B=None, ids_b=None, b
         raise ValueError("chain: input blocks have fewer rows than the output")
     dims_c = (ctypes.c_int32 * len(dims))(*dims)
     acts_c = (ctypes.c_int32 * len(acts))(*[ACT_CODES[a] for a in acts])
-    code = load().amar_chain_f32(
+    if out_index is not None and out_index.numel() != P:
+        raise ValueError("chain: out_index must have one entry per output row")
+    code = load().amar_chain_indexed_f32(
         _ptr(A, torch.float32, 'A'), _ld(A, 'A'), Da, _ptr(ids_a, torch.int32, 'ids_a'), int(base_a),
         _ptr(B, torch.float32, 'B'), _ld(B, 'B') if B is not None else 0, Db, _ptr(ids_b, torch.int32, 'ids_b'), int(base_b),
         1 if sum_inputs else 0, ACT_CODES[in_act],
         _ptr(wpack, torch.float32, 'wpack'), dims_c, acts_c, len(acts),
-        _ptr(out, torch.float32, 'out'), _ld(out, 'out'), P, _stream())
-    _check(code, 'amar_chain_f32')
+        _ptr(out, torch.float32, 'out'), _ld(out, 'out'), _ptr(out_index, torch.int32, 'out_index'), P, _stream())
+    _check(code, 'amar_chain_indexed_f32' if out_index is not None else 'amar_chain_f32')
 
 
 def dual_chain_supported(D, n_branch_dims_equal, trunk_dims):

@@ -39,7 +39,10 @@ struct ChainArgs {
     int has_dot, dot_off, dot_bias_off, dot_act, dot_kt;
     int n_out;                          // width of the written block (last MFMA layer) when !has_dot
     float *out; int64_t ldo; int64_t P;
+    const int32_t *out_index;           // row p is written to out row out_index[p] (a pair list kept in another order), or NULL
 };
+
+__device__ __forceinline__ int64_t chain_out_row(const ChainArgs &a, int64_t p) { return a.out_index ? (int64_t)a.out_index[p] : p; }
 
 __device__ __forceinline__ float chain_act(float v, int act) {
     if (act == AMAR_ACT_RELU) return fmaxf(v, 0.f);
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
                 s += __shfl_xor(s, 16, 64);
                 s += __shfl_xor(s, 32, 64);
                 const int64_t p = base + 16 * pt + col;
-                if (g == 0 && p < a.P) a.out[p * a.ldo] = chain_act(s + bd, a.dot_act);
+                if (g == 0 && p < a.P) a.out[chain_out_row(a, p) * a.ldo] = chain_act(s + bd, a.dot_act);
             }
         } else {
 #pragma unroll
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
 #pragma unroll
                 for (int m = 0; m < MAXT; ++m) {
                     const int f = 16 * m + 4 * g;
-                    if (p < a.P && f < a.n_out) *reinterpret_cast<f32x4 *>(a.out + p * a.ldo + f) = x[m][pt];
+                    if (p < a.P && f < a.n_out) *reinterpret_cast<f32x4 *>(a.out + chain_out_row(a, p) * a.ldo + f) = x[m][pt];
                 }
             }
         }
@@ -186,7 +189,9 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
 // Same arithmetic in the same order as the generic kernel: the scores are bit-identical.
 __device__ __forceinline__ float relu_bits(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
 
-template <int MAXT, int PT>
+// SCATTER: scores go to out[out_index[p]] (a pair list prepared in XCD-affine order writes back in the caller's order); the index is
+// requested at the top of the iteration, unconditionally like every other load here, and has the whole MFMA block to arrive.
+template <int MAXT, int PT, bool SCATTER>
 __global__ __launch_bounds__(256) void chain_pipe_kernel(const ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float w_lds[];
     for (int i = threadIdx.x * 4; i < a.wpack_floats; i += blockDim.x * 4)
@@ -227,6 +232,8 @@ __global__ __launch_bounds__(256) void chain_pipe_kernel(const ChainArgs a) {
     // one iteration: consume (va, vb), start the next iteration's gathers into (na, nb), run the layers, store
     auto step = [&](int64_t base, int32_t (&ra)[PT], int32_t (&rb)[PT], f32x4 (&va)[MAXT][PT], f32x4 (&vb)[MAXT][PT],
                     f32x4 (&na)[MAXT][PT], f32x4 (&nb)[MAXT][PT]) {
+        int32_t out_row = 0;
+        if (SCATTER) out_row = a.out_index[min(base + 16 * min(g, PT - 1) + col, last)];
         f32x4 x[MAXT][PT];
 #pragma unroll
         for (int t = 0; t < MAXT; ++t)
@@ -290,7 +297,7 @@ __global__ __launch_bounds__(256) void chain_pipe_kernel(const ChainArgs a) {
             z += bd;
             z = chain_act(z, a.dot_act);                            // same expression as the generic kernel: bit-identical scores
             const int64_t p = base + 16 * g + col;
-            if (g < PT && p < a.P) a.out[p * a.ldo] = z;
+            if (g < PT && p < a.P) a.out[(SCATTER ? (int64_t)out_row : p) * a.ldo] = z;
         } else {
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(256) void chain_pipe_kernel(const ChainArgs a) {
 #pragma unroll
                 for (int m = 0; m < MAXT; ++m) {
                     const int f = 16 * m + 4 * g;
-                    if (p < a.P && f < a.n_out) *reinterpret_cast<f32x4 *>(a.out + p * a.ldo + f) = x[m][pt];
+                    if (p < a.P && f < a.n_out) *reinterpret_cast<f32x4 *>(a.out + chain_out_row(a, p) * a.ldo + f) = x[m][pt];
                 }
             }
         }
@@ -632,6 +639,15 @@ int amar_chain_f32(const float *A, int64_t lda, int32_t Da, const int32_t *ids_a
                    int32_t sum_inputs, int32_t in_act,
                    const float *wpack, const int32_t *dims, const int32_t *acts, int32_t n_layers,
                    float *out, int64_t ldo, int64_t P, amar_stream_t stream) {
+    return amar_chain_indexed_f32(A, lda, Da, ids_a, base_a, B, ldb, Db, ids_b, base_b, sum_inputs, in_act, wpack, dims, acts, n_layers,
+                                  out, ldo, nullptr, P, stream);
+}
+
+int amar_chain_indexed_f32(const float *A, int64_t lda, int32_t Da, const int32_t *ids_a, int32_t base_a,
+                           const float *B, int64_t ldb, int32_t Db, const int32_t *ids_b, int32_t base_b,
+                           int32_t sum_inputs, int32_t in_act,
+                           const float *wpack, const int32_t *dims, const int32_t *acts, int32_t n_layers,
+                           float *out, int64_t ldo, const int32_t *out_index, int64_t P, amar_stream_t stream) {
     if (P < 0 || !A || !wpack || !dims || !acts || !out || Da < 4 || Db < 0) return AMAR_EINVAL;
     if (sum_inputs && (Db != Da || !B)) return AMAR_EINVAL;
     if (in_act != AMAR_ACT_NONE && in_act != AMAR_ACT_RELU && in_act != AMAR_ACT_SIGMOID) return AMAR_EINVAL;
@@ -642,6 +658,7 @@ int amar_chain_f32(const float *A, int64_t lda, int32_t Da, const int32_t *ids_a
     a.A = A; a.lda = lda; a.Da = Da; a.ids_a = ids_a; a.base_a = base_a;
     a.B = B; a.ldb = ldb; a.Db = Db; a.ids_b = ids_b; a.base_b = base_b;
     a.wpack = wpack; a.out = out; a.ldo = ldo; a.P = P; a.sum_inputs = sum_inputs ? 1 : 0; a.in_act = in_act;
+    a.out_index = out_index;
     int maxw = 0, off = 0;
     for (int l = 0; l < n_layers; ++l) {
         const int K = dims[l], N = dims[l + 1], act = acts[l];
@@ -701,8 +718,14 @@ int amar_chain_f32(const float *A, int64_t lda, int32_t Da, const int32_t *ids_a
         int64_t blocks = (P + 4 * 16 * 2 - 1) / (4 * 16 * 2);
         if (blocks > 4096) blocks = 4096;
         const dim3 grid((unsigned)blocks), block(256);
-        if (maxt == 3) hipLaunchKernelGGL((chain_pipe_kernel<3, 2>), grid, block, lds_bytes, st, a);
-        else hipLaunchKernelGGL((chain_pipe_kernel<4, 2>), grid, block, lds_bytes, st, a);
+        if (a.out_index && !a.has_dot) return AMAR_EUNSUPPORTED;
+        if (a.out_index) {
+            if (maxt == 3) hipLaunchKernelGGL((chain_pipe_kernel<3, 2, true>), grid, block, lds_bytes, st, a);
+            else hipLaunchKernelGGL((chain_pipe_kernel<4, 2, true>), grid, block, lds_bytes, st, a);
+        } else {
+            if (maxt == 3) hipLaunchKernelGGL((chain_pipe_kernel<3, 2, false>), grid, block, lds_bytes, st, a);
+            else hipLaunchKernelGGL((chain_pipe_kernel<4, 2, false>), grid, block, lds_bytes, st, a);
+        }
         return amar_check_launch();
     }
     if (maxt == 3) { if (pt == 1) AMAR_CHAIN_LAUNCH(3, 1); else if (pt == 2) AMAR_CHAIN_LAUNCH(3, 2); else AMAR_CHAIN_LAUNCH(3, 4); }

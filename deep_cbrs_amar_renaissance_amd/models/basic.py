@@ -116,7 +116,9 @@ class BasicRS(Model):
             out.append(t)
         return (out[0], out[1], True)
 
-    def score_towers(self, towers, u_ids, i_ids, u_base=0, i_base=0):
+    def score_towers(self, towers, u_ids, i_ids, u_base=0, i_base=0, pair_plan=None):
+        """Scores of the pairs (u_ids[p], i_ids[p]) from per-entity tower tables.  `pair_plan` (PairPlan of the same id lists):
+        the launch walks the list in the plan's XCD-affine order and writes every score to its place in the caller's order."""
         tu, ti, split = towers
         if not split:
             return self.clf.apply2(tu, ti, ids_a=u_ids, base_a=u_base, ids_b=i_ids, base_b=i_base)
@@ -124,9 +126,47 @@ class BasicRS(Model):
         blob, dims, acts = plan['rest']
         m = u_ids.numel() if u_ids is not None else tu.shape[0]
         out = torch.empty((m, 1), dtype=torch.float32, device=tu.device)
+        if pair_plan is not None:
+            pair_plan.check(u_ids, i_ids)
+            capi.chain(tu, blob, dims, acts, out, ids_a=pair_plan.u_ids, base_a=u_base, B=ti, ids_b=pair_plan.i_ids, base_b=i_base,
+                       sum_inputs=True, in_act=plan['in_act'], out_index=pair_plan.out_index)
+            return out
         capi.chain(tu, blob, dims, acts, out, ids_a=u_ids, base_a=u_base, B=ti, ids_b=i_ids, base_b=i_base,
                    sum_inputs=True, in_act=plan['in_act'])
         return out
+
+
+class PairPlan:
+    """A pair list prepared ONCE per dataset for the pair stage (the test Sequence's pairs are constant across steps and
+    epochs: datasets.py:199-203 only reshuffles the TRAIN order).  The scoring kernel deals its 128-pair chunks to workgroups
+    round-robin, and workgroups to the eight XCDs round-robin, so the pairs at positions p with (p >> 7) % 8 == x run on XCD x.
+    The plan sorts the pairs by item id, cuts that order into eight contiguous item ranges sized to the positions each XCD
+    owns, and places range x on XCD x's positions — inside a range in the caller's original order, so that neighbouring
+    lanes write neighbouring scores.  Every XCD then gathers item-tower rows of one eighth of the items (~5 MB at
+    ml1m(s=64): L2-resident) instead of all of them; `out_index` sends each score back to the caller's position."""
+
+    N_XCD, CHUNK = 8, 128
+
+    def __init__(self, u_ids, i_ids):
+        p = int(u_ids.numel())
+        dev = u_ids.device
+        pos = torch.arange(p, device=dev)
+        xcd = (pos // self.CHUNK) % self.N_XCD
+        slots = torch.bincount(xcd, minlength=self.N_XCD)                      # positions owned by each XCD
+        by_item = torch.argsort(i_ids.to(torch.int64), stable=True)
+        bucket = torch.repeat_interleave(torch.arange(self.N_XCD, device=dev), slots)   # bucket of the k-th pair in item order
+        order = by_item[torch.argsort(bucket * p + by_item)]                    # (bucket, original position)
+        place = torch.argsort(xcd * p + pos)                                    # positions grouped by XCD, ascending inside
+        src = torch.empty(p, dtype=torch.int64, device=dev)
+        src[place] = order                                                      # position -> original pair
+        self.u_ids = u_ids[src].contiguous()
+        self.i_ids = i_ids[src].contiguous()
+        self.out_index = src.to(torch.int32).contiguous()
+        self._key = (u_ids.data_ptr(), i_ids.data_ptr(), p)
+
+    def check(self, u_ids, i_ids):
+        if (u_ids.data_ptr(), i_ids.data_ptr(), int(u_ids.numel())) != self._key:
+            raise ValueError("this PairPlan was prepared for another pair list")
 
 
 class BasicGNN(Model, abc.ABC):

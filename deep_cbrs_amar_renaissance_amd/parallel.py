@@ -98,6 +98,11 @@ class SingleRunner:
         a = model.gnn.gnn_layers.adj_matrix
         self.local_rows, self.local_nnz = a.shape[0], a.nnz
         self._prop_ms = None
+        # the pair list does not change between steps: prepared once in XCD-affine item ranges (models/basic.py:PairPlan)
+        self.pair_plan = None
+        if hasattr(model.rs, 'unet') and os.environ.get('AMAR_PAIR_PLAN', '1') != '0' and u_ids.numel() >= (1 << 16):
+            from deep_cbrs_amar_renaissance_amd.models.basic import PairPlan
+            self.pair_plan = PairPlan(u_ids, i_ids)
 
     def step(self):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -110,9 +115,10 @@ class SingleRunner:
     def _score(self, emb):
         # per-entity towers, then gather + classifier per pair (nothing is cached across steps)
         nu, ni = self.model.n_users, self.model.n_items
+        kw = {'pair_plan': self.pair_plan} if self.pair_plan is not None else {}
         if nu is None or ni is None:
-            return self.model.rs.score_towers(self.model.rs.towers(emb, emb), self.u_ids, self.i_ids)
-        return self.model.rs.score_towers(self.model.rs.towers(emb[:nu], emb[nu:nu + ni]), self.u_ids, self.i_ids, 0, nu)
+            return self.model.rs.score_towers(self.model.rs.towers(emb, emb), self.u_ids, self.i_ids, **kw)
+        return self.model.rs.score_towers(self.model.rs.towers(emb[:nu], emb[nu:nu + ni]), self.u_ids, self.i_ids, 0, nu, **kw)
 
     def last_propagation_ms(self):
         e0, e1 = self._events
@@ -195,6 +201,10 @@ class PartitionedGCNRunner:
             if self.pair_range is None and self.u_ids.numel():
                 self.u_rows = (int(self.u_ids.min()), int(self.u_ids.max()) + 1)   # the user rows this shard touches
         self._bert_version, self._bert_pad = None, None
+        self.pair_plan = None
+        if ops is capi and not self.hybrid and os.environ.get('AMAR_PAIR_PLAN', '1') != '0' and self.u_ids.numel() >= (1 << 16):
+            from deep_cbrs_amar_renaissance_amd.models.basic import PairPlan
+            self.pair_plan = PairPlan(self.u_ids, self.i_ids)          # the rank's pairs, fixed for the runner's lifetime
 
     def _x0_padded(self):
         emb = self.seq.embeddings
@@ -322,6 +332,8 @@ class PartitionedGCNRunner:
             towers = self.model.rs.towers(emb[u0:u1], emb[i0:i1], bert[u0:u1], bert[i0:i1])
         else:
             towers = self.model.rs.towers(emb[u0:u1], emb[i0:i1])
+        if self.pair_plan is not None:
+            return self.model.rs.score_towers(towers, self.u_ids, self.i_ids, u0, i0, pair_plan=self.pair_plan)
         return self.model.rs.score_towers(towers, self.u_ids, self.i_ids, u0, i0)
 
     def _use_xs(self, width):

@@ -229,6 +229,19 @@ int amar_chain_f32(const float *A, int64_t lda, int32_t Da, const int32_t *ids_a
                    const float *wpack, const int32_t *dims, const int32_t *acts, int32_t n_layers,
                    float *out, int64_t ldo, int64_t P, amar_stream_t stream);
 
+/* The same with an output index: row p of the chain is written to out row out_index[p] (int32 [P], a permutation of
+ * 0..P-1, or NULL = amar_chain_f32).  For a pair list the caller keeps in another order than the one the scores are
+ * wanted in — the pair stage of a predict pass (src/experiment.py:197, the test Sequence's order, datasets.py:199-203)
+ * bucketed ONCE per dataset by item range so that the workgroups of one XCD (pairs p with (p >> 7) % 8 equal, under
+ * round-robin dispatch) gather item-tower rows of one eighth of the items and find them in that XCD's L2: the list is
+ * constant across steps and epochs, the scores still land in the Sequence's order.
+ */
+int amar_chain_indexed_f32(const float *A, int64_t lda, int32_t Da, const int32_t *ids_a, int32_t base_a,
+                           const float *B, int64_t ldb, int32_t Db, const int32_t *ids_b, int32_t base_b,
+                           int32_t sum_inputs, int32_t in_act,
+                           const float *wpack, const int32_t *dims, const int32_t *acts, int32_t n_layers,
+                           float *out, int64_t ldo, const int32_t *out_index, int64_t P, amar_stream_t stream);
+
 /* Fused two-branch scorer for the hybrid head (src/models/hybrid.py:72-89) once the first Dense layers of
  * dense3a / dense3b have been folded into the per-entity tables:
  *     x_b  = in_act( A[b][ida_b(p)] + B[b][idb_b(p)] )            b = 0, 1;  [P, D]

@@ -785,3 +785,56 @@ def test_spmm_lds_tiled_heavy_rows(hip):
         A = sparse.coo_matrix((np.ones(rows.numel()), (rows.cpu().numpy(), cols.cpu().numpy())), shape=(n, n)).tocsr()
         want = scale.cpu().numpy()[:, None].astype(np.float64) * (xs_tab.astype(np.float64) + A @ xs_tab.astype(np.float64))
         assert rel_err(y.cpu().numpy(), want) < 1e-5             # rows of 20 000 fp32 terms
+
+
+@pytest.mark.parametrize('D,units,last_act', [(48, [48, 1], 'sigmoid'), (64, [64, 1], 'sigmoid'), (16, [24, 1], 'sigmoid'), (16, [24, 8], 'relu')])
+def test_chain_out_index(hip, D, units, last_act):
+    """amar_chain_indexed_f32: row p of the chain lands in out row out_index[p] — pipelined pair-stage kernel (square ReLU
+    stacks) and generic kernel (other shapes, vector outputs) — bit-identical to the direct call on the un-permuted list."""
+    rng = np.random.default_rng(D + len(units))
+    P = 5003
+    A = rng.standard_normal((200, D)).astype(np.float32)
+    B = rng.standard_normal((150, D)).astype(np.float32)
+    ia, ib = rng.integers(0, 200, P).astype(np.int32), rng.integers(0, 150, P).astype(np.int32)
+    dims = [D] + units
+    ks = [rng.uniform(-0.4, 0.4, (dims[k], dims[k + 1])).astype(np.float32) for k in range(len(units))]
+    bs = [rng.uniform(-0.2, 0.2, dims[k + 1]).astype(np.float32) for k in range(len(units))]
+    acts = ['relu'] * (len(units) - 1) + [last_act]
+    blob, _ = hip.chain_pack(ks, bs)
+    ref = torch.empty((P, units[-1]), device=DEV)
+    hip.chain(_t(A), _t(blob), dims, acts, ref, ids_a=_t(ia), B=_t(B), ids_b=_t(ib), sum_inputs=True, in_act='relu')
+    perm = rng.permutation(P)
+    out = torch.full((P, units[-1]), float('nan'), device=DEV)
+    hip.chain(_t(A), _t(blob), dims, acts, out, ids_a=_t(ia[perm]), B=_t(B), ids_b=_t(ib[perm]), sum_inputs=True, in_act='relu',
+              out_index=_t(perm.astype(np.int32)))
+    assert torch.equal(out, ref)
+
+
+def test_pair_plan_scores_equal_direct(hip):
+    """models.basic.PairPlan: the XCD-affine item-range order of a pair list + out_index gives the same bits, in the caller's
+    order, as scoring the list directly; positions p with (p >> 7) % 8 == x only see items of the x-th item range."""
+    from deep_cbrs_amar_renaissance_amd import engine
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    engine.set_seed(3)
+    nu, ni, P = 5000, 3000, 200_001
+    rs = basic.BasicRS([24, 24], [48, 48])
+    rs.build_head(24, 24)
+    helpers.randomize_biases(rs, seed=4)
+    emb = torch.randn((nu + ni, 24), device=DEV)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(5)
+    u = torch.randint(0, nu, (P,), device=DEV, generator=g, dtype=torch.int32)
+    i = (torch.randint(0, ni, (P,), device=DEV, generator=g, dtype=torch.int32) + nu).to(torch.int32)
+    tw = rs.towers(emb[:nu], emb[nu:])
+    ref = rs.score_towers(tw, u, i, 0, nu)
+    plan = basic.PairPlan(u, i)
+    assert sorted(plan.out_index.cpu().tolist()) == list(range(P))
+    assert torch.equal(plan.u_ids, u[plan.out_index.long()]) and torch.equal(plan.i_ids, i[plan.out_index.long()])
+    xcd = (torch.arange(P, device=DEV) // 128) % 8
+    hi = torch.stack([plan.i_ids[xcd == x].max() for x in range(8)])
+    lo = torch.stack([plan.i_ids[xcd == x].min() for x in range(8)])
+    assert bool((lo[1:] >= hi[:-1]).all())                              # item ranges of consecutive XCDs do not overlap (they may touch)
+    got = rs.score_towers(tw, u, i, 0, nu, pair_plan=plan)
+    assert torch.equal(got, ref)
+    with pytest.raises(ValueError):
+        rs.score_towers(tw, u.clone(), i, 0, nu, pair_plan=plan)

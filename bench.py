@@ -304,6 +304,11 @@ def main():
     if world != args.gpus:
         sys.exit("bench.py: --gpus {} but WORLD_SIZE={}: start it as `python bench.py --gpus N` (it launches its own ranks) or "
                  "under torchrun with --nproc-per-node equal to --gpus".format(args.gpus, world))
+    # stdout carries exactly ONE line, the JSON: whatever libraries print meanwhile (RCCL's version banner goes to stdout)
+    # is sent to stderr until then
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
     torch.cuda.set_device(local_rank)
     force_dist = bool(os.environ.get('AMAR_FORCE_DIST'))      # rehearse the RCCL path with a single rank
@@ -359,6 +364,10 @@ def main():
             spmm_events.append((e0, e1))
             kinds_seen.append(name)
         return wrapper
+    # Multi-rank runs (and AMAR_FORCE_DIST rehearsals) replay the partitioned step, collectives included, from a hipGraph
+    # (AMAR_STEP_GRAPH=0: eager).  No per-launch event can be recorded inside a capture, so for them the kernel-level objects
+    # below come from the eager warm-up steps; the single-GPU run times its launches inside the timed region.
+    graph_step = hasattr(runner, 'step_graphed') and os.environ.get('AMAR_STEP_GRAPH', '1') != '0'
     for name in spmm_names:                                   # whichever form the layer dispatches to
         setattr(capi, name, timed(name, raw_spmm[name]))
     pair_events, raw_chain = [], capi.chain
@@ -378,15 +387,25 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1)):
         runner.step()
     barrier()
-    spmm_events.clear()
-    pair_events.clear()
-    del kinds_seen[:]
+    step = runner.step
+    if graph_step:                                            # keep the warm-up launches' timings, then capture and replay
+        warm_spmm, warm_pair, warm_kinds = list(spmm_events), list(pair_events), list(kinds_seen)
+        for name in spmm_names:
+            setattr(capi, name, raw_spmm[name])
+        capi.chain = raw_chain
+        runner.step_graphed()
+        step = runner.step_graphed
+        barrier()
+    else:
+        spmm_events.clear()
+        pair_events.clear()
+        del kinds_seen[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        runner.step()
+        step()
     host_dt = time.perf_counter() - t0                        # time to ENQUEUE the steps (host-side launch cost)
     barrier()
     dt = time.perf_counter() - t0
@@ -398,6 +417,8 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 
+    if graph_step:
+        spmm_events, pair_events, kinds_seen = warm_spmm, warm_pair, warm_kinds
     spmm_ms = [e0.elapsed_time(e1) for e0, e1 in spmm_events]
     rows_local = runner.local_rows
     nnz_local = runner.local_nnz
@@ -422,12 +443,12 @@ def main():
             'config': {'workload': 'ml1m(s={}) user-item graph: N={} nodes, nnz(A_hat)={}, {} test pairs; '
                                    'econfigs/basic-gnn.yaml grid1 BasicGCN d=8 L=2 concat, dense [24,24], clf [48,48]; '
                                    'one propagation + per-entity towers + all pairs (shuffled order) per step (hoisted)'.format(args.scale, n_nodes, nnz, n_pairs),
-                       'scale': args.scale, 'parallelism': runner.describe()},
+                       'scale': args.scale, 'parallelism': runner.describe() + (' (step replayed from a hipGraph)' if graph_step else '')},
             'roofline': {'bound': 'hbm', 'kernel': kernel_names[kind] + ' (fused GCN layer: SpMM + bias + ReLU + next X.W)', 'achieved': achieved,
                          'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
                          'traffic': pmc['traffic_bytes_per_launch'] if pmc else None, 'traffic_source': traffic_source,
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': avg_ms,
-                         'launches_timed': len(spmm_ms),
+                         'launches_timed': len(spmm_ms), 'timed_in': 'warm-up steps (eager)' if graph_step else 'timed region',
                          'note': 'achieved = SURVEY 8(d) bytes (canonical CSR: 8 B per non-zero) / time, i.e. a CSR-equivalent effective '
                                  'bandwidth; the dispatched image streams {} B per non-zero'.format(image_entry_bytes)},
             # the limit that bound the XS form: one 128-B L2 line request per gathered row at 0.44 requests / clock / CU
@@ -436,7 +457,7 @@ def main():
                             'frac': (1e3 * nnz_local / L2_REQUESTS_PER_S) / avg_ms,
                             'note': 'frac > 1 means the dispatched kernel issues fewer than one L2 request per non-zero '
                                     '(the LDS-tiled form gathers in column order: neighbouring entries share L1 lines)'},
-            'propagation_ms': runner.last_propagation_ms(),
+            'propagation_ms': None if graph_step else runner.last_propagation_ms(),
             'host_enqueue_ms_per_step': 1e3 * host_dt / args.steps,
         }
         pair_ms = [e0.elapsed_time(e1) for e0, e1 in pair_events]
@@ -470,7 +491,9 @@ def main():
             out['hybrid_head'] = hybrid_head(dev, args.scale)
             out['ml1m_s1'], s1 = ml1m_true_size(dev)
             out['cpu_baseline'] = cpu_baseline(s1)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         torch.distributed.destroy_process_group()
 

@@ -301,11 +301,13 @@ class PartitionedGCNRunner:
                 ops.gcn_layer(self.csr.rowptr, self.csr.colidx, self.csr.vals, h, layer.bias, y_local[:rows])
             x_full = self._buffer(('x', k), (self.world * R, widths[k + 1]))
             self.dist.all_gather_into_tensor(x_full, y_local)
-            ops.copy_columns(x_full, e_all[:, offs[k + 1]:offs[k + 2]])
             if k + 1 < len(layers):
+                # the gathered block's copy into its slice of the final table rides on the next layer's X.W launch
                 h = self._buffer(('h', k + 1), (self.world * R, widths[k + 2]))
                 scale = pre_scale(widths[k + 2])
-                ops.rowwise_xw(x_full, layers[k + 1].kernel, h, row_scale=scale)
+                ops.rowwise_xw(x_full, layers[k + 1].kernel, h, copy_to=e_all[:, offs[k + 1]:offs[k + 2]], row_scale=scale)
+            else:
+                ops.copy_columns(x_full, e_all[:, offs[k + 1]:offs[k + 2]])
         return e_all
 
     def _buffer(self, key, shape, zero=False):
@@ -316,6 +318,23 @@ class PartitionedGCNRunner:
             dev = self.seq.embeddings.device
             buf = cache[key] = (torch.zeros if zero else torch.empty)(tuple(shape), dtype=torch.float32, device=dev)
         return buf
+
+    def step_graphed(self):
+        """The same step replayed from a hipGraph, collectives included (at 8 ranks a step is ~0.4 ms of device work behind
+        ~0.3 ms of host-side enqueueing: replayed, the host side is one call).  Captured on first use, after one eager step.
+        Rehearsed by the builder with one rank only (RCCL all-gather inside the capture: profiles/r2_partitioned_1rank.txt)."""
+        state = self.__dict__.setdefault('_graph_state', {})
+        if 'graph' not in state:
+            self.step()                                              # eager once: lazy image builds, persistent buffers
+            timing, self.timing = self.timing, False                 # no event records inside a capture
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                out = self.step()
+            self.timing = timing
+            state['graph'], state['out'] = g, out
+        state['graph'].replay()
+        return state['out']
 
     def step(self):
         if self.timing:

@@ -60,6 +60,14 @@ def geometry(F):
     return eps, rw, 31 - lbits
 
 
+def _run_starts(first, idx):
+    """Index of the first element of every element's run (`first` marks run starts of a sorted key sequence)."""
+    if idx.numel() == 0:
+        return idx
+    starts = torch.nonzero(first).view(-1)
+    return starts[torch.searchsorted(starts, idx, right=True) - 1]
+
+
 def supported(F, n_cols):
     return F in (4, 8, 16, 32) and n_cols <= (1 << geometry(F)[2])
 
@@ -200,7 +208,7 @@ class LdsTiled:
         first = torch.ones(m, dtype=torch.bool, device=dev)
         if m > 1:
             first[1:] = g4[1:] != g4[:-1]
-        run_start = torch.cummax(torch.where(first, idx, torch.zeros_like(idx)), 0).values
+        run_start = _run_starts(first, idx)
         rank = idx - run_start
         pair = (rank == 1) & (s4 == s4[run_start] + 1) & (s4 % spr != 0)
         flagged = (rank >= 1) & ~pair

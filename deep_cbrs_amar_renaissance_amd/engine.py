@@ -124,6 +124,27 @@ def ids_to_device(ids):
     return t.to(device=default_device(), dtype=torch.int32).contiguous()
 
 
+def capture_graph(fn):
+    """Capture `fn()`'s launches on the current device into a hipGraph; returns (graph, fn's result).
+
+    The cyclic garbage collector is held off for the duration of the capture: a collection that happens to free an OLDER
+    graph (a model that went out of use still holds its predict / training graphs) would call hipGraphExecDestroy in the
+    middle of the capture, which HIP rejects — the process aborts."""
+    import gc
+    torch.cuda.synchronize()
+    gc.collect()
+    graph = torch.cuda.CUDAGraph()
+    was_enabled = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph):
+            out = fn()
+    finally:
+        if was_enabled:
+            gc.enable()
+    return graph, out
+
+
 class Model(Layer):
     """Keras ``Model`` protocol used by the reference driver (experiment.py:155-198)."""
 
@@ -162,8 +183,8 @@ class Model(Layer):
         graph (default on; AMAR_PREDICT_GRAPH=0 or graph=False turns it off): models whose batches are id pairs only replay
         the whole call from a captured hipGraph — at ML-1M size the launches of a predict pass are mostly gaps (hoisted:
         8 launches, 0.13 ms eager vs 0.065 ms replayed; per-batch: ~650 launches).  The ids are uploaded once per Sequence,
-        the capture is redone when the Sequence, the mode or a weight tensor changes identity (in-place weight updates
-        replay fine), and replayed scores equal the eager ones bit for bit (tests/test_models_gpu.py).
+        the capture is redone when the batch sizes, the mode or any weight changes (a reshuffled Sequence of the same batch
+        sizes only refreshes the id buffers), and replayed scores equal the eager ones bit for bit (tests/test_models_gpu.py).
         """
         if graph is None:
             graph = os.environ.get('AMAR_PREDICT_GRAPH', '1') != '0'
@@ -180,21 +201,27 @@ class Model(Layer):
         return False
 
     def _sequence_ids(self, sequence):
-        """All (user, item) id pairs of a Sequence on the device, uploaded once (key: the Sequence object and its length)."""
+        """All (user, item) id pairs of a Sequence on the device.  The host ids are read on every call (a shuffling Sequence
+        changes its order between epochs, datasets.py:205-213) and compared with what the device buffers hold; a changed list of
+        the same batch sizes is copied INTO those buffers, so that a captured graph reading them stays valid."""
+        us, its, sizes = [], [], []
+        for b in range(len(sequence)):
+            (u, i), _ = sequence[b]
+            us.append(np.asarray(u))
+            its.append(np.asarray(i))
+            sizes.append(len(us[-1]))
+        u_host = np.concatenate(us).astype(np.int64) if us else np.zeros(0, np.int64)
+        i_host = np.concatenate(its).astype(np.int64) if its else np.zeros(0, np.int64)
         cache = self.__dict__.get('_seq_ids')
-        key = (id(sequence), len(sequence))
-        if cache is None or cache[0] != key:
-            us, its, sizes = [], [], []
-            for b in range(len(sequence)):
-                (u, i), _ = sequence[b]
-                us.append(np.asarray(u))
-                its.append(np.asarray(i))
-                sizes.append(len(us[-1]))
-            u_all = ids_to_device(np.concatenate(us)) if us else torch.empty(0, dtype=torch.int32, device=default_device())
-            i_all = ids_to_device(np.concatenate(its)) if its else torch.empty(0, dtype=torch.int32, device=default_device())
-            cache = (key, u_all, i_all, sizes, sequence)                 # the Sequence is kept alive: its id() is the key
+        if cache is not None and cache['sizes'] == sizes:
+            if not (np.array_equal(cache['u_host'], u_host) and np.array_equal(cache['i_host'], i_host)):
+                cache['u'].copy_(ids_to_device(u_host))
+                cache['i'].copy_(ids_to_device(i_host))
+                cache['u_host'], cache['i_host'] = u_host, i_host
+        else:
+            cache = {'sizes': sizes, 'u_host': u_host, 'i_host': i_host, 'u': ids_to_device(u_host), 'i': ids_to_device(i_host)}
             self.__dict__['_seq_ids'] = cache
-        return cache[1], cache[2], cache[3]
+        return cache['u'], cache['i'], sizes
 
     def _predict_graphed(self, sequence, hoist):
         u_all, i_all, sizes = self._sequence_ids(sequence)
@@ -214,14 +241,14 @@ class Model(Layer):
             finally:
                 self._hoist_end()
 
-        key = (hoist, u_all.data_ptr(), i_all.data_ptr(), tuple(sizes), tuple((id(p), p.data_ptr(), tuple(p.shape)) for p in self.parameters()))
+        # weight VALUES are part of the key: the Dense stacks' weights reach the kernels as blobs packed on the host (amar_chain_pack_f32),
+        # which a replay cannot redo — any weight update (fit() bumps the version counters) re-captures on the next predict()
+        key = (hoist, u_all.data_ptr(), i_all.data_ptr(), tuple(sizes), self.weights_version,
+               tuple(p.data_ptr() for p in self.parameters()))
         cached = self.__dict__.get('_predict_graph')
         if cached is None or cached[0] != key:
             run()                                                        # eager once: lazy builds (graph images, packed weights, kernel attributes)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = run()
+            g, out = capture_graph(run)
             cached = (key, g, out)
             self.__dict__['_predict_graph'] = cached
         cached[1].replay()

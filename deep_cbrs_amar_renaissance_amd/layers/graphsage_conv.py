@@ -61,7 +61,7 @@ class GraphSageConv(Layer):
         xa = torch.empty((n, f if fused_tail else 2 * f), dtype=torch.float32, device=x.device)
         agg = xa if fused_tail else xa[:, f:]
         if kind == 'xs':
-            capi.spmm_xs(a.xcd_sliced_mean(self.self_loops), x, agg, prescaled=True)
+            capi.spmm_xs(a.tiled_mean_image(f, self.self_loops), x, agg, prescaled=True)
         else:
             # widths the fused row kernel is not instantiated for (TwoStep / TwoWay 'concatenation' hand-over, 24 / 48):
             # neighbour sum as column chunks of the value-free SpMM, then (sum + own row) / count

@@ -257,7 +257,7 @@ class PartitionedGCNRunner:
                 y_local = torch.zeros((R, c), dtype=torch.float32, device=dev)
                 if self.kind == 'sage':
                     agg = torch.empty((rows, f), dtype=torch.float32, device=dev)
-                    ops.spmm_xs(self.csr.xcd_sliced_mean(layer.self_loops), x_full, agg, prescaled=True)
+                    ops.spmm_xs(self.csr.tiled_mean_image(f, layer.self_loops), x_full, agg, prescaled=True)
                     if ops.sage_tail_supported(f, c):
                         ops.sage_tail(x_full[lo:lo + rows], agg, layer.kernel, layer.bias, y_local[:rows])
                     else:
@@ -327,10 +327,8 @@ class PartitionedGCNRunner:
         if 'graph' not in state:
             self.step()                                              # eager once: lazy image builds, persistent buffers
             timing, self.timing = self.timing, False                 # no event records inside a capture
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                out = self.step()
+            from deep_cbrs_amar_renaissance_amd.engine import capture_graph
+            g, out = capture_graph(self.step)
             self.timing = timing
             state['graph'], state['out'] = g, out
         state['graph'].replay()

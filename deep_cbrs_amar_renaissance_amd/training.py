@@ -547,10 +547,12 @@ class Trainer:
                            'ub': torch.zeros((b, d), dtype=torch.float32, device=dev) if with_blocks else None,
                            'ib': torch.zeros((b, d), dtype=torch.float32, device=dev) if with_blocks else None}
             g['slot_host'] = torch.empty(64 * len(self.params) + 64, dtype=torch.uint8).pin_memory()   # >= sizeof(amar_adam_slot) per parameter
-            torch.cuda.synchronize()
-            g['graph'] = torch.cuda.CUDAGraph()
-            with torch.no_grad(), torch.cuda.graph(g['graph']):
-                self._graph_body()
+            from deep_cbrs_amar_renaissance_amd.engine import capture_graph
+
+            def body():
+                with torch.no_grad():
+                    self._graph_body()
+            g['graph'], _ = capture_graph(body)
             self._graphs[key] = g
         self._g = g
         g['u'].copy_(ids_to_device(u_ids))

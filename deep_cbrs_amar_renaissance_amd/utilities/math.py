@@ -41,6 +41,7 @@ def gcn_filter(a, symmetric=True):
         m = sparse.csr_matrix(a, copy=True)
         m.sum_duplicates()
         m = (m + sparse.identity(m.shape[0], dtype=m.dtype, format='csr')).tocsr()
+        m.sort_indices()
         with np.errstate(divide='ignore'):
             dinv = np.power(np.asarray(m.sum(1)).ravel(), -0.5 if symmetric else -1.0).astype(m.dtype)
         dinv[np.isinf(dinv)] = 0.0
@@ -48,8 +49,11 @@ def gcn_filter(a, symmetric=True):
         data = (dinv[coo.row] * coo.data).astype(m.dtype)          # D . A first,
         if symmetric:
             data = (data * dinv[coo.col]).astype(m.dtype)          # ... then (D . A) . D: two fp32 roundings
-        out = sparse.csr_matrix((data, (coo.row, coo.col)), shape=m.shape)
-        out.sort_indices()
+        out = sparse.csr_matrix((data, m.indices.copy(), m.indptr.copy()), shape=m.shape)   # m's structure: sorted, duplicate-free
+        # the factors, for the value-free device images (A_hat = S (A + I) S with small integer entries): kept on the result so
+        # that DeviceCSR.from_scipy can hand them to the XS / LT image builders, as gcn_filter_device does
+        if symmetric and m.dtype == np.float32 and m.nnz and float(np.abs(m.data - np.rint(m.data)).max()) == 0.0 and m.data.max() < (1 << 20):
+            out.amar_factors = (dinv.astype(np.float32), np.rint(m.data).astype(np.int32))
         return out
     m = np.array(a, copy=True)
     m[np.diag_indices_from(m)] += 1
@@ -92,8 +96,14 @@ class DeviceCSR:
         rowptr = np.zeros(coo.shape[0] + 1, dtype=np.int64)
         np.cumsum(np.bincount(row, minlength=coo.shape[0]), out=rowptr[1:])
         vals = torch.from_numpy(data[order].astype(np.float32)).to(device) if with_values else None
-        return cls(torch.from_numpy(rowptr.astype(np.int32)).to(device),
-                   torch.from_numpy(col.astype(np.int32)).to(device), vals, coo.shape)
+        out = cls(torch.from_numpy(rowptr.astype(np.int32)).to(device),
+                  torch.from_numpy(col.astype(np.int32)).to(device), vals, coo.shape)
+        factors = getattr(x, 'amar_factors', None)                  # set by gcn_filter: A_hat = S C S
+        if factors is not None and with_values and not drop_diagonal and len(factors[1]) == len(order):
+            out.gcn_filtered = True
+            out.dinv = torch.from_numpy(factors[0]).to(device)
+            out.mult = torch.from_numpy(factors[1][order]).to(device)
+        return out
 
     def to_scipy(self):
         rowptr = self.rowptr.cpu().numpy()
@@ -221,6 +231,10 @@ def spmm_kind(a, F):
     # (its scan is amortised over only 64/(F/4) lanes' worth of entries)
     table_bytes = a.shape[1] * F * 4
     big = table_bytes >= ((8 << 20) if F <= 8 else (16 << 20))
+    if a.shape[0] == a.shape[1] and table_bytes >= (4 << 20) and lt_eligible(a, F):
+        # the LDS-tiled image (DeviceCSR.tiled_image) already wins once the table leaves one XCD's L2: ml1m(s=16), F = 8:
+        # 0.075 ms against 0.093 (row streaming) / 0.110 (XS); s=64: F = 16 0.35 / 0.78 / 0.54, F = 32 0.60 / 0.91 / 1.12
+        return 'xs'
     return 'xs' if (a.shape[0] == a.shape[1] and F in (4, 8, 16) and big) else 'csr'
 
 
@@ -421,7 +435,36 @@ def lt_eligible(a, F):
         return False
     if forced == '1':
         return True
-    return F in (8, 16) and a.nnz >= LT_MIN_DENSITY * lds_tiled.N_CU * a.shape[1]
+    return F in (8, 16, 32) and a.nnz >= LT_MIN_DENSITY * lds_tiled.N_CU * a.shape[1]
+
+
+def _csr_tiled_mean_image(self, F, self_loops=True):
+    """GraphSAGE's mean aggregate of an edge-list CSR (vals None, duplicates kept) on whichever tiled image pays: the
+    LDS-tiled one (value-free entries, diag = 1 for the added self loop, row_scale = 1 / count, X gathered as is: call
+    capi.spmm_xs with prescaled=True) under the same density rule as lt_eligible, else xcd_sliced_mean."""
+    from deep_cbrs_amar_renaissance_amd.utilities import lds_tiled
+    forced = os.environ.get('AMAR_SPMM_LT')
+    ok = forced != '0' and self.vals is None and lds_tiled.supported(F, self.shape[1]) and \
+        (forced == '1' or (F in (8, 16, 32) and self.nnz >= LT_MIN_DENSITY * lds_tiled.N_CU * self.shape[1]))
+    if not ok:
+        return self.xcd_sliced_mean(self_loops)
+    cache = self.__dict__.setdefault('_lt_mean_cache', {})
+    key = (F, bool(self_loops))
+    if key not in cache:
+        rows, cols, diag, diag_offset = _unit_entries(self, False)
+        deg = (self.rowptr[1:] - self.rowptr[:-1]).to(torch.float32)
+        if self_loops:
+            diag = diag + 1.0
+            inv = 1.0 / (deg + 1.0)
+        else:
+            inv = torch.where(deg > 0, 1.0 / deg.clamp(min=1.0), torch.zeros_like(deg))
+        breaks = tuple(getattr(self, 'row_breaks', ())) if not diag_offset else ()
+        cache[key] = lds_tiled.LdsTiled.build(rows, cols, self.shape[0], self.shape[1], F, diag, inv.contiguous(), None, diag_offset,
+                                              row_breaks=breaks)
+    return cache[key]
+
+
+DeviceCSR.tiled_mean_image = _csr_tiled_mean_image
 
 
 def _csr_tiled_image(self, F):

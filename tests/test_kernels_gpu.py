@@ -838,3 +838,61 @@ def test_pair_plan_scores_equal_direct(hip):
     assert torch.equal(got, ref)
     with pytest.raises(ValueError):
         rs.score_towers(tw, u.clone(), i, 0, nu, pair_plan=plan)
+
+
+@pytest.mark.parametrize('F', [8, 16])
+@pytest.mark.parametrize('self_loops', [True, False])
+def test_sage_mean_on_lds_tiled(hip, F, self_loops, monkeypatch):
+    """GraphSAGE's mean aggregate on the LDS-tiled image (edge-list CSR with duplicate edges, optional self loop,
+    rows without edges) against the row kernel's aggregate, and the whole layer through it against the fused row kernel."""
+    from deep_cbrs_amar_renaissance_amd.layers.graphsage_conv import GraphSageConv
+    from deep_cbrs_amar_renaissance_amd.utilities.lds_tiled import LdsTiled
+    g = helpers.tiny_graph(n_users=700, n_items=400, n_ratings=30000, seed=F, n_props=120, n_links=900)
+    e = _dev_csr(g['adj'], with_values=False, drop_diagonal=True)
+    n = e.shape[0]
+    rng = np.random.default_rng(3)
+    x = _t(rng.standard_normal((n, F)).astype(np.float32))
+    monkeypatch.setenv('AMAR_SPMM_LT', '1')
+    img = e.tiled_mean_image(F, self_loops)
+    assert isinstance(img, LdsTiled)
+    agg = torch.full((n, F), float('nan'), device=DEV)
+    hip.spmm_xs(img, x, agg, prescaled=True)
+    ref = torch.empty((n, F), device=DEV)
+    hip.spmm_csr(e.rowptr, e.colidx, None, x, ref)
+    deg = (e.rowptr[1:] - e.rowptr[:-1]).float()
+    want = (ref + x) / (deg + 1)[:, None] if self_loops else torch.where(deg[:, None] > 0, ref / deg.clamp(min=1)[:, None], torch.zeros_like(ref))
+    assert float((agg - want).abs().max()) < 1e-5
+    layer = GraphSageConv(8, activation='relu', self_loops=self_loops)
+    layer.build([(n, F), None])
+    helpers.randomize_biases(layer, seed=2)
+    monkeypatch.setenv('AMAR_SPMM_KIND', 'csr')
+    y_row = layer([x, e])
+    monkeypatch.setenv('AMAR_SPMM_KIND', 'xs')
+    y_lt = layer([x, e])
+    assert float((y_row - y_lt).abs().max()) < 2e-5
+
+
+def test_host_gcn_filter_route_keeps_the_factors(hip, monkeypatch):
+    """utilities.math.gcn_filter (host scipy, the route `experiment.py` takes from files) keeps A_hat's factors on its result,
+    DeviceCSR.from_scipy hands them on: the same value-free LT / XS images as from gcn_filter_device, bit-equal values."""
+    from deep_cbrs_amar_renaissance_amd.utilities.math import DeviceCSR, gcn_filter
+    from deep_cbrs_amar_renaissance_amd.utilities.lds_tiled import LdsTiled
+    g = helpers.tiny_graph(n_users=800, n_items=500, n_ratings=30000, seed=21, n_props=100, n_links=900)
+    a_hat = gcn_filter(g['adj'])
+    a = DeviceCSR.from_scipy(a_hat)
+    assert a.dinv is not None and a.mult is not None and a.gcn_filtered and int(a.mult.max()) > 1
+    deg = (a.rowptr[1:] - a.rowptr[:-1]).long()
+    r = torch.repeat_interleave(torch.arange(a.shape[0], device=DEV), deg)
+    assert torch.equal(a.vals, (a.dinv[r] * a.mult.float()) * a.dinv[a.colidx.long()])
+    monkeypatch.setenv('AMAR_SPMM_LT', '1')
+    img = a.tiled_image(8)
+    assert isinstance(img, LdsTiled)
+    x = np.random.default_rng(0).standard_normal((a.shape[0], 8)).astype(np.float32)
+    y = torch.empty((a.shape[0], 8), device=DEV)
+    hip.spmm_xs(img, _t(x), y)
+    assert rel_err(y.cpu().numpy(), a_hat.astype(np.float64) @ x.astype(np.float64)) < 2e-6
+    monkeypatch.setenv('AMAR_SPMM_LT', '0')
+    xs = a.xcd_sliced()
+    assert xs.vals is None and xs.row_scale is not None              # value-free XS image too
+    hip.spmm_xs(xs, _t(x), y)
+    assert rel_err(y.cpu().numpy(), a_hat.astype(np.float64) @ x.astype(np.float64)) < 2e-6

@@ -331,6 +331,8 @@ def test_partitioned_runner_with_real_kernels(hip, world, case, monkeypatch):
     e_want = model.gnn(None).cpu().numpy()
     if '-xs' in case:
         monkeypatch.setenv('AMAR_SPMM_KIND', 'xs')             # the ranks' row blocks on the XCD-sliced kernels
+        if not case.endswith('-valuefree'):
+            monkeypatch.setenv('AMAR_XS_VALUES', '1')          # ... in their valued form (the host filter keeps the factors too now)
     fake = _LockstepGather(world)
     results, errors = [None] * world, []
 
@@ -459,7 +461,8 @@ def test_hybrid_hoisted_fused_head(hip, ml1m_s1, feature_based):
 @pytest.mark.parametrize('name', ['BasicGCN', 'BasicLightGCN', 'BasicGraphSage', 'BasicGAT'])
 def test_predict_replayed_from_graph_equals_eager(hip, ml1m_s1, name):
     """Model.predict() replays the pass from a hipGraph it captures itself (default): same bits as the eager pass, hoisted and
-    per-batch; after an in-place weight update the SAME graph replays with the new weights; a new Sequence re-captures."""
+    per-batch; a weight update re-captures (the Dense weights are packed on the host); a reshuffled Sequence only refreshes the
+    id buffers; other batch sizes re-capture."""
     from deep_cbrs_amar_renaissance_amd import engine
     from deep_cbrs_amar_renaissance_amd.models import basic
     from deep_cbrs_amar_renaissance_amd.data.datasets import UserItemGraph
@@ -474,10 +477,21 @@ def test_predict_replayed_from_graph_equals_eager(hip, ml1m_s1, name):
         assert eager.shape == (9000, 1) and np.array_equal(eager, replayed) and np.array_equal(eager, again)
     graph_obj = model.__dict__['_predict_graph'][1]
     with torch.no_grad():
-        model.gnn.gnn_layers.embeddings.mul_(1.5)                   # in place: the captured graph stays valid
+        model.gnn.gnn_layers.embeddings.mul_(1.5)
+        for name, prm in model.rs.named_parameters():
+            if name.endswith('kernel'):
+                prm.mul_(0.9)                                       # Dense weights: their packed blobs must be rebuilt
     eager = model.predict(seq, hoist=False, graph=False)
     replayed = model.predict(seq, hoist=False)
-    assert model.__dict__['_predict_graph'][1] is graph_obj and np.array_equal(eager, replayed)
+    assert model.__dict__['_predict_graph'][1] is not graph_obj and np.array_equal(eager, replayed)
+    graph_obj = model.__dict__['_predict_graph'][1]
+    # a Sequence that reshuffles between epochs: same batch sizes, other order -> the ids are refreshed in place, same graph
+    shuffled = UserItemGraph(ml1m_s1['test'][:9000], ml1m_s1['users'], ml1m_s1['items'], ml1m_s1['adj_ui'], batch_size=2048, shuffle=True)
+    first = model.predict(shuffled, hoist=False)
+    assert model.__dict__['_predict_graph'][1] is graph_obj and np.array_equal(first, model.predict(shuffled, hoist=False, graph=False))
+    shuffled.on_epoch_end()
+    assert np.array_equal(model.predict(shuffled, hoist=False), model.predict(shuffled, hoist=False, graph=False))
+    assert model.__dict__['_predict_graph'][1] is graph_obj
     seq2 = UserItemGraph(ml1m_s1['test'][9000:12500], ml1m_s1['users'], ml1m_s1['items'], ml1m_s1['adj_ui'], batch_size=1024, shuffle=False)
     assert np.array_equal(model.predict(seq2), model.predict(seq2, graph=False))
     assert model.__dict__['_predict_graph'][1] is not graph_obj

@@ -46,7 +46,9 @@ def main():
     y_xs, y_lt = torch.empty((n, F), device=dev), torch.empty((n, F), device=dev)
     capi.spmm_xs(xs, xs_tab, y_xs, prescaled=True)
     t_xs = timeit(lambda: capi.spmm_xs(xs, xs_tab, y_xs, prescaled=True))
-    print('scale %d F %d: N %d, nnz %d; XS %.4f ms' % (scale, F, n, a.nnz, t_xs), flush=True)
+    y_csr = torch.empty_like(y_xs)
+    t_csr = timeit(lambda: capi.spmm_csr(a.rowptr, a.colidx, a.vals, x, y_csr))
+    print('scale %d F %d: N %d, nnz %d; XS %.4f ms; CSR row-stream kernel %.4f ms' % (scale, F, n, a.nnz, t_xs, t_csr), flush=True)
     rows, cols, diag, off = _unit_entries(a, True)
     col_scale = a.dinv.to(torch.float32).contiguous()
     for w in windows:

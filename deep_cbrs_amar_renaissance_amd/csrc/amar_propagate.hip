@@ -602,6 +602,7 @@ struct LtArgs {
     const int32_t *words; const int32_t *stream_start; const int32_t *wsteps; const int32_t *tile_row0; const int32_t *n_win;
     const int32_t *vstart; const int32_t *vcount;
     int maxwin1; int cbits;
+    int pace_mask;                               // the waves meet at a barrier after every window w with (w & pace_mask) == pace_mask
     const float *X; int64_t ldx; const float *Xself; const float *diag; const float *row_scale;
     long long *stamps;                           // development: cycles per tile (tools/exp_lt.py), or NULL
     SpmmArgs e;
@@ -617,8 +618,8 @@ __device__ __forceinline__ int lt_lds_row(int v) {                    // virtual
 }
 
 // ABL (development, tools/exp_lt.py): 1 = no atomic path, 2 = no LDS read-add-write, 4 = no gathers (timing only: wrong sums)
-// PACE: 0 = waves run free, 1 = one s_barrier per window, 2 = arrival counters in LDS: a wave leaves window w once every
-// wave has left window w - 1 (one window of slack: measured slower than the barrier), 3 = s_barrier every other window
+// PACE: 0 = waves run free, 1 = one s_barrier per (pace_mask + 1) windows, 2 = arrival counters in LDS: a wave leaves window w
+// once every wave has left window w - 1 (one window of slack: measured slower than the barrier)
 // OFF32: 0 = 64-bit gather addresses, 1 = 32-bit byte offsets, 2 = 32-bit offsets into a dense table (ldx == F: a shift, no multiply)
 template <int F, int OFF32, bool FUSE_NEXT, int U, int PACE, int ABL = 0>
 __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtArgs a) {
@@ -713,7 +714,7 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtA
     int wend = nwin > 0 ? window_end(0) : 0x7fffffff;
     auto pace = [&](int done) {                                       // `done` steps finished: leave every window that ends here
         while (wend <= done) {
-            if (PACE == 1 || (PACE == 3 && (win & 1))) __builtin_amdgcn_s_barrier();
+            if (PACE == 1 && (win & a.pace_mask) == a.pace_mask) __builtin_amdgcn_s_barrier();
             if (PACE == 2) {
                 if (lane == 0) atomicAdd(arrived + (win & 7), 1u);
                 if (win > 0) {
@@ -801,13 +802,18 @@ int launch_spmm_lt(const LtArgs &a, int n_tiles, int off32, bool fuse, int varia
             case 2:  AMAR_LT_LAUNCH(2, false, 4, 0, 0); break;      // unpaced
             case 3:  AMAR_LT_LAUNCH(2, false, 8, 1, 0); break;      // 7 steps ahead
             case 5:  AMAR_LT_LAUNCH(2, false, 4, 2, 0); break;      // counter pacing, one window of slack
-            case 7:  AMAR_LT_LAUNCH(2, false, 4, 3, 0); break;      // barrier every other window
             case 8:  AMAR_LT_LAUNCH(1, false, 4, 1, 0); break;      // multiply-add addressing
-            case 11: AMAR_LT_LAUNCH(2, false, 4, 0, 1); break;      // ablations (wrong sums): no atomics
-            case 12: AMAR_LT_LAUNCH(2, false, 4, 0, 3); break;      //   ... no LDS update
-            case 13: AMAR_LT_LAUNCH(2, false, 4, 0, 5); break;      //   ... no gathers
-            case 14: AMAR_LT_LAUNCH(2, false, 4, 0, 7); break;
-            case 16: AMAR_LT_LAUNCH(2, false, 4, 1, 1); break;
+            // ablations (wrong sums; ABL bits: 1 no atomic path, 2 no LDS update, 4 no gathers): 20 + ABL paced, 30 + ABL unpaced
+            case 21: AMAR_LT_LAUNCH(2, false, 4, 1, 1); break;
+            case 22: AMAR_LT_LAUNCH(2, false, 4, 1, 2); break;
+            case 23: AMAR_LT_LAUNCH(2, false, 4, 1, 3); break;
+            case 24: AMAR_LT_LAUNCH(2, false, 4, 1, 4); break;
+            case 25: AMAR_LT_LAUNCH(2, false, 4, 1, 5); break;
+            case 27: AMAR_LT_LAUNCH(2, false, 4, 1, 7); break;
+            case 31: AMAR_LT_LAUNCH(2, false, 4, 0, 1); break;
+            case 33: AMAR_LT_LAUNCH(2, false, 4, 0, 3); break;
+            case 35: AMAR_LT_LAUNCH(2, false, 4, 0, 5); break;
+            case 37: AMAR_LT_LAUNCH(2, false, 4, 0, 7); break;
             default: return AMAR_EINVAL;
             }
             return amar_check_launch();
@@ -1470,13 +1476,13 @@ int amar_spmm_xs_f32(const float *diag, const int32_t *rowptr, const int32_t *co
 }
 
 int amar_spmm_lt_f32(const int32_t *words, const int32_t *stream_start, const int32_t *wsteps, const int32_t *tile_row0,
-                     const int32_t *n_win, const int32_t *vstart, const int32_t *vcount, int32_t n_tiles, int32_t maxwin1,
+                     const int32_t *n_win, const int32_t *vstart, const int32_t *vcount, int32_t n_tiles, int32_t maxwin1, int32_t pace_every,
                      const float *diag, const float *row_scale,
                      const float *X, int64_t ldx, int32_t n_cols, const float *Xself,
                      float *Y, int64_t ldy, int32_t n_rows, int32_t F, uint32_t flags, const float *bias,
                      const float *acc_in, int64_t ld_acc_in, float *acc_out, int64_t ld_acc_out, float acc_div,
                      const float *Wnext, int32_t Cn, float *Hnext, int64_t ldhn, amar_stream_t stream) {
-    if (n_rows < 0 || n_cols < 0 || n_tiles < 0 || maxwin1 < 1) return AMAR_EINVAL;
+    if (n_rows < 0 || n_cols < 0 || n_tiles < 0 || maxwin1 < 1 || pace_every < 1 || (pace_every & (pace_every - 1))) return AMAR_EINVAL;
     if (n_rows == 0 || n_tiles == 0) return n_rows == 0 ? AMAR_OK : AMAR_EINVAL;
     if (!words || !stream_start || !wsteps || !tile_row0 || !n_win || !vstart || !vcount || !diag || !row_scale || !X) return AMAR_EINVAL;
     if (F != 4 && F != 8 && F != 16 && F != 32) return AMAR_EUNSUPPORTED;
@@ -1501,7 +1507,7 @@ int amar_spmm_lt_f32(const int32_t *words, const int32_t *stream_start, const in
     LtArgs a{};
     a.words = words; a.stream_start = stream_start; a.wsteps = wsteps; a.tile_row0 = tile_row0; a.n_win = n_win;
     a.vstart = vstart; a.vcount = vcount;
-    a.maxwin1 = maxwin1; a.cbits = cbits;
+    a.maxwin1 = maxwin1; a.cbits = cbits; a.pace_mask = pace_every - 1;
     a.X = X; a.ldx = ldx; a.Xself = Xself; a.diag = diag; a.row_scale = row_scale;
     a.e.next_scale = (flags & AMAR_SPMM_SCALE_NEXT) ? row_scale : nullptr;
     a.e.X = X; a.e.ldx = ldx; a.e.Y = Y; a.e.ldy = ldy;

@@ -123,12 +123,13 @@ int amar_spmm_xs_f32(const float *diag, const int32_t *rowptr, const int32_t *co
  *                          (same 16-lane DPP row, flag 0) is folded into its neighbour in registers; any other repeat
  *                          carries flag = 1 and is added with an LDS atomic after the step.
  *   stream_start[n_tiles*W], wsteps[n_tiles][W][maxwin1], n_win[n_tiles]: see utilities/lds_tiled.py
+ *   pace_every             the tile's waves meet at a barrier after every pace_every-th window (a power of two >= 1)
  * X (n_cols rows) must hold S.X; Y[i] = epilogue( row_scale[i] . (diag[i] . Xself[i] + sum of the row's entries) ),
  * flags / bias / acc_* / Wnext / AMAR_SPMM_SCALE_NEXT as amar_spmm_xs_f32.  The summation order of a row is fixed by
  * the image, so results are bitwise reproducible run to run (they differ from the XS / CSR forms in the last bits).
  */
 int amar_spmm_lt_f32(const int32_t *words, const int32_t *stream_start, const int32_t *wsteps, const int32_t *tile_row0,
-                     const int32_t *n_win, const int32_t *vstart, const int32_t *vcount, int32_t n_tiles, int32_t maxwin1,
+                     const int32_t *n_win, const int32_t *vstart, const int32_t *vcount, int32_t n_tiles, int32_t maxwin1, int32_t pace_every,
                      const float *diag, const float *row_scale,
                      const float *X, int64_t ldx, int32_t n_cols, const float *Xself,
                      float *Y, int64_t ldy, int32_t n_rows, int32_t F, uint32_t flags, const float *bias,

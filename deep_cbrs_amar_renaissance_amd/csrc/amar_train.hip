@@ -3,7 +3,9 @@
 // config.yaml:50-58 and applied by experiment.py:155-188; reverse-mode derivatives of the Dense /
 // GCNConv / LightGCNConv / embedding_lookup operations of src/models/{basic,gnn}.py.
 // All element-wise or small-reduction work: HBM-bound, one float (or a few) per lane, fixed
-// summation orders (the weight gradient is reduced in two stages, never with float atomics).
+// summation orders (the weight gradient is reduced in two stages, never with float atomics).  The one exception is the
+// embedding-row gradient (scatter_add_rows_kernel): rows that occur several times in a batch are added with global float
+// atomics, so that gradient's last bits depend on the order of arrival; ids are range-checked on the host (engine.ids_to_device).
 #include "amar_common.h"
 
 namespace {

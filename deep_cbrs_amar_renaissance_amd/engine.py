@@ -113,14 +113,21 @@ def to_device_tensor(x, dtype=torch.float32):
     return t.to(device=default_device(), dtype=dtype).contiguous()
 
 
-def ids_to_device(ids):
-    """Host int64 ids (numpy default, datasets.py:203) -> device int32."""
+def ids_to_device(ids, n_rows=None):
+    """Host int64 ids (numpy default, datasets.py:203) -> device int32.  Host arrays are range-checked here — against the
+    table height `n_rows` where the caller knows it: the kernels gather / scatter rows by id without a bounds check, so an
+    id past the table would be an out-of-bounds device access where TensorFlow's embedding_lookup raises.  Device tensors are
+    taken as they are (checking them would force a synchronisation); producers of device ids own their range."""
     if isinstance(ids, torch.Tensor):
         t = ids
     else:
         t = torch.from_numpy(np.ascontiguousarray(ids))
-    if not t.is_cuda and t.numel() and (int(t.max()) >= 2 ** 31 or int(t.min()) < 0):    # device ids: no sync here
-        raise ValueError("ids must be in [0, 2^31)")
+    if not t.is_cuda and t.numel():
+        lo, hi = int(t.min()), int(t.max())
+        if lo < 0 or hi >= 2 ** 31:
+            raise ValueError("ids must be in [0, 2^31)")
+        if n_rows is not None and hi >= n_rows:
+            raise IndexError("id {} is out of range for a table of {} rows".format(hi, n_rows))
     return t.to(device=default_device(), dtype=torch.int32).contiguous()
 
 

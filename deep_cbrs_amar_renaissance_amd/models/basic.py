@@ -198,7 +198,8 @@ class BasicGNN(Model, abc.ABC):
 
         Faithful mode gathers per pair.  Hoisted mode (predict) computes the two towers once per entity —
         same kernel, same per-row arithmetic, so both modes return identical bits."""
-        u, i = ids_to_device(inputs[0]), ids_to_device(inputs[1])
+        n_nodes = embeddings.shape[0]
+        u, i = ids_to_device(inputs[0], n_nodes), ids_to_device(inputs[1], n_nodes)
         if not self.gnn.hoist:
             return self.rs([embeddings, embeddings], u_ids=u, i_ids=i)
         key = (self.weights_version, embeddings.data_ptr())

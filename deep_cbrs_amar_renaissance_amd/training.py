@@ -492,7 +492,8 @@ class Trainer:
     def loss_and_grads(self, u_ids, i_ids, y, bert=None):
         """Forward + reverse pass of one batch. Returns (data loss + regularisation loss, {param: gradient}).
         `bert` = (user block, item block) for the hybrid head (None: rows of the resident table)."""
-        u, i = ids_to_device(u_ids), ids_to_device(i_ids)
+        n_nodes = self.seq.adj_matrix.shape[0] if getattr(self, 'seq', None) is not None else None
+        u, i = ids_to_device(u_ids, n_nodes), ids_to_device(i_ids, n_nodes)
         yv = to_device_tensor(np.asarray(y, dtype=np.float32) if not isinstance(y, torch.Tensor) else y)
         with torch.no_grad():
             terms, grads = self._forward_backward(u, i, yv, bert)
@@ -555,8 +556,9 @@ class Trainer:
             g['graph'], _ = capture_graph(body)
             self._graphs[key] = g
         self._g = g
-        g['u'].copy_(ids_to_device(u_ids))
-        g['i'].copy_(ids_to_device(i_ids))
+        n_nodes = self.seq.adj_matrix.shape[0] if getattr(self, 'seq', None) is not None else None
+        g['u'].copy_(ids_to_device(u_ids, n_nodes))
+        g['i'].copy_(ids_to_device(i_ids, n_nodes))
         g['y'].copy_(to_device_tensor(np.asarray(y, dtype=np.float32) if not isinstance(y, torch.Tensor) else y))
         if with_blocks:
             g['ub'].copy_(to_device_tensor(bert[0]))

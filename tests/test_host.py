@@ -214,3 +214,13 @@ def test_streaming_embedding_readers(tmp_path):
     (tmp_path / 'empty.json').write_text('[]')
     e_ids, e_tab = jsonstream.stream_bert_records(str(tmp_path / 'empty.json'), 'embedding')
     assert e_ids.size == 0 and e_tab.size == 0
+
+
+def test_host_ids_are_range_checked():
+    """engine.ids_to_device refuses ids past the table (TensorFlow's embedding_lookup would raise; the kernels do not check)."""
+    from deep_cbrs_amar_renaissance_amd import engine
+    ids = np.array([0, 5, 9])
+    with pytest.raises(IndexError):
+        engine.ids_to_device(ids, n_rows=9)
+    with pytest.raises(ValueError):
+        engine.ids_to_device(np.array([-1, 2]), n_rows=9)

@@ -996,8 +996,10 @@ __device__ __forceinline__ void soft_merge(Soft4 &a, float m2, float l2, const f
     a.m = M;
 }
 
-template <int CTRL>
-__device__ __forceinline__ void soft_scan_level(Soft4 &st, int key) {
+// DIST / EPS: with fewer than 16 entries per step several feature quads share a 16-lane DPP row, so a lane only merges with
+// the lane DIST to its left when that lane belongs to the same quad (s >= DIST); with EPS = 16 a DPP row is one quad.
+template <int CTRL, int DIST, int EPS>
+__device__ __forceinline__ void soft_scan_level(Soft4 &st, int key, int s) {
     const int kprev = __builtin_amdgcn_update_dpp(-1, key, CTRL, 0xF, 0xF, false);
     const float mp = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, st.m), CTRL, 0xF, 0xF, false));
     const float lp = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, st.l), CTRL, 0xF, 0xF, false));
@@ -1006,13 +1008,15 @@ __device__ __forceinline__ void soft_scan_level(Soft4 &st, int key) {
     op.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, st.o.y), CTRL, 0xF, 0xF, false));
     op.z = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, st.o.z), CTRL, 0xF, 0xF, false));
     op.w = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, st.o.w), CTRL, 0xF, 0xF, false));
-    if (kprev == key) soft_merge(st, mp, lp, op);          // lanes without a source got key -1: no merge
+    if (kprev == key && (EPS >= 16 || s >= DIST)) soft_merge(st, mp, lp, op);          // lanes without a source got key -1: no merge
 }
 
 template <int C, bool OFF32>
 __global__ __launch_bounds__(XS_WAVES * AMAR_WAVE) void gat_xs_partial_kernel(const GatXsArgs a) {
-    constexpr int G = 2 * C, EPS = 16, EPL = 8, SUPER = EPS * EPL, QH = C / 4;   // QH quads carry h, quad QH carries s_neigh; lanes of quad 3 idle
-    static_assert(C == 8 && EPS == 16, "the cross-lane scan below covers exactly one 16-lane DPP row per feature quad (C = 8)");
+    // a packed row is G = 2C floats: QH = C/4 quads of h, then one quad whose first float is s_neigh, the rest padding; an
+    // entry takes 2 QH lanes (quads above QH idle), so a step covers EPS = 32 / QH entries: 16 (C = 8), 8 (C = 16), 4 (C = 32)
+    constexpr int G = 2 * C, QH = C / 4, EPS = AMAR_WAVE / (2 * QH), EPL = 8, SUPER = EPS * EPL;
+    static_assert(C == 8 || C == 16 || C == 32, "EPS must stay inside one 16-lane DPP row");
     constexpr int PAD_KEY = AMAR_WAVE;
     __shared__ float lds_o[XS_WAVES][C * AMAR_WAVE];
     __shared__ float lds_ml[XS_WAVES][3 * AMAR_WAVE];              // m, l, and the tile's s_self
@@ -1089,9 +1093,10 @@ __global__ __launch_bounds__(XS_WAVES * AMAR_WAVE) void gat_xs_partial_kernel(co
                 soft_merge(st, e, 1.f, x[j]);
             }
         }
-        // one segmented scan over the 16 lanes of the quad's DPP row (row_shr:1, 2, 4, 8), keyed by the lane's last key
-        soft_scan_level<0x111>(st, kcur); soft_scan_level<0x112>(st, kcur);
-        soft_scan_level<0x114>(st, kcur); soft_scan_level<0x118>(st, kcur);
+        // one segmented scan over the EPS lanes of the quad inside its DPP row (row_shr:1, 2, 4, 8), keyed by the lane's last key
+        soft_scan_level<0x111, 1, EPS>(st, kcur, s); soft_scan_level<0x112, 2, EPS>(st, kcur, s);
+        if (EPS >= 8) soft_scan_level<0x114, 4, EPS>(st, kcur, s);
+        if (EPS >= 16) soft_scan_level<0x118, 8, EPS>(st, kcur, s);
         const int knext = __builtin_amdgcn_mov_dpp(kcur, 0x130, 0xF, 0xF, true);
         if (kcur != PAD_KEY && (s == EPS - 1 || knext != kcur)) flush(kcur, st);
     }
@@ -1385,7 +1390,7 @@ int amar_gat_xs_f32(const int32_t *rowptr, const int32_t *colidx, int32_t n_slic
     if (n_rows < 0 || n_slices < 1 || !rowptr || !H || !s_self || !s_neigh || !bias || !packed || !partials || !Y) return AMAR_EINVAL;
     if (n_cols < n_rows || row_offset < 0 || row_offset + n_rows > n_cols) return AMAR_EINVAL;
     if (ldh < C || ldy < C || !amar_aligned16(packed) || !amar_aligned16(partials)) return AMAR_EINVAL;
-    if (C != 8) return AMAR_EUNSUPPORTED;                               // 16 lanes per feature quad = one DPP row
+    if (C != 8 && C != 16 && C != 32) return AMAR_EUNSUPPORTED;
     if (n_rows == 0) return AMAR_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int64_t total = (int64_t)n_cols * (2 * C);
@@ -1394,10 +1399,16 @@ int amar_gat_xs_f32(const int32_t *rowptr, const int32_t *colidx, int32_t n_slic
     GatXsArgs pa{rowptr, colidx, packed, s_self, partials, n_rows, n_slices,
                  (n_rows + XS_WAVES * AMAR_WAVE - 1) / (XS_WAVES * AMAR_WAVE), (int64_t)n_cols * (2 * C) * 4 < (int64_t(1) << 32), row_offset};
     const dim3 pgrid((unsigned)(pa.blocks_per_slice * pa.n_slices)), block(XS_WAVES * AMAR_WAVE);
-    if (pa.off32) hipLaunchKernelGGL((gat_xs_partial_kernel<8, true>), pgrid, block, 0, st, pa);
-    else hipLaunchKernelGGL((gat_xs_partial_kernel<8, false>), pgrid, block, 0, st, pa);
     GatXsCombineArgs ca{partials, rowptr, packed, s_self, bias, Y, ldy, n_rows, n_slices, self_loop ? 1 : 0, row_offset};
-    hipLaunchKernelGGL((gat_xs_combine_kernel<8>), dim3((n_rows + 255) / 256), dim3(256), 0, st, ca);
+    const dim3 cgrid((n_rows + 255) / 256);
+#define AMAR_GAT_XS(CC)                                                                                     \
+    do {                                                                                                     \
+        if (pa.off32) hipLaunchKernelGGL((gat_xs_partial_kernel<CC, true>), pgrid, block, 0, st, pa);        \
+        else hipLaunchKernelGGL((gat_xs_partial_kernel<CC, false>), pgrid, block, 0, st, pa);                \
+        hipLaunchKernelGGL((gat_xs_combine_kernel<CC>), cgrid, dim3(256), 0, st, ca);                        \
+    } while (0)
+    if (C == 8) AMAR_GAT_XS(8); else if (C == 16) AMAR_GAT_XS(16); else AMAR_GAT_XS(32);
+#undef AMAR_GAT_XS
     return amar_check_launch();
 }
 

@@ -150,10 +150,10 @@ class PartitionedGCNRunner:
         elif layers and all(isinstance(l, GraphSageConv) for l in layers) and seq.final_node == 'concatenation':
             self.kind = 'sage'
         elif layers and all(isinstance(l, GATConv) for l in layers) and seq.final_node == 'concatenation' and \
-                all(l.channels == 8 for l in layers):
+                all(l.channels in (8, 16, 32) for l in layers):
             self.kind = 'gat'
         else:
-            raise NotImplementedError("the partitioned runner covers GCN / GraphSAGE / GAT (8 channels) stacks with "
+            raise NotImplementedError("the partitioned runner covers GCN / GraphSAGE / GAT (8, 16 or 32 channels) stacks with "
                                       "'concatenation' and LightGCN / DGCF stacks ('mean')")
         if self.kind in ('sage', 'gat') and ops is not capi:
             raise NotImplementedError("partitioned GraphSAGE / GAT run on the XCD-sliced HIP kernels only")

@@ -578,7 +578,8 @@ def test_spmm_xcd_sliced_dense_tiles(hip, F, n, avg_deg, seed):
 
 @pytest.mark.parametrize('n,avg_deg,seed,dup', [(67, 9, 1, False), (1000, 9, 2, True), (300, 160, 3, False), (1030, 400, 4, True), (4097, 20, 5, False)])
 @pytest.mark.parametrize('self_loop', [True, False])
-def test_gat_xcd_sliced(hip, n, avg_deg, seed, dup, self_loop):
+@pytest.mark.parametrize('C', [8, 16, 32])
+def test_gat_xcd_sliced(hip, n, avg_deg, seed, dup, self_loop, C):
     """amar_gat_xs_f32 (XCD-sliced image, online softmax) against the row kernel and the dense float64 softmax, incl. tiles
     longer than a super-step, duplicate edges, empty rows and widely spread attention scalars."""
     from deep_cbrs_amar_renaissance_amd.utilities.math import XcdSliced
@@ -588,7 +589,6 @@ def test_gat_xcd_sliced(hip, n, avg_deg, seed, dup, self_loop):
     a = _dev_csr(m, with_values=False)
     xs = XcdSliced.from_csr(a)
     rng = np.random.default_rng(seed)
-    C = 8
     h = rng.standard_normal((n, C)).astype(np.float32)
     ss = (rng.standard_normal(n) * 4).astype(np.float32)            # spread: exp() ranges over many decades
     sn = (rng.standard_normal(n) * 4).astype(np.float32)

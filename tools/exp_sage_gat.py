@@ -61,6 +61,21 @@ def main():
     print('gat on XS (pack + partial + combine): %.3f ms -> %.0f GB/s (%.1f %% of 8 TB/s)' % (t, alg / t / 1e6, alg / t / 1e6 / 80), flush=True)
     t = timeit(lambda: capi.spmm_csr(a.rowptr, a.colidx, None, x, y))
     print('value-free spmm_csr (stream kernel): %.3f ms' % t, flush=True)
+    # GraphSAGE's mean aggregate on the LDS-tiled image, and GAT at the wider grids (C = 16, 32): row kernel vs XS form
+    os.environ['AMAR_SPMM_LT'] = '1'
+    img = a.tiled_mean_image(F, True)
+    agg = torch.empty((n, F), device=dev)
+    t = timeit(lambda: capi.spmm_xs(img, x, agg, prescaled=True))
+    t2 = timeit(lambda: capi.spmm_xs(xs, x, agg, prescaled=True))
+    print('sage mean aggregate alone: LT %.3f ms, XS %.3f ms' % (t, t2), flush=True)
+    for C in (16, 32):
+        hC = torch.randn((n, C), device=dev)
+        bC = torch.zeros(C, device=dev)
+        yr, yx = torch.empty((n, C), device=dev), torch.empty((n, C), device=dev)
+        t_row = timeit(lambda: capi.gat_layer(a.rowptr, a.colidx, hC, ss, sn, bC, yr, self_loop=True))
+        capi.gat_xs(xs_e, hC, ss, sn, bC, yx, self_loop=True)
+        t_xs = timeit(lambda: capi.gat_xs(xs_e, hC, ss, sn, bC, yx, self_loop=True))
+        print('GAT C=%d: row kernel %.3f ms, XS form %.3f ms, max |diff| %.2e' % (C, t_row, t_xs, float((yr - yx).abs().max())), flush=True)
 
 
 if __name__ == '__main__':

@@ -418,14 +418,16 @@ def _csr_lds_tiled(self, F):
 
 DeviceCSR.lds_tiled = _csr_lds_tiled
 
-LT_MIN_DENSITY = 0.2       # entries per (tile, column): below this neighbouring entries no longer share L1 lines
+LT_MIN_DENSITY = 0.06      # entries per (tile, column): below this neighbouring entries no longer share L1 lines often enough
 
 
 def lt_eligible(a, F):
     """Whether the large-graph product of `a` (a DeviceCSR or a row block of one) at width F runs on the LDS-tiled image
     rather than the XCD-sliced one: the value-free factors must be known, the packed word must hold the column, and a
-    tile must see enough entries per column for the column-ordered walk to pay (measured on ml1m(s=64): -27 % per layer;
-    a row block of an 8-rank partition has 1/8 of the entries per tile over the same columns and stays on XS).
+    tile must see enough entries per column for the column-ordered walk to pay.  Measured on ml1m(s=64), F = 8
+    (tools/exp_lt_blocks.py, LT / XS per launch): whole matrix (0.37 entries per tile and column) 0.22 / 0.36 ms; the row
+    blocks of a 2-rank partition (0.14) 0.13-0.19 / 0.18-0.23; 4 ranks (0.07) 0.092 / 0.10-0.12; 8 ranks (0.035) 0.08 / 0.06-0.07:
+    the blocks of an 8-rank partition stay on XS.
     AMAR_SPMM_LT=0|1 overrides the density rule."""
     from deep_cbrs_amar_renaissance_amd.utilities import lds_tiled
     forced = os.environ.get('AMAR_SPMM_LT')

@@ -113,3 +113,33 @@ def test_randomised_model_sweep(hip):
         got = model((pu, pi)).cpu().numpy()
         want = om.basic_gnn_scores(adj, helpers.gnn_to_oracle(model.gnn), helpers.basic_head_to_oracle(model.rs), pu, pi, dtype=np.float64)
         assert np.isfinite(got).all() and np.abs(got - want).max() < 1e-4, (case, cls, n_users, n_items, len(ratings))
+
+
+@pytest.mark.parametrize('F', [8, 16, 32])
+def test_lds_tiled_edge_graphs(hip, F):
+    """amar_spmm_lt_f32 on degenerate inputs: a graph without any off-diagonal entry (only the diag term survives), a single
+    node, one lone edge among many isolated nodes, and a tile count far above the row count."""
+    from deep_cbrs_amar_renaissance_amd.utilities import lds_tiled
+    dev = 'cuda'
+
+    def run(rows, cols, n, n_cu=256):
+        r = torch.tensor(rows, dtype=torch.int64, device=dev)
+        c = torch.tensor(cols, dtype=torch.int64, device=dev)
+        diag = torch.ones(n, device=dev)
+        scale = torch.linspace(0.5, 1.5, n, device=dev)
+        lt = lds_tiled.LdsTiled.build(r, c, n, n, F, diag, scale, scale, 0, n_cu=n_cu)
+        x = torch.randn((n, F), device=dev)
+        y = torch.full((n, F), float('nan'), device=dev)
+        hip.spmm_lt(lt, x, y, prescaled=True)
+        want = x.clone().double()
+        for a, b in zip(rows, cols):
+            want[a] += x[b].double()
+        want = want * scale.double()[:, None]
+        assert torch.isfinite(y).all() and float((y.double() - want).abs().max()) < 1e-5
+        return lt
+
+    run([], [], 37)                                   # no entries at all: one padded word, every tile empty
+    run([], [], 1)
+    lt = run([5, 900], [900, 5], 1000)                # one edge, 998 isolated nodes
+    assert lt.n_entries == 2
+    run([0, 1, 1, 2], [1, 0, 2, 1], 3, n_cu=64)       # more tiles asked for than rows exist

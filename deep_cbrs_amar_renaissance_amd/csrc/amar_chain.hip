@@ -187,6 +187,8 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
 //   * takes ReLU as one integer max on the float's bits (no NaN-quieting pre-pass), forms addresses from 32-bit row
 //     numbers, and evaluates the final activation once per 32 pairs (lane group g finishes pair tile g).
 // Same arithmetic in the same order as the generic kernel: the scores are bit-identical.
+// Identical to fmaxf(v, 0) for every finite v (and -0, -NaN -> 0).  A positive-sign NaN stays a NaN here while fmaxf(NaN, 0) = 0
+// in the generic kernel: not reachable from finite weights and rows, so the two kernels agree bit for bit on real inputs.
 __device__ __forceinline__ float relu_bits(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
 
 // SCATTER: scores go to out[out_index[p]] (a pair list prepared in XCD-affine order writes back in the caller's order); the index is

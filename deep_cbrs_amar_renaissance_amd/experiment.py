@@ -6,9 +6,11 @@ sections), same resolution of model / loader classes from name strings, same per
 catch-and-continue.  Differences, all forced by scope:
 
 * tracking goes to a JSON-lines run log instead of MLflow (not installed);
-* ``Model.fit`` is the HIP training step of training.py (every model class named in ``econfigs/``); a model without
-  one (TwoStep / TwoWay names) raises NotImplementedError at construction and the grid goes on with the next experiment;
-* Precision/Recall/F1@k come from a host-side evaluator instead of ``binaries/mimir.jar``.
+* ``Model.fit`` is the HIP training step of training.py (every model class named in ``econfigs/`` and the TwoStep / TwoWay
+  classes the factories generate); a model or reduction without a training recipe raises and the experiment fails — the
+  grid goes on with the next one, nothing is evaluated on untrained weights;
+* Precision/Recall/F1@k come from a host-side restatement of RiVal's holdout metrics instead of ``binaries/mimir.jar``
+  (utilities/metrics.py: hand-computed vectors in tests/test_metrics_cpu.py).
 
 Run from the directory that holds ``config.yaml`` and the ``datasets/`` tree:
 ``python -m deep_cbrs_amar_renaissance_amd.experiment -e econfigs/basic-gnn.yaml``

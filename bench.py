@@ -319,7 +319,7 @@ def main():
             os.environ.setdefault('MASTER_PORT', '29531')
             os.environ.setdefault('RANK', '0')
             os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     from deep_cbrs_amar_renaissance_amd import capi, engine
     from deep_cbrs_amar_renaissance_amd.data import synthetic

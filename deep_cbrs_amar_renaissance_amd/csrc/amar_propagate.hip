@@ -604,7 +604,6 @@ struct LtArgs {
     int maxwin1; int cbits;
     int pace_mask;                               // the waves meet at a barrier after every window w with (w & pace_mask) == pace_mask
     const float *X; int64_t ldx; const float *Xself; const float *diag; const float *row_scale;
-    long long *stamps;                           // development: cycles per tile (tools/exp_lt.py), or NULL
     SpmmArgs e;
 };
 
@@ -633,7 +632,6 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtA
     const int t = blockIdx.x;
     const int lane = threadIdx.x & (AMAR_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long long t_start = a.stamps ? (long long)__builtin_readcyclecounter() : 0;
     const int r0 = a.tile_row0[t], nr = a.tile_row0[t + 1] - r0;
     for (int i = threadIdx.x; i < LT_WAVES * RW * F / 4; i += LT_WAVES * AMAR_WAVE)
         reinterpret_cast<float4 *>(ytile)[i] = f4_zero();
@@ -779,7 +777,6 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtA
         for (int qq = 0; qq < LPN; ++qq) { acc[qq].x *= sc; acc[qq].y *= sc; acc[qq].z *= sc; acc[qq].w *= sc; }
         lane_row_epilogue<F, FUSE_NEXT>(a.e, row, acc);
     }
-    if (a.stamps && threadIdx.x == 0) a.stamps[t] = (long long)__builtin_readcyclecounter() - t_start;
 }
 
 template <int F>
@@ -1527,10 +1524,8 @@ int amar_spmm_lt_f32(const int32_t *words, const int32_t *stream_start, const in
     a.e.acc_div = acc_div; a.e.accum = accum ? 1 : 0; a.e.accum_div = (flags & AMAR_SPMM_ACCUM_DIV) ? 1 : 0;
     a.e.Wn = Wnext; a.e.Cn = Cn; a.e.Hn = Hnext; a.e.ldhn = ldhn; a.e.n_rows = n_rows;
     const int off32 = (int64_t)n_cols * ldx * 4 < (int64_t(1) << 32) ? (ldx == F ? 2 : 1) : 0;
-    const char *venv = getenv("AMAR_LT_VARIANT");               // development switches (tools/exp_lt.py)
+    const char *venv = getenv("AMAR_LT_VARIANT");               // development switch (tools/exp_lt.py)
     const int variant = venv ? atoi(venv) : 0;
-    const char *senv = getenv("AMAR_LT_STAMPS");                // device address of a [n_tiles] int64 buffer, decimal
-    a.stamps = senv ? reinterpret_cast<long long *>(strtoull(senv, nullptr, 10)) : nullptr;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (F) {
     case 4:  return launch_spmm_lt<4>(a, n_tiles, off32, Wnext != nullptr, variant, st);

@@ -16,8 +16,9 @@ import torch.distributed as dist
 def main():
     case = sys.argv[1]
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
-    torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', 0)))
-    dist.init_process_group('nccl')
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
     from deep_cbrs_amar_renaissance_amd import capi, engine, parallel
     from deep_cbrs_amar_renaissance_amd.models import basic, hybrid
     from oracle import models as om

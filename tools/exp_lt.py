@@ -76,26 +76,15 @@ def main():
                    int(lt.vcount.max()), lt.maxwin1 - 1, 100.0 * lt.n_pairs / max(1, lt.n_entries), 100.0 * lt.n_flagged / max(1, lt.n_entries),
                    100.0 * (lt.words.numel() - lt.n_entries) / max(1, lt.n_entries), t_build), flush=True)
         os.environ.pop('AMAR_LT_VARIANT', None)
-        if os.environ.get('LT_STAMPS'):
-            # cycles per tile (shader clock), user-row tiles vs item-row tiles
-            for variant in variants:
-                os.environ['AMAR_LT_VARIANT'] = variant
-                stamps = torch.zeros(lt.n_tiles, dtype=torch.int64, device=dev)
-                os.environ['AMAR_LT_STAMPS'] = str(stamps.data_ptr())
-                capi.spmm_lt(lt, xs_tab, y_lt, prescaled=True)
-                torch.cuda.synchronize()
-                os.environ.pop('AMAR_LT_STAMPS')
-                st = stamps.cpu().numpy().astype(float)
-                is_user = (lt.tile_row0[:-1] < data['n_users']).cpu().numpy()
-                tc = torch.bincount(torch.searchsorted(lt.tile_row0.long(), rows, right=True) - 1, minlength=lt.n_tiles).cpu().numpy()
-                worst = int(st.argmax())
-                print('    variant %s slowest tile %d: rows [%d, %d) entries %d windows %d cycles %.0f' % (variant, worst, int(lt.tile_row0[worst]), int(lt.tile_row0[worst + 1]), tc[worst], int(lt.n_win[worst]), st[worst]), flush=True)
-                for name, sel in (('user tiles', is_user), ('item tiles', ~is_user)):
-                    if sel.any():
-                        print('    variant %s %s: n %d cycles min %.0f median %.0f max %.0f | entries median %.0f -> %.2f cycles/entry' %
-                              (variant, name, sel.sum(), st[sel].min(), np.median(st[sel]), st[sel].max(), np.median(tc[sel]),
-                               np.median(st[sel]) / max(1.0, np.median(tc[sel]))), flush=True)
-            os.environ.pop('AMAR_LT_VARIANT', None)
+        # the call as the fused GCN chain makes it: bias + ReLU, Y into a column slice of the [N, 3F] concat buffer, next layer's X.W
+        cat = torch.empty((n, 3 * F), device=dev)
+        wn = torch.randn((F, F), device=dev) * 0.3
+        hn = torch.empty((n, F), device=dev)
+        t_a = timeit(lambda: capi.spmm_lt(lt, xs_tab, y_lt, prescaled=True))
+        t_b = timeit(lambda: capi.spmm_lt(lt, xs_tab, y_lt, bias=bias, relu=True, prescaled=True))
+        t_c = timeit(lambda: capi.spmm_lt(lt, xs_tab, cat[:, F:2 * F], bias=bias, relu=True, prescaled=True))
+        t_d = timeit(lambda: capi.spmm_lt(lt, xs_tab, cat[:, F:2 * F], bias=bias, relu=True, Wnext=wn, Hnext=hn, prescaled=True, scale_next=True))
+        print('  epilogue forms: plain %.4f | + bias, ReLU %.4f | ... into a concat slice %.4f | ... + next X.W %.4f ms' % (t_a, t_b, t_c, t_d), flush=True)
         del lt
 
 

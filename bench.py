@@ -364,9 +364,10 @@ def main():
             spmm_events.append((e0, e1))
             kinds_seen.append(name)
         return wrapper
-    # Multi-rank runs (and AMAR_FORCE_DIST rehearsals) replay the partitioned step, collectives included, from a hipGraph
-    # (AMAR_STEP_GRAPH=0: eager).  No per-launch event can be recorded inside a capture, so for them the kernel-level objects
-    # below come from the eager warm-up steps; the single-GPU run times its launches inside the timed region.
+    # The timed steps replay the whole step — on several ranks its collectives too — from a hipGraph the runner captures itself
+    # (AMAR_STEP_GRAPH=0: the eager steps are the timed ones).  No per-launch event can be recorded inside a capture, so the
+    # kernel-level objects below (roofline, pair_stage) are timed over K EAGER steps run just before, whose own rate is reported
+    # as `eager`; the kernels and their durations are the same in both.
     graph_step = hasattr(runner, 'step_graphed') and os.environ.get('AMAR_STEP_GRAPH', '1') != '0'
     for name in spmm_names:                                   # whichever form the layer dispatches to
         setattr(capi, name, timed(name, raw_spmm[name]))
@@ -390,35 +391,38 @@ def main():
     for _ in range(max(args.warmup, 1)):
         runner.step()
     barrier()
-    step = runner.step
-    if graph_step:                                            # keep the warm-up launches' timings, then capture and replay
-        warm_spmm, warm_pair, warm_kinds = list(spmm_events), list(pair_events), list(kinds_seen)
-        for name in spmm_names:
-            setattr(capi, name, raw_spmm[name])
-        capi.chain = raw_chain
-        runner.step_graphed()
-        step = runner.step_graphed
-        barrier()
-    else:
-        spmm_events.clear()
-        pair_events.clear()
-        del kinds_seen[:]
+    spmm_events.clear()
+    pair_events.clear()
+    del kinds_seen[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-    host_dt = time.perf_counter() - t0                        # time to ENQUEUE the steps (host-side launch cost)
+        runner.step()
+    eager_host_dt = time.perf_counter() - t0
     barrier()
-    dt = time.perf_counter() - t0
+    eager_dt = time.perf_counter() - t0
     for name in spmm_names:
         setattr(capi, name, raw_spmm[name])
     capi.chain = raw_chain
-    if world > 1 or force_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-
+    step = runner.step
     if graph_step:
-        spmm_events, pair_events, kinds_seen = warm_spmm, warm_pair, warm_kinds
+        for _ in range(3):                                    # capture on the first call; a graph's first replays are slower
+            runner.step_graphed()
+        step = runner.step_graphed
+        barrier()
+    t0 = time.perf_counter()
+    if graph_step:
+        for _ in range(args.steps):
+            step()
+        host_dt = time.perf_counter() - t0                    # time to ENQUEUE the steps (host-side launch cost)
+        barrier()
+        dt = time.perf_counter() - t0
+    else:
+        host_dt, dt = eager_host_dt, eager_dt
+    if world > 1 or force_dist:
+        t = torch.tensor([dt, eager_dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt, eager_dt = float(t[0].item()), float(t[1].item())
+
     spmm_ms = [e0.elapsed_time(e1) for e0, e1 in spmm_events]
     rows_local = runner.local_rows
     nnz_local = runner.local_nnz
@@ -448,7 +452,7 @@ def main():
                          'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
                          'traffic': pmc['traffic_bytes_per_launch'] if pmc else None, 'traffic_source': traffic_source,
                          'algorithmic_bytes_per_launch': alg_bytes, 'avg_launch_ms': avg_ms,
-                         'launches_timed': len(spmm_ms), 'timed_in': 'warm-up steps (eager)' if graph_step else 'timed region',
+                         'launches_timed': len(spmm_ms), 'timed_in': 'the K eager steps just before the replayed ones' if graph_step else 'timed region',
                          'note': 'achieved = SURVEY 8(d) bytes (canonical CSR: 8 B per non-zero) / time, i.e. a CSR-equivalent effective '
                                  'bandwidth; the dispatched image streams {} B per non-zero'.format(image_entry_bytes)},
             # the limit that bound the XS form: one 128-B L2 line request per gathered row at 0.44 requests / clock / CU
@@ -457,8 +461,11 @@ def main():
                             'frac': (1e3 * nnz_local / L2_REQUESTS_PER_S) / avg_ms,
                             'note': 'frac > 1 means the dispatched kernel issues fewer than one L2 request per non-zero '
                                     '(the LDS-tiled form gathers in column order: neighbouring entries share L1 lines)'},
-            'propagation_ms': None if graph_step else runner.last_propagation_ms(),
+            'propagation_ms': runner.last_propagation_ms(),
             'host_enqueue_ms_per_step': 1e3 * host_dt / args.steps,
+            'eager': {'ms_per_step': 1e3 * eager_dt / args.steps, 'value': n_pairs * args.steps / eager_dt, 'unit': 'pairs/s',
+                      'host_enqueue_ms_per_step': 1e3 * eager_host_dt / args.steps,
+                      'note': 'the same K steps launched one kernel at a time, each SpMM / pair-stage launch bracketed by HIP events'},
         }
         pair_ms = [e0.elapsed_time(e1) for e0, e1 in pair_events]
         if pair_ms:

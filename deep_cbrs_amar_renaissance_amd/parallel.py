@@ -112,6 +112,24 @@ class SingleRunner:
         self._events = (e0, e1)
         return self._score(emb)
 
+    def step_graphed(self):
+        """The same step replayed from a hipGraph (captured on first use, after one eager step): the launch gaps of the eight
+        kernels go away.  The graph is valid while the weights keep their storage and the Dense weights their values (packed
+        blobs are made on the host): call it between weight updates only, as bench.py does."""
+        state = self.__dict__.setdefault('_graph_state', {})
+        key = self.model.weights_version
+        if state.get('key') != key:
+            self.step()
+            from deep_cbrs_amar_renaissance_amd.engine import capture_graph
+
+            def body():
+                emb = self.model.gnn(None)
+                return self._score(emb)
+            state['graph'], state['out'] = capture_graph(body)
+            state['key'] = key
+        state['graph'].replay()
+        return state['out']
+
     def _score(self, emb):
         # per-entity towers, then gather + classifier per pair (nothing is cached across steps)
         nu, ni = self.model.n_users, self.model.n_items

@@ -610,6 +610,9 @@ struct LtArgs {
 constexpr int LT_WAVES = 16;
 constexpr int LT_TILE_BYTES = 128 << 10;
 constexpr int LT_CHUNK = 256;                      // entries per index chunk: 64 lanes x one 16-byte load
+#ifndef LT_PREFETCH
+#define LT_PREFETCH 2                              // index chunks in flight per wave ahead of the one being issued
+#endif
 
 __device__ __forceinline__ int lt_lds_row(int v) {                    // virtual row -> row of the LDS tile (see lds_tiled.py)
     const int w = v & (LT_WAVES - 1), l = v / LT_WAVES;
@@ -726,15 +729,18 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtA
         }
     };
     pace(0);
-    // index chunks are requested two chunks ahead, alternately into two register sets: `next` holds chunk c + 1 when chunk c
-    // reaches the point where it starts issuing that chunk's steps, and is then reloaded with chunk c + 3
-    v4i pre_a = {0, 0, 0, 0}, pre_b = {0, 0, 0, 0};
+    // index chunks are requested PF chunks ahead, in turn into PF register sets: `next` holds chunk c + 1 when chunk c reaches
+    // the point where it starts issuing that chunk's steps, and is then reloaded with chunk c + 1 + PF
+    constexpr int PF = LT_PREFETCH;
+    v4i pre[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) pre[j] = v4i{0, 0, 0, 0};
     auto chunk_body = [&](int c, v4i &next) {
 #pragma unroll
         for (int js = 0; js < CS; ++js) {
             if (js + G == CS) {                                       // the steps issued from here on belong to the next chunk
                 refill(next);                                         // (past the last chunk: stale words, valid columns, never added)
-                if (c + 3 < n_chunks) next = load_chunk(c + 3);
+                if (c + 1 + PF < n_chunks) next = load_chunk(c + 1 + PF);
             }
             issue((js + G) % CS, (js + G) % U);
             accumulate(js % U);
@@ -742,16 +748,18 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtA
         }
     };
     if (n_chunks > 0) {
-        pre_a = load_chunk(0);
-        refill(pre_a);
-        if (n_chunks > 1) pre_b = load_chunk(1);
-        if (n_chunks > 2) pre_a = load_chunk(2);
+        pre[0] = load_chunk(0);
+        refill(pre[0]);
+#pragma unroll
+        for (int j = 1; j <= PF; ++j)                                 // chunk j waits in set j % PF
+            if (j < n_chunks) pre[j % PF] = load_chunk(j);
 #pragma unroll
         for (int j = 0; j < G; ++j) issue(j, j);
     }
-    for (int c = 0; c < n_chunks; c += 2) {
-        chunk_body(c, pre_b);
-        if (c + 1 < n_chunks) chunk_body(c + 1, pre_a);
+    for (int c = 0; c < n_chunks; c += PF) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j)
+            if (c + j < n_chunks) chunk_body(c + j, pre[(j + 1) % PF]);      // chunk k waits in set k % PF (c is a multiple of PF)
     }
     __syncthreads();
 

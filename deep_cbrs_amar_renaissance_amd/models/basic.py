@@ -148,21 +148,32 @@ class PairPlan:
 
     N_XCD, CHUNK = 8, 128
 
-    def __init__(self, u_ids, i_ids):
+    def __init__(self, u_ids, i_ids, phases=None):
         p = int(u_ids.numel())
         dev = u_ids.device
+        if phases is None:
+            phases = int(os.environ.get('AMAR_PAIR_PHASES', '1'))
         pos = torch.arange(p, device=dev)
-        xcd = (pos // self.CHUNK) % self.N_XCD
-        slots = torch.bincount(xcd, minlength=self.N_XCD)                      # positions owned by each XCD
+        # position -> class: (phase, XCD).  A workgroup walks its chunks in ascending position, so the first 1/phases of the
+        # positions are visited first by every workgroup: with `phases` > 1 an XCD works through `phases` item ranges one after
+        # the other, each a 1/(8 phases) of the items
+        per_phase = -(-p // phases)
+        cls = (pos // per_phase) * self.N_XCD + (pos // self.CHUNK) % self.N_XCD
+        n_cls = phases * self.N_XCD
+        slots = torch.bincount(cls, minlength=n_cls)                           # positions owned by each class
         by_item = torch.argsort(i_ids.to(torch.int64), stable=True)
-        bucket = torch.repeat_interleave(torch.arange(self.N_XCD, device=dev), slots)   # bucket of the k-th pair in item order
+        # item ranges in class order: range k (k-th slice of the item-sorted pairs) goes to the class with the k-th ... the ranges are
+        # sized to the classes taken in (XCD, phase) order, so that XCD x gets `phases` neighbouring ranges
+        order_cls = torch.arange(n_cls, device=dev).view(phases, self.N_XCD).t().reshape(-1)     # (xcd, phase) -> class id
+        bucket_sizes = slots[order_cls]
+        bucket_of_rank = torch.repeat_interleave(order_cls, bucket_sizes)       # class of the k-th pair in item order
         if os.environ.get('AMAR_PAIR_INNER', 'user') == 'user' and p:
             # inside a range by user id, so that consecutive pairs also share user-tower rows (0.674 against 0.689 ms at
             # ml1m(s=64) for the original order inside a range, AMAR_PAIR_INNER=pos; the scattered score writes cost nothing extra)
-            order = by_item[torch.argsort((bucket * (int(u_ids.max()) + 1) + u_ids[by_item].to(torch.int64)) * p + by_item)]
+            order = by_item[torch.argsort((bucket_of_rank * (int(u_ids.max()) + 1) + u_ids[by_item].to(torch.int64)) * p + by_item)]
         else:
-            order = by_item[torch.argsort(bucket * p + by_item)]                # (range, original position)
-        place = torch.argsort(xcd * p + pos)                                    # positions grouped by XCD, ascending inside
+            order = by_item[torch.argsort(bucket_of_rank * p + by_item)]        # (class, original position)
+        place = torch.argsort(cls * p + pos)                                    # positions grouped by class, ascending inside
         src = torch.empty(p, dtype=torch.int64, device=dev)
         src[place] = order                                                      # position -> original pair
         self.u_ids = u_ids[src].contiguous()

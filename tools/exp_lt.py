@@ -33,6 +33,8 @@ def main():
     from deep_cbrs_amar_renaissance_amd.data import synthetic
     from deep_cbrs_amar_renaissance_amd.utilities import lds_tiled
     from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter_device, _unit_entries
+    if os.environ.get('LT_LIB'):                                 # same-box A/B of another build of the library
+        capi.LIB_PATH = os.path.join(ROOT, os.environ['LT_LIB'])
     capi.load()
     dev = torch.device('cuda')
     data = synthetic.ml1m_device(scale, device=dev)
@@ -80,6 +82,16 @@ def main():
         cat = torch.empty((n, 3 * F), device=dev)
         wn = torch.randn((F, F), device=dev) * 0.3
         hn = torch.empty((n, F), device=dev)
+        # cold caches: 600 MB written between launches (what the pair stage does to the layer inside a bench step)
+        scratch = torch.empty(150_000_000, device=dev)
+        colds = []
+        for _ in range(8):
+            scratch.fill_(1.0)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); capi.spmm_lt(lt, xs_tab, y_lt, prescaled=True); e1.record(); e1.synchronize()
+            colds.append(e0.elapsed_time(e1))
+        print('  from cold caches: LT %.4f ms (median of 8)' % sorted(colds)[4], flush=True)
+        del scratch
         t_a = timeit(lambda: capi.spmm_lt(lt, xs_tab, y_lt, prescaled=True))
         t_b = timeit(lambda: capi.spmm_lt(lt, xs_tab, y_lt, bias=bias, relu=True, prescaled=True))
         t_c = timeit(lambda: capi.spmm_lt(lt, xs_tab, cat[:, F:2 * F], bias=bias, relu=True, prescaled=True))

@@ -187,6 +187,8 @@ def ml1m_true_size(dev):
     u_np, i_np = u.cpu().numpy().astype(np.int64), i.cpu().numpy().astype(np.int64)
 
     class TestSequence:
+        order_version = 0                                       # fixed order: predict() reads the batches once
+
         def __len__(self):
             return (p + 2047) // 2048
 
@@ -204,8 +206,9 @@ def ml1m_true_size(dev):
         dt = (time.perf_counter() - t0) / reps
         out[name + '_pairs_per_s'], out[name + '_ms'] = p / dt, 1e3 * dt
         assert scores.shape[0] == p
+    model.predict(seq)                                              # (mode switch: captures the hoisted pass again)
     t0 = time.perf_counter()
-    host_scores = model.predict(seq)                                # the same plus the copy of the scores to a host ndarray
+    host_scores = model.predict(seq)                                # the replayed pass plus the copy of the scores to a host ndarray
     out['predict_call_ms'] = 1e3 * (time.perf_counter() - t0)
     assert host_scores.shape == (p, 1)
     # full ranking: every (user, item) combination, P_all = |U| x |I| (SURVEY.md 8d "pair sets"), hoisted

@@ -25,6 +25,7 @@ class _RatingsSequence:
         self.seed = seed
         self.indexes = None
         self.random_state = None
+        self.order_version = 0          # bumped whenever the batch order changes: lets predict() keep its uploaded id list
         self.on_epoch_end()
 
     def __len__(self):
@@ -48,6 +49,7 @@ class _RatingsSequence:
                 self.random_state = np.random.RandomState(self.seed)
             self.indexes = np.arange(len(self.ratings))
             self.random_state.shuffle(self.indexes)
+            self.order_version += 1
 
 
 class UserItemEmbeddings(_RatingsSequence):

@@ -210,7 +210,13 @@ class Model(Layer):
     def _sequence_ids(self, sequence):
         """All (user, item) id pairs of a Sequence on the device.  The host ids are read on every call (a shuffling Sequence
         changes its order between epochs, datasets.py:205-213) and compared with what the device buffers hold; a changed list of
-        the same batch sizes is copied INTO those buffers, so that a captured graph reading them stays valid."""
+        the same batch sizes is copied INTO those buffers, so that a captured graph reading them stays valid.  A Sequence that
+        carries an `order_version` counter (data/datasets.py bumps it on every reshuffle) is not re-read while the counter, the
+        object and its length stay the same: at ML-1M size reading 81 batches costs more than the replayed pass itself."""
+        cache = self.__dict__.get('_seq_ids')
+        stamp = (id(sequence), len(sequence), getattr(sequence, 'order_version', None), id(getattr(sequence, 'ratings', None)))
+        if cache is not None and stamp[2] is not None and cache.get('stamp') == stamp:
+            return cache['u'], cache['i'], cache['sizes']
         us, its, sizes = [], [], []
         for b in range(len(sequence)):
             (u, i), _ = sequence[b]
@@ -219,7 +225,6 @@ class Model(Layer):
             sizes.append(len(us[-1]))
         u_host = np.concatenate(us).astype(np.int64) if us else np.zeros(0, np.int64)
         i_host = np.concatenate(its).astype(np.int64) if its else np.zeros(0, np.int64)
-        cache = self.__dict__.get('_seq_ids')
         if cache is not None and cache['sizes'] == sizes:
             if not (np.array_equal(cache['u_host'], u_host) and np.array_equal(cache['i_host'], i_host)):
                 cache['u'].copy_(ids_to_device(u_host))
@@ -228,6 +233,7 @@ class Model(Layer):
         else:
             cache = {'sizes': sizes, 'u_host': u_host, 'i_host': i_host, 'u': ids_to_device(u_host), 'i': ids_to_device(i_host)}
             self.__dict__['_seq_ids'] = cache
+        cache['stamp'], cache['keepalive'] = stamp, sequence          # (the object is kept alive: its id() is part of the stamp)
         return cache['u'], cache['i'], sizes
 
     def _predict_graphed(self, sequence, hoist):

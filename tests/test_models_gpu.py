@@ -396,6 +396,33 @@ def test_hip_path_reproduces_golden_vectors(hip, kind, cls, graph):
             assert np.array_equal(got_i, z['top{}_items'.format(kk)])
 
 
+@pytest.mark.parametrize('kind,cls', [('gcn', 'BasicGCN'), ('lightgcn', 'BasicLightGCN'), ('sage', 'BasicGraphSage'), ('gat', 'BasicGAT')])
+@pytest.mark.parametrize('graph', ['ui', 'uip'])
+@pytest.mark.parametrize('form', ['lt', 'xs'])
+def test_large_graph_forms_reproduce_golden_vectors(hip, kind, cls, graph, form, monkeypatch):
+    """The same committed fixtures with the propagation forced onto the forms large graphs take — the LDS-tiled image
+    (GCN / LightGCN layers, GraphSAGE's mean aggregate) and the XCD-sliced one (also GAT) — which these small graphs
+    would not select by themselves: node table and scores against the stored oracle outputs."""
+    import os
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    from deep_cbrs_amar_renaissance_amd.utilities.lds_tiled import LdsTiled
+    from tests.test_oracle import load_golden, GOLDEN
+    z, k, adj, gnn, head = load_golden(os.path.join(GOLDEN, 'basic_{}_{}.npz'.format(kind, graph)))
+    monkeypatch.setenv('AMAR_SPMM_KIND', 'xs')
+    monkeypatch.setenv('AMAR_SPMM_LT', '1' if form == 'lt' else '0')
+    model = getattr(basic, cls)(adj, embedding_dim=8, n_hiddens=[8, 8], n_layers=2, dense_units=[24, 24], clf_units=[48, 48])
+    helpers.load_oracle_weights(model, gnn, head)
+    emb = model.gnn(None).cpu().numpy()
+    assert helpers.rel_err(emb, z['emb_f64']) < 1e-5
+    scores = model((z['u_ids'], z['i_ids'])).cpu().numpy()
+    assert np.abs(scores - z['scores_f64']).max() < 1e-5
+    a = model.gnn.gnn_layers.adj_matrix
+    if form == 'lt' and kind in ('gcn', 'lightgcn'):
+        assert isinstance(a.tiled_image(8), LdsTiled)                # the host gcn_filter route kept A_hat's factors
+    if form == 'lt' and kind == 'sage':
+        assert isinstance(a.tiled_mean_image(8, True), LdsTiled)
+
+
 @pytest.mark.parametrize('name', ['dgcf_uip', 'hybrid_attention', 'hybrid_residual', 'hybrid_entity-attention'])
 def test_hip_path_reproduces_extra_golden_vectors(hip, name):
     """Committed fixtures of DGCF and the hybrid-gnn-tweaks heads through the HIP path."""

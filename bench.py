@@ -408,9 +408,13 @@ def main():
     capi.chain = raw_chain
     step = runner.step
     if graph_step:
-        for _ in range(3):                                    # capture on the first call; a graph's first replays are slower
-            runner.step_graphed()
-        step = runner.step_graphed
+        try:
+            for _ in range(3):                                # capture on the first call; a graph's first replays are slower
+                runner.step_graphed()
+            step = runner.step_graphed
+        except Exception as exc:                              # a capture the runtime refuses: the eager steps stand
+            sys.stderr.write("bench.py: hipGraph capture of the step failed ({}); timing eager steps\n".format(exc))
+            graph_step = False
         barrier()
     t0 = time.perf_counter()
     if graph_step:

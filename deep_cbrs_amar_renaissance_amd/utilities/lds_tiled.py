@@ -87,7 +87,8 @@ class LdsTiled:
         # the waves of a tile meet at a barrier every `pace_every` windows: windows of ONE step per wave keep the dealing span (and
         # with it the L1 footprint) small — 24 M L2 requests per ml1m(s=64) layer against 28 M for two-step windows — while a barrier
         # per four of them costs no more synchronisation than before (0.2136 against 0.2200 ms)
-        self.pace_every = int(os.environ.get('AMAR_LT_PACE', 4 if self.window_entries <= WAVES * (64 // (F // 4)) else 1))
+        steps = max(1, self.window_entries // (WAVES * (64 // (F // 4))))
+        self.pace_every = int(os.environ.get('AMAR_LT_PACE', 4 if steps == 1 else (2 if steps == 2 else 1)))
 
     @classmethod
     def build(cls, rows, cols, n_rows, n_cols, F, diag, row_scale, col_scale, diag_offset=0, window_entries=None, n_cu=N_CU,
@@ -100,8 +101,6 @@ class LdsTiled:
         eps, rw, cbits = geometry(F)
         if not supported(F, n_cols):
             raise ValueError("LT image: F = {} with {} columns is outside the packed word's range".format(F, n_cols))
-        if window_entries is None:
-            window_entries = W * eps if F == 8 else 2 * W * eps       # F = 8: one step per wave and window, a barrier per four
         vmax = W * (rw - 1)                                           # virtual rows a tile can hold
         m = int(rows.numel())
         idx = torch.arange(m, device=dev)
@@ -166,6 +165,14 @@ class LdsTiled:
             if n_rows else torch.zeros(0, dtype=torch.int64, device=dev)
         vstart = torch.cat([vstart, torch.zeros(1, dtype=torch.int64, device=dev)])
         vcount = vcum_t[tb_t[1:]] - vbase_tile
+        if window_entries is None:
+            # steps per wave and window by tile height: short tiles (few LDS rows per wave) need longer lists to spread the
+            # repeats of a row over several steps, tall tiles prefer the smallest L1 footprint.  ml1m(s), F = 8, ms per launch
+            # for 1 / 2 / 4 steps per window: s=16 (~600 rows per tile) .092 / .073 / .067, s=32 (~1 150) .129 / .117 / .124,
+            # s=64 (~2 300) .218 / .222 / .238, s=128 .540 / .546 / .570
+            avg_v = float(vcount.double().mean()) if T else 0.0
+            steps = 1 if avg_v >= 0.4 * vmax and F == 8 else (2 if avg_v >= 0.2 * vmax else 4)
+            window_entries = max(steps * W * eps, 1024 if F >= 16 else 0)   # F = 16, 32 at s=64: 1 024 entries (.33 / .58 ms) beat 512 / 256 (.35 / .70)
         # b. windows + the virtual row of every entry: both from the tile's column-sorted order
         order = torch.argsort(tile * n_cols + cols)
         tile_cnt = torch.bincount(tile, minlength=T)

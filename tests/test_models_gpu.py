@@ -291,7 +291,7 @@ class _LockstepGather:
         self.barrier.wait()
 
 
-@pytest.mark.parametrize('world', [1, 2, 4])
+@pytest.mark.parametrize('world', [1, 2, 4, 8])
 @pytest.mark.parametrize('case', ['BasicGCN', 'BasicGCN-ranges', 'BasicLightGCN', 'HybridBertGCN-uip', 'BasicGCN-xs', 'BasicGCN-xs-valuefree',
                                   'BasicGraphSage', 'BasicGAT-ranges', 'BasicDGCF'])
 def test_partitioned_runner_with_real_kernels(hip, world, case, monkeypatch):

@@ -224,3 +224,31 @@ def test_host_ids_are_range_checked():
         engine.ids_to_device(ids, n_rows=9)
     with pytest.raises(ValueError):
         engine.ids_to_device(np.array([-1, 2]), n_rows=9)
+
+
+@pytest.mark.parametrize('phases', [1, 2])
+def test_pair_plan_is_a_permutation_with_xcd_affine_item_ranges(phases):
+    """models.basic.PairPlan (plain torch: runs on CPU tensors): a permutation of the list; positions with equal
+    (p >> 7) % 8 — the pairs one XCD's workgroups score — hold one contiguous item range per phase; out_index sends every
+    score back to its place."""
+    from deep_cbrs_amar_renaissance_amd.models.basic import PairPlan
+    g = torch.Generator().manual_seed(3)
+    p = 40_013
+    u = torch.randint(0, 900, (p,), generator=g, dtype=torch.int32)
+    i = (torch.randint(0, 700, (p,), generator=g) + 900).to(torch.int32)
+    plan = PairPlan(u, i, phases=phases)
+    assert sorted(plan.out_index.tolist()) == list(range(p))
+    assert torch.equal(plan.u_ids, u[plan.out_index.long()]) and torch.equal(plan.i_ids, i[plan.out_index.long()])
+    pos = torch.arange(p)
+    per_phase = -(-p // phases)
+    cls = (pos // per_phase) * 8 + (pos // 128) % 8
+    lo = [int(plan.i_ids[cls == c].min()) for c in range(8 * phases)]
+    hi = [int(plan.i_ids[cls == c].max()) for c in range(8 * phases)]
+    order = [ph * 8 + x for x in range(8) for ph in range(phases)]          # item ranges ascend in (XCD, phase) order
+    assert all(lo[b] >= hi[a] for a, b in zip(order[:-1], order[1:]))
+    scores_in_plan_order = (plan.u_ids.double() * 1000 + plan.i_ids.double())
+    out = torch.empty(p, dtype=torch.float64)
+    out[plan.out_index.long()] = scores_in_plan_order                        # what the kernel's indexed store does
+    assert torch.equal(out, u.double() * 1000 + i.double())
+    with pytest.raises(ValueError):
+        plan.check(u.clone(), i)

@@ -31,6 +31,10 @@ SIGNATURES = {
                                         _P, _I64, _P, _I64, _F32, _P, _I32, _P, _I64, _P]),
     'amar_spmm_xs_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _P, _P, _P, _I64, _I32, _I32, _U32, _P,
                                         _P, _I64, _P, _I64, _F32, _P, _I32, _P, _I64, _P]),
+    'amar_gat_lt_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _I64,
+                                       _I32, _I32, _I32, _I32, _P]),
+    'amar_gat_lt_rows_per_wave': (ctypes.c_int, [_I32]),
+    'amar_colmax_f32': (ctypes.c_int, [_P, _I64, _P, _P]),
     'amar_spmm_lt_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _I64, _I32, _P, _P, _I64, _I32, _I32, _U32, _P,
                                         _P, _I64, _P, _I64, _F32, _P, _I32, _P, _I64, _P]),
     'amar_gat_xs_f32': (ctypes.c_int, [_P, _P, _I32, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P]),
@@ -398,6 +402,36 @@ def gat_xs(xs, H, s_self, s_neigh, bias, Y, self_loop=True):
         _ptr(bias, torch.float32, 'bias'), _ptr(packed), _ptr(partials), _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y'),
         1 if self_loop else 0, n, n_cols, row_offset, _stream())
     _check(code, 'amar_gat_xs_f32')
+
+
+def colmax(x, out):
+    """out[0] = max(x) (a 1-element float32 device tensor), in-stream."""
+    if not x.is_contiguous() or out.numel() < 1:
+        raise ValueError("colmax: contiguous x and a 1-element out expected")
+    _check(load().amar_colmax_f32(_ptr(x, torch.float32, 'x'), x.numel(), _ptr(out, torch.float32, 'out'), _stream()), 'amar_colmax_f32')
+
+
+def gat_lt(lt, csr, H, s_self, s_neigh, bias, Y, self_loop=True):
+    """gat_layer on the LDS-tiled image `lt` (utilities.lds_tiled.LdsTiled built with the GAT geometry, DeviceCSR.tiled_gat_image)
+    of the edge-list adjacency `csr` (a DeviceCSR, or a row block carrying diag_offset): one launch + the bound's reduction."""
+    n, n_cols = lt.shape
+    row_offset = int(getattr(lt, 'diag_offset', 0))
+    C = H.shape[1]
+    if C != lt.F or tuple(Y.shape) != (n, C) or H.shape[0] != n_cols or bias.numel() != C or s_self.numel() != n_cols or s_neigh.numel() != n_cols:
+        raise ValueError("gat_lt: H [n_cols, C], Y [n_rows, C], bias [C], s_self / s_neigh [n_cols] and an image built for C expected")
+    if tuple(csr.shape) != (n, n_cols):
+        raise ValueError("gat_lt: the CSR and the image must describe the same block")
+    bmax = lt.__dict__.setdefault('_gat_bound', torch.empty(1, dtype=torch.float32, device=H.device))
+    colmax(s_neigh, bmax)
+    code = load().amar_gat_lt_f32(
+        _ptr(lt.words, torch.int32, 'words'), _ptr(lt.stream_start, torch.int32, 'stream_start'),
+        _ptr(lt.wsteps, torch.int32, 'wsteps'), _ptr(lt.tile_row0, torch.int32, 'tile_row0'), _ptr(lt.n_win, torch.int32, 'n_win'),
+        _ptr(lt.vstart, torch.int32, 'vstart'), _ptr(lt.vcount, torch.int32, 'vcount'), lt.n_tiles, lt.maxwin1, lt.pace_every,
+        _ptr(lt.diag, torch.float32, 'diag'), _ptr(csr.rowptr, torch.int32, 'rowptr'), _ptr(csr.colidx, torch.int32, 'colidx'),
+        _ptr(H, torch.float32, 'H'), _ld(H, 'H'), C, _ptr(s_self, torch.float32, 's_self'), _ptr(s_neigh, torch.float32, 's_neigh'),
+        _ptr(bmax, torch.float32, 'bmax'), _ptr(bias, torch.float32, 'bias'), _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y'),
+        1 if self_loop else 0, n, n_cols, row_offset, _stream())
+    _check(code, 'amar_gat_lt_f32')
 
 
 DENSE_WT = 0x100

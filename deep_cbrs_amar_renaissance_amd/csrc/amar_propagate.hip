@@ -605,10 +605,18 @@ struct LtArgs {
     int pace_mask;                               // the waves meet at a barrier after every window w with (w & pace_mask) == pace_mask
     const float *X; int64_t ldx; const float *Xself; const float *diag; const float *row_scale;
     SpmmArgs e;
+    // GAT mode (amar_gat_lt_f32): per-node attention scalars over the image's columns, the upper bound of s_neigh, the rows' own
+    // scalars (row i of the block = column row_offset + i), the block's CSR for the exact per-row fall-back
+    const float *s_neigh; const float *bmax; const float *s_self_rows; const float *s_neigh_rows;
+    const int32_t *csr_rowptr; const int32_t *csr_colidx; int self_loop;
 };
 
 constexpr int LT_WAVES = 16;
 constexpr int LT_TILE_BYTES = 128 << 10;
+// GAT mode keeps (sum of weights, s_self) next to every LDS row: 4F + 8 bytes per virtual row, fewer rows per wave
+// (utilities/lds_tiled.py:GAT_ROWS_PER_WAVE holds the same table)
+constexpr int lt_gat_rw(int F) { return F == 8 ? 216 : F == 16 ? 124 : F == 32 ? 64 : 384; }
+constexpr int lt_bits(int n) { int b = 0; while ((1 << b) < n) ++b; return b; }
 constexpr int LT_CHUNK = 256;                      // entries per index chunk: 64 lanes x one 16-byte load
 #ifndef LT_PREFETCH
 #define LT_PREFETCH 2                              // index chunks in flight per wave ahead of the one being issued
@@ -623,23 +631,42 @@ __device__ __forceinline__ int lt_lds_row(int v) {                    // virtual
 // PACE: 0 = waves run free, 1 = one s_barrier per (pace_mask + 1) windows, 2 = arrival counters in LDS: a wave leaves window w
 // once every wave has left window w - 1 (one window of slack: measured slower than the barrier)
 // OFF32: 0 = 64-bit gather addresses, 1 = 32-bit byte offsets, 2 = 32-bit offsets into a dense table (ldx == F: a shift, no multiply)
-template <int F, int OFF32, bool FUSE_NEXT, int U, int PACE, int ABL = 0>
+// GAT: the attention layer on the same walk (amar_gat_lt_f32).  An entry (r, c) weighs w = exp(e_rc - M_r), e_rc =
+// LeakyReLU_0.2(s_self[r] + s_neigh[c]), against the row's fixed bound M_r = LeakyReLU(s_self[r] + max_j s_neigh[j]) >= max_c e_rc:
+// weights are then ADDITIVE (no running maximum), so virtual rows, in-register pairs and flagged repeats work as for the plain
+// sum; the LDS row carries (sum w.h, sum w, s_self[r]).  The softmax is invariant to the choice of M_r as long as nothing
+// underflows: a row whose weight sum stays below e^-60 is recomputed in the epilogue from the block's CSR with its true maximum.
+template <int F, int OFF32, bool FUSE_NEXT, int U, int PACE, int ABL = 0, bool GAT = false>
 __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtArgs a) {
-    constexpr int LPN = F / 4, EPS = AMAR_WAVE / LPN, RW = LT_TILE_BYTES / (4 * F * LT_WAVES), CS = LT_CHUNK / EPS;
+    constexpr int LPN = F / 4, EPS = AMAR_WAVE / LPN, RW = GAT ? lt_gat_rw(F) : LT_TILE_BYTES / (4 * F * LT_WAVES), CS = LT_CHUNK / EPS;
+    constexpr unsigned LMASK = (1u << lt_bits(RW)) - 1u;
     constexpr int G = U - 1;                                          // steps of gathers in flight ahead of the accumulation
     static_assert(CS % U == 0 && G < CS, "register slots of the in-flight steps must be static inside a chunk");
     extern __shared__ __attribute__((aligned(16))) float lt_lds[];
     float *ytile = lt_lds;                                            // [RW * LT_WAVES][F]
-    int32_t *ring_all = reinterpret_cast<int32_t *>(lt_lds + LT_WAVES * RW * F);   // [LT_WAVES][LT_CHUNK]
+    float2 *side = reinterpret_cast<float2 *>(lt_lds + LT_WAVES * RW * F);          // GAT: [RW * LT_WAVES] (sum of weights, s_self)
+    int32_t *ring_all = reinterpret_cast<int32_t *>(lt_lds + LT_WAVES * RW * (GAT ? F + 2 : F));   // [LT_WAVES][LT_CHUNK]
     unsigned *arrived = reinterpret_cast<unsigned *>(ring_all + LT_WAVES * LT_CHUNK);   // [8] arrival counters (PACE 2)
     const int t = blockIdx.x;
     const int lane = threadIdx.x & (AMAR_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r0 = a.tile_row0[t], nr = a.tile_row0[t + 1] - r0;
-    for (int i = threadIdx.x; i < LT_WAVES * RW * F / 4; i += LT_WAVES * AMAR_WAVE)
+    for (int i = threadIdx.x; i < LT_WAVES * RW * (GAT ? F + 2 : F) / 4; i += LT_WAVES * AMAR_WAVE)
         reinterpret_cast<float4 *>(ytile)[i] = f4_zero();
     if (threadIdx.x < 8) arrived[threadIdx.x] = 0;
     __syncthreads();
+    float bmax = 0.f;
+    if (GAT) {                                                        // every virtual row carries its row's s_self
+        bmax = *a.bmax;
+        const int vt = a.vcount[t];
+        for (int lr = threadIdx.x; lr < nr; lr += LT_WAVES * AMAR_WAVE) {
+            const int row = r0 + lr;
+            const float as = a.s_self_rows[row];
+            const int v0 = a.vstart[row], v1 = lr + 1 < nr ? a.vstart[row + 1] : vt;
+            for (int v = v0; v < v1; ++v) side[lt_lds_row(v)].y = as;
+        }
+        __syncthreads();
+    }
 
     const int s = lane / LPN, q = lane % LPN;                         // LPN adjacent lanes share an entry
     const int32_t *stream = a.words + a.stream_start[t * LT_WAVES + wave];
@@ -655,6 +682,7 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtA
     };
     int wd[U], wn[CS];                                                // words of the steps in flight / of the chunk being issued
     float4 x[U];
+    float bs[GAT ? U : 1];                                            // GAT: s_neigh of the steps in flight
     auto refill = [&](const v4i &pre) {                               // chunk registers -> LDS -> one word per (step, entry slot)
         *reinterpret_cast<v4i *>(ring + 4 * lane) = pre;
 #pragma unroll
@@ -668,15 +696,25 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtA
         else if (OFF32 == 2) x[slot] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.X) + ((col * (unsigned)F + 4u * q) * 4u));
         else if (OFF32 == 1) x[slot] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.X) + (col * (unsigned)a.ldx + 4u * q) * 4u);
         else x[slot] = *reinterpret_cast<const float4 *>(a.X + (int64_t)col * a.ldx + 4 * q);
+        if (GAT) bs[slot] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.s_neigh) + (uint64_t)col * 4u);
     };
     auto accumulate = [&](int slot) {
         const int w = wd[slot];
-        const int lrow = (int)(((unsigned)w >> a.cbits) & (unsigned)(RW - 1));
-        float *yp = ytile + (lrow * LT_WAVES + ((wave + lrow) & (LT_WAVES - 1))) * F + 4 * q;
+        const int lrow = (int)(((unsigned)w >> a.cbits) & LMASK);
+        const int lds_row = lrow * LT_WAVES + ((wave + lrow) & (LT_WAVES - 1));
+        float *yp = ytile + lds_row * F + 4 * q;
         float4 xv = x[slot];
         if (ABL & 2) {                                                // keep the gathers alive without LDS traffic
             if (xv.x == 123.f && xv.y == 4.f) *reinterpret_cast<float4 *>(yp) = xv;
             return;
+        }
+        float wgt = 0.f, lsum = 0.f;
+        if (GAT) {
+            const float2 sd = side[lds_row];                          // (sum of weights so far, s_self of the row)
+            lsum = sd.x;
+            const float z = sd.y + bs[slot], zz = sd.y + bmax;
+            wgt = __expf(fmaxf(z, 0.2f * z) - fmaxf(zz, 0.2f * zz));
+            xv.x *= wgt; xv.y *= wgt; xv.z *= wgt; xv.w *= wgt;
         }
         // implicit pair: same virtual row as the previous slot (row_shr: lane l reads l - LPN inside its 16-lane DPP row;
         // the first slot of a DPP row keeps -1) and not flagged -> its values go to that slot's registers, no LDS update
@@ -687,13 +725,19 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtA
         xv.y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.y), 0x100 + LPN, 0xF, 0xF, true));
         xv.z += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.z), 0x100 + LPN, 0xF, 0xF, true));
         xv.w += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.w), 0x100 + LPN, 0xF, 0xF, true));
+        if (GAT) {
+            const float gw = paired ? wgt : 0.f;
+            wgt += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gw), 0x100 + LPN, 0xF, 0xF, true));
+        }
         if (w >= 0 && !paired) {
             float4 y = *reinterpret_cast<float4 *>(yp);
             y = f4_add(y, xv);
             *reinterpret_cast<float4 *>(yp) = y;
+            if (GAT) side[lds_row].x = lsum + wgt;                    // the LPN lanes of the entry store the same value
         }
         if (!(ABL & 1) && w < 0) {                                    // the row occurs earlier in this step: after its plain add
             atomicAdd(yp + 0, xv.x); atomicAdd(yp + 1, xv.y); atomicAdd(yp + 2, xv.z); atomicAdd(yp + 3, xv.w);
+            if (GAT && q == 0) atomicAdd(&side[lds_row].x, wgt);
         }
     };
 
@@ -769,20 +813,66 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtA
         const int row = r0 + lr;
         const int v0 = a.vstart[row], v1 = lr + 1 < nr ? a.vstart[row + 1] : vtile;
         const float d = a.diag[row];
-        const float sc = a.row_scale[row];
         float4 acc[LPN];
+        if (GAT) {
+            // self term: the added self loop and any (i, i) edges of A itself, with the same bound as the walk
+            const float as = a.s_self_rows[row], bself = a.s_neigh_rows[row];
+            const float zz = as + bmax, zs = as + bself;
+            const float nself = d + (a.self_loop ? 1.f : 0.f);
+            const float ws = nself > 0.f ? nself * __expf(fmaxf(zs, 0.2f * zs) - fmaxf(zz, 0.2f * zz)) : 0.f;
+            float l = ws;
 #pragma unroll
-        for (int qq = 0; qq < LPN; ++qq) {
-            const float4 xs = *reinterpret_cast<const float4 *>(a.Xself + (int64_t)row * a.e.ldx + 4 * qq);
-            acc[qq] = make_float4(d * xs.x, d * xs.y, d * xs.z, d * xs.w);
+            for (int qq = 0; qq < LPN; ++qq) {
+                const float4 xs = *reinterpret_cast<const float4 *>(a.Xself + (int64_t)row * a.e.ldx + 4 * qq);
+                acc[qq] = make_float4(ws * xs.x, ws * xs.y, ws * xs.z, ws * xs.w);
+            }
+            for (int v = v0; v < v1; ++v) {
+                const int lv = lt_lds_row(v);
+                const float *yp = ytile + lv * F;
+#pragma unroll
+                for (int qq = 0; qq < LPN; ++qq) acc[qq] = f4_add(acc[qq], *reinterpret_cast<const float4 *>(yp + 4 * qq));
+                l += side[lv].x;
+            }
+            float inv;
+            if (l >= 8.7e-27f) inv = 1.f / l;                          // e^-60: the row's largest weight is a normal number
+            else {
+                // the bound is more than 60 above this row's own maximum (or the row is empty): Spektral's arithmetic on the
+                // block's CSR row, with the row's true maximum (gat_row_kernel's two passes, one lane)
+                const int beg = a.csr_rowptr[row], end = a.csr_rowptr[row + 1];
+                float mn = a.self_loop ? bself : -INFINITY;
+                for (int p = beg; p < end; ++p) mn = fmaxf(mn, a.s_neigh[a.csr_colidx[p]]);
+                const float zm = as + mn, emax = fmaxf(zm, 0.2f * zm);
+                l = 0.f;
+#pragma unroll
+                for (int qq = 0; qq < LPN; ++qq) acc[qq] = f4_zero();
+                for (int p = beg; p <= end; ++p) {
+                    if (p == end && !a.self_loop) break;
+                    const int64_t c = p < end ? (int64_t)a.csr_colidx[p] : (int64_t)(a.s_neigh_rows - a.s_neigh) + row;
+                    const float z = as + a.s_neigh[c];
+                    const float wv = __expf(fmaxf(z, 0.2f * z) - emax);
+                    l += wv;
+#pragma unroll
+                    for (int qq = 0; qq < LPN; ++qq) acc[qq] = f4_fma(wv, *reinterpret_cast<const float4 *>(a.X + c * a.ldx + 4 * qq), acc[qq]);
+                }
+                inv = 1.f / (l + 1e-9f);
+            }
+#pragma unroll
+            for (int qq = 0; qq < LPN; ++qq) { acc[qq].x *= inv; acc[qq].y *= inv; acc[qq].z *= inv; acc[qq].w *= inv; }
+        } else {
+            const float sc = a.row_scale[row];
+#pragma unroll
+            for (int qq = 0; qq < LPN; ++qq) {
+                const float4 xs = *reinterpret_cast<const float4 *>(a.Xself + (int64_t)row * a.e.ldx + 4 * qq);
+                acc[qq] = make_float4(d * xs.x, d * xs.y, d * xs.z, d * xs.w);
+            }
+            for (int v = v0; v < v1; ++v) {
+                const float *yp = ytile + lt_lds_row(v) * F;
+#pragma unroll
+                for (int qq = 0; qq < LPN; ++qq) acc[qq] = f4_add(acc[qq], *reinterpret_cast<const float4 *>(yp + 4 * qq));
+            }
+#pragma unroll
+            for (int qq = 0; qq < LPN; ++qq) { acc[qq].x *= sc; acc[qq].y *= sc; acc[qq].z *= sc; acc[qq].w *= sc; }
         }
-        for (int v = v0; v < v1; ++v) {
-            const float *yp = ytile + lt_lds_row(v) * F;
-#pragma unroll
-            for (int qq = 0; qq < LPN; ++qq) acc[qq] = f4_add(acc[qq], *reinterpret_cast<const float4 *>(yp + 4 * qq));
-        }
-#pragma unroll
-        for (int qq = 0; qq < LPN; ++qq) { acc[qq].x *= sc; acc[qq].y *= sc; acc[qq].z *= sc; acc[qq].w *= sc; }
         lane_row_epilogue<F, FUSE_NEXT>(a.e, row, acc);
     }
 }
@@ -829,6 +919,39 @@ int launch_spmm_lt(const LtArgs &a, int n_tiles, int off32, bool fuse, int varia
     else { if (fuse) AMAR_LT_LAUNCH(0, true, 4, 1, 0); else AMAR_LT_LAUNCH(0, false, 4, 1, 0); }
 #undef AMAR_LT_LAUNCH
     return amar_check_launch();
+}
+
+template <int F>
+int launch_gat_lt(const LtArgs &a, int n_tiles, int off32, hipStream_t st) {
+    constexpr int RW = lt_gat_rw(F);
+    const size_t lds = (size_t)LT_WAVES * RW * (F + 2) * 4 + (size_t)LT_WAVES * LT_CHUNK * 4 + 32;
+    static_assert((size_t)LT_WAVES * RW * (F + 2) * 4 + (size_t)LT_WAVES * LT_CHUNK * 4 + 32 <= (160u << 10), "one workgroup's LDS");
+    const dim3 grid((unsigned)n_tiles), block(LT_WAVES * AMAR_WAVE);
+#define AMAR_GAT_LT_LAUNCH(OFF)                                                                                          \
+    do {                                                                                                                 \
+        auto kern = spmm_lt_kernel<F, OFF, false, 4, 1, 0, true>;                                                        \
+        static bool once = false;                                                                                        \
+        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                               \
+    } while (0)
+    if (off32 == 2) AMAR_GAT_LT_LAUNCH(2); else if (off32 == 1) AMAR_GAT_LT_LAUNCH(1); else AMAR_GAT_LT_LAUNCH(0);
+#undef AMAR_GAT_LT_LAUNCH
+    return amar_check_launch();
+}
+
+// max over a vector, for the GAT bound: out is reset to -inf in-stream, blocks fold with the ordered-integer form of float max
+__global__ __launch_bounds__(256) void colmax_kernel(const float *__restrict__ x, int64_t n, float *out) {
+    float m = -INFINITY;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) m = fmaxf(m, x[i]);
+    m = wave_max_all(m);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+        if (m >= 0.f) atomicMax(reinterpret_cast<int *>(out), __builtin_bit_cast(int, m));      // non-negative floats order like ints,
+        else atomicMin(reinterpret_cast<unsigned *>(out), __builtin_bit_cast(unsigned, m));     // negative ones like reversed unsigneds
+    }
 }
 
 bool ld_ok(int64_t ld, int F) { return ld >= F && (ld & 3) == 0; }
@@ -1540,6 +1663,50 @@ int amar_spmm_lt_f32(const int32_t *words, const int32_t *stream_start, const in
     case 8:  return launch_spmm_lt<8>(a, n_tiles, off32, Wnext != nullptr, variant, st);
     case 16: return launch_spmm_lt<16>(a, n_tiles, off32, Wnext != nullptr, variant, st);
     default: return launch_spmm_lt<32>(a, n_tiles, off32, Wnext != nullptr, variant, st);
+    }
+}
+
+int amar_colmax_f32(const float *x, int64_t n, float *out, amar_stream_t stream) {
+    if (n < 0 || !out || (n > 0 && !x)) return AMAR_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(out), 0xFF800000u, 1, st) != hipSuccess) return amar_check_launch();   // -inf
+    if (n == 0) return AMAR_OK;
+    const int64_t blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(colmax_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, st, x, n, out);
+    return amar_check_launch();
+}
+
+int amar_gat_lt_rows_per_wave(int32_t C) { return (C == 8 || C == 16 || C == 32) ? lt_gat_rw(C) : 0; }
+
+int amar_gat_lt_f32(const int32_t *words, const int32_t *stream_start, const int32_t *wsteps, const int32_t *tile_row0,
+                    const int32_t *n_win, const int32_t *vstart, const int32_t *vcount, int32_t n_tiles, int32_t maxwin1, int32_t pace_every,
+                    const float *diag, const int32_t *rowptr, const int32_t *colidx,
+                    const float *H, int64_t ldh, int32_t C, const float *s_self, const float *s_neigh, const float *s_neigh_max,
+                    const float *bias, float *Y, int64_t ldy, int32_t self_loop, int32_t n_rows, int32_t n_cols, int32_t row_offset,
+                    amar_stream_t stream) {
+    if (n_rows < 0 || n_cols < 0 || n_tiles < 0 || maxwin1 < 1 || pace_every < 1 || (pace_every & (pace_every - 1)) || row_offset < 0) return AMAR_EINVAL;
+    if (n_rows == 0 || n_tiles == 0) return n_rows == 0 ? AMAR_OK : AMAR_EINVAL;
+    if (!words || !stream_start || !wsteps || !tile_row0 || !n_win || !vstart || !vcount || !diag || !rowptr || !colidx ||
+        !H || !s_self || !s_neigh || !s_neigh_max || !bias || !Y) return AMAR_EINVAL;
+    if (C != 8 && C != 16 && C != 32) return AMAR_EUNSUPPORTED;
+    if ((int64_t)row_offset + n_rows > n_cols) return AMAR_EINVAL;
+    const int cbits = 31 - lt_bits(lt_gat_rw(C));
+    if ((int64_t)n_cols > (int64_t(1) << cbits)) return AMAR_EUNSUPPORTED;
+    if (!ld_ok(ldh, C) || !amar_aligned16(H) || !ld_ok(ldy, C) || !amar_aligned16(Y) || !amar_aligned16(bias) || !amar_aligned16(words)) return AMAR_EINVAL;
+    LtArgs a{};
+    a.words = words; a.stream_start = stream_start; a.wsteps = wsteps; a.tile_row0 = tile_row0; a.n_win = n_win;
+    a.vstart = vstart; a.vcount = vcount;
+    a.maxwin1 = maxwin1; a.cbits = cbits; a.pace_mask = pace_every - 1;
+    a.X = H; a.ldx = ldh; a.Xself = H + (int64_t)row_offset * ldh; a.diag = diag; a.row_scale = nullptr;
+    a.s_neigh = s_neigh; a.bmax = s_neigh_max; a.s_self_rows = s_self + row_offset; a.s_neigh_rows = s_neigh + row_offset;
+    a.csr_rowptr = rowptr; a.csr_colidx = colidx; a.self_loop = self_loop ? 1 : 0;
+    a.e.X = H; a.e.ldx = ldh; a.e.Y = Y; a.e.ldy = ldy; a.e.bias = bias; a.e.relu = 1; a.e.n_rows = n_rows;
+    const int off32 = (int64_t)n_cols * ldh * 4 < (int64_t(1) << 32) ? (ldh == C ? 2 : 1) : 0;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    switch (C) {
+    case 8:  return launch_gat_lt<8>(a, n_tiles, off32, st);
+    case 16: return launch_gat_lt<16>(a, n_tiles, off32, st);
+    default: return launch_gat_lt<32>(a, n_tiles, off32, st);
     }
 }
 

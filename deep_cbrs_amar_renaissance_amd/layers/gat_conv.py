@@ -13,6 +13,8 @@ On the device: `amar_rowwise_xw_f32` (H and the two attention scalars per node) 
 node table exceeds the per-XCD L2s, `amar_gat_xs_f32` (XCD-sliced image, exact online softmax over (max, sum, weighted
 sum) triples).
 """
+import os
+
 import torch
 
 from deep_cbrs_amar_renaissance_amd import capi
@@ -56,7 +58,14 @@ class GATConv(Layer):
             out = torch.empty((n, c), dtype=torch.float32, device=x.device)
         # large graphs: XCD-sliced form, exact online softmax.  ml1m(s=64): C = 8 0.54 ms against 0.94 (row kernel), C = 16 0.94 / 1.08;
         # at C = 32 the XS form (4 entries per step) loses, 2.20 / 1.37, and is only used for the row blocks of a partition
-        if c in (8, 16) and spmm_kind(a, c) == 'xs':
+        kind = spmm_kind(a, c)
+        large = kind == 'xs' or (c == 32 and kind == 'csr' and not os.environ.get('AMAR_SPMM_KIND') and
+                                 a.shape[0] == a.shape[1] and a.shape[1] * c * 4 >= (16 << 20))
+        lt = a.tiled_gat_image(c) if c in (8, 16, 32) and large else None
+        if lt is not None:
+            # the LDS-tiled walk with additive softmax weights against a per-row bound (amar_gat_lt_f32)
+            capi.gat_lt(lt, a, h, s_self, s_neigh, self.bias, out, self_loop=self.add_self_loops)
+        elif c in (8, 16) and kind == 'xs':
             capi.gat_xs(a.xcd_sliced(), h, s_self, s_neigh, self.bias, out, self_loop=self.add_self_loops)
         else:
             capi.gat_layer(a.rowptr, a.colidx, h, s_self, s_neigh, self.bias, out, self_loop=self.add_self_loops)

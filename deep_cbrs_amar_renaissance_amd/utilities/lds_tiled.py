@@ -54,11 +54,14 @@ BALANCE_PASSES = 3
 COST_ENTRY, COST_LINE = 1.68, 1.71   # cycles per entry / per 128-byte line of X a tile touches (fit on ml1m(s=64), F = 8)
 
 
-def geometry(F):
-    """(entries per step, rows per wave in the LDS tile, column bits) for feature width F."""
+GAT_ROWS_PER_WAVE = {8: 216, 16: 124, 32: 64}      # amar_gat_lt_f32: the LDS row also holds (sum of weights, s_self) — csrc lt_gat_rw
+
+
+def geometry(F, rw=None):
+    """(entries per step, rows per wave in the LDS tile, column bits) for feature width F (rw: a smaller tile, GAT mode)."""
     eps = 64 // (F // 4)
-    rw = TILE_BYTES // (4 * F * WAVES)
-    lbits = rw.bit_length() - 1
+    rw = TILE_BYTES // (4 * F * WAVES) if rw is None else int(rw)
+    lbits = (rw - 1).bit_length()
     return eps, rw, 31 - lbits
 
 
@@ -70,8 +73,8 @@ def _run_starts(first, idx):
     return starts[torch.searchsorted(starts, idx, right=True) - 1]
 
 
-def supported(F, n_cols):
-    return F in (4, 8, 16, 32) and n_cols <= (1 << geometry(F)[2])
+def supported(F, n_cols, rw=None):
+    return F in (4, 8, 16, 32) and n_cols <= (1 << geometry(F, rw)[2])
 
 
 class LdsTiled:
@@ -92,14 +95,16 @@ class LdsTiled:
 
     @classmethod
     def build(cls, rows, cols, n_rows, n_cols, F, diag, row_scale, col_scale, diag_offset=0, window_entries=None, n_cu=N_CU,
-              split=SPLIT, balance=True, row_breaks=()):
+              split=SPLIT, balance=True, row_breaks=(), rw=None, split_growth=2.0):
         """`rows`/`cols`: int64 device tensors of the unit-weight off-diagonal entries (multiplicities expanded).
+        `rw`: LDS rows per wave when the tile is smaller than the plain sum's (GAT mode); `split_growth`: factor by which the
+        virtual-row length grows while the tiles do not fit the LDS (longer virtual rows repeat more often inside a step).
         `row_breaks`: rows at which a tile must end (node-type boundaries of a bipartite / tripartite graph with grouped ids:
         a tile that straddles one walks two column ranges at half the density each and runs ~25 % longer than its peers)."""
         dev = rows.device
         W = WAVES
-        eps, rw, cbits = geometry(F)
-        if not supported(F, n_cols):
+        eps, rw, cbits = geometry(F, rw)
+        if not supported(F, n_cols, rw):
             raise ValueError("LT image: F = {} with {} columns is outside the packed word's range".format(F, n_cols))
         vmax = W * (rw - 1)                                           # virtual rows a tile can hold
         m = int(rows.numel())
@@ -154,7 +159,7 @@ class LdsTiled:
                 del tb0, tile0
             if len(tb) - 1 <= wanted or split >= 4096:                # the LDS capacity forced extra tiles: cut long rows less finely
                 break
-            split *= 2
+            split = max(split + 1, int(split * split_growth))
         k_row = torch.from_numpy(k_row_np).to(dev)
         T = len(tb) - 1
         tb_t = torch.tensor(tb, dtype=torch.int64, device=dev)

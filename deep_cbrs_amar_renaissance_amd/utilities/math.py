@@ -469,6 +469,31 @@ def _csr_tiled_mean_image(self, F, self_loops=True):
 DeviceCSR.tiled_mean_image = _csr_tiled_mean_image
 
 
+def _csr_tiled_gat_image(self, C):
+    """The LDS-tiled image amar_gat_lt_f32 walks (capi.gat_lt) for an edge-list CSR (vals None, duplicates kept), or None where
+    the XCD-sliced / row forms stay: same density rule as lt_eligible, the tile geometry of the GAT mode (the LDS row also holds
+    the weight sum and s_self: lds_tiled.GAT_ROWS_PER_WAVE).  `diag` counts the (i, i) edges of the list itself."""
+    from deep_cbrs_amar_renaissance_amd.utilities import lds_tiled
+    forced = os.environ.get('AMAR_SPMM_LT')
+    rw = lds_tiled.GAT_ROWS_PER_WAVE.get(C)
+    ok = forced != '0' and self.vals is None and rw is not None and lds_tiled.supported(C, self.shape[1], rw) and \
+        (forced == '1' or self.nnz >= LT_MIN_DENSITY * lds_tiled.N_CU * self.shape[1])
+    if not ok:
+        return None
+    cache = self.__dict__.setdefault('_lt_gat_cache', {})
+    if C not in cache:
+        rows, cols, diag, diag_offset = _unit_entries(self, False)
+        ones = torch.ones(self.shape[0], dtype=torch.float32, device=diag.device)
+        breaks = tuple(getattr(self, 'row_breaks', ())) if not diag_offset else ()
+        cache[C] = lds_tiled.LdsTiled.build(rows, cols, self.shape[0], self.shape[1], C, diag, ones, None, diag_offset,
+                                            row_breaks=breaks, rw=rw, split_growth=1.25,   # ml1m(s=64), C = 8: 0.364 ms (x2: 0.398)
+                                            window_entries=int(os.environ['AMAR_LT_WINDOW']) if os.environ.get('AMAR_LT_WINDOW') else None)
+    return cache[C]
+
+
+DeviceCSR.tiled_gat_image = _csr_tiled_gat_image
+
+
 def _csr_tiled_image(self, F):
     """The image the large-graph SpMM of width F runs on: LdsTiled where eligible (capi.spmm_xs accepts both), else XcdSliced."""
     return self.lds_tiled(F) if lt_eligible(self, F) else self.xcd_sliced()

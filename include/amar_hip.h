@@ -281,6 +281,30 @@ int amar_gat_xs_f32(const int32_t *rowptr, const int32_t *colidx, int32_t n_slic
                     float *packed, float *partials, float *Y, int64_t ldy, int32_t self_loop, int32_t n_rows,
                     int32_t n_cols, int32_t row_offset, amar_stream_t stream);
 
+/* The same GAT layer (Spektral GATConv as instantiated at src/models/gnn.py:321-328) on the LDS-tiled image of the
+ * edge-list adjacency (layout as amar_spmm_lt_f32; every edge a unit entry, duplicates repeated), C = 8, 16 or 32.
+ * The LDS row of a virtual row holds (sum w.h [C], sum w, s_self of its row): RW = amar_gat_lt_rows_per_wave(C) rows per
+ * wave (216 / 124 / 64), cbits = 31 - ceil(log2(RW)).  An entry (i, j) weighs
+ *     w_ij = exp( LeakyReLU_0.2(s_self[i] + s_neigh[j]) - M_i ),   M_i = LeakyReLU_0.2(s_self[i] + *s_neigh_max)
+ * with *s_neigh_max >= every s_neigh (amar_colmax_f32 writes it): M_i bounds the row's maximum, so no running maximum is
+ * needed and the weights add up like the plain sum's entries; out_i = ReLU( (sum_j w_ij H_j) / (sum_j w_ij) + bias ) is
+ * Spektral's max-subtracted softmax up to rounding (its +1e-9 in the denominator, >= 1 there, is below fp32 resolution).
+ * A row whose weight sum stays below e^-60 (its own maximum lies more than 60 under the bound), and every empty row, is
+ * recomputed in the same launch from rowptr / colidx (the CSR of the same rows and columns, duplicates kept) with the row's true
+ * maximum and the 1e-9, exactly as amar_gat_layer_f32 does.  diag[i] = number of (i, i) edges in the list (they, and the added
+ * self loop when self_loop != 0, enter as the row's self term).  H, s_self, s_neigh cover the n_cols columns; row i of a row
+ * block (multi-GPU partition) is node row_offset + i.
+ */
+int amar_gat_lt_f32(const int32_t *words, const int32_t *stream_start, const int32_t *wsteps, const int32_t *tile_row0,
+                    const int32_t *n_win, const int32_t *vstart, const int32_t *vcount, int32_t n_tiles, int32_t maxwin1, int32_t pace_every,
+                    const float *diag, const int32_t *rowptr, const int32_t *colidx,
+                    const float *H, int64_t ldh, int32_t C, const float *s_self, const float *s_neigh, const float *s_neigh_max,
+                    const float *bias, float *Y, int64_t ldy, int32_t self_loop, int32_t n_rows, int32_t n_cols, int32_t row_offset,
+                    amar_stream_t stream);
+int amar_gat_lt_rows_per_wave(int32_t C);
+/* out[0] = max(x[0..n)) (-inf for n = 0), reset and folded in-stream: the bound amar_gat_lt_f32 takes. */
+int amar_colmax_f32(const float *x, int64_t n, float *out, amar_stream_t stream);
+
 /* ---- hybrid-head variants of econfigs/hybrid-gnn-tweaks*.yaml -----------------------
  * amar_attention_mix_f32      FusionLayer('attention') (src/layers/fusion.py:54-68) after the two products
  *                             TA = A . att_weight, TB = B . att_weight (amar_dense_f32, no bias): the softmax over the two

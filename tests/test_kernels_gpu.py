@@ -613,6 +613,82 @@ def test_gat_xcd_sliced(hip, n, avg_deg, seed, dup, self_loop, C):
     assert np.abs(got - y_row.cpu().numpy()).max() < 2e-5 * max(1.0, np.abs(want).max())
 
 
+@pytest.mark.parametrize('n,avg_deg,seed,dup', [(67, 9, 1, False), (1000, 9, 2, True), (300, 160, 3, False), (1030, 400, 4, True), (4097, 20, 5, False)])
+@pytest.mark.parametrize('self_loop', [True, False])
+@pytest.mark.parametrize('C', [8, 16, 32])
+def test_gat_lds_tiled(hip, n, avg_deg, seed, dup, self_loop, C):
+    """amar_gat_lt_f32 (LDS-tiled walk, additive weights against the per-row bound) against the row kernel and the dense
+    float64 softmax: several tiles, rows cut into virtual rows, duplicate edges, (i, i) edges of the list itself, empty rows;
+    attention scalars of moderate spread (the bound holds) and spread so widely that most rows take the exact fall-back."""
+    from deep_cbrs_amar_renaissance_amd.utilities import lds_tiled
+    from deep_cbrs_amar_renaissance_amd.utilities.math import _unit_entries
+    m = _rand_csr(n, avg_deg, seed=seed, dup=dup).tocoo()
+    a = _dev_csr(m, with_values=False)                              # self edges stay in the list
+    rows, cols, diag, off = _unit_entries(a, False)
+    assert seed != 2 or float(diag.sum()) > 0
+    rw = lds_tiled.GAT_ROWS_PER_WAVE[C]
+    assert rw == hip.load().amar_gat_lt_rows_per_wave(C)
+    lt = lds_tiled.LdsTiled.build(rows, cols, n, n, C, diag, torch.ones(n, device=DEV), None, off, n_cu=3, split=64, rw=rw, split_growth=1.25)
+    rng = np.random.default_rng(seed)
+    h = rng.standard_normal((n, C)).astype(np.float32)
+    b = rng.uniform(-0.3, 0.3, C).astype(np.float32)
+    for spread in (4.0, 60.0):
+        ss = (rng.standard_normal(n) * spread).astype(np.float32)
+        sn = (rng.standard_normal(n) * spread).astype(np.float32)
+        y_row, y_lt = torch.empty((n, C), device=DEV), torch.full((n, C), float('nan'), device=DEV)
+        hip.gat_layer(a.rowptr, a.colidx, _t(h), _t(ss), _t(sn), _t(b), y_row, self_loop=self_loop)
+        hip.gat_lt(lt, a, _t(h), _t(ss), _t(sn), _t(b), y_lt, self_loop=self_loop)
+        got = y_lt.cpu().numpy()
+        assert np.isfinite(got).all()
+        r, c = m.row, m.col
+        if self_loop:
+            r, c = np.concatenate([r, np.arange(n)]), np.concatenate([c, np.arange(n)])
+        e = ss.astype(np.float64)[r] + sn.astype(np.float64)[c]
+        e = np.where(e > 0, e, 0.2 * e)
+        mx = np.full(n, -np.inf); np.maximum.at(mx, r, e)
+        ex = np.exp(e - mx[r])
+        den = np.zeros(n); np.add.at(den, r, ex)
+        num = np.zeros((n, C)); np.add.at(num, r, ex[:, None] * h.astype(np.float64)[c])
+        want = np.maximum(num / (den + 1e-9)[:, None] + b, 0)
+        tol = 2e-5 * max(1.0, np.abs(want).max())
+        assert np.abs(got - want).max() < tol
+        assert np.abs(got - y_row.cpu().numpy()).max() < tol
+        again = torch.empty_like(y_lt)
+        hip.gat_lt(lt, a, _t(h), _t(ss), _t(sn), _t(b), again, self_loop=self_loop)
+        assert torch.equal(again, y_lt)                             # fixed summation order: reproducible bit for bit
+
+
+@pytest.mark.parametrize('C', [8, 16, 32])
+def test_gat_layer_on_lds_tiled(hip, C, monkeypatch):
+    """GATConv routed onto the LDS-tiled image (forced: the graph is far below the size rule) on a user-item-property graph
+    with duplicate links, against the oracle and the row-kernel route."""
+    from deep_cbrs_amar_renaissance_amd.layers.gat_conv import GATConv
+    g = helpers.tiny_graph(n_users=700, n_items=400, n_ratings=30000, seed=C, n_props=120, n_links=900)
+    e = _dev_csr(g['adj_uip'] if 'adj_uip' in g else g['adj'], with_values=False, drop_diagonal=True)
+    n = e.shape[0]
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((n, 8)).astype(np.float32)
+    layer = GATConv(C, dropout_rate=0.0, activation='relu')
+    layer.build([(n, 8), None])
+    helpers.randomize_biases(layer, seed=2)
+    monkeypatch.setenv('AMAR_SPMM_KIND', 'csr')
+    y_row = layer([_t(x), e])
+    monkeypatch.setenv('AMAR_SPMM_KIND', 'xs')
+    monkeypatch.setenv('AMAR_SPMM_LT', '1')
+    calls = []
+    monkeypatch.setattr(hip, 'gat_lt', lambda *a, _f=hip.gat_lt, **k: (calls.append(1), _f(*a, **k))[1])
+    y_lt = layer([_t(x), e])
+    assert calls, "the layer did not take the LDS-tiled route"
+    assert float((y_row - y_lt).abs().max()) < 2e-5
+    coo = e.to_scipy().tocoo() if hasattr(e, 'to_scipy') else None
+    if coo is not None:
+        w = layer.kernel.detach().cpu().numpy().reshape(8, C).astype(np.float64)
+        want, _ = ol.gat_conv(x.astype(np.float64), coo.col, coo.row, w, layer.attn_kernel_self.detach().cpu().numpy().reshape(C).astype(np.float64),
+                              layer.attn_kernel_neighs.detach().cpu().numpy().reshape(C).astype(np.float64),
+                              layer.bias.detach().cpu().numpy().astype(np.float64), self_loops=True)
+        assert rel_err(y_lt.cpu().numpy(), want) < 1e-5
+
+
 @pytest.mark.parametrize('n_slices', [16, 24, 5])
 def test_xcd_sliced_multi_phase(hip, n_slices, monkeypatch):
     """8 k slices processed in k phases (tables beyond the aggregate L2), and a slice count that is no multiple of 8: the

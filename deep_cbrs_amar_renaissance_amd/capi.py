@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'libamar_hip.so')
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 ACT_CODES = {None: ACT_NONE, 'linear': ACT_NONE, 'relu': ACT_RELU, 'sigmoid': ACT_SIGMOID}
-SPMM_BIAS, SPMM_RELU, SPMM_ACCUM, SPMM_ACCUM_DIV, SPMM_SCALE_NEXT = 1, 2, 4, 8, 16
+SPMM_BIAS, SPMM_RELU, SPMM_ACCUM, SPMM_ACCUM_DIV, SPMM_SCALE_NEXT, SPMM_SAGE_TAIL = 1, 2, 4, 8, 16, 32
 
 _P = ctypes.c_void_p
 _I32, _I64, _U32, _F32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_float
@@ -258,14 +258,24 @@ def spmm_xs(xs, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc
 
 
 def spmm_lt(lt, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc_div=None, Wnext=None, Hnext=None,
-            prescaled=False, scale_next=False):
+            prescaled=False, scale_next=False, sage_tail=None):
     """Y = A.X on the LDS-tiled image `lt` of a value-free A = S C S (utilities.lds_tiled.LdsTiled): one launch, the
-    row tile's sums in LDS, gathers in column order.  Keywords as spmm_xs (`prescaled`: X already holds S.X)."""
+    row tile's sums in LDS, gathers in column order.  Keywords as spmm_xs (`prescaled`: X already holds S.X).
+    sage_tail = (kernel [2F, F], bias [F]) on GraphSAGE's mean-aggregate image: Y = relu(l2_normalize([X || mean] . kernel + bias))
+    in the same launch (AMAR_SPMM_SAGE_TAIL)."""
     n_rows, n_cols = lt.shape
     F = X.shape[1]
+    if sage_tail is not None:
+        if bias is not None or relu or acc_out is not None or Wnext is not None or not prescaled or Y is None:
+            raise ValueError("spmm_lt: sage_tail takes the un-scaled table (prescaled=True), Y, and no other epilogue")
+        if Hnext is not None and tuple(Hnext.shape) != (n_rows, F):
+            raise ValueError("spmm_lt: with sage_tail, Hnext is a second [n_rows, F] copy of Y")
+        Wnext, bias = sage_tail
+        if tuple(Wnext.shape) != (2 * F, F) or not Wnext.is_contiguous() or bias.numel() != F:
+            raise ValueError("spmm_lt: sage_tail = (kernel [2F, F] contiguous, bias [F]) expected")
     if F != lt.F:
         raise ValueError("spmm_lt: the image was built for width {}, X is {} wide".format(lt.F, F))
-    flags = (SPMM_BIAS if bias is not None else 0) | (SPMM_RELU if relu else 0)
+    flags = (SPMM_SAGE_TAIL if sage_tail is not None else (SPMM_BIAS if bias is not None else 0) | (SPMM_RELU if relu else 0))
     if acc_out is not None:
         flags |= SPMM_ACCUM | (SPMM_ACCUM_DIV if acc_div is not None else 0)
         if acc_in is None or tuple(acc_in.shape) != (n_rows, F) or tuple(acc_out.shape) != (n_rows, F):
@@ -275,7 +285,9 @@ def spmm_lt(lt, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc
     if X.shape[0] != n_cols or lt.diag_offset + n_rows > X.shape[0]:
         raise ValueError("X must have one row per column of the matrix")
     Cn = 0
-    if Wnext is not None:
+    if sage_tail is not None:
+        Cn = F
+    elif Wnext is not None:
         if Wnext.shape[0] != F or not Wnext.is_contiguous() or Hnext is None or tuple(Hnext.shape) != (n_rows, Wnext.shape[1]):
             raise ValueError("spmm_lt: Wnext [F, Cn] contiguous and Hnext [n_rows, Cn] expected")
         Cn = Wnext.shape[1]

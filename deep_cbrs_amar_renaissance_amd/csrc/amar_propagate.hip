@@ -636,7 +636,9 @@ __device__ __forceinline__ int lt_lds_row(int v) {                    // virtual
 // weights are then ADDITIVE (no running maximum), so virtual rows, in-register pairs and flagged repeats work as for the plain
 // sum; the LDS row carries (sum w.h, sum w, s_self[r]).  The softmax is invariant to the choice of M_r as long as nothing
 // underflows: a row whose weight sum stays below e^-60 is recomputed in the epilogue from the block's CSR with its true maximum.
-template <int F, int OFF32, bool FUSE_NEXT, int U, int PACE, int ABL = 0, bool GAT = false>
+// SAGE: GraphSAGE's tail in the epilogue (AMAR_SPMM_SAGE_TAIL): the tile's sums are the mean aggregate; the row leaves as
+// relu(l2_normalize([x_i || agg_i] . W + b)) with W = e.Wn [2F, F], in sage_tail_kernel's order of operations.
+template <int F, int OFF32, bool FUSE_NEXT, int U, int PACE, int ABL = 0, bool GAT = false, bool SAGE = false>
 __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtArgs a) {
     constexpr int LPN = F / 4, EPS = AMAR_WAVE / LPN, RW = GAT ? lt_gat_rw(F) : LT_TILE_BYTES / (4 * F * LT_WAVES), CS = LT_CHUNK / EPS;
     constexpr unsigned LMASK = (1u << lt_bits(RW)) - 1u;
@@ -860,9 +862,11 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtA
             for (int qq = 0; qq < LPN; ++qq) { acc[qq].x *= inv; acc[qq].y *= inv; acc[qq].z *= inv; acc[qq].w *= inv; }
         } else {
             const float sc = a.row_scale[row];
+            float4 xself[SAGE ? LPN : 1];
 #pragma unroll
             for (int qq = 0; qq < LPN; ++qq) {
                 const float4 xs = *reinterpret_cast<const float4 *>(a.Xself + (int64_t)row * a.e.ldx + 4 * qq);
+                if (SAGE) xself[qq] = xs;
                 acc[qq] = make_float4(d * xs.x, d * xs.y, d * xs.z, d * xs.w);
             }
             for (int v = v0; v < v1; ++v) {
@@ -872,23 +876,60 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtA
             }
 #pragma unroll
             for (int qq = 0; qq < LPN; ++qq) { acc[qq].x *= sc; acc[qq].y *= sc; acc[qq].z *= sc; acc[qq].w *= sc; }
+            if (SAGE) {
+                float z[F];
+#pragma unroll
+                for (int c = 0; c < F; ++c) z[c] = 0.f;
+#pragma unroll
+                for (int half = 0; half < 2; ++half)
+#pragma unroll
+                    for (int qq = 0; qq < LPN; ++qq)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v = f4_get(half == 0 ? xself[qq] : acc[qq], j);
+                            const float *w = a.e.Wn + (int64_t)(half * F + 4 * qq + j) * F;      // wave-uniform: scalar loads (staged in LDS: slower)
+#pragma unroll
+                            for (int c = 0; c < F; ++c) z[c] = fmaf(v, w[c], z[c]);
+                        }
+                float sq = 0.f;
+#pragma unroll
+                for (int c = 0; c < F; ++c) { z[c] += a.e.bias[c]; sq = fmaf(z[c], z[c], sq); }
+                const float iv = rsqrtf(fmaxf(sq, 1e-12f));          // tf.nn.l2_normalize
+                float *y = a.e.Y + (int64_t)row * a.e.ldy;
+                float *y2 = a.e.Hn ? a.e.Hn + (int64_t)row * a.e.ldhn : nullptr;     // a dense copy for the next layer's gathers
+#pragma unroll
+                for (int c4 = 0; c4 < F; c4 += 4) {
+                    const float4 o = make_float4(fmaxf(z[c4] * iv, 0.f), fmaxf(z[c4 + 1] * iv, 0.f), fmaxf(z[c4 + 2] * iv, 0.f), fmaxf(z[c4 + 3] * iv, 0.f));
+                    *reinterpret_cast<float4 *>(y + c4) = o;
+                    if (y2) *reinterpret_cast<float4 *>(y2 + c4) = o;
+                }
+                continue;
+            }
         }
         lane_row_epilogue<F, FUSE_NEXT>(a.e, row, acc);
     }
 }
 
 template <int F>
-int launch_spmm_lt(const LtArgs &a, int n_tiles, int off32, bool fuse, int variant, hipStream_t st) {
+int launch_spmm_lt(const LtArgs &a, int n_tiles, int off32, bool fuse, int variant, bool sage, hipStream_t st) {
     constexpr int RW = LT_TILE_BYTES / (4 * F * LT_WAVES);
     const size_t lds = (size_t)LT_WAVES * RW * F * 4 + (size_t)LT_WAVES * LT_CHUNK * 4 + 32;
     const dim3 grid((unsigned)n_tiles), block(LT_WAVES * AMAR_WAVE);
-#define AMAR_LT_LAUNCH(OFF, FUSE, UU, PP, AA)                                                                           \
+#define AMAR_LT_LAUNCH_S(OFF, FUSE, UU, PP, AA, SS)                                                                     \
     do {                                                                                                                 \
-        auto kern = spmm_lt_kernel<F, OFF, FUSE, UU, PP, AA>;                                                            \
+        auto kern = spmm_lt_kernel<F, OFF, FUSE, UU, PP, AA, false, SS>;                                                 \
         static bool once = false;                                                                                        \
         if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } \
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                               \
     } while (0)
+#define AMAR_LT_LAUNCH(OFF, FUSE, UU, PP, AA) AMAR_LT_LAUNCH_S(OFF, FUSE, UU, PP, AA, false)
+    if constexpr (F >= 8) {
+        if (sage) {                                                   // GraphSAGE tail fused (the layer's input is a dense table or a concat slice)
+            if (off32 == 2) AMAR_LT_LAUNCH_S(2, false, 4, 1, 0, true); else if (off32 == 1) AMAR_LT_LAUNCH_S(1, false, 4, 1, 0, true);
+            else return AMAR_EUNSUPPORTED;
+            return amar_check_launch();
+        }
+    } else if (sage) return AMAR_EUNSUPPORTED;
     // variant (development, AMAR_LT_VARIANT; F = 8, dense table, no fused next layer only): see tools/exp_lt.py
     if constexpr (F == 8) {
         if (variant && off32 == 2 && !fuse) {
@@ -918,6 +959,7 @@ int launch_spmm_lt(const LtArgs &a, int n_tiles, int off32, bool fuse, int varia
     else if (off32 == 1) { if (fuse) AMAR_LT_LAUNCH(1, true, 4, 1, 0); else AMAR_LT_LAUNCH(1, false, 4, 1, 0); }
     else { if (fuse) AMAR_LT_LAUNCH(0, true, 4, 1, 0); else AMAR_LT_LAUNCH(0, false, 4, 1, 0); }
 #undef AMAR_LT_LAUNCH
+#undef AMAR_LT_LAUNCH_S
     return amar_check_launch();
 }
 
@@ -1640,7 +1682,12 @@ int amar_spmm_lt_f32(const int32_t *words, const int32_t *stream_start, const in
     if (accum && (!acc_in || !acc_out || !ld_ok(ld_acc_in, F) || !ld_ok(ld_acc_out, F) ||
                   !amar_aligned16(acc_in) || !amar_aligned16(acc_out))) return AMAR_EINVAL;
     if ((flags & AMAR_SPMM_ACCUM_DIV) && !(acc_div != 0.f)) return AMAR_EINVAL;
-    if (Wnext && (!Hnext || Cn < 1 || ldhn < Cn)) return AMAR_EINVAL;
+    const bool sage = flags & AMAR_SPMM_SAGE_TAIL;
+    if (sage) {                                                       // Wnext = the layer's kernel [2F, F], bias its bias, Y the layer's output
+        if (!Wnext || !bias || !Y || accum || (flags & (AMAR_SPMM_RELU | AMAR_SPMM_SCALE_NEXT))) return AMAR_EINVAL;
+        if (Cn != F || F < 8) return AMAR_EUNSUPPORTED;
+        if (Hnext && (!ld_ok(ldhn, F) || !amar_aligned16(Hnext))) return AMAR_EINVAL;
+    } else if (Wnext && (!Hnext || Cn < 1 || ldhn < Cn)) return AMAR_EINVAL;
     if (Wnext && Cn > 64) return AMAR_EUNSUPPORTED;
     if ((flags & AMAR_SPMM_SCALE_NEXT) && !Wnext) return AMAR_EINVAL;
     LtArgs a{};
@@ -1650,7 +1697,7 @@ int amar_spmm_lt_f32(const int32_t *words, const int32_t *stream_start, const in
     a.X = X; a.ldx = ldx; a.Xself = Xself; a.diag = diag; a.row_scale = row_scale;
     a.e.next_scale = (flags & AMAR_SPMM_SCALE_NEXT) ? row_scale : nullptr;
     a.e.X = X; a.e.ldx = ldx; a.e.Y = Y; a.e.ldy = ldy;
-    a.e.bias = (flags & AMAR_SPMM_BIAS) ? bias : nullptr; a.e.relu = (flags & AMAR_SPMM_RELU) ? 1 : 0;
+    a.e.bias = ((flags & AMAR_SPMM_BIAS) || sage) ? bias : nullptr; a.e.relu = (flags & AMAR_SPMM_RELU) ? 1 : 0;
     a.e.acc_in = acc_in; a.e.ld_acc_in = ld_acc_in; a.e.acc_out = acc_out; a.e.ld_acc_out = ld_acc_out;
     a.e.acc_div = acc_div; a.e.accum = accum ? 1 : 0; a.e.accum_div = (flags & AMAR_SPMM_ACCUM_DIV) ? 1 : 0;
     a.e.Wn = Wnext; a.e.Cn = Cn; a.e.Hn = Hnext; a.e.ldhn = ldhn; a.e.n_rows = n_rows;
@@ -1659,10 +1706,10 @@ int amar_spmm_lt_f32(const int32_t *words, const int32_t *stream_start, const in
     const int variant = venv ? atoi(venv) : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (F) {
-    case 4:  return launch_spmm_lt<4>(a, n_tiles, off32, Wnext != nullptr, variant, st);
-    case 8:  return launch_spmm_lt<8>(a, n_tiles, off32, Wnext != nullptr, variant, st);
-    case 16: return launch_spmm_lt<16>(a, n_tiles, off32, Wnext != nullptr, variant, st);
-    default: return launch_spmm_lt<32>(a, n_tiles, off32, Wnext != nullptr, variant, st);
+    case 4:  return launch_spmm_lt<4>(a, n_tiles, off32, Wnext != nullptr && !sage, variant, sage, st);
+    case 8:  return launch_spmm_lt<8>(a, n_tiles, off32, Wnext != nullptr && !sage, variant, sage, st);
+    case 16: return launch_spmm_lt<16>(a, n_tiles, off32, Wnext != nullptr && !sage, variant, sage, st);
+    default: return launch_spmm_lt<32>(a, n_tiles, off32, Wnext != nullptr && !sage, variant, sage, st);
     }
 }
 

@@ -163,8 +163,16 @@ class SequentialGNN(Model):
                 h = h_next
         else:
             capi.copy_columns(x, slices[0])
+            dense_in = x if x.stride(0) == widths[0] else None      # a dense copy of the layer's input, where one exists
             for k, layer in enumerate(layers):
-                layer([slices[k], a], out=slices[k + 1])
+                if dense_in is not None and hasattr(layer, 'wants_dense_input') and layer.wants_dense_input(a, widths[k]):
+                    # GraphSAGE on the LDS-tiled walk: gathers from a dense table, the launch also leaves the next layer's
+                    dense_next = torch.empty((n, widths[k + 1]), dtype=torch.float32, device=dev) if k + 1 < len(layers) else None
+                    layer([dense_in, a], out=slices[k + 1], dense_out=dense_next)
+                    dense_in = dense_next
+                else:
+                    layer([slices[k], a], out=slices[k + 1])
+                    dense_in = None
 
         out = self._reduce(cat, slices, widths)
         return (out, cat) if with_layers else out

@@ -409,7 +409,7 @@ def _csr_lds_tiled(self, F):
         rows, cols, diag, diag_offset = _unit_entries(self, True)
         col_scale = self.dinv.to(torch.float32).contiguous()
         n = self.shape[0]
-        breaks = tuple(b - diag_offset for b in getattr(self, 'row_breaks', ()))
+        breaks = tuple(b - diag_offset for b in (_row_breaks_of(self, rows, cols) if not diag_offset else getattr(self, 'row_breaks', None) or ()))
         cache[F] = LdsTiled.build(rows, cols, n, self.shape[1], F, diag, col_scale[diag_offset:diag_offset + n].contiguous(),
                                   col_scale, diag_offset, row_breaks=breaks,
                                   window_entries=int(os.environ['AMAR_LT_WINDOW']) if os.environ.get('AMAR_LT_WINDOW') else None)
@@ -440,6 +440,34 @@ def lt_eligible(a, F):
     return F in (8, 16, 32) and a.nnz >= LT_MIN_DENSITY * lds_tiled.N_CU * a.shape[1]
 
 
+def infer_row_breaks(rows, cols, n):
+    """Node-type boundaries of a graph with grouped ids (users | items [| properties], loaders.py:43-68), read off the
+    entries: rows [lo, b) form a type when none of their columns falls inside [lo, b) and b is the smallest column above
+    the diagonal.  The LDS-tiled builders end a tile there (a tile that straddles two types walks two column ranges at half
+    the density each and runs ~25 % longer than its peers).  Blocks narrower than n/16 are not taken for node types."""
+    breaks, lo = [], 0
+    off = rows != cols
+    for _ in range(4):
+        upper = off & (rows >= lo) & (cols > rows)
+        if not bool(upper.any()):
+            break
+        b = int(cols[upper].min())
+        if b - lo < max(1, n // 16) or n - b < max(1, n // 16):
+            break
+        if bool((off & (rows >= lo) & (rows < b) & (cols >= lo) & (cols < b)).any()):
+            break
+        breaks.append(b)
+        lo = b
+    return tuple(breaks)
+
+
+def _row_breaks_of(a, rows, cols):
+    """`a.row_breaks` where the builder of `a` recorded them, else inferred once from the entries (square matrices only)."""
+    if getattr(a, 'row_breaks', None) is None:
+        a.row_breaks = infer_row_breaks(rows, cols, a.shape[0]) if a.shape[0] == a.shape[1] and not getattr(a, 'diag_offset', 0) else ()
+    return tuple(a.row_breaks)
+
+
 def _csr_tiled_mean_image(self, F, self_loops=True):
     """GraphSAGE's mean aggregate of an edge-list CSR (vals None, duplicates kept) on whichever tiled image pays: the
     LDS-tiled one (value-free entries, diag = 1 for the added self loop, row_scale = 1 / count, X gathered as is: call
@@ -460,7 +488,7 @@ def _csr_tiled_mean_image(self, F, self_loops=True):
             inv = 1.0 / (deg + 1.0)
         else:
             inv = torch.where(deg > 0, 1.0 / deg.clamp(min=1.0), torch.zeros_like(deg))
-        breaks = tuple(getattr(self, 'row_breaks', ())) if not diag_offset else ()
+        breaks = _row_breaks_of(self, rows, cols) if not diag_offset else ()
         cache[key] = lds_tiled.LdsTiled.build(rows, cols, self.shape[0], self.shape[1], F, diag, inv.contiguous(), None, diag_offset,
                                               row_breaks=breaks)
     return cache[key]
@@ -484,7 +512,7 @@ def _csr_tiled_gat_image(self, C):
     if C not in cache:
         rows, cols, diag, diag_offset = _unit_entries(self, False)
         ones = torch.ones(self.shape[0], dtype=torch.float32, device=diag.device)
-        breaks = tuple(getattr(self, 'row_breaks', ())) if not diag_offset else ()
+        breaks = _row_breaks_of(self, rows, cols) if not diag_offset else ()
         cache[C] = lds_tiled.LdsTiled.build(rows, cols, self.shape[0], self.shape[1], C, diag, ones, None, diag_offset,
                                             row_breaks=breaks, rw=rw, split_growth=1.25,   # ml1m(s=64), C = 8: 0.364 ms (x2: 0.398)
                                             window_entries=int(os.environ['AMAR_LT_WINDOW']) if os.environ.get('AMAR_LT_WINDOW') else None)

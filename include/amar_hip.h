@@ -41,6 +41,10 @@ extern "C" {
 #define AMAR_SPMM_ACCUM     4u   /* acc_out = acc_in + y (LightGCN running layer sum)         */
 #define AMAR_SPMM_ACCUM_DIV 8u   /* ... and acc_out /= acc_div (ReductionLayer 'mean')        */
 #define AMAR_SPMM_SCALE_NEXT 16u /* amar_spmm_xs_f32, value-free image: Hnext[i] *= row_scale[i] */
+#define AMAR_SPMM_SAGE_TAIL 32u  /* amar_spmm_lt_f32 on GraphSAGE's mean-aggregate image (diag = self loop, row_scale = 1/count, X un-scaled):
+                                    Y[i] = relu(l2_normalize([X_i || mean_i] . Wnext + bias)), Wnext [2F, F] (Cn = F), the tail of
+                                    spektral GraphSageConv (src/models/gnn.py:354-361) in the same launch; Hnext (optional, ld ldhn) receives
+                                    a second copy of Y: a dense table for the next layer's gathers when Y is a concat slice */
 
 typedef void *amar_stream_t;
 

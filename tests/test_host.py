@@ -252,3 +252,25 @@ def test_pair_plan_is_a_permutation_with_xcd_affine_item_ranges(phases):
     assert torch.equal(out, u.double() * 1000 + i.double())
     with pytest.raises(ValueError):
         plan.check(u.clone(), i)
+
+
+def test_infer_row_breaks():
+    """Node-type boundaries read off the entries: users | items, users | items | properties, none for an ordinary graph."""
+    import torch
+    from deep_cbrs_amar_renaissance_amd.utilities.math import infer_row_breaks
+    rng = np.random.default_rng(0)
+    nu, ni, npr = 300, 200, 150
+    u, i = rng.integers(0, nu, 4000), rng.integers(0, ni, 4000) + nu
+    i[0], i[1] = nu, nu + ni - 1
+    rows, cols = np.concatenate([u, i]), np.concatenate([i, u])
+    t = lambda a: torch.from_numpy(a.astype(np.int64))
+    assert infer_row_breaks(t(rows), t(cols), nu + ni) == (nu,)
+    it, pr = rng.integers(0, ni, 900) + nu, rng.integers(0, npr, 900) + nu + ni
+    pr[0] = nu + ni
+    rows3, cols3 = np.concatenate([rows, it, pr]), np.concatenate([cols, pr, it])
+    assert infer_row_breaks(t(rows3), t(cols3), nu + ni + npr) == (nu, nu + ni)
+    # self edges do not hide the structure; an ordinary graph has none
+    assert infer_row_breaks(t(np.concatenate([rows, [5]])), t(np.concatenate([cols, [5]])), nu + ni) == (nu,)
+    r, c = rng.integers(0, 500, 5000), rng.integers(0, 500, 5000)
+    assert infer_row_breaks(t(np.concatenate([r, c])), t(np.concatenate([c, r])), 500) == ()
+    assert infer_row_breaks(t(np.zeros(0)), t(np.zeros(0)), 10) == ()

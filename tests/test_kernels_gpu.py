@@ -916,11 +916,13 @@ def test_pair_plan_scores_equal_direct(hip):
         rs.score_towers(tw, u.clone(), i, 0, nu, pair_plan=plan)
 
 
-@pytest.mark.parametrize('F', [8, 16])
+@pytest.mark.parametrize('F,C', [(8, 8), (16, 16), (32, 32), (16, 8)])
 @pytest.mark.parametrize('self_loops', [True, False])
-def test_sage_mean_on_lds_tiled(hip, F, self_loops, monkeypatch):
+def test_sage_mean_on_lds_tiled(hip, F, C, self_loops, monkeypatch):
     """GraphSAGE's mean aggregate on the LDS-tiled image (edge-list CSR with duplicate edges, optional self loop,
-    rows without edges) against the row kernel's aggregate, and the whole layer through it against the fused row kernel."""
+    rows without edges) against the row kernel's aggregate, and the whole layer through it against the fused row kernel:
+    C == F takes the tail fused into the SpMM launch (AMAR_SPMM_SAGE_TAIL), C != F the separate tail kernel; the layer's
+    input once as a dense table and once as a column slice of a wider buffer."""
     from deep_cbrs_amar_renaissance_amd.layers.graphsage_conv import GraphSageConv
     from deep_cbrs_amar_renaissance_amd.utilities.lds_tiled import LdsTiled
     g = helpers.tiny_graph(n_users=700, n_items=400, n_ratings=30000, seed=F, n_props=120, n_links=900)
@@ -938,7 +940,7 @@ def test_sage_mean_on_lds_tiled(hip, F, self_loops, monkeypatch):
     deg = (e.rowptr[1:] - e.rowptr[:-1]).float()
     want = (ref + x) / (deg + 1)[:, None] if self_loops else torch.where(deg[:, None] > 0, ref / deg.clamp(min=1)[:, None], torch.zeros_like(ref))
     assert float((agg - want).abs().max()) < 1e-5
-    layer = GraphSageConv(8, activation='relu', self_loops=self_loops)
+    layer = GraphSageConv(C, activation='relu', self_loops=self_loops)
     layer.build([(n, F), None])
     helpers.randomize_biases(layer, seed=2)
     monkeypatch.setenv('AMAR_SPMM_KIND', 'csr')
@@ -946,6 +948,13 @@ def test_sage_mean_on_lds_tiled(hip, F, self_loops, monkeypatch):
     monkeypatch.setenv('AMAR_SPMM_KIND', 'xs')
     y_lt = layer([x, e])
     assert float((y_row - y_lt).abs().max()) < 2e-5
+    wide = torch.zeros((n, F + 8), device=DEV)
+    wide[:, 4:4 + F] = x
+    y_slice = layer([wide[:, 4:4 + F], e], out=torch.full((n, C + 4), float('nan'), device=DEV)[:, 4:])
+    assert torch.equal(y_slice, y_lt)
+    dense = torch.full((n, C), float('nan'), device=DEV)           # the second, dense copy for the next layer's gathers
+    y_two = layer([x, e], out=torch.full((n, C + 4), float('nan'), device=DEV)[:, 4:], dense_out=dense)
+    assert torch.equal(dense, y_lt) and torch.equal(y_two, y_lt)
 
 
 def test_host_gcn_filter_route_keeps_the_factors(hip, monkeypatch):

@@ -17,7 +17,8 @@ under torchrun (WORLD_SIZE set) it is one rank.  Rank 0 prints ONE JSON line.  E
 `roofline` (dominant kernel = the fused GCN SpMM layer, algorithmic bytes nnz*8 + (N+1)*4 + 2*N*F*4
 per launch over its HIP-event time), `roofline_l2` (the same launch against the XS form's binding
 limit, one L2 line request per gathered row), `pair_stage`, `hybrid_head` (econfigs/hybrid-gnn.yaml
-grid1 head at the same scale: MFMA utilisation), `ml1m_s1` (the reference's real size) and
+grid1 head at the same scale: MFMA utilisation), `uip_graph` (econfigs/basic-gnn-uip-2relconf.yaml grid1: the same model on
+the user-item-property graph), `ml1m_s1` (the reference's real size) and
 `cpu_baseline` (the oracle timed on one host core on the SAME ml1m(s=1) graph, weights and pairs).
 """
 import argparse
@@ -297,6 +298,72 @@ def hybrid_head(dev, scale):
                            'mfma_frac': p * flop_pair / ms_pairs / 1e9 / MFMA_F32_PEAK_TFLOPS}}
 
 
+def uip_graph(dev, scale, steps):
+    """configs[2] / the graph of configs[4]: econfigs/basic-gnn-uip-2relconf.yaml grid1 — the same BasicGCN over the
+    user-item-PROPERTY graph (three node types, duplicate item-property links kept, preprocess.py:149-168) at the same
+    ml1m(s): hoisted step and the fused GCN layer's HIP-event time against the 8(d) bytes of that graph."""
+    from deep_cbrs_amar_renaissance_amd import capi, engine, parallel
+    from deep_cbrs_amar_renaissance_amd.data import synthetic
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter_device
+    data = synthetic.ml1m_device(scale, device=dev, with_props=True)
+    nu, ni, npr = data['n_users'], data['n_items'], data['n_props']
+    n = nu + ni + npr
+    rows = torch.cat([data['train_pos'][:, 0], data['item_prop'][:, 0]])
+    cols = torch.cat([data['train_pos'][:, 1], data['item_prop'][:, 1]])
+    a = gcn_filter_device(rows, cols, n)
+    engine.set_seed(42)
+    model = basic.BasicGCN(a, **GRID1)
+    model.n_users, model.n_items = nu, ni
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(42)
+    perm = torch.randperm(data['test'].shape[0], device=dev, generator=gen)
+    u = data['test'][perm, 0].to(torch.int32).contiguous()
+    i = data['test'][perm, 1].to(torch.int32).contiguous()
+    p = int(u.numel())
+    del data, perm, rows, cols
+    runner = parallel.SingleRunner(model, u, i)
+    events, names, raw = [], ('gcn_layer', 'spmm_xs', 'spmm_lt'), {}
+
+    def timed(fn):
+        def wrapper(*args, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(*args, **kw)
+            e1.record()
+            events.append((e0, e1))
+        return wrapper
+    runner.step()
+    for name in names:
+        raw[name] = getattr(capi, name)
+        setattr(capi, name, timed(raw[name]))
+    for _ in range(3):
+        runner.step()
+    torch.cuda.synchronize()
+    for name in names:
+        setattr(capi, name, raw[name])
+    layer_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events])) if events else float('nan')
+    prop_ms = runner.last_propagation_ms()
+    for _ in range(3):
+        runner.step_graphed()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        runner.step_graphed()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    f = GRID1['n_hiddens'][0]
+    alg = a.nnz * 8 + (n + 1) * 4 + 2 * n * f * 4
+    out = {'config': 'econfigs/basic-gnn-uip-2relconf.yaml grid1: BasicGCN d=8 L=2 on the user-item-property graph, ml1m(s={}): '
+                     'N={} nodes ({} users, {} items, {} properties), nnz(A_hat)={}, {} test pairs'.format(scale, n, nu, ni, npr, a.nnz, p),
+           'ms_per_step': 1e3 * dt, 'pairs_per_s': p / dt, 'propagation_ms': prop_ms,
+           'gcn_layer': {'avg_launch_ms': layer_ms, 'algorithmic_bytes_per_launch': alg,
+                         'achieved_gbps': alg / (layer_ms * 1e-3) / 1e9, 'frac_of_hbm_peak': alg / (layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
+    del runner, model, a
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse_args()
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -503,6 +570,7 @@ def main():
             del runner, model, a_hat, u_all, i_all
             torch.cuda.empty_cache()
             out['hybrid_head'] = hybrid_head(dev, args.scale)
+            out['uip_graph'] = uip_graph(dev, args.scale, args.steps)
             out['ml1m_s1'], s1 = ml1m_true_size(dev)
             out['cpu_baseline'] = cpu_baseline(s1)
         sys.stdout.flush()

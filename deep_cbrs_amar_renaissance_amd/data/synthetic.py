@@ -195,14 +195,17 @@ def write_dataset(ds, dirpath, bert_dim=None, kge_dim=None):
     return paths
 
 
-def ml1m_device(scale=64, seed=GRAPH_SEED, device=None):
+def ml1m_device(scale=64, seed=GRAPH_SEED, device=None, with_props=False):
     """ml1m(s) drawn directly in index space on the GPU (torch as plumbing), for large scales.
 
     Same shape laws as :func:`ml1m` (user activity, item popularity, 57.22 % positives, 80/20
     split) but a different random stream: torch's device generator instead of numpy, and a
     single draw-and-dedupe round.  Returns a dict of device tensors:
     ``train_pos`` [E, 2] (user index, item index + |U|) of positive train ratings,
-    ``test`` [P, 2] pairs, plus ``n_users``, ``n_items``.  Used by bench.py only.
+    ``test`` [P, 2] pairs, plus ``n_users``, ``n_items``.  with_props: also ``item_prop`` [L, 2] (item index + |U|,
+    property index + |U| + |I|) and ``n_props`` — the RS2 item-property links of :func:`ml1m` (every property linked at
+    least once, heavy-tailed property degree, ~3 % duplicate (item, property) pairs, carriers among the train items).
+    Used by bench.py only.
     """
     import torch
     s = int(scale)
@@ -231,4 +234,19 @@ def ml1m_device(scale=64, seed=GRAPH_SEED, device=None):
     tr = liked & ~is_test
     train_pos = torch.stack([u[tr], i[tr] + n_users], dim=1)
     test = torch.stack([u[is_test], i[is_test] + n_users], dim=1)
-    return {'train_pos': train_pos, 'test': test, 'n_users': n_users, 'n_items': n_items, 'scale': s}
+    out = {'train_pos': train_pos, 'test': test, 'n_users': n_users, 'n_items': n_items, 'scale': s}
+    if with_props:
+        n_props, n_links = ML1M_PROPS_RS2 * s, ML1M_PROP_LINKS_RS2 * s
+        train_items = torch.nonzero(train_cnt > 0).view(-1)
+        carriers = train_items[torch.randperm(train_items.numel(), device=device, generator=gen)[:ML1M_ITEMS_WITH_PROPS * s]]
+        tail = (n_props * torch.rand(n_links - n_props, device=device, generator=gen, dtype=torch.float64) ** 2.5).long().clamp_(0, n_props - 1)
+        p_idx = torch.cat([torch.arange(n_props, device=device), tail])
+        it_idx = carriers[torch.randint(0, carriers.numel(), (n_links,), device=device, generator=gen)]
+        n_dup = int(0.03 * n_links)
+        src = torch.randint(0, n_links, (n_dup,), device=device, generator=gen)
+        dst = n_props + torch.randperm(n_links - n_props, device=device, generator=gen)[:n_dup]
+        src_it, src_p = it_idx[src].clone(), p_idx[src].clone()
+        it_idx[dst], p_idx[dst] = src_it, src_p
+        out['item_prop'] = torch.stack([it_idx + n_users, p_idx + n_users + n_items], dim=1)
+        out['n_props'] = n_props
+    return out

@@ -65,6 +65,14 @@ def main():
         t = timeit(lambda: capi.spmm_lt(lt, xs_tab, yb, prescaled=True))
         print('   rows of type %d alone (%d rows, %d entries): %d tiles, window %d, %.4f ms' % (k, r1 - r0, int(sel.sum()), lt.n_tiles, lt.window_entries, t), flush=True)
         del lt
+        # the same rows on the CSR row-streaming kernel: values s_i . c_ij on the pre-scaled table (the diagonal is an ordinary entry)
+        rp = a.rowptr[r0:r1 + 1]
+        rows_all = torch.repeat_interleave(torch.arange(n, device=dev), (a.rowptr[1:] - a.rowptr[:-1]).long())
+        vals2 = (a.mult.to(torch.float32) * cs[rows_all]).contiguous()
+        yc = torch.empty((r1 - r0, F), device=dev)
+        t = timeit(lambda: capi.spmm_csr(rp, a.colidx, vals2, xs_tab, yc))
+        print('      ... on the CSR row kernel: %.4f ms, max |diff| %.2e' % (t, float((yc - yb).abs().max())), flush=True)
+        del rows_all, vals2
 
 
 if __name__ == '__main__':

@@ -698,7 +698,7 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtA
         else if (OFF32 == 2) x[slot] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.X) + ((col * (unsigned)F + 4u * q) * 4u));
         else if (OFF32 == 1) x[slot] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.X) + (col * (unsigned)a.ldx + 4u * q) * 4u);
         else x[slot] = *reinterpret_cast<const float4 *>(a.X + (int64_t)col * a.ldx + 4 * q);
-        if (GAT) bs[slot] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.s_neigh) + (uint64_t)col * 4u);
+        if (GAT) bs[slot] = (ABL & 8) ? 0.25f : *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.s_neigh) + (uint64_t)col * 4u);
     };
     auto accumulate = [&](int slot) {
         const int w = wd[slot];
@@ -712,10 +712,10 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtA
         }
         float wgt = 0.f, lsum = 0.f;
         if (GAT) {
-            const float2 sd = side[lds_row];                          // (sum of weights so far, s_self of the row)
+            const float2 sd = (ABL & 16) ? make_float2(0.f, 0.5f) : side[lds_row];   // (sum of weights so far, s_self of the row)
             lsum = sd.x;
             const float z = sd.y + bs[slot], zz = sd.y + bmax;
-            wgt = __expf(fmaxf(z, 0.2f * z) - fmaxf(zz, 0.2f * zz));
+            wgt = (ABL & 32) ? z * 0.01f : __expf(fmaxf(z, 0.2f * z) - fmaxf(zz, 0.2f * zz));
             xv.x *= wgt; xv.y *= wgt; xv.z *= wgt; xv.w *= wgt;
         }
         // implicit pair: same virtual row as the previous slot (row_shr: lane l reads l - LPN inside its 16-lane DPP row;
@@ -735,7 +735,7 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtA
             float4 y = *reinterpret_cast<float4 *>(yp);
             y = f4_add(y, xv);
             *reinterpret_cast<float4 *>(yp) = y;
-            if (GAT) side[lds_row].x = lsum + wgt;                    // the LPN lanes of the entry store the same value
+            if (GAT && !(ABL & 16)) side[lds_row].x = lsum + wgt;     // the LPN lanes of the entry store the same value
         }
         if (!(ABL & 1) && w < 0) {                                    // the row occurs earlier in this step: after its plain add
             atomicAdd(yp + 0, xv.x); atomicAdd(yp + 1, xv.y); atomicAdd(yp + 2, xv.z); atomicAdd(yp + 3, xv.w);
@@ -994,15 +994,31 @@ int launch_gat_lt(const LtArgs &a, int n_tiles, int off32, hipStream_t st) {
     const size_t lds = (size_t)LT_WAVES * RW * (F + 2) * 4 + (size_t)LT_WAVES * LT_CHUNK * 4 + 32;
     static_assert((size_t)LT_WAVES * RW * (F + 2) * 4 + (size_t)LT_WAVES * LT_CHUNK * 4 + 32 <= (160u << 10), "one workgroup's LDS");
     const dim3 grid((unsigned)n_tiles), block(LT_WAVES * AMAR_WAVE);
-#define AMAR_GAT_LT_LAUNCH(OFF)                                                                                          \
+#define AMAR_GAT_LT_LAUNCH_A(OFF, AA)                                                                                    \
     do {                                                                                                                 \
-        auto kern = spmm_lt_kernel<F, OFF, false, 4, 1, 0, true>;                                                        \
+        auto kern = spmm_lt_kernel<F, OFF, false, 4, 1, AA, true>;                                                       \
         static bool once = false;                                                                                        \
         if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } \
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                               \
     } while (0)
+#define AMAR_GAT_LT_LAUNCH(OFF) AMAR_GAT_LT_LAUNCH_A(OFF, 0)
+    if constexpr (F == 8) {                                           // development ablations (wrong results): tools/exp_gat_lt.py
+        static const int abl = getenv("AMAR_GAT_ABL") ? atoi(getenv("AMAR_GAT_ABL")) : 0;
+        if (abl && off32 == 2) {
+            switch (abl) {
+            case 8:  AMAR_GAT_LT_LAUNCH_A(2, 8); break;               // no s_neigh gather
+            case 16: AMAR_GAT_LT_LAUNCH_A(2, 16); break;              // no side-array traffic
+            case 24: AMAR_GAT_LT_LAUNCH_A(2, 24); break;
+            case 32: AMAR_GAT_LT_LAUNCH_A(2, 32); break;              // no exp
+            case 56: AMAR_GAT_LT_LAUNCH_A(2, 56); break;
+            default: return AMAR_EINVAL;
+            }
+            return amar_check_launch();
+        }
+    }
     if (off32 == 2) AMAR_GAT_LT_LAUNCH(2); else if (off32 == 1) AMAR_GAT_LT_LAUNCH(1); else AMAR_GAT_LT_LAUNCH(0);
 #undef AMAR_GAT_LT_LAUNCH
+#undef AMAR_GAT_LT_LAUNCH_A
     return amar_check_launch();
 }
 

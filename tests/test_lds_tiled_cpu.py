@@ -32,12 +32,13 @@ def _gcn_csr(n_users, n_items, n_ratings, seed, dup=True):
     return csr, gcn_filter(sym)
 
 
-def walk(lt, xs):
+def walk(lt, xs, rw=None):
     """What spmm_lt_kernel computes, in its order: per tile, per wave, steps of EPS words; implicit pairs folded into the
     previous slot, plain read-add-writes (which must hit distinct LDS rows), then the flagged adds; epilogue over the
     row's virtual rows."""
     F = lt.F
-    eps, rw, cbits = lds_tiled.geometry(F)
+    eps, rw, cbits = lds_tiled.geometry(F, rw)
+    lmask = (1 << (rw - 1).bit_length()) - 1
     W = lds_tiled.WAVES
     spr = max(1, 16 // (F // 4))
     words = lt.words.numpy().astype(np.int64) & 0xffffffff
@@ -58,7 +59,7 @@ def walk(lt, xs):
             assert beg % lds_tiled.CHUNK == 0
             for k in range(total):
                 ws = words[beg + k * eps: beg + (k + 1) * eps]
-                lrow = (ws >> cbits) & (rw - 1)
+                lrow = (ws >> cbits) & lmask
                 col = ws & ((1 << cbits) - 1)
                 flag = (ws >> 31).astype(bool)
                 vals = xs[col].copy()
@@ -133,3 +134,66 @@ def test_lt_rejects_too_many_columns():
     with pytest.raises(ValueError):
         lds_tiled.LdsTiled.build(torch.zeros(1, dtype=torch.int64), torch.zeros(1, dtype=torch.int64), 4, (1 << 23) + 1, 8,
                                  torch.ones(4), torch.ones(4), torch.ones(4))
+
+
+def _uip_entries(seed):
+    """users | items | many low-degree property rows (duplicate links kept), symmetrised unit entries."""
+    rng = np.random.default_rng(seed)
+    nu, ni, npr = 90, 60, 400
+    u, i = rng.integers(0, nu, 2500), rng.integers(0, ni, 2500) + nu
+    it, pr = rng.integers(0, ni, 900) + nu, rng.integers(0, npr, 900) + nu + ni
+    r, c = np.concatenate([u, it]), np.concatenate([i, pr])
+    return np.concatenate([r, c]), np.concatenate([c, r]), nu + ni + npr, (nu, nu + ni)
+
+
+@pytest.mark.parametrize('F,rw', [(8, 12), (8, None), (16, 10)])
+def test_lt_image_three_node_types_and_small_tiles(F, rw):
+    """A user-item-property graph with forced breaks at the type boundaries, also with a tile far smaller than the plain
+    sum's (the GAT mode's geometry argument, here tiny so that the LDS capacity binds): the walk still gives the product,
+    no tile straddles a boundary, and the property rows — whose COUNT needs more tiles than their share of the entries —
+    get those tiles without the split being raised for everyone."""
+    rows, cols, n, breaks = _uip_entries(F)
+    rng = np.random.default_rng(1)
+    diag = torch.from_numpy(rng.integers(0, 3, n).astype(np.float32))
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, n).astype(np.float32))
+    lt = lds_tiled.LdsTiled.build(torch.from_numpy(rows), torch.from_numpy(cols), n, n, F, diag, scale, None, 0, n_cu=4, split=32,
+                                  row_breaks=breaks, rw=rw, split_growth=1.25)
+    xs = rng.standard_normal((n, F)).astype(np.float32)
+    got = walk(lt, xs, rw)
+    a = sparse.coo_matrix((np.ones(len(rows)), (rows, cols)), shape=(n, n)).tocsr()
+    want = scale.numpy()[:, None].astype(np.float64) * (diag.numpy()[:, None] * xs.astype(np.float64) + a @ xs.astype(np.float64))
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-5)
+    tb = lt.tile_row0.numpy()
+    assert all(b in tb for b in breaks), "a tile straddles a node-type boundary"
+    if rw is not None:
+        vmax = lds_tiled.WAVES * (rw - 1)
+        assert int((tb[:-1] >= breaks[1]).sum()) >= -(-400 // vmax)
+        deg = np.bincount(rows, minlength=n)
+        heavy = int(np.argmax(deg[:breaks[1]]))                     # the heaviest user / item row is still cut every 32 entries
+        t = int(np.searchsorted(tb, heavy, side='right') - 1)
+        vs = lt.vstart.numpy()
+        k = (vs[heavy + 1] if heavy + 1 < tb[t + 1] else int(lt.vcount[t])) - vs[heavy]
+        assert k == -(-deg[heavy] // 32)
+
+
+def test_lt_image_row_block_with_column_offset():
+    """A row block of a larger matrix (multi-GPU partition): rows [lo, hi) against all columns, own rows at column offset lo."""
+    rows, cols, n, _ = _uip_entries(3)
+    lo, hi = 40, 130
+    sel = (rows >= lo) & (rows < hi)
+    rng = np.random.default_rng(2)
+    diag = torch.from_numpy(rng.integers(0, 2, hi - lo).astype(np.float32))
+    scale = torch.from_numpy(rng.uniform(0.5, 1.5, hi - lo).astype(np.float32))
+    lt = lds_tiled.LdsTiled.build(torch.from_numpy(rows[sel] - lo), torch.from_numpy(cols[sel]), hi - lo, n, 8, diag, scale, None, lo, n_cu=2)
+    xs = rng.standard_normal((n, 8)).astype(np.float32)
+    got = walk(lt, xs)
+    a = sparse.coo_matrix((np.ones(int(sel.sum())), (rows[sel] - lo, cols[sel])), shape=(hi - lo, n)).tocsr()
+    want = scale.numpy()[:, None].astype(np.float64) * (diag.numpy()[:, None] * xs[lo:hi].astype(np.float64) + a @ xs.astype(np.float64))
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-5)
+
+
+def test_lt_geometry_tables():
+    assert lds_tiled.geometry(8) == (32, 256, 23) and lds_tiled.geometry(16) == (16, 128, 24) and lds_tiled.geometry(32) == (8, 64, 25)
+    assert lds_tiled.geometry(8, 216) == (32, 216, 23) and lds_tiled.geometry(16, 124) == (16, 124, 24)
+    for C, rw in lds_tiled.GAT_ROWS_PER_WAVE.items():               # one workgroup's LDS: rows + (sum w, s_self) + the index ring
+        assert lds_tiled.WAVES * rw * (C + 2) * 4 + lds_tiled.WAVES * lds_tiled.CHUNK * 4 + 32 <= 160 * 1024

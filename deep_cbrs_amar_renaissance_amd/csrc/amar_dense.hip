@@ -10,6 +10,7 @@
 //   LDS images are k-major so that the MFMA operand fetch (lane l: row/col l&31, k = l>>5)
 //   is a conflict-free ds_read_b32 for A and B alike.
 #include "amar_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -33,7 +34,11 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
-template <bool VEC_X, bool VEC_W>
+// FULL: K a multiple of BK, N of BN, vector-aligned operands, W not transposed — the staging loads carry no guards (rows past
+// M re-read row M - 1 and are dropped by the epilogue): the k loop is straight-line code.  On gfx950 an fp32 MFMA holds the
+// SIMD's VALU port, so the ~100 scalar / vector instructions and the dozen divergent branches the guarded staging costs per
+// k-tile came straight out of the matrix pipe's time (768 -> 256 -> 64 towers: 57 % of the fp32 MFMA peak with them).
+template <bool VEC_X, bool VEC_W, bool FULL = false>
 __global__ __launch_bounds__(256) void dense_mfma_kernel(const DenseArgs a) {
     __shared__ float As[BK * A_LD];
     __shared__ float Bs[BK * B_LD];
@@ -55,9 +60,12 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const DenseArgs a) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int64_t m = m0 + xr + 64 * h;
-        src_row[h] = m < a.M ? (a.ids ? (int64_t)a.ids[m] : m) : -1;
+        if (FULL) { const int64_t mc = m < a.M ? m : a.M - 1; src_row[h] = a.ids ? (int64_t)a.ids[mc] : mc; }
+        else src_row[h] = m < a.M ? (a.ids ? (int64_t)a.ids[m] : m) : -1;
     }
     const int wk = tid >> 4, wq = tid & 15;
+    const float *xp0 = a.X + src_row[0] * a.ldx + 4 * xq, *xp1 = a.X + src_row[1] * a.ldx + 4 * xq;   // FULL: this thread's staging sources
+    const float *wp = a.W + (int64_t)wk * a.N + n0 + 4 * wq;
 
     f32x16 acc0, acc1;
 #pragma unroll
@@ -66,6 +74,14 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const DenseArgs a) {
     // global -> registers for the k-tile that starts at k0
     float xa[2][4], wb[4];
     auto fetch = [&](int k0) {
+        if (FULL) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(xp0 + k0), v1 = *reinterpret_cast<const float4 *>(xp1 + k0);
+            const float4 w4 = *reinterpret_cast<const float4 *>(wp + (int64_t)k0 * a.N);
+            xa[0][0] = v0.x; xa[0][1] = v0.y; xa[0][2] = v0.z; xa[0][3] = v0.w;
+            xa[1][0] = v1.x; xa[1][1] = v1.y; xa[1][2] = v1.z; xa[1][3] = v1.w;
+            wb[0] = w4.x; wb[1] = w4.y; wb[2] = w4.z; wb[3] = w4.w;
+            return;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int k = k0 + 4 * xq;
@@ -197,7 +213,9 @@ int amar_dense_f32(const float *X, int64_t ldx, const int32_t *ids,
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool vx = (ldx & 3) == 0 && amar_aligned16(X);
     const bool vw = (N & 3) == 0 && amar_aligned16(W);
-    if (vx && vw) hipLaunchKernelGGL((dense_mfma_kernel<true, true>), grid, block, 0, st, a);
+    static const bool no_full = getenv("AMAR_DENSE_FULL") && atoi(getenv("AMAR_DENSE_FULL")) == 0;     // development switch (A/B timing)
+    if (vx && vw && !w_trans && K % BK == 0 && N % BN == 0 && !no_full) hipLaunchKernelGGL((dense_mfma_kernel<true, true, true>), grid, block, 0, st, a);
+    else if (vx && vw) hipLaunchKernelGGL((dense_mfma_kernel<true, true>), grid, block, 0, st, a);
     else if (vx) hipLaunchKernelGGL((dense_mfma_kernel<true, false>), grid, block, 0, st, a);
     else if (vw) hipLaunchKernelGGL((dense_mfma_kernel<false, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((dense_mfma_kernel<false, false>), grid, block, 0, st, a);

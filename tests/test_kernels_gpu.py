@@ -254,6 +254,22 @@ def test_dense(hip, M, K, N, act):
     assert rel_err(y.cpu().numpy(), want) < 3e-6
 
 
+def test_dense_guard_free_form_with_row_gather(hip):
+    """The guard-free staging form of amar_dense_f32 (K % 16 == 0, N % 64 == 0): row gather through ids, a last row tile that is
+    mostly past M (those lanes re-read row M - 1 and are dropped), all three activations."""
+    rng = np.random.default_rng(5)
+    table = rng.standard_normal((400, 48)).astype(np.float32)
+    for M in (1, 129, 333):
+        ids = rng.integers(7, 400, size=M).astype(np.int32)
+        w = rng.uniform(-0.3, 0.3, (48, 128)).astype(np.float32)
+        b = rng.uniform(-0.2, 0.2, 128).astype(np.float32)
+        for act in ('relu', 'sigmoid', None):
+            y = torch.full((M, 128), float('nan'), device=DEV)
+            hip.dense(_t(table), _t(w), _t(b), y, act=act, ids=_t(ids))
+            want = ol.dense(table[ids].astype(np.float64), w.astype(np.float64), b.astype(np.float64), act)
+            assert rel_err(y.cpu().numpy(), want) < 3e-6
+
+
 def test_dense_gather_and_concat_slices(hip):
     """embedding_lookup fused into the load (basic.py:73-74) + two producers filling one concat buffer (basic.py:35)."""
     rng = np.random.default_rng(0)

@@ -109,3 +109,77 @@ def test_full_size_scoring_properties(hip, big):
     users2, top_items2, top_scores2 = metrics.top_k_arrays(again_u, top_items[valid], top_scores[valid], 10)
     assert np.array_equal(users, users2) and np.array_equal(top_items, top_items2) and np.array_equal(top_scores, top_scores2)
     assert (np.diff(np.where(valid, top_scores, -1.0), axis=1) <= 0).all()             # every list is sorted (scores lie in [0, 1])
+
+
+def _edge_csr(big):
+    """The raw edge list GraphSAGE / GAT take at full size: A_hat's pattern without its diagonal, no values."""
+    from deep_cbrs_amar_renaissance_amd.utilities.math import DeviceCSR
+    a, n = big['a'], big['n']
+    dev = a.rowptr.device
+    rp = a.rowptr.long()
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), rp[1:] - rp[:-1])
+    keep = rows != a.colidx.long()
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(torch.bincount(rows[keep], minlength=n), 0)
+    return DeviceCSR(rowptr.to(torch.int32), a.colidx[keep].contiguous(), None, (n, n))
+
+
+def test_full_size_gat_and_sage_on_the_lds_tiled_walk(hip, big, monkeypatch):
+    """ml1m(s=64): the layers' default route (LDS-tiled walk: amar_gat_lt_f32, fused GraphSAGE tail; node-type boundary inferred
+    from the entries) against the row-kernel route, 200 sampled rows of the GAT layer against float64 host arithmetic, and the
+    softmax invariance the GAT form rests on: shifting every s_neigh by a constant changes the bound, not the result."""
+    from deep_cbrs_amar_renaissance_amd.layers.gat_conv import GATConv
+    from deep_cbrs_amar_renaissance_amd.layers.graphsage_conv import GraphSageConv
+    from deep_cbrs_amar_renaissance_amd.utilities.lds_tiled import LdsTiled
+    from tests import helpers
+    e, n = _edge_csr(big), big['n']
+    dev = e.rowptr.device
+    g = torch.Generator(device=dev); g.manual_seed(11)
+    x = torch.randn((n, 8), device=dev, generator=g)
+    calls = []
+    for name in ('gat_lt', 'spmm_lt'):
+        monkeypatch.setattr(hip, name, lambda *a, _f=getattr(hip, name), _n=name, **k: (calls.append(_n), _f(*a, **k))[1])
+    gat = GATConv(8, dropout_rate=0.0, activation='relu')
+    gat.build([(n, 8), None])
+    sage = GraphSageConv(8, activation='relu')
+    sage.build([(n, 8), None])
+    helpers.randomize_biases(gat, seed=3)
+    helpers.randomize_biases(sage, seed=4)
+    y_gat, y_sage = gat([x, e]), sage([x, e])
+    assert 'gat_lt' in calls and 'spmm_lt' in calls
+    assert e.row_breaks == (big['n_users'],) and isinstance(e.tiled_gat_image(8), LdsTiled)
+    monkeypatch.setenv('AMAR_SPMM_KIND', 'csr')
+    r_gat, r_sage = gat([x, e]), sage([x, e])
+    monkeypatch.delenv('AMAR_SPMM_KIND')
+    assert float((y_gat - r_gat).abs().max()) < 2e-5 and float((y_sage - r_sage).abs().max()) < 2e-5
+    # sampled GAT rows in float64 on the host
+    c = 8
+    w = gat.kernel.detach().view(8, c).double().cpu().numpy()
+    a_s, a_n = gat.attn_kernel_self.detach().view(c).double().cpu().numpy(), gat.attn_kernel_neighs.detach().view(c).double().cpu().numpy()
+    b = gat.bias.detach().double().cpu().numpy()
+    xd = x.double().cpu().numpy()
+    rp = e.rowptr.long()
+    for r in np.random.default_rng(2).integers(0, n, 200).tolist():
+        cols = np.concatenate([e.colidx[int(rp[r]):int(rp[r + 1])].long().cpu().numpy(), [r]])
+        h = xd[cols] @ w
+        z = (xd[r] @ w) @ a_s + h @ a_n
+        z = np.where(z > 0, z, 0.2 * z)
+        p = np.exp(z - z.max())
+        want = np.maximum((p[:, None] * h).sum(0) / (p.sum() + 1e-9) + b, 0)
+        assert np.abs(y_gat[r].double().cpu().numpy() - want).max() < 1e-5 * max(1.0, np.abs(want).max())
+    # invariance: the same layer with s_neigh shifted by +5 (another bound M_i), straight through the C-ABI
+    h = torch.empty((n, c), device=dev)
+    ss, sn = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    hip.rowwise_xw(x, gat.kernel.view(-1, c), h, a_self=gat.attn_kernel_self.view(c), a_neigh=gat.attn_kernel_neighs.view(c), s_self=ss, s_neigh=sn)
+    lt = e.tiled_gat_image(c)
+    y0, y1 = torch.empty((n, c), device=dev), torch.empty((n, c), device=dev)
+    hip.gat_lt(lt, e, h, ss, sn, gat.bias, y0)
+    assert torch.equal(y0, y_gat)
+    bound = lt._gat_bound.clone() + 5.0
+    code = hip.load().amar_gat_lt_f32(
+        lt.words.data_ptr(), lt.stream_start.data_ptr(), lt.wsteps.data_ptr(), lt.tile_row0.data_ptr(), lt.n_win.data_ptr(),
+        lt.vstart.data_ptr(), lt.vcount.data_ptr(), lt.n_tiles, lt.maxwin1, lt.pace_every, lt.diag.data_ptr(), e.rowptr.data_ptr(),
+        e.colidx.data_ptr(), h.data_ptr(), c, c, ss.data_ptr(), sn.data_ptr(), bound.data_ptr(), gat.bias.data_ptr(),
+        y1.data_ptr(), c, 1, n, n, 0, None)
+    torch.cuda.synchronize()
+    assert code == 0 and float((y1 - y0).abs().max()) < 2e-6

@@ -380,6 +380,11 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
+    # AMAR_REHEARSE_ONE_GPU=1: all ranks on device 0 over gloo (parallel.SharedDeviceCollectives) — a rehearsal of the multi-rank
+    # code path on a one-GPU box, not a measurement (the ranks share the GPU; RCCL and the captured step are not exercised)
+    rehearse = os.environ.get('AMAR_REHEARSE_ONE_GPU') == '1' and world > 1
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     force_dist = bool(os.environ.get('AMAR_FORCE_DIST'))      # rehearse the RCCL path with a single rank
     if world > 1 or force_dist:
@@ -389,7 +394,10 @@ def main():
             os.environ.setdefault('MASTER_PORT', '29531')
             os.environ.setdefault('RANK', '0')
             os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if rehearse:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     from deep_cbrs_amar_renaissance_amd import capi, engine
     from deep_cbrs_amar_renaissance_amd.data import synthetic
@@ -417,8 +425,8 @@ def main():
     del data
     torch.cuda.empty_cache()
 
-    runner = parallel.make_runner(model, u_all, i_all, rank, world) if not force_dist else \
-        parallel.PartitionedGCNRunner(model, u_all, i_all, rank, world)
+    runner = parallel.make_runner(model, u_all, i_all, rank, world, dist=parallel.SharedDeviceCollectives(rank, world) if rehearse else None) \
+        if not force_dist else parallel.PartitionedGCNRunner(model, u_all, i_all, rank, world)
 
     spmm_events = []
     spmm_names = ('gcn_layer', 'spmm_sj', 'spmm_xs', 'spmm_lt')
@@ -438,7 +446,7 @@ def main():
     # (AMAR_STEP_GRAPH=0: the eager steps are the timed ones).  No per-launch event can be recorded inside a capture, so the
     # kernel-level objects below (roofline, pair_stage) are timed over K EAGER steps run just before, whose own rate is reported
     # as `eager`; the kernels and their durations are the same in both.
-    graph_step = hasattr(runner, 'step_graphed') and os.environ.get('AMAR_STEP_GRAPH', '1') != '0'
+    graph_step = hasattr(runner, 'step_graphed') and os.environ.get('AMAR_STEP_GRAPH', '1') != '0' and not rehearse
     for name in spmm_names:                                   # whichever form the layer dispatches to
         setattr(capi, name, timed(name, raw_spmm[name]))
     pair_events, raw_chain = [], capi.chain
@@ -493,7 +501,7 @@ def main():
     else:
         host_dt, dt = eager_host_dt, eager_dt
     if world > 1 or force_dist:
-        t = torch.tensor([dt, eager_dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt, eager_dt], device='cpu' if rehearse else dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt, eager_dt = float(t[0].item()), float(t[1].item())
 
@@ -521,7 +529,8 @@ def main():
             'config': {'workload': 'ml1m(s={}) user-item graph: N={} nodes, nnz(A_hat)={}, {} test pairs; '
                                    'econfigs/basic-gnn.yaml grid1 BasicGCN d=8 L=2 concat, dense [24,24], clf [48,48]; '
                                    'one propagation + per-entity towers + all pairs (shuffled order) per step (hoisted)'.format(args.scale, n_nodes, nnz, n_pairs),
-                       'scale': args.scale, 'parallelism': runner.describe() + (' (step replayed from a hipGraph)' if graph_step else '')},
+                       'scale': args.scale, 'parallelism': runner.describe() + (' (step replayed from a hipGraph)' if graph_step else '') +
+                       (' — one-GPU rehearsal over gloo: NOT a scaling measurement' if rehearse else '')},
             'roofline': {'bound': 'hbm', 'kernel': kernel_names[kind] + ' (fused GCN layer: SpMM + bias + ReLU + next X.W)', 'achieved': achieved,
                          'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
                          'traffic': pmc['traffic_bytes_per_launch'] if pmc else None, 'traffic_source': traffic_source,

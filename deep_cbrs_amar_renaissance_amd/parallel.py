@@ -90,6 +90,23 @@ class RowPartition:
         return local
 
 
+class SharedDeviceCollectives:
+    """`torch.distributed` stand-in for REHEARSING several ranks on ONE GPU (AMAR_REHEARSE_ONE_GPU=1: a `gloo` process group, every
+    rank a process of its own on device 0).  RCCL refuses two ranks on one device and gloo moves GPU tensors for all_reduce /
+    broadcast only, so the per-layer exchange is an all_reduce of the zero-padded table — the same bytes in the same layout as
+    `all_gather_into_tensor` (x + 0 is exact).  It exercises everything of a multi-rank run except RCCL itself: the launcher, the
+    row partition and the padded layout per process, pair sharding, the per-rank images and pair plans, the rank-0 report."""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+
+    def all_gather_into_tensor(self, out, inp):
+        rows = inp.shape[0]
+        out.zero_()
+        out[self.rank * rows:(self.rank + 1) * rows] = inp
+        torch.distributed.all_reduce(out)
+
+
 class SingleRunner:
     """world == 1: the model's own path, no padding, no exchange."""
 
@@ -420,7 +437,7 @@ class PartitionedGCNRunner:
             self.world, 'by user range (equal counts)' if self.pair_range is None else 'in contiguous slices')
 
 
-def make_runner(model, u_ids, i_ids, rank=0, world=1):
+def make_runner(model, u_ids, i_ids, rank=0, world=1, dist=None):
     if world == 1:
         return SingleRunner(model, u_ids, i_ids)
-    return PartitionedGCNRunner(model, u_ids, i_ids, rank, world)
+    return PartitionedGCNRunner(model, u_ids, i_ids, rank, world, dist=dist)

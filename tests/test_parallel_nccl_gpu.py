@@ -21,8 +21,8 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _torchrun(world, script_args, timeout=600):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+def _torchrun(world, script_args, timeout=600, **extra_env):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', **extra_env)
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
@@ -38,6 +38,30 @@ def test_partitioned_runner_on_rccl_matches_oracle(world, case):
     r = _torchrun(world, [os.path.join(ROOT, 'tests', 'nccl_worker.py'), case])
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert 'every pair scored once: True' in r.stdout
+
+
+@pytest.mark.parametrize('case', ['basic_ui', 'hybrid_uip'])
+@pytest.mark.parametrize('world', [2, 3])
+def test_partitioned_runner_rehearsed_on_one_gpu(world, case):
+    """The same worker with `world` PROCESSES sharing one GPU (gloo process group, the layer exchange as an all_reduce of the
+    zero-padded table: parallel.SharedDeviceCollectives): everything of a multi-rank run but RCCL itself, on a one-GPU box."""
+    r = _torchrun(world, [os.path.join(ROOT, 'tests', 'nccl_worker.py'), case], AMAR_REHEARSE_ONE_GPU='1')
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert 'every pair scored once: True' in r.stdout and 'rehearsal' in r.stdout
+
+
+def test_bench_two_ranks_rehearsed_on_one_gpu():
+    """`python bench.py --gpus 2` end to end on one GPU in rehearsal mode: the launcher, two ranks, one JSON line with n_gpus = 2."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', AMAR_REHEARSE_ONE_GPU='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--scale', '4', '--no-cpu-baseline'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['value'] > 0 and 'roofline' in out and 'rehearsal' in out['config']['parallelism']
 
 
 @pytest.mark.parametrize('gpus', [1, 2])

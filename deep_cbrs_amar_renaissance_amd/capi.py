@@ -31,7 +31,7 @@ SIGNATURES = {
                                         _P, _I64, _P, _I64, _F32, _P, _I32, _P, _I64, _P]),
     'amar_spmm_xs_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, _I32, _P, _I64, _I32, _P, _P, _P, _I64, _I32, _I32, _U32, _P,
                                         _P, _I64, _P, _I64, _F32, _P, _I32, _P, _I64, _P]),
-    'amar_gat_lt_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _I64,
+    'amar_gat_lt_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _P, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _I64,
                                        _I32, _I32, _I32, _I32, _P]),
     'amar_gat_lt_rows_per_wave': (ctypes.c_int, [_I32]),
     'amar_colmax_f32': (ctypes.c_int, [_P, _I64, _P, _P]),
@@ -275,6 +275,9 @@ def spmm_lt(lt, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc
             raise ValueError("spmm_lt: sage_tail = (kernel [2F, F] contiguous, bias [F]) expected")
     if F != lt.F:
         raise ValueError("spmm_lt: the image was built for width {}, X is {} wide".format(lt.F, F))
+    from deep_cbrs_amar_renaissance_amd.utilities import lds_tiled
+    if lt.rw > lds_tiled.geometry(F)[1]:
+        raise ValueError("spmm_lt: the image's tiles hold {} rows per wave, the kernel's {}".format(lt.rw, lds_tiled.geometry(F)[1]))
     flags = (SPMM_SAGE_TAIL if sage_tail is not None else (SPMM_BIAS if bias is not None else 0) | (SPMM_RELU if relu else 0))
     if acc_out is not None:
         flags |= SPMM_ACCUM | (SPMM_ACCUM_DIV if acc_div is not None else 0)
@@ -439,7 +442,7 @@ def gat_lt(lt, csr, H, s_self, s_neigh, bias, Y, self_loop=True):
         _ptr(lt.words, torch.int32, 'words'), _ptr(lt.stream_start, torch.int32, 'stream_start'),
         _ptr(lt.wsteps, torch.int32, 'wsteps'), _ptr(lt.tile_row0, torch.int32, 'tile_row0'), _ptr(lt.n_win, torch.int32, 'n_win'),
         _ptr(lt.vstart, torch.int32, 'vstart'), _ptr(lt.vcount, torch.int32, 'vcount'), lt.n_tiles, lt.maxwin1, lt.pace_every,
-        _ptr(lt.diag, torch.float32, 'diag'), _ptr(csr.rowptr, torch.int32, 'rowptr'), _ptr(csr.colidx, torch.int32, 'colidx'),
+        int(lt.rw), _ptr(lt.diag, torch.float32, 'diag'), _ptr(csr.rowptr, torch.int32, 'rowptr'), _ptr(csr.colidx, torch.int32, 'colidx'),
         _ptr(H, torch.float32, 'H'), _ld(H, 'H'), C, _ptr(s_self, torch.float32, 's_self'), _ptr(s_neigh, torch.float32, 's_neigh'),
         _ptr(bmax, torch.float32, 'bmax'), _ptr(bias, torch.float32, 'bias'), _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y'),
         1 if self_loop else 0, n, n_cols, row_offset, _stream())

@@ -1769,10 +1769,12 @@ int amar_gat_lt_rows_per_wave(int32_t C) { return (C == 8 || C == 16 || C == 32)
 
 int amar_gat_lt_f32(const int32_t *words, const int32_t *stream_start, const int32_t *wsteps, const int32_t *tile_row0,
                     const int32_t *n_win, const int32_t *vstart, const int32_t *vcount, int32_t n_tiles, int32_t maxwin1, int32_t pace_every,
-                    const float *diag, const int32_t *rowptr, const int32_t *colidx,
+                    int32_t rows_per_wave, const float *diag, const int32_t *rowptr, const int32_t *colidx,
                     const float *H, int64_t ldh, int32_t C, const float *s_self, const float *s_neigh, const float *s_neigh_max,
                     const float *bias, float *Y, int64_t ldy, int32_t self_loop, int32_t n_rows, int32_t n_cols, int32_t row_offset,
                     amar_stream_t stream) {
+    // the image's geometry is part of the contract: an image cut for taller tiles would index past the workgroup's LDS rows
+    if (rows_per_wave != amar_gat_lt_rows_per_wave(C)) return (C == 8 || C == 16 || C == 32) ? AMAR_EINVAL : AMAR_EUNSUPPORTED;
     if (n_rows < 0 || n_cols < 0 || n_tiles < 0 || maxwin1 < 1 || pace_every < 1 || (pace_every & (pace_every - 1)) || row_offset < 0) return AMAR_EINVAL;
     if (n_rows == 0 || n_tiles == 0) return n_rows == 0 ? AMAR_OK : AMAR_EINVAL;
     if (!words || !stream_start || !wsteps || !tile_row0 || !n_win || !vstart || !vcount || !diag || !rowptr || !colidx ||

@@ -79,12 +79,13 @@ def supported(F, n_cols, rw=None):
 
 class LdsTiled:
     def __init__(self, F, words, stream_start, wsteps, tile_row0, n_win, maxwin1, vstart, vcount, diag, row_scale, col_scale,
-                 diag_offset, shape, window_entries, n_entries, n_flagged, n_pairs):
+                 diag_offset, shape, window_entries, n_entries, n_flagged, n_pairs, rw=None):
         self.F, self.words, self.stream_start, self.wsteps = F, words, stream_start, wsteps
         self.tile_row0, self.n_win, self.maxwin1 = tile_row0, n_win, int(maxwin1)
         self.vstart, self.vcount = vstart, vcount
         self.diag, self.row_scale, self.col_scale, self.diag_offset = diag, row_scale, col_scale, int(diag_offset)
         self.shape = tuple(shape)
+        self.rw = int(rw) if rw is not None else geometry(F)[1]        # LDS rows per wave the image was cut for
         self.n_tiles = int(n_win.numel())
         self.window_entries, self.n_entries, self.n_flagged, self.n_pairs = int(window_entries), int(n_entries), int(n_flagged), int(n_pairs)
         # the waves of a tile meet at a barrier every `pace_every` windows: windows of ONE step per wave keep the dealing span (and
@@ -267,4 +268,4 @@ class LdsTiled:
         return cls(F, words, stream_start.to(torch.int32), wsteps.to(torch.int32).contiguous(),
                    tb_t.to(torch.int32), n_win.to(torch.int32), maxwin + 1, vstart.to(torch.int32).contiguous(),
                    vcount.to(torch.int32).contiguous(), diag, row_scale, col_scale, diag_offset,
-                   (n_rows, n_cols), window_entries, m, n_flagged, n_pairs)
+                   (n_rows, n_cols), window_entries, m, n_flagged, n_pairs, rw)

@@ -288,7 +288,8 @@ int amar_gat_xs_f32(const int32_t *rowptr, const int32_t *colidx, int32_t n_slic
 /* The same GAT layer (Spektral GATConv as instantiated at src/models/gnn.py:321-328) on the LDS-tiled image of the
  * edge-list adjacency (layout as amar_spmm_lt_f32; every edge a unit entry, duplicates repeated), C = 8, 16 or 32.
  * The LDS row of a virtual row holds (sum w.h [C], sum w, s_self of its row): RW = amar_gat_lt_rows_per_wave(C) rows per
- * wave (216 / 124 / 64), cbits = 31 - ceil(log2(RW)).  An entry (i, j) weighs
+ * wave (216 / 124 / 64), cbits = 31 - ceil(log2(RW)); `rows_per_wave` states the RW the image was cut for and must equal that
+ * value (AMAR_EINVAL otherwise: a taller tile would index past the workgroup's LDS).  An entry (i, j) weighs
  *     w_ij = exp( LeakyReLU_0.2(s_self[i] + s_neigh[j]) - M_i ),   M_i = LeakyReLU_0.2(s_self[i] + *s_neigh_max)
  * with *s_neigh_max >= every s_neigh (amar_colmax_f32 writes it): M_i bounds the row's maximum, so no running maximum is
  * needed and the weights add up like the plain sum's entries; out_i = ReLU( (sum_j w_ij H_j) / (sum_j w_ij) + bias ) is
@@ -301,7 +302,7 @@ int amar_gat_xs_f32(const int32_t *rowptr, const int32_t *colidx, int32_t n_slic
  */
 int amar_gat_lt_f32(const int32_t *words, const int32_t *stream_start, const int32_t *wsteps, const int32_t *tile_row0,
                     const int32_t *n_win, const int32_t *vstart, const int32_t *vcount, int32_t n_tiles, int32_t maxwin1, int32_t pace_every,
-                    const float *diag, const int32_t *rowptr, const int32_t *colidx,
+                    int32_t rows_per_wave, const float *diag, const int32_t *rowptr, const int32_t *colidx,
                     const float *H, int64_t ldh, int32_t C, const float *s_self, const float *s_neigh, const float *s_neigh_max,
                     const float *bias, float *Y, int64_t ldy, int32_t self_loop, int32_t n_rows, int32_t n_cols, int32_t row_offset,
                     amar_stream_t stream);

@@ -178,7 +178,7 @@ def test_full_size_gat_and_sage_on_the_lds_tiled_walk(hip, big, monkeypatch):
     bound = lt._gat_bound.clone() + 5.0
     code = hip.load().amar_gat_lt_f32(
         lt.words.data_ptr(), lt.stream_start.data_ptr(), lt.wsteps.data_ptr(), lt.tile_row0.data_ptr(), lt.n_win.data_ptr(),
-        lt.vstart.data_ptr(), lt.vcount.data_ptr(), lt.n_tiles, lt.maxwin1, lt.pace_every, lt.diag.data_ptr(), e.rowptr.data_ptr(),
+        lt.vstart.data_ptr(), lt.vcount.data_ptr(), lt.n_tiles, lt.maxwin1, lt.pace_every, lt.rw, lt.diag.data_ptr(), e.rowptr.data_ptr(),
         e.colidx.data_ptr(), h.data_ptr(), c, c, ss.data_ptr(), sn.data_ptr(), bound.data_ptr(), gat.bias.data_ptr(),
         y1.data_ptr(), c, 1, n, n, 0, None)
     torch.cuda.synchronize()

@@ -18,7 +18,7 @@ under torchrun (WORLD_SIZE set) it is one rank.  Rank 0 prints ONE JSON line.  E
 per launch over its HIP-event time), `roofline_l2` (the same launch against the XS form's binding
 limit, one L2 line request per gathered row), `pair_stage`, `hybrid_head` (econfigs/hybrid-gnn.yaml
 grid1 head at the same scale: MFMA utilisation), `uip_graph` (econfigs/basic-gnn-uip-2relconf.yaml grid1: the same model on
-the user-item-property graph), `ml1m_s1` (the reference's real size) and
+the user-item-property graph), `train_s1` (one `fit()` epoch at the reference's real size), `ml1m_s1` (the reference's real size) and
 `cpu_baseline` (the oracle timed on one host core on the SAME ml1m(s=1) graph, weights and pairs).
 """
 import argparse
@@ -296,6 +296,33 @@ def hybrid_head(dev, scale):
                            'pairs_per_s': p / ms_pairs * 1e3, 'flop_per_pair': flop_pair,
                            'tflops': p * flop_pair / ms_pairs / 1e9, 'peak_tflops': MFMA_F32_PEAK_TFLOPS,
                            'mfma_frac': p * flop_pair / ms_pairs / 1e9 / MFMA_F32_PEAK_TFLOPS}}
+
+
+def train_true_size():
+    """SURVEY 8(f) N1 at the reference's real size: `model.fit` on ml1m(s=1) for the config the reference publishes a training time
+    for (doc.pdf p.22 Table 5: BasicGCN 16 channels x 2 layers, dense [48, 48], clf [64, 64], batch 1024, Adam 1e-3 — 211 s per 25
+    epochs on an RTX 3060, other hardware, for orientation): full-graph propagation, BCE + L2, reverse pass and Adam per batch, each
+    batch replayed from a hipGraph (training.py).  One warm-up epoch, one timed epoch."""
+    from deep_cbrs_amar_renaissance_amd import engine
+    from deep_cbrs_amar_renaissance_amd.data.datasets import UserItemGraph
+    from deep_cbrs_amar_renaissance_amd.experiment import Adam
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    from tests import helpers
+    g = helpers.ml1m_indexed(1)
+    engine.set_seed(42)
+    model = basic.BasicGCN(g['adj_ui'], embedding_dim=16, n_hiddens=[16, 16], dense_units=[48, 48], clf_units=[64, 64], l2_regularizer=1e-4)
+    model.compile(loss='binary_crossentropy', optimizer=Adam(learning_rate=1e-3), metrics=['accuracy'])
+    train = UserItemGraph(g['train'], g['users'], g['items'], g['adj_ui'], batch_size=1024, shuffle=True)
+    first = model.fit(train, epochs=1, verbose=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    hist = model.fit(train, epochs=1, verbose=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {'config': 'BasicGCN d=16 [16,16], dense [48,48], clf [64,64], batch 1024, Adam(1e-3), l2 1e-4 on ml1m(s=1): {} train pairs, {} batches per epoch'.format(len(g['train']), len(train)),
+            's_per_epoch': dt, 'ms_per_batch': 1e3 * dt / len(train), 'train_pairs_per_s': len(g['train']) / dt,
+            's_per_25_epochs': 25 * dt, 'loss_epoch1': float(first['loss'][-1]), 'loss_epoch2': float(hist['loss'][-1]),
+            'reference_published': '211 s per 25 epochs on an RTX 3060 (doc.pdf p.22 Table 5; other hardware)'}
 
 
 def uip_graph(dev, scale, steps):
@@ -581,6 +608,7 @@ def main():
             out['hybrid_head'] = hybrid_head(dev, args.scale)
             out['uip_graph'] = uip_graph(dev, args.scale, args.steps)
             out['ml1m_s1'], s1 = ml1m_true_size(dev)
+            out['train_s1'] = train_true_size()
             out['cpu_baseline'] = cpu_baseline(s1)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)

@@ -718,7 +718,10 @@ int amar_chain_indexed_f32(const float *A, int64_t lda, int32_t Da, const int32_
     if (!no_pipe && relu && a.sum_inputs && a.in_act == AMAR_ACT_RELU && full && a_dot_ok && a.ids_a && a.ids_b && a.Da == 16 * maxt &&
         a.Db == a.Da && maxt <= 4 && pt == 2 && lds_bytes <= 64 * 1024 && small_tables) {
         int64_t blocks = (P + 4 * 16 * 2 - 1) / (4 * 16 * 2);
-        if (blocks > 4096) blocks = 4096;
+        // 1 536 = 256 CUs x 3 resident workgroups x 2: whole rounds of workgroups, no tail (ml1m(s=64): 0.639 ms against 0.647 at 4 096,
+        // 0.658 at 8 192; AMAR_CHAIN_BLOCKS overrides — keep it a multiple of 8: PairPlan's XCD affinity)
+        static const int cap = getenv("AMAR_CHAIN_BLOCKS") ? atoi(getenv("AMAR_CHAIN_BLOCKS")) : 1536;
+        if (blocks > cap) blocks = cap;
         const dim3 grid((unsigned)blocks), block(256);
         if (a.out_index && !a.has_dot) return AMAR_EUNSUPPORTED;
         if (a.out_index) {

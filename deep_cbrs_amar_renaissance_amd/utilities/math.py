@@ -235,7 +235,20 @@ def spmm_kind(a, F):
         # the LDS-tiled image (DeviceCSR.tiled_image) already wins once the table leaves one XCD's L2: ml1m(s=16), F = 8:
         # 0.075 ms against 0.093 (row streaming) / 0.110 (XS); s=64: F = 16 0.35 / 0.78 / 0.54, F = 32 0.60 / 0.91 / 1.12
         return 'xs'
+    if a.shape[0] == a.shape[1] and a.vals is None and table_bytes >= (4 << 20) and F in (8, 16, 32) and _edge_list_lt_density(a, F):
+        # edge-list graphs (GraphSAGE's mean aggregate, GAT) walk the LT image from the same size on: ml1m(s=16) GAT C = 8 0.104 ms
+        # against 0.193 (row kernel), C = 16 0.133 / 0.246; GraphSAGE aggregate 0.067 against 0.103 for the whole row-kernel layer
+        return 'xs'
     return 'xs' if (a.shape[0] == a.shape[1] and F in (4, 8, 16) and big) else 'csr'
+
+
+def _edge_list_lt_density(a, F):
+    """The density rule of lt_eligible for an edge-list CSR (no factors needed: its LT images are value-free by construction)."""
+    from deep_cbrs_amar_renaissance_amd.utilities import lds_tiled
+    forced = os.environ.get('AMAR_SPMM_LT')
+    if forced == '0' or not lds_tiled.supported(F, a.shape[1]):
+        return False
+    return forced == '1' or a.nnz >= LT_MIN_DENSITY * lds_tiled.N_CU * a.shape[1]
 
 
 def _csr_sliced(self, F):

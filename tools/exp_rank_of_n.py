@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""Device time of ONE rank's step in a world-W node-range partition of bench.py's workload, on one GPU (development aid for the
+scaling estimate of DESIGN.md §6): the rank's own kernels run for real — its row block on LT / XS, the replicated X.W, towers,
+its pair shard — while the two all-gathers are replaced by a local copy of the rank's own block (wrong neighbours' data, right
+sizes), so the number is the step WITHOUT the exchange.  `python tools/exp_rank_of_n.py [scale] [world ...]`."""
+import os
+import sys
+import time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+GRID1 = dict(embedding_dim=8, n_hiddens=[8, 8], n_layers=2, dense_units=[24, 24], clf_units=[48, 48], l2_regularizer=1e-4,
+             final_node='concatenation', activation='relu')
+
+
+class LocalCopy:
+    """all_gather_into_tensor stand-in: only this rank's block lands (at its place); the other blocks keep last step's bytes."""
+    def __init__(self, rank):
+        self.rank = rank
+
+    def all_gather_into_tensor(self, out, inp):
+        r = inp.shape[0]
+        out[self.rank * r:(self.rank + 1) * r].copy_(inp)
+
+
+def main():
+    scale = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    worlds = [int(v) for v in sys.argv[2:]] or [2, 4, 8]
+    from deep_cbrs_amar_renaissance_amd import capi, engine, parallel
+    from deep_cbrs_amar_renaissance_amd.data import synthetic
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter_device
+    capi.load()
+    dev = torch.device('cuda')
+    data = synthetic.ml1m_device(scale, device=dev)
+    n = data['n_users'] + data['n_items']
+    a = gcn_filter_device(data['train_pos'][:, 0], data['train_pos'][:, 1], n)
+    engine.set_seed(42)
+    model = basic.BasicGCN(a, **GRID1)
+    model.n_users, model.n_items = data['n_users'], data['n_items']
+    g = torch.Generator(device=dev); g.manual_seed(42)
+    perm = torch.randperm(data['test'].shape[0], device=dev, generator=g)
+    u = data['test'][perm, 0].to(torch.int32).contiguous()
+    i = data['test'][perm, 1].to(torch.int32).contiguous()
+    single = parallel.SingleRunner(model, u, i)
+    for _ in range(3):
+        single.step_graphed()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        single.step_graphed()
+    torch.cuda.synchronize()
+    t1 = (time.perf_counter() - t0) / 20
+    print('ml1m(s=%d): single GPU %.4f ms per step (graph-replayed)' % (scale, 1e3 * t1), flush=True)
+    for world in worlds:
+        for rank in sorted({0, world // 2, world - 1}):
+            runner = parallel.PartitionedGCNRunner(model, u, i, rank, world, dist=LocalCopy(rank), timing=False)
+            for _ in range(3):
+                runner.step_graphed()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                runner.step_graphed()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 20
+            gathered = sum(runner.widths[1:]) * world * runner.part.R * 4 / 1e6
+            print('  world %d rank %d: rows %d nnz %d pairs %d | %.4f ms per step without the exchange (%.1f MB gathered per step) -> '
+                  'bound on the speed-up %.2fx' % (world, rank, runner.local_rows, runner.local_nnz, runner.u_ids.numel(), 1e3 * dt, gathered, t1 / dt), flush=True)
+            del runner
+
+
+if __name__ == '__main__':
+    main()

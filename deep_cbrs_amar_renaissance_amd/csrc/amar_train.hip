@@ -10,7 +10,13 @@
 
 namespace {
 
-constexpr int WG_ROWS = 512;      // rows per partial block of the weight-gradient kernel
+// rows per partial block of the weight-gradient kernel: 128 for a batch-sized operand (a fixed 512 gave 18 blocks for a 1 024-row
+// batch and a 48 x 48 layer: 22 us per call, a third of a training batch at ml1m(s=1)), growing to 512 so that node-table-sized
+// operands do not multiply the partials the second stage has to add
+__host__ __device__ inline int wg_rows(int64_t M) {
+    const int64_t r = ((M / 64 + 63) / 64) * 64;
+    return (int)(r < 128 ? 128 : r > 512 ? 512 : r);
+}
 
 __device__ __forceinline__ float act_grad(float dy, float y, int act) {
     if (act == AMAR_ACT_RELU) return y > 0.f ? dy : 0.f;
@@ -32,7 +38,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ 
 // block = 16 x 16 threads = one 16x16 tile of dW; grid = (row chunks, K tiles, N tiles)
 __global__ __launch_bounds__(256) void wgrad_partial_kernel(const float *__restrict__ X, int64_t ldx, const float *__restrict__ dZ,
                                                             int64_t ldz, int64_t M, int K, int N, float *__restrict__ part_w,
-                                                            float *__restrict__ part_b) {
+                                                            float *__restrict__ part_b, int WG_ROWS) {
     __shared__ float xs[64][17], zs[64][17];
     const int tk = threadIdx.x >> 4, tn = threadIdx.x & 15;
     const int k0 = blockIdx.y * 16, n0 = blockIdx.z * 16;
@@ -472,7 +478,7 @@ int amar_act_bwd_f32(const float *dY, int64_t ldd, const float *Y, int64_t ldy, 
 
 int64_t amar_wgrad_scratch_floats(int64_t M, int32_t K, int32_t N) {
     if (M < 0 || K < 0 || N < 1) return AMAR_EINVAL;
-    const int64_t chunks = (M + WG_ROWS - 1) / WG_ROWS;
+    const int64_t chunks = (M + wg_rows(M) - 1) / wg_rows(M);
     return chunks * ((int64_t)K * N + N);
 }
 
@@ -481,13 +487,14 @@ int amar_wgrad_f32(const float *X, int64_t ldx, const float *dZ, int64_t ldz, in
     if (M < 1 || N < 1 || !dZ || ldz < N || !scratch || (!dW && !db)) return AMAR_EINVAL;
     if (dW && (!X || K < 1 || ldx < K)) return AMAR_EINVAL;
     const int Kk = dW ? K : 0;
+    const int WG_ROWS = wg_rows(M);
     const int64_t chunks = (M + WG_ROWS - 1) / WG_ROWS;
     if (chunks > 0x7fffffff) return AMAR_EUNSUPPORTED;
     float *part_w = dW ? scratch : nullptr;
     float *part_b = db ? scratch + chunks * (int64_t)Kk * N : nullptr;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)chunks, (unsigned)(dW ? (K + 15) / 16 : 1), (unsigned)((N + 15) / 16));
-    hipLaunchKernelGGL(wgrad_partial_kernel, grid, dim3(256), 0, st, dW ? X : nullptr, ldx, dZ, ldz, M, Kk ? Kk : 1, N, part_w, part_b);
+    hipLaunchKernelGGL(wgrad_partial_kernel, grid, dim3(256), 0, st, dW ? X : nullptr, ldx, dZ, ldz, M, Kk ? Kk : 1, N, part_w, part_b, WG_ROWS);
     if (dW && db) hipLaunchKernelGGL(reduce_partials2_kernel, dim3(grid1d((int64_t)K * N + N)), dim3(256), 0, st, part_w, (int64_t)K * N, dW,
                                      part_b, (int64_t)N, db, (int)chunks);
     else if (dW) hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid1d((int64_t)K * N)), dim3(256), 0, st, part_w, (int)chunks, (int64_t)K * N, dW);

@@ -121,31 +121,61 @@ class LdsTiled:
         breaks = sorted(int(b) for b in row_breaks if 0 < int(b) < n_rows)
 
         def make_tiles(weight_cum, split_):
-            k_row_ = np.maximum((deg_np + split_ - 1) // split_, 1)
-            vcum_ = np.concatenate([[0], np.cumsum(k_row_)])
-            # the segments between forced breaks share the tiles in proportion to their weight (at least one each); a segment
-            # whose ROW count alone needs more tiles than that share (the four-entry property rows of a user-item-property
-            # graph: 275 tiles of 4 080 rows at ml1m(s=64) for 7 % of the entries) takes what the LDS capacity dictates and
-            # leaves the rounds of the others alone — its tiles are short and fill in behind the tall ones
             edges = [0] + breaks + [n_rows]
             n_seg = len(edges) - 1
             seg_w = np.array([weight_cum[edges[i + 1]] - weight_cum[edges[i]] for i in range(n_seg)])
-            seg_v = np.array([vcum_[edges[i + 1]] - vcum_[edges[i]] for i in range(n_seg)], dtype=np.int64)
-            cap = -(-seg_v // vmax)
-            share = np.ones(n_seg, dtype=np.int64)
-            free = np.ones(n_seg, dtype=bool)
-            while free.any():
-                wanted_free = n_cu * max(1, -(-int(seg_v[free].sum()) // (n_cu * vmax)))
-                w_free = np.where(free, seg_w, 0.0)
-                sh = np.maximum(1, np.floor(w_free / max(w_free.sum(), 1e-30) * wanted_free)).astype(np.int64)
-                while sh[free].sum() < max(wanted_free, int(free.sum())):   # hand the remaining tiles to the segments with the most weight per tile
-                    sh[int(np.argmax(np.where(free, seg_w / sh, -1.0)))] += 1
-                bound = free & (cap > sh)
-                share[free] = sh[free]
-                if not bound.any():
-                    break
-                share[bound] = cap[bound]
-                free &= ~bound
+            seg_e = np.array([int(deg_np[edges[i]:edges[i + 1]].sum()) for i in range(n_seg)], dtype=np.int64)
+            k_row_ = np.maximum((deg_np + split_ - 1) // split_, 1)
+
+            def shares(k_row__):
+                # the segments between forced breaks share the tiles in proportion to their weight (at least one each); a segment
+                # whose ROW count alone needs more tiles than that share (the four-entry property rows of a user-item-property
+                # graph: 275 tiles of 4 080 rows at ml1m(s=64) for 7 % of the entries) takes what the LDS capacity dictates and
+                # leaves the rounds of the others alone — its tiles are short and fill in behind the tall ones
+                vcum__ = np.concatenate([[0], np.cumsum(k_row__)])
+                seg_v = np.array([vcum__[edges[i + 1]] - vcum__[edges[i]] for i in range(n_seg)], dtype=np.int64)
+                cap = -(-seg_v // vmax)
+                share_ = np.ones(n_seg, dtype=np.int64)
+                bound_ = np.zeros(n_seg, dtype=bool)
+                free = np.ones(n_seg, dtype=bool)
+                while free.any():
+                    wanted_free = n_cu * max(1, -(-int(seg_v[free].sum()) // (n_cu * vmax)))
+                    w_free = np.where(free, seg_w, 0.0)
+                    sh = np.maximum(1, np.floor(w_free / max(w_free.sum(), 1e-30) * wanted_free)).astype(np.int64)
+                    while sh[free].sum() < max(wanted_free, int(free.sum())):   # hand the remaining tiles to the segments with the most weight per tile
+                        sh[int(np.argmax(np.where(free, seg_w / sh, -1.0)))] += 1
+                    bound = free & (cap > sh)
+                    share_[free] = sh[free]
+                    if not bound.any():
+                        break
+                    share_[bound] = cap[bound]
+                    bound_ |= bound
+                    free &= ~bound
+                return vcum__, share_, bound_
+
+            vcum_, share, cap_bound = shares(k_row_)
+            # Small tiles need fine virtual rows.  A wave's step touches 32 entries; they fall on distinct LDS rows only if the tile
+            # offers the wave several times that many virtual rows (~1 000 per tile).  Tall tiles get them from their row count; a
+            # segment cut into SMALL tiles of few heavy rows does not (the head of the property rows of a user-item-property graph:
+            # tiles of 10-200 rows, 75-190 virtual rows and 19 k entries had 37-66 % of their entries on the LDS-atomic path and took
+            # 137 us each, at the END of the launch).  Where a segment's tiles hold E entries, rows are cut into pieces of E / 1 024
+            # entries (at least 16, never coarser than the split; no more pieces than one tile holds).
+            changed = False
+            for i in range(n_seg):
+                e_tile = seg_e[i] / max(int(share[i]), 1)
+                fine = int(min(split_, max(16, e_tile // 1024)))
+                if fine >= split_:
+                    continue
+                lo, hi = edges[i], edges[i + 1]
+                k_fine = np.maximum(k_row_[lo:hi], np.minimum(np.maximum(-(-deg_np[lo:hi] // fine), 1), vmax))
+                # ... only where the extra virtual rows cannot push the segment past its tiles (ONE tile more than a round of CUs
+                # doubles the launch: GAT C = 8 at ml1m(s=64) went from 256 to 257 tiles and from 0.36 to 0.64 ms): segments whose
+                # tile count the LDS capacity dictates anyway, or with a fifth of their capacity to spare afterwards
+                if (k_fine > k_row_[lo:hi]).any() and (cap_bound[i] or int(k_fine.sum()) <= 0.8 * int(share[i]) * vmax):
+                    k_row_[lo:hi] = k_fine
+                    changed = True
+            if changed:
+                vcum_, share, _ = shares(k_row_)
             wanted_ = int(share.sum())
             tb_ = [0]
             for i in range(len(edges) - 1):

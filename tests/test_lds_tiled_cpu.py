@@ -169,11 +169,11 @@ def test_lt_image_three_node_types_and_small_tiles(F, rw):
         vmax = lds_tiled.WAVES * (rw - 1)
         assert int((tb[:-1] >= breaks[1]).sum()) >= -(-400 // vmax)
         deg = np.bincount(rows, minlength=n)
-        heavy = int(np.argmax(deg[:breaks[1]]))                     # the heaviest user / item row is still cut every 32 entries
+        heavy = int(np.argmax(deg[:breaks[1]]))                     # the heaviest user / item row is cut at least every 32 entries (never coarser)
         t = int(np.searchsorted(tb, heavy, side='right') - 1)
         vs = lt.vstart.numpy()
         k = (vs[heavy + 1] if heavy + 1 < tb[t + 1] else int(lt.vcount[t])) - vs[heavy]
-        assert k == -(-deg[heavy] // 32)
+        assert -(-deg[heavy] // 32) <= k <= -(-deg[heavy] // 16)
 
 
 def test_lt_image_row_block_with_column_offset():

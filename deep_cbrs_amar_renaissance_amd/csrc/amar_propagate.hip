@@ -611,6 +611,12 @@ struct LtArgs {
     const int32_t *csr_rowptr; const int32_t *csr_colidx; int self_loop;
 };
 
+#ifdef AMAR_LT_STAMPS                                  // development build only (tools/exp_lt_stamps.py): per-tile cycle stamps
+__device__ unsigned long long lt_debug_stamps[4 * 8192];
+#define LT_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) lt_debug_stamps[4 * blockIdx.x + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define LT_STAMP(i) do { } while (0)
+#endif
 constexpr int LT_WAVES = 16;
 constexpr int LT_TILE_BYTES = 128 << 10;
 // GAT mode keeps (sum of weights, s_self) next to every LDS row: 4F + 8 bytes per virtual row, fewer rows per wave
@@ -652,6 +658,7 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtA
     const int t = blockIdx.x;
     const int lane = threadIdx.x & (AMAR_WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    LT_STAMP(0);
     const int r0 = a.tile_row0[t], nr = a.tile_row0[t + 1] - r0;
     for (int i = threadIdx.x; i < LT_WAVES * RW * (GAT ? F + 2 : F) / 4; i += LT_WAVES * AMAR_WAVE)
         reinterpret_cast<float4 *>(ytile)[i] = f4_zero();
@@ -774,6 +781,7 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtA
             wend = win < nwin ? window_end(win) : 0x7fffffff;
         }
     };
+    LT_STAMP(1);
     pace(0);
     // index chunks are requested PF chunks ahead, in turn into PF register sets: `next` holds chunk c + 1 when chunk c reaches
     // the point where it starts issuing that chunk's steps, and is then reloaded with chunk c + 1 + PF
@@ -810,6 +818,7 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtA
     __syncthreads();
 
     // epilogue: y_i = row_scale_i . (diag_i . x_i + the row's virtual rows), then bias / ReLU / store / running sum / next X.W
+    LT_STAMP(2);
     // A thread finishes up to EK rows per pass; their global operands (virtual-row range, diag, scale, the row's own X) are all
     // requested before the first one is used: one memory round trip per pass instead of one per row (a 4 080-row tile of
     // four-entry rows spent a quarter of its time in these).
@@ -933,6 +942,10 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtA
         lane_row_epilogue<F, FUSE_NEXT>(a.e, row, acc);
     }
     }
+#ifdef AMAR_LT_STAMPS
+    __syncthreads();
+    LT_STAMP(3);
+#endif
 }
 
 template <int F>
@@ -1800,6 +1813,12 @@ int amar_gat_lt_f32(const int32_t *words, const int32_t *stream_start, const int
     default: return launch_gat_lt<32>(a, n_tiles, off32, st);
     }
 }
+
+#ifdef AMAR_LT_STAMPS
+int amar_lt_debug_copy(unsigned long long *host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(lt_debug_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#endif
 
 }  // extern "C"
 

@@ -187,11 +187,22 @@ class LdsTiled:
                     if rv <= r0:
                         raise ValueError("LT image: a single row needs more than {} virtual rows".format(vmax))
                     tb_.append(min(max(r1, r0 + 1), rv, seg_end))
-            return tb_, k_row_, vcum_, wanted_
+            return tb_, k_row_, vcum_, wanted_, bool(cap_bound.any())
 
+        # The per-line term holds while the gathered table lives in the L2s (32 MB in all): there a tile whose entries spread over
+        # more lines pays for more L1 fills.  Past that size every tile's gathers go to the Infinity Cache and the entries cost the
+        # same whatever their spread (in-kernel cycle stamps, tools/exp_lt_stamps.py: F = 16 at ml1m(s=64), 37.8 MB: 3.22 / 3.20
+        # cycles per entry for user / item tiles): tiles are then cut by entry count alone (ml1m(s=256), 75 MB: 1.26 -> 1.17 ms per
+        # layer) — unless a capacity-bound segment supplies short fill-in tiles: then the staggered finish the line term gives
+        # the tall tiles is what lets the short ones start early (user-item-property graph, 55 MB: 0.334 ms with the term, 0.349
+        # without, same box).
+        big_table = n_cols * F * 4 > (32 << 20)
         cum = np.concatenate([[0.0], np.cumsum(deg_np.astype(np.float64))])
         while True:
-            tb, k_row_np, vcum, wanted = make_tiles(cum, split)
+            tb, k_row_np, vcum, wanted, fill_in = make_tiles(cum, split)
+            line_cost = 0.0 if big_table and not fill_in else COST_LINE
+            if os.environ.get('AMAR_LT_LINE_COST'):                   # development switch (A/B of the rule above)
+                line_cost = float(os.environ['AMAR_LT_LINE_COST'])
             for _ in range(BALANCE_PASSES if balance and m else 0):
                 tb0 = torch.tensor(tb, dtype=torch.int64, device=dev)
                 tile0 = torch.searchsorted(tb0, rows, right=True) - 1
@@ -199,10 +210,10 @@ class LdsTiled:
                 n_lines = (n_cols + cpl - 1) // cpl
                 lines_t = torch.bincount(torch.unique(tile0 * n_lines + cols // cpl) // n_lines, minlength=len(tb) - 1).cpu().numpy()
                 ent_t = torch.bincount(tile0, minlength=len(tb) - 1).cpu().numpy()
-                cost_t = COST_ENTRY + COST_LINE * lines_t / np.maximum(ent_t, 1)
+                cost_t = COST_ENTRY + line_cost * lines_t / np.maximum(ent_t, 1)
                 row_tile = np.searchsorted(np.asarray(tb), np.arange(n_rows), side='right') - 1
                 wcum = np.concatenate([[0.0], np.cumsum(deg_np * cost_t[row_tile])])
-                tb, k_row_np, vcum, wanted = make_tiles(wcum, split)
+                tb, k_row_np, vcum, wanted, _ = make_tiles(wcum, split)
                 del tb0, tile0
             # the LDS capacity forced extra tiles: cut long rows less finely — where that can help.  When the extra tiles come
             # from the sheer number of ROWS (the 1.1 M four-entry property rows of a user-item-property graph need 275 tiles

@@ -431,7 +431,7 @@ def _csr_lds_tiled(self, F):
 
 DeviceCSR.lds_tiled = _csr_lds_tiled
 
-LT_MIN_DENSITY = 0.06      # entries per (tile, column): below this neighbouring entries no longer share L1 lines often enough
+LT_MIN_DENSITY = 0.03      # entries per (tile, column): the sparsest case measured in LT's favour (the row blocks of an 8-rank partition of ml1m(s=64))
 
 
 def lt_eligible(a, F):
@@ -439,8 +439,8 @@ def lt_eligible(a, F):
     rather than the XCD-sliced one: the value-free factors must be known, the packed word must hold the column, and a
     tile must see enough entries per column for the column-ordered walk to pay.  Measured on ml1m(s=64), F = 8
     (tools/exp_lt_blocks.py, LT / XS per launch): whole matrix (0.37 entries per tile and column) 0.22 / 0.36 ms; the row
-    blocks of a 2-rank partition (0.14) 0.13-0.19 / 0.18-0.23; 4 ranks (0.07) 0.092 / 0.10-0.12; 8 ranks (0.035) 0.08 / 0.06-0.07:
-    the blocks of an 8-rank partition stay on XS.
+    blocks of a 2-rank partition (0.14) 0.12-0.17 / 0.18-0.23; 4 ranks (0.07) 0.072-0.077 / 0.10-0.12; 8 ranks (0.035) 0.044-0.048 /
+    0.059-0.066 — since small tiles get fine virtual rows (lds_tiled.py) the blocks of an 8-rank partition walk LT too (0.08 before).
     AMAR_SPMM_LT=0|1 overrides the density rule."""
     from deep_cbrs_amar_renaissance_amd.utilities import lds_tiled
     forced = os.environ.get('AMAR_SPMM_LT')

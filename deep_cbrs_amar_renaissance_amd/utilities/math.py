@@ -231,11 +231,12 @@ def spmm_kind(a, F):
     # (its scan is amortised over only 64/(F/4) lanes' worth of entries)
     table_bytes = a.shape[1] * F * 4
     big = table_bytes >= ((8 << 20) if F <= 8 else (16 << 20))
-    if a.shape[0] == a.shape[1] and table_bytes >= (4 << 20) and lt_eligible(a, F):
-        # the LDS-tiled image (DeviceCSR.tiled_image) already wins once the table leaves one XCD's L2: ml1m(s=16), F = 8:
-        # 0.075 ms against 0.093 (row streaming) / 0.110 (XS); s=64: F = 16 0.35 / 0.78 / 0.54, F = 32 0.60 / 0.91 / 1.12
+    if a.shape[0] == a.shape[1] and table_bytes >= (2 << 20) and lt_eligible(a, F):
+        # the LDS-tiled image (DeviceCSR.tiled_image) wins from a 2 MB table on: F = 8, ms per launch LT / row streaming / XS:
+        # ml1m(s=8) 0.036 / 0.052 / 0.062, ml1m(s=16) 0.061 / 0.093 / 0.110 (ml1m(s=4), 1.2 MB: 0.025 / 0.028; s=2: 0.018 / 0.016);
+        # s=64: F = 16 0.33 / 0.78 / 0.54, F = 32 0.60 / 0.91 / 1.12
         return 'xs'
-    if a.shape[0] == a.shape[1] and a.vals is None and table_bytes >= (4 << 20) and F in (8, 16, 32) and _edge_list_lt_density(a, F):
+    if a.shape[0] == a.shape[1] and a.vals is None and table_bytes >= (2 << 20) and F in (8, 16, 32) and _edge_list_lt_density(a, F):
         # edge-list graphs (GraphSAGE's mean aggregate, GAT) walk the LT image from the same size on: ml1m(s=16) GAT C = 8 0.104 ms
         # against 0.193 (row kernel), C = 16 0.133 / 0.246; GraphSAGE aggregate 0.067 against 0.103 for the whole row-kernel layer
         return 'xs'

@@ -278,7 +278,7 @@ def test_infer_row_breaks():
 
 def test_spmm_kind_size_and_density_rules(monkeypatch):
     """Which propagation form a graph takes (utilities.math.spmm_kind), on stand-in shapes: row kernels while the gathered table
-    stays inside one XCD's L2, the tiled route (LT where eligible) from a 4 MB table on for gcn-filtered matrices with known
+    is small, the tiled route (LT where eligible) from a 2 MB table on for gcn-filtered matrices with known
     factors AND for edge-list graphs (GraphSAGE / GAT) that are dense enough per tile and column, XS by the older 8 / 16 MB rule
     otherwise; AMAR_SPMM_KIND / AMAR_SPMM_LT override."""
     from deep_cbrs_amar_renaissance_amd.utilities import math as m
@@ -291,9 +291,10 @@ def test_spmm_kind_size_and_density_rules(monkeypatch):
         monkeypatch.delenv(k, raising=False)
     n16 = 9228 * 16                                                  # 4.7 MB at F = 8
     assert m.spmm_kind(G(9228, 876_000, True), 8) == 'csr'           # ML-1M itself: row streaming
-    assert m.spmm_kind(G(n16, 14_000_000, True), 8) == 'xs'          # factors known, dense enough: tiled (LT) from 4 MB on
+    assert m.spmm_kind(G(n16, 14_000_000, True), 8) == 'xs'          # factors known, dense enough: tiled (LT) from 2 MB on
+    assert m.spmm_kind(G(9228 * 8, 6_900_000, True), 8) == 'xs' and m.spmm_kind(G(9228 * 4, 3_400_000, True), 8) == 'csr'
     assert m.spmm_kind(G(n16, 14_000_000, False), 8) == 'csr'        # valued matrix without factors: below the 8 MB XS rule
-    assert m.spmm_kind(G(n16, 14_000_000, False, vals=None), 8) == 'xs'      # edge list (GraphSAGE / GAT): LT walk from 4 MB on
+    assert m.spmm_kind(G(n16, 14_000_000, False, vals=None), 8) == 'xs'      # edge list (GraphSAGE / GAT): LT walk from 2 MB on
     assert m.spmm_kind(G(n16, 1_000_000, False, vals=None), 8) == 'csr'      # ... unless too sparse per tile and column
     assert m.spmm_kind(G(9228 * 64, 1_000_000, False, vals=None), 8) == 'xs' # a large sparse one: the XS forms (18.9 MB table)
     assert m.spmm_kind(G(n16, 14_000_000, False, vals=None), 32) == 'xs'     # C = 32 walks LT too

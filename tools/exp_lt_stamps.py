@@ -83,6 +83,16 @@ def main():
                   k, sel.sum(), (d[:, 0].min() - t0) / 1e3, (d[:, 0].max() - t0) / 1e3, (d[:, 2] - d[:, 1]).min() / 1e3,
                   np.median(d[:, 2] - d[:, 1]) / 1e3, (d[:, 2] - d[:, 1]).max() / 1e3, np.median(d[:, 3] - d[:, 2]) / 1e3, np.median(tot) / 1e3, tot.max() / 1e3,
                   np.median(d[:, 3] - t0) / 1e3, (d[:, 3] - t0).max() / 1e3, int(np.median(ent[sel])), np.median(tot) / max(1, np.median(ent[sel]))))
+        idx = np.where(sel)[0]
+        order = np.argsort(-tot)
+        tile_of_word = torch.repeat_interleave(torch.arange(T * 16, device=dev), ss[1:] - ss[:-1]) // 16
+        flagged = torch.bincount(tile_of_word[img.words < 0], minlength=T).cpu().numpy()
+        vc, rr = img.vcount.cpu().numpy(), tb[1:] - tb[:-1]
+        for lab, pick in (('slowest', order[:4]), ('fastest', order[-4:])):
+            for o in pick:
+                t = idx[o]
+                print('    %s tile %4d: total %.0f k | entries %d rows %d vrows %d flagged %.2f %% windows %d' % (
+                    lab, t, tot[o] / 1e3, ent[t], rr[t], vc[t], 100.0 * flagged[t] / max(1, ent[t]), int(img.n_win[t])))
 
 
 if __name__ == '__main__':

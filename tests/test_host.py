@@ -302,3 +302,20 @@ def test_spmm_kind_size_and_density_rules(monkeypatch):
     assert m.spmm_kind(G(n16, 14_000_000, False, vals=None), 8) == 'csr'
     monkeypatch.setenv('AMAR_SPMM_KIND', 'sj')
     assert m.spmm_kind(G(n16, 14_000_000, True), 8) == 'sj'
+
+
+def test_integration_md_stubs_match_the_binding_table():
+    """Every `lib.<symbol>.argtypes = [...]` line of INTEGRATION.md lists the same ctypes, in the same order, as capi.SIGNATURES
+    (which tests/test_capi_cpu.py holds against include/amar_hip.h): the documented binding cannot drift from the library."""
+    import ctypes
+    import os
+    import re
+    from deep_cbrs_amar_renaissance_amd import capi
+    text = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'INTEGRATION.md')).read()
+    names = {'P': ctypes.c_void_p, 'I32': ctypes.c_int32, 'I64': ctypes.c_int64, 'U32': ctypes.c_uint32, 'F32': ctypes.c_float}
+    found = re.findall(r'lib\.(amar_\w+)\.argtypes\s*=\s*\[([^\]]*)\]', text, flags=re.S)
+    assert len(found) >= 4
+    for sym, body in found:
+        doc = [names[t.strip()] for t in body.replace('\n', ' ').split(',') if t.strip()]
+        assert sym in capi.SIGNATURES, sym
+        assert doc == list(capi.SIGNATURES[sym][1]), sym

@@ -306,7 +306,7 @@ def test_spmm_kind_size_and_density_rules(monkeypatch):
 
 def test_integration_md_stubs_match_the_binding_table():
     """Every `lib.<symbol>.argtypes = [...]` line of INTEGRATION.md lists the same ctypes, in the same order, as capi.SIGNATURES
-    (which tests/test_capi_cpu.py holds against include/amar_hip.h): the documented binding cannot drift from the library."""
+    (which test_capi_library_exports_every_declared_symbol holds against include/amar_hip.h): the documented binding cannot drift from the library."""
     import ctypes
     import os
     import re

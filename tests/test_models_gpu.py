@@ -401,7 +401,7 @@ def test_hip_path_reproduces_golden_vectors(hip, kind, cls, graph):
 @pytest.mark.parametrize('form', ['lt', 'xs'])
 def test_large_graph_forms_reproduce_golden_vectors(hip, kind, cls, graph, form, monkeypatch):
     """The same committed fixtures with the propagation forced onto the forms large graphs take — the LDS-tiled image
-    (GCN / LightGCN layers, GraphSAGE's mean aggregate) and the XCD-sliced one (also GAT) — which these small graphs
+    (GCN / LightGCN layers, GraphSAGE's aggregate with the fused tail, GAT on amar_gat_lt_f32) and the XCD-sliced one — which these small graphs
     would not select by themselves: node table and scores against the stored oracle outputs."""
     import os
     from deep_cbrs_amar_renaissance_amd.models import basic
@@ -421,6 +421,8 @@ def test_large_graph_forms_reproduce_golden_vectors(hip, kind, cls, graph, form,
         assert isinstance(a.tiled_image(8), LdsTiled)                # the host gcn_filter route kept A_hat's factors
     if form == 'lt' and kind == 'sage':
         assert isinstance(a.tiled_mean_image(8, True), LdsTiled)
+    if form == 'lt' and kind == 'gat':
+        assert isinstance(a.tiled_gat_image(8), LdsTiled)
 
 
 @pytest.mark.parametrize('name', ['dgcf_uip', 'hybrid_attention', 'hybrid_residual', 'hybrid_entity-attention'])

@@ -442,7 +442,7 @@ def gat_lt(lt, csr, H, s_self, s_neigh, bias, Y, self_loop=True):
         _ptr(lt.words, torch.int32, 'words'), _ptr(lt.stream_start, torch.int32, 'stream_start'),
         _ptr(lt.wsteps, torch.int32, 'wsteps'), _ptr(lt.tile_row0, torch.int32, 'tile_row0'), _ptr(lt.n_win, torch.int32, 'n_win'),
         _ptr(lt.vstart, torch.int32, 'vstart'), _ptr(lt.vcount, torch.int32, 'vcount'), lt.n_tiles, lt.maxwin1, lt.pace_every,
-        int(lt.rw), _ptr(lt.diag, torch.float32, 'diag'), _ptr(csr.rowptr, torch.int32, 'rowptr'), _ptr(csr.colidx, torch.int32, 'colidx'),
+        int(lt.rw), _ptr(lt.diag, torch.float32, 'diag'), _ptr(csr.rowptr, torch.int32, 'rowptr'), _ptr_entries(csr.colidx, torch.int32, 'colidx'),
         _ptr(H, torch.float32, 'H'), _ld(H, 'H'), C, _ptr(s_self, torch.float32, 's_self'), _ptr(s_neigh, torch.float32, 's_neigh'),
         _ptr(bmax, torch.float32, 'bmax'), _ptr(bias, torch.float32, 'bias'), _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y'),
         1 if self_loop else 0, n, n_cols, row_offset, _stream())

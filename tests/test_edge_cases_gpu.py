@@ -143,3 +143,41 @@ def test_lds_tiled_edge_graphs(hip, F):
     lt = run([5, 900], [900, 5], 1000)                # one edge, 998 isolated nodes
     assert lt.n_entries == 2
     run([0, 1, 1, 2], [1, 0, 2, 1], 3, n_cu=64)       # more tiles asked for than rows exist
+
+
+@pytest.mark.parametrize('C', [8, 16, 32])
+@pytest.mark.parametrize('self_loop', [True, False])
+def test_gat_lds_tiled_edge_graphs(hip, C, self_loop):
+    """amar_gat_lt_f32 on degenerate inputs, against the row kernel: no edge at all (with the self loop every row attends to
+    itself; without it every row is empty and leaves as relu(bias)), a single node, one lone edge among isolated nodes, more
+    tiles than rows, and a list made of (i, i) edges only (they enter through `diag`)."""
+    from deep_cbrs_amar_renaissance_amd.utilities import lds_tiled
+    from deep_cbrs_amar_renaissance_amd.utilities.math import DeviceCSR, _unit_entries
+    dev = 'cuda'
+    rw = lds_tiled.GAT_ROWS_PER_WAVE[C]
+
+    def run(rows, cols, n, n_cu=256):
+        order = np.lexsort((cols, rows)) if len(rows) else np.zeros(0, np.int64)
+        r, c = np.asarray(rows, np.int64)[order], np.asarray(cols, np.int64)[order]
+        rowptr = np.zeros(n + 1, np.int64)
+        np.add.at(rowptr, r + 1, 1)
+        a = DeviceCSR(torch.from_numpy(np.cumsum(rowptr).astype(np.int32)).to(dev), torch.from_numpy(c.astype(np.int32)).to(dev), None, (n, n))
+        er, ec, diag, off = _unit_entries(a, False)
+        lt = lds_tiled.LdsTiled.build(er, ec, n, n, C, diag, torch.ones(n, device=dev), None, off, n_cu=n_cu, rw=rw)
+        g = torch.Generator(device=dev); g.manual_seed(n + C)
+        h = torch.randn((n, C), device=dev, generator=g)
+        ss, sn = torch.randn(n, device=dev, generator=g), torch.randn(n, device=dev, generator=g)
+        b = torch.randn(C, device=dev, generator=g) * 0.3
+        want, got = torch.empty((n, C), device=dev), torch.full((n, C), float('nan'), device=dev)
+        hip.gat_layer(a.rowptr, a.colidx, h, ss, sn, b, want, self_loop=self_loop)
+        hip.gat_lt(lt, a, h, ss, sn, b, got, self_loop=self_loop)
+        assert torch.isfinite(got).all() and float((got - want).abs().max()) < 1e-5
+        if not len(rows) and not self_loop:
+            assert torch.equal(got, torch.relu(b).expand(n, C))
+        return lt
+
+    run([], [], 37)
+    run([], [], 1)
+    assert run([5, 900], [900, 5], 1000).n_entries == 2
+    run([0, 1, 1, 2], [1, 0, 2, 1], 3, n_cu=64)
+    assert run([0, 1, 2, 2], [0, 1, 2, 2], 3).n_entries == 0            # self edges only (one of them twice)

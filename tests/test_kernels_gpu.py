@@ -157,6 +157,26 @@ def test_rowwise_xw(hip, F, C):
     assert rel_err(sn.cpu().numpy(), want @ a_n) < 3e-6
 
 
+@pytest.mark.parametrize('F', [8, 16])
+def test_rowwise_xw_one_thread_per_row_on_slices(hip, F):
+    """The one-thread-per-row form (square widths 8 / 16, float4-aligned operands) with its operands as column slices of wider
+    buffers — the layer input inside a concatenation buffer, the slice copy into another — and an operand whose leading
+    dimension is not a multiple of 4 floats, which must fall back to the generic kernel with the same results."""
+    n = 1500
+    rng = np.random.default_rng(F)
+    x = rng.standard_normal((n, F)).astype(np.float32)
+    w = rng.standard_normal((F, F)).astype(np.float32)
+    want = x.astype(np.float64) @ w.astype(np.float64)
+    for ld_in, off in ((3 * F, F), (3 * F + 1, 0)):
+        wide = torch.zeros((n, ld_in), device=DEV)
+        wide[:, off:off + F] = _t(x)
+        h = torch.full((n, F), float('nan'), device=DEV)
+        cat = torch.full((n, 2 * F + 4), float('nan'), device=DEV)
+        hip.rowwise_xw(wide[:, off:off + F], _t(w), h, copy_to=cat[:, 4:4 + F])
+        assert rel_err(h.cpu().numpy(), want) < 2e-6
+        assert np.array_equal(cat[:, 4:4 + F].cpu().numpy(), x) and torch.isnan(cat[:, :4]).all() and torch.isnan(cat[:, 4 + F:]).all()
+
+
 @pytest.mark.parametrize('F,C', [(8, 8), (24, 16), (5, 3)])
 def test_rowwise_xw_row_scale(hip, F, C):
     """The fused d^-1/2 pre-scale of the value-free XS chain: H = diag(s).(X.W), bit-identical to X.W followed by the

@@ -18,6 +18,21 @@ __global__ __launch_bounds__(256) void copy_columns_kernel(const float *__restri
     }
 }
 
+// the same copy in 16-byte pieces (width and both leading dimensions multiples of 4 floats, 16-byte aligned bases): a quarter of
+// the memory instructions — the per-element form moved the 768 k x 8 block of a partitioned step in 18 us
+__global__ __launch_bounds__(256) void copy_columns_vec_kernel(const float *__restrict__ src, int64_t lds,
+                                                               const int32_t *__restrict__ ids, int base,
+                                                               float *__restrict__ dst, int64_t ldd, int64_t n_rows,
+                                                               int quads) {
+    const int64_t total = n_rows * quads;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / quads;
+        const int q = (int)(i - r * quads);
+        const int64_t sr = ids ? (int64_t)ids[r] - base : r;
+        *reinterpret_cast<float4 *>(dst + r * ldd + 4 * q) = *reinterpret_cast<const float4 *>(src + sr * lds + 4 * q);
+    }
+}
+
 // out[r, c] = (((X_0 + X_1) + X_2) + ...)[r, c]  (/ n_layers for 'mean'): tf.add_n order, then tf.divide
 __global__ __launch_bounds__(256) void reduce_layers_kernel(const float *__restrict__ cat, int64_t ld, int n_layers,
                                                             int width, float *__restrict__ out, int64_t ldo,
@@ -45,8 +60,12 @@ int amar_copy_columns_f32(const float *src, int64_t lds, const int32_t *ids, int
                           float *dst, int64_t ldd, int64_t n_rows, int32_t width, amar_stream_t stream) {
     if (n_rows < 0 || width < 1 || !src || !dst || lds < width || ldd < width) return AMAR_EINVAL;
     if (n_rows == 0) return AMAR_OK;
-    hipLaunchKernelGGL(copy_columns_kernel, dim3(grid_for(n_rows * width)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), src, lds, ids, base, dst, ldd, n_rows, width);
+    if ((width & 3) == 0 && (lds & 3) == 0 && (ldd & 3) == 0 && amar_aligned16(src) && amar_aligned16(dst))
+        hipLaunchKernelGGL(copy_columns_vec_kernel, dim3(grid_for(n_rows * (width / 4))), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), src, lds, ids, base, dst, ldd, n_rows, width / 4);
+    else
+        hipLaunchKernelGGL(copy_columns_kernel, dim3(grid_for(n_rows * width)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), src, lds, ids, base, dst, ldd, n_rows, width);
     return amar_check_launch();
 }
 

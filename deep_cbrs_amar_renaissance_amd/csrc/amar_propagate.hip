@@ -1118,7 +1118,15 @@ __global__ __launch_bounds__(256) void rowwise_xw_vec_kernel(const XwArgs a) {
         for (int k = 0; k < F; ++k)                               // same order of operations per output as the generic kernel: k ascending
 #pragma unroll
             for (int c4 = 0; c4 < F; c4 += 4) {
-                const float4 w = *reinterpret_cast<const float4 *>(&w_lds[k * F + c4]);
+                // F = 8: the 64 weights by wave-uniform (scalar) loads straight into the FMAs' operands — 16 LDS broadcasts per
+                // row made this form slower than the generic one on a dense 590 k-row table (25 us against 22)
+                // (read through the constant address space: the kernel never writes W, and only then does the compiler keep the
+                // loads scalar across the loop's stores)
+                float4 w;
+                if (F == 8) {
+                    const __attribute__((address_space(4))) float *wc = (const __attribute__((address_space(4))) float *)a.W;
+                    w = make_float4(wc[k * F + c4], wc[k * F + c4 + 1], wc[k * F + c4 + 2], wc[k * F + c4 + 3]);
+                } else w = *reinterpret_cast<const float4 *>(&w_lds[k * F + c4]);
                 h[c4] = fmaf(x[k], w.x, h[c4]); h[c4 + 1] = fmaf(x[k], w.y, h[c4 + 1]);
                 h[c4 + 2] = fmaf(x[k], w.z, h[c4 + 2]); h[c4 + 3] = fmaf(x[k], w.w, h[c4 + 3]);
             }

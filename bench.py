@@ -493,7 +493,7 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(args.warmup, 20)):                   # the kernel-level timings below want settled clocks too
         runner.step()
     barrier()
     spmm_events.clear()
@@ -511,7 +511,10 @@ def main():
     step = runner.step
     if graph_step:
         try:
-            for _ in range(3):                                # capture on the first call; a graph's first replays are slower
+            # capture on the first call, then untimed replays until the clocks have settled: the eager steps before leave gaps
+            # between kernels, and the first few dozen replays of the graph run below the sustained rate (10 timed steps right
+            # after the capture: 1.26 ms per step; 100: 1.19 ms — profiles/r2_bench_repeats.txt)
+            for _ in range(max(args.warmup, 40)):
                 runner.step_graphed()
             step = runner.step_graphed
         except Exception as exc:                              # a capture the runtime refuses: the eager steps stand

@@ -360,18 +360,19 @@ def uip_graph(dev, scale, steps):
             e1.record()
             events.append((e0, e1))
         return wrapper
-    runner.step()
+    for _ in range(10):
+        runner.step()
     for name in names:
         raw[name] = getattr(capi, name)
         setattr(capi, name, timed(raw[name]))
-    for _ in range(3):
+    for _ in range(5):
         runner.step()
     torch.cuda.synchronize()
     for name in names:
         setattr(capi, name, raw[name])
     layer_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events])) if events else float('nan')
     prop_ms = runner.last_propagation_ms()
-    for _ in range(3):
+    for _ in range(40):                                           # untimed replays until the clocks have settled, as in main()
         runner.step_graphed()
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -2,8 +2,9 @@
 
 ``top_k_predictions`` keeps, for every user, the k best-scored items among THAT USER'S test
 pairs (`metrics.py:11-34`), on the GPU (`amar_topk_segmented_f32`: one wavefront per user).
-Ordering is (user ascending, score descending); equal scores — left to an unstable quicksort
-in the reference (`metrics.py:27`) — break on item id ascending here.
+Ordering is (user ascending, score descending); equal scores — left to pandas' sort in the reference
+(`metrics.py:27`: whatever order `sort_values` leaves a tie in) — break on item id ascending here.  The reference's own
+function, run on committed inputs, gives the same rows in the same order (tests/golden/topk_reference.npz).
 
 ``top_k_metrics`` in the reference shells out to ``java -jar binaries/mimir.jar`` (RiVal
 Precision/Recall, `metrics.py:60-65`); no JVM exists where this runs, so the holdout

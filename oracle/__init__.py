@@ -19,4 +19,9 @@ so those published algorithms are restated here and anchored on (a) the referenc
 sites, (b) the trainable-parameter counts published in the reference's doc.pdf (SURVEY.md §8c
 KAT table), (c) hand-computed tiny graphs, and (d) an independent second implementation
 (`oracle/torch_ref.py`, dense torch-CPU) that must agree to 1e-6.
+
+One row IS pinned by the reference itself: `top_k` (models.py) against vectors that the reference's own
+`top_k_predictions` (`src/utilities/metrics.py:11-34` — the only module of the reference that imports in the build
+container) produced there; `tests/golden/make_topk_reference_golden.py` made them, `tests/golden/topk_reference.npz`
+holds them.
 """

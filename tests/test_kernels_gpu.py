@@ -321,6 +321,24 @@ def test_copy_and_reduce_layers(hip):
         assert np.array_equal(out.cpu().numpy(), want), "same fp32 operations in the same order: bit-exact"
 
 
+@pytest.mark.parametrize('k', [5, 10])
+def test_topk_reproduces_the_reference_functions_own_output(hip, k):
+    """The device top-k (amar_topk_segmented_f32 behind utilities.metrics.top_k_predictions) against the vectors the REFERENCE's
+    own `top_k_predictions` produced (tests/golden/topk_reference.npz, made by tests/golden/make_topk_reference_golden.py from
+    /root/reference/src/utilities/metrics.py:11-34): same users, same items in the same order, scores equal to fp32 rounding."""
+    import os
+    from deep_cbrs_amar_renaissance_amd.utilities.metrics import top_k_predictions
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'topk_reference.npz'))
+    users, items, pred = z['users'], z['items'], z['pred_distinct']
+    assert len(np.unique(pred[:, 2].astype(np.float32))) == len(pred)          # distinct in fp32 too: the order is defined
+    df = top_k_predictions(pred, users, items, k=k)
+    got_u, got_i, got_s = df['users'].to_numpy(), df['items'].to_numpy(), df['scores'].to_numpy()
+    order = np.argsort(got_u, kind='stable')
+    assert np.array_equal(got_u[order], z['distinct_k{}_users'.format(k)])
+    assert np.array_equal(got_i[order], z['distinct_k{}_items'.format(k)])
+    assert np.abs(got_s[order] - z['distinct_k{}_scores'.format(k)]).max() < 1e-7
+
+
 def test_topk_segmented(hip):
     from oracle import models as om
     from deep_cbrs_amar_renaissance_amd.utilities.metrics import top_k_arrays

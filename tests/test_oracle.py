@@ -224,3 +224,35 @@ def test_top_k_tie_rule():
     s = np.array([0.5, 0.5, 0.9, 0.1, 0.1], dtype=np.float32)
     tu, ti, ts = om.top_k(u, i, s, users, items, 2)
     assert tu.tolist() == [10, 10, 20, 20] and ti.tolist() == [100, 200, 100, 200]   # ties: item id ascending
+
+
+def _by_user(users_out, items_out, scores_out):
+    res = {}
+    for u, i, s in zip(users_out.tolist(), items_out.tolist(), scores_out.tolist()):
+        res.setdefault(u, []).append((i, s))
+    return res
+
+
+@pytest.mark.parametrize('k', [5, 10])
+def test_top_k_reproduces_the_reference_functions_own_output(k):
+    """tests/golden/topk_reference.npz holds inputs and outputs of the REFERENCE's `top_k_predictions`
+    (`/root/reference/src/utilities/metrics.py:11-34`), run in the build container by tests/golden/make_topk_reference_golden.py —
+    the one function of the hot path that imports without TensorFlow.  With distinct scores the oracle must give the same rows in
+    the same order per user (id mapping, score-descending order, fewer than k pairs); with tied scores the rows may differ only
+    inside a tie (the reference keeps pandas' sort order there, the oracle breaks ties on item id) and the scores are the same."""
+    z = np.load(os.path.join(GOLDEN, 'topk_reference.npz'))
+    users, items = z['users'], z['items']
+    for name in ('distinct', 'ties'):
+        pred = z['pred_' + name]
+        tu, ti, ts = om.top_k(pred[:, 0], pred[:, 1], pred[:, 2], users, items, k)
+        got = _by_user(tu, ti, ts)
+        want = _by_user(z['{}_k{}_users'.format(name, k)], z['{}_k{}_items'.format(name, k)], z['{}_k{}_scores'.format(name, k)])
+        assert sorted(got) == sorted(want)
+        assert len(want[int(users[7])]) == 2                           # a user with fewer than k test pairs keeps what it has
+        for u in want:
+            assert [s for _, s in got[u]] == [s for _, s in want[u]], (name, u)       # bit-equal float64 scores, same order
+            if name == 'distinct':
+                assert [i for i, _ in got[u]] == [i for i, _ in want[u]], u
+            else:
+                strict = [i for i, s in want[u] if [t for _, t in want[u]].count(s) == 1 and s > want[u][-1][1]]
+                assert [i for i, s in got[u] if i in strict] == strict, u              # everything outside a tie matches exactly

@@ -319,3 +319,40 @@ def test_integration_md_stubs_match_the_binding_table():
         doc = [names[t.strip()] for t in body.replace('\n', ' ').split(',') if t.strip()]
         assert sym in capi.SIGNATURES, sym
         assert doc == list(capi.SIGNATURES[sym][1]), sym
+
+
+@pytest.mark.parametrize('sym', [True, False])
+def test_loaders_reproduce_the_reference_functions_own_output(tmp_path, sym):
+    """The product's `data.loaders.load_train_test_ratings` (+ `data.preprocess`) on the files of tests/golden/graph_reference.npz
+    against what the REFERENCE's own functions returned for them (made by tests/golden/make_graph_reference_golden.py): indexed
+    ratings, users / items, and the adjacency matrices — same triplets in the same order, shape and dtype — for 'unary',
+    'unary-uip', 'unary-kg' and the user-property graph."""
+    import os
+    from scipy import sparse
+    from deep_cbrs_amar_renaissance_amd.data import loaders, preprocess
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'graph_reference.npz'))
+    paths = {}
+    for k in ('train', 'test', 'props'):
+        paths[k] = str(tmp_path / (k + '.tsv'))
+        np.savetxt(paths[k], z['raw_' + k], fmt='%d', delimiter='\t')
+    (tr, te), (users, items) = loaders.load_train_test_ratings(paths['train'], paths['test'])
+    assert np.array_equal(tr, z['train_indexed']) and np.array_equal(te, z['test_indexed'])
+    assert np.array_equal(users, z['users']) and np.array_equal(items, z['items'])
+
+    def same(m, tag, j=0):
+        m = m.tocoo() if not sparse.isspmatrix_coo(m) else m
+        assert tuple(m.shape) == tuple(z['{}_{}_shape'.format(tag, j)]) and str(m.dtype) == str(z['{}_{}_dtype'.format(tag, j)])
+        assert np.array_equal(m.row, z['{}_{}_row'.format(tag, j)]) and np.array_equal(m.col, z['{}_{}_col'.format(tag, j)])
+        assert np.array_equal(np.asarray(m.data), z['{}_{}_val'.format(tag, j)])
+    tag = 'sym' if sym else 'raw'
+    for kind in ('unary', 'unary-uip', 'unary-kg'):
+        _, _, adj = loaders.load_train_test_ratings(paths['train'], paths['test'], paths['props'] if kind != 'unary' else None,
+                                                    return_adjacency=True, type_adjacency=kind, symmetric_adjacency=sym)
+        mats = adj if isinstance(adj, tuple) else (adj,)
+        for j, m in enumerate(mats):
+            same(m, '{}_{}'.format(kind.replace('-', '_'), tag), j)
+        if kind == 'unary-kg' and sym:
+            up = preprocess.get_user_properties(mats[0], mats[1], len(users), len(items)).tocoo()
+            ref = sparse.coo_matrix((z['user_props_val'], (z['user_props_row'], z['user_props_col'])), shape=tuple(z['user_props_shape']))
+            assert tuple(up.shape) == ref.shape and str(up.dtype) == str(z['user_props_dtype'])
+            assert (abs(up - ref)).nnz == 0                           # the sparse build: same matrix (its triplet order is its own)

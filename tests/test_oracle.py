@@ -256,3 +256,39 @@ def test_top_k_reproduces_the_reference_functions_own_output(k):
             else:
                 strict = [i for i, s in want[u] if [t for _, t in want[u]].count(s) == 1 and s > want[u][-1][1]]
                 assert [i for i, s in got[u] if i in strict] == strict, u              # everything outside a tie matches exactly
+
+
+def _ref_coo(z, tag, j=0):
+    return z['{}_{}_row'.format(tag, j)], z['{}_{}_col'.format(tag, j)], z['{}_{}_val'.format(tag, j)], tuple(z['{}_{}_shape'.format(tag, j)]), str(z['{}_{}_dtype'.format(tag, j)])
+
+
+def _same_coo(m, ref):
+    r, c, v, shape, dtype = ref
+    m = m.tocoo() if not sparse.isspmatrix_coo(m) else m
+    assert tuple(m.shape) == shape and str(m.dtype) == dtype
+    assert np.array_equal(m.row, r) and np.array_equal(m.col, c) and np.array_equal(np.asarray(m.data), v)      # same triplets, same ORDER
+
+
+@pytest.mark.parametrize('sym', [True, False])
+def test_graph_construction_reproduces_the_reference_functions_own_output(sym):
+    """tests/golden/graph_reference.npz holds inputs and outputs of the REFERENCE's `load_train_test_ratings`,
+    `build_adjacency_matrix`, `symmetrize_matrix` and `get_user_properties` (loaders.py:11-82, preprocess.py:9-170, math.py:6-21),
+    executed in the build container by tests/golden/make_graph_reference_golden.py.  The oracle's rows A1 / A1' must give the same
+    contiguous ids, the same users / items arrays and bit-identical COO triplets IN THE SAME ORDER (duplicates kept) and dtype."""
+    from oracle import graph as og
+    z = np.load(os.path.join(GOLDEN, 'graph_reference.npz'))
+    (train, test), (users, items) = og.remap_ratings(z['raw_train'], z['raw_test'])
+    assert np.array_equal(train, z['train_indexed']) and np.array_equal(test, z['test_indexed'])
+    assert np.array_equal(users, z['users']) and np.array_equal(items, z['items'])
+    triples, props = og.remap_props(z['raw_props'], items)
+    nu, ni, n_props = len(users), len(items), len(props)
+    tag = 'sym' if sym else 'raw'
+    _same_coo(og.adjacency_unary(train, nu, ni, sym), _ref_coo(z, 'unary_' + tag))
+    _same_coo(og.adjacency_unary_uip(train, triples, nu, ni, n_props, sym), _ref_coo(z, 'unary_uip_' + tag))
+    bi, kg = og.adjacency_unary_kg(train, triples, nu, ni, n_props, sym)
+    _same_coo(bi, _ref_coo(z, 'unary_kg_' + tag, 0))
+    _same_coo(kg, _ref_coo(z, 'unary_kg_' + tag, 1))
+    if sym:
+        up = og.user_properties(bi, kg, nu, ni)
+        assert tuple(up.shape) == tuple(z['user_props_shape']) and str(up.dtype) == str(z['user_props_dtype'])
+        assert np.array_equal(up.row, z['user_props_row']) and np.array_equal(up.col, z['user_props_col']) and np.array_equal(up.data, z['user_props_val'])

@@ -6,19 +6,25 @@ The modules that hold them import TensorFlow at their top (`src/utilities/math.p
 and so cannot be imported here (ModuleNotFoundError, an ordinary import error) — but the four functions themselves are plain
 numpy / pandas / scipy:
 
-    symmetrize_matrix          /root/reference/src/utilities/math.py:6-21
-    get_user_properties        /root/reference/src/data/preprocess.py:9-41
-    build_adjacency_matrix     /root/reference/src/data/preprocess.py:44-170
-    load_train_test_ratings    /root/reference/src/data/loaders.py:11-82
+    symmetrize_matrix               /root/reference/src/utilities/math.py:6-21
+    get_user_properties             /root/reference/src/data/preprocess.py:9-41
+    build_adjacency_matrix          /root/reference/src/data/preprocess.py:44-170
+    process_item_properties_graph   /root/reference/src/data/preprocess.py:173-198
+    load_train_test_ratings         /root/reference/src/data/loaders.py:11-82
+    json_load_graph_embeddings, json_load_bert_embeddings, load_graph_user_item_embeddings,
+    load_bert_user_item_embeddings  /root/reference/src/data/loaders.py:85-144
 
 This script reads those files as text, takes exactly these function definitions out of the syntax tree and executes THEM,
-unchanged, in a namespace that holds numpy, pandas and scipy.sparse — nothing of the reference is copied into the repo, nothing
+unchanged, in a namespace that holds json, numpy, pandas and scipy.sparse — nothing of the reference is copied into the repo, nothing
 is stubbed.  It then writes small rating / property files, calls `load_train_test_ratings` on them for every adjacency type of
-the hot path, and stores inputs and outputs in tests/golden/graph_reference.npz.  The reference tree does not travel; the fixture does.
+the hot path, and stores inputs and outputs in tests/golden/graph_reference.npz; the embedding loaders and the offline property
+filter run on small JSON / TSV files of the reference's formats -> tests/golden/loaders_reference.npz.  The reference
+tree does not travel; the fixtures do.
 
     python tests/golden/make_graph_reference_golden.py      (needs /root/reference; CPU only)
 """
 import ast
+import json
 import os
 import sys
 import tempfile
@@ -30,12 +36,13 @@ from scipy import sparse
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = '/root/reference/src'
 WANTED = {'utilities/math.py': ['symmetrize_matrix'],
-          'data/preprocess.py': ['get_user_properties', 'build_adjacency_matrix'],
-          'data/loaders.py': ['load_train_test_ratings']}
+          'data/preprocess.py': ['get_user_properties', 'build_adjacency_matrix', 'process_item_properties_graph'],
+          'data/loaders.py': ['load_train_test_ratings', 'json_load_graph_embeddings', 'json_load_bert_embeddings',
+                              'load_graph_user_item_embeddings', 'load_bert_user_item_embeddings']}
 
 
 def reference_functions():
-    ns = {'np': np, 'pd': pd, 'sparse': sparse}
+    ns = {'json': json, 'np': np, 'pd': pd, 'sparse': sparse}
     for rel, names in WANTED.items():
         path = os.path.join(REF, rel)
         tree = ast.parse(open(path).read(), filename=path)
@@ -105,8 +112,35 @@ def main():
                     r, c, v, shp = coo(up)
                     out.update(user_props_row=r, user_props_col=c, user_props_val=v, user_props_shape=shp,
                                user_props_dtype=np.array(str(up.dtype)))
+        # --- embedding files and the offline property filter, in the reference's on-disk formats
+        lo = {}
+        dim = 6
+        n_ent = int(max(users.max(), items.max())) + 1
+        kge = rng.uniform(-0.1, 0.1, (n_ent, dim)).astype(np.float32)
+        kge_path = os.path.join(d, 'kge.json')
+        json.dump({'ent_embeddings': kge.tolist()}, open(kge_path, 'w'))
+        ub = (0.5 * rng.standard_normal((len(users), dim))).astype(np.float32)
+        ib = (0.5 * rng.standard_normal((len(items), dim))).astype(np.float32)
+        pu, pi = rng.permutation(len(users)), rng.permutation(len(items))                # file order is not id order
+        ub_path, ib_path = os.path.join(d, 'user-lastlayer.json'), os.path.join(d, 'item-lastlayer.json')
+        json.dump([{'ID_OpenKE': int(users[k]), 'profile_embedding': ub[k].tolist()} for k in pu], open(ub_path, 'w'))
+        json.dump([{'ID_OpenKE': int(items[k]), 'embedding': ib[k].tolist()} for k in pi], open(ib_path, 'w'))
+        lo.update(kge_table=kge, bert_users=ub, bert_items=ib, bert_user_file_order=pu, bert_item_file_order=pi, users=users, items=items)
+        lo['kge_rows'] = fn['load_graph_user_item_embeddings'](kge_path, users, items)
+        lo['bert_rows'] = fn['load_bert_user_item_embeddings'](ub_path, ib_path, users, items)
+        # graph file: a header line, the train ratings, then KG triples — some about items that never occur in train
+        extra = np.stack([rng.choice(np.setdiff1d(np.arange(900), items), 12), rng.integers(0, 3000, 12), rng.integers(0, 11, 12)], axis=1)
+        kg_rows = np.concatenate([props, extra])[rng.permutation(len(props) + 12)]
+        graph_path, kg_out = os.path.join(d, 'graph.tsv'), os.path.join(d, 'kg_out.tsv')
+        with open(graph_path, 'w') as fp:
+            fp.write('head\ttail\trel\n')
+            np.savetxt(fp, np.concatenate([train, kg_rows]), fmt='%d', delimiter='\t')
+        fn['process_item_properties_graph'](paths['train'], graph_path, kg_out)
+        lo.update(filter_ratings=train, filter_kg_rows=kg_rows, filter_output=np.loadtxt(kg_out, dtype=np.int64, delimiter='\t').reshape(-1, 3))
     np.savez_compressed(os.path.join(HERE, 'graph_reference.npz'), **out)
+    np.savez_compressed(os.path.join(HERE, 'loaders_reference.npz'), **lo)
     print('wrote graph_reference.npz:', len(out), 'arrays;', {k: out[k].shape for k in ('raw_train', 'raw_test', 'raw_props', 'users', 'items')})
+    print('wrote loaders_reference.npz:', {k: v.shape for k, v in lo.items()})
 
 
 if __name__ == '__main__':

@@ -356,3 +356,31 @@ def test_loaders_reproduce_the_reference_functions_own_output(tmp_path, sym):
             ref = sparse.coo_matrix((z['user_props_val'], (z['user_props_row'], z['user_props_col'])), shape=tuple(z['user_props_shape']))
             assert tuple(up.shape) == ref.shape and str(up.dtype) == str(z['user_props_dtype'])
             assert (abs(up - ref)).nnz == 0                           # the sparse build: same matrix (its triplet order is its own)
+
+
+def test_embedding_loaders_and_property_filter_reproduce_the_reference_functions_own_output(tmp_path):
+    """SURVEY 8f N2 against the reference itself: tests/golden/loaders_reference.npz holds what the REFERENCE's
+    `load_graph_user_item_embeddings`, `load_bert_user_item_embeddings` (loaders.py:85-144) and `process_item_properties_graph`
+    (preprocess.py:173-198) returned for small files of its on-disk formats (made by tests/golden/make_graph_reference_golden.py);
+    the product's loaders must return the same arrays bit for bit and write the same filtered property file."""
+    import json
+    import os
+    from deep_cbrs_amar_renaissance_amd.data import loaders, preprocess
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'loaders_reference.npz'))
+    users, items = z['users'], z['items']
+    kge = str(tmp_path / 'kge.json')
+    json.dump({'ent_embeddings': z['kge_table'].tolist()}, open(kge, 'w'))
+    got = loaders.load_graph_user_item_embeddings(kge, users, items)
+    assert got.dtype == np.float32 and np.array_equal(got, z['kge_rows'])
+    ub, ib = str(tmp_path / 'u.json'), str(tmp_path / 'i.json')
+    json.dump([{'ID_OpenKE': int(users[k]), 'profile_embedding': z['bert_users'][k].tolist()} for k in z['bert_user_file_order']], open(ub, 'w'))
+    json.dump([{'ID_OpenKE': int(items[k]), 'embedding': z['bert_items'][k].tolist()} for k in z['bert_item_file_order']], open(ib, 'w'))
+    got = loaders.load_bert_user_item_embeddings(ub, ib, users, items)
+    assert got.dtype == np.float32 and np.array_equal(got, z['bert_rows'])
+    ratings, graph, out = str(tmp_path / 'train.tsv'), str(tmp_path / 'graph.tsv'), str(tmp_path / 'kg.tsv')
+    np.savetxt(ratings, z['filter_ratings'], fmt='%d', delimiter='\t')
+    with open(graph, 'w') as fp:
+        fp.write('head\ttail\trel\n')
+        np.savetxt(fp, np.concatenate([z['filter_ratings'], z['filter_kg_rows']]), fmt='%d', delimiter='\t')
+    preprocess.process_item_properties_graph(ratings, graph, out)
+    assert np.array_equal(np.loadtxt(out, dtype=np.int64, delimiter='\t').reshape(-1, 3), z['filter_output'])

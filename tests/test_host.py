@@ -384,3 +384,18 @@ def test_embedding_loaders_and_property_filter_reproduce_the_reference_functions
         np.savetxt(fp, np.concatenate([z['filter_ratings'], z['filter_kg_rows']]), fmt='%d', delimiter='\t')
     preprocess.process_item_properties_graph(ratings, graph, out)
     assert np.array_equal(np.loadtxt(out, dtype=np.int64, delimiter='\t').reshape(-1, 3), z['filter_output'])
+
+
+def test_experiment_grid_expansion_reproduces_the_reference_functions_own_output():
+    """tests/golden/grid_reference.json: grids shaped like the reference's econfigs and what the REFERENCE's `make_grid` /
+    `nested_dict_update` (utils.py:19-99, executed by tests/golden/make_grid_reference_golden.py) made of them — the product's
+    `utilities.utils` must expand to the same experiments in the same order and merge nested sections the same way."""
+    import copy
+    import json
+    import os
+    from deep_cbrs_amar_renaissance_amd.utilities import utils
+    z = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'grid_reference.json')))
+    for name, case in z['grids'].items():
+        assert utils.make_grid(copy.deepcopy(case['input'])) == case['output'], name
+    for case in z['updates']:
+        assert utils.nested_dict_update(copy.deepcopy(case['d']), copy.deepcopy(case['u'])) == case['output']

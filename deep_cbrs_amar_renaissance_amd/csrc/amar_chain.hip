@@ -57,11 +57,14 @@ __device__ __forceinline__ float chain_act(float v, int act) {
 // body is straight-line code.
 template <bool RELU>
 __device__ __forceinline__ float chain_act_t(float v, int act) { return RELU ? fmaxf(v, 0.f) : chain_act(v, act); }
+// AM (activation mode of chain_kernel): 0 = run-time values, 1 = ReLU everywhere, 2 = ReLU everywhere but the LAST MFMA layer, which is
+// linear — the per-entity towers that end in the folded half of the classifier's first layer (models/basic.py:_split_plan).
 
 // FULL: every MFMA layer has exactly MAXT input and MAXT output tiles (e.g. grid1's 48 -> 48 -> 48 classifier with
 // MAXT = 3): the tile guards fold away and the layer bodies become straight-line MFMA code.
-template <int MAXT, int PT, bool FULL, bool RELU>
+template <int MAXT, int PT, bool FULL, int AM>
 __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
+    constexpr bool RELU = AM != 0;
     extern __shared__ __attribute__((aligned(16))) float w_lds[];
     for (int i = threadIdx.x * 4; i < a.wpack_floats; i += blockDim.x * 4)
         *reinterpret_cast<float4 *>(&w_lds[i]) = *reinterpret_cast<const float4 *>(a.wpack + i);
@@ -126,18 +129,28 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
                 }
             }
             const int act = a.act[l];
+            if (AM == 2 && l == a.n_layers - 1) {                              // the linear last layer
 #pragma unroll
-            for (int m = 0; m < MAXT; ++m)
+                for (int m = 0; m < MAXT; ++m)
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt) {
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (FULL || m < NT) {
-                        v = y[m][pt];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = chain_act_t<RELU>(v[r], act);
+                    for (int pt = 0; pt < PT; ++pt) {
+                        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                        x[m][pt] = (FULL || m < NT) ? y[m][pt] : zero;
                     }
-                    x[m][pt] = v;
-                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < MAXT; ++m)
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) {
+                        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                        if (FULL || m < NT) {
+                            v = y[m][pt];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = chain_act_t<RELU>(v[r], act);
+                        }
+                        x[m][pt] = v;
+                    }
+            }
         }
         // ---- output
         if (a.has_dot) {
@@ -173,6 +186,111 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
     }
 }
 
+// ReLU as one integer max on the float's bits (no NaN-quieting pre-pass).
+// Identical to fmaxf(v, 0) for every finite v (and -0, -NaN -> 0).  A positive-sign NaN stays a NaN here while fmaxf(NaN, 0) = 0
+// in the generic kernel: not reachable from finite weights and rows, so the two kernels agree bit for bit on real inputs.
+__device__ __forceinline__ float relu_bits(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
+
+// Entity-tower form of the same chain: ONE input table (rows themselves or ids), no trailing dot, ReLU layers with an optionally linear
+// last one, and the tile counts of every layer known at COMPILE time (SHAPE = layer count | tiles of dims[0] << 3 | tiles of
+// dims[1] << 6 | ...).  The generic kernel above walks its layers with run-time tile guards — a scalar branch around every weight
+// fragment — and asks for its rows at the top of an iteration; here the layer bodies are straight-line MFMA code and the rows of
+// iteration k+1 are requested right after layer 0 of iteration k has consumed the current ones (unconditionally: positions past the
+// end re-read the last row).  Same arithmetic in the same order: bit-identical to the generic kernel.
+constexpr int chain_shape(int nl, int t0, int t1, int t2 = 0, int t3 = 0) { return nl | t0 << 3 | t1 << 6 | t2 << 9 | t3 << 12; }
+constexpr int shape_nl(int s) { return s & 7; }
+constexpr int shape_t(int s, int j) { return (s >> (3 * (j + 1))) & 7; }
+constexpr int shape_maxt(int s) {
+    int m = 0;
+    for (int j = 0; j <= shape_nl(s); ++j) m = shape_t(s, j) > m ? shape_t(s, j) : m;
+    return m;
+}
+
+template <int SHAPE, int PT, bool LASTLIN>
+__global__ __launch_bounds__(256) void chain_rows_kernel(const ChainArgs a) {
+    constexpr int NL = shape_nl(SHAPE), T0 = shape_t(SHAPE, 0), TN = shape_t(SHAPE, NL), MAXT = shape_maxt(SHAPE);
+    extern __shared__ __attribute__((aligned(16))) float w_lds[];
+    for (int i = threadIdx.x * 4; i < a.wpack_floats; i += blockDim.x * 4)
+        *reinterpret_cast<float4 *>(&w_lds[i]) = *reinterpret_cast<const float4 *>(a.wpack + i);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, g = lane >> 4, col = lane & 15;
+    constexpr uint32_t rows_per_wave = 16 * PT;
+    const uint32_t stride = gridDim.x * 4 * rows_per_wave;
+    const uint32_t P = (uint32_t)a.P, last = P - 1;                 // (the launcher checks P + 2 strides < 2^30 and the row bytes)
+    const uint32_t lda = (uint32_t)a.lda * 4u;
+    const int f_last = 16 * (T0 - 1) + 4 * g;                      // this lane's features of the last input tile: past Da -> zeros
+    const bool tail_ok = f_last < a.Da;
+    const char *Ag = reinterpret_cast<const char *>(a.A) + 16 * g;
+    const int tail_off = tail_ok ? 64 * (T0 - 1) : -16 * g;        // (a lane past Da in the last tile re-reads the row's first features)
+
+    f32x4 xin[MAXT][PT];
+    auto gather = [&](uint32_t b) {
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const uint32_t p = min(b + 16 * pt + col, last);
+            const uint32_t row = a.ids_a ? (uint32_t)(a.ids_a[p] - a.base_a) : p;
+            const char *pa = Ag + (uint64_t)row * lda;
+#pragma unroll
+            for (int t = 0; t < T0; ++t)
+                xin[t][pt] = *reinterpret_cast<const f32x4 *>(pa + (t == T0 - 1 ? tail_off : 64 * t));
+        }
+    };
+
+    uint32_t base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * rows_per_wave;
+    if (base >= P) return;
+    gather(base);
+    for (; base < P; base += stride) {
+        f32x4 x[MAXT][PT];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const int KT = shape_t(SHAPE, l), NT = shape_t(SHAPE, l + 1);
+            const float *wl = w_lds + a.w_off[l];
+            const float *bl = w_lds + a.b_off[l];
+            f32x4 y[MAXT][PT];
+#pragma unroll
+            for (int m = 0; m < MAXT; ++m) {
+                if (m < NT) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bl + 16 * m + 4 * g);
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt) y[m][pt] = b4;
+#pragma unroll
+                    for (int t = 0; t < MAXT; ++t) {
+                        if (t < KT) {
+                            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wl + ((m * KT + t) * 64 + lane) * 4);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                                for (int pt = 0; pt < PT; ++pt) {
+                                    float xv = l == 0 ? xin[t][pt][r] : x[t][pt][r];
+                                    if (l == 0 && t == T0 - 1) xv = tail_ok ? xv : 0.f;
+                                    y[m][pt] = __builtin_amdgcn_mfma_f32_16x16x4f32(w4[r], xv, y[m][pt], 0, 0, 0);
+                                }
+                        }
+                    }
+                }
+            }
+            if (l == 0) gather(base + stride);                      // the current rows are consumed: request the next iteration's
+#pragma unroll
+            for (int m = 0; m < MAXT; ++m)
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt)
+                    if (m < NT) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) x[m][pt][r] = (LASTLIN && l == NL - 1) ? y[m][pt][r] : relu_bits(y[m][pt][r]);
+                    }
+        }
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const uint32_t p = base + 16 * pt + col;
+            float *po = a.out + (int64_t)p * a.ldo + 4 * g;
+#pragma unroll
+            for (int m = 0; m < TN; ++m)
+                if (p < P && 16 * m + 4 * g < a.n_out) *reinterpret_cast<f32x4 *>(po + 16 * m) = x[m][pt];
+        }
+    }
+}
+
 // Pair-stage form of the same chain (x = relu(A[ida] + B[idb]), every layer MAXT x MAXT tiles with ReLU, Da = 16 MAXT).
 //
 // What bounds this stage (tools/micro/mfma_valu_overlap.hip, tools/exp_chain_bound.py): on gfx950 an fp32 MFMA holds the
@@ -187,9 +305,6 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
 //   * takes ReLU as one integer max on the float's bits (no NaN-quieting pre-pass), forms addresses from 32-bit row
 //     numbers, and evaluates the final activation once per 32 pairs (lane group g finishes pair tile g).
 // Same arithmetic in the same order as the generic kernel: the scores are bit-identical.
-// Identical to fmaxf(v, 0) for every finite v (and -0, -NaN -> 0).  A positive-sign NaN stays a NaN here while fmaxf(NaN, 0) = 0
-// in the generic kernel: not reachable from finite weights and rows, so the two kernels agree bit for bit on real inputs.
-__device__ __forceinline__ float relu_bits(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
 
 // SCATTER: scores go to out[out_index[p]] (a pair list prepared in XCD-affine order writes back in the caller's order); the index is
 // requested at the top of the iteration, unconditionally like every other load here, and has the whole MFMA block to arrive.
@@ -201,41 +316,45 @@ __global__ __launch_bounds__(256) void chain_pipe_kernel(const ChainArgs a) {
     __syncthreads();
 
     const int lane = threadIdx.x & 63, g = lane >> 4, col = lane & 15;
-    const int64_t pairs_per_wave = 16 * PT;
-    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t stride = (int64_t)gridDim.x * 4 * pairs_per_wave;
-    const float *Ag = a.A + 4 * g, *Bg = a.B + 4 * g;
-    const uint32_t lda = (uint32_t)a.lda, ldb = (uint32_t)a.ldb;   // (the launcher checks that both fit 32 bits)
+    // Positions are 32-bit (the launcher checks P + 3 strides < 2^30): the ids' byte offsets stay 32-bit next to a scalar base
+    // and a row address is ONE v_mad_u64_u32 (row x row bytes + base) — a dozen 64-bit VALU operations per iteration gone.
+    constexpr uint32_t pairs_per_wave = 16 * PT;
+    const uint32_t wave0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t stride = gridDim.x * 4 * pairs_per_wave;
+    const uint32_t P = (uint32_t)a.P, last = P - 1;
+    const char *Ag = reinterpret_cast<const char *>(a.A + 4 * g), *Bg = reinterpret_cast<const char *>(a.B + 4 * g);
+    const uint32_t lda = (uint32_t)a.lda * 4u, ldb = (uint32_t)a.ldb * 4u;   // row bytes (the launcher checks that both fit 32 bits)
+    const char *ids_a = reinterpret_cast<const char *>(a.ids_a), *ids_b = reinterpret_cast<const char *>(a.ids_b);
 
     // Ids and gathers are requested UNCONDITIONALLY (positions past the end re-read the last pair, whose rows exist): an
     // exec-masked load is followed by its own s_waitcnt, which would also wait for every gather still in flight, and a
     // conditionally overwritten register set costs a copy of all 48 registers per iteration.
-    const int64_t last = a.P - 1;
-    auto load_ids = [&](int64_t b, int32_t (&ra)[PT], int32_t (&rb)[PT]) {
+    auto load_ids = [&](uint32_t b, int32_t (&ra)[PT], int32_t (&rb)[PT]) {
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
-            const int64_t p = min(b + 16 * pt + col, last);
-            ra[pt] = a.ids_a[p];
-            rb[pt] = a.ids_b[p];
+            const uint32_t off = min(b + 16 * pt + col, last) << 2;
+            ra[pt] = *reinterpret_cast<const int32_t *>(ids_a + off);
+            rb[pt] = *reinterpret_cast<const int32_t *>(ids_b + off);
         }
     };
     auto issue = [&](const int32_t (&ra)[PT], const int32_t (&rb)[PT], f32x4 (&va)[MAXT][PT], f32x4 (&vb)[MAXT][PT]) {
 #pragma unroll
         for (int pt = 0; pt < PT; ++pt) {
-            const float *pa = Ag + (uint64_t)(uint32_t)(ra[pt] - a.base_a) * lda;   // one v_mad_u64_u32 each
-            const float *pb = Bg + (uint64_t)(uint32_t)(rb[pt] - a.base_b) * ldb;
+            const char *pa = Ag + (uint64_t)(uint32_t)(ra[pt] - a.base_a) * lda;   // one v_mad_u64_u32 each
+            const char *pb = Bg + (uint64_t)(uint32_t)(rb[pt] - a.base_b) * ldb;
 #pragma unroll
             for (int t = 0; t < MAXT; ++t) {
-                va[t][pt] = *reinterpret_cast<const f32x4 *>(pa + 16 * t);
-                vb[t][pt] = *reinterpret_cast<const f32x4 *>(pb + 16 * t);
+                va[t][pt] = *reinterpret_cast<const f32x4 *>(pa + 64 * t);
+                vb[t][pt] = *reinterpret_cast<const f32x4 *>(pb + 64 * t);
             }
         }
     };
     // one iteration: consume (va, vb), start the next iteration's gathers into (na, nb), run the layers, store
-    auto step = [&](int64_t base, int32_t (&ra)[PT], int32_t (&rb)[PT], f32x4 (&va)[MAXT][PT], f32x4 (&vb)[MAXT][PT],
+    auto step = [&](uint32_t base, int32_t (&ra)[PT], int32_t (&rb)[PT], f32x4 (&va)[MAXT][PT], f32x4 (&vb)[MAXT][PT],
                     f32x4 (&na)[MAXT][PT], f32x4 (&nb)[MAXT][PT]) {
         int32_t out_row = 0;
-        if (SCATTER) out_row = a.out_index[min(base + 16 * min(g, PT - 1) + col, last)];
+        if (SCATTER) out_row = *reinterpret_cast<const int32_t *>(reinterpret_cast<const char *>(a.out_index) +
+                                                                  (min(base + 16 * min(g, PT - 1) + col, last) << 2));
         f32x4 x[MAXT][PT];
 #pragma unroll
         for (int t = 0; t < MAXT; ++t)
@@ -298,29 +417,29 @@ __global__ __launch_bounds__(256) void chain_pipe_kernel(const ChainArgs a) {
             for (int pt = 1; pt < PT; ++pt) z = g == pt ? s[pt] : z;
             z += bd;
             z = chain_act(z, a.dot_act);                            // same expression as the generic kernel: bit-identical scores
-            const int64_t p = base + 16 * g + col;
-            if (g < PT && p < a.P) a.out[(SCATTER ? (int64_t)out_row : p) * a.ldo] = z;
+            const uint32_t p = base + 16 * g + col;
+            if (g < PT && p < P) a.out[(SCATTER ? (int64_t)out_row : (int64_t)p) * a.ldo] = z;
         } else {
 #pragma unroll
             for (int pt = 0; pt < PT; ++pt) {
-                const int64_t p = base + 16 * pt + col;
+                const uint32_t p = base + 16 * pt + col;
 #pragma unroll
                 for (int m = 0; m < MAXT; ++m) {
                     const int f = 16 * m + 4 * g;
-                    if (p < a.P && f < a.n_out) *reinterpret_cast<f32x4 *>(a.out + chain_out_row(a, p) * a.ldo + f) = x[m][pt];
+                    if (p < P && f < a.n_out) *reinterpret_cast<f32x4 *>(a.out + chain_out_row(a, p) * a.ldo + f) = x[m][pt];
                 }
             }
         }
     };
 
-    int64_t base = wave0 * pairs_per_wave;
-    if (base >= a.P) return;
+    uint32_t base = wave0 * pairs_per_wave;
+    if (base >= P) return;
     f32x4 va[MAXT][PT], vb[MAXT][PT];
     int32_t ra[PT], rb[PT];
     load_ids(base, ra, rb);
     issue(ra, rb, va, vb);
     load_ids(base + stride, ra, rb);
-    for (; base < a.P; base += stride) step(base, ra, rb, va, vb, va, vb);   // the raw rows are consumed before the next ones are requested
+    for (; base < P; base += stride) step(base, ra, rb, va, vb, va, vb);   // the raw rows are consumed before the next ones are requested
 }
 
 // Two-branch form for the hybrid head (src/models/hybrid.py:72-89 with the first layers of dense3a / dense3b folded
@@ -695,16 +814,24 @@ int amar_chain_indexed_f32(const float *A, int64_t lda, int32_t Da, const int32_
     const int maxt = maxw <= 48 ? 3 : (maxw <= 64 ? 4 : 8);
     bool full = (dims[0] + 15) / 16 == maxt && (!a.has_dot || a.dot_kt == maxt);
     for (int l = 0; l < a.n_layers; ++l) full = full && a.kt[l] == maxt && a.nt[l] == maxt;
-    bool relu = !a.sum_inputs || a.in_act == AMAR_ACT_RELU;
-    for (int l = 0; l < a.n_layers; ++l) relu = relu && a.act[l] == AMAR_ACT_RELU;
+    bool relu = !a.sum_inputs || a.in_act == AMAR_ACT_RELU, relu_but_last = relu && !a.has_dot;
+    for (int l = 0; l < a.n_layers; ++l) {
+        relu = relu && a.act[l] == AMAR_ACT_RELU;
+        relu_but_last = relu_but_last && a.act[l] == (l == a.n_layers - 1 ? AMAR_ACT_NONE : AMAR_ACT_RELU);
+    }
+    static const bool no_am2 = getenv("AMAR_CHAIN_AM2") && atoi(getenv("AMAR_CHAIN_AM2")) == 0;   // A/B: run-time activations for the towers
+    const int am = relu ? 1 : (relu_but_last && !no_am2 ? 2 : 0);
     int pt = 2;                                                   // measured best on grid1/grid2/grid6 shapes (tools/exp_chain.py)
     if (force_pt == 1 || force_pt == 2 || (force_pt == 4 && maxt != 8)) pt = force_pt;
+    static const int gen_cap = getenv("AMAR_CHAIN_GRID") ? atoi(getenv("AMAR_CHAIN_GRID")) : 4096;
 #define AMAR_CHAIN_LAUNCH(MT, PTT)                                                                                      \
     do {                                                                                                                \
         int64_t blocks = (P + 4 * 16 * PTT - 1) / (4 * 16 * PTT);                                                       \
-        if (blocks > 4096) blocks = 4096;                                                                               \
-        auto kern = full ? (relu ? chain_kernel<MT, PTT, true, true> : chain_kernel<MT, PTT, true, false>)              \
-                         : (relu ? chain_kernel<MT, PTT, false, true> : chain_kernel<MT, PTT, false, false>);           \
+        if (blocks > gen_cap) blocks = gen_cap;                                                                         \
+        auto kern = full ? (am == 1 ? chain_kernel<MT, PTT, true, 1> : am == 2 ? chain_kernel<MT, PTT, true, 2>         \
+                                                                               : chain_kernel<MT, PTT, true, 0>)        \
+                         : (am == 1 ? chain_kernel<MT, PTT, false, 1> : am == 2 ? chain_kernel<MT, PTT, false, 2>       \
+                                                                                : chain_kernel<MT, PTT, false, 0>);     \
         if (lds_bytes > 64 * 1024 &&                                                                                    \
             hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,       \
                                 (int)lds_bytes) != hipSuccess)                                                          \
@@ -714,7 +841,7 @@ int amar_chain_indexed_f32(const float *A, int64_t lda, int32_t Da, const int32_
     // pair stage (ReLU of the sum of two gathered rows, square ReLU layers): the pipelined kernel; AMAR_CHAIN_PIPE=0 keeps the generic one
     static const bool no_pipe = getenv("AMAR_CHAIN_PIPE") && atoi(getenv("AMAR_CHAIN_PIPE")) == 0;
     const bool a_dot_ok = !a.has_dot || a.dot_kt == maxt;
-    const bool small_tables = lda < (1ll << 32) && ldb < (1ll << 32);
+    const bool small_tables = lda < (1ll << 30) && ldb < (1ll << 30) && P < (1ll << 30) - (4ll << 20);   // 32-bit row bytes and positions (+ 3 strides of <= 8 192 workgroups)
     if (!no_pipe && relu && a.sum_inputs && a.in_act == AMAR_ACT_RELU && full && a_dot_ok && a.ids_a && a.ids_b && a.Da == 16 * maxt &&
         a.Db == a.Da && maxt <= 4 && pt == 2 && lds_bytes <= 64 * 1024 && small_tables) {
         int64_t blocks = (P + 4 * 16 * 2 - 1) / (4 * 16 * 2);
@@ -722,6 +849,7 @@ int amar_chain_indexed_f32(const float *A, int64_t lda, int32_t Da, const int32_
         // 0.658 at 8 192; AMAR_CHAIN_BLOCKS overrides — keep it a multiple of 8: PairPlan's XCD affinity)
         static const int cap = getenv("AMAR_CHAIN_BLOCKS") ? atoi(getenv("AMAR_CHAIN_BLOCKS")) : 1536;
         if (blocks > cap) blocks = cap;
+        if (blocks > 8192) blocks = 8192;
         const dim3 grid((unsigned)blocks), block(256);
         if (a.out_index && !a.has_dot) return AMAR_EUNSUPPORTED;
         if (a.out_index) {
@@ -732,6 +860,35 @@ int amar_chain_indexed_f32(const float *A, int64_t lda, int32_t Da, const int32_
             else hipLaunchKernelGGL((chain_pipe_kernel<4, 2, false>), grid, block, lds_bytes, st, a);
         }
         return amar_check_launch();
+    }
+    // entity towers (one table, no dot, ReLU with an optionally linear last layer) in a shape with a compile-time kernel; AMAR_CHAIN_ROWS=0
+    // keeps the generic one
+    static const bool no_rows = getenv("AMAR_CHAIN_ROWS") && atoi(getenv("AMAR_CHAIN_ROWS")) == 0;
+    if (!no_rows && (am == 1 || am == 2) && !a.sum_inputs && a.Db == 0 && !a.has_dot && !a.out_index && pt == 2 && a.n_layers <= 3 &&
+        maxt <= 4 && lds_bytes <= 64 * 1024 && lda < (1ll << 30) && P < (1ll << 30) - (4ll << 20)) {
+        const int shape = chain_shape(a.n_layers, a.kt[0], a.nt[0], a.n_layers > 1 ? a.nt[1] : 0, a.n_layers > 2 ? a.nt[2] : 0);
+        // 1 024 workgroups = 4 per CU, every wave a few iterations deep in its prefetch (ml1m(s=64) towers: 0.059 ms against 0.063 at
+        // 4 096 and 0.068 for the generic kernel; AMAR_CHAIN_GRID overrides)
+        int64_t blocks = (P + 4 * 16 * 2 - 1) / (4 * 16 * 2);
+        const int64_t rows_cap = getenv("AMAR_CHAIN_GRID") ? gen_cap : 1024;
+        if (blocks > rows_cap) blocks = rows_cap;
+        if (blocks > 8192) blocks = 8192;
+        const dim3 grid((unsigned)blocks), block(256);
+        bool done = true;
+#define AMAR_ROWS_CASE(NLL, A0, A1, A2, A3)                                                                                      \
+        case chain_shape(NLL, A0, A1, A2, A3):                                                                                   \
+            if (am == 2) hipLaunchKernelGGL((chain_rows_kernel<chain_shape(NLL, A0, A1, A2, A3), 2, true>), grid, block, lds_bytes, st, a);   \
+            else hipLaunchKernelGGL((chain_rows_kernel<chain_shape(NLL, A0, A1, A2, A3), 2, false>), grid, block, lds_bytes, st, a);          \
+            break
+        switch (shape) {
+        AMAR_ROWS_CASE(3, 2, 2, 2, 3);      // 24 -> 24 -> 24 -> 48: basic-gnn grid1's towers with the classifier's first layer folded in
+        AMAR_ROWS_CASE(3, 3, 3, 3, 4);      // 48 -> 48 -> 48 -> 64: grid2
+        AMAR_ROWS_CASE(2, 2, 2, 2, 0);      // 24 -> 24 -> 24: the graph towers of the hybrid head
+        AMAR_ROWS_CASE(2, 3, 3, 3, 0);      // 48 -> 48 -> 48
+        default: done = false;
+        }
+#undef AMAR_ROWS_CASE
+        if (done) return amar_check_launch();
     }
     if (maxt == 3) { if (pt == 1) AMAR_CHAIN_LAUNCH(3, 1); else if (pt == 2) AMAR_CHAIN_LAUNCH(3, 2); else AMAR_CHAIN_LAUNCH(3, 4); }
     else if (maxt == 4) { if (pt == 1) AMAR_CHAIN_LAUNCH(4, 1); else if (pt == 2) AMAR_CHAIN_LAUNCH(4, 2); else AMAR_CHAIN_LAUNCH(4, 4); }

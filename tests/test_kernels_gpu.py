@@ -944,6 +944,46 @@ def test_chain_out_index(hip, D, units, last_act):
     assert torch.equal(out, ref)
 
 
+@pytest.mark.parametrize('Da,units,last_act', [(24, [24, 24, 48], None), (48, [48, 48, 64], None), (24, [24, 24], 'relu'), (48, [48, 48], 'relu'),
+                                               (20, [24, 24, 40], None), (36, [44, 48, 64], None)])
+@pytest.mark.parametrize('P', [1, 130, 300_001])
+def test_entity_towers_compile_time_shapes(hip, Da, units, last_act, P):
+    """The per-entity towers (one table, ReLU layers, an optionally linear last layer — the folded half of the classifier's first
+    layer, models/basic.py:_split_plan) run a kernel whose tile counts are compile-time constants and whose rows are requested one
+    iteration ahead (chain_rows_kernel).  Against the float64 oracle, with and without ids, and bit for bit against the generic
+    kernel (a call with an identity out_index takes the generic one).  300 001 rows: every wave loops, the last iteration is ragged;
+    widths 20 / 36 / 44 / 40: partly filled last tiles on the input and the output side."""
+    rng = np.random.default_rng(Da + len(units) + P)
+    n = max(P, 200)
+    A = rng.standard_normal((n, Da)).astype(np.float32)
+    dims = [Da] + units
+    ks = [rng.uniform(-0.4, 0.4, (dims[k], dims[k + 1])).astype(np.float32) for k in range(len(units))]
+    bs = [rng.uniform(-0.2, 0.2, dims[k + 1]).astype(np.float32) for k in range(len(units))]
+    acts = ['relu'] * (len(units) - 1) + [last_act]
+    blob, _ = hip.chain_pack(ks, bs)
+    Ad, bd = _t(A), _t(blob)
+    x = A[:P].astype(np.float64)
+    for k, b, a in zip(ks, bs, acts):
+        x = ol.dense(x, k.astype(np.float64), b.astype(np.float64), a)
+    out = torch.full((P, units[-1]), float('nan'), device=DEV)
+    hip.chain(Ad, bd, dims, acts, out)                                          # rows in order
+    assert rel_err(out.cpu().numpy(), x) < 5e-6
+    generic = torch.full((P, units[-1]), float('nan'), device=DEV)
+    hip.chain(Ad, bd, dims, acts, generic, out_index=torch.arange(P, device=DEV, dtype=torch.int32))
+    assert torch.equal(out, generic)
+    ids = rng.integers(0, n, P).astype(np.int32)                                # gathered rows
+    out_ids = torch.full((P, units[-1]), float('nan'), device=DEV)
+    hip.chain(Ad, bd, dims, acts, out_ids, ids_a=_t(ids))
+    gen_ids = torch.full((P, units[-1]), float('nan'), device=DEV)
+    hip.chain(Ad, bd, dims, acts, gen_ids, ids_a=_t(ids), out_index=torch.arange(P, device=DEV, dtype=torch.int32))
+    assert torch.equal(out_ids, gen_ids)
+    if P <= 130:
+        x = A[ids].astype(np.float64)
+        for k, b, a in zip(ks, bs, acts):
+            x = ol.dense(x, k.astype(np.float64), b.astype(np.float64), a)
+        assert rel_err(out_ids.cpu().numpy(), x) < 5e-6
+
+
 def test_pair_plan_scores_equal_direct(hip):
     """models.basic.PairPlan: the XCD-affine item-range order of a pair list + out_index gives the same bits, in the caller's
     order, as scoring the list directly; positions p with (p >> 7) % 8 == x only see items of the x-th item range."""

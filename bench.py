@@ -591,7 +591,10 @@ def main():
             pms = float(np.mean(pair_ms))
             flop_pair = 2 * (c1 * c2 + c2)
             out['pair_stage'] = {'kernel': 'chain_pipe_kernel<3,2> (relu(T_u[u] + T_i[i]) -> Dense 48 -> Dense 1, sigmoid)',
-                                 'avg_launch_ms': pms, 'pairs_per_launch': pairs_local, 'bound': 'hbm',
+                                 'avg_launch_ms': pms, 'pairs_per_launch': pairs_local, 'bound': 'mfma',
+                                 'bound_note': 'with the prepared pair list the gathered rows come from the L2s (traffic = what the memory side moved, '
+                                               'about half the gathered bytes) and the compute side binds: fp32 MFMA and VALU time add up on gfx950 '
+                                               '(the mfma object); the byte fractions below are kept for comparison with SURVEY 8(d) and may exceed 1',
                                  'algorithmic_bytes_per_launch': pair_alg, 'achieved': pair_alg / (pms * 1e-3) / 1e9,
                                  'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': pair_alg / (pms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                  'frac_label': '396 B/pair: the two 48-float per-entity rows (classifier layer 1 folded into the towers) + ids + score',

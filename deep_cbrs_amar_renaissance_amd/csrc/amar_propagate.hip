@@ -1104,43 +1104,60 @@ __global__ __launch_bounds__(256) void rowwise_xw_vec_kernel(const XwArgs a) {
     for (int i = threadIdx.x; i < F * F; i += 256) w_lds[i] = a.W[i];
     if (a.s_self) for (int i = threadIdx.x; i < F; i += 256) { w_lds[F * F + i] = a.a_self[i]; w_lds[F * F + F + i] = a.a_neigh[i]; }
     __syncthreads();
-    for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < a.n_rows; row += (int64_t)gridDim.x * 256) {
-        float x[F], h[F];
+    // R rows per thread, all of their loads requested before the first FMA (F = 8: one row per thread left 9 228 waves of 2 KB for
+    // 8 192 wave slots at ml1m(s=64), a second, nearly empty round — 20.5 -> 15.9 us; F = 16: two rows per thread are slower, 37 -> 46)
+    constexpr int R = F == 8 ? 2 : 1;
+    for (int64_t row0 = (int64_t)blockIdx.x * 256 * R + threadIdx.x; row0 < a.n_rows; row0 += (int64_t)gridDim.x * 256 * R) {
+        float x[R][F], sc[R];
 #pragma unroll
-        for (int q = 0; q < F / 4; ++q) {
-            const float4 v = *reinterpret_cast<const float4 *>(a.X + row * a.ldx + 4 * q);
-            x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
-            if (a.copy_to) *reinterpret_cast<float4 *>(a.copy_to + row * a.ld_copy + 4 * q) = v;
+        for (int j = 0; j < R; ++j) {
+            const int64_t row = row0 + 256 * j < a.n_rows ? row0 + 256 * j : row0;        // (past the end: the first row again, not stored)
+#pragma unroll
+            for (int q = 0; q < F / 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4 *>(a.X + row * a.ldx + 4 * q);
+                x[j][4 * q] = v.x; x[j][4 * q + 1] = v.y; x[j][4 * q + 2] = v.z; x[j][4 * q + 3] = v.w;
+            }
+            sc[j] = a.row_scale ? a.row_scale[row] : 1.f;
         }
 #pragma unroll
-        for (int c = 0; c < F; ++c) h[c] = 0.f;
+        for (int j = 0; j < R; ++j) {
+            const int64_t row = row0 + 256 * j;
+            if (row >= a.n_rows) break;
+            float h[F];
+            if (a.copy_to) {
 #pragma unroll
-        for (int k = 0; k < F; ++k)                               // same order of operations per output as the generic kernel: k ascending
-#pragma unroll
-            for (int c4 = 0; c4 < F; c4 += 4) {
-                // F = 8: the 64 weights by wave-uniform (scalar) loads straight into the FMAs' operands — 16 LDS broadcasts per
-                // row made this form slower than the generic one on a dense 590 k-row table (25 us against 22)
-                // (read through the constant address space: the kernel never writes W, and only then does the compiler keep the
-                // loads scalar across the loop's stores)
-                float4 w;
-                if (F == 8) {
-                    const __attribute__((address_space(4))) float *wc = (const __attribute__((address_space(4))) float *)a.W;
-                    w = make_float4(wc[k * F + c4], wc[k * F + c4 + 1], wc[k * F + c4 + 2], wc[k * F + c4 + 3]);
-                } else w = *reinterpret_cast<const float4 *>(&w_lds[k * F + c4]);
-                h[c4] = fmaf(x[k], w.x, h[c4]); h[c4 + 1] = fmaf(x[k], w.y, h[c4 + 1]);
-                h[c4 + 2] = fmaf(x[k], w.z, h[c4 + 2]); h[c4 + 3] = fmaf(x[k], w.w, h[c4 + 3]);
+                for (int q = 0; q < F / 4; ++q)
+                    *reinterpret_cast<float4 *>(a.copy_to + row * a.ld_copy + 4 * q) = make_float4(x[j][4 * q], x[j][4 * q + 1], x[j][4 * q + 2], x[j][4 * q + 3]);
             }
-        const float sc = a.row_scale ? a.row_scale[row] : 1.f;
 #pragma unroll
-        for (int q = 0; q < F / 4; ++q)
-            *reinterpret_cast<float4 *>(a.H + row * a.ldh + 4 * q) = a.row_scale
-                ? make_float4(h[4 * q] * sc, h[4 * q + 1] * sc, h[4 * q + 2] * sc, h[4 * q + 3] * sc)
-                : make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
-        if (a.s_self) {                                           // (the generic kernel adds these by an xor butterfly: last-bit differences)
-            float ps = 0.f, pn = 0.f;
+            for (int c = 0; c < F; ++c) h[c] = 0.f;
 #pragma unroll
-            for (int c = 0; c < F; ++c) { ps = fmaf(h[c], w_lds[F * F + c], ps); pn = fmaf(h[c], w_lds[F * F + F + c], pn); }
-            a.s_self[row] = ps; a.s_neigh[row] = pn;
+            for (int k = 0; k < F; ++k)                               // same order of operations per output as the generic kernel: k ascending
+#pragma unroll
+                for (int c4 = 0; c4 < F; c4 += 4) {
+                    // F = 8: the 64 weights by wave-uniform (scalar) loads straight into the FMAs' operands — 16 LDS broadcasts per
+                    // row made this form slower than the generic one on a dense 590 k-row table (25 us against 22)
+                    // (read through the constant address space: the kernel never writes W, and only then does the compiler keep the
+                    // loads scalar across the loop's stores)
+                    float4 w;
+                    if (F == 8) {
+                        const __attribute__((address_space(4))) float *wc = (const __attribute__((address_space(4))) float *)a.W;
+                        w = make_float4(wc[k * F + c4], wc[k * F + c4 + 1], wc[k * F + c4 + 2], wc[k * F + c4 + 3]);
+                    } else w = *reinterpret_cast<const float4 *>(&w_lds[k * F + c4]);
+                    h[c4] = fmaf(x[j][k], w.x, h[c4]); h[c4 + 1] = fmaf(x[j][k], w.y, h[c4 + 1]);
+                    h[c4 + 2] = fmaf(x[j][k], w.z, h[c4 + 2]); h[c4 + 3] = fmaf(x[j][k], w.w, h[c4 + 3]);
+                }
+#pragma unroll
+            for (int q = 0; q < F / 4; ++q)
+                *reinterpret_cast<float4 *>(a.H + row * a.ldh + 4 * q) = a.row_scale
+                    ? make_float4(h[4 * q] * sc[j], h[4 * q + 1] * sc[j], h[4 * q + 2] * sc[j], h[4 * q + 3] * sc[j])
+                    : make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
+            if (a.s_self) {                                           // (the generic kernel adds these by an xor butterfly: last-bit differences)
+                float ps = 0.f, pn = 0.f;
+#pragma unroll
+                for (int c = 0; c < F; ++c) { ps = fmaf(h[c], w_lds[F * F + c], ps); pn = fmaf(h[c], w_lds[F * F + F + c], pn); }
+                a.s_self[row] = ps; a.s_neigh[row] = pn;
+            }
         }
     }
 }
@@ -1573,7 +1590,8 @@ int amar_rowwise_xw_f32(const float *X, int64_t ldx, int32_t F, const float *W, 
     static const bool no_vec = getenv("AMAR_XW_VEC") && atoi(getenv("AMAR_XW_VEC")) == 0;            // development switch (A/B timing)
     if (!no_vec && F == C && (F == 8 || F == 16) && (ldx & 3) == 0 && (ldh & 3) == 0 && amar_aligned16(X) && amar_aligned16(H) &&
         (!copy_to || ((ld_copy & 3) == 0 && amar_aligned16(copy_to)))) {
-        int64_t vblocks = ((int64_t)n_rows + 255) / 256;
+        const int rows_per_block = F == 8 ? 512 : 256;              // (two rows per thread at F = 8)
+        int64_t vblocks = ((int64_t)n_rows + rows_per_block - 1) / rows_per_block;
         if (vblocks > 8192) vblocks = 8192;
         if (F == 8) hipLaunchKernelGGL(rowwise_xw_vec_kernel<8>, dim3((unsigned)vblocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
         else hipLaunchKernelGGL(rowwise_xw_vec_kernel<16>, dim3((unsigned)vblocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);

@@ -51,6 +51,9 @@ SIGNATURES = {
     'amar_dual_chain_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _I32, _P, _P, _I64, _I64, _P]),
     'amar_copy_columns_f32': (ctypes.c_int, [_P, _I64, _P, _I32, _P, _I64, _I64, _I32, _P]),
     'amar_reduce_layers_f32': (ctypes.c_int, [_P, _I64, _I32, _I32, _P, _I64, _I64, _I32, _P]),
+    'amar_reduce_layers_wsum_f32': (ctypes.c_int, [_P, _I64, _I32, _I32, _P, _P, _I64, _I64, _P]),
+    'amar_reduce_layers_wsum_bwd_scratch': (ctypes.c_int64, []),
+    'amar_reduce_layers_wsum_bwd_f32': (ctypes.c_int, [_P, _I64, _I32, _I32, _P, _P, _I64, _P, _I64, _P, _P, _I64, _P]),
     'amar_act_bwd_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I32, _I32, _P]),
     'amar_wgrad_scratch_floats': (ctypes.c_int64, [_I64, _I32, _I32]),
     'amar_wgrad_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I32, _I32, _P, _P, _P, _P]),
@@ -571,6 +574,29 @@ def reduce_layers(cat, n_layers, width, out, mean=False):
                                          _ptr(out, torch.float32, 'out'), _ld(out, 'out'), cat.shape[0],
                                          1 if mean else 0, _stream())
     _check(code, 'amar_reduce_layers_f32')
+
+
+def reduce_layers_wsum(cat, n_layers, width, w, out):
+    """out = sum_l (w_l * w_l) * cat[:, block l]  (ReductionLayer('w-sum'), reduction.py:36-55); w: device vector of n_layers floats."""
+    if cat.shape[1] != n_layers * width or tuple(out.shape) != (cat.shape[0], width) or w.numel() != n_layers or not w.is_contiguous():
+        raise ValueError("reduce_layers_wsum: cat [n, n_layers*width], w [n_layers], out [n, width] expected")
+    code = load().amar_reduce_layers_wsum_f32(_ptr(cat, torch.float32, 'cat'), _ld(cat, 'cat'), n_layers, width, _ptr(w, torch.float32, 'w'),
+                                              _ptr(out, torch.float32, 'out'), _ld(out, 'out'), cat.shape[0], _stream())
+    _check(code, 'amar_reduce_layers_wsum_f32')
+
+
+def reduce_layers_wsum_bwd(cat, n_layers, width, w, d_out, d_cat, dw):
+    """Reverse of reduce_layers_wsum: d_cat[:, block l] = w_l^2 d_out, dw[l] = 2 w_l sum(d_out . cat[:, block l]) (deterministic)."""
+    n = cat.shape[0]
+    if (cat.shape[1] != n_layers * width or tuple(d_cat.shape) != tuple(cat.shape) or tuple(d_out.shape) != (n, width)
+            or w.numel() != n_layers or dw.numel() != n_layers or not w.is_contiguous() or not dw.is_contiguous()):
+        raise ValueError("reduce_layers_wsum_bwd: cat / d_cat [n, n_layers*width], d_out [n, width], w / dw [n_layers] expected")
+    scratch = torch.empty(int(load().amar_reduce_layers_wsum_bwd_scratch()), dtype=torch.float32, device=cat.device)
+    code = load().amar_reduce_layers_wsum_bwd_f32(_ptr(cat, torch.float32, 'cat'), _ld(cat, 'cat'), n_layers, width, _ptr(w, torch.float32, 'w'),
+                                                  _ptr(d_out, torch.float32, 'd_out'), _ld(d_out, 'd_out'),
+                                                  _ptr(d_cat, torch.float32, 'd_cat'), _ld(d_cat, 'd_cat'), _ptr(dw, torch.float32, 'dw'),
+                                                  _ptr(scratch, torch.float32, 'scratch'), n, _stream())
+    _check(code, 'amar_reduce_layers_wsum_bwd_f32')
 
 
 def adam_advance(state, learning_rate, beta_1, beta_2):

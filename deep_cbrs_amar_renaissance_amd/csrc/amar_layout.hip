@@ -47,6 +47,66 @@ __global__ __launch_bounds__(256) void reduce_layers_kernel(const float *__restr
     }
 }
 
+// 'w-sum' (WeightedSum, reduction.py:36-55): out = reduce_sum(multiply(w * w, [X_0 .. X_L]), axis 0) with a learnable w [L+1] on the
+// device.  Products are rounded before they are added, like the two TF ops (no fused multiply-add), and added in layer order.
+constexpr int WSUM_MAX_LAYERS = 8, WSUM_BWD_BLOCKS = 512;
+__global__ __launch_bounds__(256) void reduce_layers_wsum_kernel(const float *__restrict__ cat, int64_t ld, int n_layers, int width,
+                                                                 const float *__restrict__ w, float *__restrict__ out, int64_t ldo,
+                                                                 int64_t n_rows) {
+    float ww[WSUM_MAX_LAYERS];
+    for (int l = 0; l < n_layers; ++l) ww[l] = __fmul_rn(w[l], w[l]);
+    const int64_t total = n_rows * width;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / width;
+        const int c = (int)(i - r * width);
+        float s = __fmul_rn(ww[0], cat[r * ld + c]);
+        for (int l = 1; l < n_layers; ++l) s = __fadd_rn(s, __fmul_rn(ww[l], cat[r * ld + (int64_t)l * width + c]));
+        out[r * ldo + c] = s;
+    }
+}
+
+// Reverse of it: d_cat[:, slice l] = w_l^2 d_out and, per workgroup, the partial sums of d_out . X_l (fixed grid, fixed order: the
+// result does not depend on scheduling); wsum_dw_kernel adds the partials in workgroup order: dw_l = 2 w_l sum(d_out . X_l).
+__global__ __launch_bounds__(256) void reduce_layers_wsum_bwd_kernel(const float *__restrict__ cat, int64_t ld, int n_layers, int width,
+                                                                     const float *__restrict__ w, const float *__restrict__ d_out, int64_t ldd,
+                                                                     float *__restrict__ d_cat, int64_t ldc, int64_t n_rows,
+                                                                     float *__restrict__ partials) {
+    __shared__ float red[4][WSUM_MAX_LAYERS];
+    float ww[WSUM_MAX_LAYERS], acc[WSUM_MAX_LAYERS];
+    for (int l = 0; l < WSUM_MAX_LAYERS; ++l) { ww[l] = l < n_layers ? w[l] * w[l] : 0.f; acc[l] = 0.f; }
+    const int64_t total = n_rows * width;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / width;
+        const int c = (int)(i - r * width);
+        const float g = d_out[r * ldd + c];
+#pragma unroll
+        for (int l = 0; l < WSUM_MAX_LAYERS; ++l)
+            if (l < n_layers) {
+                acc[l] = fmaf(g, cat[r * ld + (int64_t)l * width + c], acc[l]);
+                d_cat[r * ldc + (int64_t)l * width + c] = ww[l] * g;
+            }
+    }
+#pragma unroll
+    for (int l = 0; l < WSUM_MAX_LAYERS; ++l) {
+        float v = acc[l];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][l] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < WSUM_MAX_LAYERS)
+        partials[(int64_t)blockIdx.x * WSUM_MAX_LAYERS + threadIdx.x] =
+            ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+}
+
+__global__ __launch_bounds__(64) void reduce_layers_wsum_dw_kernel(const float *__restrict__ partials, int n_blocks, int n_layers,
+                                                                   const float *__restrict__ w, float *__restrict__ dw) {
+    const int l = blockIdx.x;                               // one wavefront per layer weight
+    float v = 0.f;
+    for (int b = threadIdx.x; b < n_blocks; b += 64) v += partials[(int64_t)b * WSUM_MAX_LAYERS + l];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (threadIdx.x == 0 && l < n_layers) dw[l] = 2.f * w[l] * v;
+}
+
 unsigned grid_for(int64_t total) {
     int64_t b = (total + 255) / 256;
     return (unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
@@ -77,6 +137,36 @@ int amar_reduce_layers_f32(const float *cat, int64_t ld, int32_t n_layers, int32
     hipLaunchKernelGGL(reduce_layers_kernel, dim3(grid_for(n_rows * width)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), cat, ld, n_layers, width, out, ldo, n_rows,
                        mean ? (float)n_layers : 0.f);
+    return amar_check_launch();
+}
+
+int amar_reduce_layers_wsum_f32(const float *cat, int64_t ld, int32_t n_layers, int32_t width, const float *w, float *out, int64_t ldo,
+                                int64_t n_rows, amar_stream_t stream) {
+    if (n_rows < 0 || n_layers < 1 || width < 1 || !cat || !w || !out || ld < (int64_t)n_layers * width || ldo < width)
+        return AMAR_EINVAL;
+    if (n_layers > WSUM_MAX_LAYERS) return AMAR_EUNSUPPORTED;
+    if (n_rows == 0) return AMAR_OK;
+    hipLaunchKernelGGL(reduce_layers_wsum_kernel, dim3(grid_for(n_rows * width)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), cat, ld, n_layers, width, w, out, ldo, n_rows);
+    return amar_check_launch();
+}
+
+int64_t amar_reduce_layers_wsum_bwd_scratch(void) { return (int64_t)WSUM_BWD_BLOCKS * WSUM_MAX_LAYERS; }
+
+int amar_reduce_layers_wsum_bwd_f32(const float *cat, int64_t ld, int32_t n_layers, int32_t width, const float *w,
+                                    const float *d_out, int64_t ldd, float *d_cat, int64_t ld_dcat, float *dw, float *scratch,
+                                    int64_t n_rows, amar_stream_t stream) {
+    if (n_rows < 0 || n_layers < 1 || width < 1 || !cat || !w || !d_out || !d_cat || !dw || !scratch ||
+        ld < (int64_t)n_layers * width || ld_dcat < (int64_t)n_layers * width || ldd < width)
+        return AMAR_EINVAL;
+    if (n_layers > WSUM_MAX_LAYERS) return AMAR_EUNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int64_t blocks = (n_rows * width + 255) / 256;
+    if (blocks > WSUM_BWD_BLOCKS) blocks = WSUM_BWD_BLOCKS;
+    if (blocks < 1) blocks = 1;                              // (no rows: every partial is 0, dw = 0)
+    hipLaunchKernelGGL(reduce_layers_wsum_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, cat, ld, n_layers, width, w, d_out, ldd,
+                       d_cat, ld_dcat, n_rows, scratch);
+    hipLaunchKernelGGL(reduce_layers_wsum_dw_kernel, dim3((unsigned)n_layers), dim3(64), 0, st, scratch, (int)blocks, n_layers, w, dw);
     return amar_check_launch();
 }
 

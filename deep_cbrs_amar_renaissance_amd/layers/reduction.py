@@ -1,10 +1,9 @@
-"""ReductionLayer — mirrors `/root/reference/src/layers/reduction.py:5-33`.
+"""ReductionLayer — mirrors `/root/reference/src/layers/reduction.py:5-55`.
 
-Reduces the per-layer node representations [X_0 .. X_L]:
-'concatenation' (default, `config.yaml:12`), 'sum', 'mean', 'last'.  Inside SequentialGNN the
-concatenation is a layout decision (every layer writes its own column slice of one buffer), so
-this layer only does work when it is called stand-alone on separate tensors.  'w-sum'
-(WeightedSum) is out of scope.
+Reduces the per-layer node representations [X_0 .. X_L]: 'concatenation' (default, `config.yaml:12`), 'sum', 'mean', 'last' and
+'w-sum' (`WeightedSum`, reduction.py:36-55: sum_l w_l^2 X_l with learnable weights initialised to ones).  Inside SequentialGNN the
+concatenation is a layout decision (every layer writes its own column slice of one buffer), so this layer only does work when it is
+called stand-alone on separate tensors; the stack asks it for the 'w-sum' weights (`build_weights`) and reduces the slices itself.
 """
 import torch
 
@@ -15,11 +14,17 @@ from deep_cbrs_amar_renaissance_amd.engine import Layer
 class ReductionLayer(Layer):
     def __init__(self, method='concatenate', regularizer=None):
         super().__init__()
-        if method == 'w-sum':
-            raise NotImplementedError("'w-sum' (WeightedSum) is out of scope for the HIP path")
-        if method not in ('concatenation', 'sum', 'mean', 'last'):
+        if method not in ('concatenation', 'sum', 'mean', 'last', 'w-sum'):
             raise ValueError('Reduction method not supported: ' + method)
         self.method = method
+        self.regularizer = regularizer
+        self.w = None
+
+    def build_weights(self, n_layers):
+        """WeightedSum.build (reduction.py:45-52): 'reduction-weights' [n_layers, 1, 1], ones."""
+        if self.method == 'w-sum' and self.w is None:
+            self.add_weight('w', (n_layers, 1, 1), 'ones', self.regularizer)
+        return self.w
 
     def call(self, inputs, **kwargs):
         if self.method == 'last':
@@ -33,8 +38,15 @@ class ReductionLayer(Layer):
             off += w
         if self.method == 'concatenation':
             return cat
+        return self.reduce_slices(cat, widths)
+
+    def reduce_slices(self, cat, widths):
+        """'sum' / 'mean' / 'w-sum' over the equal-width column blocks of `cat`."""
         if len(set(widths)) != 1:
             raise ValueError("'{}' needs layers of equal width".format(self.method))
-        out = torch.empty((n, widths[0]), dtype=torch.float32, device=cat.device)
-        capi.reduce_layers(cat, len(inputs), widths[0], out, mean=self.method == 'mean')
+        out = torch.empty((cat.shape[0], widths[0]), dtype=torch.float32, device=cat.device)
+        if self.method == 'w-sum':
+            capi.reduce_layers_wsum(cat, len(widths), widths[0], self.build_weights(len(widths)).view(-1), out)
+        else:
+            capi.reduce_layers(cat, len(widths), widths[0], out, mean=self.method == 'mean')
         return out

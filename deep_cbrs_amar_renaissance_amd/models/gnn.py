@@ -45,7 +45,7 @@ class SequentialGNN(Model):
         :param adj_matrix: the (sparse) graph adjacency matrix, already pre-processed for the layer type.
         :param seq_layers: list of GNN layers.
         :param embedding_dim: width of the trainable node table.
-        :param final_node: 'concatenation', 'sum', 'mean' or 'last'.
+        :param final_node: 'concatenation', 'sum', 'mean', 'w-sum' or 'last'.
         :param dropout: must be None (no `dropout` key exists in config.yaml; training-only anyway).
         :param regularizer: regulariser object carried by the node table.
         :param cache_neighbours: must be False (the reference raises NotImplementedError too, gnn.py:52-53).
@@ -68,6 +68,7 @@ class SequentialGNN(Model):
         self.final_node = final_node
         self.reduce = ReductionLayer(final_node)
         self.seq_layers = torch.nn.ModuleList(seq_layers)
+        self.reduce.build_weights(len(seq_layers) + 1)          # 'w-sum': one weight per term X_0 .. X_L (reduction.py:45-52)
         self.built = True
 
     @property
@@ -183,11 +184,7 @@ class SequentialGNN(Model):
             return cat
         if self.final_node == 'last':
             return slices[-1]
-        if len(set(widths)) != 1:
-            raise ValueError("'{}' needs layers of equal width".format(self.final_node))
-        out = torch.empty((cat.shape[0], widths[0]), dtype=torch.float32, device=cat.device)
-        capi.reduce_layers(cat, len(widths), widths[0], out, mean=self.final_node == 'mean')
-        return out
+        return self.reduce.reduce_slices(cat, widths)        # 'sum' / 'mean' / 'w-sum'
 
 
 class HalfInputSequentialGNN(SequentialGNN):
@@ -267,7 +264,7 @@ class GNN(Model, _Hoisted, abc.ABC):
         :param adj_matrix: the (sparse) graph adjacency matrix.
         :param n_hops: number of convolution layers.
         :param embedding_dim: width of the trainable node table.
-        :param final_node: 'concatenation', 'sum', 'mean' or 'last'.
+        :param final_node: 'concatenation', 'sum', 'mean', 'w-sum' or 'last'.
         :param dropout: see SequentialGNN.
         :param l2_regularizer: L2 factor carried by the node table and the layers' weights (may be None).
         :param cache_neighbours: see SequentialGNN.

@@ -12,7 +12,7 @@ gradients, row scatter-add for the embedding lookup, Adam) and reuses the forwar
 A_hat^T . dZ (A_hat is symmetric) and the forward GEMM for dX = dZ . W^T.
 
 Implemented for GCN, GraphSAGE, GAT, LightGCN and DGCF stacks under every reduction ('concatenation', 'mean', 'sum',
-'last'), alone (models/gnn.py) or chained as TwoStep / TwoWay models (models/tsgnn.py, twgnn.py): `_StackTape` is the
+'w-sum', 'last'), alone (models/gnn.py) or chained as TwoStep / TwoWay models (models/tsgnn.py, twgnn.py): `_StackTape` is the
 forward-with-kept-activations + reverse pass of ONE stack, and the Trainer chains the tapes the way the model chains the
 stacks (the gradient of a stack's leading rows is lifted back to its full node table).  GraphSAGE trains on an unfused
 forward that keeps what the reverse pass needs ([x || mean] and the normalised pre-activation); its aggregate
@@ -235,7 +235,7 @@ class _StackTape:
         self.kind = next((name for cls, name in self.KINDS if layers and all(isinstance(l, cls) for l in layers)), None)
         if self.kind is None:
             raise NotImplementedError("training needs a stack of one layer type (GCN, GraphSAGE, GAT, LightGCN or DGCF)")
-        if seq.final_node not in ('concatenation', 'mean', 'sum', 'last'):
+        if seq.final_node not in ('concatenation', 'mean', 'sum', 'last', 'w-sum'):
             raise NotImplementedError("no reverse pass for the '{}' reduction".format(seq.final_node))
         if self.kind == 'sage':
             a = seq.adj_matrix
@@ -299,12 +299,19 @@ class _StackTape:
         return seq._reduce(cat, [sl(k) for k in range(len(widths))], widths)
 
     # -- reverse ----------------------------------------------------------------------------------------------------
-    def _expand(self, d_out):
-        """d(loss)/d(cat) from d(loss)/d(reduced output)."""
+    def _expand(self, d_out, grads):
+        """d(loss)/d(cat) from d(loss)/d(reduced output) ('w-sum': also the gradient of the reduction weights, into `grads`)."""
         final, widths = self.seq.final_node, self.widths
         n_terms = len(widths)
         if final == 'concatenation':
             return d_out
+        if final == 'w-sum':
+            w = self.seq.reduce.w
+            d_cat = torch.empty((d_out.shape[0], self.offs[-1]), dtype=torch.float32, device=d_out.device)
+            dw = torch.empty(n_terms, dtype=torch.float32, device=d_out.device)
+            capi.reduce_layers_wsum_bwd(self.cat, n_terms, widths[0], w.view(-1), d_out, d_cat, dw)
+            grads[w] = dw.view_as(w)
+            return d_cat
         d_cat = torch.zeros((d_out.shape[0], self.offs[-1]), dtype=torch.float32, device=d_out.device)
         sl = self._slices(d_cat)
         if final == 'last':
@@ -332,7 +339,7 @@ class _StackTape:
                 capi.add_inplace(g0, nxt)
                 acc = nxt
             return g0
-        e, de = self.cat, self._expand(d_out)
+        e, de = self.cat, self._expand(d_out, grads)
         sl, dsl = self._slices(e), self._slices(de)
         for k in range(len(layers) - 1, -1, -1):
             layer = layers[k]

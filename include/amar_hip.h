@@ -273,6 +273,19 @@ int amar_copy_columns_f32(const float *src, int64_t lds, const int32_t *ids, int
 int amar_reduce_layers_f32(const float *cat, int64_t ld, int32_t n_layers, int32_t width, float *out, int64_t ldo,
                            int64_t n_rows, int32_t mean, amar_stream_t stream);
 
+/* ReductionLayer('w-sum') = WeightedSum (src/layers/reduction.py:36-55): out = sum over the n_layers column blocks of
+ * (w[l] * w[l]) * X_l with a learnable device vector w [n_layers] (initialised to ones); products rounded, then added in layer order.
+ * n_layers <= 8.  The reverse pass writes d_cat[:, block l] = w[l]^2 d_out and dw[l] = 2 w[l] sum(d_out . X_l), the sums formed per
+ * workgroup of a fixed grid and added in workgroup order (no float atomics); `scratch` holds amar_reduce_layers_wsum_bwd_scratch()
+ * floats.
+ */
+int amar_reduce_layers_wsum_f32(const float *cat, int64_t ld, int32_t n_layers, int32_t width, const float *w, float *out, int64_t ldo,
+                                int64_t n_rows, amar_stream_t stream);
+int64_t amar_reduce_layers_wsum_bwd_scratch(void);
+int amar_reduce_layers_wsum_bwd_f32(const float *cat, int64_t ld, int32_t n_layers, int32_t width, const float *w,
+                                    const float *d_out, int64_t ldd, float *d_cat, int64_t ld_dcat, float *dw, float *scratch,
+                                    int64_t n_rows, amar_stream_t stream);
+
 /* The same GAT layer on the XCD-sliced image of the (square) edge-list adjacency, for graphs whose node table exceeds the
  * per-XCD L2s: rowptr / colidx as in amar_spmm_xs_f32 (values unused).  `packed` is scratch [n, 2C] floats that the call
  * fills with [ H | s_neigh | 0 .. ] rows (one L2 request then serves the neighbour's features and its scalar), `partials`

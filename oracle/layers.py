@@ -110,8 +110,15 @@ def gat_conv(x, row, col, kernel, attn_self, attn_neigh, bias, activation='relu'
     return _act(out.astype(x.dtype), activation), alpha
 
 
-def reduce_layers(hs, method='concatenation'):
-    """reduction.py:15-33 (w-sum is out of scope)."""
+def reduce_layers(hs, method='concatenation', w=None):
+    """reduction.py:15-33; 'w-sum' = WeightedSum.call (reduction.py:54-55): reduce_sum(multiply(w * w, inputs), axis=0) with the
+    learnable `w` [n_layers] (ones when None: its initial value, reduction.py:50)."""
+    if method == 'w-sum':
+        w = np.ones(len(hs), dtype=hs[0].dtype) if w is None else np.asarray(w, dtype=hs[0].dtype).reshape(-1)
+        out = (w[0] * w[0]) * hs[0]
+        for k, h in enumerate(hs[1:], start=1):
+            out = out + (w[k] * w[k]) * h
+        return out
     if method == 'concatenation':
         return np.concatenate(hs, axis=1)
     if method == 'sum':

@@ -6,7 +6,7 @@ Weights travel as plain dicts of numpy arrays:
 
     gnn     {'kind': 'gcn'|'lightgcn'|'sage'|'gat'|'dgcf', 'embeddings': [N,d],
              'layers': [ {'kernel','bias'} | {} | {'kernel','bias'} | {'kernel','attn_self','attn_neigh','bias'} | {'w'} ],
-             'final_node': 'concatenation'|'mean'|'sum'|'last'}
+             'final_node': 'concatenation'|'mean'|'sum'|'last'|'w-sum' (+ 'reduction_w' [n_layers] for 'w-sum')}
     basic   {'unet': [(W,b)..], 'inet': [(W,b)..], 'clf': [(W,b).., (W_out,b_out)]}
     hybrid  {'dense1a','dense1b','dense2a','dense2b','dense3a','dense3b': [(W,b)..], 'clf': [...]}
 """
@@ -61,7 +61,7 @@ def propagate_from(adj, x0, gnn, dtype=np.float32, self_loops=True, force_mean=T
     final_node = gnn.get('final_node', 'concatenation')
     if force_mean and kind in ('lightgcn', 'dgcf'):
         final_node = 'mean'
-    return olayers.reduce_layers(hs, final_node)
+    return olayers.reduce_layers(hs, final_node, gnn.get('reduction_w'))
 
 
 def two_step(adjs, ts, n_users, n_items, dtype=np.float32):

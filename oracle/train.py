@@ -206,6 +206,9 @@ def _torch_stack(adj, x, st, self_loops=True, force_mean=True):
         return torch.cat(hs, 1)
     if final_node == 'last':
         return hs[-1]
+    if final_node == 'w-sum':                                        # reduction.py:54-55
+        w = st['reduction_w'].reshape(-1)
+        return sum((w[k] * w[k]) * h for k, h in enumerate(hs))
     return sum(hs) / (len(hs) if final_node == 'mean' else 1)
 
 
@@ -234,6 +237,8 @@ def torch_model_grads(adj, gnn, head, u_ids, i_ids, y, l2=0.0, self_loops=True, 
              'layers': [{k: T(v) for k, v in lw.items()} for lw in w['layers']], 'table_l2': table_l2}
         if 'embeddings' in w:
             t['embeddings'] = T(w['embeddings'])
+        if t['final_node'] == 'w-sum':                               # gnn.py:62 builds ReductionLayer(final_node) without a regulariser
+            t['reduction_w'] = T(w['reduction_w'] if w.get('reduction_w') is not None else np.ones(len(w['layers']) + 1))
         stacks[name] = t
         return t
     if 'step_one' in gnn:
@@ -299,6 +304,8 @@ def torch_model_grads(adj, gnn, head, u_ids, i_ids, y, l2=0.0, self_loops=True, 
         out = {'layers': [{k: g(v) for k, v in lw.items()} for lw in st['layers']]}
         if 'embeddings' in st:
             out['embeddings'] = g(st['embeddings'])
+        if 'reduction_w' in st:
+            out['reduction_w'] = g(st['reduction_w'])
         return out
     grads = {'gnn': export(stacks['gnn']) if 'gnn' in stacks else {name: export(st) for name, st in stacks.items()},
              'head': {name: [(g(w), g(b)) for w, b in nets[name]] for name in nets}}

@@ -91,6 +91,8 @@ def seq_to_oracle(seq):
         else:
             layers.append({'kernel': _np(l.kernel), 'bias': _np(l.bias)})
     out = {'kind': kind, 'layers': layers, 'final_node': seq.final_node}
+    if seq.final_node == 'w-sum':
+        out['reduction_w'] = _np(seq.reduce.w).reshape(-1)
     if getattr(seq, 'embeddings', None) is not None:
         out['embeddings'] = _np(seq.embeddings)
     return out

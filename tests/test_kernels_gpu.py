@@ -984,6 +984,33 @@ def test_entity_towers_compile_time_shapes(hip, Da, units, last_act, P):
         assert rel_err(out_ids.cpu().numpy(), x) < 5e-6
 
 
+@pytest.mark.parametrize('n,L,width', [(1, 1, 4), (77, 3, 8), (5000, 4, 16), (1234, 8, 12)])
+def test_weighted_sum_reduction_kernels(hip, n, L, width):
+    """amar_reduce_layers_wsum_f32 / _bwd_f32 (WeightedSum, reduction.py:36-55): out = sum_l w_l^2 X_l over the column blocks of a
+    strided buffer; reverse: d_cat = w_l^2 d_out per block, dw_l = 2 w_l sum(d_out . X_l), reproducible bit for bit."""
+    rng = np.random.default_rng(n + L)
+    buf = rng.standard_normal((n, L * width + 4)).astype(np.float32)
+    w = rng.uniform(-1.5, 1.5, L).astype(np.float32)
+    cat = _t(buf)[:, :L * width]
+    out = torch.full((n, width), float('nan'), device=DEV)
+    hip.reduce_layers_wsum(cat, L, width, _t(w), out)
+    blocks = [buf[:, l * width:(l + 1) * width].astype(np.float64) for l in range(L)]
+    want = ol.reduce_layers(blocks, 'w-sum', w.astype(np.float64))
+    assert rel_err(out.cpu().numpy(), want) < 1e-6
+    d_out = rng.standard_normal((n, width)).astype(np.float32)
+    d_cat, dw = torch.full((n, L * width), float('nan'), device=DEV), torch.full((L,), float('nan'), device=DEV)
+    hip.reduce_layers_wsum_bwd(cat, L, width, _t(w), _t(d_out), d_cat, dw)
+    for l in range(L):
+        assert rel_err(d_cat[:, l * width:(l + 1) * width].cpu().numpy(), (w[l].astype(np.float64) ** 2) * d_out) < 1e-6
+    want_dw = np.array([2 * w[l] * float((d_out.astype(np.float64) * blocks[l]).sum()) for l in range(L)])
+    assert np.abs(dw.cpu().numpy() - want_dw).max() <= 1e-5 * max(1.0, np.abs(want_dw).max())
+    dw2 = torch.empty_like(dw)
+    hip.reduce_layers_wsum_bwd(cat, L, width, _t(w), _t(d_out), torch.empty_like(d_cat), dw2)
+    assert torch.equal(dw, dw2)
+    with pytest.raises(Exception):
+        hip.reduce_layers_wsum(torch.zeros((4, 9 * 4), device=DEV), 9, 4, torch.ones(9, device=DEV), torch.empty((4, 4), device=DEV))   # > 8 terms
+
+
 def test_pair_plan_scores_equal_direct(hip):
     """models.basic.PairPlan: the XCD-affine item-range order of a pair list + out_index gives the same bits, in the caller's
     order, as scoring the list directly; positions p with (p >> 7) % 8 == x only see items of the x-th item range."""

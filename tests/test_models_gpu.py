@@ -102,7 +102,7 @@ def test_basic_gnn_wider_grids(hip, ml1m_s1, name, cfg):
                      check_topk=False)
 
 
-@pytest.mark.parametrize('final_node', ['sum', 'mean', 'last'])
+@pytest.mark.parametrize('final_node', ['sum', 'mean', 'last', 'w-sum'])
 def test_other_reductions(hip, final_node):
     from deep_cbrs_amar_renaissance_amd.models import basic
     g = helpers.tiny_graph(n_users=50, n_items=40, n_ratings=600, seed=1)

@@ -292,3 +292,27 @@ def test_graph_construction_reproduces_the_reference_functions_own_output(sym):
         up = og.user_properties(bi, kg, nu, ni)
         assert tuple(up.shape) == tuple(z['user_props_shape']) and str(up.dtype) == str(z['user_props_dtype'])
         assert np.array_equal(up.row, z['user_props_row']) and np.array_equal(up.col, z['user_props_col']) and np.array_equal(up.data, z['user_props_val'])
+
+
+def test_weighted_sum_reduction_by_hand():
+    """ReductionLayer('w-sum') = WeightedSum.call (reduction.py:54-55): reduce_sum(multiply(w * w, inputs), axis=0); weights start
+    at ones (reduction.py:50), where it equals 'sum'; the torch restatement used as the training oracle agrees and gives
+    d out / d w_l = 2 w_l X_l."""
+    import torch
+    from oracle import layers as ol
+    from oracle import train as otrain
+    hs = [np.array([[1.0, 2.0]]), np.array([[3.0, 4.0]])]
+    assert np.array_equal(ol.reduce_layers(hs, 'w-sum', [2.0, -1.0]), np.array([[7.0, 12.0]]))     # 4 * [1, 2] + 1 * [3, 4]
+    assert np.array_equal(ol.reduce_layers(hs, 'w-sum'), ol.reduce_layers(hs, 'sum'))
+    adj = sparse.csr_matrix(np.array([[0.0, 1.0, 0.0], [1.0, 0.0, 1.0], [0.0, 1.0, 0.0]]))
+    x0 = np.arange(6, dtype=np.float64).reshape(3, 2) / 10
+    gnn = {'kind': 'lightgcn', 'embeddings': x0, 'layers': [{}, {}], 'final_node': 'w-sum', 'reduction_w': np.array([0.5, 2.0, -1.0])}
+    want = om.propagate_from(adj, x0, gnn, np.float64, force_mean=False)
+    w = torch.tensor(gnn['reduction_w'], requires_grad=True)
+    st = {'kind': 'lightgcn', 'layers': [{}, {}], 'final_node': 'w-sum', 'reduction_w': w}
+    got = otrain._torch_stack(adj, torch.tensor(x0), st, force_mean=False)
+    assert np.allclose(got.detach().numpy(), want, atol=1e-12)
+    got.sum().backward()
+    a_hat = og.gcn_filter(adj).toarray()
+    terms = [x0, a_hat @ x0, a_hat @ a_hat @ x0]
+    assert np.allclose(w.grad.numpy(), [2 * wk * t.sum() for wk, t in zip(gnn['reduction_w'], terms)], atol=1e-12)

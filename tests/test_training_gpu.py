@@ -153,6 +153,8 @@ def _flatten_oracle_grads(model, grads):
     for layer, gl in zip(seq.seq_layers, grads['gnn']['layers']):
         for name, arr in gl.items():
             out[getattr(layer, {'attn_self': 'attn_kernel_self', 'attn_neigh': 'attn_kernel_neighs'}.get(name, name))] = arr
+    if 'reduction_w' in grads['gnn']:                                # ReductionLayer('w-sum')
+        out[seq.reduce.w] = grads['gnn']['reduction_w']
     for name in grads['head']:
         if name.startswith('fuse'):                                  # attention fusion weights
             for key, arr in grads['head'][name].items():
@@ -223,6 +225,44 @@ def test_gradients_match_autograd_oracle(hip, cls, graph):
         got += 2 * trainer._l2(prm) * prm.detach().cpu().numpy().reshape(gw.shape)
         # (absolute floor: d/d(attn_kernel_self) vanishes where a row's softmax is shift-invariant in s_i)
         assert np.abs(got - gw).max() <= 2e-4 * np.abs(gw).max() + 1e-10, tuple(prm.shape)
+
+
+@pytest.mark.parametrize('cls', ['BasicGCN', 'BasicGraphSage', 'BasicGAT'])
+def test_weighted_sum_reduction_gradients_match_autograd_oracle(hip, cls):
+    """final_node='w-sum' (WeightedSum, reduction.py:36-55): out = sum_l w_l^2 X_l with learnable w.  Forward against the numpy
+    oracle, loss and every gradient — the reduction weights' included — against torch autograd of the restated forward (float64),
+    with the weights moved away from their all-ones start."""
+    from deep_cbrs_amar_renaissance_amd import engine, training
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    from oracle import models as om
+    engine.set_seed(7)
+    g = helpers.tiny_graph(n_users=80, n_items=60, n_ratings=1500, seed=9, n_props=30, n_links=90)
+    model = getattr(basic, cls)(g['adj'], **dict(CFG, final_node='w-sum'))
+    helpers.randomize_biases(model, seed=6)
+    red = model.gnn.gnn_layers.reduce
+    assert tuple(red.w.shape) == (3, 1, 1) and float(red.w.detach().min()) == 1.0 and red.w.regularizer is None       # reduction.py:45-52, gnn.py:62
+    with torch.no_grad():
+        red.w.copy_(torch.tensor([0.7, -1.3, 0.4], device=red.w.device).view(3, 1, 1))
+    got = model.gnn(None).cpu().numpy()
+    want_e = om.propagate(g['adj'], helpers.gnn_to_oracle(model.gnn), np.float64)
+    assert got.shape == want_e.shape == (g['adj'].shape[0], 8) and helpers.rel_err(got, want_e) < 1e-5
+    y = np.random.default_rng(2).integers(0, 2, len(g['u_ids']))
+    trainer = training.Trainer(model)
+    assert any(p is red.w for p in trainer.params)
+    loss, grads = trainer.loss_and_grads(g['u_ids'], g['i_ids'], y)
+    want_loss, want, _ = otrain.torch_model_grads(g['adj'], helpers.gnn_to_oracle(model.gnn), helpers.basic_head_to_oracle(model.rs),
+                                                  g['u_ids'], g['i_ids'], y, l2=1e-4)
+    assert abs(loss - want_loss) < 1e-5
+    flat = _flatten_oracle_grads(model, want)
+    assert set(flat) == set(grads)
+    for prm, gw in flat.items():
+        got = grads[prm].cpu().numpy().reshape(gw.shape).astype(np.float64)
+        got += 2 * trainer._l2(prm) * prm.detach().cpu().numpy().reshape(gw.shape)
+        assert np.abs(got - gw).max() <= 2e-4 * np.abs(gw).max() + 1e-10, tuple(prm.shape)
+    # (the reduction's own reverse pass is bit-reproducible — test_weighted_sum_reduction_kernels; the d(loss)/d(node rows) it is fed
+    # comes from the batch's scatter-add, whose float atomics leave last-bit differences between runs)
+    loss2, grads2 = trainer.loss_and_grads(g['u_ids'], g['i_ids'], y)
+    assert loss2 == loss and torch.allclose(grads2[red.w], grads[red.w], rtol=1e-4, atol=1e-9)
 
 
 @pytest.mark.parametrize('cls,feature_based,fusion,residual', [

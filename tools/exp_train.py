@@ -12,6 +12,7 @@ import torch
 
 def main():
     epochs = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    only_table5 = len(sys.argv) > 2 and sys.argv[2] == 'table5'          # (tools/profile_train.sh)
     from deep_cbrs_amar_renaissance_amd import capi, engine
     from deep_cbrs_amar_renaissance_amd.data.datasets import UserItemGraph
     from deep_cbrs_amar_renaissance_amd.experiment import Adam
@@ -23,6 +24,8 @@ def main():
     for name, cfg in (('BasicGCN 16x2 (Table 5)', dict(embedding_dim=16, n_hiddens=[16, 16], dense_units=[48, 48], clf_units=[64, 64], l2_regularizer=1e-4)),
                       ('BasicGCN 8x2 (grid1)', dict(embedding_dim=8, n_hiddens=[8, 8], dense_units=[24, 24], clf_units=[48, 48], l2_regularizer=1e-4)),
                       ('BasicLightGCN 8x2', dict(embedding_dim=8, n_layers=2, dense_units=[24, 24], clf_units=[48, 48], l2_regularizer=1e-4))):
+        if only_table5 and 'Table 5' not in name:
+            continue
         cls = basic.BasicLightGCN if 'Light' in name else basic.BasicGCN
         model = cls(g['adj_ui'], **cfg)
         model.compile(loss='binary_crossentropy', optimizer=Adam(learning_rate=1e-3), metrics=['accuracy'])

@@ -3,7 +3,8 @@
 combination of an econfig's value lists), produced by the REFERENCE'S OWN functions run in the build container.
 
 `/root/reference/src/utilities/utils.py` imports mlflow at its top and cannot be imported here (ModuleNotFoundError), but
-`nested_dict_update`, `linearize`, `extract`, `delinearize` and `make_grid` (utils.py:19-99) are plain Python: this script reads the
+`nested_dict_update`, `linearize`, `extract`, `delinearize`, `make_grid` (utils.py:19-99) and `mlflow_linearize` (the keys the run log
+receives, utils.py:132-146) are plain Python: this script reads the
 file as text, takes exactly these function definitions out of the syntax tree and executes THEM, unchanged, in a namespace that
 holds `collections`, `groupby` and `product`.  Inputs (grids shaped like the reference's econfigs, written here) and the functions'
 outputs go to tests/golden/grid_reference.json.
@@ -20,7 +21,7 @@ from itertools import groupby, product
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PATH = '/root/reference/src/utilities/utils.py'
-NAMES = ['nested_dict_update', 'linearize', 'extract', 'delinearize', 'make_grid']
+NAMES = ['nested_dict_update', 'linearize', 'extract', 'delinearize', 'make_grid', 'mlflow_linearize']
 
 GRIDS = {
     'basic_gnn_like': {'model': {'name': ['basic.BasicGCN', 'basic.BasicGAT'], 'embedding_dim': [8, 16], 'n_hiddens': [[8, 8], [16, 16]],
@@ -45,11 +46,14 @@ def main():
     for node in tree.body:
         if isinstance(node, ast.FunctionDef) and node.name in NAMES:
             exec(compile(ast.Module(body=[node], type_ignores=[]), PATH, 'exec'), ns)
-    out = {'grids': {}, 'updates': []}
+    out = {'grids': {}, 'updates': [], 'log_keys': []}
     for name, grid in GRIDS.items():
         out['grids'][name] = {'input': grid, 'output': ns['make_grid'](copy.deepcopy(grid))}
     for d, u in UPDATES:
         out['updates'].append({'d': d, 'u': u, 'output': ns['nested_dict_update'](copy.deepcopy(d), copy.deepcopy(u))})
+    for name, grid in GRIDS.items():
+        for exp in out['grids'][name]['output'][:2]:
+            out['log_keys'].append({'input': exp, 'output': ns['mlflow_linearize'](copy.deepcopy(exp))})
     json.dump(out, open(os.path.join(HERE, 'grid_reference.json'), 'w'), indent=1, sort_keys=False)
     print('wrote grid_reference.json:', {k: len(v['output']) for k, v in out['grids'].items()})
 

@@ -399,3 +399,6 @@ def test_experiment_grid_expansion_reproduces_the_reference_functions_own_output
         assert utils.make_grid(copy.deepcopy(case['input'])) == case['output'], name
     for case in z['updates']:
         assert utils.nested_dict_update(copy.deepcopy(case['d']), copy.deepcopy(case['u'])) == case['output']
+    for case in z['log_keys']:                                       # the parameter names a run is logged under (experiment.py:149)
+        got = utils.mlflow_linearize(copy.deepcopy(case['input']))
+        assert got == case['output'] and list(got) == list(case['output'])

@@ -618,7 +618,13 @@ __device__ unsigned long long lt_debug_stamps[4 * 8192];
 #define LT_STAMP(i) do { } while (0)
 #endif
 constexpr int LT_WAVES = 16;
-constexpr int LT_TILE_BYTES = 128 << 10;
+#ifndef AMAR_LT_TILE_BYTES                          // development builds (tools/exp_lt_half.py): a smaller Y tile, several workgroups per CU
+#define AMAR_LT_TILE_BYTES (128 << 10)
+#endif
+#ifndef AMAR_LT_MIN_WAVES                           // ... and the waves per SIMD the register allocation must leave room for
+#define AMAR_LT_MIN_WAVES 4
+#endif
+constexpr int LT_TILE_BYTES = AMAR_LT_TILE_BYTES;
 // GAT mode keeps (sum of weights, s_self) next to every LDS row: 4F + 8 bytes per virtual row, fewer rows per wave
 // (utilities/lds_tiled.py:GAT_ROWS_PER_WAVE holds the same table)
 constexpr int lt_gat_rw(int F) { return F == 8 ? 216 : F == 16 ? 124 : F == 32 ? 64 : 384; }
@@ -645,7 +651,7 @@ __device__ __forceinline__ int lt_lds_row(int v) {                    // virtual
 // SAGE: GraphSAGE's tail in the epilogue (AMAR_SPMM_SAGE_TAIL): the tile's sums are the mean aggregate; the row leaves as
 // relu(l2_normalize([x_i || agg_i] . W + b)) with W = e.Wn [2F, F], in sage_tail_kernel's order of operations.
 template <int F, int OFF32, bool FUSE_NEXT, int U, int PACE, int ABL = 0, bool GAT = false, bool SAGE = false>
-__global__ __launch_bounds__(LT_WAVES * AMAR_WAVE) void spmm_lt_kernel(const LtArgs a) {
+__global__ __launch_bounds__(LT_WAVES * AMAR_WAVE, AMAR_LT_MIN_WAVES) void spmm_lt_kernel(const LtArgs a) {
     constexpr int LPN = F / 4, EPS = AMAR_WAVE / LPN, RW = GAT ? lt_gat_rw(F) : LT_TILE_BYTES / (4 * F * LT_WAVES), CS = LT_CHUNK / EPS;
     constexpr unsigned LMASK = (1u << lt_bits(RW)) - 1u;
     constexpr int G = U - 1;                                          // steps of gathers in flight ahead of the accumulation

@@ -288,7 +288,7 @@ def hybrid_head(dev, scale):
     del model, bert, tw, emb
     torch.cuda.empty_cache()
     return {'config': 'econfigs/hybrid-gnn.yaml grid1: HybridBertGCN d=8 L=2, dense [[24,24],[256,64],[64,64]], clf [64,64], 768-d BERT, ml1m(s={})'.format(scale),
-            'bert_tower': {'kernel': 'dense_mfma_kernel (amar_dense_f32): 768->256->64 over the {} user rows'.format(nu),
+            'bert_tower': {'kernel': 'dense_mfma128_kernel / dense_mfma_kernel (amar_dense_f32): 768->256->64 over the {} user rows'.format(nu),
                            'ms': ms_bert_u, 'tflops': flop_bert_u / ms_bert_u / 1e9, 'peak_tflops': MFMA_F32_PEAK_TFLOPS,
                            'mfma_frac': flop_bert_u / ms_bert_u / 1e9 / MFMA_F32_PEAK_TFLOPS},
             'entity_towers_ms': ms_towers,

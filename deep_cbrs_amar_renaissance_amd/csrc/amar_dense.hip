@@ -147,6 +147,101 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const DenseArgs a) {
     }
 }
 
+// The guard-free form on a 128 x 128 tile (N a multiple of 128: the 768 -> 256 BERT layers): every wave keeps its 32 rows against all
+// 128 columns in FOUR accumulators, so one A fragment read feeds four MFMAs (three LDS reads per four MFMAs instead of three per two)
+// and a k-tile's two barriers are paid once per 32 MFMAs per wave instead of once per 16.  Same k order per output: bit-identical.
+constexpr int BN2 = 128, B2_LD = BN2;
+template <int BKT>                                                  // k-tile depth: 16 or 32
+__global__ __launch_bounds__(256) void dense_mfma128_kernel(const DenseArgs a) {
+    __shared__ float As[BKT * A_LD];
+    __shared__ float Bs[BKT * B2_LD];
+    constexpr int XQ = BKT / 4;                                     // float4 per X row and k-tile
+    constexpr int XH = 128 * XQ / 256;                              // X float4 per thread (2 or 4)
+    constexpr int WH = BKT * 32 / 256;                              // W float4 per thread (2 or 4)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t L = blockIdx.x;                                  // XCD-affine tile order, as in dense_mfma_kernel
+    const int64_t j = L >> 3;
+    const int64_t m_blk = (j / a.n_col_blocks) * 8 + (L & 7);
+    if (m_blk * BM >= a.M) return;
+    const int64_t m0 = m_blk * BM;
+    const int n0 = (int)(j % a.n_col_blocks) * BN2;
+
+    const int xr = tid / XQ, xq = tid % XQ;                         // X tile: thread's rows xr + (256 / XQ) h
+    auto row_ptr = [&](int h) {
+        const int64_t m = m0 + xr + (256 / XQ) * h;
+        const int64_t mc = m < a.M ? m : a.M - 1;
+        return a.X + (a.ids ? (int64_t)a.ids[mc] : mc) * a.ldx + 4 * xq;
+    };
+    const float *xp0 = row_ptr(0), *xp1 = row_ptr(1), *xp2 = XH > 2 ? row_ptr(2) : xp0, *xp3 = XH > 2 ? row_ptr(3) : xp0;
+    const int wk = tid >> 5, wq = tid & 31;                        // W tile: k rows wk + 8 h, float4 column wq
+    const float *wp = a.W + (int64_t)wk * a.N + n0 + 4 * wq;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+    float4 xa0, xa1, xa2, xa3, wb0, wb1, wb2, wb3;
+    xa2 = xa3 = wb2 = wb3 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define AMAR_D128_FETCH(k0_)                                                                                     \
+    do {                                                                                                         \
+        xa0 = *reinterpret_cast<const float4 *>(xp0 + (k0_));                                                    \
+        xa1 = *reinterpret_cast<const float4 *>(xp1 + (k0_));                                                    \
+        if (XH > 2) { xa2 = *reinterpret_cast<const float4 *>(xp2 + (k0_)); xa3 = *reinterpret_cast<const float4 *>(xp3 + (k0_)); } \
+        wb0 = *reinterpret_cast<const float4 *>(wp + (int64_t)(k0_) * a.N);                                      \
+        wb1 = *reinterpret_cast<const float4 *>(wp + (int64_t)((k0_) + 8) * a.N);                                \
+        if (WH > 2) { wb2 = *reinterpret_cast<const float4 *>(wp + (int64_t)((k0_) + 16) * a.N);                 \
+                      wb3 = *reinterpret_cast<const float4 *>(wp + (int64_t)((k0_) + 24) * a.N); }               \
+    } while (0)
+#define AMAR_D128_STAGE_X(v_, h_)                                                                                \
+    do {                                                                                                         \
+        const int r_ = xr + (256 / XQ) * (h_);                                                                   \
+        As[(4 * xq + 0) * A_LD + r_] = (v_).x; As[(4 * xq + 1) * A_LD + r_] = (v_).y;                            \
+        As[(4 * xq + 2) * A_LD + r_] = (v_).z; As[(4 * xq + 3) * A_LD + r_] = (v_).w;                            \
+    } while (0)
+    AMAR_D128_FETCH(0);
+    for (int k0 = 0; k0 < a.K; k0 += BKT) {
+        __syncthreads();                                            // previous tile fully consumed
+        AMAR_D128_STAGE_X(xa0, 0);
+        AMAR_D128_STAGE_X(xa1, 1);
+        if (XH > 2) { AMAR_D128_STAGE_X(xa2, 2); AMAR_D128_STAGE_X(xa3, 3); }
+        *reinterpret_cast<float4 *>(&Bs[wk * B2_LD + 4 * wq]) = wb0;
+        *reinterpret_cast<float4 *>(&Bs[(wk + 8) * B2_LD + 4 * wq]) = wb1;
+        if (WH > 2) {
+            *reinterpret_cast<float4 *>(&Bs[(wk + 16) * B2_LD + 4 * wq]) = wb2;
+            *reinterpret_cast<float4 *>(&Bs[(wk + 24) * B2_LD + 4 * wq]) = wb3;
+        }
+        __syncthreads();
+        if (k0 + BKT < a.K) AMAR_D128_FETCH(k0 + BKT);
+#pragma unroll
+        for (int kk = 0; kk < BKT; kk += 2) {
+            const int k = kk + (lane >> 5);
+            const float av = As[k * A_LD + 32 * wave + (lane & 31)];
+            const float *bp = &Bs[k * B2_LD + (lane & 31)];
+            const float b0 = bp[0], b1 = bp[32], b2 = bp[64], b3 = bp[96];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b2, acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b3, acc[3], 0, 0, 0);
+        }
+    }
+    const int col = lane & 31;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int n = n0 + 32 * c + col;
+        const float b = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < a.M) a.Y[m * a.ldy + n] = apply_act(acc[c][r] + b, a.act);
+        }
+    }
+}
+
+#undef AMAR_D128_FETCH
+#undef AMAR_D128_STAGE_X
+
 // ---- per-user top-k --------------------------------------------------------------------------
 // One wave per user.  Round t picks the best pair that comes strictly after round t-1's winner in
 // the order (score descending, item id ascending); items are distinct within a user.
@@ -214,6 +309,16 @@ int amar_dense_f32(const float *X, int64_t ldx, const int32_t *ids,
     const bool vx = (ldx & 3) == 0 && amar_aligned16(X);
     const bool vw = (N & 3) == 0 && amar_aligned16(W);
     static const bool no_full = getenv("AMAR_DENSE_FULL") && atoi(getenv("AMAR_DENSE_FULL")) == 0;     // development switch (A/B timing)
+    static const bool no_128 = getenv("AMAR_DENSE_128") && atoi(getenv("AMAR_DENSE_128")) == 0;        // ... the 128-column tile
+    if (vx && vw && !w_trans && K % BK == 0 && N % BN2 == 0 && !no_full && !no_128) {
+        DenseArgs a2 = a;
+        a2.n_col_blocks = N / BN2;
+        const int64_t total2 = ((gx + 7) / 8) * 8 * a2.n_col_blocks;
+        static const int bk2 = getenv("AMAR_DENSE_BK") ? atoi(getenv("AMAR_DENSE_BK")) : 16;            // development switch
+        if (bk2 == 32 && K % 32 == 0) hipLaunchKernelGGL(dense_mfma128_kernel<32>, dim3((unsigned)total2), block, 0, st, a2);
+        else hipLaunchKernelGGL(dense_mfma128_kernel<16>, dim3((unsigned)total2), block, 0, st, a2);
+        return amar_check_launch();
+    }
     if (vx && vw && !w_trans && K % BK == 0 && N % BN == 0 && !no_full) hipLaunchKernelGGL((dense_mfma_kernel<true, true, true>), grid, block, 0, st, a);
     else if (vx && vw) hipLaunchKernelGGL((dense_mfma_kernel<true, true>), grid, block, 0, st, a);
     else if (vx) hipLaunchKernelGGL((dense_mfma_kernel<true, false>), grid, block, 0, st, a);

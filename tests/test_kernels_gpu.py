@@ -275,19 +275,28 @@ def test_dense(hip, M, K, N, act):
 
 
 def test_dense_guard_free_form_with_row_gather(hip):
-    """The guard-free staging form of amar_dense_f32 (K % 16 == 0, N % 64 == 0): row gather through ids, a last row tile that is
-    mostly past M (those lanes re-read row M - 1 and are dropped), all three activations."""
+    """The guard-free staging forms of amar_dense_f32 (K % 16 == 0): the 128 x 64 tile (N % 64 == 0: N = 64, 192) and the 128 x 128
+    tile with four accumulators per wave (N % 128 == 0: N = 128, 256 — one and two column blocks).  Row gather through ids, last
+    row tiles that are mostly past M (those lanes re-read row M - 1 and are dropped), several row tiles (the XCD-affine tile
+    order), all three activations."""
     rng = np.random.default_rng(5)
     table = rng.standard_normal((400, 48)).astype(np.float32)
-    for M in (1, 129, 333):
-        ids = rng.integers(7, 400, size=M).astype(np.int32)
-        w = rng.uniform(-0.3, 0.3, (48, 128)).astype(np.float32)
-        b = rng.uniform(-0.2, 0.2, 128).astype(np.float32)
-        for act in ('relu', 'sigmoid', None):
-            y = torch.full((M, 128), float('nan'), device=DEV)
-            hip.dense(_t(table), _t(w), _t(b), y, act=act, ids=_t(ids))
-            want = ol.dense(table[ids].astype(np.float64), w.astype(np.float64), b.astype(np.float64), act)
-            assert rel_err(y.cpu().numpy(), want) < 3e-6
+    for N in (64, 128, 192, 256):
+        w = rng.uniform(-0.3, 0.3, (48, N)).astype(np.float32)
+        b = rng.uniform(-0.2, 0.2, N).astype(np.float32)
+        for M in (1, 129, 333, 1100):
+            ids = rng.integers(7, 400, size=M).astype(np.int32)
+            for act in ('relu', 'sigmoid', None):
+                y = torch.full((M, N), float('nan'), device=DEV)
+                hip.dense(_t(table), _t(w), _t(b), y, act=act, ids=_t(ids))
+                want = ol.dense(table[ids].astype(np.float64), w.astype(np.float64), b.astype(np.float64), act)
+                assert rel_err(y.cpu().numpy(), want) < 3e-6
+    # a deep product without ids or bias (the BERT tower's first layer in small): 768 -> 256
+    x = rng.standard_normal((300, 768)).astype(np.float32)
+    w = rng.uniform(-0.05, 0.05, (768, 256)).astype(np.float32)
+    y = torch.full((300, 256), float('nan'), device=DEV)
+    hip.dense(_t(x), _t(w), None, y, act=None)
+    assert rel_err(y.cpu().numpy(), x.astype(np.float64) @ w.astype(np.float64)) < 3e-6
 
 
 def test_dense_gather_and_concat_slices(hip):

@@ -3,10 +3,12 @@
 // config.yaml:50-58 and applied by experiment.py:155-188; reverse-mode derivatives of the Dense /
 // GCNConv / LightGCNConv / embedding_lookup operations of src/models/{basic,gnn}.py.
 // All element-wise or small-reduction work: HBM-bound, one float (or a few) per lane, fixed
-// summation orders (the weight gradient is reduced in two stages, never with float atomics).  The one exception is the
-// embedding-row gradient (scatter_add_rows_kernel): rows that occur several times in a batch are added with global float
-// atomics, so that gradient's last bits depend on the order of arrival; ids are range-checked on the host (engine.ids_to_device).
+// summation orders (the weight gradient is reduced in two stages, never with float atomics; the embedding-row gradient of a batch is
+// added by the first position of every id, in position order: scatter_add_rows_owner_kernel).  Only an id list longer than 8 192 rows
+// falls back to global float atomics (scatter_add_rows_kernel), whose last bits depend on the order of arrival; ids are range-checked
+// on the host (engine.ids_to_device).
 #include "amar_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -109,6 +111,45 @@ __global__ __launch_bounds__(256) void scatter_add_rows_kernel(const float *__re
         const int64_t r = i / W;
         const int c = (int)(i - r * W);
         atomicAdd(dst + ((int64_t)ids[r] - base) * ldd + c, src[r * lds + c]);
+    }
+}
+
+// The same sum WITHOUT atomics for batch-sized calls (M <= SCATTER_OWNER_MAX ids, held in LDS): the FIRST position of every distinct id
+// owns its destination row and adds the rows of all positions with that id in ascending position order — one writer per row, a fixed
+// order of additions: the embedding-row gradient no longer depends on the order in which workgroups arrive.  One wavefront per
+// position: its 64 lanes compare 64 ids of the list at a time (a ballot tells whether an earlier position holds the id, later ballots
+// list the positions to add), then take one column each.  (First form: one thread per position walking the list alone — a serial chain
+// of 1 024 LDS reads, 85 us per call against 4.5 for the atomics; this one costs about the same as the atomics.)
+constexpr int SCATTER_OWNER_MAX = 8192;
+__global__ __launch_bounds__(256) void scatter_add_rows_owner_kernel(const float *__restrict__ src, int64_t lds, const int32_t *__restrict__ ids,
+                                                                     int base, float *__restrict__ dst, int64_t ldd, int M, int W) {
+    extern __shared__ int32_t id_lds[];
+    for (int q = threadIdx.x; q < M; q += blockDim.x) id_lds[q] = ids[q];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int p = blockIdx.x * 4 + wave; p < M; p += gridDim.x * 4) {          // wave-uniform
+        const int32_t id = id_lds[p];
+        bool owner = true;
+        for (int q0 = 0; q0 < p && owner; q0 += 64) {
+            const int q = q0 + lane;
+            owner = __ballot(q < p && id_lds[q] == id) == 0ull;
+        }
+        if (!owner) continue;
+        for (int c0 = 0; c0 < W; c0 += 64) {
+            const int c = c0 + lane;
+            float acc = c < W ? src[(int64_t)p * lds + c] : 0.f;
+            for (int q0 = (p + 1) & ~63; q0 < M; q0 += 64) {
+                const int q = q0 + lane;
+                unsigned long long later = __ballot(q > p && q < M && id_lds[q] == id);
+                while (later) {                                                 // ascending positions
+                    const int b = __builtin_ctzll(later);
+                    later &= later - 1;
+                    if (c < W) acc += src[(int64_t)(q0 + b) * lds + c];
+                }
+            }
+            if (c < W) dst[((int64_t)id - base) * ldd + c] += acc;
+        }
     }
 }
 
@@ -512,6 +553,14 @@ int amar_scatter_add_rows_f32(const float *src, int64_t lds, const int32_t *ids,
                               int64_t M, int32_t W, amar_stream_t stream) {
     if (M < 0 || W < 1 || !src || !ids || !dst || lds < W || ldd < W) return AMAR_EINVAL;
     if (M == 0) return AMAR_OK;
+    static const bool atomics = getenv("AMAR_SCATTER_ATOMIC") && atoi(getenv("AMAR_SCATTER_ATOMIC")) == 1;   // development switch (A/B)
+    if (M <= SCATTER_OWNER_MAX && !atomics) {
+        int64_t blocks = (M + 3) / 4;                                 // one wavefront per position, every workgroup holds the id list
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(scatter_add_rows_owner_kernel, dim3((unsigned)blocks), dim3(256), (size_t)M * sizeof(int32_t), static_cast<hipStream_t>(stream),
+                           src, lds, ids, base, dst, ldd, (int)M, W);
+        return amar_check_launch();
+    }
     hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid1d(M * W)), dim3(256), 0, static_cast<hipStream_t>(stream), src, lds, ids, base, dst, ldd, M, W);
     return amar_check_launch();
 }

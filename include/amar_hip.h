@@ -358,7 +358,9 @@ int amar_locality_scale_bwd_f32(const float *dOut, int64_t ldd, const float *X, 
  *                           order (no float atomics); scratch must hold amar_wgrad_scratch_floats(M, K, N) floats
  * amar_bce_grad_f32         Keras backend binary_crossentropy on probabilities (epsilon 1e-7, mean over B):
  *                           loss_terms[i] and dz[i] = dL/dlogit_i through the final sigmoid
- * amar_scatter_add_rows_f32 dst[ids[m] - base, :] += src[m, :]   (gradient of embedding_lookup; float atomics)
+ * amar_scatter_add_rows_f32 dst[ids[m] - base, :] += src[m, :]   (gradient of embedding_lookup).  Up to 8 192 ids: without atomics —
+ *                           the first position of an id adds the rows of all its positions in position order (one writer per row,
+ *                           reproducible bit for bit); longer lists: global float atomics (order-dependent last bits)
  * amar_add_inplace_f32      dst += scale * src on strided [M, W] blocks
  * amar_row_affine_f32       out = (A + B) * scale[row], B optional: GraphSAGE's mean aggregate (sum + self) / count
  *                           (Spektral GraphSageConv, built at src/models/gnn.py:354-361) and its reverse

@@ -154,6 +154,15 @@ def test_model_classes_resolve_and_param_counts():
         hybrid.HybridCBRS(fusion_method='bogus')
     from deep_cbrs_amar_renaissance_amd import training
     assert training.Trainer(basic.BasicGCN(adj, **dict(cfg, final_node='last'))).tapes[0].kind == 'gcn'     # every reduction has a reverse pass
+    # 'w-sum' (WeightedSum, reduction.py:36-55): one learnable weight per term X_0 .. X_L, ones, no regulariser (gnn.py:62 passes none);
+    # the output is one layer wide (the heads are built for it) and the weights train with everything else
+    ws = basic.BasicGCN(adj, **dict(cfg, final_node='w-sum'))
+    red = ws.gnn.gnn_layers.reduce
+    assert tuple(red.w.shape) == (3, 1, 1) and bool((red.w == 1).all()) and red.w.regularizer is None
+    assert ws.gnn.output_dim() == 8
+    assert count(ws) == 8 * N + 2 * (8 * 8 + 8) + 2 * ((8 * 24 + 24) + (24 * 24 + 24)) + (48 * 48 + 48) * 2 + 49 + 3
+    trainer = training.Trainer(ws)
+    assert trainer.tapes[0].kind == 'gcn' and any(p is red.w for p in trainer.params)
 
 
 def test_seed_reproducibility_and_glorot_limits():

@@ -884,6 +884,8 @@ int amar_chain_indexed_f32(const float *A, int64_t lda, int32_t Da, const int32_
         AMAR_ROWS_CASE(3, 2, 2, 2, 3);      // 24 -> 24 -> 24 -> 48: basic-gnn grid1's towers with the classifier's first layer folded in
         AMAR_ROWS_CASE(3, 3, 3, 3, 4);      // 48 -> 48 -> 48 -> 64: grid2
         AMAR_ROWS_CASE(2, 2, 2, 2, 0);      // 24 -> 24 -> 24: the graph towers of the hybrid head
+        AMAR_ROWS_CASE(3, 1, 2, 2, 3);      //  8 -> 24 -> 24 -> 48: grid1's towers after a 'mean' / 'sum' / 'w-sum' reduction (LightGCN, DGCF)
+        AMAR_ROWS_CASE(3, 1, 3, 3, 4);      // 16 -> 48 -> 48 -> 64: grid2's
         AMAR_ROWS_CASE(2, 3, 3, 3, 0);      // 48 -> 48 -> 48
         default: done = false;
         }

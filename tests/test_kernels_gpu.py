@@ -954,7 +954,7 @@ def test_chain_out_index(hip, D, units, last_act):
 
 
 @pytest.mark.parametrize('Da,units,last_act', [(24, [24, 24, 48], None), (48, [48, 48, 64], None), (24, [24, 24], 'relu'), (48, [48, 48], 'relu'),
-                                               (20, [24, 24, 40], None), (36, [44, 48, 64], None)])
+                                               (20, [24, 24, 40], None), (36, [44, 48, 64], None), (8, [24, 24, 48], None), (16, [48, 48, 64], None)])
 @pytest.mark.parametrize('P', [1, 130, 300_001])
 def test_entity_towers_compile_time_shapes(hip, Da, units, last_act, P):
     """The per-entity towers (one table, ReLU layers, an optionally linear last layer — the folded half of the classifier's first

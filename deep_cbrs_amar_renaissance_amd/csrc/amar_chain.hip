@@ -368,9 +368,12 @@ __global__ __launch_bounds__(256) void chain_pipe_kernel(const ChainArgs a) {
         issue(ra, rb, na, nb);                                     // next iteration's rows (the last pair's again past the end)
         load_ids(base + 2 * stride, ra, rb);
         for (int l = 0; l < a.n_layers; ++l) {
-            const float *wl = w_lds + a.w_off[l];
+            const float *wl = w_lds + a.w_off[l] + lane * 4;
             const float *bl = w_lds + a.b_off[l];
             f32x4 y[MAXT][PT];
+            // the weight fragment of tile (m, t) + 1 is requested BEFORE the eight MFMAs of tile (m, t) are issued (left to itself the
+            // compiler reads a fragment right before its own MFMAs: the LDS round trip sat between every two MFMA groups of a wave)
+            f32x4 wnext = *reinterpret_cast<const f32x4 *>(wl);
 #pragma unroll
             for (int m = 0; m < MAXT; ++m) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bl + 16 * m + 4 * g);
@@ -378,7 +381,11 @@ __global__ __launch_bounds__(256) void chain_pipe_kernel(const ChainArgs a) {
                 for (int pt = 0; pt < PT; ++pt) y[m][pt] = b4;
 #pragma unroll
                 for (int t = 0; t < MAXT; ++t) {
-                    const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wl + ((m * MAXT + t) * 64 + lane) * 4);
+                    const f32x4 w4 = wnext;
+                    if (m * MAXT + t + 1 < MAXT * MAXT) {
+                        wnext = *reinterpret_cast<const f32x4 *>(wl + (m * MAXT + t + 1) * 256);
+                        __builtin_amdgcn_sched_barrier(0);                  // keep the read above this tile's MFMAs
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
 #pragma unroll

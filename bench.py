@@ -15,11 +15,14 @@ Workload: ml1m(s) graph of MovieLens-1M shape scaled by s (default 64: |U| = 386
 (`python -m torch.distributed.run`, fresh child processes, before this process touches the GPU);
 under torchrun (WORLD_SIZE set) it is one rank.  Rank 0 prints ONE JSON line.  Extra objects:
 `roofline` (dominant kernel = the fused GCN SpMM layer, algorithmic bytes nnz*8 + (N+1)*4 + 2*N*F*4
-per launch over its HIP-event time), `roofline_l2` (the same launch against the XS form's binding
-limit, one L2 line request per gathered row), `pair_stage`, `hybrid_head` (econfigs/hybrid-gnn.yaml
+per launch over its HIP-event time), `roofline_onchip` (the same launch against the DISPATCHED kernel's own on-chip
+floors: its L2 request count from this build's counters and its measured no-gather time), `wider_layers` (the fused layer of
+econfigs/basic-gnn.yaml grid2 / grid3: F = 16 / 32 at the same scale), `pair_stage`, `hybrid_head` (econfigs/hybrid-gnn.yaml
 grid1 head at the same scale: MFMA utilisation), `uip_graph` (econfigs/basic-gnn-uip-2relconf.yaml grid1: the same model on
 the user-item-property graph), `train_s1` (one `fit()` epoch at the reference's real size), `ml1m_s1` (the reference's real size) and
-`cpu_baseline` (the oracle timed on one host core on the SAME ml1m(s=1) graph, weights and pairs).
+`cpu_baseline` (the oracle on the host: one core and all usable cores on the SAME ml1m(s=1) inputs, plus one hoisted repetition on
+the headline workload itself with the score difference against the GPU leg).  With N > 1 ranks: `per_rank` (every rank's
+local_spmm_ms / exchange_ms / replicated_ms of an eager step).
 """
 import argparse
 import hashlib
@@ -39,6 +42,8 @@ import torch
 
 GRID1 = dict(embedding_dim=8, n_hiddens=[8, 8], n_layers=2, dense_units=[24, 24], clf_units=[48, 48],
              l2_regularizer=1e-4, final_node='concatenation', activation='relu')
+GRID2 = dict(GRID1, embedding_dim=16, n_hiddens=[16, 16], dense_units=[48, 48], clf_units=[64, 64])      # basic-gnn.yaml:13-22
+GRID3 = dict(GRID1, embedding_dim=32, n_hiddens=[32, 32], dense_units=[96, 48], clf_units=[64, 64])      # basic-gnn.yaml:24-33
 HYBRID_GRID1 = dict(embedding_dim=8, n_hiddens=[8, 8], dense_units=[[24, 24], [256, 64], [64, 64]], clf_units=[64, 64],
                     feature_based=True)
 HBM_PEAK_GBPS = 8000.0
@@ -96,21 +101,31 @@ def pmc_profile(scale, kind):
     return pmc, src
 
 
-def cpu_baseline(s1):
+def usable_cores():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_baseline(s1, headline=None):
     """Oracle (numpy/scipy port of the reference arithmetic) on the SAME ml1m(s=1) graph, weights and pair list as the
-    `ml1m_s1` GPU leg, one host thread: hoisted (one propagation, then all pairs) and faithful (propagation re-run per
-    2 048-pair batch as basic.py:61-63 does, batch size config.yaml:47).  gcn_filter is the model-construction
-    preprocess (gnn.py:283) and is outside both timed regions, as it is outside the GPU's."""
+    `ml1m_s1` GPU leg: hoisted (one propagation, then all pairs) and faithful (propagation re-run per 2 048-pair batch as
+    basic.py:61-63 does, batch size config.yaml:47) on ONE thread, hoisted again on all usable cores (the reference runs
+    with n_workers: 12, config.yaml:2; what scales here is the BLAS pool of the Dense layers — scipy's CSR product is
+    single-threaded whatever the pool).  gcn_filter is the model-construction preprocess (gnn.py:283) and is outside every
+    timed region, as it is outside the GPU's.  `headline`: the inputs of the headline workload itself — one hoisted repetition
+    on all usable cores, scores compared with the GPU leg's."""
     from threadpoolctl import threadpool_limits
     from oracle import graph as ograph, layers as olayers, models as om
     adj, gnn, head, u, i = s1['adj'], s1['gnn'], s1['head'], s1['u'], s1['i']
     a_hat = ograph.gcn_filter(adj)
 
-    def propagate():
-        x = gnn['embeddings'].astype(np.float32)
+    def propagate(a=a_hat, g=gnn):
+        x = g['embeddings'].astype(np.float32)
         hs = [x]
-        for lw in gnn['layers']:
-            x = olayers.gcn_conv(x, a_hat, lw['kernel'], lw['bias'])
+        for lw in g['layers']:
+            x = olayers.gcn_conv(x, a, lw['kernel'], lw['bias'])
             hs.append(x)
         return olayers.reduce_layers(hs, 'concatenation')
 
@@ -125,25 +140,71 @@ def cpu_baseline(s1):
             outs.append(om.basic_rs(e[u[lo:lo + 2048]], e[i[lo:lo + 2048]], head))
         return np.concatenate(outs)
 
+    def timed(fn, budget, min_reps):
+        reps, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < budget or reps < min_reps:
+            fn()
+            reps += 1
+        return (time.perf_counter() - t0) / reps, reps
+
     with threadpool_limits(limits=1):
         scores = hoisted()                                          # warm; also the parity check of the GPU leg
-        reps, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < 8.0 or reps < 3:
+        dt, reps = timed(hoisted, 6.0, 3)
+        fdt, freps = timed(faithful, 6.0, 1)
+    cores = usable_cores()
+    # the BLAS pool that serves this workload best: the Dense layers are [pairs, 24..48] x [24..48, 24..48] products, far too small
+    # for one thread per core of a 256-thread host (64 threads: 3-4x SLOWER than one) — a short sweep picks the pool, all are reported
+    sweep = {}
+    for pool in sorted({p for p in (2, 4, 8, 16, 32, 64) if p <= cores}):
+        with threadpool_limits(limits=pool):
             hoisted()
-            reps += 1
-        dt = (time.perf_counter() - t0) / reps
-        freps, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < 8.0 or freps < 1:
-            faithful()
-            freps += 1
-        fdt = (time.perf_counter() - t0) / freps
+            sweep[pool] = timed(hoisted, 1.0, 2)[0]
+    threads = min(sweep, key=sweep.get) if sweep else 1
+    with threadpool_limits(limits=threads):
+        hoisted()
+        adt, areps = timed(hoisted, 3.0, 3)
     err = float(np.abs(scores.reshape(-1) - s1['gpu_scores'].reshape(-1)).max())
-    return {'value': len(u) / dt, 'unit': 'pairs/s', 'cores': 1, 'kind': 'port',
-            'sample': 'ml1m(s=1), the graph / weights / {} test pairs of the ml1m_s1 GPU leg: 2-layer GCN propagation + all pairs, '
-                      'hoisted, {} reps of {:.3f} s on one thread'.format(len(u), reps, dt),
-            'faithful': {'value': len(u) / fdt, 'unit': 'pairs/s', 'cores': 1, 'batch': 2048,
-                         'sample': 'propagation re-run per 2048-pair batch (basic.py:61-63), {} passes of {:.2f} s'.format(freps, fdt)},
-            'max_abs_score_diff_vs_gpu': err}
+    out = {'value': len(u) / dt, 'unit': 'pairs/s', 'cores': 1, 'kind': 'port',
+           'sample': 'ml1m(s=1), the graph / weights / {} test pairs of the ml1m_s1 GPU leg: 2-layer GCN propagation + all pairs, '
+                     'hoisted, {} reps of {:.3f} s on one thread'.format(len(u), reps, dt),
+           'faithful': {'value': len(u) / fdt, 'unit': 'pairs/s', 'cores': 1, 'batch': 2048,
+                        'sample': 'propagation re-run per 2048-pair batch (basic.py:61-63), {} passes of {:.2f} s'.format(freps, fdt)},
+           'all_cores': {'value': len(u) / adt, 'unit': 'pairs/s', 'cores': threads, 'usable_cores': cores, 'host_cpus': os.cpu_count(),
+                         'pool_sweep_pairs_per_s': {str(p): len(u) / t for p, t in sweep.items()},
+                         'sample': 'the same hoisted pass with the BLAS pool that serves it best, {} threads of {} usable ({} reps of {:.3f} s); '
+                                   'scipy\'s CSR product stays single-threaded'.format(threads, cores, areps, adt)},
+           'max_abs_score_diff_vs_gpu': err}
+    if headline is not None:
+        from scipy import sparse
+        hg, hh, hu, hi_ = headline['gnn'], headline['head'], headline['u'], headline['i']
+        rowptr, colidx, vals = headline['a_hat']
+        ah = sparse.csr_matrix((vals, colidx, rowptr), shape=(len(rowptr) - 1, len(rowptr) - 1))
+        e1 = propagate(ah, hg)                                      # (untimed: warms the pages; also the sweep's input)
+        hsweep = {}
+        for pool in sorted({p for p in (8, 32, 64, 128) if p <= cores}):      # a 1 Mi-pair batch has work for a larger pool than ml1m(s=1)
+            with threadpool_limits(limits=pool):
+                t0 = time.perf_counter()
+                om.basic_rs(e1[hu[:1 << 20]], e1[hi_[:1 << 20]], hh)
+                hsweep[pool] = time.perf_counter() - t0
+        threads = min(hsweep, key=hsweep.get) if hsweep else 1
+        del e1
+        with threadpool_limits(limits=threads):
+            t0 = time.perf_counter()
+            e = propagate(ah, hg)
+            t_prop = time.perf_counter() - t0
+            worst = 0.0
+            for lo in range(0, len(hu), 1 << 20):                   # pair batches bound the host memory, not the arithmetic
+                sc = om.basic_rs(e[hu[lo:lo + (1 << 20)]], e[hi_[lo:lo + (1 << 20)]], hh)
+                worst = max(worst, float(np.abs(sc.reshape(-1) - headline['gpu_scores'][lo:lo + (1 << 20)].reshape(-1)).max()))
+            hdt = time.perf_counter() - t0
+        out['headline_workload'] = {'value': len(hu) / hdt, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
+                                    'sample': 'ONE hoisted repetition on the headline workload itself ({}): propagation {:.2f} s (scipy CSR product, one thread), '
+                                              'all {} pairs in 1 Mi-pair batches on a BLAS pool of {} threads, {:.2f} s in all; A_hat is the '
+                                              'device-built matrix copied to the host (bit-identical to the oracle\'s gcn_filter: '
+                                              'tests/test_models_gpu.py::test_device_gcn_filter_matches_host)'.format(
+                                                  headline['workload'], t_prop, len(hu), threads, hdt),
+                                    'max_abs_score_diff_vs_gpu': worst}
+    return out
 
 
 def ml1m_true_size(dev):
@@ -325,11 +386,75 @@ def train_true_size():
             'reference_published': '211 s per 25 epochs on an RTX 3060 (doc.pdf p.22 Table 5; other hardware)'}
 
 
+def leaf_spmm_timers(capi, events, kinds_seen=None):
+    """HIP-event wrappers around the LEAF propagation entry points (capi.spmm_xs forwards an LDS-tiled image to capi.spmm_lt: only
+    the leaf records, so a launch is timed once).  Returns the function that restores the originals."""
+    names = ('gcn_layer', 'spmm_sj', 'spmm_xs', 'spmm_lt')
+    raw = {name: getattr(capi, name) for name in names}
+
+    def timed(name, fn):
+        def wrapper(*a, **k):
+            if name == 'spmm_xs' and hasattr(a[0], 'words'):      # forwarded to spmm_lt, which records
+                return fn(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(*a, **k)
+            e1.record()
+            events.append((e0, e1))
+            if kinds_seen is not None:
+                kinds_seen.append(name)
+        return wrapper
+    for name in names:
+        setattr(capi, name, timed(name, raw[name]))
+
+    def restore():
+        for name in names:
+            setattr(capi, name, raw[name])
+    return restore
+
+
+def timed_model(model, u, i, steps, n, nnz, f):
+    """Hoisted step of a Basic* model replayed from a hipGraph + the HIP-event time of its fused propagation layers over a few
+    eager steps, against the 8(d) bytes of an [n, n] graph with nnz non-zeros at width f."""
+    from deep_cbrs_amar_renaissance_amd import capi, parallel
+    runner = parallel.SingleRunner(model, u, i)
+    events = []
+    for _ in range(10):
+        runner.step()
+    restore = leaf_spmm_timers(capi, events)
+    for _ in range(5):
+        runner.step()
+    torch.cuda.synchronize()
+    restore()
+    layer_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events])) if events else float('nan')
+    prop_ms = runner.last_propagation_ms()
+    for _ in range(40):                                           # untimed replays until the clocks have settled, as in main()
+        runner.step_graphed()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        runner.step_graphed()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    alg = nnz * 8 + (n + 1) * 4 + 2 * n * f * 4
+    p = int(u.numel())
+    return {'ms_per_step': 1e3 * dt, 'pairs_per_s': p / dt, 'propagation_ms': prop_ms,
+            'gcn_layer': {'avg_launch_ms': layer_ms, 'launches_timed': len(events), 'algorithmic_bytes_per_launch': alg,
+                          'achieved_gbps': alg / (layer_ms * 1e-3) / 1e9, 'frac_of_hbm_peak': alg / (layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
+
+
+def shuffled_test_pairs(data, dev, seed=42):
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(seed)
+    perm = torch.randperm(data['test'].shape[0], device=dev, generator=gen)
+    return data['test'][perm, 0].to(torch.int32).contiguous(), data['test'][perm, 1].to(torch.int32).contiguous()
+
+
 def uip_graph(dev, scale, steps):
     """configs[2] / the graph of configs[4]: econfigs/basic-gnn-uip-2relconf.yaml grid1 — the same BasicGCN over the
     user-item-PROPERTY graph (three node types, duplicate item-property links kept, preprocess.py:149-168) at the same
     ml1m(s): hoisted step and the fused GCN layer's HIP-event time against the 8(d) bytes of that graph."""
-    from deep_cbrs_amar_renaissance_amd import capi, engine, parallel
+    from deep_cbrs_amar_renaissance_amd import engine
     from deep_cbrs_amar_renaissance_amd.data import synthetic
     from deep_cbrs_amar_renaissance_amd.models import basic
     from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter_device
@@ -342,54 +467,102 @@ def uip_graph(dev, scale, steps):
     engine.set_seed(42)
     model = basic.BasicGCN(a, **GRID1)
     model.n_users, model.n_items = nu, ni
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(42)
-    perm = torch.randperm(data['test'].shape[0], device=dev, generator=gen)
-    u = data['test'][perm, 0].to(torch.int32).contiguous()
-    i = data['test'][perm, 1].to(torch.int32).contiguous()
-    p = int(u.numel())
-    del data, perm, rows, cols
-    runner = parallel.SingleRunner(model, u, i)
-    events, names, raw = [], ('gcn_layer', 'spmm_xs', 'spmm_lt'), {}
-
-    def timed(fn):
-        def wrapper(*args, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            fn(*args, **kw)
-            e1.record()
-            events.append((e0, e1))
-        return wrapper
-    for _ in range(10):
-        runner.step()
-    for name in names:
-        raw[name] = getattr(capi, name)
-        setattr(capi, name, timed(raw[name]))
-    for _ in range(5):
-        runner.step()
-    torch.cuda.synchronize()
-    for name in names:
-        setattr(capi, name, raw[name])
-    layer_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events])) if events else float('nan')
-    prop_ms = runner.last_propagation_ms()
-    for _ in range(40):                                           # untimed replays until the clocks have settled, as in main()
-        runner.step_graphed()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        runner.step_graphed()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
-    f = GRID1['n_hiddens'][0]
-    alg = a.nnz * 8 + (n + 1) * 4 + 2 * n * f * 4
+    u, i = shuffled_test_pairs(data, dev)
+    del data, rows, cols
     out = {'config': 'econfigs/basic-gnn-uip-2relconf.yaml grid1: BasicGCN d=8 L=2 on the user-item-property graph, ml1m(s={}): '
-                     'N={} nodes ({} users, {} items, {} properties), nnz(A_hat)={}, {} test pairs'.format(scale, n, nu, ni, npr, a.nnz, p),
-           'ms_per_step': 1e3 * dt, 'pairs_per_s': p / dt, 'propagation_ms': prop_ms,
-           'gcn_layer': {'avg_launch_ms': layer_ms, 'algorithmic_bytes_per_launch': alg,
-                         'achieved_gbps': alg / (layer_ms * 1e-3) / 1e9, 'frac_of_hbm_peak': alg / (layer_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
-    del runner, model, a
+                     'N={} nodes ({} users, {} items, {} properties), nnz(A_hat)={}, {} test pairs'.format(scale, n, nu, ni, npr, a.nnz, int(u.numel()))}
+    out.update(timed_model(model, u, i, steps, n, a.nnz, GRID1['n_hiddens'][0]))
+    del model, a
     torch.cuda.empty_cache()
     return out
+
+
+def wider_layers(dev, scale, steps):
+    """econfigs/basic-gnn.yaml grid2 (d = 16) and grid3 (d = 32) — /root/reference/econfigs/basic-gnn.yaml:13-33 — at the same
+    ml1m(s): the same BasicGCN, two fused layers of width 16 / 32, against the 8(d) bytes at that width."""
+    from deep_cbrs_amar_renaissance_amd import engine
+    from deep_cbrs_amar_renaissance_amd.data import synthetic
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter_device
+    data = synthetic.ml1m_device(scale, device=dev)
+    n = data['n_users'] + data['n_items']
+    a = gcn_filter_device(data['train_pos'][:, 0], data['train_pos'][:, 1], n)
+    u, i = shuffled_test_pairs(data, dev)
+    nu, ni = data['n_users'], data['n_items']
+    del data
+    out = {}
+    for name, cfg in (('grid2_F16', GRID2), ('grid3_F32', GRID3)):
+        engine.set_seed(42)
+        model = basic.BasicGCN(a, **cfg)
+        model.n_users, model.n_items = nu, ni
+        f = cfg['n_hiddens'][0]
+        res = {'config': 'econfigs/basic-gnn.yaml {}: BasicGCN d={} L=2 concat, dense {}, clf {}, ml1m(s={})'.format(
+            name.split('_')[0], f, cfg['dense_units'], cfg['clf_units'], scale)}
+        res.update(timed_model(model, u, i, steps, n, a.nnz, f))
+        out[name] = res
+        del model
+        a.__dict__.pop('_lt_cache', None)                          # one width's image at a time
+        torch.cuda.empty_cache()
+    return out
+
+
+def value_spread(scale):
+    """min / max ms per step of the default run over the boxes of the build session (profiles/r3_bench_repeats.json, written by
+    tools/bench_repeats.py from back-to-back bench.py runs on different gpurun boxes), with the csrc/ hash it was measured at."""
+    path = os.path.join(ROOT, 'profiles', 'r3_bench_repeats.json')
+    if not os.path.exists(path):
+        return None
+    rep = json.load(open(path))
+    if rep.get('scale') != scale:
+        return None
+    rep['stale'] = rep.get('csrc_sha') != csrc_sha()
+    return rep
+
+
+def onchip_floor(capi, a_hat, f, nnz, fused_ms, pmc):
+    """The dispatched LDS-tiled kernel against ITS OWN on-chip floors (the HBM roofline stays in `roofline`): (1) the L2 line
+    requests it issues per launch — this build's TCC_REQ counter, profiles/spmm_pmc_latest.json — at the rate a CU front end
+    sustains (profiles/r1_exp_gather_frontend.txt); (2) the same launch with the gathers compiled out (index walk + one LDS
+    read-add-write per non-zero: AMAR_LT_VARIANT=24, wrong sums, timing only), measured here on the same image."""
+    lt = a_hat.tiled_image(f)
+    n = a_hat.shape[0]
+    x = torch.randn((n, f), device=a_hat.rowptr.device)
+    y = torch.empty_like(x)
+
+    def ms(reps=10):
+        for _ in range(3):
+            capi.spmm_lt(lt, x, y, prescaled=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            capi.spmm_lt(lt, x, y, prescaled=True)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+    plain_ms = ms()
+    ablation = {}
+    for name, variant in (('paced', '24'), ('unpaced', '35')):     # 24: gathers compiled out, the shipped barrier pacing; 35: no pacing either
+        os.environ['AMAR_LT_VARIANT'] = variant
+        try:
+            ablation[name] = ms()
+        finally:
+            os.environ.pop('AMAR_LT_VARIANT', None)
+    no_gather_ms = min(ablation.values())
+    req = (pmc or {}).get('TCC', {}).get('REQ') if pmc else None
+    floor_ms = 1e3 * req / L2_REQUESTS_PER_S if req else None
+    return {'kernel': 'spmm_lt_kernel<8>', 'plain_launch_ms': plain_ms, 'fused_launch_ms': fused_ms,
+            'l2_requests_per_launch': req, 'l2_requests_per_nonzero': req / nnz if req else None,
+            'l2_requests_per_s_sustained': L2_REQUESTS_PER_S, 'request_floor_ms': floor_ms,
+            'frac_of_request_floor': floor_ms / plain_ms if floor_ms else None,
+            'no_gather_ms': no_gather_ms, 'no_gather_paced_ms': ablation['paced'], 'no_gather_unpaced_ms': ablation['unpaced'],
+            'frac_of_no_gather_floor': no_gather_ms / plain_ms,
+            'structural_ceiling_frac_of_hbm_peak': (nnz * 8 + (n + 1) * 4 + 2 * n * f * 4) / (no_gather_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            'ceiling_note': 'with every gather compiled out (AMAR_LT_VARIANT 24 / 35: wrong sums, timing only) the walk — index stream, one '
+                            'LDS read-add-write per non-zero, with and without the window barriers — still takes no_gather_ms (the faster of '
+                            'the two): that caps this kernel STRUCTURE at structural_ceiling_frac_of_hbm_peak of the HBM roofline on the 8(d) '
+                            'bytes at F = 8, fp32, whatever the gathers cost (DESIGN.md 4a); the request floor counts this build\'s own L2 '
+                            'requests (about 0.5 per non-zero: neighbouring entries of the column-ordered walk share L1 lines), not one per '
+                            'non-zero as round 1\'s XS model did'}
 
 
 def main():
@@ -456,27 +629,13 @@ def main():
     runner = parallel.make_runner(model, u_all, i_all, rank, world, dist=parallel.SharedDeviceCollectives(rank, world) if rehearse else None) \
         if not force_dist else parallel.PartitionedGCNRunner(model, u_all, i_all, rank, world)
 
-    spmm_events = []
-    spmm_names = ('gcn_layer', 'spmm_sj', 'spmm_xs', 'spmm_lt')
-    raw_spmm = {name: getattr(capi, name) for name in spmm_names}
-    kinds_seen = []
-
-    def timed(name, fn):
-        def wrapper(*a, **k):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            fn(*a, **k)
-            e1.record()
-            spmm_events.append((e0, e1))
-            kinds_seen.append(name)
-        return wrapper
+    spmm_events, kinds_seen = [], []
     # The timed steps replay the whole step — on several ranks its collectives too — from a hipGraph the runner captures itself
     # (AMAR_STEP_GRAPH=0: the eager steps are the timed ones).  No per-launch event can be recorded inside a capture, so the
     # kernel-level objects below (roofline, pair_stage) are timed over K EAGER steps run just before, whose own rate is reported
     # as `eager`; the kernels and their durations are the same in both.
     graph_step = hasattr(runner, 'step_graphed') and os.environ.get('AMAR_STEP_GRAPH', '1') != '0' and not rehearse
-    for name in spmm_names:                                   # whichever form the layer dispatches to
-        setattr(capi, name, timed(name, raw_spmm[name]))
+    restore_spmm = leaf_spmm_timers(capi, spmm_events, kinds_seen)       # whichever form the layer dispatches to, timed once
     pair_events, raw_chain = [], capi.chain
 
     def timed_chain(*a, **k):                                  # the pair stage = the sum-input chain launch
@@ -488,9 +647,11 @@ def main():
         e1.record()
         pair_events.append((e0, e1))
     capi.chain = timed_chain
+    multi = world > 1 or force_dist
+    cdev = 'cpu' if rehearse else dev                          # gloo reduces host tensors
 
     def barrier():
-        if world > 1 or force_dist:
+        if multi:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -506,21 +667,32 @@ def main():
     eager_host_dt = time.perf_counter() - t0
     barrier()
     eager_dt = time.perf_counter() - t0
-    for name in spmm_names:
-        setattr(capi, name, raw_spmm[name])
+    restore_spmm()
     capi.chain = raw_chain
+    phases = runner.phase_times() if hasattr(runner, 'phase_times') else None      # the last eager step, by phase (typed partition)
     step = runner.step
     if graph_step:
+        # Capture first, replay only once EVERY rank has a graph: a replay enqueues the step's collectives, which a rank whose
+        # capture failed would never match (the others would hang in their next synchronisation).  All ranks switch to eager steps
+        # together if any capture failed.
+        ok = 1
         try:
-            # capture on the first call, then untimed replays until the clocks have settled: the eager steps before leave gaps
-            # between kernels, and the first few dozen replays of the graph run below the sustained rate (10 timed steps right
-            # after the capture: 1.26 ms per step; 100: 1.19 ms — profiles/r2_bench_repeats.txt)
+            runner.capture_step()
+        except Exception as exc:                              # a capture the runtime refuses: the eager steps stand
+            sys.stderr.write("bench.py: rank {}: hipGraph capture of the step failed ({}); timing eager steps\n".format(rank, exc))
+            ok = 0
+        if multi:
+            flag = torch.tensor([ok], device=cdev, dtype=torch.int32)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            ok = int(flag.item())
+        graph_step = bool(ok)
+        if graph_step:
+            # untimed replays until the clocks have settled: the eager steps before leave gaps between kernels, and the first few
+            # dozen replays of the graph run below the sustained rate (10 timed steps right after the capture: 1.26 ms per step;
+            # 100: 1.19 ms — profiles/r2_bench_repeats.txt)
             for _ in range(max(args.warmup, 40)):
                 runner.step_graphed()
             step = runner.step_graphed
-        except Exception as exc:                              # a capture the runtime refuses: the eager steps stand
-            sys.stderr.write("bench.py: hipGraph capture of the step failed ({}); timing eager steps\n".format(exc))
-            graph_step = False
         barrier()
     t0 = time.perf_counter()
     if graph_step:
@@ -531,10 +703,14 @@ def main():
         dt = time.perf_counter() - t0
     else:
         host_dt, dt = eager_host_dt, eager_dt
-    if world > 1 or force_dist:
-        t = torch.tensor([dt, eager_dt], device='cpu' if rehearse else dev, dtype=torch.float64)
+    per_rank = None
+    if multi:
+        t = torch.tensor([dt, eager_dt], device=cdev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt, eager_dt = float(t[0].item()), float(t[1].item())
+        mine = dict(phases or {}, rank=rank, rows=int(runner.local_rows), nnz=int(runner.local_nnz), pairs=int(runner.u_ids.numel()))
+        per_rank = [None] * world
+        torch.distributed.all_gather_object(per_rank, mine)
 
     spmm_ms = [e0.elapsed_time(e1) for e0, e1 in spmm_events]
     rows_local = runner.local_rows
@@ -544,7 +720,7 @@ def main():
     alg_bytes = nnz_local * 8 + (rows_local + 1) * 4 + (n_nodes + rows_local) * f * 4
     avg_ms = float(np.mean(spmm_ms)) if spmm_ms else float('nan')
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
-    pmc, traffic_source = (pmc_profile(args.scale, kind) if world == 1 and not force_dist else (None, 'not profiled for multi-rank runs'))
+    pmc, traffic_source = (pmc_profile(args.scale, kind) if not multi else (None, 'not profiled for multi-rank runs'))
     kernel_names = {'sj': 'spmm_sj_kernel<8>', 'xs': 'spmm_xs_partial_kernel<8> + spmm_xs_combine_kernel<8>', 'csr': 'spmm_stream_kernel<8>',
                     'lt': 'spmm_lt_kernel<8> (LDS-tiled, one launch)', 'none': 'none'}
 
@@ -569,18 +745,23 @@ def main():
                          'launches_timed': len(spmm_ms), 'timed_in': 'the K eager steps just before the replayed ones' if graph_step else 'timed region',
                          'note': 'achieved = SURVEY 8(d) bytes (canonical CSR: 8 B per non-zero) / time, i.e. a CSR-equivalent effective '
                                  'bandwidth; the dispatched image streams {} B per non-zero'.format(image_entry_bytes)},
-            # the limit that bound the XS form: one 128-B L2 line request per gathered row at 0.44 requests / clock / CU
-            'roofline_l2': {'bound': 'l2_line_requests (one per gathered row, XS form)', 'requests_per_s': L2_REQUESTS_PER_S,
-                            'floor_ms': 1e3 * nnz_local / L2_REQUESTS_PER_S,
-                            'frac': (1e3 * nnz_local / L2_REQUESTS_PER_S) / avg_ms,
-                            'note': 'frac > 1 means the dispatched kernel issues fewer than one L2 request per non-zero '
-                                    '(the LDS-tiled form gathers in column order: neighbouring entries share L1 lines)'},
             'propagation_ms': runner.last_propagation_ms(),
             'host_enqueue_ms_per_step': 1e3 * host_dt / args.steps,
             'eager': {'ms_per_step': 1e3 * eager_dt / args.steps, 'value': n_pairs * args.steps / eager_dt, 'unit': 'pairs/s',
                       'host_enqueue_ms_per_step': 1e3 * eager_host_dt / args.steps,
                       'note': 'the same K steps launched one kernel at a time, each SpMM / pair-stage launch bracketed by HIP events'},
         }
+        spread = value_spread(args.scale)
+        if spread is not None and not multi:
+            out['value_spread_boxes'] = spread
+        if per_rank is not None:
+            out['per_rank'] = {'ranks': per_rank,
+                               'note': 'one EAGER step by phase on every rank, HIP events on the compute stream: local_spmm_ms and pair_stage_ms '
+                                       'shrink with the rank count, replicated_ms (X_0 . W_1 over all rows + the item tower) does not, exchange_ms is '
+                                       'the time the compute stream spent issuing and waiting for all-gathers (the item-row gathers overlap the next '
+                                       'SpMM / the user tower)'}
+        if kind == 'lt' and not multi:
+            out['roofline_onchip'] = onchip_floor(capi, a_hat, f, nnz_local, avg_ms, pmc)
         pair_ms = [e0.elapsed_time(e1) for e0, e1 in pair_events]
         if pair_ms:
             # the other large kernel of a step: the sum-input chain kernel gathers two 48-float per-entity rows per pair
@@ -610,13 +791,20 @@ def main():
                                           'frac': pairs_local * flop_pair / (pms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                                           'pmc_busy_frac': pmc.get('pair_stage_mfma_busy_frac') if pmc else None}}
         if world == 1 and not args.no_cpu_baseline:
+            # the headline workload's own inputs for the CPU leg (host copies), before the GPU objects go
+            from tests import helpers
+            headline = {'a_hat': (a_hat.rowptr.cpu().numpy(), a_hat.colidx.cpu().numpy(), a_hat.vals.cpu().numpy()),
+                        'gnn': helpers.gnn_to_oracle(model.gnn), 'head': helpers.basic_head_to_oracle(model.rs),
+                        'u': u_all.cpu().numpy().astype(np.int64), 'i': i_all.cpu().numpy().astype(np.int64),
+                        'gpu_scores': runner.step().cpu().numpy(), 'workload': 'ml1m(s={})'.format(args.scale)}
             del runner, model, a_hat, u_all, i_all
             torch.cuda.empty_cache()
+            out['wider_layers'] = wider_layers(dev, args.scale, args.steps)
             out['hybrid_head'] = hybrid_head(dev, args.scale)
             out['uip_graph'] = uip_graph(dev, args.scale, args.steps)
             out['ml1m_s1'], s1 = ml1m_true_size(dev)
             out['train_s1'] = train_true_size()
-            out['cpu_baseline'] = cpu_baseline(s1)
+            out['cpu_baseline'] = cpu_baseline(s1, headline)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'libamar_hip.so')
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 ACT_CODES = {None: ACT_NONE, 'linear': ACT_NONE, 'relu': ACT_RELU, 'sigmoid': ACT_SIGMOID}
-SPMM_BIAS, SPMM_RELU, SPMM_ACCUM, SPMM_ACCUM_DIV, SPMM_SCALE_NEXT, SPMM_SAGE_TAIL = 1, 2, 4, 8, 16, 32
+SPMM_BIAS, SPMM_RELU, SPMM_ACCUM, SPMM_ACCUM_DIV, SPMM_SCALE_NEXT, SPMM_SAGE_TAIL, SPMM_LT_NOPAIRS, SPMM_LT_TWO_QUADS = 1, 2, 4, 8, 16, 32, 64, 128
 
 _P = ctypes.c_void_p
 _I32, _I64, _U32, _F32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_float
@@ -40,6 +40,7 @@ SIGNATURES = {
     'amar_gat_xs_f32': (ctypes.c_int, [_P, _P, _I32, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P]),
     'amar_gcn_layer_f32': (ctypes.c_int, [_P, _P, _P, _P, _I64, _I32, _P, _P, _I64, _P, _I32, _P, _I64, _I32, _P]),
     'amar_rowwise_xw_f32': (ctypes.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _P, _I64, _P, _P, _P, _P, _P, _I32, _P]),
+    'amar_rowwise_xw_gather_f32': (ctypes.c_int, [_P, _I64, _I32, _P, _P, _I32, _P, _I64, _P, _I32, _P]),
     'amar_sage_layer_f32': (ctypes.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _I32, _P, _I64, _I32, _I32, _P]),
     'amar_sage_tail_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I32, _P, _P, _I32, _P, _I64, _I64, _P]),
     'amar_gat_layer_f32': (ctypes.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _P, _I64, _I32, _I32, _P]),
@@ -48,6 +49,7 @@ SIGNATURES = {
     'amar_chain_pack_f32': (ctypes.c_int, [_P, _P, _P, _I32, _P]),
     'amar_chain_f32': (ctypes.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _I32, _P, _I32, _I32, _I32, _P, _P, _P, _I32, _P, _I64, _I64, _P]),
     'amar_chain_indexed_f32': (ctypes.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _I32, _P, _I32, _I32, _I32, _P, _P, _P, _I32, _P, _I64, _P, _I64, _P]),
+    'amar_chain_segments_f32': (ctypes.c_int, [_P, _P, _P, _I32, _P, _I32, _P, _P, _P, _I32, _P, _I64, _I64, _P]),
     'amar_dual_chain_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _I32, _P, _P, _I64, _I64, _P]),
     'amar_copy_columns_f32': (ctypes.c_int, [_P, _I64, _P, _I32, _P, _I64, _I64, _I32, _P]),
     'amar_reduce_layers_f32': (ctypes.c_int, [_P, _I64, _I32, _I32, _P, _I64, _I64, _I32, _P]),
@@ -303,6 +305,12 @@ def spmm_lt(lt, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc
         X = Xs
     if scale_next:
         flags |= SPMM_SCALE_NEXT
+    if not getattr(lt, 'pairs', True):
+        flags |= SPMM_LT_NOPAIRS
+    if getattr(lt, 'quads', 1) == 2:
+        if sage_tail is not None:
+            raise ValueError("spmm_lt: the GraphSAGE tail runs on one-quad images")
+        flags |= SPMM_LT_TWO_QUADS
     off = lt.diag_offset
     code = load().amar_spmm_lt_f32(
         _ptr(lt.words, torch.int32, 'words'), _ptr(lt.stream_start, torch.int32, 'stream_start'),
@@ -338,7 +346,22 @@ def gcn_layer(rowptr, colidx, vals, H, bias, Y, Wnext=None, Hnext=None):
     _check(code, 'amar_gcn_layer_f32')
 
 
-def rowwise_xw(X, W, H, copy_to=None, a_self=None, a_neigh=None, s_self=None, s_neigh=None, row_scale=None):
+def rowwise_xw(X, W, H, copy_to=None, a_self=None, a_neigh=None, s_self=None, s_neigh=None, row_scale=None, row_ids=None):
+    """H = X . W row by row (+ the X_0 slice copy, GAT's attention scalars, a row scale).  row_ids (int32 [rows of H]): output row p
+    reads X[row_ids[p]] and a negative id leaves a zero row (amar_rowwise_xw_gather_f32: the block layout of a node-range partition)."""
+    if row_ids is not None:
+        n_out, F = int(row_ids.numel()), X.shape[1]
+        if copy_to is not None or a_self is not None or s_self is not None:
+            raise ValueError("rowwise_xw: the row-gather form computes H only")
+        if W.shape[0] != F or not W.is_contiguous() or tuple(H.shape) != (n_out, W.shape[1]) or not row_ids.is_contiguous():
+            raise ValueError("rowwise_xw: W [F, C] contiguous, row_ids contiguous and H [len(row_ids), C] expected")
+        if row_scale is not None and (row_scale.numel() != n_out or not row_scale.is_contiguous()):
+            raise ValueError("rowwise_xw: row_scale must be a contiguous [len(row_ids)] vector")
+        code = load().amar_rowwise_xw_gather_f32(
+            _ptr(X, torch.float32, 'X'), _ld(X, 'X'), F, _ptr(row_ids, torch.int32, 'row_ids'), _ptr(W, torch.float32, 'W'), W.shape[1],
+            _ptr(H, torch.float32, 'H'), _ld(H, 'H'), _ptr(row_scale, torch.float32, 'row_scale'), n_out, _stream())
+        _check(code, 'amar_rowwise_xw_gather_f32')
+        return
     n_rows, F = X.shape
     if W.shape[0] != F or not W.is_contiguous() or tuple(H.shape) != (n_rows, W.shape[1]):
         raise ValueError("rowwise_xw: W [F, C] contiguous and H [n_rows, C] expected")
@@ -503,10 +526,67 @@ def chain_pack(kernels, biases):
     return out, dims
 
 
+class ConcatTable:
+    """The column-wise concatenation of several [rows, w_j] device tables with the same row numbering, NOT materialised: what
+    ReductionLayer('concatenation') hands to the towers when every layer's output stays where its producer (or the all-gather of a
+    node-range partition) left it.  `chain` reads it in place (amar_chain_segments_f32) where the stack has a compile-time tower
+    shape and assembles it once otherwise (`materialize`)."""
+
+    def __init__(self, tables):
+        tables = list(tables)
+        rows = int(tables[0].shape[0])
+        if not tables or any(t.dim() != 2 or int(t.shape[0]) != rows or t.shape[1] % 4 or t.dtype != torch.float32 for t in tables):
+            raise ValueError("ConcatTable: float32 [rows, w] tables with equal row counts and widths that are multiples of 4 expected")
+        self.segments = tables
+        self.shape = (rows, sum(int(t.shape[1]) for t in tables))
+        self.device, self.dtype = tables[0].device, torch.float32
+
+    def __getitem__(self, key):
+        if not isinstance(key, slice) or key.step not in (None, 1):
+            raise TypeError("ConcatTable supports contiguous row slices only")
+        return ConcatTable([t[key] for t in self.segments])
+
+    def materialize(self):
+        out = torch.empty(self.shape, dtype=torch.float32, device=self.device)
+        off = 0
+        for t in self.segments:
+            copy_columns(t, out[:, off:off + t.shape[1]])
+            off += t.shape[1]
+        return out
+
+
+def chain_segments(table, wpack, dims, acts, out, ids=None, base=0):
+    """`chain` on a ConcatTable read in place; returns False when the stack's shape has no segment-reading kernel."""
+    P = out.shape[0]
+    segs = table.segments
+    if ids is not None and ids.numel() != P:
+        raise ValueError("chain: ids must have one id per output row")
+    if ids is None and table.shape[0] < P:
+        raise ValueError("chain: input blocks have fewer rows than the output")
+    n = len(segs)
+    ptrs = (ctypes.c_void_p * n)(*[_ptr(t, torch.float32, 'segment') for t in segs])
+    lds = (ctypes.c_int64 * n)(*[_ld(t, 'segment') for t in segs])
+    ws = (ctypes.c_int32 * n)(*[int(t.shape[1]) for t in segs])
+    dims_c = (ctypes.c_int32 * len(dims))(*dims)
+    acts_c = (ctypes.c_int32 * len(acts))(*[ACT_CODES[a] for a in acts])
+    code = load().amar_chain_segments_f32(ptrs, lds, ws, n, _ptr(ids, torch.int32, 'ids'), int(base),
+                                          _ptr(wpack, torch.float32, 'wpack'), dims_c, acts_c, len(acts),
+                                          _ptr(out, torch.float32, 'out'), _ld(out, 'out'), P, _stream())
+    if code == -2:                                                   # AMAR_EUNSUPPORTED: no compile-time tower shape for this stack
+        return False
+    _check(code, 'amar_chain_segments_f32')
+    return True
+
+
 def chain(A, wpack, dims, acts, out, ids_a=None, base_a=0, B=None, ids_b=None, base_b=0, sum_inputs=False, in_act=None, out_index=None):
     """out = DenseStack([A[ids_a - base_a] || B[ids_b - base_b]]), or DenseStack(in_act(A[..] + B[..])) with
     sum_inputs; see amar_chain_f32 in include/amar_hip.h.  out_index (int32 [P]): row p goes to out[out_index[p]]
-    (amar_chain_indexed_f32: a pair list kept in XCD-affine order, scores back in the caller's order)."""
+    (amar_chain_indexed_f32: a pair list kept in XCD-affine order, scores back in the caller's order).
+    A may be a ConcatTable (per-layer tables read in place: amar_chain_segments_f32)."""
+    if isinstance(A, ConcatTable):
+        if B is None and not sum_inputs and out_index is None and chain_segments(A, wpack, dims, acts, out, ids=ids_a, base=base_a):
+            return
+        A = A.materialize()
     P = out.shape[0]
     Da, Db = A.shape[1], (B.shape[1] if B is not None else 0)
     for ids, nm in ((ids_a, 'ids_a'), (ids_b, 'ids_b')):

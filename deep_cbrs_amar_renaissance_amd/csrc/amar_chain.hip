@@ -27,9 +27,14 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CHAIN_MAX_LAYERS = 8;
+constexpr int CHAIN_MAX_SEG = 8;
 
 struct ChainArgs {
     const float *A; int64_t lda; int Da; const int32_t *ids_a; int base_a;
+    // n_seg > 0 (chain_rows_kernel<.., SEG = true> only): row p of the A input is [seg[0][p] || seg[1][p] || ...], the concatenation of
+    // n_seg tables with the same row numbering — a 'concatenation' reduction (reduction.py:15-17) read in place from the per-layer
+    // tables, never materialised.  seg_off[s] = first feature of table s (multiples of 4), seg_off[n_seg] = Da.
+    int n_seg; const float *seg[CHAIN_MAX_SEG]; int64_t seg_ld[CHAIN_MAX_SEG]; int seg_off[CHAIN_MAX_SEG + 1];
     const float *B; int64_t ldb; int Db; const int32_t *ids_b; int base_b;
     const float *wpack; int wpack_floats;
     int sum_inputs, in_act;             // x = in_act(A[ida] + B[idb]) instead of [A[ida] || B[idb]]
@@ -206,7 +211,7 @@ constexpr int shape_maxt(int s) {
     return m;
 }
 
-template <int SHAPE, int PT, bool LASTLIN>
+template <int SHAPE, int PT, bool LASTLIN, bool SEG>
 __global__ __launch_bounds__(256) void chain_rows_kernel(const ChainArgs a) {
     constexpr int NL = shape_nl(SHAPE), T0 = shape_t(SHAPE, 0), TN = shape_t(SHAPE, NL), MAXT = shape_maxt(SHAPE);
     extern __shared__ __attribute__((aligned(16))) float w_lds[];
@@ -223,6 +228,20 @@ __global__ __launch_bounds__(256) void chain_rows_kernel(const ChainArgs a) {
     const bool tail_ok = f_last < a.Da;
     const char *Ag = reinterpret_cast<const char *>(a.A) + 16 * g;
     const int tail_off = tail_ok ? 64 * (T0 - 1) : -16 * g;        // (a lane past Da in the last tile re-reads the row's first features)
+    // SEG: this lane's float4 of input tile t (features 16t + 4g .. +3) lies in ONE of the concatenated tables (their widths are
+    // multiples of 4): its column-0 address and row bytes, fixed for the launch (a lane past Da takes table 0's first features)
+    const char *seg_base[SEG ? T0 : 1];
+    uint32_t seg_ldb[SEG ? T0 : 1];
+    if constexpr (SEG) {
+#pragma unroll
+        for (int t = 0; t < T0; ++t) {
+            const int f = 16 * t + 4 * g;
+            int sidx = 0;
+            for (int j = 1; j < a.n_seg; ++j) sidx = (f < a.Da && f >= a.seg_off[j]) ? j : sidx;
+            seg_base[t] = reinterpret_cast<const char *>(a.seg[sidx] + (f < a.Da ? f - a.seg_off[sidx] : 0));
+            seg_ldb[t] = (uint32_t)a.seg_ld[sidx] * 4u;
+        }
+    }
 
     f32x4 xin[MAXT][PT];
     auto gather = [&](uint32_t b) {
@@ -232,8 +251,10 @@ __global__ __launch_bounds__(256) void chain_rows_kernel(const ChainArgs a) {
             const uint32_t row = a.ids_a ? (uint32_t)(a.ids_a[p] - a.base_a) : p;
             const char *pa = Ag + (uint64_t)row * lda;
 #pragma unroll
-            for (int t = 0; t < T0; ++t)
-                xin[t][pt] = *reinterpret_cast<const f32x4 *>(pa + (t == T0 - 1 ? tail_off : 64 * t));
+            for (int t = 0; t < T0; ++t) {
+                if constexpr (SEG) xin[t][pt] = *reinterpret_cast<const f32x4 *>(seg_base[t] + (uint64_t)row * seg_ldb[t]);
+                else xin[t][pt] = *reinterpret_cast<const f32x4 *>(pa + (t == T0 - 1 ? tail_off : 64 * t));
+            }
         }
     };
 
@@ -771,15 +792,49 @@ int amar_chain_f32(const float *A, int64_t lda, int32_t Da, const int32_t *ids_a
                                   out, ldo, nullptr, P, stream);
 }
 
+static int chain_run(const float *A, int64_t lda, int32_t Da, const int32_t *ids_a, int32_t base_a,
+                     const float *B, int64_t ldb, int32_t Db, const int32_t *ids_b, int32_t base_b,
+                     int32_t sum_inputs, int32_t in_act,
+                     const float *wpack, const int32_t *dims, const int32_t *acts, int32_t n_layers,
+                     float *out, int64_t ldo, const int32_t *out_index, int64_t P, amar_stream_t stream,
+                     int32_t n_seg, const float *const *seg, const int64_t *seg_ld, const int32_t *seg_width);
+
 int amar_chain_indexed_f32(const float *A, int64_t lda, int32_t Da, const int32_t *ids_a, int32_t base_a,
                            const float *B, int64_t ldb, int32_t Db, const int32_t *ids_b, int32_t base_b,
                            int32_t sum_inputs, int32_t in_act,
                            const float *wpack, const int32_t *dims, const int32_t *acts, int32_t n_layers,
                            float *out, int64_t ldo, const int32_t *out_index, int64_t P, amar_stream_t stream) {
+    return chain_run(A, lda, Da, ids_a, base_a, B, ldb, Db, ids_b, base_b, sum_inputs, in_act, wpack, dims, acts, n_layers, out, ldo, out_index, P,
+                     stream, 0, nullptr, nullptr, nullptr);
+}
+
+int amar_chain_segments_f32(const float *const *seg, const int64_t *seg_ld, const int32_t *seg_width, int32_t n_seg,
+                            const int32_t *ids, int32_t base,
+                            const float *wpack, const int32_t *dims, const int32_t *acts, int32_t n_layers,
+                            float *out, int64_t ldo, int64_t P, amar_stream_t stream) {
+    if (!seg || !seg_ld || !seg_width || n_seg < 1 || n_seg > CHAIN_MAX_SEG) return AMAR_EINVAL;
+    int64_t da = 0;
+    for (int j = 0; j < n_seg; ++j) {
+        if (!seg[j] || seg_width[j] < 4 || (seg_width[j] & 3) || seg_ld[j] < seg_width[j] || (seg_ld[j] & 3) || !amar_aligned16(seg[j]) ||
+            seg_ld[j] >= (1ll << 30))
+            return AMAR_EINVAL;
+        da += seg_width[j];
+    }
+    if (da > 128) return AMAR_EUNSUPPORTED;
+    return chain_run(seg[0], seg_ld[0], (int32_t)da, ids, base, nullptr, 0, 0, nullptr, 0, 0, AMAR_ACT_NONE, wpack, dims, acts, n_layers, out, ldo,
+                     nullptr, P, stream, n_seg, seg, seg_ld, seg_width);
+}
+
+static int chain_run(const float *A, int64_t lda, int32_t Da, const int32_t *ids_a, int32_t base_a,
+                     const float *B, int64_t ldb, int32_t Db, const int32_t *ids_b, int32_t base_b,
+                     int32_t sum_inputs, int32_t in_act,
+                     const float *wpack, const int32_t *dims, const int32_t *acts, int32_t n_layers,
+                     float *out, int64_t ldo, const int32_t *out_index, int64_t P, amar_stream_t stream,
+                     int32_t n_seg, const float *const *seg, const int64_t *seg_ld, const int32_t *seg_width) {
     if (P < 0 || !A || !wpack || !dims || !acts || !out || Da < 4 || Db < 0) return AMAR_EINVAL;
     if (sum_inputs && (Db != Da || !B)) return AMAR_EINVAL;
     if (in_act != AMAR_ACT_NONE && in_act != AMAR_ACT_RELU && in_act != AMAR_ACT_SIGMOID) return AMAR_EINVAL;
-    if ((Da & 3) || (Db & 3) || (lda & 3) || lda < Da || !amar_aligned16(A) || !amar_aligned16(wpack)) return AMAR_EINVAL;
+    if ((Da & 3) || (Db & 3) || (lda & 3) || (n_seg == 0 && lda < Da) || !amar_aligned16(A) || !amar_aligned16(wpack)) return AMAR_EINVAL;
     if (Db && (!B || (ldb & 3) || ldb < Db || !amar_aligned16(B))) return AMAR_EINVAL;
     if (n_layers < 1 || n_layers > CHAIN_MAX_LAYERS || dims[0] != (sum_inputs ? Da : Da + Db)) return AMAR_EINVAL;
     ChainArgs a{};
@@ -787,6 +842,11 @@ int amar_chain_indexed_f32(const float *A, int64_t lda, int32_t Da, const int32_
     a.B = B; a.ldb = ldb; a.Db = Db; a.ids_b = ids_b; a.base_b = base_b;
     a.wpack = wpack; a.out = out; a.ldo = ldo; a.P = P; a.sum_inputs = sum_inputs ? 1 : 0; a.in_act = in_act;
     a.out_index = out_index;
+    a.n_seg = n_seg;
+    for (int j = 0; j < n_seg; ++j) {
+        a.seg[j] = seg[j]; a.seg_ld[j] = seg_ld[j];
+        a.seg_off[j + 1] = a.seg_off[j] + seg_width[j];
+    }
     int maxw = 0, off = 0;
     for (int l = 0; l < n_layers; ++l) {
         const int K = dims[l], N = dims[l + 1], act = acts[l];
@@ -871,7 +931,7 @@ int amar_chain_indexed_f32(const float *A, int64_t lda, int32_t Da, const int32_
     // entity towers (one table, no dot, ReLU with an optionally linear last layer) in a shape with a compile-time kernel; AMAR_CHAIN_ROWS=0
     // keeps the generic one
     static const bool no_rows = getenv("AMAR_CHAIN_ROWS") && atoi(getenv("AMAR_CHAIN_ROWS")) == 0;
-    if (!no_rows && (am == 1 || am == 2) && !a.sum_inputs && a.Db == 0 && !a.has_dot && !a.out_index && pt == 2 && a.n_layers <= 3 &&
+    if ((!no_rows || n_seg > 0) && (am == 1 || am == 2) && !a.sum_inputs && a.Db == 0 && !a.has_dot && !a.out_index && (pt == 2 || n_seg > 0) && a.n_layers <= 3 &&
         maxt <= 4 && lds_bytes <= 64 * 1024 && lda < (1ll << 30) && P < (1ll << 30) - (4ll << 20)) {
         const int shape = chain_shape(a.n_layers, a.kt[0], a.nt[0], a.n_layers > 1 ? a.nt[1] : 0, a.n_layers > 2 ? a.nt[2] : 0);
         // 1 024 workgroups = 4 per CU, every wave a few iterations deep in its prefetch (ml1m(s=64) towers: 0.059 ms against 0.063 at
@@ -884,8 +944,11 @@ int amar_chain_indexed_f32(const float *A, int64_t lda, int32_t Da, const int32_
         bool done = true;
 #define AMAR_ROWS_CASE(NLL, A0, A1, A2, A3)                                                                                      \
         case chain_shape(NLL, A0, A1, A2, A3):                                                                                   \
-            if (am == 2) hipLaunchKernelGGL((chain_rows_kernel<chain_shape(NLL, A0, A1, A2, A3), 2, true>), grid, block, lds_bytes, st, a);   \
-            else hipLaunchKernelGGL((chain_rows_kernel<chain_shape(NLL, A0, A1, A2, A3), 2, false>), grid, block, lds_bytes, st, a);          \
+            if (n_seg > 0) {                                                                                                     \
+                if (am == 2) hipLaunchKernelGGL((chain_rows_kernel<chain_shape(NLL, A0, A1, A2, A3), 2, true, true>), grid, block, lds_bytes, st, a);   \
+                else hipLaunchKernelGGL((chain_rows_kernel<chain_shape(NLL, A0, A1, A2, A3), 2, false, true>), grid, block, lds_bytes, st, a);          \
+            } else if (am == 2) hipLaunchKernelGGL((chain_rows_kernel<chain_shape(NLL, A0, A1, A2, A3), 2, true, false>), grid, block, lds_bytes, st, a);   \
+            else hipLaunchKernelGGL((chain_rows_kernel<chain_shape(NLL, A0, A1, A2, A3), 2, false, false>), grid, block, lds_bytes, st, a);          \
             break
         switch (shape) {
         AMAR_ROWS_CASE(3, 2, 2, 2, 3);      // 24 -> 24 -> 24 -> 48: basic-gnn grid1's towers with the classifier's first layer folded in
@@ -899,6 +962,7 @@ int amar_chain_indexed_f32(const float *A, int64_t lda, int32_t Da, const int32_
 #undef AMAR_ROWS_CASE
         if (done) return amar_check_launch();
     }
+    if (n_seg > 0) return AMAR_EUNSUPPORTED;       // segments are read by the compile-time tower shapes only: the caller concatenates for the others
     if (maxt == 3) { if (pt == 1) AMAR_CHAIN_LAUNCH(3, 1); else if (pt == 2) AMAR_CHAIN_LAUNCH(3, 2); else AMAR_CHAIN_LAUNCH(3, 4); }
     else if (maxt == 4) { if (pt == 1) AMAR_CHAIN_LAUNCH(4, 1); else if (pt == 2) AMAR_CHAIN_LAUNCH(4, 2); else AMAR_CHAIN_LAUNCH(4, 4); }
     else { if (pt == 1) AMAR_CHAIN_LAUNCH(8, 1); else AMAR_CHAIN_LAUNCH(8, 2); }

@@ -16,6 +16,22 @@ static inline int amar_check_launch() {
 
 static inline bool amar_aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is kept PER DEVICE by the runtime: a kernel that needs more than 64 KB of dynamic LDS
+// gets the attribute once on every device it is launched on (`done` = the call site's own per-device flags); a refused call is
+// reported instead of surfacing later as an opaque launch failure.
+#define AMAR_MAX_DEVICES 64
+static inline int amar_allow_lds(const void *kern, size_t bytes, bool (&done)[AMAR_MAX_DEVICES]) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess || dev < 0 || dev >= AMAR_MAX_DEVICES) { amar_tls_hip_error = (int)e; return AMAR_ELAUNCH; }
+    if (!done[dev]) {
+        e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) { amar_tls_hip_error = (int)e; return AMAR_ELAUNCH; }
+        done[dev] = true;
+    }
+    return AMAR_OK;
+}
+
 __device__ __forceinline__ float4 f4_zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 f4_fma(float a, float4 x, float4 acc) {
     acc.x = fmaf(a, x.x, acc.x); acc.y = fmaf(a, x.y, acc.y);

@@ -217,7 +217,7 @@ int launch_spmm(const SpmmArgs &a, int F, hipStream_t st) {
 // bias, ReLU, store into the concat slice, running layer sum, and the next layer's X.W with
 // wave-uniform (scalar) reads of Wnext.
 template <int F, bool FUSE_NEXT>
-__device__ __forceinline__ void lane_row_epilogue(const SpmmArgs &e, int row, float4 (&acc)[F / 4]) {
+__device__ __forceinline__ void lane_row_epilogue(const SpmmArgs &e, int row, float4 (&acc)[F / 4], const float *wn_lds = nullptr) {
     constexpr int LPN = F / 4;
 #pragma unroll
     for (int q = 0; q < LPN; ++q) {
@@ -233,7 +233,21 @@ __device__ __forceinline__ void lane_row_epilogue(const SpmmArgs &e, int row, fl
             *reinterpret_cast<float4 *>(e.acc_out + (int64_t)row * e.ld_acc_out + 4 * q) = s;
         }
     }
-    if (FUSE_NEXT) {
+    if (FUSE_NEXT && wn_lds && (e.Cn & 3) == 0) {
+        // the kernel staged in LDS ([F][Cn], read as broadcasts); same order of operations per output as the scalar form below
+        for (int j0 = 0; j0 < e.Cn; j0 += 4) {
+            float4 h = f4_zero();
+#pragma unroll
+            for (int q = 0; q < LPN; ++q)
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    h = f4_fma(f4_get(acc[q], c), *reinterpret_cast<const float4 *>(wn_lds + (4 * q + c) * e.Cn + j0), h);
+            if (e.next_scale) { const float sc = e.next_scale[row]; h.x *= sc; h.y *= sc; h.z *= sc; h.w *= sc; }
+            float *dst = e.Hn + (int64_t)row * e.ldhn + j0;
+            if ((e.ldhn & 3) == 0) *reinterpret_cast<float4 *>(dst) = h;
+            else { dst[0] = h.x; dst[1] = h.y; dst[2] = h.z; dst[3] = h.w; }
+        }
+    } else if (FUSE_NEXT) {
         for (int j0 = 0; j0 < e.Cn; j0 += 4) {
             float h[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -650,9 +664,20 @@ __device__ __forceinline__ int lt_lds_row(int v) {                    // virtual
 // underflows: a row whose weight sum stays below e^-60 is recomputed in the epilogue from the block's CSR with its true maximum.
 // SAGE: GraphSAGE's tail in the epilogue (AMAR_SPMM_SAGE_TAIL): the tile's sums are the mean aggregate; the row leaves as
 // relu(l2_normalize([x_i || agg_i] . W + b)) with W = e.Wn [2F, F], in sage_tail_kernel's order of operations.
-template <int F, int OFF32, bool FUSE_NEXT, int U, int PACE, int ABL = 0, bool GAT = false, bool SAGE = false>
+// PAIRS = false (AMAR_SPMM_LT_NOPAIRS: the image flags EVERY repeat of a row inside a step, utilities/lds_tiled.py `pairs=False`):
+// the implicit-pair logic — one DPP read of the previous slot's row, two compares, four selects and four DPP adds per step — is
+// compiled out.  Wide rows are few entries per wave-instruction (F = 32: 8), so a step's fixed instructions weigh 4x what they
+// do at F = 8 (rocprofv3, ml1m(s=64): 32 VALU instructions per 8 entries, the VALU 70 % busy) while repeats inside a step are
+// rare (0.14 % pairs at F = 32): they go to the atomic path instead.
+// VPL = 2 (AMAR_SPMM_LT_TWO_QUADS: an image dealt for F / 8 lanes per entry, utilities/lds_tiled.py `quads=2`): a lane carries TWO
+// float4 of its entry (features 4q.. and 4(q + F/8)..), so a wave-instruction covers twice the entries and a step's index
+// arithmetic, pacing and LDS addressing are paid once per two quads.
+template <int F, int OFF32, bool FUSE_NEXT, int U, int PACE, int ABL = 0, bool GAT = false, bool SAGE = false, bool PAIRS = true, int VPL = 1>
 __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE, AMAR_LT_MIN_WAVES) void spmm_lt_kernel(const LtArgs a) {
-    constexpr int LPN = F / 4, EPS = AMAR_WAVE / LPN, RW = GAT ? lt_gat_rw(F) : LT_TILE_BYTES / (4 * F * LT_WAVES), CS = LT_CHUNK / EPS;
+    static_assert(VPL == 1 || (VPL == 2 && F >= 16 && !GAT && ABL == 0), "two quads per lane: plain / fused sums of width 16 or 32");
+    constexpr int LPN = F / 4;                                        // float4 per row (the epilogue's unit)
+    constexpr int LPE = LPN / VPL;                                    // lanes per entry in the walk
+    constexpr int EPS = AMAR_WAVE / LPE, RW = GAT ? lt_gat_rw(F) : LT_TILE_BYTES / (4 * F * LT_WAVES), CS = LT_CHUNK / EPS;
     constexpr unsigned LMASK = (1u << lt_bits(RW)) - 1u;
     constexpr int G = U - 1;                                          // steps of gathers in flight ahead of the accumulation
     static_assert(CS % U == 0 && G < CS, "register slots of the in-flight steps must be static inside a chunk");
@@ -683,7 +708,7 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE, AMAR_LT_MIN_WAVES) void spmm_
         __syncthreads();
     }
 
-    const int s = lane / LPN, q = lane % LPN;                         // LPN adjacent lanes share an entry
+    const int s = lane / LPE, q = lane % LPE;                         // LPE adjacent lanes share an entry
     const int32_t *stream = a.words + a.stream_start[t * LT_WAVES + wave];
     const int32_t *ws = a.wsteps + ((int64_t)t * LT_WAVES + wave) * a.maxwin1;     // the wave's window table [maxwin1]
     const int nwin = a.n_win[t];
@@ -697,6 +722,7 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE, AMAR_LT_MIN_WAVES) void spmm_
     };
     int wd[U], wn[CS];                                                // words of the steps in flight / of the chunk being issued
     float4 x[U];
+    float4 x2[VPL == 2 ? U : 1];                                      // the lane's second quad (features 4 (q + LPE) ..)
     float bs[GAT ? U : 1];                                            // GAT: s_neigh of the steps in flight
     auto refill = [&](const v4i &pre) {                               // chunk registers -> LDS -> one word per (step, entry slot)
         *reinterpret_cast<v4i *>(ring + 4 * lane) = pre;
@@ -711,6 +737,11 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE, AMAR_LT_MIN_WAVES) void spmm_
         else if (OFF32 == 2) x[slot] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.X) + ((col * (unsigned)F + 4u * q) * 4u));
         else if (OFF32 == 1) x[slot] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.X) + (col * (unsigned)a.ldx + 4u * q) * 4u);
         else x[slot] = *reinterpret_cast<const float4 *>(a.X + (int64_t)col * a.ldx + 4 * q);
+        if constexpr (VPL == 2) {
+            if (OFF32 == 2) x2[slot] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.X) + ((col * (unsigned)F + 4u * (q + LPE)) * 4u));
+            else if (OFF32 == 1) x2[slot] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.X) + (col * (unsigned)a.ldx + 4u * (q + LPE)) * 4u);
+            else x2[slot] = *reinterpret_cast<const float4 *>(a.X + (int64_t)col * a.ldx + 4 * (q + LPE));
+        }
         if (GAT) bs[slot] = (ABL & 8) ? 0.25f : *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.s_neigh) + (uint64_t)col * 4u);
     };
     auto accumulate = [&](int slot) {
@@ -733,25 +764,43 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE, AMAR_LT_MIN_WAVES) void spmm_
         }
         // implicit pair: same virtual row as the previous slot (row_shr: lane l reads l - LPN inside its 16-lane DPP row;
         // the first slot of a DPP row keeps -1) and not flagged -> its values go to that slot's registers, no LDS update
-        const int prev = __builtin_amdgcn_update_dpp(-1, lrow, 0x110 + LPN, 0xF, 0xF, false);
-        const bool paired = prev == lrow && w >= 0;
-        const float4 give = paired ? xv : f4_zero();
-        xv.x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.x), 0x100 + LPN, 0xF, 0xF, true));
-        xv.y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.y), 0x100 + LPN, 0xF, 0xF, true));
-        xv.z += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.z), 0x100 + LPN, 0xF, 0xF, true));
-        xv.w += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.w), 0x100 + LPN, 0xF, 0xF, true));
-        if (GAT) {
-            const float gw = paired ? wgt : 0.f;
-            wgt += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gw), 0x100 + LPN, 0xF, 0xF, true));
+        bool paired = false;
+        float4 xw = VPL == 2 ? x2[VPL == 2 ? slot : 0] : f4_zero();   // the second quad
+        if constexpr (PAIRS) {
+            const int prev = __builtin_amdgcn_update_dpp(-1, lrow, 0x110 + LPE, 0xF, 0xF, false);
+            paired = prev == lrow && w >= 0;
+            const float4 give = paired ? xv : f4_zero();
+            xv.x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.x), 0x100 + LPE, 0xF, 0xF, true));
+            xv.y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.y), 0x100 + LPE, 0xF, 0xF, true));
+            xv.z += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.z), 0x100 + LPE, 0xF, 0xF, true));
+            xv.w += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.w), 0x100 + LPE, 0xF, 0xF, true));
+            if constexpr (VPL == 2) {
+                const float4 give2 = paired ? xw : f4_zero();
+                xw.x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give2.x), 0x100 + LPE, 0xF, 0xF, true));
+                xw.y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give2.y), 0x100 + LPE, 0xF, 0xF, true));
+                xw.z += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give2.z), 0x100 + LPE, 0xF, 0xF, true));
+                xw.w += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give2.w), 0x100 + LPE, 0xF, 0xF, true));
+            }
+            if (GAT) {
+                const float gw = paired ? wgt : 0.f;
+                wgt += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gw), 0x100 + LPE, 0xF, 0xF, true));
+            }
         }
+        float *yp2 = yp + 4 * LPE;
         if (w >= 0 && !paired) {
             float4 y = *reinterpret_cast<float4 *>(yp);
             y = f4_add(y, xv);
             *reinterpret_cast<float4 *>(yp) = y;
-            if (GAT && !(ABL & 16)) side[lds_row].x = lsum + wgt;     // the LPN lanes of the entry store the same value
+            if constexpr (VPL == 2) {
+                float4 y2 = *reinterpret_cast<float4 *>(yp2);
+                y2 = f4_add(y2, xw);
+                *reinterpret_cast<float4 *>(yp2) = y2;
+            }
+            if (GAT && !(ABL & 16)) side[lds_row].x = lsum + wgt;     // the LPE lanes of the entry store the same value
         }
         if (!(ABL & 1) && w < 0) {                                    // the row occurs earlier in this step: after its plain add
             atomicAdd(yp + 0, xv.x); atomicAdd(yp + 1, xv.y); atomicAdd(yp + 2, xv.z); atomicAdd(yp + 3, xv.w);
+            if constexpr (VPL == 2) { atomicAdd(yp2 + 0, xw.x); atomicAdd(yp2 + 1, xw.y); atomicAdd(yp2 + 2, xw.z); atomicAdd(yp2 + 3, xw.w); }
             if (GAT && q == 0) atomicAdd(&side[lds_row].x, wgt);
         }
     };
@@ -825,6 +874,15 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE, AMAR_LT_MIN_WAVES) void spmm_
 
     // epilogue: y_i = row_scale_i . (diag_i . x_i + the row's virtual rows), then bias / ReLU / store / running sum / next X.W
     LT_STAMP(2);
+    // Wide layers keep the next layer's kernel in the (now idle) index ring: one thread finishes one row, and F x Cn weights by
+    // wave-uniform scalar loads are F x Cn / 4 dependent s_load round trips per wave with nothing left to hide them — the fused
+    // next X.W cost 0.27 ms per ml1m(s=64) layer at F = 32 (0.57 -> 0.84) and 0.05 at F = 16; broadcast ds_read_b128 instead.
+    constexpr bool WN_LDS = FUSE_NEXT && !SAGE && !GAT && F >= 16;
+    float *wn_lds = reinterpret_cast<float *>(ring_all);              // [F][Cn], Cn <= 64: at most 8 KB of the 16 KB ring
+    if constexpr (WN_LDS) {
+        for (int i = threadIdx.x; i < F * a.e.Cn; i += LT_WAVES * AMAR_WAVE) wn_lds[i] = a.e.Wn[i];
+        __syncthreads();
+    }
     // A thread finishes up to EK rows per pass; their global operands (virtual-row range, diag, scale, the row's own X) are all
     // requested before the first one is used: one memory round trip per pass instead of one per row (a 4 080-row tile of
     // four-entry rows spent a quarter of its time in these).
@@ -945,7 +1003,7 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE, AMAR_LT_MIN_WAVES) void spmm_
                 continue;
             }
         }
-        lane_row_epilogue<F, FUSE_NEXT>(a.e, row, acc);
+        lane_row_epilogue<F, FUSE_NEXT>(a.e, row, acc, WN_LDS ? wn_lds : nullptr);
     }
     }
 #ifdef AMAR_LT_STAMPS
@@ -955,15 +1013,18 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE, AMAR_LT_MIN_WAVES) void spmm_
 }
 
 template <int F>
-int launch_spmm_lt(const LtArgs &a, int n_tiles, int off32, bool fuse, int variant, bool sage, hipStream_t st) {
+int launch_spmm_lt(const LtArgs &a, int n_tiles, int off32, bool fuse, int variant, bool sage, bool nopairs, bool two_quads, hipStream_t st) {
+    if (two_quads && F < 16) return AMAR_EINVAL;
     constexpr int RW = LT_TILE_BYTES / (4 * F * LT_WAVES);
     const size_t lds = (size_t)LT_WAVES * RW * F * 4 + (size_t)LT_WAVES * LT_CHUNK * 4 + 32;
     const dim3 grid((unsigned)n_tiles), block(LT_WAVES * AMAR_WAVE);
-#define AMAR_LT_LAUNCH_S(OFF, FUSE, UU, PP, AA, SS)                                                                     \
+#define AMAR_LT_LAUNCH_S(OFF, FUSE, UU, PP, AA, SS) AMAR_LT_LAUNCH_P(OFF, FUSE, UU, PP, AA, SS, true)
+#define AMAR_LT_LAUNCH_P(OFF, FUSE, UU, PP, AA, SS, PR) AMAR_LT_LAUNCH_V(OFF, FUSE, UU, PP, AA, SS, PR, 1)
+#define AMAR_LT_LAUNCH_V(OFF, FUSE, UU, PP, AA, SS, PR, VV)                                                             \
     do {                                                                                                                 \
-        auto kern = spmm_lt_kernel<F, OFF, FUSE, UU, PP, AA, false, SS>;                                                 \
-        static bool once = false;                                                                                        \
-        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } \
+        auto kern = spmm_lt_kernel<F, OFF, FUSE, UU, PP, AA, false, SS, PR, VV>;                                         \
+        static bool allowed[AMAR_MAX_DEVICES] = {};                                                                      \
+        if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(kern), lds, allowed)) return rc;               \
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                               \
     } while (0)
 #define AMAR_LT_LAUNCH(OFF, FUSE, UU, PP, AA) AMAR_LT_LAUNCH_S(OFF, FUSE, UU, PP, AA, false)
@@ -999,11 +1060,31 @@ int launch_spmm_lt(const LtArgs &a, int n_tiles, int off32, bool fuse, int varia
             return amar_check_launch();
         }
     }
+    if constexpr (F >= 16) {
+        if (two_quads) {                                              // an image dealt for F / 8 lanes per entry
+            if (off32 == 0 || sage) return AMAR_EUNSUPPORTED;
+            if (nopairs) {
+                if (off32 == 2) { if (fuse) AMAR_LT_LAUNCH_V(2, true, 4, 1, 0, false, false, 2); else AMAR_LT_LAUNCH_V(2, false, 4, 1, 0, false, false, 2); }
+                else { if (fuse) AMAR_LT_LAUNCH_V(1, true, 4, 1, 0, false, false, 2); else AMAR_LT_LAUNCH_V(1, false, 4, 1, 0, false, false, 2); }
+            } else {
+                if (off32 == 2) { if (fuse) AMAR_LT_LAUNCH_V(2, true, 4, 1, 0, false, true, 2); else AMAR_LT_LAUNCH_V(2, false, 4, 1, 0, false, true, 2); }
+                else { if (fuse) AMAR_LT_LAUNCH_V(1, true, 4, 1, 0, false, true, 2); else AMAR_LT_LAUNCH_V(1, false, 4, 1, 0, false, true, 2); }
+            }
+            return amar_check_launch();
+        }
+        if (nopairs && off32 != 0) {                                  // an image without implicit pairs: the lean step (see PAIRS above)
+            if (off32 == 2) { if (fuse) AMAR_LT_LAUNCH_P(2, true, 4, 1, 0, false, false); else AMAR_LT_LAUNCH_P(2, false, 4, 1, 0, false, false); }
+            else { if (fuse) AMAR_LT_LAUNCH_P(1, true, 4, 1, 0, false, false); else AMAR_LT_LAUNCH_P(1, false, 4, 1, 0, false, false); }
+            return amar_check_launch();
+        }
+    }
     if (off32 == 2) { if (fuse) AMAR_LT_LAUNCH(2, true, 4, 1, 0); else AMAR_LT_LAUNCH(2, false, 4, 1, 0); }
     else if (off32 == 1) { if (fuse) AMAR_LT_LAUNCH(1, true, 4, 1, 0); else AMAR_LT_LAUNCH(1, false, 4, 1, 0); }
     else { if (fuse) AMAR_LT_LAUNCH(0, true, 4, 1, 0); else AMAR_LT_LAUNCH(0, false, 4, 1, 0); }
 #undef AMAR_LT_LAUNCH
 #undef AMAR_LT_LAUNCH_S
+#undef AMAR_LT_LAUNCH_P
+#undef AMAR_LT_LAUNCH_V
     return amar_check_launch();
 }
 
@@ -1016,8 +1097,8 @@ int launch_gat_lt(const LtArgs &a, int n_tiles, int off32, hipStream_t st) {
 #define AMAR_GAT_LT_LAUNCH_A(OFF, AA)                                                                                    \
     do {                                                                                                                 \
         auto kern = spmm_lt_kernel<F, OFF, false, 4, 1, AA, true>;                                                       \
-        static bool once = false;                                                                                        \
-        if (!once) { (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); once = true; } \
+        static bool allowed[AMAR_MAX_DEVICES] = {};                                                                      \
+        if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(kern), lds, allowed)) return rc;               \
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                               \
     } while (0)
 #define AMAR_GAT_LT_LAUNCH(OFF) AMAR_GAT_LT_LAUNCH_A(OFF, 0)
@@ -1074,6 +1155,7 @@ struct XwArgs {
     const float *a_self; const float *a_neigh; float *s_self; float *s_neigh;
     int n_rows;
     const float *row_scale;                      // H rows are multiplied by row_scale[row] (value-free XS image), or NULL
+    const int32_t *row_ids;                      // output row p reads X[row_ids[p]] (a negative id: a zero row), or NULL: X[p]
 };
 
 // One wave handles 64/CP rows at a time (CP = C rounded up to a power of two): lane = (row slot, out column).
@@ -1085,10 +1167,12 @@ __global__ __launch_bounds__(256) void rowwise_xw_kernel(const XwArgs a, int CP)
     const int c = threadIdx.x % CP, rslot = threadIdx.x / CP;
     for (int64_t row = (int64_t)blockIdx.x * rows_per_block + rslot; row < a.n_rows;
          row += (int64_t)gridDim.x * rows_per_block) {
-        const float *x = a.X + row * a.ldx;
+        const int64_t src = a.row_ids ? (int64_t)a.row_ids[row] : row;
+        const float *x = a.X + (src < 0 ? 0 : src) * a.ldx;
         float h = 0.f;
         if (c < a.C) {
             for (int k = 0; k < a.F; ++k) h = fmaf(x[k], w_lds[k * a.C + c], h);
+            if (src < 0) h = 0.f;
             a.H[row * a.ldh + c] = a.row_scale ? h * a.row_scale[row] : h;
         }
         if (a.copy_to) for (int k = c; k < a.F; k += CP) a.copy_to[row * a.ld_copy + k] = x[k];
@@ -1115,15 +1199,19 @@ __global__ __launch_bounds__(256) void rowwise_xw_vec_kernel(const XwArgs a) {
     constexpr int R = F == 8 ? 2 : 1;
     for (int64_t row0 = (int64_t)blockIdx.x * 256 * R + threadIdx.x; row0 < a.n_rows; row0 += (int64_t)gridDim.x * 256 * R) {
         float x[R][F], sc[R];
+        bool pad[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const int64_t row = row0 + 256 * j < a.n_rows ? row0 + 256 * j : row0;        // (past the end: the first row again, not stored)
+            const int64_t src = a.row_ids ? (int64_t)a.row_ids[row] : row;
+            pad[j] = src < 0;
+            const int64_t xrow = pad[j] ? 0 : src;
 #pragma unroll
             for (int q = 0; q < F / 4; ++q) {
-                const float4 v = *reinterpret_cast<const float4 *>(a.X + row * a.ldx + 4 * q);
+                const float4 v = *reinterpret_cast<const float4 *>(a.X + xrow * a.ldx + 4 * q);
                 x[j][4 * q] = v.x; x[j][4 * q + 1] = v.y; x[j][4 * q + 2] = v.z; x[j][4 * q + 3] = v.w;
             }
-            sc[j] = a.row_scale ? a.row_scale[row] : 1.f;
+            sc[j] = pad[j] ? 0.f : (a.row_scale ? a.row_scale[row] : 1.f);
         }
 #pragma unroll
         for (int j = 0; j < R; ++j) {
@@ -1155,7 +1243,7 @@ __global__ __launch_bounds__(256) void rowwise_xw_vec_kernel(const XwArgs a) {
                 }
 #pragma unroll
             for (int q = 0; q < F / 4; ++q)
-                *reinterpret_cast<float4 *>(a.H + row * a.ldh + 4 * q) = a.row_scale
+                *reinterpret_cast<float4 *>(a.H + row * a.ldh + 4 * q) = (a.row_scale || a.row_ids)
                     ? make_float4(h[4 * q] * sc[j], h[4 * q + 1] * sc[j], h[4 * q + 2] * sc[j], h[4 * q + 3] * sc[j])
                     : make_float4(h[4 * q], h[4 * q + 1], h[4 * q + 2], h[4 * q + 3]);
             if (a.s_self) {                                           // (the generic kernel adds these by an xor butterfly: last-bit differences)
@@ -1579,10 +1667,28 @@ int amar_gcn_layer_f32(const int32_t *rowptr, const int32_t *colidx, const float
     return vals ? launch_spmm<true, false>(a, C, st) : launch_spmm<false, false>(a, C, st);
 }
 
+static int rowwise_xw_run(const float *X, int64_t ldx, int32_t F, const float *W, int32_t C,
+                          float *H, int64_t ldh, float *copy_to, int64_t ld_copy,
+                          const float *a_self, const float *a_neigh, float *s_self, float *s_neigh,
+                          const float *row_scale, const int32_t *row_ids, int32_t n_rows, amar_stream_t stream);
+
 int amar_rowwise_xw_f32(const float *X, int64_t ldx, int32_t F, const float *W, int32_t C,
                         float *H, int64_t ldh, float *copy_to, int64_t ld_copy,
                         const float *a_self, const float *a_neigh, float *s_self, float *s_neigh,
                         const float *row_scale, int32_t n_rows, amar_stream_t stream) {
+    return rowwise_xw_run(X, ldx, F, W, C, H, ldh, copy_to, ld_copy, a_self, a_neigh, s_self, s_neigh, row_scale, nullptr, n_rows, stream);
+}
+
+int amar_rowwise_xw_gather_f32(const float *X, int64_t ldx, int32_t F, const int32_t *row_ids, const float *W, int32_t C,
+                               float *H, int64_t ldh, const float *row_scale, int32_t n_rows, amar_stream_t stream) {
+    if (!row_ids) return AMAR_EINVAL;
+    return rowwise_xw_run(X, ldx, F, W, C, H, ldh, nullptr, 0, nullptr, nullptr, nullptr, nullptr, row_scale, row_ids, n_rows, stream);
+}
+
+static int rowwise_xw_run(const float *X, int64_t ldx, int32_t F, const float *W, int32_t C,
+                          float *H, int64_t ldh, float *copy_to, int64_t ld_copy,
+                          const float *a_self, const float *a_neigh, float *s_self, float *s_neigh,
+                          const float *row_scale, const int32_t *row_ids, int32_t n_rows, amar_stream_t stream) {
     if (n_rows < 0 || !X || !W || !H || F < 1 || C < 1 || ldx < F || ldh < C) return AMAR_EINVAL;
     if (F > 64 || C > 64) return AMAR_EUNSUPPORTED;
     if (copy_to && ld_copy < F) return AMAR_EINVAL;
@@ -1592,7 +1698,7 @@ int amar_rowwise_xw_f32(const float *X, int64_t ldx, int32_t F, const float *W, 
     int CP = 1;
     while (CP < C) CP <<= 1;
     if (attn && row_scale) return AMAR_EINVAL;                       // the attention scalars are defined on the un-scaled product
-    XwArgs a{X, ldx, F, W, C, H, ldh, copy_to, ld_copy, a_self, a_neigh, attn ? s_self : nullptr, s_neigh, n_rows, row_scale};
+    XwArgs a{X, ldx, F, W, C, H, ldh, copy_to, ld_copy, a_self, a_neigh, attn ? s_self : nullptr, s_neigh, n_rows, row_scale, row_ids};
     static const bool no_vec = getenv("AMAR_XW_VEC") && atoi(getenv("AMAR_XW_VEC")) == 0;            // development switch (A/B timing)
     if (!no_vec && F == C && (F == 8 || F == 16) && (ldx & 3) == 0 && (ldh & 3) == 0 && amar_aligned16(X) && amar_aligned16(H) &&
         (!copy_to || ((ld_copy & 3) == 0 && amar_aligned16(copy_to)))) {
@@ -1840,14 +1946,15 @@ int amar_spmm_lt_f32(const int32_t *words, const int32_t *stream_start, const in
     a.e.acc_div = acc_div; a.e.accum = accum ? 1 : 0; a.e.accum_div = (flags & AMAR_SPMM_ACCUM_DIV) ? 1 : 0;
     a.e.Wn = Wnext; a.e.Cn = Cn; a.e.Hn = Hnext; a.e.ldhn = ldhn; a.e.n_rows = n_rows;
     const int off32 = (int64_t)n_cols * ldx * 4 < (int64_t(1) << 32) ? (ldx == F ? 2 : 1) : 0;
+    const bool nopairs = (flags & AMAR_SPMM_LT_NOPAIRS) != 0, two_quads = (flags & AMAR_SPMM_LT_TWO_QUADS) != 0;
     const char *venv = getenv("AMAR_LT_VARIANT");               // development switch (tools/exp_lt.py)
     const int variant = venv ? atoi(venv) : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (F) {
-    case 4:  return launch_spmm_lt<4>(a, n_tiles, off32, Wnext != nullptr && !sage, variant, sage, st);
-    case 8:  return launch_spmm_lt<8>(a, n_tiles, off32, Wnext != nullptr && !sage, variant, sage, st);
-    case 16: return launch_spmm_lt<16>(a, n_tiles, off32, Wnext != nullptr && !sage, variant, sage, st);
-    default: return launch_spmm_lt<32>(a, n_tiles, off32, Wnext != nullptr && !sage, variant, sage, st);
+    case 4:  return launch_spmm_lt<4>(a, n_tiles, off32, Wnext != nullptr && !sage, variant, sage, nopairs, two_quads, st);
+    case 8:  return launch_spmm_lt<8>(a, n_tiles, off32, Wnext != nullptr && !sage, variant, sage, nopairs, two_quads, st);
+    case 16: return launch_spmm_lt<16>(a, n_tiles, off32, Wnext != nullptr && !sage, variant, sage, nopairs, two_quads, st);
+    default: return launch_spmm_lt<32>(a, n_tiles, off32, Wnext != nullptr && !sage, variant, sage, nopairs, two_quads, st);
     }
 }
 

@@ -197,7 +197,16 @@ class Experimenter:
             top_k_dest = path_join(self.predictions_dest, "top_{}".format(k))
             os.makedirs(top_k_dest, exist_ok=True)
             top_predictions.to_csv(path_join(top_k_dest, "predictions_1.tsv"), sep='\t', header=False, index=False)
-            top_k_metrics(self.config.dataset.test_ratings_filepath, top_k_dest)
+            # the evaluator's switches are reachable from the experiment config (parameters.metrics_short_lists / metrics_no_relevant);
+            # unset = RiVal's behaviour as restated (utilities/metrics.py), users skipped by them are logged with the metrics
+            prm = self.config.parameters
+            top_k_metrics(self.config.dataset.test_ratings_filepath, top_k_dest,
+                          short_lists=prm.get('metrics_short_lists'), no_relevant=prm.get('metrics_no_relevant'))
+            users_tsv = path_join(top_k_dest, "results_users.tsv")
+            if os.path.exists(users_tsv):
+                cnt = pd.read_csv(users_tsv, sep='\t').iloc[0]
+                self.run_log.log_metrics({"users_skipped_short_list_at_{}".format(k): int(cnt['skipped_short_list']),
+                                          "users_skipped_no_relevant_at_{}".format(k): int(cnt['skipped_no_relevant_item'])})
             results = pd.read_csv(path_join(top_k_dest, "results.tsv"), sep='\t', header=None)
             results = results.drop(0, axis=1).to_numpy().squeeze()
             precision_at[k], recall_at[k], f1_at[k] = results[0], results[1], results[2]

@@ -118,6 +118,22 @@ class BasicRS(Model):
             out.append(t)
         return (out[0], out[1], True)
 
+    def tower(self, key, table, ids=None):
+        """One tower ('u' or 'i') of `towers` on its own — the partitioned runner evaluates the user tower (its own rows) while the
+        last item rows are still arriving.  `table` may be a capi.ConcatTable (per-layer tables read in place)."""
+        plan = self._split_plan(table.shape[1], table.shape[1])
+        if plan is None:
+            return (self.unet if key == 'u' else self.inet).apply2(table, ids_a=ids)
+        blob, dims, acts = plan[key]
+        m = ids.numel() if ids is not None else table.shape[0]
+        t = torch.empty((m, dims[-1]), dtype=torch.float32, device=table.device)
+        capi.chain(table, blob, dims, acts, t, ids_a=ids)
+        return t
+
+    def split_ready(self):
+        """Whether the last tower() / towers() call produced the split form (classifier layer 1 folded into the towers)."""
+        return self._split_cache[1] is not None
+
     def score_towers(self, towers, u_ids, i_ids, u_base=0, i_base=0, pair_plan=None):
         """Scores of the pairs (u_ids[p], i_ids[p]) from per-entity tower tables.  `pair_plan` (PairPlan of the same id lists):
         the launch walks the list in the plan's XCD-affine order and writes every score to its place in the caller's order."""

@@ -82,6 +82,8 @@ class Sequential(Layer):
             blob, _, acts = self._packed()
             capi.chain(a, blob, dims, acts, out, ids_a=ids_a, base_a=base_a, B=b, ids_b=ids_b, base_b=base_b)
             return out
+        if isinstance(a, capi.ConcatTable):
+            a = a.materialize()                                 # (only the fused chain reads per-layer tables in place)
         if b is None and base_a == 0:
             x, ids = a, ids_a                                   # the first dense layer gathers by itself
         else:

@@ -2,7 +2,21 @@
 
 The reference is single-device; this layer is new design.  One process per GPU
 (``torch.distributed``, backend ``nccl`` = RCCL over xGMI).  The graph propagation Y = A_hat.X
-is row-separable, the scoring head is pair-separable:
+is row-separable, the scoring head is pair-separable.
+
+GCN stacks of models that know their user / item split run on the TYPED partition (round 3, `TypedPartition` and
+`PartitionedGCNRunner._step_typed`): every node type is cut into `world` blocks of equal height, a rank owns one block of
+each type, and nothing in a rank's step passes over the whole node table except the X_0 . W_1 prologue:
+
+* the fused SpMM layer leaves BOTH its own rows of X_l and its own rows of the next layer's pre-scaled gathered table
+  H_{l+1} = S (X_l W_{l+1}) (epilogue of amar_spmm_lt_f32 / amar_spmm_xs_f32): the exchange per layer is one all-gather of the
+  H_{l+1} block (every rank's SpMM gathers from all of it) plus one all-gather of the ITEM rows of X_l (all the item tower
+  reads), issued asynchronously so that the item-row gathers hide behind the next layer's SpMM and the user tower;
+* the towers read [X_0 || X_1 || ... ] in place from the per-layer tables (capi.ConcatTable -> amar_chain_segments_f32): the
+  user tower over the rank's own users only (pairs are sharded by the SAME user ranges), the item tower over all items;
+* ids stay the reference's ids: the only remapped index space is the column index of the local CSR block.
+
+The other layer kinds (and models without a known user / item split) keep the round-1/2 scheme below:
 
 * rows of A_hat are split into contiguous ranges of (nearly) equal non-zero count, one per rank;
 * node tables live in a *padded* index space: node j owned by rank r at local offset o sits at
@@ -89,6 +103,97 @@ class RowPartition:
             local.mult = a.mult[p0:p1].contiguous()
         return local
 
+class TypedPartition:
+    """Node-range partition of a graph whose ids are grouped by node TYPE (users | items [| properties], loaders.py:43-68).
+
+    Type t with n_t nodes is cut into `world` contiguous blocks of EQUAL HEIGHT h_t = ceil(n_t / world) (only a type's last
+    blocks can be short or empty); rank r owns block r of every type.  A rank's rows, in local order, are
+    [its users | its items | its properties], each padded to h_t rows: R = sum(h_t) rows per rank, and the gathered tables the
+    SpMM reads from are RANK-MAJOR, [world * R, C] — `all_gather_into_tensor` of the ranks' [R, C] blocks lands in place.
+    Node j of type t sits at row  (j' // h_t) * R + off_t + j' % h_t,  j' = j - first id of type t.
+    Because a type's blocks are equally tall, its rows taken out of the ranks' blocks in rank order ARE the type in id order
+    (plus padding at the very end): the all-gather of the item parts of the blocks is the item table in the reference's own
+    item order, and a rank's user rows are a contiguous range of user ids — towers and pair ids need no remapping.
+    Against equal-nnz row ranges (RowPartition) the padded index space is N + O(world) rows instead of 1.3 N at ml1m(s=64);
+    the price is that non-zeros are balanced only as far as degrees are unrelated to id order (`nnz_imbalance`)."""
+
+    def __init__(self, type_bounds, world):
+        tb = [int(b) for b in type_bounds]
+        if len(tb) < 2 or tb[0] != 0 or any(tb[k] > tb[k + 1] for k in range(len(tb) - 1)):
+            raise ValueError("type_bounds must be an ascending list starting at 0")
+        self.tb, self.world, self.n, self.T = tb, int(world), tb[-1], len(tb) - 1
+        self.h = [max(1, -(-(tb[t + 1] - tb[t]) // self.world)) for t in range(self.T)]
+        self.off = [0]
+        for h in self.h:
+            self.off.append(self.off[-1] + h)
+        self.R = self.off[-1]
+
+    def owned(self, rank, t):
+        """[lo, hi) of the ids of type t that rank owns (empty when the type ran out before this rank's block)."""
+        lo = min(self.tb[t] + rank * self.h[t], self.tb[t + 1])
+        return lo, min(lo + self.h[t], self.tb[t + 1])
+
+    def padded_index(self, ids):
+        """Global node ids (int tensor) -> rows of the rank-major [world * R, *] tables."""
+        ids = ids.to(torch.int64)
+        dev = ids.device
+        tb = torch.tensor(self.tb, dtype=torch.int64, device=dev)
+        t = (torch.searchsorted(tb, ids, right=True) - 1).clamp_(0, self.T - 1)
+        h = torch.tensor(self.h, dtype=torch.int64, device=dev)[t]
+        j = ids - tb[t]
+        return (j // h) * self.R + torch.tensor(self.off[:-1], dtype=torch.int64, device=dev)[t] + j % h
+
+    def node_of_row(self, device):
+        """int32 [world * R]: the node id held by every row of the rank-major tables, -1 for padding rows."""
+        out = torch.full((self.world * self.R,), -1, dtype=torch.int32, device=device)
+        ids = torch.arange(self.n, device=device)
+        out[self.padded_index(ids)] = ids.to(torch.int32)
+        return out
+
+    def pad_vector(self, v):
+        """[n] per-node vector -> [world * R] in the rank-major layout (padding rows zero)."""
+        out = torch.zeros(self.world * self.R, dtype=v.dtype, device=v.device)
+        out[self.padded_index(torch.arange(self.n, device=v.device))] = v
+        return out
+
+    def local_block(self, a, rank):
+        """The rank's rows of `a` (a square DeviceCSR over the n nodes) as an [R, world * R] DeviceCSR in local row order, column
+        indices in the rank-major layout; carries what the tiled images need of a row block: `diag_offset` (column of local row 0's
+        own entry), `row_breaks` (local rows where the node type changes), and the value-free factors when `a` has them."""
+        dev = a.rowptr.device
+        rp = a.rowptr.to(torch.int64)
+        deg = torch.zeros(self.R, dtype=torch.int64, device=dev)
+        cols, vals, mult = [], [], []
+        for t in range(self.T):
+            lo, hi = self.owned(rank, t)
+            if hi <= lo:
+                continue
+            p0, p1 = int(rp[lo]), int(rp[hi])
+            deg[self.off[t]:self.off[t] + hi - lo] = rp[lo + 1:hi + 1] - rp[lo:hi]
+            cols.append(self.padded_index(a.colidx[p0:p1]).to(torch.int32))
+            if a.vals is not None:
+                vals.append(a.vals[p0:p1])
+            if getattr(a, 'mult', None) is not None:
+                mult.append(a.mult[p0:p1])
+        rowptr = torch.zeros(self.R + 1, dtype=torch.int64, device=dev)
+        rowptr[1:] = torch.cumsum(deg, 0)
+        empty = torch.zeros(0, dtype=torch.int32, device=dev)
+        local = DeviceCSR(rowptr.to(torch.int32).contiguous(), torch.cat(cols).contiguous() if cols else empty,
+                          (torch.cat(vals).contiguous() if vals else torch.zeros(0, dtype=torch.float32, device=dev)) if a.vals is not None else None,
+                          (self.R, self.world * self.R), gcn_filtered=a.gcn_filtered)
+        local.diag_offset = rank * self.R
+        local.row_breaks = tuple(self.off[1:-1])
+        if getattr(a, 'dinv', None) is not None and getattr(a, 'mult', None) is not None:
+            local.dinv = self.pad_vector(a.dinv).contiguous()
+            local.mult = torch.cat(mult).contiguous() if mult else empty
+        return local
+
+    def nnz_imbalance(self, rowptr):
+        """max over ranks of the rank's non-zero count / the mean: 1.0 = perfectly balanced."""
+        rp = rowptr.to(torch.int64).cpu()
+        per = [sum(int(rp[hi] - rp[lo]) for lo, hi in (self.owned(r, t) for t in range(self.T))) for r in range(self.world)]
+        return max(per) * self.world / max(1, sum(per))
+
 
 class SharedDeviceCollectives:
     """`torch.distributed` stand-in for REHEARSING several ranks on ONE GPU (AMAR_REHEARSE_ONE_GPU=1: a `gloo` process group, every
@@ -133,9 +238,15 @@ class SingleRunner:
         """The same step replayed from a hipGraph (captured on first use, after one eager step): the launch gaps of the eight
         kernels go away.  The graph is valid while the weights keep their storage and the Dense weights their values (packed
         blobs are made on the host): call it between weight updates only, as bench.py does."""
+        state = self.capture_step()
+        state['graph'].replay()
+        return state['out']
+
+    def capture_step(self):
         state = self.__dict__.setdefault('_graph_state', {})
         key = self.model.weights_version
         if state.get('key') != key:
+            state.clear()
             self.step()
             from deep_cbrs_amar_renaissance_amd.engine import capture_graph
 
@@ -144,8 +255,7 @@ class SingleRunner:
                 return self._score(emb)
             state['graph'], state['out'] = capture_graph(body)
             state['key'] = key
-        state['graph'].replay()
-        return state['out']
+        return state
 
     def _score(self, emb):
         # per-entity towers, then gather + classifier per pair (nothing is cached across steps)
@@ -195,6 +305,14 @@ class PartitionedGCNRunner:
         self.hybrid = hasattr(model.rs, 'dense1a')
         self.model, self.seq = model, seq
         a = seq.adj_matrix
+        self._events, self.phase_ms = None, None
+        known_types = getattr(model, 'n_users', None) is not None and getattr(model, 'n_items', None) is not None
+        # GCN stacks with a known user / item split: equal-height blocks per node type, no pass over the whole table but the
+        # X_0 . W_1 prologue (AMAR_PARTITION=rows keeps the equal-nnz row ranges of rounds 1-2 for A/B runs)
+        self.typed = self.kind == 'gcn' and known_types and os.environ.get('AMAR_PARTITION', 'typed') != 'rows'
+        if self.typed:
+            self._init_typed(model, u_ids, i_ids, a)
+            return
         self.part = RowPartition(partition_rows_by_nnz(a.rowptr, world))
         self.csr = self.part.local_csr(a, rank)
         self.local_rows, self.local_nnz = self.csr.shape[0], self.csr.nnz
@@ -240,6 +358,144 @@ class PartitionedGCNRunner:
         if ops is capi and not self.hybrid and os.environ.get('AMAR_PAIR_PLAN', '1') != '0' and self.u_ids.numel() >= (1 << 16):
             from deep_cbrs_amar_renaissance_amd.models.basic import PairPlan
             self.pair_plan = PairPlan(self.u_ids, self.i_ids)          # the rank's pairs, fixed for the runner's lifetime
+
+    # ---- typed partition (GCN stacks) -------------------------------------------------------------------------------------
+    def _init_typed(self, model, u_ids, i_ids, a):
+        nu, ni, n = int(model.n_users), int(model.n_items), int(a.shape[0])
+        if nu + ni > n:
+            raise ValueError("n_users + n_items exceeds the graph's node count")
+        self.part = self.tpart = TypedPartition([0, nu, nu + ni] + ([n] if n > nu + ni else []), self.world)
+        self.csr = self.tpart.local_block(a, self.rank)
+        self.local_rows = sum(hi - lo for lo, hi in (self.tpart.owned(self.rank, t) for t in range(self.tpart.T)))
+        self.local_nnz = self.csr.nnz
+        self.nnz_imbalance = self.tpart.nnz_imbalance(a.rowptr)
+        self.widths = self.seq.layer_widths()
+        dev = u_ids.device
+        self.row_ids = self.tpart.node_of_row(dev)
+        # pairs follow their user: the rank scores the pairs of the users it owns, so its user tower reads its own rows only
+        self.u_lo, self.u_hi = self.tpart.owned(self.rank, 0)
+        self.i_lo, self.n_items = nu, ni
+        mine = torch.nonzero((u_ids >= self.u_lo) & (u_ids < self.u_hi)).view(-1)
+        self.pair_index, self.pair_range = mine, None
+        self.u_ids = u_ids[mine].to(torch.int32).contiguous()            # the reference's ids, unchanged
+        self.i_ids = i_ids[mine].to(torch.int32).contiguous()
+        self.pair_plan = None
+        if self.ops is capi and not self.hybrid and os.environ.get('AMAR_PAIR_PLAN', '1') != '0' and self.u_ids.numel() >= (1 << 16):
+            from deep_cbrs_amar_renaissance_amd.models.basic import PairPlan
+            self.pair_plan = PairPlan(self.u_ids, self.i_ids)
+        # item-row gathers behind the next kernels: only with a real process group (stand-ins copy synchronously)
+        self.async_exchange = self.dist is torch.distributed and os.environ.get('AMAR_EXCHANGE_ASYNC', '1') != '0'
+
+    def _gather(self, out, inp, defer=False):
+        """all_gather_into_tensor of equal blocks; defer=True: issued on the collective's own stream, returns the handle to wait on."""
+        if defer and self.async_exchange:
+            return self.dist.all_gather_into_tensor(out, inp, async_op=True)
+        self.dist.all_gather_into_tensor(out, inp)
+        return None
+
+    def _mark(self, name):
+        if self.timing:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._marks.append((name, e))
+
+    def propagate_typed(self):
+        """One propagation on the typed partition.  Returns (x_local, x_items): per layer l = 1..L the rank's own [R, C_l] block of
+        X_l (local row order: users | items | properties, each padded to its block height) and the all-gathered item rows
+        [world * h_items, C_l] (the reference's item order; rows past n_items are padding).  X_0 is the node table itself."""
+        ops, tp, dev = self.ops, self.tpart, self.seq.embeddings.device
+        layers, widths = list(self.seq.seq_layers), self.widths
+        n_tab, R = self.world * tp.R, tp.R
+        emb = self.seq.embeddings.detach()
+        tiled = [self._use_xs(w) for w in widths[1:]]
+        images = [self.csr.tiled_image(w) if t else None for w, t in zip(widths[1:], tiled)]
+        pre = all(tiled) and all(im.row_scale is not None for im in images)       # the chain of gathered tables stays pre-scaled by d^-1/2
+        h = self._buffer(('h', 0), (n_tab, widths[1]))
+        ops.rowwise_xw(emb, layers[0].kernel, h, row_ids=self.row_ids, row_scale=images[0].col_scale if pre else None)
+        self._mark('prologue')
+        i0, hi_ = tp.off[1], tp.h[1]
+        x_local, x_items, pending = [], [], []
+        for k, layer in enumerate(layers):
+            nxt = layers[k + 1] if k + 1 < len(layers) else None
+            y = self._buffer(('y', k), (R, widths[k + 1]), zero=True)
+            hn = self._buffer(('hl', k + 1), (R, widths[k + 2]), zero=True) if nxt is not None else None
+            if tiled[k]:
+                ops.spmm_xs(images[k], h, y, bias=layer.bias, relu=True, Wnext=nxt.kernel if nxt is not None else None, Hnext=hn,
+                            prescaled=pre, scale_next=pre and nxt is not None)
+            else:
+                ops.gcn_layer(self.csr.rowptr, self.csr.colidx, self.csr.vals, h, layer.bias, y,
+                              Wnext=nxt.kernel if nxt is not None else None, Hnext=hn)
+            self._mark('spmm')
+            wait_h = None
+            if nxt is not None:
+                h = self._buffer(('h', k + 1), (n_tab, widths[k + 2]))
+                wait_h = self._gather(h, hn, defer=True)
+            xi = self._buffer(('xi', k), (self.world * hi_, widths[k + 1]))
+            pending.append(self._gather(xi, y[i0:i0 + hi_], defer=True))
+            if wait_h is not None:
+                wait_h.wait()
+            self._mark('exchange')
+            x_local.append(y)
+            x_items.append(xi)
+        self._pending = [w for w in pending if w is not None]
+        return x_local, x_items
+
+    def wait_exchange(self):
+        """Make the compute stream wait for the item-row gathers still in flight (a no-op with synchronous collectives)."""
+        for w in getattr(self, '_pending', []):
+            w.wait()
+        self._pending = []
+
+    def _step_typed(self):
+        self._marks = []
+        self._mark('start')
+        x_local, x_items = self.propagate_typed()
+        emb = self.seq.embeddings.detach()
+        nu_loc = self.u_hi - self.u_lo
+        u_table = capi.ConcatTable([emb[self.u_lo:self.u_hi]] + [x[:nu_loc] for x in x_local])
+        i_table = capi.ConcatTable([emb[self.i_lo:self.i_lo + self.n_items]] + [x[:self.n_items] for x in x_items])
+        rs = self.model.rs
+        if self.u_ids.numel() == 0:                                    # a rank without users (more ranks than user blocks): nothing to score
+            self.wait_exchange()
+            return torch.empty((0, 1), dtype=torch.float32, device=emb.device)
+        # the user tower runs first: it reads the rank's own rows only and hides the last item-row gather
+        if self.hybrid:
+            bert = self.model.bert_table
+            if bert is None:
+                raise ValueError("the hybrid model needs its BERT table registered (set_bert_table) for the partitioned run")
+            if not rs.built:
+                rs.build_head(self.model.gnn.output_dim(), bert.shape[1])
+            self.wait_exchange()
+            towers = rs.towers(u_table, i_table, bert[self.u_lo:self.u_hi], bert[self.i_lo:self.i_lo + self.n_items])
+            self._mark('towers')
+            out = rs.score_towers(towers, self.u_ids, self.i_ids, self.u_lo, self.i_lo)
+        else:
+            tu = rs.tower('u', u_table)
+            self._mark('user_tower')
+            self.wait_exchange()
+            self._mark('exchange')
+            ti = rs.tower('i', i_table)
+            self._mark('item_tower')
+            kw = {'pair_plan': self.pair_plan} if self.pair_plan is not None else {}
+            out = rs.score_towers((tu, ti, rs.split_ready()), self.u_ids, self.i_ids, self.u_lo, self.i_lo, **kw)
+        self._mark('pairs')
+        return out
+
+    def phase_times(self):
+        """Milliseconds of the last eager step by phase (HIP events on the compute stream): `replicated` = work every rank repeats
+        whatever the world size (X_0 . W_1 over all rows, the item tower), `local` = work that shrinks with it (SpMM blocks, user
+        tower, pair stage), `exchange` = time the compute stream spent issuing and waiting for all-gathers."""
+        if not getattr(self, '_marks', None):
+            return None
+        self._marks[-1][1].synchronize()
+        out = {}
+        for (_, e0), (name, e1) in zip(self._marks[:-1], self._marks[1:]):
+            out[name] = out.get(name, 0.0) + e0.elapsed_time(e1)
+        spmm, pairs = out.get('spmm', 0.0), out.get('pairs', 0.0)
+        return {'local_spmm_ms': spmm, 'exchange_ms': out.get('exchange', 0.0),
+                'replicated_ms': out.get('prologue', 0.0) + out.get('item_tower', 0.0),
+                'user_tower_ms': out.get('user_tower', 0.0), 'towers_ms': out.get('towers', 0.0), 'pair_stage_ms': pairs,
+                'prologue_ms': out.get('prologue', 0.0), 'item_tower_ms': out.get('item_tower', 0.0)}
 
     def _x0_padded(self):
         emb = self.seq.embeddings
@@ -358,18 +614,31 @@ class PartitionedGCNRunner:
         """The same step replayed from a hipGraph, collectives included (at 8 ranks a step is ~0.4 ms of device work behind
         ~0.3 ms of host-side enqueueing: replayed, the host side is one call).  Captured on first use, after one eager step.
         Rehearsed by the builder with one rank only (RCCL all-gather inside the capture: profiles/r2_partitioned_1rank.txt)."""
-        state = self.__dict__.setdefault('_graph_state', {})
-        if 'graph' not in state:
-            self.step()                                              # eager once: lazy image builds, persistent buffers
-            timing, self.timing = self.timing, False                 # no event records inside a capture
-            from deep_cbrs_amar_renaissance_amd.engine import capture_graph
-            g, out = capture_graph(self.step)
-            self.timing = timing
-            state['graph'], state['out'] = g, out
+        state = self.capture_step()
         state['graph'].replay()
         return state['out']
 
+    def capture_step(self):
+        """Capture the step (no replay).  Keyed on the model's weights version: the Dense weights are packed on the host at capture
+        time, so a weight update invalidates the graph.  Several ranks should agree that EVERY rank captured before any of them
+        replays (a replay enqueues collectives the others must match): bench.py all-reduces a flag between the two."""
+        state = self.__dict__.setdefault('_graph_state', {})
+        key = self.model.weights_version
+        if state.get('key') != key:
+            state.clear()
+            self.step()                                              # eager once: lazy image builds, persistent buffers
+            timing, self.timing = self.timing, False                 # no event records inside a capture
+            from deep_cbrs_amar_renaissance_amd.engine import capture_graph
+            try:
+                g, out = capture_graph(self.step)
+            finally:
+                self.timing = timing
+            state['graph'], state['out'], state['key'] = g, out, key
+        return state
+
     def step(self):
+        if self.typed:
+            return self._step_typed()
         if self.timing:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -426,6 +695,9 @@ class PartitionedGCNRunner:
         return self._bert_pad
 
     def last_propagation_ms(self):
+        if self.typed:
+            ph = self.phase_times()
+            return None if ph is None else ph['prologue_ms'] + ph['local_spmm_ms'] + ph['exchange_ms']
         if not self._events:
             return None
         e0, e1 = self._events
@@ -433,6 +705,9 @@ class PartitionedGCNRunner:
         return e0.elapsed_time(e1)
 
     def describe(self):
+        if self.typed:
+            return ('node-range partition over {} GPUs (equal-height blocks per node type, nnz imbalance {:.3f}), per layer one RCCL all-gather of '
+                    'the next gathered table + one of the item rows, pairs sharded by the same user ranges').format(self.world, self.nnz_imbalance)
         return 'node-range partition over {} GPUs (equal nnz), per-layer RCCL all-gather, pairs sharded {}'.format(
             self.world, 'by user range (equal counts)' if self.pair_range is None else 'in contiguous slices')
 

@@ -423,7 +423,8 @@ def _csr_lds_tiled(self, F):
         rows, cols, diag, diag_offset = _unit_entries(self, True)
         col_scale = self.dinv.to(torch.float32).contiguous()
         n = self.shape[0]
-        breaks = tuple(b - diag_offset for b in (_row_breaks_of(self, rows, cols) if not diag_offset else getattr(self, 'row_breaks', None) or ()))
+        # (a row block of a partition carries its type boundaries as LOCAL row numbers: parallel.TypedPartition.local_block)
+        breaks = _row_breaks_of(self, rows, cols) if not hasattr(self, 'diag_offset') else tuple(getattr(self, 'row_breaks', None) or ())
         cache[F] = LdsTiled.build(rows, cols, n, self.shape[1], F, diag, col_scale[diag_offset:diag_offset + n].contiguous(),
                                   col_scale, diag_offset, row_breaks=breaks,
                                   window_entries=int(os.environ['AMAR_LT_WINDOW']) if os.environ.get('AMAR_LT_WINDOW') else None)

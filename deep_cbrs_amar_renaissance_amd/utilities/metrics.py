@@ -64,7 +64,7 @@ def top_k_predictions(predictions, users, items, k=5):
 
 
 def precision_recall_f1_at_k(test_filepath, predictions_filepath, k, sep='\t', short_lists='skip', no_relevant='skip',
-                             relevance_threshold=1.0):
+                             relevance_threshold=1.0, counts=None):
     """Precision / Recall / F1 @k of a top-k predictions file against the test ratings, as `mimir.jar -holdout -cutoff k`
     computes them (metrics.py:60-65) — restated from RiVal's ranking metrics, the library inside the jar
     (net.recommenders.rival.evaluation.metric.ranking.{AbstractRankingMetric,Precision,Recall}; there is no JVM here, so
@@ -83,6 +83,9 @@ def precision_recall_f1_at_k(test_filepath, predictions_filepath, k, sep='\t', s
       takes the aggregated precision and recall), 0 when both are 0.
     `relevance_threshold`: the jar's constant is not recoverable from its call site; with the {0, 1} ratings of every
     dataset in the reference any threshold in (0, 1] gives the same result.
+    `counts` (a dict, optional) receives how many users each mean covers and how many the switches dropped — the defaults are
+    RiVal's behaviour as restated from its source, NOT checked against mimir.jar, so what they exclude is
+    reported with every result.
     """
     if short_lists not in ('skip', 'count') or no_relevant not in ('skip', 'zero'):
         raise ValueError("short_lists must be 'skip' or 'count', no_relevant 'skip' or 'zero'")
@@ -107,11 +110,24 @@ def precision_recall_f1_at_k(test_filepath, predictions_filepath, k, sep='\t', s
     precision = float(np.mean(prec)) if prec else 0.0
     recall = float(np.mean(rec)) if rec else 0.0
     f1 = 2 * precision * recall / (precision + recall) if precision + recall > 0 else 0.0
+    info = {'users_with_predictions': len(listed), 'users_in_precision_mean': len(prec), 'users_in_recall_mean': len(rec),
+            'skipped_short_list': len(listed) - len(users), 'skipped_no_relevant_item': len(users) - len(rec),
+            'short_lists': short_lists, 'no_relevant': no_relevant}
+    if info['skipped_short_list'] or info['skipped_no_relevant_item']:
+        logger.info("P/R/F1@%d of %s: %d users with fewer than %d predictions left out of both means (short_lists='%s'), %d users "
+                    "without a relevant test item left out of the recall mean (no_relevant='%s')", k, predictions_filepath,
+                    info['skipped_short_list'], k, short_lists, info['skipped_no_relevant_item'], no_relevant)
+    if counts is not None:
+        counts.update(info)
     return precision, recall, f1
 
 
-def top_k_metrics(test_filepath, predictions_path):
-    """Write ``results.tsv`` (label, precision, recall, F1) next to every ``predictions*`` file found."""
+def top_k_metrics(test_filepath, predictions_path, short_lists=None, no_relevant=None):
+    """Write ``results.tsv`` (label, precision, recall, F1) next to every ``predictions*`` file found, and ``results_users.tsv``
+    (users in the precision / recall means, users skipped by each switch) beside it.  The switches come from the arguments, else
+    from AMAR_METRICS_SHORT_LISTS / AMAR_METRICS_NO_RELEVANT, else the RiVal defaults ('skip', 'skip')."""
+    short_lists = short_lists or os.environ.get('AMAR_METRICS_SHORT_LISTS', 'skip')
+    no_relevant = no_relevant or os.environ.get('AMAR_METRICS_NO_RELEVANT', 'skip')
     if not os.path.isdir(predictions_path):
         logger.error("Invalid predictions path specified. Unable to run evaluator.")
         return
@@ -120,7 +136,13 @@ def top_k_metrics(test_filepath, predictions_path):
         if not found:
             continue
         cutoff = int(str(root)[root.rfind(os.sep):].split("_")[1])
-        rows = [precision_recall_f1_at_k(test_filepath, os.path.join(root, f), cutoff) for f in found]
+        infos = [{} for _ in found]
+        rows = [precision_recall_f1_at_k(test_filepath, os.path.join(root, f), cutoff, short_lists=short_lists, no_relevant=no_relevant,
+                                         counts=info) for f, info in zip(found, infos)]
         p, r, f1 = np.mean(np.asarray(rows), axis=0)
         pd.DataFrame([["top_{}".format(cutoff), p, r, f1]]).to_csv(
             os.path.join(root, "results.tsv"), sep='\t', header=False, index=False)
+        keys = ['users_with_predictions', 'users_in_precision_mean', 'users_in_recall_mean', 'skipped_short_list', 'skipped_no_relevant_item',
+                'short_lists', 'no_relevant']
+        pd.DataFrame([[f] + [info[key] for key in keys] for f, info in zip(found, infos)], columns=['file'] + keys).to_csv(
+            os.path.join(root, "results_users.tsv"), sep='\t', index=False)

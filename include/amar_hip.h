@@ -45,6 +45,11 @@ extern "C" {
                                     Y[i] = relu(l2_normalize([X_i || mean_i] . Wnext + bias)), Wnext [2F, F] (Cn = F), the tail of
                                     spektral GraphSageConv (src/models/gnn.py:354-361) in the same launch; Hnext (optional, ld ldhn) receives
                                     a second copy of Y: a dense table for the next layer's gathers when Y is a concat slice */
+#define AMAR_SPMM_LT_NOPAIRS 64u /* amar_spmm_lt_f32: the image holds no implicit pairs — every repeat of a virtual row inside a step is
+                                    flagged (utilities/lds_tiled.py, pairs=False: the default for F >= 16) — so the kernel may skip
+                                    the pair logic of a step; an image WITH implicit pairs must not carry this flag */
+#define AMAR_SPMM_LT_TWO_QUADS 128u /* amar_spmm_lt_f32, F = 16 or 32: the image was dealt for F / 8 lanes per entry (utilities/lds_tiled.py,
+                                    quads=2): a lane carries two float4 of its entry, a wave-instruction covers 128 / (F / 4) entries */
 
 typedef void *amar_stream_t;
 
@@ -166,6 +171,14 @@ int amar_rowwise_xw_f32(const float *X, int64_t ldx, int32_t F, const float *W, 
                         const float *a_self, const float *a_neigh, float *s_self, float *s_neigh,
                         const float *row_scale, int32_t n_rows, amar_stream_t stream);
 
+/* The same product with a row gather:  H[p, 0:C] = row_scale[p] . ( X[row_ids[p], 0:F] . W[F, C] ),  p < n_rows
+ * (row_scale NULL: 1; row_ids[p] < 0: a zero row).  The X_0 . W_1 prologue of the SAME call site (src/models/gnn.py:78) when
+ * the gathered table is kept in the rank-major block layout of a node-range partition (parallel.py:TypedPartition): X is the
+ * trainable node table in the reference's id order (users | items [| properties], src/data/loaders.py:43-68), row_ids maps
+ * every row of the block layout to its node (-1 for the padding rows at the end of a type's last block). */
+int amar_rowwise_xw_gather_f32(const float *X, int64_t ldx, int32_t F, const int32_t *row_ids, const float *W, int32_t C,
+                               float *H, int64_t ldh, const float *row_scale, int32_t n_rows, amar_stream_t stream);
+
 /* One GraphSAGE-mean layer (Spektral 1.x GraphSageConv, built at src/models/gnn.py:354-361):
  *     agg_i = ( [self_loop] X_i + sum_{j in N(i)} X_j ) / ( [self_loop] 1 + |N(i)| )
  *     Y_i   = ReLU( l2_normalize( [X_i || agg_i] . W[2F, C] + bias ) )
@@ -246,6 +259,20 @@ int amar_chain_indexed_f32(const float *A, int64_t lda, int32_t Da, const int32_
                            int32_t sum_inputs, int32_t in_act,
                            const float *wpack, const int32_t *dims, const int32_t *acts, int32_t n_layers,
                            float *out, int64_t ldo, const int32_t *out_index, int64_t P, amar_stream_t stream);
+
+/* The per-entity tower form of the chain (one input table, no second table, no trailing 1-unit layer) reading the
+ * `Concatenate` of ReductionLayer('concatenation') (src/layers/reduction.py:15-17; src/models/gnn.py:84) IN PLACE:
+ *     x = [ seg[0][r, 0:w_0] || seg[1][r, 0:w_1] || ... ],   r = ids ? ids[p] - base : p       (HOST arrays of n_seg entries)
+ * so that the [N, d(L+1)] table never has to be assembled — each X_l stays where its layer (or the all-gather of a
+ * node-range partition) left it.  Widths are multiples of 4, their sum <= 128, n_seg <= 8.  Only stacks with a
+ * compile-time tower shape run this way (ReLU layers with an optionally linear last one, every width <= 64, at most three
+ * layers: the towers of every econfig of the reference); other shapes return AMAR_EUNSUPPORTED — the caller then copies the
+ * columns together (amar_copy_columns_f32) and calls amar_chain_f32.  Same arithmetic as amar_chain_f32 on the assembled
+ * table, bit for bit. */
+int amar_chain_segments_f32(const float *const *seg, const int64_t *seg_ld, const int32_t *seg_width, int32_t n_seg,
+                            const int32_t *ids, int32_t base,
+                            const float *wpack, const int32_t *dims, const int32_t *acts, int32_t n_layers,
+                            float *out, int64_t ldo, int64_t P, amar_stream_t stream);
 
 /* Fused two-branch scorer for the hybrid head (src/models/hybrid.py:72-89) once the first Dense layers of
  * dense3a / dense3b have been folded into the per-entity tables:

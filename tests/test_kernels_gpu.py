@@ -907,6 +907,48 @@ def test_spmm_lds_tiled(hip, F, uip, n_cu, window):
     assert rel_err(e.cpu().numpy(), (x + want + A @ want) / 3) < 3e-6
 
 
+@pytest.mark.parametrize('F', [16, 32])
+@pytest.mark.parametrize('pairs,quads', [(True, 1), (False, 1), (True, 2), (False, 2)])
+def test_spmm_lds_tiled_wide_row_forms(hip, F, pairs, quads):
+    """The wide-row forms of the LT walk (F = 16, 32): images without implicit pairs (AMAR_SPMM_LT_NOPAIRS: the step without its pair
+    logic) and images dealt for two float4 per lane (AMAR_SPMM_LT_TWO_QUADS), each with the table dense and as a column slice of a
+    wider buffer, plain and with the fused layer epilogue whose next kernel is staged in LDS.  All forms compute the same sums in
+    the same per-row order of virtual rows: against float64, and against each other within rounding."""
+    from deep_cbrs_amar_renaissance_amd.utilities import lds_tiled
+    from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter_device, _unit_entries
+    g = helpers.tiny_graph(n_users=900, n_items=500, n_ratings=40000, seed=F + quads, n_props=160, n_links=1500)
+    coo = g['adj'].tocoo()
+    keep = coo.row < coo.col
+    rows, cols = torch.from_numpy(coo.row[keep].astype(np.int64)).to(DEV), torch.from_numpy(coo.col[keep].astype(np.int64)).to(DEV)
+    n = coo.shape[0]
+    a = gcn_filter_device(rows, cols, n)
+    r, c, diag, off = _unit_entries(a, True)
+    lt = lds_tiled.LdsTiled.build(r, c, n, n, F, diag, a.dinv, a.dinv, off, n_cu=5, pairs=pairs, quads=quads)
+    assert lt.pairs == pairs and lt.quads == quads
+    A = a.to_scipy().astype(np.float64)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((n, F)).astype(np.float32)
+    b = rng.uniform(-0.5, 0.5, F).astype(np.float32)
+    w2 = rng.uniform(-0.5, 0.5, (F, F)).astype(np.float32)
+    want = A @ x.astype(np.float64)
+    h0 = torch.empty((n, F), device=DEV)
+    hip.row_affine(_t(x), lt.row_scale, h0)
+    wide = torch.zeros((n, F + 8), device=DEV)
+    wide[:, 4:4 + F] = h0
+    for table in (h0, wide[:, 4:4 + F]):                         # dense table: 32-bit shifted offsets; slice: multiply-add offsets
+        y = torch.full((n, F), float('nan'), device=DEV)
+        hip.spmm_lt(lt, table, y, prescaled=True)
+        assert rel_err(y.cpu().numpy(), want) < 2e-6
+        y1, h1 = torch.full((n, F), float('nan'), device=DEV), torch.full((n, F), float('nan'), device=DEV)
+        hip.spmm_lt(lt, table, y1, bias=_t(b), relu=True, Wnext=_t(w2), Hnext=h1, prescaled=True, scale_next=True)
+        w1 = np.maximum(want + b, 0)
+        assert rel_err(y1.cpu().numpy(), w1) < 2e-6
+        assert rel_err(h1.cpu().numpy(), a.dinv.cpu().numpy().astype(np.float64)[:, None] * (w1 @ w2.astype(np.float64))) < 3e-6
+        again = torch.empty_like(y)
+        hip.spmm_lt(lt, table, again, prescaled=True)
+        assert torch.equal(y, again)
+
+
 def test_spmm_lds_tiled_heavy_rows(hip):
     """Rows holding a large share of all entries (long same-row runs inside a window: ranks, flagged atomic adds) and
     rows without any entry."""
@@ -991,6 +1033,70 @@ def test_entity_towers_compile_time_shapes(hip, Da, units, last_act, P):
         for k, b, a in zip(ks, bs, acts):
             x = ol.dense(x, k.astype(np.float64), b.astype(np.float64), a)
         assert rel_err(out_ids.cpu().numpy(), x) < 5e-6
+
+
+@pytest.mark.parametrize('widths,units,last_act', [([8, 8, 8], [24, 24, 48], None), ([16, 16, 16], [48, 48, 64], None), ([8, 8, 8], [24, 24], 'relu'),
+                                                   ([16, 16, 16], [48, 48], 'relu'), ([8, 12], [24, 24, 40], None), ([8], [24, 24, 48], None),
+                                                   ([32, 32, 32], [96, 48, 64], None)])
+@pytest.mark.parametrize('P', [1, 130, 100_003])
+def test_towers_read_per_layer_tables_in_place(hip, widths, units, last_act, P):
+    """amar_chain_segments_f32 (capi.ConcatTable): the towers over [X_0 || X_1 || ...] read from the per-layer tables where
+    they lie — tables with their own leading dimensions, one of them a row slice of a larger buffer — must equal, BIT FOR BIT,
+    the same stack on the assembled table; with and without ids.  Shapes without a segment-reading kernel (96-wide) fall back
+    to assembling inside capi.chain, same result."""
+    rng = np.random.default_rng(sum(widths) + len(units) + P)
+    n = max(P, 300) + 8
+    tabs = [rng.standard_normal((n + 7, w + (4 * j))).astype(np.float32) for j, w in enumerate(widths)]     # padded leading dimensions
+    views = [_t(t)[5:5 + n, :w] if j == 1 else _t(t)[:n, :w] for j, (t, w) in enumerate(zip(tabs, widths))]
+    cat = torch.cat(views, dim=1).contiguous()
+    dims = [sum(widths)] + units
+    ks = [rng.uniform(-0.4, 0.4, (dims[k], dims[k + 1])).astype(np.float32) for k in range(len(units))]
+    bs = [rng.uniform(-0.2, 0.2, dims[k + 1]).astype(np.float32) for k in range(len(units))]
+    acts = ['relu'] * (len(units) - 1) + [last_act]
+    bd = _t(hip.chain_pack(ks, bs)[0])
+    table = hip.ConcatTable(views)
+    assert table.shape == (n, sum(widths)) and torch.equal(table.materialize(), cat)
+    want, got = torch.full((P, units[-1]), float('nan'), device=DEV), torch.full((P, units[-1]), float('nan'), device=DEV)
+    hip.chain(cat, bd, dims, acts, want)
+    hip.chain(table, bd, dims, acts, got)
+    assert torch.equal(got, want)
+    x = cat[:P].cpu().numpy().astype(np.float64)
+    for k, b, a in zip(ks, bs, acts):
+        x = ol.dense(x, k.astype(np.float64), b.astype(np.float64), a)
+    assert rel_err(got.cpu().numpy(), x) < 5e-6
+    ids = _t(rng.integers(40, 40 + n, P).astype(np.int32))                      # gathered rows with a base
+    want_i, got_i = torch.full_like(want, float('nan')), torch.full_like(want, float('nan'))
+    hip.chain(cat, bd, dims, acts, want_i, ids_a=ids, base_a=40)
+    hip.chain(table, bd, dims, acts, got_i, ids_a=ids, base_a=40)
+    assert torch.equal(got_i, want_i)
+    sub = table[3:3 + P]                                                        # a row range of the concatenation
+    got_s = torch.full_like(want, float('nan'))
+    hip.chain(sub, bd, dims, acts, got_s)
+    hip.chain(cat[3:3 + P], bd, dims, acts, want)
+    assert torch.equal(got_s, want)
+
+
+@pytest.mark.parametrize('F,C', [(8, 8), (16, 16), (8, 16), (24, 8)])
+def test_rowwise_xw_row_gather(hip, F, C):
+    """amar_rowwise_xw_gather_f32: H[p] = s[p] . (X[ids[p]] . W), a negative id leaves a zero row — bit-identical to the plain
+    product of the gathered rows followed by the row scale."""
+    rng = np.random.default_rng(F * 7 + C)
+    n, m = 900, 2500
+    x, w = _t(rng.standard_normal((n, F)).astype(np.float32)), _t(rng.standard_normal((F, C)).astype(np.float32))
+    ids_np = rng.integers(0, n, m).astype(np.int32)
+    ids_np[rng.integers(0, m, 60)] = -1
+    ids = _t(ids_np)
+    s = _t(rng.uniform(0.1, 1.0, m).astype(np.float32))
+    for scale in (None, s):
+        h = torch.full((m, C), float('nan'), device=DEV)
+        hip.rowwise_xw(x, w, h, row_ids=ids, row_scale=scale)
+        gathered = x[ids.long().clamp(min=0)].contiguous()
+        ref = torch.empty((m, C), device=DEV)
+        hip.rowwise_xw(gathered, w, ref, row_scale=scale)
+        ref[ids < 0] = 0
+        assert torch.equal(h, ref)
+    with pytest.raises(ValueError):
+        hip.rowwise_xw(x, w, torch.empty((m, C), device=DEV), row_ids=ids, copy_to=torch.empty((m, F), device=DEV))
 
 
 @pytest.mark.parametrize('n,L,width', [(1, 1, 4), (77, 3, 8), (5000, 4, 16), (1234, 8, 12)])

@@ -37,10 +37,11 @@ def walk(lt, xs, rw=None):
     previous slot, plain read-add-writes (which must hit distinct LDS rows), then the flagged adds; epilogue over the
     row's virtual rows."""
     F = lt.F
-    eps, rw, cbits = lds_tiled.geometry(F, rw)
+    quads = getattr(lt, 'quads', 1)
+    eps, rw, cbits = lds_tiled.geometry(F, rw, quads)
     lmask = (1 << (rw - 1).bit_length()) - 1
     W = lds_tiled.WAVES
-    spr = max(1, 16 // (F // 4))
+    spr = max(1, 16 // max(1, F // 4 // quads))
     words = lt.words.numpy().astype(np.int64) & 0xffffffff
     n_rows = lt.shape[0]
     y = np.zeros((n_rows, F), np.float32)
@@ -68,6 +69,9 @@ def walk(lt, xs, rw=None):
                 prev_same[np.arange(eps) % spr == 0] = False
                 paired = prev_same & ~flag
                 real = lrow != rw - 1                                # PAD words (scratch row) may chain: harmless
+                if not getattr(lt, 'pairs', True):                   # AMAR_SPMM_LT_NOPAIRS: the kernel runs no pair logic at all,
+                    assert not (paired & real).any(), "an image built without pairs must flag every repeat of a step"
+                    paired &= False                                  # ... so PAD words are plain adds to the scratch row
                 for j in np.where(paired)[0]:
                     assert not real[j] or (not paired[j - 1] and not flag[j - 1]), "a pair folds into a plain first entry"
                     vals[j - 1] += xs[col[j]]
@@ -107,6 +111,21 @@ def test_lt_image_walk_matches_scipy(F, n_cu, window):
     np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-6)
     # every entry is stored once per unit of multiplicity
     assert lt.n_entries == int(csr.mult.sum()) - int(diag.sum())
+
+
+@pytest.mark.parametrize('F,pairs,quads', [(16, False, 1), (32, False, 1), (16, True, 2), (16, False, 2), (32, False, 2), (32, True, 2), (8, False, 1)])
+def test_lt_image_without_pairs_and_with_two_quads(F, pairs, quads):
+    """The wide-row forms of the image: no implicit pairs (every repeat of a step flagged: AMAR_SPMM_LT_NOPAIRS) and two float4
+    per lane (F / 8 lanes per entry, twice the entries per step: AMAR_SPMM_LT_TWO_QUADS) — same product, same invariants."""
+    csr, a_hat = _gcn_csr(500, 200, 20000, seed=F + 3 * quads + int(pairs))
+    rows, cols, diag, off = _unit_entries(csr, True)
+    n = csr.shape[0]
+    lt = lds_tiled.LdsTiled.build(rows, cols, n, n, F, diag, csr.dinv, csr.dinv, off, n_cu=3, pairs=pairs, quads=quads)
+    assert lt.pairs == pairs and lt.quads == quads and (pairs or lt.n_pairs == 0)
+    assert lds_tiled.geometry(F, quads=quads)[0] == 64 // (F // 4 // quads)
+    x = np.random.default_rng(2).standard_normal((n, F)).astype(np.float32)
+    xs = (csr.dinv.numpy()[:, None] * x).astype(np.float32)
+    np.testing.assert_allclose(walk(lt, xs), a_hat.astype(np.float64) @ x.astype(np.float64), rtol=2e-5, atol=2e-6)
 
 
 def test_lt_image_heavy_row_and_empty_rows():

@@ -18,7 +18,23 @@ GRID2 = dict(GRID1, embedding_dim=16, n_hiddens=[16, 16], dense_units=[48, 48], 
 GRID6 = dict(GRID1, embedding_dim=32, n_hiddens=[32, 32, 32], n_layers=3, dense_units=[128, 64], clf_units=[64, 64])
 
 
-def _score_and_check(model, adj, data, users, items, check_topk=True):
+TOPK_PARITY_JSON = 'gpurun_out/topk_parity.json'     # per case: users without a near-tie, lists differing from the fp32 / fp64 oracle
+TOPK_MAX_DIFFERING = 10                               # observed over all cases and boxes: 0-6 of 6 035 users (profiles/r3_topk_parity.json)
+
+
+def _record_topk_parity(label, k, entry):
+    """Append one case to the JSON the GPU run leaves under gpurun_out/ (copied to profiles/r3_topk_parity.json by the builder)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, TOPK_PARITY_JSON)
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    doc = json.load(open(path)) if os.path.exists(path) else {}
+    doc['{} top-{}'.format(label, k)] = entry
+    json.dump(doc, open(path, 'w'), indent=1, sort_keys=True)
+
+
+def _score_and_check(model, adj, data, users, items, check_topk=True, label=None):
     from deep_cbrs_amar_renaissance_amd.utilities.metrics import top_k_arrays
     u, i = data[:, 0], data[:, 1]
     got = model((u, i)).cpu().numpy()
@@ -46,7 +62,7 @@ def _score_and_check(model, adj, data, users, items, check_topk=True):
             picked = np.array([score_of[(int(a), int(b))] for a, b in zip(got_u, got_i)])
             assert np.abs(picked - o_s).max() < 1e-6, "top-{} differs from the oracle beyond near-ties".format(k)
             differing_users = len(set(got_u[got_i != o_i].tolist()))
-            assert differing_users <= 0.01 * len(set(o_u.tolist())), differing_users
+            assert differing_users <= TOPK_MAX_DIFFERING, differing_users
             # the north star's wording: IDENTICAL lists.  Against the fp32 oracle (the reference computes in fp32 too) with
             # the same deterministic tie rule the lists must agree for every user; the count against the fp64 ranking
             # (near-ties resolved by rounding, not by the algorithm) is reported, not hidden
@@ -74,7 +90,11 @@ def _score_and_check(model, adj, data, users, items, check_topk=True):
             n_users_k = len(gap_ok)
             print('top-{}: {} of {} users have no near-tie (gap > {:.1e}) and get exactly the oracle list; lists differing from the '
                   'fp32 oracle: {}, from the fp64 oracle: {}'.format(k, sum(gap_ok.values()), n_users_k, 2 * err, len(differing_fp32), differing_users))
-            assert sum(gap_ok.values()) >= 0.98 * n_users_k and len(differing_fp32) <= 0.002 * n_users_k
+            _record_topk_parity(label or type(model).__name__, k, {
+                'users': n_users_k, 'users_without_near_tie': int(sum(gap_ok.values())), 'near_tie_gap': 2 * err,
+                'lists_differing_from_fp32_oracle': len(differing_fp32), 'lists_differing_from_fp64_oracle': differing_users,
+                'max_abs_score_error': err, 'pairs': int(len(u))})
+            assert sum(gap_ok.values()) >= 0.98 * n_users_k and len(differing_fp32) <= TOPK_MAX_DIFFERING
     return got
 
 
@@ -87,7 +107,7 @@ def test_basic_gnn_ml1m_grid1(hip, ml1m_s1, name, graph):
     model = getattr(basic, name)(ml1m_s1[graph], **GRID1)
     helpers.randomize_biases(model, seed=11)
     helpers.spread_scores(model)
-    _score_and_check(model, ml1m_s1[graph], ml1m_s1['test'], ml1m_s1['users'], ml1m_s1['items'])
+    _score_and_check(model, ml1m_s1[graph], ml1m_s1['test'], ml1m_s1['users'], ml1m_s1['items'], label='{} {} ml1m(s=1)'.format(name, graph))
 
 
 @pytest.mark.parametrize('name,cfg', [('BasicGCN', GRID2), ('BasicGCN', GRID6), ('BasicGraphSage', GRID6),
@@ -293,7 +313,9 @@ class _LockstepGather:
 
 @pytest.mark.parametrize('world', [1, 2, 4, 8])
 @pytest.mark.parametrize('case', ['BasicGCN', 'BasicGCN-ranges', 'BasicLightGCN', 'HybridBertGCN-uip', 'BasicGCN-xs', 'BasicGCN-xs-valuefree',
-                                  'BasicGraphSage', 'BasicGAT-ranges', 'BasicDGCF'])
+                                  'BasicGraphSage', 'BasicGAT-ranges', 'BasicDGCF',
+                                  # the typed partition (user / item split known) on the tiled forms of its row blocks
+                                  'BasicGCN-ranges-xs', 'BasicGCN-ranges-xs-valuefree', 'BasicGCN-ranges-lt-valuefree', 'BasicGCN-ranges-rows'])
 def test_partitioned_runner_with_real_kernels(hip, world, case, monkeypatch):
     """parallel.PartitionedGCNRunner (node-range partition, padded index space, per-layer gather) driving the real HIP
     kernels: `world` rank threads on one GPU, the collective replaced by an in-process copy.  Scores of every rank's
@@ -322,17 +344,21 @@ def test_partitioned_runner_with_real_kernels(hip, world, case, monkeypatch):
             keep = coo.row < coo.col
             adj = gcn_filter_device(torch.from_numpy(coo.row[keep].astype(np.int64)).cuda(), torch.from_numpy(coo.col[keep].astype(np.int64)).cuda(), coo.shape[0])
         model = getattr(basic, case.split('-')[0])(adj, **GRID1)
-        if case.endswith('-ranges'):
+        if '-ranges' in case:
             model.n_users, model.n_items = 300, 200
         inputs = (u, i)
     helpers.randomize_biases(model, seed=4)
     helpers.spread_scores(model)
     want = model(inputs).cpu().numpy()
     e_want = model.gnn(None).cpu().numpy()
-    if '-xs' in case:
+    if '-xs' in case or '-lt' in case:
         monkeypatch.setenv('AMAR_SPMM_KIND', 'xs')             # the ranks' row blocks on the XCD-sliced kernels
         if not case.endswith('-valuefree'):
             monkeypatch.setenv('AMAR_XS_VALUES', '1')          # ... in their valued form (the host filter keeps the factors too now)
+        if '-lt' in case:
+            monkeypatch.setenv('AMAR_SPMM_LT', '1')            # ... or on the LDS-tiled walk (a graph this small fails the density rule)
+    if case.endswith('-rows'):
+        monkeypatch.setenv('AMAR_PARTITION', 'rows')           # the equal-nnz row ranges of rounds 1-2 for the same model
     fake = _LockstepGather(world)
     results, errors = [None] * world, []
 
@@ -341,13 +367,29 @@ def test_partitioned_runner_with_real_kernels(hip, world, case, monkeypatch):
             torch.cuda.set_device(0)
             fake.local.rank = rank
             runner = parallel.PartitionedGCNRunner(model, u, i, rank, world, dist=fake, timing=False)
-            e_pad = runner.propagate()
-            idx = runner.part.padded_index(torch.arange(e_want.shape[0], device='cuda'))
+            typed_expected = 'GCN' in case and getattr(model, 'n_users', None) is not None and not case.endswith('-rows')
+            assert runner.typed == typed_expected
+            if runner.typed:
+                # per layer: the rank's own block (users first) and the gathered item rows, against the single-GPU table's columns
+                x_local, x_items = runner.propagate_typed()
+                runner.wait_exchange()
+                e_got = np.array(e_want, dtype=np.float64)
+                for k in range(2):
+                    cols = slice(8 * (k + 1), 8 * (k + 2))
+                    e_got[runner.u_lo:runner.u_hi, cols] = x_local[k][:runner.u_hi - runner.u_lo].cpu().numpy()
+                    e_got[300:500, cols] = x_items[k][:200].cpu().numpy()
+                u_rows = (runner.u_lo, runner.u_hi)
+                if '-lt' in case:
+                    assert hasattr(runner.csr.tiled_image(8), 'words')
+            else:
+                e_pad = runner.propagate()
+                idx = runner.part.padded_index(torch.arange(e_want.shape[0], device='cuda'))
+                e_got, u_rows = e_pad[idx].cpu().numpy(), runner.u_rows
             scores = runner.step()
             torch.cuda.synchronize()
             if '-xs' in case and 'GCN' in case:
                 assert runner._use_xs(8) and (runner.csr.xcd_sliced().row_scale is not None) == case.endswith('-valuefree')
-            results[rank] = (e_pad[idx].cpu().numpy(), scores.cpu().numpy(), runner.pair_index.cpu().numpy(), runner.u_rows)
+            results[rank] = (e_got, scores.cpu().numpy(), runner.pair_index.cpu().numpy(), u_rows)
         except Exception as exc:                              # surface thread failures in the main thread
             errors.append(exc)
             fake.barrier.abort()

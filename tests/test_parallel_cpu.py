@@ -28,7 +28,12 @@ class NumpyOps:
         dst.copy_(src)
 
     @staticmethod
-    def rowwise_xw(X, W, H, copy_to=None, **kw):
+    def rowwise_xw(X, W, H, copy_to=None, row_ids=None, row_scale=None, **kw):
+        if row_ids is not None:                                     # amar_rowwise_xw_gather_f32: a negative id leaves a zero row
+            src = X[row_ids.long().clamp(min=0)] * (row_ids >= 0).to(X.dtype)[:, None]
+            h = src @ W.detach()
+            H.copy_(h if row_scale is None else h * row_scale[:, None])
+            return
         H.copy_(X @ W.detach())
         if copy_to is not None:
             copy_to.copy_(X)
@@ -85,6 +90,88 @@ def _worker(rank, world, port, out_dir):
                  e_light=e_light[lrun.part.padded_index(torch.arange(n))].detach().numpy())
     finally:
         dist.destroy_process_group()
+
+
+def _typed_worker(rank, world, port, out_dir):
+    """The typed partition (GCN stack of a model that knows its user / item split): equal-height blocks per node type, per layer one
+    all-gather of the next gathered table and one of the item rows."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from deep_cbrs_amar_renaissance_amd import engine, parallel
+        from deep_cbrs_amar_renaissance_amd.models import basic
+        engine.set_seed(42)
+        g = helpers.tiny_graph(n_users=70, n_items=45, n_ratings=1500, seed=8, n_props=25, n_links=90)
+        model = basic.BasicGCN(g['adj'], **GRID1)
+        model.n_users, model.n_items = g['n_users'], g['n_items']
+        helpers.randomize_biases(model, seed=3)
+        u, i = torch.from_numpy(g['u_ids']), torch.from_numpy(g['i_ids'])
+        runner = parallel.PartitionedGCNRunner(model, u, i, rank, world, ops=NumpyOps, dist=dist, timing=False)
+        assert runner.typed
+        x_local, x_items = runner.propagate_typed()
+        runner.wait_exchange()
+        tp = runner.tpart
+        np.savez(os.path.join(out_dir, 'typed{}.npz'.format(rank)),
+                 owned=np.array([tp.owned(rank, t) for t in range(tp.T)]), off=np.array(tp.off), h=np.array(tp.h),
+                 pair_index=runner.pair_index.numpy(), u_ids=runner.u_ids.numpy(), i_ids=runner.i_ids.numpy(),
+                 nnz=np.array(runner.local_nnz), **{'xl%d' % k: x.numpy() for k, x in enumerate(x_local)},
+                 **{'xi%d' % k: x.numpy() for k, x in enumerate(x_items)})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize('world', [2, 3])
+def test_typed_partition_matches_oracle(tmp_path, world):
+    from oracle import models as om
+    from deep_cbrs_amar_renaissance_amd import engine
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter
+    mp.spawn(_typed_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    engine.set_seed(42)
+    g = helpers.tiny_graph(n_users=70, n_items=45, n_ratings=1500, seed=8, n_props=25, n_links=90)
+    model = basic.BasicGCN(g['adj'], **GRID1)
+    helpers.randomize_biases(model, seed=3)
+    want = om.propagate(g['adj'], helpers.gnn_to_oracle(model.gnn), np.float64)      # [N, 24] = [X_0 || X_1 || X_2]
+    nu, ni = g['n_users'], g['n_items']
+    shards, total_nnz = [], 0
+    for r in range(world):
+        z = np.load(os.path.join(str(tmp_path), 'typed{}.npz'.format(r)))
+        for k in range(2):
+            cols = slice(8 * (k + 1), 8 * (k + 2))
+            # the gathered item rows are the item table in the reference's item order, on every rank
+            assert helpers.rel_err(z['xi%d' % k][:ni], want[nu:nu + ni, cols]) < 1e-5
+            # the rank's own block, type after type at the block offsets
+            for t, (lo, hi) in enumerate(z['owned']):
+                assert helpers.rel_err(z['xl%d' % k][z['off'][t]:z['off'][t] + hi - lo], want[lo:hi, cols]) < 1e-5
+        ulo, uhi = z['owned'][0]
+        assert ((z['u_ids'] >= ulo) & (z['u_ids'] < uhi)).all()                     # pairs follow their user's owner
+        assert np.array_equal(z['u_ids'], g['u_ids'][z['pair_index']]) and np.array_equal(z['i_ids'], g['i_ids'][z['pair_index']])
+        shards.append(z['pair_index'])
+        total_nnz += int(z['nnz'])
+    assert np.array_equal(np.sort(np.concatenate(shards)), np.arange(len(g['u_ids'])))   # every pair scored exactly once
+    assert total_nnz == gcn_filter(g['adj']).nnz
+
+
+def test_typed_partition_layout():
+    from deep_cbrs_amar_renaissance_amd.parallel import TypedPartition
+    for bounds, world in (([0, 70, 115, 140], 4), ([0, 6036, 9228], 8), ([0, 3, 5], 8), ([0, 10, 10, 17], 2)):
+        tp = TypedPartition(bounds, world)
+        n = bounds[-1]
+        ids = torch.arange(n)
+        p = tp.padded_index(ids)
+        assert len(torch.unique(p)) == n and int(p.max()) < world * tp.R
+        assert torch.equal(tp.node_of_row('cpu')[p].long(), ids) and int((tp.node_of_row('cpu') >= 0).sum()) == n
+        for t in range(tp.T):
+            spans = [tp.owned(r, t) for r in range(world)]
+            assert spans[0][0] == bounds[t] and spans[-1][1] == bounds[t + 1]
+            assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:])) and all(hi - lo <= tp.h[t] for lo, hi in spans)
+            # a type's rows, taken out of the blocks in rank order, are the type in id order: block r starts at r * h_t
+            for r, (lo, hi) in enumerate(spans):
+                if hi > lo:
+                    assert lo - bounds[t] == r * tp.h[t]
+                    assert torch.equal(p[lo:hi], r * tp.R + tp.off[t] + torch.arange(hi - lo))
+        assert world * tp.R - n <= sum(world for _ in range(tp.T)) + sum(tp.h)   # padding: O(world) rows per type (+ a short last block)
 
 
 def _free_port():

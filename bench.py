@@ -508,7 +508,7 @@ def wider_layers(dev, scale, steps):
 
 def value_spread(scale):
     """min / max ms per step of the default run over the boxes of the build session (profiles/r3_bench_repeats.json, written by
-    tools/bench_repeats.py from back-to-back bench.py runs on different gpurun boxes), with the csrc/ hash it was measured at."""
+    tools/collect_spread.py from the bench.py lines of different gpurun boxes), with the csrc/ hash it was measured at."""
     path = os.path.join(ROOT, 'profiles', 'r3_bench_repeats.json')
     if not os.path.exists(path):
         return None
@@ -729,7 +729,7 @@ def main():
         image_entry_bytes = {'csr': 8, 'sj': 8, 'xs': 4, 'lt': 4, 'none': 0}[kind]
         out = {
             'metric': '(user,item) pairs scored/sec, ML-1M basic-gnn 2-layer, 1/2/4/8 MI355X',
-            'value': n_pairs * args.steps / dt, 'unit': 'pairs/s',
+            'value': n_pairs * args.steps / dt, 'unit': 'pairs/s', 'csrc_sha': csrc_sha(),
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
             'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'libamar_hip.so')
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 ACT_CODES = {None: ACT_NONE, 'linear': ACT_NONE, 'relu': ACT_RELU, 'sigmoid': ACT_SIGMOID}
-SPMM_BIAS, SPMM_RELU, SPMM_ACCUM, SPMM_ACCUM_DIV, SPMM_SCALE_NEXT, SPMM_SAGE_TAIL, SPMM_LT_NOPAIRS, SPMM_LT_TWO_QUADS = 1, 2, 4, 8, 16, 32, 64, 128
+SPMM_BIAS, SPMM_RELU, SPMM_ACCUM, SPMM_ACCUM_DIV, SPMM_SCALE_NEXT, SPMM_SAGE_TAIL, SPMM_LT_NOPAIRS = 1, 2, 4, 8, 16, 32, 64
 
 _P = ctypes.c_void_p
 _I32, _I64, _U32, _F32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_float
@@ -307,10 +307,6 @@ def spmm_lt(lt, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc
         flags |= SPMM_SCALE_NEXT
     if not getattr(lt, 'pairs', True):
         flags |= SPMM_LT_NOPAIRS
-    if getattr(lt, 'quads', 1) == 2:
-        if sage_tail is not None:
-            raise ValueError("spmm_lt: the GraphSAGE tail runs on one-quad images")
-        flags |= SPMM_LT_TWO_QUADS
     off = lt.diag_offset
     code = load().amar_spmm_lt_f32(
         _ptr(lt.words, torch.int32, 'words'), _ptr(lt.stream_start, torch.int32, 'stream_start'),

@@ -669,15 +669,12 @@ __device__ __forceinline__ int lt_lds_row(int v) {                    // virtual
 // compiled out.  Wide rows are few entries per wave-instruction (F = 32: 8), so a step's fixed instructions weigh 4x what they
 // do at F = 8 (rocprofv3, ml1m(s=64): 32 VALU instructions per 8 entries, the VALU 70 % busy) while repeats inside a step are
 // rare (0.14 % pairs at F = 32): they go to the atomic path instead.
-// VPL = 2 (AMAR_SPMM_LT_TWO_QUADS: an image dealt for F / 8 lanes per entry, utilities/lds_tiled.py `quads=2`): a lane carries TWO
-// float4 of its entry (features 4q.. and 4(q + F/8)..), so a wave-instruction covers twice the entries and a step's index
-// arithmetic, pacing and LDS addressing are paid once per two quads.
-template <int F, int OFF32, bool FUSE_NEXT, int U, int PACE, int ABL = 0, bool GAT = false, bool SAGE = false, bool PAIRS = true, int VPL = 1>
+// (Tried on top of it and not kept, profiles/r3_exp_lt_two_quads.txt: TWO float4 per lane — F / 8 lanes per entry, twice the entries
+// per step — 0.45 / 0.61 ms per ml1m(s=64) product at F = 16 / 32 against 0.30 / 0.485: the LDS read-add-write then moves 32
+// contiguous bytes per entry and instruction instead of 64 / 128 and conflicts more than the saved index arithmetic is worth.)
+template <int F, int OFF32, bool FUSE_NEXT, int U, int PACE, int ABL = 0, bool GAT = false, bool SAGE = false, bool PAIRS = true>
 __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE, AMAR_LT_MIN_WAVES) void spmm_lt_kernel(const LtArgs a) {
-    static_assert(VPL == 1 || (VPL == 2 && F >= 16 && !GAT && ABL == 0), "two quads per lane: plain / fused sums of width 16 or 32");
-    constexpr int LPN = F / 4;                                        // float4 per row (the epilogue's unit)
-    constexpr int LPE = LPN / VPL;                                    // lanes per entry in the walk
-    constexpr int EPS = AMAR_WAVE / LPE, RW = GAT ? lt_gat_rw(F) : LT_TILE_BYTES / (4 * F * LT_WAVES), CS = LT_CHUNK / EPS;
+    constexpr int LPN = F / 4, EPS = AMAR_WAVE / LPN, RW = GAT ? lt_gat_rw(F) : LT_TILE_BYTES / (4 * F * LT_WAVES), CS = LT_CHUNK / EPS;
     constexpr unsigned LMASK = (1u << lt_bits(RW)) - 1u;
     constexpr int G = U - 1;                                          // steps of gathers in flight ahead of the accumulation
     static_assert(CS % U == 0 && G < CS, "register slots of the in-flight steps must be static inside a chunk");
@@ -708,7 +705,7 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE, AMAR_LT_MIN_WAVES) void spmm_
         __syncthreads();
     }
 
-    const int s = lane / LPE, q = lane % LPE;                         // LPE adjacent lanes share an entry
+    const int s = lane / LPN, q = lane % LPN;                         // LPN adjacent lanes share an entry
     const int32_t *stream = a.words + a.stream_start[t * LT_WAVES + wave];
     const int32_t *ws = a.wsteps + ((int64_t)t * LT_WAVES + wave) * a.maxwin1;     // the wave's window table [maxwin1]
     const int nwin = a.n_win[t];
@@ -722,7 +719,6 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE, AMAR_LT_MIN_WAVES) void spmm_
     };
     int wd[U], wn[CS];                                                // words of the steps in flight / of the chunk being issued
     float4 x[U];
-    float4 x2[VPL == 2 ? U : 1];                                      // the lane's second quad (features 4 (q + LPE) ..)
     float bs[GAT ? U : 1];                                            // GAT: s_neigh of the steps in flight
     auto refill = [&](const v4i &pre) {                               // chunk registers -> LDS -> one word per (step, entry slot)
         *reinterpret_cast<v4i *>(ring + 4 * lane) = pre;
@@ -737,11 +733,6 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE, AMAR_LT_MIN_WAVES) void spmm_
         else if (OFF32 == 2) x[slot] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.X) + ((col * (unsigned)F + 4u * q) * 4u));
         else if (OFF32 == 1) x[slot] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.X) + (col * (unsigned)a.ldx + 4u * q) * 4u);
         else x[slot] = *reinterpret_cast<const float4 *>(a.X + (int64_t)col * a.ldx + 4 * q);
-        if constexpr (VPL == 2) {
-            if (OFF32 == 2) x2[slot] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.X) + ((col * (unsigned)F + 4u * (q + LPE)) * 4u));
-            else if (OFF32 == 1) x2[slot] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(a.X) + (col * (unsigned)a.ldx + 4u * (q + LPE)) * 4u);
-            else x2[slot] = *reinterpret_cast<const float4 *>(a.X + (int64_t)col * a.ldx + 4 * (q + LPE));
-        }
         if (GAT) bs[slot] = (ABL & 8) ? 0.25f : *reinterpret_cast<const float *>(reinterpret_cast<const char *>(a.s_neigh) + (uint64_t)col * 4u);
     };
     auto accumulate = [&](int slot) {
@@ -765,42 +756,27 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE, AMAR_LT_MIN_WAVES) void spmm_
         // implicit pair: same virtual row as the previous slot (row_shr: lane l reads l - LPN inside its 16-lane DPP row;
         // the first slot of a DPP row keeps -1) and not flagged -> its values go to that slot's registers, no LDS update
         bool paired = false;
-        float4 xw = VPL == 2 ? x2[VPL == 2 ? slot : 0] : f4_zero();   // the second quad
         if constexpr (PAIRS) {
-            const int prev = __builtin_amdgcn_update_dpp(-1, lrow, 0x110 + LPE, 0xF, 0xF, false);
+            const int prev = __builtin_amdgcn_update_dpp(-1, lrow, 0x110 + LPN, 0xF, 0xF, false);
             paired = prev == lrow && w >= 0;
             const float4 give = paired ? xv : f4_zero();
-            xv.x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.x), 0x100 + LPE, 0xF, 0xF, true));
-            xv.y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.y), 0x100 + LPE, 0xF, 0xF, true));
-            xv.z += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.z), 0x100 + LPE, 0xF, 0xF, true));
-            xv.w += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.w), 0x100 + LPE, 0xF, 0xF, true));
-            if constexpr (VPL == 2) {
-                const float4 give2 = paired ? xw : f4_zero();
-                xw.x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give2.x), 0x100 + LPE, 0xF, 0xF, true));
-                xw.y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give2.y), 0x100 + LPE, 0xF, 0xF, true));
-                xw.z += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give2.z), 0x100 + LPE, 0xF, 0xF, true));
-                xw.w += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give2.w), 0x100 + LPE, 0xF, 0xF, true));
-            }
+            xv.x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.x), 0x100 + LPN, 0xF, 0xF, true));
+            xv.y += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.y), 0x100 + LPN, 0xF, 0xF, true));
+            xv.z += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.z), 0x100 + LPN, 0xF, 0xF, true));
+            xv.w += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, give.w), 0x100 + LPN, 0xF, 0xF, true));
             if (GAT) {
                 const float gw = paired ? wgt : 0.f;
-                wgt += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gw), 0x100 + LPE, 0xF, 0xF, true));
+                wgt += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, gw), 0x100 + LPN, 0xF, 0xF, true));
             }
         }
-        float *yp2 = yp + 4 * LPE;
         if (w >= 0 && !paired) {
             float4 y = *reinterpret_cast<float4 *>(yp);
             y = f4_add(y, xv);
             *reinterpret_cast<float4 *>(yp) = y;
-            if constexpr (VPL == 2) {
-                float4 y2 = *reinterpret_cast<float4 *>(yp2);
-                y2 = f4_add(y2, xw);
-                *reinterpret_cast<float4 *>(yp2) = y2;
-            }
-            if (GAT && !(ABL & 16)) side[lds_row].x = lsum + wgt;     // the LPE lanes of the entry store the same value
+            if (GAT && !(ABL & 16)) side[lds_row].x = lsum + wgt;     // the LPN lanes of the entry store the same value
         }
         if (!(ABL & 1) && w < 0) {                                    // the row occurs earlier in this step: after its plain add
             atomicAdd(yp + 0, xv.x); atomicAdd(yp + 1, xv.y); atomicAdd(yp + 2, xv.z); atomicAdd(yp + 3, xv.w);
-            if constexpr (VPL == 2) { atomicAdd(yp2 + 0, xw.x); atomicAdd(yp2 + 1, xw.y); atomicAdd(yp2 + 2, xw.z); atomicAdd(yp2 + 3, xw.w); }
             if (GAT && q == 0) atomicAdd(&side[lds_row].x, wgt);
         }
     };
@@ -1013,16 +989,14 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE, AMAR_LT_MIN_WAVES) void spmm_
 }
 
 template <int F>
-int launch_spmm_lt(const LtArgs &a, int n_tiles, int off32, bool fuse, int variant, bool sage, bool nopairs, bool two_quads, hipStream_t st) {
-    if (two_quads && F < 16) return AMAR_EINVAL;
+int launch_spmm_lt(const LtArgs &a, int n_tiles, int off32, bool fuse, int variant, bool sage, bool nopairs, hipStream_t st) {
     constexpr int RW = LT_TILE_BYTES / (4 * F * LT_WAVES);
     const size_t lds = (size_t)LT_WAVES * RW * F * 4 + (size_t)LT_WAVES * LT_CHUNK * 4 + 32;
     const dim3 grid((unsigned)n_tiles), block(LT_WAVES * AMAR_WAVE);
 #define AMAR_LT_LAUNCH_S(OFF, FUSE, UU, PP, AA, SS) AMAR_LT_LAUNCH_P(OFF, FUSE, UU, PP, AA, SS, true)
-#define AMAR_LT_LAUNCH_P(OFF, FUSE, UU, PP, AA, SS, PR) AMAR_LT_LAUNCH_V(OFF, FUSE, UU, PP, AA, SS, PR, 1)
-#define AMAR_LT_LAUNCH_V(OFF, FUSE, UU, PP, AA, SS, PR, VV)                                                             \
+#define AMAR_LT_LAUNCH_P(OFF, FUSE, UU, PP, AA, SS, PR)                                                                 \
     do {                                                                                                                 \
-        auto kern = spmm_lt_kernel<F, OFF, FUSE, UU, PP, AA, false, SS, PR, VV>;                                         \
+        auto kern = spmm_lt_kernel<F, OFF, FUSE, UU, PP, AA, false, SS, PR>;                                             \
         static bool allowed[AMAR_MAX_DEVICES] = {};                                                                      \
         if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(kern), lds, allowed)) return rc;               \
         hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                               \
@@ -1061,18 +1035,12 @@ int launch_spmm_lt(const LtArgs &a, int n_tiles, int off32, bool fuse, int varia
         }
     }
     if constexpr (F >= 16) {
-        if (two_quads) {                                              // an image dealt for F / 8 lanes per entry
-            if (off32 == 0 || sage) return AMAR_EUNSUPPORTED;
-            if (nopairs) {
-                if (off32 == 2) { if (fuse) AMAR_LT_LAUNCH_V(2, true, 4, 1, 0, false, false, 2); else AMAR_LT_LAUNCH_V(2, false, 4, 1, 0, false, false, 2); }
-                else { if (fuse) AMAR_LT_LAUNCH_V(1, true, 4, 1, 0, false, false, 2); else AMAR_LT_LAUNCH_V(1, false, 4, 1, 0, false, false, 2); }
-            } else {
-                if (off32 == 2) { if (fuse) AMAR_LT_LAUNCH_V(2, true, 4, 1, 0, false, true, 2); else AMAR_LT_LAUNCH_V(2, false, 4, 1, 0, false, true, 2); }
-                else { if (fuse) AMAR_LT_LAUNCH_V(1, true, 4, 1, 0, false, true, 2); else AMAR_LT_LAUNCH_V(1, false, 4, 1, 0, false, true, 2); }
-            }
-            return amar_check_launch();
-        }
         if (nopairs && off32 != 0) {                                  // an image without implicit pairs: the lean step (see PAIRS above)
+            static const int uenv = getenv("AMAR_LT_U") ? atoi(getenv("AMAR_LT_U")) : 0;      // development: steps of gathers in flight
+            if (uenv == 8 && off32 == 2) {
+                if (fuse) AMAR_LT_LAUNCH_P(2, true, 8, 1, 0, false, false); else AMAR_LT_LAUNCH_P(2, false, 8, 1, 0, false, false);
+                return amar_check_launch();
+            }
             if (off32 == 2) { if (fuse) AMAR_LT_LAUNCH_P(2, true, 4, 1, 0, false, false); else AMAR_LT_LAUNCH_P(2, false, 4, 1, 0, false, false); }
             else { if (fuse) AMAR_LT_LAUNCH_P(1, true, 4, 1, 0, false, false); else AMAR_LT_LAUNCH_P(1, false, 4, 1, 0, false, false); }
             return amar_check_launch();
@@ -1084,7 +1052,6 @@ int launch_spmm_lt(const LtArgs &a, int n_tiles, int off32, bool fuse, int varia
 #undef AMAR_LT_LAUNCH
 #undef AMAR_LT_LAUNCH_S
 #undef AMAR_LT_LAUNCH_P
-#undef AMAR_LT_LAUNCH_V
     return amar_check_launch();
 }
 
@@ -1946,15 +1913,15 @@ int amar_spmm_lt_f32(const int32_t *words, const int32_t *stream_start, const in
     a.e.acc_div = acc_div; a.e.accum = accum ? 1 : 0; a.e.accum_div = (flags & AMAR_SPMM_ACCUM_DIV) ? 1 : 0;
     a.e.Wn = Wnext; a.e.Cn = Cn; a.e.Hn = Hnext; a.e.ldhn = ldhn; a.e.n_rows = n_rows;
     const int off32 = (int64_t)n_cols * ldx * 4 < (int64_t(1) << 32) ? (ldx == F ? 2 : 1) : 0;
-    const bool nopairs = (flags & AMAR_SPMM_LT_NOPAIRS) != 0, two_quads = (flags & AMAR_SPMM_LT_TWO_QUADS) != 0;
+    const bool nopairs = (flags & AMAR_SPMM_LT_NOPAIRS) != 0;
     const char *venv = getenv("AMAR_LT_VARIANT");               // development switch (tools/exp_lt.py)
     const int variant = venv ? atoi(venv) : 0;
     hipStream_t st = static_cast<hipStream_t>(stream);
     switch (F) {
-    case 4:  return launch_spmm_lt<4>(a, n_tiles, off32, Wnext != nullptr && !sage, variant, sage, nopairs, two_quads, st);
-    case 8:  return launch_spmm_lt<8>(a, n_tiles, off32, Wnext != nullptr && !sage, variant, sage, nopairs, two_quads, st);
-    case 16: return launch_spmm_lt<16>(a, n_tiles, off32, Wnext != nullptr && !sage, variant, sage, nopairs, two_quads, st);
-    default: return launch_spmm_lt<32>(a, n_tiles, off32, Wnext != nullptr && !sage, variant, sage, nopairs, two_quads, st);
+    case 4:  return launch_spmm_lt<4>(a, n_tiles, off32, Wnext != nullptr && !sage, variant, sage, nopairs, st);
+    case 8:  return launch_spmm_lt<8>(a, n_tiles, off32, Wnext != nullptr && !sage, variant, sage, nopairs, st);
+    case 16: return launch_spmm_lt<16>(a, n_tiles, off32, Wnext != nullptr && !sage, variant, sage, nopairs, st);
+    default: return launch_spmm_lt<32>(a, n_tiles, off32, Wnext != nullptr && !sage, variant, sage, nopairs, st);
     }
 }
 

@@ -273,6 +273,47 @@ class Model(Layer):
     def _hoist_end(self):
         pass
 
+    # -- weights export / import -----------------------------------------------------------------
+    def keras_variable_names(self):
+        """[(name, parameter)] for every weight, named as Keras names variables of a subclassed model: '<layer name>/<variable>:0',
+        the layer name being Keras' automatic one — the class name in snake_case with a per-class counter in creation order
+        ('dense', 'dense_1', ..., 'gcn_conv', 'gcn_conv_1', 'sequential_gnn').  The reference keeps its trained models through
+        mlflow.tensorflow.autolog() (utilities/utils.py:108); its checkpoints are not available here, so these strings follow
+        Keras' naming rules as documented, not a file of the reference."""
+        import re
+        counters, out = {}, []
+        for module in self.modules():
+            own = list(module.named_parameters(recurse=False))
+            if not own:
+                continue
+            base = re.sub(r'(?<=[a-z0-9])(?=[A-Z])|(?<=[A-Z])(?=[A-Z][a-z])', '_', type(module).__name__).lower()
+            k = counters.get(base, 0)
+            counters[base] = k + 1
+            layer = base if k == 0 else '{}_{}'.format(base, k)
+            out.extend(('{}/{}:0'.format(layer, name), prm) for name, prm in own)
+        return out
+
+    def save_weights(self, path):
+        """Write every weight to an .npz archive keyed by `keras_variable_names()` (fp32, host byte order)."""
+        arrays = {name: prm.detach().cpu().numpy() for name, prm in self.keras_variable_names()}
+        np.savez(path if str(path).endswith('.npz') else str(path) + '.npz', **arrays)
+
+    def load_weights(self, path):
+        """Read the archive `save_weights` wrote into this model's weights (same architecture: names and shapes must match).
+        Every weight's version counter moves, so hoisted tables, packed Dense blobs and captured graphs are rebuilt on next use."""
+        z = np.load(path if str(path).endswith('.npz') else str(path) + '.npz')
+        names = self.keras_variable_names()
+        missing = [n for n, _ in names if n not in z.files]
+        extra = sorted(set(z.files) - {n for n, _ in names})
+        if missing or extra:
+            raise ValueError("load_weights: the archive does not match this model (missing {}, unexpected {})".format(missing[:4], extra[:4]))
+        with torch.no_grad():
+            for name, prm in names:
+                value = z[name]
+                if tuple(value.shape) != tuple(prm.shape):
+                    raise ValueError("load_weights: {} is {} in the archive, {} in the model".format(name, tuple(value.shape), tuple(prm.shape)))
+                prm.copy_(torch.from_numpy(np.ascontiguousarray(value, dtype=np.float32)).to(prm.device))
+
     def evaluate(self, sequence, **kwargs):
         """Loss and accuracy on `sequence` (experiment.py:194).  As Keras' evaluate(), 'loss' is the binary cross-entropy plus
         the regularisation losses of the model (l2 * sum(w^2) for every weight carrying a regulariser: gnn.py:45,293-294),

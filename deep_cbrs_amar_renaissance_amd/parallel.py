@@ -565,7 +565,13 @@ class PartitionedGCNRunner:
                     s_neigh = torch.empty(self.world * R, dtype=torch.float32, device=dev)
                     ops.rowwise_xw(x_full, layer.kernel.view(-1, c), h, a_self=layer.attn_kernel_self.view(c),
                                    a_neigh=layer.attn_kernel_neighs.view(c), s_self=s_self, s_neigh=s_neigh)
-                    ops.gat_xs(self.csr.xcd_sliced(), h, s_self, s_neigh, layer.bias, y_local[:rows], self_loop=layer.add_self_loops)
+                    # the rank's row block on the LDS-tiled walk where its density allows (amar_gat_lt_f32 takes a block whose own
+                    # rows sit at a column offset, like the plain sum), else on the XCD-sliced online-softmax form
+                    lt = self.csr.tiled_gat_image(c)
+                    if lt is not None:
+                        ops.gat_lt(lt, self.csr, h, s_self, s_neigh, layer.bias, y_local[:rows], self_loop=layer.add_self_loops)
+                    else:
+                        ops.gat_xs(self.csr.xcd_sliced(), h, s_self, s_neigh, layer.bias, y_local[:rows], self_loop=layer.add_self_loops)
                 x_full = torch.empty((self.world * R, c), dtype=torch.float32, device=dev)
                 self.dist.all_gather_into_tensor(x_full, y_local)
                 ops.copy_columns(x_full, e_all[:, offs[k + 1]:offs[k + 2]])

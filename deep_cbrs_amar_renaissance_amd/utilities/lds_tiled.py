@@ -57,18 +57,12 @@ COST_ENTRY, COST_LINE = 1.68, 1.71   # cycles per entry / per 128-byte line of X
 GAT_ROWS_PER_WAVE = {8: 216, 16: 124, 32: 64}      # amar_gat_lt_f32: the LDS row also holds (sum of weights, s_self) — csrc lt_gat_rw
 
 
-def geometry(F, rw=None, quads=1):
-    """(entries per step, rows per wave in the LDS tile, column bits) for feature width F (rw: a smaller tile, GAT mode;
-    quads: float4 per lane in the walk — 2 halves the lanes per entry, AMAR_SPMM_LT_TWO_QUADS)."""
-    eps = 64 // max(1, F // 4 // quads)
+def geometry(F, rw=None):
+    """(entries per step, rows per wave in the LDS tile, column bits) for feature width F (rw: a smaller tile, GAT mode)."""
+    eps = 64 // (F // 4)
     rw = TILE_BYTES // (4 * F * WAVES) if rw is None else int(rw)
     lbits = (rw - 1).bit_length()
     return eps, rw, 31 - lbits
-
-
-def default_quads(F):
-    """float4 per lane of the walk for the plain / GCN / GraphSAGE images of width F (measured: see DESIGN.md 4a)."""
-    return 1
 
 
 def _run_starts(first, idx):
@@ -85,7 +79,7 @@ def supported(F, n_cols, rw=None):
 
 class LdsTiled:
     def __init__(self, F, words, stream_start, wsteps, tile_row0, n_win, maxwin1, vstart, vcount, diag, row_scale, col_scale,
-                 diag_offset, shape, window_entries, n_entries, n_flagged, n_pairs, rw=None, pairs=True, quads=1):
+                 diag_offset, shape, window_entries, n_entries, n_flagged, n_pairs, rw=None, pairs=True):
         self.F, self.words, self.stream_start, self.wsteps = F, words, stream_start, wsteps
         self.tile_row0, self.n_win, self.maxwin1 = tile_row0, n_win, int(maxwin1)
         self.vstart, self.vcount = vstart, vcount
@@ -93,18 +87,17 @@ class LdsTiled:
         self.shape = tuple(shape)
         self.rw = int(rw) if rw is not None else geometry(F)[1]        # LDS rows per wave the image was cut for
         self.pairs = bool(pairs)                                       # False: every repeat inside a step is flagged (AMAR_SPMM_LT_NOPAIRS)
-        self.quads = int(quads)                                        # float4 per lane the image was dealt for (2: AMAR_SPMM_LT_TWO_QUADS)
         self.n_tiles = int(n_win.numel())
         self.window_entries, self.n_entries, self.n_flagged, self.n_pairs = int(window_entries), int(n_entries), int(n_flagged), int(n_pairs)
         # the waves of a tile meet at a barrier every `pace_every` windows: windows of ONE step per wave keep the dealing span (and
         # with it the L1 footprint) small — 24 M L2 requests per ml1m(s=64) layer against 28 M for two-step windows — while a barrier
         # per four of them costs no more synchronisation than before (0.2136 against 0.2200 ms)
-        steps = max(1, self.window_entries // (WAVES * geometry(F, quads=self.quads)[0]))
+        steps = max(1, self.window_entries // (WAVES * (64 // (F // 4))))
         self.pace_every = int(os.environ.get('AMAR_LT_PACE', 4 if steps == 1 else (2 if steps == 2 else 1)))
 
     @classmethod
     def build(cls, rows, cols, n_rows, n_cols, F, diag, row_scale, col_scale, diag_offset=0, window_entries=None, n_cu=N_CU,
-              split=SPLIT, balance=True, row_breaks=(), rw=None, split_growth=2.0, pairs=None, quads=None):
+              split=SPLIT, balance=True, row_breaks=(), rw=None, split_growth=2.0, pairs=None):
         """`rows`/`cols`: int64 device tensors of the unit-weight off-diagonal entries (multiplicities expanded).
         `rw`: LDS rows per wave when the tile is smaller than the plain sum's (GAT mode); `split_growth`: factor by which the
         virtual-row length grows while the tiles do not fit the LDS (longer virtual rows repeat more often inside a step).
@@ -116,9 +109,7 @@ class LdsTiled:
         dev = rows.device
         W = WAVES
         rw_arg = rw
-        if quads is None:                                             # AMAR_LT_QUADS=2: development switch (A/B of the two-quads walk)
-            quads = int(os.environ.get('AMAR_LT_QUADS', default_quads(F))) if rw_arg is None and F >= 16 else 1
-        eps, rw, cbits = geometry(F, rw, quads)
+        eps, rw, cbits = geometry(F, rw)
         if not supported(F, n_cols, rw):
             raise ValueError("LT image: F = {} with {} columns is outside the packed word's range".format(F, n_cols))
         vmax = W * (rw - 1)                                           # virtual rows a tile can hold
@@ -252,7 +243,9 @@ class LdsTiled:
             # s=64 (~2 300) .218 / .222 / .238, s=128 .540 / .546 / .570
             avg_v = float(vcount.double().mean()) if T else 0.0
             steps = 1 if avg_v >= 0.4 * vmax and F == 8 else (2 if avg_v >= 0.2 * vmax else 4)
-            window_entries = max(steps * W * eps, 1024 if F >= 16 else 0)   # F = 16, 32 at s=64: 1 024 entries (.33 / .58 ms) beat 512 / 256 (.35 / .70)
+            # F = 16, 32 at s=64: 1 024 entries (.33 / .58 ms) beat 512 / 256 (.35 / .70); round 3, the step without pair logic: F = 32
+            # 1 024 / 2 048 / 4 096 entries .493 / .445 / .445 ms, F = 16 .297 / .302 (profiles/r3_exp_lt_nopairs_windows.txt)
+            window_entries = max(steps * W * eps, 2048 if F >= 32 and rw_arg is None else (1024 if F >= 16 else 0))   # (GAT geometry: as tuned)
         # b. windows + the virtual row of every entry: both from the tile's column-sorted order
         order = torch.argsort(tile * n_cols + cols)
         tile_cnt = torch.bincount(tile, minlength=T)
@@ -294,7 +287,7 @@ class LdsTiled:
         # d. inside every step: the first entry of a virtual row is plain; the one in the next slot (same DPP row) is an implicit
         #    pair; every other repeat is flagged
         step, slot = dest // eps, dest % eps
-        spr = max(1, 16 // max(1, F // 4 // quads))                    # entry slots per 16-lane DPP row
+        spr = max(1, 16 // (F // 4))                                   # entry slots per 16-lane DPP row
         o4 = torch.argsort((step * rw + lrow_s) * eps + slot)
         g4 = (step * rw + lrow_s)[o4]
         s4 = slot[o4]
@@ -329,4 +322,4 @@ class LdsTiled:
         return cls(F, words, stream_start.to(torch.int32), wsteps.to(torch.int32).contiguous(),
                    tb_t.to(torch.int32), n_win.to(torch.int32), maxwin + 1, vstart.to(torch.int32).contiguous(),
                    vcount.to(torch.int32).contiguous(), diag, row_scale, col_scale, diag_offset,
-                   (n_rows, n_cols), window_entries, m, n_flagged, n_pairs, rw, pairs=pairs, quads=quads)
+                   (n_rows, n_cols), window_entries, m, n_flagged, n_pairs, rw, pairs=pairs)

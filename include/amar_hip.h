@@ -48,8 +48,6 @@ extern "C" {
 #define AMAR_SPMM_LT_NOPAIRS 64u /* amar_spmm_lt_f32: the image holds no implicit pairs — every repeat of a virtual row inside a step is
                                     flagged (utilities/lds_tiled.py, pairs=False: the default for F >= 16) — so the kernel may skip
                                     the pair logic of a step; an image WITH implicit pairs must not carry this flag */
-#define AMAR_SPMM_LT_TWO_QUADS 128u /* amar_spmm_lt_f32, F = 16 or 32: the image was dealt for F / 8 lanes per entry (utilities/lds_tiled.py,
-                                    quads=2): a lane carries two float4 of its entry, a wave-instruction covers 128 / (F / 4) entries */
 
 typedef void *amar_stream_t;
 

@@ -55,6 +55,21 @@ def main():
     runner = parallel.PartitionedGCNRunner(model, u, i, rank, world, dist=parallel.SharedDeviceCollectives(rank, world) if rehearse else None)
     for _ in range(2):                                               # twice: persistent buffers are reused by the second step
         scores = runner.step()
+    graph_ok = True
+    if not rehearse:
+        # the step replayed from a hipGraph, RCCL all-gathers included, must give the eager step's bits; a weight update must
+        # invalidate the captured graph (its Dense weights are packed on the host at capture time)
+        eager = scores.clone()
+        for _ in range(2):
+            replayed = runner.step_graphed()
+        graph_ok = bool(torch.equal(replayed, eager))
+        with torch.no_grad():
+            model.rs.clf.layers[-1].bias.add_(0.25)
+        moved = runner.step().clone()
+        graph_ok = graph_ok and bool(torch.equal(runner.step_graphed(), moved)) and not bool(torch.equal(moved, eager))
+        with torch.no_grad():
+            model.rs.clf.layers[-1].bias.sub_(0.25)
+        scores = runner.step()
     # every rank scored its shard; collect (pair position, score) on all ranks
     cdev = torch.device('cpu') if rehearse else dev                 # gloo gathers host tensors
     counts = [torch.zeros(1, dtype=torch.int64, device=cdev) for _ in range(world)]
@@ -88,8 +103,10 @@ def main():
         ok = bool((seen == 1).all()) and err < 1e-4
         print('{} world {} case {}: every pair scored once: {}, max |score - oracle| = {:.2e}, {}'.format(
             'one-GPU rehearsal (gloo)' if rehearse else 'nccl', world, case, bool((seen == 1).all()), err, runner.describe()), flush=True)
-    flag = torch.tensor([1 if ok else 0], device=cdev)
-    dist.broadcast(flag, 0)
+    if not graph_ok:
+        print('rank {}: the graph-replayed step differs from the eager one (or survived a weight update)'.format(rank), flush=True)
+    flag = torch.tensor([1 if (ok and graph_ok) else 0], device=cdev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     dist.destroy_process_group()
     sys.exit(0 if int(flag.item()) == 1 else 1)
 

@@ -411,3 +411,32 @@ def test_experiment_grid_expansion_reproduces_the_reference_functions_own_output
     for case in z['log_keys']:                                       # the parameter names a run is logged under (experiment.py:149)
         got = utils.mlflow_linearize(copy.deepcopy(case['input']))
         assert got == case['output'] and list(got) == list(case['output'])
+
+
+def test_weights_roundtrip_through_npz(tmp_path):
+    """Model.save_weights / load_weights (what mlflow.tensorflow.autolog keeps for the reference, utils.py:108): an .npz keyed by
+    Keras-style variable names; a rebuilt model of the same architecture takes the values back, bit for bit, and every weight's
+    version counter moves (hoisted tables and captured graphs are invalidated); a different architecture is refused."""
+    import torch
+    from deep_cbrs_amar_renaissance_amd import engine
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    from tests import helpers
+    g = helpers.tiny_graph()
+    cfg = dict(embedding_dim=8, n_hiddens=[8, 8], dense_units=[24, 24], clf_units=[48, 48])
+    engine.set_seed(1)
+    a = basic.BasicGCN(g['adj'], **cfg)
+    helpers.randomize_biases(a, seed=2)
+    names = [n for n, _ in a.keras_variable_names()]
+    assert len(names) == len(set(names)) == len(list(a.parameters()))
+    assert 'sequential_gnn/embeddings:0' in names and 'gcn_conv_1/kernel:0' in names and 'dense/kernel:0' in names and 'dense_6/bias:0' in names
+    path = str(tmp_path / 'weights')
+    a.save_weights(path)
+    engine.set_seed(99)
+    b = basic.BasicGCN(g['adj'], **cfg)
+    assert not all(torch.equal(p, q) for p, q in zip(a.parameters(), b.parameters()))
+    before = b.weights_version
+    b.load_weights(path)
+    assert all(torch.equal(p, q) for p, q in zip(a.parameters(), b.parameters())) and b.weights_version != before
+    other = basic.BasicGCN(g['adj'], **dict(cfg, n_hiddens=[8, 8, 8]))
+    with pytest.raises(ValueError):
+        other.load_weights(path)

@@ -908,23 +908,22 @@ def test_spmm_lds_tiled(hip, F, uip, n_cu, window):
 
 
 @pytest.mark.parametrize('F', [16, 32])
-@pytest.mark.parametrize('pairs,quads', [(True, 1), (False, 1), (True, 2), (False, 2)])
-def test_spmm_lds_tiled_wide_row_forms(hip, F, pairs, quads):
-    """The wide-row forms of the LT walk (F = 16, 32): images without implicit pairs (AMAR_SPMM_LT_NOPAIRS: the step without its pair
-    logic) and images dealt for two float4 per lane (AMAR_SPMM_LT_TWO_QUADS), each with the table dense and as a column slice of a
-    wider buffer, plain and with the fused layer epilogue whose next kernel is staged in LDS.  All forms compute the same sums in
-    the same per-row order of virtual rows: against float64, and against each other within rounding."""
+@pytest.mark.parametrize('pairs', [True, False])
+def test_spmm_lds_tiled_wide_row_forms(hip, F, pairs):
+    """The wide-row forms of the LT walk (F = 16, 32): images with and without implicit pairs (AMAR_SPMM_LT_NOPAIRS: the step without
+    its pair logic), each with the table dense and as a column slice of a wider buffer, plain and with the fused layer epilogue whose
+    next kernel is staged in LDS: against float64."""
     from deep_cbrs_amar_renaissance_amd.utilities import lds_tiled
     from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter_device, _unit_entries
-    g = helpers.tiny_graph(n_users=900, n_items=500, n_ratings=40000, seed=F + quads, n_props=160, n_links=1500)
+    g = helpers.tiny_graph(n_users=900, n_items=500, n_ratings=40000, seed=F + int(pairs), n_props=160, n_links=1500)
     coo = g['adj'].tocoo()
     keep = coo.row < coo.col
     rows, cols = torch.from_numpy(coo.row[keep].astype(np.int64)).to(DEV), torch.from_numpy(coo.col[keep].astype(np.int64)).to(DEV)
     n = coo.shape[0]
     a = gcn_filter_device(rows, cols, n)
     r, c, diag, off = _unit_entries(a, True)
-    lt = lds_tiled.LdsTiled.build(r, c, n, n, F, diag, a.dinv, a.dinv, off, n_cu=5, pairs=pairs, quads=quads)
-    assert lt.pairs == pairs and lt.quads == quads
+    lt = lds_tiled.LdsTiled.build(r, c, n, n, F, diag, a.dinv, a.dinv, off, n_cu=5, pairs=pairs)
+    assert lt.pairs == pairs
     A = a.to_scipy().astype(np.float64)
     rng = np.random.default_rng(3)
     x = rng.standard_normal((n, F)).astype(np.float32)

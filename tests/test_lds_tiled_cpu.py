@@ -37,11 +37,10 @@ def walk(lt, xs, rw=None):
     previous slot, plain read-add-writes (which must hit distinct LDS rows), then the flagged adds; epilogue over the
     row's virtual rows."""
     F = lt.F
-    quads = getattr(lt, 'quads', 1)
-    eps, rw, cbits = lds_tiled.geometry(F, rw, quads)
+    eps, rw, cbits = lds_tiled.geometry(F, rw)
     lmask = (1 << (rw - 1).bit_length()) - 1
     W = lds_tiled.WAVES
-    spr = max(1, 16 // max(1, F // 4 // quads))
+    spr = max(1, 16 // (F // 4))
     words = lt.words.numpy().astype(np.int64) & 0xffffffff
     n_rows = lt.shape[0]
     y = np.zeros((n_rows, F), np.float32)
@@ -113,16 +112,15 @@ def test_lt_image_walk_matches_scipy(F, n_cu, window):
     assert lt.n_entries == int(csr.mult.sum()) - int(diag.sum())
 
 
-@pytest.mark.parametrize('F,pairs,quads', [(16, False, 1), (32, False, 1), (16, True, 2), (16, False, 2), (32, False, 2), (32, True, 2), (8, False, 1)])
-def test_lt_image_without_pairs_and_with_two_quads(F, pairs, quads):
-    """The wide-row forms of the image: no implicit pairs (every repeat of a step flagged: AMAR_SPMM_LT_NOPAIRS) and two float4
-    per lane (F / 8 lanes per entry, twice the entries per step: AMAR_SPMM_LT_TWO_QUADS) — same product, same invariants."""
-    csr, a_hat = _gcn_csr(500, 200, 20000, seed=F + 3 * quads + int(pairs))
+@pytest.mark.parametrize('F,pairs', [(16, False), (32, False), (16, True), (32, True), (8, False)])
+def test_lt_image_without_pairs(F, pairs):
+    """The wide-row form of the image: no implicit pairs (every repeat of a step flagged: AMAR_SPMM_LT_NOPAIRS, the default from
+    F = 16 on) — same product, same invariants."""
+    csr, a_hat = _gcn_csr(500, 200, 20000, seed=F + int(pairs))
     rows, cols, diag, off = _unit_entries(csr, True)
     n = csr.shape[0]
-    lt = lds_tiled.LdsTiled.build(rows, cols, n, n, F, diag, csr.dinv, csr.dinv, off, n_cu=3, pairs=pairs, quads=quads)
-    assert lt.pairs == pairs and lt.quads == quads and (pairs or lt.n_pairs == 0)
-    assert lds_tiled.geometry(F, quads=quads)[0] == 64 // (F // 4 // quads)
+    lt = lds_tiled.LdsTiled.build(rows, cols, n, n, F, diag, csr.dinv, csr.dinv, off, n_cu=3, pairs=pairs)
+    assert lt.pairs == pairs and (pairs or lt.n_pairs == 0)
     x = np.random.default_rng(2).standard_normal((n, F)).astype(np.float32)
     xs = (csr.dinv.numpy()[:, None] * x).astype(np.float32)
     np.testing.assert_allclose(walk(lt, xs), a_hat.astype(np.float64) @ x.astype(np.float64), rtol=2e-5, atol=2e-6)

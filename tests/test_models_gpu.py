@@ -315,7 +315,8 @@ class _LockstepGather:
 @pytest.mark.parametrize('case', ['BasicGCN', 'BasicGCN-ranges', 'BasicLightGCN', 'HybridBertGCN-uip', 'BasicGCN-xs', 'BasicGCN-xs-valuefree',
                                   'BasicGraphSage', 'BasicGAT-ranges', 'BasicDGCF',
                                   # the typed partition (user / item split known) on the tiled forms of its row blocks
-                                  'BasicGCN-ranges-xs', 'BasicGCN-ranges-xs-valuefree', 'BasicGCN-ranges-lt-valuefree', 'BasicGCN-ranges-rows'])
+                                  'BasicGCN-ranges-xs', 'BasicGCN-ranges-xs-valuefree', 'BasicGCN-ranges-lt-valuefree', 'BasicGCN-ranges-rows',
+                                  'BasicGAT-ranges-lt', 'BasicGraphSage-lt'])
 def test_partitioned_runner_with_real_kernels(hip, world, case, monkeypatch):
     """parallel.PartitionedGCNRunner (node-range partition, padded index space, per-layer gather) driving the real HIP
     kernels: `world` rank threads on one GPU, the collective replaced by an in-process copy.  Scores of every rank's
@@ -351,7 +352,9 @@ def test_partitioned_runner_with_real_kernels(hip, world, case, monkeypatch):
     helpers.spread_scores(model)
     want = model(inputs).cpu().numpy()
     e_want = model.gnn(None).cpu().numpy()
-    if '-xs' in case or '-lt' in case:
+    if case in ('BasicGAT-ranges-lt', 'BasicGraphSage-lt'):
+        monkeypatch.setenv('AMAR_SPMM_LT', '1')                # edge-list row blocks on the LDS-tiled walk (amar_gat_lt_f32 / the mean image)
+    elif '-xs' in case or '-lt' in case:
         monkeypatch.setenv('AMAR_SPMM_KIND', 'xs')             # the ranks' row blocks on the XCD-sliced kernels
         if not case.endswith('-valuefree'):
             monkeypatch.setenv('AMAR_XS_VALUES', '1')          # ... in their valued form (the host filter keeps the factors too now)
@@ -566,3 +569,35 @@ def test_predict_replayed_from_graph_equals_eager(hip, ml1m_s1, name):
     seq2 = UserItemGraph(ml1m_s1['test'][9000:12500], ml1m_s1['users'], ml1m_s1['items'], ml1m_s1['adj_ui'], batch_size=1024, shuffle=False)
     assert np.array_equal(model.predict(seq2), model.predict(seq2, graph=False))
     assert model.__dict__['_predict_graph'][1] is not graph_obj
+
+
+@pytest.mark.parametrize('name', ['BasicGCN', 'BasicGAT', 'HybridBertGCN'])
+def test_saved_weights_give_the_same_scores_after_reload(hip, name, tmp_path):
+    """save_weights -> a freshly built model -> load_weights: identical scores (torch.equal), also through the graph-replayed
+    predict path, which must notice the new weights."""
+    from deep_cbrs_amar_renaissance_amd import engine
+    from deep_cbrs_amar_renaissance_amd.models import basic, hybrid
+    g = helpers.tiny_graph(n_users=120, n_items=80, n_ratings=3000, seed=5)
+    rng = np.random.default_rng(1)
+    bert = rng.standard_normal((200, 40)).astype(np.float32)
+
+    def build(seed):
+        engine.set_seed(seed)
+        if name.startswith('Hybrid'):
+            m = hybrid.HybridBertGCN(g['adj'], **dict(GRID1, dense_units=[[24, 24], [32, 16], [16, 16]], clf_units=[16, 16], feature_based=True))
+            m.set_bert_table(bert)
+            m.rs.build_head(m.gnn.output_dim(), 40)
+        else:
+            m = getattr(basic, name)(g['adj'], **GRID1)
+        return m
+    u, i = torch.from_numpy(g['u_ids']).cuda(), torch.from_numpy(g['i_ids']).cuda()
+    inputs = (u, i, None, None) if name.startswith('Hybrid') else (u, i)
+    a = build(3)
+    helpers.randomize_biases(a, seed=4)
+    want = a(inputs)
+    a.save_weights(str(tmp_path / 'w.npz'))
+    b = build(77)
+    stale = b(inputs)
+    assert not torch.equal(stale, want)
+    b.load_weights(str(tmp_path / 'w.npz'))
+    assert torch.equal(b(inputs), want)

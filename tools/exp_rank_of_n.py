@@ -43,20 +43,25 @@ def main():
     perm = torch.randperm(data['test'].shape[0], device=dev, generator=g)
     u = data['test'][perm, 0].to(torch.int32).contiguous()
     i = data['test'][perm, 1].to(torch.int32).contiguous()
-    single = parallel.SingleRunner(model, u, i)
-    for _ in range(3):
-        single.step_graphed()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(20):
-        single.step_graphed()
-    torch.cuda.synchronize()
-    t1 = (time.perf_counter() - t0) / 20
+    if os.environ.get('EXP_SINGLE_MS'):                    # (profiling runs: skip the single-GPU leg, EXP_RANKS picks the ranks)
+        t1 = float(os.environ['EXP_SINGLE_MS']) * 1e-3
+    else:
+        single = parallel.SingleRunner(model, u, i)
+        for _ in range(40):
+            single.step_graphed()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            single.step_graphed()
+        torch.cuda.synchronize()
+        t1 = (time.perf_counter() - t0) / 20
+        del single
     print('ml1m(s=%d): single GPU %.4f ms per step (graph-replayed)' % (scale, 1e3 * t1), flush=True)
     for world in worlds:
-        for rank in sorted({0, world // 2, world - 1}):
+        ranks = [int(r) for r in os.environ['EXP_RANKS'].split(',')] if os.environ.get('EXP_RANKS') else sorted({0, world // 2, world - 1})
+        for rank in ranks:
             runner = parallel.PartitionedGCNRunner(model, u, i, rank, world, dist=LocalCopy(rank), timing=False)
-            for _ in range(3):
+            for _ in range(40):
                 runner.step_graphed()
             torch.cuda.synchronize()
             t0 = time.perf_counter()

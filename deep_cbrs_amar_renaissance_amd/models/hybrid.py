@@ -129,13 +129,15 @@ class HybridCBRS(Model):
         return (len(self.dense3a.layers) >= 2 and len(self.dense3b.layers) >= 2 and max(d3) <= capi.CHAIN_MAX_WIDTH
                 and all(u % 4 == 0 for u in d3))
 
-    def towers(self, ug_table, ig_table, ub_table, ib_table):
+    def towers(self, ug_table, ig_table, ub_table, ib_table, ib_done=None):
         """Per-ENTITY outputs of the four first-stage networks (row-wise independent, hence hoistable); when the
-        fused chain can run the second stage, each table is further multiplied by its half of dense3a/3b's first layer."""
+        fused chain can run the second stage, each table is further multiplied by its half of dense3a/3b's first layer.
+        ib_done: the item-side BERT table of the result, already computed (`item_bert_part` over row blocks, gathered by the
+        partitioned runner): `ib_table` is then not read."""
         t = [self.dense1a.apply2(ug_table), self.dense1b.apply2(ig_table),
-             self.dense2a.apply2(ub_table), self.dense2b.apply2(ib_table)]
+             self.dense2a.apply2(ub_table), self.dense2b.apply2(ib_table) if ib_done is None else None]
         if not self._can_fold():
-            return (t[0], t[1], t[2], t[3], False)
+            return (t[0], t[1], t[2], t[3] if ib_done is None else ib_done, False)
         if self.feature_based:
             pairs = ((0, 1, self.dense3a), (2, 3, self.dense3b))          # x1 = dense3a([ug || ig]), x2 = dense3b([ub || ib])
         else:
@@ -144,11 +146,28 @@ class HybridCBRS(Model):
         for ia, ib, net in pairs:
             wa, wb, bias, _, _ = self._fold(None, None, net, t[ia].shape[1])
             ya = torch.empty((t[ia].shape[0], wa.shape[1]), dtype=torch.float32, device=wa.device)
-            yb = torch.empty((t[ib].shape[0], wb.shape[1]), dtype=torch.float32, device=wb.device)
             capi.dense(t[ia], wa, None, ya, act=None)
+            folded[ia] = ya
+            if ib == 3 and ib_done is not None:
+                folded[ib] = ib_done
+                continue
+            yb = torch.empty((t[ib].shape[0], wb.shape[1]), dtype=torch.float32, device=wb.device)
             capi.dense(t[ib], wb, bias, yb, act=None)
-            folded[ia], folded[ib] = ya, yb
+            folded[ib] = yb
         return (folded[0], folded[1], folded[2], folded[3], True)
+
+    def item_bert_part(self, ib_rows):
+        """The item-side BERT table `towers` would hold for these rows — dense2b, then (when the second stage is folded) its half of
+        dense3b's first layer with the bias — on ANY block of item rows: row-wise independent, so a node-partitioned run computes
+        it on every rank's own items and gathers the blocks instead of every rank running the 768-wide tower over all items."""
+        t3 = self.dense2b.apply2(ib_rows)
+        if not self._can_fold():
+            return t3
+        d_first = self.dense2a.output_units if self.feature_based else self.dense1b.output_units
+        _, wb, bias, _, _ = self._fold(None, None, self.dense3b, d_first)
+        yb = torch.empty((t3.shape[0], wb.shape[1]), dtype=torch.float32, device=wb.device)
+        capi.dense(t3, wb, bias, yb, act=None)
+        return yb
 
     def _rest(self, net):
         """Packed remaining layers (after the folded first one) of dense3a / dense3b, cached per weight version."""

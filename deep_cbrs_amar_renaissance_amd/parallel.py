@@ -446,9 +446,33 @@ class PartitionedGCNRunner:
             w.wait()
         self._pending = []
 
+    def _item_bert_sharded(self):
+        """Hybrid heads: the item-side BERT tower (768 -> 256 -> 64 at econfigs/hybrid-gnn*.yaml: 0.8 ms over all items of ml1m(s=64))
+        on the rank's OWN items only, its [h_items, D] block gathered — issued first thing in the step on the collective's stream: it
+        depends on no layer and hides behind the whole propagation.  Returns (handle or None, full table view [n_items, D])."""
+        rs, tp = self.model.rs, self.tpart
+        bert = self.model.bert_table
+        lo, hi = tp.owned(self.rank, 1)
+        hi_ = tp.h[1]
+        part = rs.item_bert_part(bert[lo:hi]) if hi > lo else None
+        width = int(part.shape[1]) if part is not None else int(rs.item_bert_part(bert[self.i_lo:self.i_lo + 1]).shape[1])
+        blk = self._buffer(('ibl', width), (hi_, width), zero=True)
+        if part is not None:
+            self.ops.copy_columns(part, blk[:hi - lo])
+        full = self._buffer(('ibf', width), (self.world * hi_, width))
+        return self._gather(full, blk, defer=True), full[:self.n_items]
+
     def _step_typed(self):
         self._marks = []
         self._mark('start')
+        ib_wait = ib_full = None
+        if self.hybrid and os.environ.get('AMAR_HYBRID_ITEM_TOWER', 'sharded') == 'sharded':      # (every rank takes part: it is a collective)
+            if self.model.bert_table is None:
+                raise ValueError("the hybrid model needs its BERT table registered (set_bert_table) for the partitioned run")
+            if not self.model.rs.built:
+                self.model.rs.build_head(self.model.gnn.output_dim(), self.model.bert_table.shape[1])
+            ib_wait, ib_full = self._item_bert_sharded()
+            self._mark('item_bert')
         x_local, x_items = self.propagate_typed()
         emb = self.seq.embeddings.detach()
         nu_loc = self.u_hi - self.u_lo
@@ -457,6 +481,8 @@ class PartitionedGCNRunner:
         rs = self.model.rs
         if self.u_ids.numel() == 0:                                    # a rank without users (more ranks than user blocks): nothing to score
             self.wait_exchange()
+            if ib_wait is not None:
+                ib_wait.wait()
             return torch.empty((0, 1), dtype=torch.float32, device=emb.device)
         # the user tower runs first: it reads the rank's own rows only and hides the last item-row gather
         if self.hybrid:
@@ -466,7 +492,9 @@ class PartitionedGCNRunner:
             if not rs.built:
                 rs.build_head(self.model.gnn.output_dim(), bert.shape[1])
             self.wait_exchange()
-            towers = rs.towers(u_table, i_table, bert[self.u_lo:self.u_hi], bert[self.i_lo:self.i_lo + self.n_items])
+            if ib_wait is not None:
+                ib_wait.wait()
+            towers = rs.towers(u_table, i_table, bert[self.u_lo:self.u_hi], bert[self.i_lo:self.i_lo + self.n_items], ib_done=ib_full)
             self._mark('towers')
             out = rs.score_towers(towers, self.u_ids, self.i_ids, self.u_lo, self.i_lo)
         else:
@@ -494,7 +522,7 @@ class PartitionedGCNRunner:
         spmm, pairs = out.get('spmm', 0.0), out.get('pairs', 0.0)
         return {'local_spmm_ms': spmm, 'exchange_ms': out.get('exchange', 0.0),
                 'replicated_ms': out.get('prologue', 0.0) + out.get('item_tower', 0.0),
-                'user_tower_ms': out.get('user_tower', 0.0), 'towers_ms': out.get('towers', 0.0), 'pair_stage_ms': pairs,
+                'user_tower_ms': out.get('user_tower', 0.0), 'towers_ms': out.get('towers', 0.0) + out.get('item_bert', 0.0), 'pair_stage_ms': pairs,
                 'prologue_ms': out.get('prologue', 0.0), 'item_tower_ms': out.get('item_tower', 0.0)}
 
     def _x0_padded(self):

@@ -3,7 +3,8 @@
 sources with -DAMAR_LT_STAMPS (the shipped library carries no stamps), runs one image and prints, per node-type segment, the
 tiles' zeroing / walk / epilogue / total cycles and the slowest tiles.
     python tools/exp_lt_stamps.py build                      (no GPU needed: hipcc cross-compiles)
-    python tools/exp_lt_stamps.py <ui|uip|gat> [scale] [F]   (on the GPU box)"""
+    python tools/exp_lt_stamps.py <ui|uip|gat> [scale] [F]   (on the GPU box)
+    python tools/exp_lt_stamps.py block [scale] [F] [world] [rank]      one rank's row block of the typed partition"""
 import ctypes
 import os
 import subprocess
@@ -44,7 +45,19 @@ def main():
     a = gcn_filter_device(rows, cols, n)
     x = torch.randn((n, F), device=dev)
     y = torch.empty((n, F), device=dev)
-    if what == 'gat':
+    if what == 'block':
+        from deep_cbrs_amar_renaissance_amd.parallel import TypedPartition
+        world = int(sys.argv[4]) if len(sys.argv) > 4 else 8
+        rank = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+        tp = TypedPartition([0, data['n_users'], n], world)
+        blk = tp.local_block(a, rank)
+        img = blk.tiled_image(F)
+        x = torch.randn((world * tp.R, F), device=dev)
+        y = torch.empty((tp.R, F), device=dev)
+        run = lambda: capi.spmm_xs(img, x, y, prescaled=True)
+        breaks = blk.row_breaks
+        n = tp.R
+    elif what == 'gat':
         from tools.exp_gat_lt import edge_csr
         os.environ['AMAR_SPMM_LT'] = '1'
         e = edge_csr(data, dev)

@@ -4,32 +4,22 @@ The reference is single-device; this layer is new design.  One process per GPU
 (``torch.distributed``, backend ``nccl`` = RCCL over xGMI).  The graph propagation Y = A_hat.X
 is row-separable, the scoring head is pair-separable.
 
-GCN stacks of models that know their user / item split run on the TYPED partition (round 3, `TypedPartition` and
-`PartitionedGCNRunner._step_typed`): every node type is cut into `world` blocks of equal height, a rank owns one block of
-each type, and nothing in a rank's step passes over the whole node table except the X_0 . W_1 prologue:
+`TypedPartition`: every node TYPE (users | items [| properties]; one type when the model does not know its split) is cut into
+`world` blocks of equal height, a rank owns one block of each type.  `PartitionedGCNRunner` runs a step on it so that nothing
+passes over the whole node table except the layer-1 prologue:
 
-* the fused SpMM layer leaves BOTH its own rows of X_l and its own rows of the next layer's pre-scaled gathered table
-  H_{l+1} = S (X_l W_{l+1}) (epilogue of amar_spmm_lt_f32 / amar_spmm_xs_f32): the exchange per layer is one all-gather of the
-  H_{l+1} block (every rank's SpMM gathers from all of it) plus one all-gather of the ITEM rows of X_l (all the item tower
-  reads), issued asynchronously so that the item-row gathers hide behind the next layer's SpMM and the user tower;
+* the table a layer gathers from is made by the PRODUCER of the previous layer from its own rows and all-gathered in a rank-major
+  layout — GCN: H_{l+1} = S (X_l W_{l+1}) straight out of the fused SpMM's epilogue (amar_spmm_lt_f32 / amar_spmm_xs_f32);
+  LightGCN: S X_l; DGCF: X_l sigmoid(w_{l+1}); GraphSAGE: X_l; GAT: X_l W_{l+1} with its neighbour scalars;
+* the ITEM rows of every X_l (all the item tower reads) are gathered on the side, asynchronously: they hide behind the next
+  layer's SpMM and the user tower; 'mean' stacks accumulate on the rank's own rows and gather the items' mean once;
 * the towers read [X_0 || X_1 || ... ] in place from the per-layer tables (capi.ConcatTable -> amar_chain_segments_f32): the
-  user tower over the rank's own users only (pairs are sharded by the SAME user ranges), the item tower over all items;
+  user tower over the rank's own users only (pairs follow their user's owner), the item tower over all items; hybrid heads run
+  the item-side BERT tower on the rank's own items and gather its output;
 * ids stay the reference's ids: the only remapped index space is the column index of the local CSR block.
 
-The other layer kinds (and models without a known user / item split) keep the round-1/2 scheme below:
-
-* rows of A_hat are split into contiguous ranges of (nearly) equal non-zero count, one per rank;
-* node tables live in a *padded* index space: node j owned by rank r at local offset o sits at
-  row r*R + o (R = largest range), so that ``all_gather_into_tensor`` of equal [R, C] shards
-  lands directly in the layout the next SpMM gathers from — the local CSR's column indices are
-  remapped once, at partition time, and no compaction pass is needed;
-* per GCN layer: ONE local SpMM kernel (bias + ReLU fused), then ONE all-gather of the layer's own
-  [R, C] output block (the bipartite id grouping means every rank needs nearly all rows of the
-  other node type, so a plain all-gather beats a sparse halo exchange); the gathered block is both
-  the layer's slice of the final node table and the input of the next layer's tiny X.W, which every
-  rank recomputes for all rows (replicated weights) rather than exchanging a second block;
-* the weights (node table included) are replicated, so the X_0.W_1 prologue needs no exchange;
-* every rank then holds the whole [N, F_cat] table and scores its contiguous 1/G slice of the pairs.
+(Rounds 1-2 split rows into equal-nnz ranges in a padded index space, gathered every layer's own block and re-ran X.W over the
+whole table on every rank: DESIGN.md 6 keeps the numbers.)
 
 ``ops`` is the kernel provider (the ctypes binding by default); tests inject a CPU stand-in to
 exercise the partition / exchange logic under ``gloo`` without a GPU.
@@ -48,61 +38,6 @@ from deep_cbrs_amar_renaissance_amd.layers.lightgcn_conv import LightGCNConv
 from deep_cbrs_amar_renaissance_amd.utilities.math import DeviceCSR
 
 
-def partition_rows_by_nnz(rowptr, world):
-    """Boundaries b[0..world] of contiguous row ranges with (nearly) equal non-zero counts."""
-    rowptr = rowptr.to(torch.int64)
-    n = rowptr.numel() - 1
-    nnz = int(rowptr[-1])
-    targets = torch.arange(1, world, dtype=torch.int64, device=rowptr.device) * nnz // world
-    cuts = torch.searchsorted(rowptr, targets, right=False).clamp_(0, n)
-    bounds = [0] + [int(c) for c in cuts.cpu()] + [n]
-    for k in range(1, len(bounds)):                      # monotone even for degenerate inputs
-        bounds[k] = max(bounds[k], bounds[k - 1])
-    return bounds
-
-
-class RowPartition:
-    def __init__(self, bounds):
-        self.bounds = list(bounds)
-        self.world = len(bounds) - 1
-        self.n = bounds[-1]
-        self.R = max(1, max(bounds[k + 1] - bounds[k] for k in range(self.world)))
-        # round the shard height up so that every shard base stays 16-byte aligned for any width
-        self.R = (self.R + 3) // 4 * 4
-
-    def rows(self, rank):
-        return self.bounds[rank + 1] - self.bounds[rank]
-
-    def padded_index(self, ids):
-        """Global node ids (int tensor) -> rows of the padded [world*R, *] tables."""
-        b = torch.tensor(self.bounds, dtype=torch.int64, device=ids.device)
-        ids = ids.to(torch.int64)
-        owner = torch.searchsorted(b, ids, right=True) - 1
-        owner.clamp_(0, self.world - 1)
-        return owner * self.R + (ids - b[owner])
-
-    def pad_table(self, table):
-        """[n, C] table in global order -> [world*R, C] padded layout (padding rows zero)."""
-        out = torch.zeros((self.world * self.R, table.shape[1]), dtype=table.dtype, device=table.device)
-        idx = self.padded_index(torch.arange(self.n, device=table.device))
-        out[idx] = table
-        return out
-
-    def local_csr(self, a, rank):
-        """Rows [b_r, b_{r+1}) of `a` with column indices remapped to the padded space."""
-        lo, hi = self.bounds[rank], self.bounds[rank + 1]
-        rp = a.rowptr[lo:hi + 1].to(torch.int64)
-        p0, p1 = int(rp[0]), int(rp[-1])
-        colidx = self.padded_index(a.colidx[p0:p1]).to(torch.int32).contiguous()
-        vals = a.vals[p0:p1].contiguous() if a.vals is not None else None
-        local = DeviceCSR((rp - p0).to(torch.int32).contiguous(), colidx, vals, (hi - lo, self.world * self.R),
-                          gcn_filtered=a.gcn_filtered)
-        local.diag_offset = rank * self.R                            # padded column of local row 0's own entry
-        if getattr(a, 'dinv', None) is not None and getattr(a, 'mult', None) is not None:
-            local.dinv = self.pad_table(a.dinv.view(-1, 1)).view(-1).contiguous()      # over the padded columns
-            local.mult = a.mult[p0:p1].contiguous()
-        return local
-
 class TypedPartition:
     """Node-range partition of a graph whose ids are grouped by node TYPE (users | items [| properties], loaders.py:43-68).
 
@@ -114,7 +49,7 @@ class TypedPartition:
     Because a type's blocks are equally tall, its rows taken out of the ranks' blocks in rank order ARE the type in id order
     (plus padding at the very end): the all-gather of the item parts of the blocks is the item table in the reference's own
     item order, and a rank's user rows are a contiguous range of user ids — towers and pair ids need no remapping.
-    Against equal-nnz row ranges (RowPartition) the padded index space is N + O(world) rows instead of 1.3 N at ml1m(s=64);
+    Against the equal-nnz row ranges of rounds 1-2 the padded index space is N + O(world) rows instead of 1.3 N at ml1m(s=64);
     the price is that non-zeros are balanced only as far as degrees are unrelated to id order (`nnz_imbalance`)."""
 
     def __init__(self, type_bounds, world):
@@ -275,9 +210,9 @@ class SingleRunner:
 
 
 class PartitionedGCNRunner:
-    """Basic* / HybridBert* models with a GCN ('concatenation') or LightGCN ('mean') stack over `world` ranks:
-    row-range SpMM + per-layer all-gather, per-entity towers (item tower replicated, user tower over the rank's own user
-    range), scoring of the pairs of that user range."""
+    """Basic* / HybridBert* models with a GCN / GraphSAGE / GAT ('concatenation') or LightGCN / DGCF ('mean') stack over `world`
+    ranks on the typed partition: the rank's row block of every layer, per layer one all-gather of the next gathered table and
+    one of the item rows, user tower over the rank's own users, item tower over all items, scoring of the pairs of its users."""
 
     def __init__(self, model, u_ids, i_ids, rank, world, ops=capi, dist=None, timing=True):
         self.ops, self.rank, self.world, self.timing = ops, rank, world, timing
@@ -305,66 +240,17 @@ class PartitionedGCNRunner:
         self.hybrid = hasattr(model.rs, 'dense1a')
         self.model, self.seq = model, seq
         a = seq.adj_matrix
-        self._events, self.phase_ms = None, None
-        known_types = getattr(model, 'n_users', None) is not None and getattr(model, 'n_items', None) is not None
-        # GCN stacks with a known user / item split: equal-height blocks per node type, no pass over the whole table but the
-        # X_0 . W_1 prologue (AMAR_PARTITION=rows keeps the equal-nnz row ranges of rounds 1-2 for A/B runs)
-        self.typed = self.kind == 'gcn' and known_types and os.environ.get('AMAR_PARTITION', 'typed') != 'rows'
-        if self.typed:
-            self._init_typed(model, u_ids, i_ids, a)
-            return
-        self.part = RowPartition(partition_rows_by_nnz(a.rowptr, world))
-        self.csr = self.part.local_csr(a, rank)
-        self.local_rows, self.local_nnz = self.csr.shape[0], self.csr.nnz
-        self.widths = seq.layer_widths()
-        # replicated node table in the padded layout (rebuilt when the weights change)
-        self._x0_version, self._x0p = None, None
-        self._events = None
-        p = int(u_ids.numel())
+        self.typed = True                      # (one partition scheme since round 3: equal-height blocks per node type)
+        n = int(a.shape[0])
         known = getattr(model, 'n_users', None) is not None and getattr(model, 'n_items', None) is not None
-        if known and world > 1 and os.environ.get('AMAR_PAIR_SHARDING', 'user') == 'user':
-            # Pairs sharded BY USER RANGE (equal pair counts): the user tower of a rank then only covers its own 1/world of the
-            # users (the item tower stays replicated), instead of every rank running both towers over all entities — at 8 ranks
-            # the replicated towers are ~15 % of the step.  `pair_index` = positions of the rank's pairs in the caller's list;
-            # inside the shard the order is re-shuffled (seeded), so no gather locality is bought by the sort.
-            order = torch.argsort(u_ids.to(torch.int64), stable=True)
-            lo, hi = p * rank // world, p * (rank + 1) // world
-            mine = order[lo:hi]
-            gen = torch.Generator(device=mine.device)
-            gen.manual_seed(1234 + rank)
-            mine = mine[torch.randperm(mine.numel(), device=mine.device, generator=gen)]
-            self.pair_index, self.pair_range = mine, None
-        else:
-            # this rank's contiguous slice of the pair list
-            lo, hi = p * rank // world, p * (rank + 1) // world
-            self.pair_index = torch.arange(lo, hi, device=u_ids.device)
-            self.pair_range = (lo, hi)
-        my_u, my_i = u_ids[self.pair_index], i_ids[self.pair_index]
-        self.u_ids = self.part.padded_index(my_u).to(torch.int32).contiguous()      # ids moved to the padded space
-        self.i_ids = self.part.padded_index(my_i).to(torch.int32).contiguous()
-        # users are the first n_users global ids, items the next n_items (loaders.py:43-56): in the padded layout they
-        # occupy two row ranges that overlap by at most one rank's block, so each tower runs on its own range only
-        if not known:
-            self.u_rows = self.i_rows = (0, self.world * self.part.R)        # unknown split: both towers over every row
-        else:
+        if known:
             nu, ni = int(model.n_users), int(model.n_items)
-            last = torch.tensor([nu - 1, nu, nu + ni - 1], device=u_ids.device)
-            pu_end, pi_beg, pi_end = [int(v) for v in self.part.padded_index(last).cpu()]
-            self.u_rows, self.i_rows = (0, pu_end + 1), (pi_beg, pi_end + 1)
-            if self.pair_range is None and self.u_ids.numel():
-                self.u_rows = (int(self.u_ids.min()), int(self.u_ids.max()) + 1)   # the user rows this shard touches
-        self._bert_version, self._bert_pad = None, None
-        self.pair_plan = None
-        if ops is capi and not self.hybrid and os.environ.get('AMAR_PAIR_PLAN', '1') != '0' and self.u_ids.numel() >= (1 << 16):
-            from deep_cbrs_amar_renaissance_amd.models.basic import PairPlan
-            self.pair_plan = PairPlan(self.u_ids, self.i_ids)          # the rank's pairs, fixed for the runner's lifetime
-
-    # ---- typed partition (GCN stacks) -------------------------------------------------------------------------------------
-    def _init_typed(self, model, u_ids, i_ids, a):
-        nu, ni, n = int(model.n_users), int(model.n_items), int(a.shape[0])
-        if nu + ni > n:
-            raise ValueError("n_users + n_items exceeds the graph's node count")
-        self.part = self.tpart = TypedPartition([0, nu, nu + ni] + ([n] if n > nu + ni else []), self.world)
+            if nu + ni > n:
+                raise ValueError("n_users + n_items exceeds the graph's node count")
+            bounds, self.item_type = [0, nu, nu + ni] + ([n] if n > nu + ni else []), 1
+        else:                                    # unknown split: one node type; "users" are whoever the pairs name first, "items" every node
+            nu, ni, bounds, self.item_type = 0, n, [0, n], 0
+        self.part = self.tpart = TypedPartition(bounds, self.world)
         self.csr = self.tpart.local_block(a, self.rank)
         self.local_rows = sum(hi - lo for lo, hi in (self.tpart.owned(self.rank, t) for t in range(self.tpart.T)))
         self.local_nnz = self.csr.nnz
@@ -372,11 +258,13 @@ class PartitionedGCNRunner:
         self.widths = self.seq.layer_widths()
         dev = u_ids.device
         self.row_ids = self.tpart.node_of_row(dev)
+        self.row_ids0 = self.row_ids.clamp(min=0).contiguous()           # (padding rows copy node 0: finite values nobody gathers)
+        self.local_ids0 = self.row_ids0[self.rank * self.tpart.R:(self.rank + 1) * self.tpart.R].contiguous()
         # pairs follow their user: the rank scores the pairs of the users it owns, so its user tower reads its own rows only
         self.u_lo, self.u_hi = self.tpart.owned(self.rank, 0)
         self.i_lo, self.n_items = nu, ni
         mine = torch.nonzero((u_ids >= self.u_lo) & (u_ids < self.u_hi)).view(-1)
-        self.pair_index, self.pair_range = mine, None
+        self.pair_index = mine
         self.u_ids = u_ids[mine].to(torch.int32).contiguous()            # the reference's ids, unchanged
         self.i_ids = i_ids[mine].to(torch.int32).contiguous()
         self.pair_plan = None
@@ -400,45 +288,168 @@ class PartitionedGCNRunner:
             self._marks.append((name, e))
 
     def propagate_typed(self):
-        """One propagation on the typed partition.  Returns (x_local, x_items): per layer l = 1..L the rank's own [R, C_l] block of
-        X_l (local row order: users | items | properties, each padded to its block height) and the all-gathered item rows
-        [world * h_items, C_l] (the reference's item order; rows past n_items are padding).  X_0 is the node table itself."""
+        """One propagation on the typed partition.  Returns (x_local, x_items).  'concatenation' stacks (GCN, GraphSAGE, GAT): per
+        layer l = 1..L the rank's own [R, C_l] block of X_l (local row order: users | items | properties, each padded to its block
+        height) and the all-gathered item rows [world * h_items, C_l] (the reference's item order; rows past n_items are padding) —
+        X_0 is the node table itself.  'mean' stacks (LightGCN, DGCF): one entry each, the mean over the layers.
+        Every kind follows the same scheme: a rank-major table T_l [world * R, C] the next layer gathers from, made by the PRODUCER
+        from its own rows of X_l (GCN: S (X_l W_{l+1}) in the SpMM epilogue; LightGCN: S X_l; DGCF: X_l sigmoid(w_{l+1}); GraphSAGE:
+        X_l; GAT: X_l W_{l+1} and its neighbour scalars) and all-gathered — no rank passes over the whole table after the prologue."""
         ops, tp, dev = self.ops, self.tpart, self.seq.embeddings.device
         layers, widths = list(self.seq.seq_layers), self.widths
-        n_tab, R = self.world * tp.R, tp.R
+        n_tab, R, lo = self.world * tp.R, tp.R, self.rank * tp.R
         emb = self.seq.embeddings.detach()
-        tiled = [self._use_xs(w) for w in widths[1:]]
-        images = [self.csr.tiled_image(w) if t else None for w, t in zip(widths[1:], tiled)]
-        pre = all(tiled) and all(im.row_scale is not None for im in images)       # the chain of gathered tables stays pre-scaled by d^-1/2
-        h = self._buffer(('h', 0), (n_tab, widths[1]))
-        ops.rowwise_xw(emb, layers[0].kernel, h, row_ids=self.row_ids, row_scale=images[0].col_scale if pre else None)
-        self._mark('prologue')
-        i0, hi_ = tp.off[1], tp.h[1]
+        i0, hi_ = tp.off[self.item_type], tp.h[self.item_type]
         x_local, x_items, pending = [], [], []
-        for k, layer in enumerate(layers):
-            nxt = layers[k + 1] if k + 1 < len(layers) else None
-            y = self._buffer(('y', k), (R, widths[k + 1]), zero=True)
-            hn = self._buffer(('hl', k + 1), (R, widths[k + 2]), zero=True) if nxt is not None else None
-            if tiled[k]:
-                ops.spmm_xs(images[k], h, y, bias=layer.bias, relu=True, Wnext=nxt.kernel if nxt is not None else None, Hnext=hn,
-                            prescaled=pre, scale_next=pre and nxt is not None)
-            else:
-                ops.gcn_layer(self.csr.rowptr, self.csr.colidx, self.csr.vals, h, layer.bias, y,
-                              Wnext=nxt.kernel if nxt is not None else None, Hnext=hn)
-            self._mark('spmm')
-            wait_h = None
-            if nxt is not None:
-                h = self._buffer(('h', k + 1), (n_tab, widths[k + 2]))
-                wait_h = self._gather(h, hn, defer=True)
-            xi = self._buffer(('xi', k), (self.world * hi_, widths[k + 1]))
-            pending.append(self._gather(xi, y[i0:i0 + hi_], defer=True))
-            if wait_h is not None:
-                wait_h.wait()
-            self._mark('exchange')
-            x_local.append(y)
+
+        def gather_items(key, block):                                   # the item rows of a local [R, C] block, behind the next kernels
+            xi = self._buffer(('xi', key), (self.world * hi_, block.shape[1]))
+            pending.append(self._gather(xi, block[i0:i0 + hi_], defer=True))
             x_items.append(xi)
+
+        def gather_table(key, block):                                    # a local [R, ...] block -> the rank-major table every rank reads
+            full = self._buffer(('t', key), (n_tab,) + tuple(block.shape[1:]))
+            self._gather(full, block)
+            return full
+
+        if self.kind == 'gcn':
+            tiled = [self._use_xs(w) for w in widths[1:]]
+            images = [self.csr.tiled_image(w) if t else None for w, t in zip(widths[1:], tiled)]
+            pre = all(tiled) and all(im.row_scale is not None for im in images)   # the chain of gathered tables stays pre-scaled by d^-1/2
+            h = self._buffer(('t', 0), (n_tab, widths[1]))
+            ops.rowwise_xw(emb, layers[0].kernel, h, row_ids=self.row_ids, row_scale=images[0].col_scale if pre else None)
+            self._mark('prologue')
+            for k, layer in enumerate(layers):
+                nxt = layers[k + 1] if k + 1 < len(layers) else None
+                y = self._buffer(('y', k), (R, widths[k + 1]), zero=True)
+                hn = self._buffer(('hl', k + 1), (R, widths[k + 2]), zero=True) if nxt is not None else None
+                if tiled[k]:
+                    ops.spmm_xs(images[k], h, y, bias=layer.bias, relu=True, Wnext=nxt.kernel if nxt is not None else None, Hnext=hn,
+                                prescaled=pre, scale_next=pre and nxt is not None)
+                else:
+                    ops.gcn_layer(self.csr.rowptr, self.csr.colidx, self.csr.vals, h, layer.bias, y,
+                                  Wnext=nxt.kernel if nxt is not None else None, Hnext=hn)
+                self._mark('spmm')
+                wait_h = None
+                if nxt is not None:
+                    h = self._buffer(('t', k + 1), (n_tab, widths[k + 2]))
+                    wait_h = self._gather(h, hn, defer=True)
+                gather_items(k, y)
+                if wait_h is not None:
+                    wait_h.wait()
+                self._mark('exchange')
+                x_local.append(y)
+
+        elif self.kind in ('lightgcn', 'dgcf'):
+            d = widths[0]
+            tiled = self._use_xs(d)
+            image = self.csr.tiled_image(d) if tiled else None
+            value_free = image is not None and image.row_scale is not None
+            t = self._buffer(('t', 0), (n_tab, d))
+            if self.kind == 'dgcf':                                      # layer 1 gathers X_0 . sigmoid(w_1)
+                gated = self._buffer(('g0',), (emb.shape[0], d))
+                ops.locality_scale(emb, layers[0].w.detach().view(-1), gated)
+                ops.copy_columns(gated, t, ids=self.row_ids0)
+            elif value_free:                                             # ... S X_0 (the identity kernel keeps the bits of X_0)
+                ops.rowwise_xw(emb, self._identity(d, dev), t, row_ids=self.row_ids, row_scale=image.col_scale)
+            else:
+                ops.copy_columns(emb, t, ids=self.row_ids0)
+            acc = self._buffer(('acc', 0), (R, d))
+            ops.copy_columns(emb, acc, ids=self.local_ids0)              # the running sum starts at the rank's own rows of X_0
+            self._mark('prologue')
+            n_l = len(layers)
+            for k, layer in enumerate(layers):
+                last = k == n_l - 1
+                y = None if last else self._buffer(('y', k), (R, d), zero=True)
+                acc_out = self._buffer(('acc', k + 1), (R, d))
+                kw = dict(acc_in=acc, acc_out=acc_out, acc_div=n_l + 1 if last else None)
+                if tiled:
+                    ops.spmm_xs(image, t, y, prescaled=value_free, **kw)
+                else:
+                    ops.spmm_csr(self.csr.rowptr, self.csr.colidx, self.csr.vals, t, y, **kw)
+                acc = acc_out
+                self._mark('spmm')
+                if not last:
+                    if self.kind == 'dgcf':
+                        nxt_local = self._buffer(('tl', k + 1), (R, d))
+                        ops.locality_scale(y, self._gate_local(k + 1, layers[k + 1]), nxt_local)
+                    elif value_free:
+                        nxt_local = self._buffer(('tl', k + 1), (R, d))
+                        ops.row_affine(y, image.row_scale, nxt_local)
+                    else:
+                        nxt_local = y
+                    t = gather_table(k + 1, nxt_local)
+                    self._mark('exchange')
+            gather_items('mean', acc)
+            self._mark('exchange')
+            x_local.append(acc)
+
+        else:                                                            # GraphSAGE / GAT: edge-list graphs, layers gather X_l (GAT: X_l W)
+            x0 = self._buffer(('t', 0), (n_tab, widths[0]))
+            ops.copy_columns(emb, x0, ids=self.row_ids0)
+            t = x0
+            if self.kind == 'gat':
+                l0, c = layers[0], widths[1]
+                t = self._buffer(('h', 0), (n_tab, c))
+                s_self, s_neigh = self._buffer(('ss', 0), (n_tab,)), self._buffer(('sn', 0), (n_tab,))
+                ops.rowwise_xw(x0, l0.kernel.view(-1, c), t, a_self=l0.attn_kernel_self.view(c), a_neigh=l0.attn_kernel_neighs.view(c),
+                               s_self=s_self, s_neigh=s_neigh)
+            self._mark('prologue')
+            for k, layer in enumerate(layers):
+                f, c = widths[k], widths[k + 1]
+                last = k == len(layers) - 1
+                y = self._buffer(('y', k), (R, c), zero=True)
+                if self.kind == 'sage':
+                    agg = self._buffer(('agg', k), (R, f))
+                    ops.spmm_xs(self.csr.tiled_mean_image(f, layer.self_loops), t, agg, prescaled=True)
+                    if ops.sage_tail_supported(f, c):
+                        ops.sage_tail(t[lo:lo + R], agg, layer.kernel, layer.bias, y)
+                    else:
+                        xa = self._buffer(('xa', k), (R, 2 * f))
+                        ops.copy_columns(t[lo:lo + R], xa[:, :f])
+                        ops.copy_columns(agg, xa[:, f:])
+                        z = self._buffer(('z', k), (R, c))
+                        ops.dense(xa, layer.kernel, layer.bias, z, act=None)
+                        nrm, inv = self._buffer(('nrm', k), (R, c)), self._buffer(('inv', k), (R,))
+                        ops.l2norm_fwd(z, nrm, inv, y, act='relu')
+                else:
+                    lt = self.csr.tiled_gat_image(c)
+                    if lt is not None:
+                        ops.gat_lt(lt, self.csr, t, s_self, s_neigh, layer.bias, y, self_loop=layer.add_self_loops)
+                    else:
+                        ops.gat_xs(self.csr.xcd_sliced(), t, s_self, s_neigh, layer.bias, y, self_loop=layer.add_self_loops)
+                self._mark('spmm')
+                gather_items(k, y)
+                if not last:
+                    if self.kind == 'sage':
+                        t = gather_table(k + 1, y)
+                    else:                                                # the producer's X_l . W_{l+1} and attention scalars, own rows only
+                        nxt, c2 = layers[k + 1], widths[k + 2]
+                        h_local = self._buffer(('hl', k + 1), (R, c2))
+                        s_self = self._buffer(('ss', k + 1), (n_tab,), zero=True)
+                        sn_local = self._buffer(('snl', k + 1), (R,))
+                        ops.rowwise_xw(y, nxt.kernel.view(-1, c2), h_local, a_self=nxt.attn_kernel_self.view(c2),
+                                       a_neigh=nxt.attn_kernel_neighs.view(c2), s_self=s_self[lo:lo + R], s_neigh=sn_local)
+                        t = gather_table(('h', k + 1), h_local)
+                        s_neigh = gather_table(('sn', k + 1), sn_local)
+                self._mark('exchange')
+                x_local.append(y)
         self._pending = [w for w in pending if w is not None]
         return x_local, x_items
+
+    def _identity(self, d, dev):
+        cache = self.__dict__.setdefault('_eye', {})
+        if d not in cache:
+            cache[d] = torch.eye(d, dtype=torch.float32, device=dev).contiguous()
+        return cache[d]
+
+    def _gate_local(self, k, layer):
+        """DGCF's per-node gate weights of layer k for the rank's own rows, in local row order (rebuilt when they change)."""
+        cache = self.__dict__.setdefault('_gates_local', {})
+        version = layer.w._version
+        if cache.get(k, (None, None))[0] != version:
+            cache[k] = (version, layer.w.detach().view(-1)[self.local_ids0.long()].contiguous())
+        return cache[k][1]
 
     def wait_exchange(self):
         """Make the compute stream wait for the item-row gathers still in flight (a no-op with synchronous collectives)."""
@@ -476,8 +487,11 @@ class PartitionedGCNRunner:
         x_local, x_items = self.propagate_typed()
         emb = self.seq.embeddings.detach()
         nu_loc = self.u_hi - self.u_lo
-        u_table = capi.ConcatTable([emb[self.u_lo:self.u_hi]] + [x[:nu_loc] for x in x_local])
-        i_table = capi.ConcatTable([emb[self.i_lo:self.i_lo + self.n_items]] + [x[:self.n_items] for x in x_items])
+        if self.kind in ('lightgcn', 'dgcf'):                           # 'mean' reduction: one table
+            u_table, i_table = x_local[0][:nu_loc], x_items[0][:self.n_items]
+        else:                                                           # 'concatenation': [X_0 || X_1 || ...] read in place
+            u_table = capi.ConcatTable([emb[self.u_lo:self.u_hi]] + [x[:nu_loc] for x in x_local])
+            i_table = capi.ConcatTable([emb[self.i_lo:self.i_lo + self.n_items]] + [x[:self.n_items] for x in x_items])
         rs = self.model.rs
         if self.u_ids.numel() == 0:                                    # a rank without users (more ranks than user blocks): nothing to score
             self.wait_exchange()
@@ -525,116 +539,6 @@ class PartitionedGCNRunner:
                 'user_tower_ms': out.get('user_tower', 0.0), 'towers_ms': out.get('towers', 0.0) + out.get('item_bert', 0.0), 'pair_stage_ms': pairs,
                 'prologue_ms': out.get('prologue', 0.0), 'item_tower_ms': out.get('item_tower', 0.0)}
 
-    def _x0_padded(self):
-        emb = self.seq.embeddings
-        if self._x0_version != emb._version:
-            self._x0p, self._x0_version = self.part.pad_table(emb.detach()), emb._version
-        return self._x0p
-
-    def propagate(self):
-        """Returns the [world*R, F_cat] table of final node representations (padded layout).
-
-        Exchange per layer: ONE all-gather of the layer's own output block [R, C_l] — it is needed for the final
-        table anyway — after which every rank recomputes the next layer's tiny dense product X_l . W_{l+1} for all
-        rows (replicated weights, ~N*C*C flops) instead of gathering a second [N, C] block.  Bytes on xGMI per
-        propagation: N * sum(C_l) * 4 (37.8 MB at s=64), half of what fusing X.W into the SpMM epilogue would move.
-        """
-        ops, R, dev = self.ops, self.part.R, self.seq.embeddings.device
-        layers, widths = list(self.seq.seq_layers), self.widths
-        rows = self.local_rows
-        x0p = self._x0_padded()
-        if self.kind in ('lightgcn', 'dgcf'):
-            # X_{l+1} = A X_l on the local rows (DGCF: A_dgcf (X_l * sigmoid(w_l)), the gate applied to the whole replicated
-            # table), gathered; the mean over layers accumulates on the full table
-            acc = x0p.clone()
-            x = x0p
-            for k, layer in enumerate(layers):
-                y_local = torch.zeros((R, widths[0]), dtype=torch.float32, device=dev)
-                if self.kind == 'dgcf':
-                    gated = torch.empty_like(x)
-                    ops.locality_scale(x, self._gate_padded(k, layer), gated)
-                    x = gated
-                ops.spmm_csr(self.csr.rowptr, self.csr.colidx, self.csr.vals, x, y_local[:rows])
-                x = torch.empty((self.world * R, widths[0]), dtype=torch.float32, device=dev)
-                self.dist.all_gather_into_tensor(x, y_local)
-                ops.add_inplace(acc, x)
-            out = torch.empty_like(acc)
-            ops.row_affine(acc, self._mean_scale(acc.shape[0], len(layers) + 1, dev), out)
-            return out
-        f_cat = sum(widths)
-        offs = np.cumsum([0] + widths)
-        e_all = self._buffer(('e',), (self.world * R, f_cat)) if self.kind == 'gcn' else \
-            torch.empty((self.world * R, f_cat), dtype=torch.float32, device=dev)
-        if self.kind in ('sage', 'gat'):
-            ops.copy_columns(x0p, e_all[:, :widths[0]])                     # X_0 is a replicated weight
-            # the rank's row block on the XCD-sliced forms (amar_spmm_xs_f32 mean aggregate / amar_gat_xs_f32): both take a
-            # block whose own rows sit at column offset rank * R of the replicated table
-            lo = self.rank * R
-            x_full = x0p
-            for k, layer in enumerate(layers):
-                f, c = widths[k], widths[k + 1]
-                y_local = torch.zeros((R, c), dtype=torch.float32, device=dev)
-                if self.kind == 'sage':
-                    agg = torch.empty((rows, f), dtype=torch.float32, device=dev)
-                    ops.spmm_xs(self.csr.tiled_mean_image(f, layer.self_loops), x_full, agg, prescaled=True)
-                    if ops.sage_tail_supported(f, c):
-                        ops.sage_tail(x_full[lo:lo + rows], agg, layer.kernel, layer.bias, y_local[:rows])
-                    else:
-                        xa = torch.empty((rows, 2 * f), dtype=torch.float32, device=dev)
-                        ops.copy_columns(x_full[lo:lo + rows], xa[:, :f])
-                        ops.copy_columns(agg, xa[:, f:])
-                        z = torch.empty((rows, c), dtype=torch.float32, device=dev)
-                        ops.dense(xa, layer.kernel, layer.bias, z, act=None)
-                        nrm, inv = torch.empty_like(z), torch.empty(rows, dtype=torch.float32, device=dev)
-                        ops.l2norm_fwd(z, nrm, inv, y_local[:rows], act='relu')
-                else:
-                    h = torch.empty((self.world * R, c), dtype=torch.float32, device=dev)
-                    s_self = torch.empty(self.world * R, dtype=torch.float32, device=dev)
-                    s_neigh = torch.empty(self.world * R, dtype=torch.float32, device=dev)
-                    ops.rowwise_xw(x_full, layer.kernel.view(-1, c), h, a_self=layer.attn_kernel_self.view(c),
-                                   a_neigh=layer.attn_kernel_neighs.view(c), s_self=s_self, s_neigh=s_neigh)
-                    # the rank's row block on the LDS-tiled walk where its density allows (amar_gat_lt_f32 takes a block whose own
-                    # rows sit at a column offset, like the plain sum), else on the XCD-sliced online-softmax form
-                    lt = self.csr.tiled_gat_image(c)
-                    if lt is not None:
-                        ops.gat_lt(lt, self.csr, h, s_self, s_neigh, layer.bias, y_local[:rows], self_loop=layer.add_self_loops)
-                    else:
-                        ops.gat_xs(self.csr.xcd_sliced(), h, s_self, s_neigh, layer.bias, y_local[:rows], self_loop=layer.add_self_loops)
-                x_full = torch.empty((self.world * R, c), dtype=torch.float32, device=dev)
-                self.dist.all_gather_into_tensor(x_full, y_local)
-                ops.copy_columns(x_full, e_all[:, offs[k + 1]:offs[k + 2]])
-            return e_all
-        def pre_scale(width):
-            # value-free XCD-sliced image: the gathered table is pre-scaled by d^-1/2 inside the X.W launch
-            if not self._use_xs(width):
-                return None
-            xs = self.csr.tiled_image(width)
-            return xs.col_scale if xs.row_scale is not None else None
-
-        # persistent buffers: at 8 ranks the local kernels take tens of microseconds, so per-step allocations and the
-        # memsets of the padded blocks would show up next to them (the pad rows are written once, here, and never again)
-        h = self._buffer(('h', 0), (self.world * R, widths[1]))
-        scale = pre_scale(widths[1])
-        ops.rowwise_xw(x0p, layers[0].kernel, h, copy_to=e_all[:, :widths[0]], row_scale=scale)   # X_0 slice rides along
-        for k, layer in enumerate(layers):
-            y_local = self._buffer(('y', k), (R, widths[k + 1]), zero=True)
-            if self._use_xs(widths[k + 1]):
-                # the rank's row block on the XCD-sliced image (value-free when A_hat's factors are known): same kernels
-                # as the single-GPU path, the block's own rows sit at column offset rank * R of the padded table
-                ops.spmm_xs(self.csr.tiled_image(widths[k + 1]), h, y_local[:rows], bias=layer.bias, relu=True, prescaled=scale is not None)
-            else:
-                ops.gcn_layer(self.csr.rowptr, self.csr.colidx, self.csr.vals, h, layer.bias, y_local[:rows])
-            x_full = self._buffer(('x', k), (self.world * R, widths[k + 1]))
-            self.dist.all_gather_into_tensor(x_full, y_local)
-            if k + 1 < len(layers):
-                # the gathered block's copy into its slice of the final table rides on the next layer's X.W launch
-                h = self._buffer(('h', k + 1), (self.world * R, widths[k + 2]))
-                scale = pre_scale(widths[k + 2])
-                ops.rowwise_xw(x_full, layers[k + 1].kernel, h, copy_to=e_all[:, offs[k + 1]:offs[k + 2]], row_scale=scale)
-            else:
-                ops.copy_columns(x_full, e_all[:, offs[k + 1]:offs[k + 2]])
-        return e_all
-
     def _buffer(self, key, shape, zero=False):
         """A per-runner float32 device buffer, allocated (and zeroed, if asked) on first use and then reused every step."""
         cache = self.__dict__.setdefault('_buffers', {})
@@ -671,25 +575,7 @@ class PartitionedGCNRunner:
         return state
 
     def step(self):
-        if self.typed:
-            return self._step_typed()
-        if self.timing:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        emb = self.propagate()
-        if self.timing:
-            e1.record()
-            self._events = (e0, e1)
-        # replicated per-entity towers, each over its own row range of the padded table
-        (u0, u1), (i0, i1) = self.u_rows, self.i_rows
-        if self.hybrid:
-            bert = self._bert_padded()
-            towers = self.model.rs.towers(emb[u0:u1], emb[i0:i1], bert[u0:u1], bert[i0:i1])
-        else:
-            towers = self.model.rs.towers(emb[u0:u1], emb[i0:i1])
-        if self.pair_plan is not None:
-            return self.model.rs.score_towers(towers, self.u_ids, self.i_ids, u0, i0, pair_plan=self.pair_plan)
-        return self.model.rs.score_towers(towers, self.u_ids, self.i_ids, u0, i0)
+        return self._step_typed()
 
     def _use_xs(self, width):
         """XCD-sliced local SpMM when the gathered table exceeds the per-XCD L2s (as utilities.math.spmm_kind decides
@@ -701,49 +587,13 @@ class PartitionedGCNRunner:
             return forced == 'xs'
         return self.world * self.part.R * width * 4 >= ((8 << 20) if width <= 8 else (16 << 20))
 
-    def _gate_padded(self, k, layer):
-        """DGCF's per-node gate weights of layer k in the padded layout (rebuilt when they change)."""
-        cache = self.__dict__.setdefault('_gates', {})
-        version = layer.w._version
-        if cache.get(k, (None, None))[0] != version:
-            cache[k] = (version, self.part.pad_table(layer.w.detach().view(-1, 1)).view(-1).contiguous())
-        return cache[k][1]
-
-    def _mean_scale(self, n_rows, n_terms, dev):
-        if getattr(self, '_mean', None) is None or self._mean.numel() != n_rows:
-            self._mean = torch.full((n_rows,), 1.0 / n_terms, dtype=torch.float32, device=dev)
-        return self._mean
-
-    def _bert_padded(self):
-        """The resident BERT table (rows = users then items) in the padded layout; property nodes get zero rows."""
-        table = self.model.bert_table
-        if table is None:
-            raise ValueError("the hybrid model needs its BERT table registered (set_bert_table) for the partitioned run")
-        key = (table.data_ptr(), table._version)
-        if self._bert_version != key:
-            full = torch.zeros((self.part.n, table.shape[1]), dtype=torch.float32, device=table.device)
-            full[:min(self.part.n, table.shape[0])] = table[:self.part.n]
-            self._bert_pad, self._bert_version = self.part.pad_table(full), key
-            if not self.model.rs.built:
-                self.model.rs.build_head(self.model.gnn.output_dim(), table.shape[1])
-        return self._bert_pad
-
     def last_propagation_ms(self):
-        if self.typed:
-            ph = self.phase_times()
-            return None if ph is None else ph['prologue_ms'] + ph['local_spmm_ms'] + ph['exchange_ms']
-        if not self._events:
-            return None
-        e0, e1 = self._events
-        e1.synchronize()
-        return e0.elapsed_time(e1)
+        ph = self.phase_times()
+        return None if ph is None else ph['prologue_ms'] + ph['local_spmm_ms'] + ph['exchange_ms']
 
     def describe(self):
-        if self.typed:
-            return ('node-range partition over {} GPUs (equal-height blocks per node type, nnz imbalance {:.3f}), per layer one RCCL all-gather of '
-                    'the next gathered table + one of the item rows, pairs sharded by the same user ranges').format(self.world, self.nnz_imbalance)
-        return 'node-range partition over {} GPUs (equal nnz), per-layer RCCL all-gather, pairs sharded {}'.format(
-            self.world, 'by user range (equal counts)' if self.pair_range is None else 'in contiguous slices')
+        return ('node-range partition over {} GPUs (equal-height blocks per node type, nnz imbalance {:.3f}), per layer one RCCL all-gather of '
+                'the next gathered table + one of the item rows, pairs sharded by the same user ranges').format(self.world, self.nnz_imbalance)
 
 
 def make_runner(model, u_ids, i_ids, rank=0, world=1, dist=None):

@@ -1,9 +1,9 @@
-"""CPU, world_size 2 over gloo: the node-range partition + per-layer all-gather logic.
+"""CPU, world_size 2 and 3 over gloo: the typed node-range partition + per-layer all-gather logic.
 
 The HIP kernels cannot run here, so the runner's kernel provider is replaced by a numpy stand-in
-(test infrastructure) while partitioning, the padded index space, CSR column remapping and the
-collectives are the shipped code.  Each rank's gathered node table must equal the single-process
-oracle propagation.
+(test infrastructure) while partitioning, the rank-major block layout, CSR column remapping and the
+collectives are the shipped code.  Each rank's own blocks and gathered tables must equal the
+single-process oracle propagation.
 """
 import os
 import socket
@@ -24,8 +24,8 @@ class NumpyOps:
     """CPU stand-ins with the signatures of the capi functions the partitioned runner calls."""
 
     @staticmethod
-    def copy_columns(src, dst):
-        dst.copy_(src)
+    def copy_columns(src, dst, ids=None, base=0):
+        dst.copy_(src if ids is None else src[ids.long() - base])
 
     @staticmethod
     def rowwise_xw(X, W, H, copy_to=None, row_ids=None, row_scale=None, **kw):
@@ -48,10 +48,14 @@ class NumpyOps:
             Hnext.copy_(torch.from_numpy(y @ Wnext.detach().numpy()))
 
     @staticmethod
-    def spmm_csr(rowptr, colidx, vals, X, Y, **kw):
+    def spmm_csr(rowptr, colidx, vals, X, Y=None, acc_in=None, acc_out=None, acc_div=None, **kw):
         n = rowptr.numel() - 1
         a = sparse.csr_matrix((vals.numpy(), colidx.numpy(), rowptr.numpy()), shape=(n, X.shape[0]))
-        Y.copy_(torch.from_numpy(a @ X.detach().numpy()))
+        y = torch.from_numpy(a @ X.detach().numpy())
+        if Y is not None:
+            Y.copy_(y)
+        if acc_out is not None:                                     # LightGCN's running layer sum / mean in the epilogue
+            acc_out.copy_((acc_in + y) / (acc_div if acc_div is not None else 1))
 
     @staticmethod
     def add_inplace(dst, src, scale=1.0):
@@ -60,36 +64,6 @@ class NumpyOps:
     @staticmethod
     def row_affine(a, scale, out, b=None):
         out.copy_((a if b is None else a + b) * scale[:, None])
-
-
-def _worker(rank, world, port, out_dir):
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
-    dist.init_process_group('gloo', rank=rank, world_size=world)
-    try:
-        from deep_cbrs_amar_renaissance_amd import engine, parallel
-        from deep_cbrs_amar_renaissance_amd.models import basic
-        engine.set_seed(42)
-        g = helpers.tiny_graph(n_users=70, n_items=45, n_ratings=1500, seed=8, n_props=25, n_links=90)
-        model = basic.BasicGCN(g['adj'], **GRID1)
-        helpers.randomize_biases(model, seed=3)
-        u = torch.from_numpy(g['u_ids'])
-        i = torch.from_numpy(g['i_ids'])
-        runner = parallel.PartitionedGCNRunner(model, u, i, rank, world, ops=NumpyOps, dist=dist, timing=False)
-        e_pad = runner.propagate()
-        n = g['adj'].shape[0]
-        idx = runner.part.padded_index(torch.arange(n))
-        # LightGCN stack ('mean' reduction accumulated on the gathered table) through the same partition
-        light = basic.BasicLightGCN(g['adj'], **dict(GRID1, n_layers=3))
-        light.n_users, light.n_items = g['n_users'], g['n_items']         # user / item split known: pairs are sharded by user range
-        lrun = parallel.PartitionedGCNRunner(light, u, i, rank, world, ops=NumpyOps, dist=dist, timing=False)
-        e_light = lrun.propagate()
-        np.savez(os.path.join(out_dir, 'rank{}.npz'.format(rank)), e=e_pad[idx].numpy(),
-                 bounds=np.array(runner.part.bounds), pair_range=np.array(runner.pair_range),
-                 u_back=e_pad[runner.u_ids.long()].numpy(), nnz=np.array(runner.local_nnz),
-                 light_index=lrun.pair_index.numpy(), light_u_back=e_light[lrun.u_ids.long()].numpy(), light_u_rows=np.array(lrun.u_rows),
-                 e_light=e_light[lrun.part.padded_index(torch.arange(n))].detach().numpy())
-    finally:
-        dist.destroy_process_group()
 
 
 def _typed_worker(rank, world, port, out_dir):
@@ -110,12 +84,27 @@ def _typed_worker(rank, world, port, out_dir):
         assert runner.typed
         x_local, x_items = runner.propagate_typed()
         runner.wait_exchange()
+        # LightGCN ('mean' over the layers, accumulated on the rank's own rows) on the same partition; and a model that does not know
+        # its user / item split: one node type, pairs follow whichever node they name first
+        light = basic.BasicLightGCN(g['adj'], **dict(GRID1, n_layers=3))
+        light.n_users, light.n_items = g['n_users'], g['n_items']
+        lrun = parallel.PartitionedGCNRunner(light, u, i, rank, world, ops=NumpyOps, dist=dist, timing=False)
+        l_local, l_items = lrun.propagate_typed()
+        lrun.wait_exchange()
+        blind = basic.BasicGCN(g['adj'], **GRID1)
+        brun = parallel.PartitionedGCNRunner(blind, u, i, rank, world, ops=NumpyOps, dist=dist, timing=False)
+        assert brun.typed and brun.tpart.T == 1 and brun.n_items == g['adj'].shape[0]
+        b_local, b_items = brun.propagate_typed()
+        brun.wait_exchange()
         tp = runner.tpart
         np.savez(os.path.join(out_dir, 'typed{}.npz'.format(rank)),
                  owned=np.array([tp.owned(rank, t) for t in range(tp.T)]), off=np.array(tp.off), h=np.array(tp.h),
                  pair_index=runner.pair_index.numpy(), u_ids=runner.u_ids.numpy(), i_ids=runner.i_ids.numpy(),
                  nnz=np.array(runner.local_nnz), **{'xl%d' % k: x.numpy() for k, x in enumerate(x_local)},
-                 **{'xi%d' % k: x.numpy() for k, x in enumerate(x_items)})
+                 **{'xi%d' % k: x.numpy() for k, x in enumerate(x_items)},
+                 light_local=l_local[0].detach().numpy(), light_items=l_items[0].detach().numpy(),
+                 blind_rows=np.array(brun.tpart.owned(rank, 0)), blind_pairs=brun.pair_index.numpy(),
+                 **{'bl%d' % k: x.numpy() for k, x in enumerate(b_local)}, **{'bi%d' % k: x.numpy() for k, x in enumerate(b_items)})
     finally:
         dist.destroy_process_group()
 
@@ -133,8 +122,13 @@ def test_typed_partition_matches_oracle(tmp_path, world):
     model = basic.BasicGCN(g['adj'], **GRID1)
     helpers.randomize_biases(model, seed=3)
     want = om.propagate(g['adj'], helpers.gnn_to_oracle(model.gnn), np.float64)      # [N, 24] = [X_0 || X_1 || X_2]
+    light = basic.BasicLightGCN(g['adj'], **dict(GRID1, n_layers=3))                  # same seed order as in the workers
+    want_light = om.propagate(g['adj'], helpers.gnn_to_oracle(light.gnn), np.float64)
+    blind = basic.BasicGCN(g['adj'], **GRID1)
+    want_blind = om.propagate(g['adj'], helpers.gnn_to_oracle(blind.gnn), np.float64)
     nu, ni = g['n_users'], g['n_items']
-    shards, total_nnz = [], 0
+    n = g['adj'].shape[0]
+    shards, blind_shards, total_nnz = [], [], 0
     for r in range(world):
         z = np.load(os.path.join(str(tmp_path), 'typed{}.npz'.format(r)))
         for k in range(2):
@@ -149,7 +143,19 @@ def test_typed_partition_matches_oracle(tmp_path, world):
         assert np.array_equal(z['u_ids'], g['u_ids'][z['pair_index']]) and np.array_equal(z['i_ids'], g['i_ids'][z['pair_index']])
         shards.append(z['pair_index'])
         total_nnz += int(z['nnz'])
+        # LightGCN: the mean over the layers for the rank's own rows and, gathered, for every item
+        assert helpers.rel_err(z['light_items'][:ni], want_light[nu:nu + ni]) < 1e-5
+        for t, (lo, hi) in enumerate(z['owned']):
+            assert helpers.rel_err(z['light_local'][z['off'][t]:z['off'][t] + hi - lo], want_light[lo:hi]) < 1e-5
+        # no user / item split known: one type, the "item" gather is the whole table
+        lo, hi = z['blind_rows']
+        for k in range(2):
+            cols = slice(8 * (k + 1), 8 * (k + 2))
+            assert helpers.rel_err(z['bi%d' % k][:n], want_blind[:, cols]) < 1e-5
+            assert helpers.rel_err(z['bl%d' % k][:hi - lo], want_blind[lo:hi, cols]) < 1e-5
+        blind_shards.append(z['blind_pairs'])
     assert np.array_equal(np.sort(np.concatenate(shards)), np.arange(len(g['u_ids'])))   # every pair scored exactly once
+    assert np.array_equal(np.sort(np.concatenate(blind_shards)), np.arange(len(g['u_ids'])))
     assert total_nnz == gcn_filter(g['adj']).nnz
 
 
@@ -180,56 +186,3 @@ def _free_port():
     port = s.getsockname()[1]
     s.close()
     return port
-
-
-@pytest.mark.timeout(180)
-def test_partitioned_propagation_matches_oracle_world2(tmp_path):
-    from oracle import models as om
-    from deep_cbrs_amar_renaissance_amd import engine
-    from deep_cbrs_amar_renaissance_amd.models import basic
-    world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    engine.set_seed(42)
-    g = helpers.tiny_graph(n_users=70, n_items=45, n_ratings=1500, seed=8, n_props=25, n_links=90)
-    model = basic.BasicGCN(g['adj'], **GRID1)
-    helpers.randomize_biases(model, seed=3)
-    want = om.propagate(g['adj'], helpers.gnn_to_oracle(model.gnn), np.float64)
-    light = basic.BasicLightGCN(g['adj'], **dict(GRID1, n_layers=3))          # same seed order as in the workers
-    want_light = om.propagate(g['adj'], helpers.gnn_to_oracle(light.gnn), np.float64)
-    total_nnz, covered, shards = 0, [], []
-    for r in range(world):
-        z = np.load(os.path.join(str(tmp_path), 'rank{}.npz'.format(r)))
-        assert helpers.rel_err(z['e'], want) < 1e-5, "rank {} holds a wrong node table".format(r)
-        assert helpers.rel_err(z['e_light'], want_light) < 1e-5, "rank {} holds a wrong LightGCN table".format(r)
-        lo, hi = z['pair_range']
-        assert helpers.rel_err(z['u_back'], want[g['u_ids'][lo:hi]]) < 1e-5     # padded pair ids hit the right rows
-        # user-range sharding (second runner): the shard's padded user ids hit the right rows, inside the rank's own user-row span
-        assert helpers.rel_err(z['light_u_back'], want_light[g['u_ids'][z['light_index']]]) < 1e-5
-        shards.append(z['light_index'])
-        assert z['light_u_rows'][1] - z['light_u_rows'][0] < g['adj'].shape[0]
-        total_nnz += int(z['nnz'])
-        covered.append((int(lo), int(hi)))
-        assert z['bounds'][0] == 0 and z['bounds'][-1] == g['adj'].shape[0]
-    from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter
-    assert np.array_equal(np.sort(np.concatenate(shards)), np.arange(len(g['u_ids'])))       # every pair scored exactly once
-    assert total_nnz == gcn_filter(g['adj']).nnz
-    assert covered[0][0] == 0 and covered[0][1] == covered[1][0] and covered[1][1] == len(g['u_ids'])
-
-
-def test_partition_balances_nnz_and_handles_edges():
-    from deep_cbrs_amar_renaissance_amd.parallel import partition_rows_by_nnz, RowPartition
-    deg = np.r_[np.full(100, 50), np.full(900, 2), [0, 0, 0]]
-    rowptr = torch.from_numpy(np.r_[0, np.cumsum(deg)])
-    for world in (1, 2, 4, 8):
-        b = partition_rows_by_nnz(rowptr, world)
-        assert b[0] == 0 and b[-1] == len(deg) and all(b[k] <= b[k + 1] for k in range(world))
-        per = [int(rowptr[b[k + 1]] - rowptr[b[k]]) for k in range(world)]
-        assert max(per) - min(per) <= 2 * 50
-        part = RowPartition(b)
-        ids = torch.arange(len(deg))
-        p = part.padded_index(ids)
-        assert len(torch.unique(p)) == len(deg) and int(p.max()) < world * part.R and part.R % 4 == 0
-        t = torch.arange(len(deg) * 3, dtype=torch.float32).reshape(-1, 3)
-        assert torch.equal(part.pad_table(t)[p], t)
-    b = partition_rows_by_nnz(torch.tensor([0, 0, 0]), 4)                 # empty graph
-    assert b == [0, 0, 0, 0, 2] or (b[0] == 0 and b[-1] == 2)

@@ -21,9 +21,9 @@ def main():
     n = data['n_users'] + data['n_items']
     a = gcn_filter_device(data['train_pos'][:, 0], data['train_pos'][:, 1], n)
     for world in (1, 2, 4, 8):
-        part = parallel.RowPartition(parallel.partition_rows_by_nnz(a.rowptr, world))
+        part = parallel.TypedPartition([0, data['n_users'], n], world)
         for rank in sorted({0, world - 1}):
-            blk = part.local_csr(a, rank)
+            blk = part.local_block(a, rank)
             x = torch.randn((world * part.R, F), device=dev)
             y = torch.empty((blk.shape[0], F), device=dev)
             os.environ['AMAR_SPMM_LT'] = '0'

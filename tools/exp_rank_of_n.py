@@ -74,19 +74,15 @@ def main():
                 runner.step_graphed()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / 20
-            if runner.typed:                       # per layer: the next gathered table (all rows) + the item rows of X_l
-                tp = runner.tpart
-                gathered = (sum(runner.widths[2:]) * world * tp.R + sum(runner.widths[1:]) * world * tp.h[1]) * 4 / 1e6
-            else:
-                gathered = sum(runner.widths[1:]) * world * runner.part.R * 4 / 1e6
+            tp = runner.tpart                      # per layer: the next gathered table (all rows) + the item rows of X_l
+            gathered = (sum(runner.widths[2:]) * world * tp.R + sum(runner.widths[1:]) * world * tp.h[1]) * 4 / 1e6
             print('  world %d rank %d: rows %d nnz %d pairs %d | %.4f ms per step without the exchange (%.1f MB gathered per step) -> '
                   'bound on the speed-up %.2fx' % (world, rank, runner.local_rows, runner.local_nnz, runner.u_ids.numel(), 1e3 * dt, gathered, t1 / dt), flush=True)
-            if runner.typed:                       # phases of one eager step (HIP events)
-                runner.timing = True
-                for _ in range(3):
-                    runner.step()
-                ph = runner.phase_times()
-                print('      eager step by phase: ' + ', '.join('%s %.4f' % (k[:-3], v) for k, v in ph.items()), flush=True)
+            runner.timing = True                   # phases of one eager step (HIP events)
+            for _ in range(3):
+                runner.step()
+            ph = runner.phase_times()
+            print('      eager step by phase: ' + ', '.join('%s %.4f' % (k[:-3], v) for k, v in ph.items()), flush=True)
             del runner
 
 

@@ -75,6 +75,49 @@ def test_full_size_spmm_properties(hip, big, monkeypatch):
         assert np.abs(ax_xs[r].double().cpu().numpy() - want).max() <= 1e-5 * max(1e-3, np.abs(want).max())
 
 
+@pytest.mark.parametrize('F', [16, 32])
+def test_full_size_wide_layers_on_the_lds_tiled_walk(hip, big, F):
+    """The F = 16 / 32 layers of econfigs/basic-gnn.yaml grid2 / grid3 at the bench's full size, on the image they dispatch to (the
+    LDS-tiled walk without implicit pairs, round 3): against the row-streaming CSR kernel, the eigenvector of A_hat, sampled rows
+    in float64, and the fused layer epilogue (bias, ReLU, next layer's kernel staged in LDS, pre-scaled next table) against the
+    un-fused sequence."""
+    a, n = big['a'], big['n']
+    dev = a.rowptr.device
+    lt = a.tiled_image(F)
+    assert hasattr(lt, 'words') and not lt.pairs and lt.n_pairs == 0
+    g = torch.Generator(device=dev); g.manual_seed(F)
+    x = torch.randn((n, F), device=dev, generator=g)
+    y_lt, y_csr = torch.empty((n, F), device=dev), torch.empty((n, F), device=dev)
+    hip.spmm_xs(lt, x, y_lt)
+    hip.spmm_csr(a.rowptr, a.colidx, a.vals, x, y_csr)
+    assert _rel(y_lt, y_csr) < 2e-6
+    v = (1.0 / a.dinv).view(-1, 1).repeat(1, F).contiguous()
+    av = torch.empty_like(v)
+    hip.spmm_xs(lt, v, av)
+    assert _rel(av, v) < 1e-5
+    rows = np.random.default_rng(F).integers(0, n, 100)
+    rp = a.rowptr.long()
+    xd = x.double().cpu().numpy()
+    for r in rows.tolist():
+        lo, hi = int(rp[r]), int(rp[r + 1])
+        cols = a.colidx[lo:hi].long().cpu().numpy()
+        vals = a.vals[lo:hi].double().cpu().numpy()
+        want = (vals[:, None] * xd[cols]).sum(0)
+        assert np.abs(y_lt[r].double().cpu().numpy() - want).max() <= 1e-5 * max(1e-3, np.abs(want).max())
+    # fused GCN layer: Y = relu(A_hat H + b), H_next = S (Y W) — against relu / bias / X.W / row scale applied one by one
+    b = torch.rand(F, device=dev, generator=g) - 0.5
+    w = (torch.rand((F, F), device=dev, generator=g) - 0.5).contiguous()
+    h0 = torch.empty_like(x)
+    hip.row_affine(x, lt.col_scale, h0)
+    y1, h1 = torch.empty((n, F), device=dev), torch.empty((n, F), device=dev)
+    hip.spmm_xs(lt, h0, y1, bias=b, relu=True, Wnext=w, Hnext=h1, prescaled=True, scale_next=True)
+    ref = torch.clamp(y_lt + b, min=0)
+    assert _rel(y1, ref) < 1e-6
+    h_ref = torch.empty_like(h1)
+    hip.rowwise_xw(y1, w, h_ref, row_scale=lt.row_scale)
+    assert _rel(h1, h_ref) < 1e-6
+
+
 def test_full_size_scoring_properties(hip, big):
     from deep_cbrs_amar_renaissance_amd import engine
     from deep_cbrs_amar_renaissance_amd.models import basic

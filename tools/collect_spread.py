@@ -22,6 +22,8 @@ def main():
             continue
         if d.get('csrc_sha') != sha or d.get('n_gpus') != 1 or d.get('config', {}).get('scale') != 64:
             continue
+        if not d.get('config', {}).get('parallelism', '').startswith('single GPU'):      # (AMAR_FORCE_DIST runs the partitioned runner)
+            continue
         runs.append({'file': os.path.relpath(path, ROOT), 'ms_per_step': d['ms_per_step'], 'value': d['value'], 'steps': d['steps']})
     if not runs:
         sys.exit('no bench lines of csrc {} under gpurun_out/'.format(sha))

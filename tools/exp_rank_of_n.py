@@ -38,11 +38,15 @@ def main():
     from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter_device
     capi.load()
     dev = torch.device('cuda')
-    data = synthetic.ml1m_device(scale, device=dev)
-    n = data['n_users'] + data['n_items']
-    a = gcn_filter_device(data['train_pos'][:, 0], data['train_pos'][:, 1], n)
+    name = os.environ.get('EXP_MODEL', 'BasicGCN')                  # BasicGCN | BasicLightGCN | BasicGraphSage | BasicGAT | HybridBertGCN
+    hybrid_uip = name == 'HybridBertGCN'                            # BASELINE config 5: hybrid head on the user-item-property graph
+    data = synthetic.ml1m_device(scale, device=dev, with_props=hybrid_uip)
+    n = data['n_users'] + data['n_items'] + (data['n_props'] if hybrid_uip else 0)
+    rows_, cols_ = data['train_pos'][:, 0], data['train_pos'][:, 1]
+    if hybrid_uip:
+        rows_, cols_ = torch.cat([rows_, data['item_prop'][:, 0]]), torch.cat([cols_, data['item_prop'][:, 1]])
+    a = gcn_filter_device(rows_, cols_, n)
     engine.set_seed(42)
-    name = os.environ.get('EXP_MODEL', 'BasicGCN')                  # BasicGCN | BasicLightGCN | BasicGraphSage | BasicGAT
     if name in ('BasicGraphSage', 'BasicGAT'):                      # edge-list graphs: the raw symmetric adjacency, no values
         from deep_cbrs_amar_renaissance_amd.utilities.math import DeviceCSR
         tp_ = data['train_pos']
@@ -51,7 +55,14 @@ def main():
         rowptr[1:] = torch.cumsum(torch.bincount(keys // n, minlength=n), 0)
         a = DeviceCSR(rowptr.to(torch.int32), (keys % n).to(torch.int32), None, (n, n))
         a.row_breaks = (data['n_users'],)
-    model = getattr(basic, name)(a, **GRID1)
+    if hybrid_uip:
+        from deep_cbrs_amar_renaissance_amd.models import hybrid
+        model = hybrid.HybridBertGCN(a, embedding_dim=8, n_hiddens=[8, 8], dense_units=[[24, 24], [256, 64], [64, 64]], clf_units=[64, 64], feature_based=True)
+        gb = torch.Generator(device=dev); gb.manual_seed(7)
+        model.set_bert_table(torch.randn((data['n_users'] + data['n_items'], 768), device=dev, generator=gb) * 0.5)
+        model.rs.build_head(model.gnn.output_dim(), 768)
+    else:
+        model = getattr(basic, name)(a, **GRID1)
     model.n_users, model.n_items = data['n_users'], data['n_items']
     g = torch.Generator(device=dev); g.manual_seed(42)
     perm = torch.randperm(data['test'].shape[0], device=dev, generator=g)
@@ -59,6 +70,21 @@ def main():
     i = data['test'][perm, 1].to(torch.int32).contiguous()
     if os.environ.get('EXP_SINGLE_MS'):                    # (profiling runs: skip the single-GPU leg, EXP_RANKS picks the ranks)
         t1 = float(os.environ['EXP_SINGLE_MS']) * 1e-3
+    elif hybrid_uip:                                       # one GPU: propagation + the four per-entity networks + every pair (eager: a 7 ms step)
+        nu_, ni_, bert_ = data['n_users'], data['n_items'], model.bert_table
+
+        def single_step():
+            emb = model.gnn(None)
+            tw = model.rs.towers(emb[:nu_], emb[nu_:nu_ + ni_], bert_[:nu_], bert_[nu_:nu_ + ni_])
+            return model.rs.score_towers(tw, u, i, 0, nu_)
+        for _ in range(3):
+            single_step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            single_step()
+        torch.cuda.synchronize()
+        t1 = (time.perf_counter() - t0) / 10
     else:
         single = parallel.SingleRunner(model, u, i)
         for _ in range(40):

@@ -93,7 +93,11 @@ class LdsTiled:
         # with it the L1 footprint) small — 24 M L2 requests per ml1m(s=64) layer against 28 M for two-step windows — while a barrier
         # per four of them costs no more synchronisation than before (0.2136 against 0.2200 ms)
         steps = max(1, self.window_entries // (WAVES * (64 // (F // 4))))
-        self.pace_every = int(os.environ.get('AMAR_LT_PACE', 4 if steps == 1 else (2 if steps == 2 else 1)))
+        # F = 32 (a gathered row is a whole 128-byte line: nothing to share in the L1, the barrier only keeps the tile's waves near
+        # each other in the L2s): one barrier per four 2 048-entry windows, 0.468 -> 0.430 ms per ml1m(s=64) product (every window 0.468,
+        # every second 0.452, every eighth 0.456; F = 16 is flat: profiles/r3_exp_lt_pace_wide.txt)
+        wide = F >= 32 and self.rw == geometry(F)[1]
+        self.pace_every = int(os.environ.get('AMAR_LT_PACE', 4 if steps == 1 or wide else (2 if steps == 2 else 1)))
 
     @classmethod
     def build(cls, rows, cols, n_rows, n_cols, F, diag, row_scale, col_scale, diag_offset=0, window_entries=None, n_cu=N_CU,

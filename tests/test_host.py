@@ -440,3 +440,30 @@ def test_weights_roundtrip_through_npz(tmp_path):
     other = basic.BasicGCN(g['adj'], **dict(cfg, n_hiddens=[8, 8, 8]))
     with pytest.raises(ValueError):
         other.load_weights(path)
+
+
+def test_bench_profile_bookkeeping(tmp_path, monkeypatch):
+    """bench.py applies counter-derived numbers (roofline.traffic, the L2 request floor, the spread over boxes) only when they belong to
+    the CURRENT kernel sources, the same kernel form and the same scale — never silently."""
+    import json
+    import importlib
+    bench = importlib.import_module('bench')
+    sha = bench.csrc_sha()
+    assert len(sha) == 16 and sha == bench.csrc_sha()
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    os.makedirs(tmp_path / 'profiles')
+    monkeypatch.setattr(bench, 'csrc_sha', lambda: sha)
+    assert bench.pmc_profile(64, 'lt')[0] is None and 'missing' in bench.pmc_profile(64, 'lt')[1]
+    good = {'scale': 64, 'kind': 'lt', 'csrc_sha': sha, 'traffic_bytes_per_launch': 1.0, 'TCC': {'REQ': 2.0}}
+    json.dump(good, open(tmp_path / 'profiles' / 'spmm_pmc_latest.json', 'w'))
+    pmc, src = bench.pmc_profile(64, 'lt')
+    assert pmc == good and sha in src
+    assert bench.pmc_profile(256, 'lt')[0] is None and bench.pmc_profile(64, 'xs')[0] is None          # other scale / kernel form
+    json.dump(dict(good, csrc_sha='0' * 16), open(tmp_path / 'profiles' / 'spmm_pmc_latest.json', 'w'))
+    pmc, src = bench.pmc_profile(64, 'lt')
+    assert pmc is None and 'stale' in src                                                              # kernels changed since the profile
+    assert bench.value_spread(64) is None
+    json.dump({'scale': 64, 'csrc_sha': sha, 'boxes': 3, 'min_ms_per_step': 1.0, 'max_ms_per_step': 1.1}, open(tmp_path / 'profiles' / 'r3_bench_repeats.json', 'w'))
+    assert bench.value_spread(64)['stale'] is False and bench.value_spread(256) is None
+    json.dump({'scale': 64, 'csrc_sha': 'x', 'boxes': 3}, open(tmp_path / 'profiles' / 'r3_bench_repeats.json', 'w'))
+    assert bench.value_spread(64)['stale'] is True

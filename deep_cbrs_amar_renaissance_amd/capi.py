@@ -52,6 +52,7 @@ SIGNATURES = {
     'amar_chain_segments_f32': (ctypes.c_int, [_P, _P, _P, _I32, _P, _I32, _P, _P, _P, _I32, _P, _I64, _I64, _P]),
     'amar_dual_chain_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _I32, _P, _P, _I64, _I64, _P]),
     'amar_copy_columns_f32': (ctypes.c_int, [_P, _I64, _P, _I32, _P, _I64, _I64, _I32, _P]),
+    'amar_scatter_f32': (ctypes.c_int, [_P, _P, _P, _I64, _I64, _P, _I32, _P]),
     'amar_reduce_layers_f32': (ctypes.c_int, [_P, _I64, _I32, _I32, _P, _I64, _I64, _I32, _P]),
     'amar_reduce_layers_wsum_f32': (ctypes.c_int, [_P, _I64, _I32, _I32, _P, _P, _I64, _I64, _P]),
     'amar_reduce_layers_wsum_bwd_scratch': (ctypes.c_int64, []),
@@ -629,6 +630,18 @@ def dual_chain(tables_a, tables_b, ids_a, ids_b, bases_a, bases_b, D, in_act, br
                                       tdims, tacts, len(trunk_acts), _ptr(wpack, torch.float32, 'wpack'),
                                       _ptr(out, torch.float32, 'out'), _ld(out, 'out'), P, _stream())
     _check(code, 'amar_dual_chain_f32')
+
+
+def scatter(src, index, dst, window_off=None, n_windows=1):
+    """dst[index[t]] = src[t] (rows of a [n, 1] / [n] float32 destination), window by window: see amar_scatter_f32."""
+    n = int(index.numel())
+    if src.numel() < n or (window_off is not None and window_off.numel() != n_windows + 1):
+        raise ValueError("scatter: one source value per index and n_windows + 1 window offsets expected")
+    if n == 0:
+        return
+    _check(load().amar_scatter_f32(_ptr(src, torch.float32, 'src'), _ptr(index, torch.int32, 'index'), _ptr(dst, torch.float32, 'dst'),
+                                   _ld(dst, 'dst') if dst.dim() == 2 else 1, n, _ptr(window_off, torch.int32, 'window_off'),
+                                   int(n_windows), _stream()), 'amar_scatter_f32')
 
 
 def copy_columns(src, dst, ids=None, base=0):

@@ -21,6 +21,7 @@
 // differs from a plain dot product only by the fixed interleave (4g + r), well inside 1e-6.
 #include "amar_common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -329,7 +330,37 @@ __global__ __launch_bounds__(256) void chain_rows_kernel(const ChainArgs a) {
 
 // SCATTER: scores go to out[out_index[p]] (a pair list prepared in XCD-affine order writes back in the caller's order); the index is
 // requested at the top of the iteration, unconditionally like every other load here, and has the whole MFMA block to arrive.
-template <int MAXT, int PT, bool SCATTER>
+//
+// SPLIT (the default since round 3; AMAR_PAIR_MFMA=f32 keeps the f32 instruction): the layers' products run on
+// v_mfma_f32_16x16x32_bf16 with BOTH operands split into three bf16 parts.  A finite f32 is EXACTLY hi + mid + lo with each part
+// its next 8 significand bits (truncation splits: x - hi is exact, and so on), every bf16 x bf16 product is exact in f32, and the matrix
+// pipe accumulates in f32; of the nine part products the six with weight >= 2^-16 are taken (lo.hi, hi.lo, mid.mid, mid.hi, hi.mid,
+// hi.hi — small ones first), so a term x.w is off by at most 3 . 2^-24 |x.w|: the size of the f32 rounding of that product itself.
+// Not bit-identical to the f32 MFMA chain (tests/test_kernels_gpu.py bounds the difference); what it buys: 6 MFMAs of 16 cycles cover
+// k = 32 where the f32 instruction needs 8 of 32 cycles, and a bf16 MFMA holds the SIMD's vector issue for 8 of its 16 cycles only,
+// so the splitting (4.5 VALU instructions per activation) and the rest of the loop run beside the matrix pipe instead of behind it.
+// k-slot j of k-step s at lane group g is feature 16 (2s + j/4) + 4g + j%4: the two f32 tiles 2s, 2s+1 the lane already holds, so the
+// gathers, the register-resident hand-over between layers and the host-side weight pack are those of the f32 form — the workgroup
+// splits its LDS copy of the packed weights into bf16 fragments once, at its start.  With an odd tile count (48 = 3 tiles) the spare
+// half k-step carries the bias (activation 1.0 at feature 16 MAXT, the bias in the weight's row), so accumulators start at 0.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// a, b -> (hi, mid, lo) bf16 pairs, a in the low half
+struct Split3 { uint32_t h, m, l; };
+__device__ __forceinline__ Split3 split_pair(float a, float b) {
+    const uint32_t ab = __float_as_uint(a), bb = __float_as_uint(b);
+    Split3 q;
+    q.h = __builtin_amdgcn_perm(bb, ab, 0x07060302u);
+    const float a1 = a - __uint_as_float(ab & 0xffff0000u), b1 = b - __uint_as_float(bb & 0xffff0000u);
+    const uint32_t a1b = __float_as_uint(a1), b1b = __float_as_uint(b1);
+    q.m = __builtin_amdgcn_perm(b1b, a1b, 0x07060302u);
+    const float a2 = a1 - __uint_as_float(a1b & 0xffff0000u), b2 = b1 - __uint_as_float(b1b & 0xffff0000u);
+    q.l = __builtin_amdgcn_perm(__float_as_uint(b2), __float_as_uint(a2), 0x07060302u);
+    return q;
+}
+
+template <int MAXT, int PT, bool SCATTER, bool SPLIT>
 __global__ __launch_bounds__(256) void chain_pipe_kernel(const ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float w_lds[];
     for (int i = threadIdx.x * 4; i < a.wpack_floats; i += blockDim.x * 4)
@@ -337,6 +368,27 @@ __global__ __launch_bounds__(256) void chain_pipe_kernel(const ChainArgs a) {
     __syncthreads();
 
     const int lane = threadIdx.x & 63, g = lane >> 4, col = lane & 15;
+    constexpr int KS = (MAXT + 1) / 2;                       // bf16 k-steps of 32 (two f32 tiles each)
+    constexpr bool BIASK = SPLIT && (MAXT & 1);              // the bias rides in the spare half k-step
+    u32x4 *frag = reinterpret_cast<u32x4 *>(w_lds + ((a.wpack_floats + 3) & ~3));   // bf16 fragments [layer][m][s][part][lane]
+    if (SPLIT) {
+        for (int idx = threadIdx.x >> 6; idx < a.n_layers * MAXT * KS; idx += 4) {
+            const int l = idx / (MAXT * KS), m = (idx % (MAXT * KS)) / KS, sk = idx % KS;
+            const float *wl = w_lds + a.w_off[l];
+            const f32x4 wa = *reinterpret_cast<const f32x4 *>(wl + ((m * MAXT + 2 * sk) * 64 + lane) * 4);
+            f32x4 wb = {0.f, 0.f, 0.f, 0.f};
+            if (2 * sk + 1 < MAXT) wb = *reinterpret_cast<const f32x4 *>(wl + ((m * MAXT + 2 * sk + 1) * 64 + lane) * 4);
+            else if (BIASK && g == 0) wb[0] = w_lds[a.b_off[l] + 16 * m + col];
+            u32x4 *dst = frag + idx * 3 * 64 + lane;
+            const Split3 q0 = split_pair(wa[0], wa[1]), q1 = split_pair(wa[2], wa[3]), q2 = split_pair(wb[0], wb[1]), q3 = split_pair(wb[2], wb[3]);
+            u32x4 h, mm, lo;
+            h[0] = q0.h; h[1] = q1.h; h[2] = q2.h; h[3] = q3.h;
+            mm[0] = q0.m; mm[1] = q1.m; mm[2] = q2.m; mm[3] = q3.m;
+            lo[0] = q0.l; lo[1] = q1.l; lo[2] = q2.l; lo[3] = q3.l;
+            dst[0] = h; dst[64] = mm; dst[128] = lo;
+        }
+        __syncthreads();
+    }
     // Positions are 32-bit (the launcher checks P + 3 strides < 2^30): the ids' byte offsets stay 32-bit next to a scalar base
     // and a row address is ONE v_mad_u64_u32 (row x row bytes + base) — a dozen 64-bit VALU operations per iteration gone.
     constexpr uint32_t pairs_per_wave = 16 * PT;
@@ -370,6 +422,9 @@ __global__ __launch_bounds__(256) void chain_pipe_kernel(const ChainArgs a) {
             }
         }
     };
+#define AMAR_SPLIT_MFMA(W, X)                                                                                                   \
+    _Pragma("unroll") for (int pt = 0; pt < PT; ++pt)                                                                           \
+        y[m][pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W, __builtin_bit_cast(bf16x8, X[pt]), y[m][pt], 0, 0, 0)
     // one iteration: consume (va, vb), start the next iteration's gathers into (na, nb), run the layers, store
     auto step = [&](uint32_t base, int32_t (&ra)[PT], int32_t (&rb)[PT], f32x4 (&va)[MAXT][PT], f32x4 (&vb)[MAXT][PT],
                     f32x4 (&na)[MAXT][PT], f32x4 (&nb)[MAXT][PT]) {
@@ -388,7 +443,57 @@ __global__ __launch_bounds__(256) void chain_pipe_kernel(const ChainArgs a) {
             }
         issue(ra, rb, na, nb);                                     // next iteration's rows (the last pair's again past the end)
         load_ids(base + 2 * stride, ra, rb);
-        for (int l = 0; l < a.n_layers; ++l) {
+        for (int l = 0; SPLIT && l < a.n_layers; ++l) {
+            // activations -> bf16 parts, in B-operand order: dwords 0,1 = tile 2s, dwords 2,3 = tile 2s + 1
+            u32x4 xq[3][KS][PT];
+#pragma unroll
+            for (int sk = 0; sk < KS; ++sk)
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const int t = 2 * sk + hf;
+                        if (t < MAXT) {
+                            const Split3 q0 = split_pair(x[t][pt][0], x[t][pt][1]), q1 = split_pair(x[t][pt][2], x[t][pt][3]);
+                            xq[0][sk][pt][2 * hf] = q0.h; xq[1][sk][pt][2 * hf] = q0.m; xq[2][sk][pt][2 * hf] = q0.l;
+                            xq[0][sk][pt][2 * hf + 1] = q1.h; xq[1][sk][pt][2 * hf + 1] = q1.m; xq[2][sk][pt][2 * hf + 1] = q1.l;
+                        } else {
+                            xq[0][sk][pt][2] = (BIASK && g == 0) ? 0x00003f80u : 0u;       // bf16 1.0 at feature 16 MAXT
+                            xq[0][sk][pt][3] = 0u;
+                            xq[1][sk][pt][2] = xq[1][sk][pt][3] = xq[2][sk][pt][2] = xq[2][sk][pt][3] = 0u;
+                        }
+                    }
+                }
+            const u32x4 *fl = frag + (size_t)l * MAXT * KS * 3 * 64 + lane;
+            const float *bl = w_lds + a.b_off[l];
+            f32x4 y[MAXT][PT];
+#pragma unroll
+            for (int m = 0; m < MAXT; ++m) {
+                f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+                if (!BIASK) b4 = *reinterpret_cast<const f32x4 *>(bl + 16 * m + 4 * g);
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) y[m][pt] = b4;
+#pragma unroll
+                for (int sk = 0; sk < KS; ++sk) {
+                    const bf16x8 wh = __builtin_bit_cast(bf16x8, fl[((m * KS + sk) * 3 + 0) * 64]);
+                    const bf16x8 wm = __builtin_bit_cast(bf16x8, fl[((m * KS + sk) * 3 + 1) * 64]);
+                    const bf16x8 wo = __builtin_bit_cast(bf16x8, fl[((m * KS + sk) * 3 + 2) * 64]);
+                    AMAR_SPLIT_MFMA(wo, xq[0][sk]);
+                    AMAR_SPLIT_MFMA(wh, xq[2][sk]);
+                    AMAR_SPLIT_MFMA(wm, xq[1][sk]);
+                    AMAR_SPLIT_MFMA(wm, xq[0][sk]);
+                    AMAR_SPLIT_MFMA(wh, xq[1][sk]);
+                    AMAR_SPLIT_MFMA(wh, xq[0][sk]);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < MAXT; ++m)
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x[m][pt][r] = relu_bits(y[m][pt][r]);
+        }
+        for (int l = 0; !SPLIT && l < a.n_layers; ++l) {
             const float *wl = w_lds + a.w_off[l] + lane * 4;
             const float *bl = w_lds + a.b_off[l];
             f32x4 y[MAXT][PT];
@@ -459,6 +564,7 @@ __global__ __launch_bounds__(256) void chain_pipe_kernel(const ChainArgs a) {
             }
         }
     };
+#undef AMAR_SPLIT_MFMA
 
     uint32_t base = wave0 * pairs_per_wave;
     if (base >= P) return;
@@ -919,13 +1025,23 @@ static int chain_run(const float *A, int64_t lda, int32_t Da, const int32_t *ids
         if (blocks > 8192) blocks = 8192;
         const dim3 grid((unsigned)blocks), block(256);
         if (a.out_index && !a.has_dot) return AMAR_EUNSUPPORTED;
+        // products on the bf16 matrix instruction with three-way split operands (see the kernel's header); AMAR_PAIR_MFMA=f32: the f32 one
+        static const bool f32_only = getenv("AMAR_PAIR_MFMA") && !strcmp(getenv("AMAR_PAIR_MFMA"), "f32");
+        const size_t split_bytes = (((size_t)off + 3) & ~(size_t)3) * sizeof(float) + (size_t)a.n_layers * maxt * ((maxt + 1) / 2) * 3 * 1024;
+        const bool split = !f32_only && split_bytes <= 64 * 1024;
+        static const size_t lds_pad = getenv("AMAR_CHAIN_LDS_PAD") ? (size_t)atoi(getenv("AMAR_CHAIN_LDS_PAD")) : 0;   // dev: fewer resident workgroups
+        const size_t lds = (split ? split_bytes : lds_bytes) + ((split ? split_bytes : lds_bytes) + lds_pad <= 64 * 1024 ? lds_pad : 0);
+#define AMAR_PIPE_LAUNCH(MT, SC)                                                                                          \
+        do {                                                                                                              \
+            if (split) hipLaunchKernelGGL((chain_pipe_kernel<MT, 2, SC, true>), grid, block, lds, st, a);                 \
+            else hipLaunchKernelGGL((chain_pipe_kernel<MT, 2, SC, false>), grid, block, lds, st, a);                      \
+        } while (0)
         if (a.out_index) {
-            if (maxt == 3) hipLaunchKernelGGL((chain_pipe_kernel<3, 2, true>), grid, block, lds_bytes, st, a);
-            else hipLaunchKernelGGL((chain_pipe_kernel<4, 2, true>), grid, block, lds_bytes, st, a);
+            if (maxt == 3) AMAR_PIPE_LAUNCH(3, true); else AMAR_PIPE_LAUNCH(4, true);
         } else {
-            if (maxt == 3) hipLaunchKernelGGL((chain_pipe_kernel<3, 2, false>), grid, block, lds_bytes, st, a);
-            else hipLaunchKernelGGL((chain_pipe_kernel<4, 2, false>), grid, block, lds_bytes, st, a);
+            if (maxt == 3) AMAR_PIPE_LAUNCH(3, false); else AMAR_PIPE_LAUNCH(4, false);
         }
+#undef AMAR_PIPE_LAUNCH
         return amar_check_launch();
     }
     // entity towers (one table, no dot, ReLU with an optionally linear last layer) in a shape with a compile-time kernel; AMAR_CHAIN_ROWS=0

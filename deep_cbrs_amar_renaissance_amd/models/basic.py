@@ -144,8 +144,21 @@ class BasicRS(Model):
         blob, dims, acts = plan['rest']
         m = u_ids.numel() if u_ids is not None else tu.shape[0]
         out = torch.empty((m, 1), dtype=torch.float32, device=tu.device)
+        if u_ids is None or i_ids is None:
+            # rows themselves (the per-batch call, towers evaluated per pair): numbered 0..m-1, so that this call too runs the pair-stage
+            # kernel — the same products as the hoisted path, hence the same bits (the generic kernel multiplies on the f32 instruction)
+            rows = getattr(self, '_row_ids', None)
+            if rows is None or rows.numel() < m or rows.device != tu.device:
+                rows = self._row_ids = torch.arange(max(m, 4096), dtype=torch.int32, device=tu.device)
+            u_ids, u_base = (rows[:m], 0) if u_ids is None else (u_ids, u_base)
+            i_ids, i_base = (rows[:m], 0) if i_ids is None else (i_ids, i_base)
         if pair_plan is not None:
             pair_plan.check(u_ids, i_ids)
+            if pair_plan.mid_index is not None:
+                capi.chain(tu, blob, dims, acts, pair_plan.mid.view(-1, 1), ids_a=pair_plan.u_ids, base_a=u_base, B=ti, ids_b=pair_plan.i_ids,
+                           base_b=i_base, sum_inputs=True, in_act=plan['in_act'], out_index=pair_plan.mid_index)
+                capi.scatter(pair_plan.mid, pair_plan.final_index, out, pair_plan.window_off, pair_plan.n_windows)
+                return out
             capi.chain(tu, blob, dims, acts, out, ids_a=pair_plan.u_ids, base_a=u_base, B=ti, ids_b=pair_plan.i_ids, base_b=i_base,
                        sum_inputs=True, in_act=plan['in_act'], out_index=pair_plan.out_index)
             return out
@@ -196,6 +209,26 @@ class PairPlan:
         self.i_ids = i_ids[src].contiguous()
         self.out_index = src.to(torch.int32).contiguous()
         self._key = (u_ids.data_ptr(), i_ids.data_ptr(), p)
+        # The way back to the caller's order in two steps (round 3).  Stored straight to out[out_index[.]], 12 M single words at random
+        # over 48 MB are each a line fetched and written back: 0.19 ms of the 0.60 ms launch at ml1m(s=64), memory-side work next to
+        # the gathers'.  Instead the kernel stores to mid[mid_index[.]], a scratch vector ordered by (WINDOW of the final position, XCD,
+        # list position) — each XCD appends to one open line per window, which its L2 completes —, and amar_scatter_f32 finishes inside
+        # the windows, one window per XCD at a time (window_off).  AMAR_PAIR_WINDOW=0: the direct store.
+        self.window = int(os.environ.get('AMAR_PAIR_WINDOW', str(1 << 16)))
+        self.mid_index = self.final_index = self.window_off = self.mid = None
+        self.n_windows = 0
+        if self.window > 0 and p > 2 * self.window:
+            n_win = -(-p // self.window)
+            key = (src // self.window) * self.N_XCD + (pos // self.CHUNK) % self.N_XCD
+            by_key = torch.argsort(key * p + pos)
+            mid_index = torch.empty(p, dtype=torch.int32, device=dev)
+            mid_index[by_key] = torch.arange(p, dtype=torch.int32, device=dev)
+            self.mid_index = mid_index
+            self.final_index = self.out_index[by_key].contiguous()
+            counts = torch.bincount(src // self.window, minlength=n_win)
+            self.window_off = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(counts, 0)]).to(torch.int32)
+            self.n_windows = n_win
+            self.mid = torch.empty(p, dtype=torch.float32, device=dev)
 
     def check(self, u_ids, i_ids):
         if (u_ids.data_ptr(), i_ids.data_ptr(), int(u_ids.numel())) != self._key:

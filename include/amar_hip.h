@@ -298,6 +298,16 @@ int amar_copy_columns_f32(const float *src, int64_t lds, const int32_t *ids, int
 int amar_reduce_layers_f32(const float *cat, int64_t ld, int32_t n_layers, int32_t width, float *out, int64_t ldo,
                            int64_t n_rows, int32_t mean, amar_stream_t stream);
 
+/* dst[index[t] * ldd] = src[t] for t in [0, n): Keras `predict` returns the scores in the order of the Sequence's pairs
+ * (src/data/datasets.py:199-213 — the test Sequence is not shuffled, its order is the file's), while the pair stage walks
+ * a list prepared for its gathers; this is the second half of the way back.  The positions are visited window by window
+ * (window w = [window_off[w], window_off[w + 1]), device array of n_windows + 1 entries; NULL: n_windows equal slices),
+ * all workgroups of one XCD in the same window: prepared so that a window's destinations are a narrow range of dst, its
+ * lines are completed in that XCD's L2 and leave it whole.  index must be a partial permutation (no two t with the same
+ * destination); n < 2^31. */
+int amar_scatter_f32(const float *src, const int32_t *index, float *dst, int64_t ldd, int64_t n,
+                     const int32_t *window_off, int32_t n_windows, amar_stream_t stream);
+
 /* ReductionLayer('w-sum') = WeightedSum (src/layers/reduction.py:36-55): out = sum over the n_layers column blocks of
  * (w[l] * w[l]) * X_l with a learnable device vector w [n_layers] (initialised to ones); products rounded, then added in layer order.
  * n_layers <= 8.  The reverse pass writes d_cat[:, block l] = w[l]^2 d_out and dw[l] = 2 w[l] sum(d_out . X_l), the sums formed per

@@ -1155,6 +1155,65 @@ def test_pair_plan_scores_equal_direct(hip):
         rs.score_towers(tw, u.clone(), i, 0, nu, pair_plan=plan)
 
 
+@pytest.mark.parametrize('width', [48, 64])
+def test_pair_stage_split_products_against_f32_and_f64(hip, width):
+    """The pair-stage kernel takes its products on the bf16 matrix instruction with both operands split three ways (csrc/amar_chain.hip,
+    SPLIT): as accurate as the f32 instruction, not bit-identical to it.  Against a float64 evaluation of the same head both forms must
+    be equally close (1e-6 is 100 times tighter than the north star's 1e-4), and the two forms must agree within a few ulps of a score:
+    the f32 form here is the generic kernel on pre-gathered, pre-summed rows (exact f32 MFMA chain)."""
+    from deep_cbrs_amar_renaissance_amd import capi, engine
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    engine.set_seed(11)
+    nu, ni, P = 3000, 2000, 150_003
+    rs = basic.BasicRS([width // 2, width // 2], [width, width])
+    rs.build_head(24, 24)
+    helpers.randomize_biases(rs, seed=12)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(13)
+    emb = torch.randn((nu + ni, 24), device=DEV, generator=g) * 3.0                     # activations up to a few tens
+    u = torch.randint(0, nu, (P,), device=DEV, generator=g, dtype=torch.int32)
+    i = (torch.randint(0, ni, (P,), device=DEV, generator=g, dtype=torch.int32) + nu).to(torch.int32)
+    tu, ti, split = rs.towers(emb[:nu], emb[nu:])
+    assert split
+    got = rs.score_towers((tu, ti, True), u, i, 0, nu).view(-1)
+    blob, dims, acts = rs._split_cache[1]['rest']
+    x = torch.relu(tu[u.long()] + ti[(i - nu).long()]).contiguous()                      # the summed input, exactly as the kernel forms it
+    f32 = torch.empty((P, 1), dtype=torch.float32, device=DEV)
+    capi.chain(x, blob, dims, acts, f32)                                                 # generic kernel, rows themselves: f32 MFMA
+    f32 = f32.view(-1)
+    ref = x.double()
+    layers = list(rs.clf.layers)[1:]
+    for l in layers[:-1]:
+        ref = torch.relu(ref @ l.kernel.detach().double() + l.bias.detach().double())
+    ref = torch.sigmoid(ref @ layers[-1].kernel.detach().double() + layers[-1].bias.detach().double()).view(-1)
+    e_split, e_f32 = (got.double() - ref).abs(), (f32.double() - ref).abs()
+    assert float(e_split.max()) < 1e-6 and float(e_f32.max()) < 1e-6
+    assert float(e_split.mean()) < 1.5 * float(e_f32.mean()) + 1e-9                      # no less accurate than the f32 instruction
+    assert float((got - f32).abs().max()) < 5e-7
+
+
+def test_scatter_by_windows(hip):
+    """amar_scatter_f32: dst[index[t]] = src[t], visited window by window; any window table gives the same result as none."""
+    from deep_cbrs_amar_renaissance_amd import capi
+    g = torch.Generator(device=DEV)
+    g.manual_seed(21)
+    n = 300_007
+    src = torch.randn(n, device=DEV, generator=g)
+    index = torch.randperm(n, device=DEV, generator=g).to(torch.int32)
+    want = torch.empty(n, device=DEV)
+    want[index.long()] = src
+    for n_win, off in ((1, None), (13, None), (5, torch.tensor([0, 10, 10, 200_000, 300_000, n], dtype=torch.int32, device=DEV))):
+        dst = torch.full((n, 1), float('nan'), device=DEV)
+        capi.scatter(src, index, dst, off, n_win)
+        assert torch.equal(dst.view(-1), want)
+    wide = torch.zeros((n, 3), device=DEV)                                               # a column of a wider destination
+    capi.scatter(src, index, wide[:, 1:2], None, 7)
+    assert torch.equal(wide[:, 1], want) and float(wide[:, 0].abs().max()) == 0.0 and float(wide[:, 2].abs().max()) == 0.0
+    capi.scatter(src[:0], index[:0], wide[:, 1:2], None, 1)                              # nothing to do
+    with pytest.raises(ValueError):
+        capi.scatter(src, index, wide[:, 1:2], torch.zeros(3, dtype=torch.int32, device=DEV), 7)
+
+
 @pytest.mark.parametrize('F,C', [(8, 8), (16, 16), (32, 32), (16, 8)])
 @pytest.mark.parametrize('self_loops', [True, False])
 def test_sage_mean_on_lds_tiled(hip, F, C, self_loops, monkeypatch):

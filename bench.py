@@ -47,6 +47,7 @@ GRID3 = dict(GRID1, embedding_dim=32, n_hiddens=[32, 32], dense_units=[96, 48], 
 HYBRID_GRID1 = dict(embedding_dim=8, n_hiddens=[8, 8], dense_units=[[24, 24], [256, 64], [64, 64]], clf_units=[64, 64],
                     feature_based=True)
 HBM_PEAK_GBPS = 8000.0
+MFMA_BF16_PEAK_TFLOPS = 2500.0         # dense bf16 (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3
 L2_REQUESTS_PER_S = 270e9          # 256 CUs x 0.44 line requests per clock at 2.4 GHz (profiles/r1_exp_gather_frontend.txt)
 
@@ -647,6 +648,15 @@ def main():
         e1.record()
         pair_events.append((e0, e1))
     capi.chain = timed_chain
+    scatter_events, raw_scatter = [], capi.scatter
+
+    def timed_scatter(*a, **k):                                # the second launch of the pair stage: scores into the caller's order
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        raw_scatter(*a, **k)
+        e1.record()
+        scatter_events.append((e0, e1))
+    capi.scatter = timed_scatter
     multi = world > 1 or force_dist
     cdev = 'cpu' if rehearse else dev                          # gloo reduces host tensors
 
@@ -660,6 +670,7 @@ def main():
     barrier()
     spmm_events.clear()
     pair_events.clear()
+    scatter_events.clear()
     del kinds_seen[:]
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -669,6 +680,7 @@ def main():
     eager_dt = time.perf_counter() - t0
     restore_spmm()
     capi.chain = raw_chain
+    capi.scatter = raw_scatter
     phases = runner.phase_times() if hasattr(runner, 'phase_times') else None      # the last eager step, by phase (typed partition)
     step = runner.step
     if graph_step:
@@ -770,25 +782,44 @@ def main():
             pair_alg = pairs_local * (2 * c1 * 4 + 2 * 4 + 4)                 # what the kernel gathers: two folded 192-B rows
             pair_alg_8d = pairs_local * 204                                    # two 24-float rows + ids + score
             pms = float(np.mean(pair_ms))
+            sms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in scatter_events])) if scatter_events else 0.0
             flop_pair = 2 * (c1 * c2 + c2)
-            out['pair_stage'] = {'kernel': 'chain_pipe_kernel<3,2> (relu(T_u[u] + T_i[i]) -> Dense 48 -> Dense 1, sigmoid)',
-                                 'avg_launch_ms': pms, 'pairs_per_launch': pairs_local, 'bound': 'mfma',
+            f32_form = os.environ.get('AMAR_PAIR_MFMA') == 'f32'
+            # executed on the bf16 pipe: 6 part products x (tiles of 16 outputs) x (k-steps of 32) x 16x16x32 MACs per 16 pairs
+            bf16_flop_pair = 6 * (-(-c2 // 16)) * (-(-c1 // 32)) * (16 * 16 * 32 * 2) / 16.0
+            out['pair_stage'] = {'kernel': 'chain_pipe_kernel<3,2> (relu(T_u[u] + T_i[i]) -> Dense 48 -> Dense 1, sigmoid)' +
+                                           (' + scatter_windows_kernel (scores into the caller\'s order)' if scatter_events else ''),
+                                 'avg_launch_ms': pms, 'scatter_launch_ms': sms, 'stage_ms': pms + sms,
+                                 'pairs_per_launch': pairs_local, 'bound': 'mfma',
                                  'bound_note': 'with the prepared pair list the gathered rows come from the L2s (traffic = what the memory side moved, '
-                                               'about half the gathered bytes) and the compute side binds: fp32 MFMA and VALU time add up on gfx950 '
-                                               '(the mfma object); the byte fractions below are kept for comparison with SURVEY 8(d) and may exceed 1',
+                                               'about half the gathered bytes); the scores go back to the caller\'s order in two steps (window streams '
+                                               'from the kernel, amar_scatter_f32 inside the windows: scatter_launch_ms) because 12 M single-word stores '
+                                               'at random cost 0.19 ms of memory-side work inside the launch; the kernel itself is bound by vector issue: '
+                                               + ('fp32 MFMA and VALU time add up on gfx950' if f32_form else
+                                                  'its products run on the bf16 matrix instruction with both operands split three ways (f32-accurate, '
+                                                  'DESIGN 4b) and the splitting shares the SIMD\'s issue port with the MFMAs') +
+                                               '; the byte fractions below are kept for comparison with SURVEY 8(d) and may exceed 1',
                                  'algorithmic_bytes_per_launch': pair_alg, 'achieved': pair_alg / (pms * 1e-3) / 1e9,
                                  'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': pair_alg / (pms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                  'frac_label': '396 B/pair: the two 48-float per-entity rows (classifier layer 1 folded into the towers) + ids + score',
                                  'frac_8d': pair_alg_8d / (pms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                  'frac_8d_label': '204 B/pair as SURVEY 8(d) counts it (two 24-float rows): the fold doubles the gathered bytes to halve the MFMA work',
                                  'traffic': pmc.get('pair_stage_traffic_bytes_per_launch') if pmc else None, 'traffic_source': traffic_source,
-                                 # the same launch against the fp32 MFMA peak (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s dense)
+                                 # the same launch against the matrix-pipe peaks: the f32 work it stands for against the f32 MFMA peak
+                                 # (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s dense), and what it executes against the dense bf16 peak
                                  'mfma': {'flop_per_pair': flop_pair,
-                                          'flop_note': 'per-pair work after hoisting the towers and the first classifier layer per entity '
+                                          'flop_note': 'per-pair f32 work after hoisting the towers and the first classifier layer per entity '
                                                        '(SURVEY 8(d) counts 13 920 flop/pair for the un-hoisted head; test_faithful_equals_hoisted_and_predict keeps the two equal)',
                                           'achieved_tflops': pairs_local * flop_pair / (pms * 1e-3) / 1e12,
                                           'peak_tflops': MFMA_F32_PEAK_TFLOPS,
                                           'frac': pairs_local * flop_pair / (pms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                          'frac_note': 'f32-equivalent work over the f32 MFMA peak: what an exact-f32 formulation could reach at most is 1',
+                                          'executed': None if f32_form else {
+                                              'instruction': 'v_mfma_f32_16x16x32_bf16, six part products per f32 product, k padded 48 -> 64',
+                                              'flop_per_pair': bf16_flop_pair,
+                                              'achieved_tflops': pairs_local * bf16_flop_pair / (pms * 1e-3) / 1e12,
+                                              'peak_tflops': MFMA_BF16_PEAK_TFLOPS,
+                                              'frac': pairs_local * bf16_flop_pair / (pms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
                                           'pmc_busy_frac': pmc.get('pair_stage_mfma_busy_frac') if pmc else None}}
         if world == 1 and not args.no_cpu_baseline:
             # the headline workload's own inputs for the CPU leg (host copies), before the GPU objects go

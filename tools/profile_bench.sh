@@ -15,7 +15,7 @@ echo "rc=$?"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES"; do
   name=$(echo $pass | cut -d' ' -f1)
   echo "== pmc $pass"; date
-  timeout -k 10 240 rocprofv3 --pmc $pass --kernel-include-regex "spmm_|chain_" --output-format csv -d "$ROOT/$OUT/pmc_$name" -- python $ARGS > "$ROOT/$OUT/pmc_$name.log" 2>&1
+  timeout -k 10 240 rocprofv3 --pmc $pass --kernel-include-regex "spmm_|chain_|scatter_" --output-format csv -d "$ROOT/$OUT/pmc_$name" -- python $ARGS > "$ROOT/$OUT/pmc_$name.log" 2>&1
   echo "rc=$?"
 done
 cd "$ROOT"
@@ -57,6 +57,9 @@ if cf is not None:
     busy, act = get('chain_pipe_kernel', 'SQ_VALU_MFMA_BUSY_CYCLES'), get('chain_pipe_kernel', 'GRBM_GUI_ACTIVE')
     if busy and act:
         js['pair_stage_mfma_busy_frac'] = busy / 1024.0 / (act / 8.0)     # busy cycles summed over 1024 SIMDs / active cycles summed over 8 XCDs
+sf, sw = get('scatter_windows_kernel', 'FETCH_SIZE'), get('scatter_windows_kernel', 'WRITE_SIZE')
+if sf is not None:
+    js['pair_stage_scatter_traffic_bytes_per_launch'] = (2 * sf + sw) * 1024
 json.dump(js, open(os.path.join('profiles', 'spmm_pmc_latest.json'), 'w'), indent=1)
 print('## profiles/spmm_pmc_latest.json'); print(json.dumps(js, indent=1))
 PY

@@ -51,6 +51,7 @@ SIGNATURES = {
     'amar_chain_indexed_f32': (ctypes.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _I32, _P, _I32, _I32, _I32, _P, _P, _P, _I32, _P, _I64, _P, _I64, _P]),
     'amar_chain_segments_f32': (ctypes.c_int, [_P, _P, _P, _I32, _P, _I32, _P, _P, _P, _I32, _P, _I64, _I64, _P]),
     'amar_dual_chain_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _I32, _P, _P, _I64, _I64, _P]),
+    'amar_dual_chain_indexed_f32': (ctypes.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P, _P, _P, _I32, _P, _P, _I64, _P, _I64, _P]),
     'amar_copy_columns_f32': (ctypes.c_int, [_P, _I64, _P, _I32, _P, _I64, _I64, _I32, _P]),
     'amar_scatter_f32': (ctypes.c_int, [_P, _P, _P, _I64, _I64, _P, _I32, _P]),
     'amar_reduce_layers_f32': (ctypes.c_int, [_P, _I64, _I32, _I32, _P, _I64, _I64, _I32, _P]),
@@ -609,8 +610,10 @@ def dual_chain_supported(D, n_branch_dims_equal, trunk_dims):
             and trunk_dims[-1] == 1 and len(set(trunk_dims[1:-1])) == 1 and trunk_dims[1] <= 64 and trunk_dims[1] % 4 == 0)
 
 
-def dual_chain(tables_a, tables_b, ids_a, ids_b, bases_a, bases_b, D, in_act, branch_acts, trunk_dims, trunk_acts, wpack, out):
-    """Fused two-branch head: see amar_dual_chain_f32. tables_* / ids_* / bases_* are 2-element sequences."""
+def dual_chain(tables_a, tables_b, ids_a, ids_b, bases_a, bases_b, D, in_act, branch_acts, trunk_dims, trunk_acts, wpack, out,
+               out_index=None):
+    """Fused two-branch head: see amar_dual_chain_f32. tables_* / ids_* / bases_* are 2-element sequences; out_index (int32 [P]):
+    pair p goes to out[out_index[p]] (amar_dual_chain_indexed_f32)."""
     P = out.shape[0]
     arr = lambda vals, ctype: (ctype * 2)(*vals)
     A = arr([_ptr(t, torch.float32, 'A') for t in tables_a], ctypes.c_void_p)
@@ -626,10 +629,13 @@ def dual_chain(tables_a, tables_b, ids_a, ids_b, bases_a, bases_b, D, in_act, br
     bacts = (ctypes.c_int32 * max(1, len(branch_acts)))(*[ACT_CODES[a] for a in branch_acts])
     tdims = (ctypes.c_int32 * len(trunk_dims))(*trunk_dims)
     tacts = (ctypes.c_int32 * len(trunk_acts))(*[ACT_CODES[a] for a in trunk_acts])
-    code = load().amar_dual_chain_f32(A, lda, IA, ba, B, ldb, IB, bb, D, ACT_CODES[in_act], len(branch_acts), bacts,
-                                      tdims, tacts, len(trunk_acts), _ptr(wpack, torch.float32, 'wpack'),
-                                      _ptr(out, torch.float32, 'out'), _ld(out, 'out'), P, _stream())
-    _check(code, 'amar_dual_chain_f32')
+    if out_index is not None and out_index.numel() != P:
+        raise ValueError("dual_chain: out_index must have one entry per output row")
+    code = load().amar_dual_chain_indexed_f32(A, lda, IA, ba, B, ldb, IB, bb, D, ACT_CODES[in_act], len(branch_acts), bacts,
+                                              tdims, tacts, len(trunk_acts), _ptr(wpack, torch.float32, 'wpack'),
+                                              _ptr(out, torch.float32, 'out'), _ld(out, 'out'), _ptr(out_index, torch.int32, 'out_index'),
+                                              P, _stream())
+    _check(code, 'amar_dual_chain_f32' if out_index is None else 'amar_dual_chain_indexed_f32')
 
 
 def scatter(src, index, dst, window_off=None, n_windows=1):

@@ -360,6 +360,29 @@ __device__ __forceinline__ Split3 split_pair(float a, float b) {
     return q;
 }
 
+// two f32 tiles of a lane (k-slots 0..3 and 4..7 of one bf16 k-step) -> the three bf16 operands
+struct Split3x4 { u32x4 h, m, l; };
+__device__ __forceinline__ Split3x4 split_tiles(const f32x4 &t0, const f32x4 &t1) {
+    const Split3 q0 = split_pair(t0[0], t0[1]), q1 = split_pair(t0[2], t0[3]), q2 = split_pair(t1[0], t1[1]), q3 = split_pair(t1[2], t1[3]);
+    Split3x4 o;
+    o.h[0] = q0.h; o.h[1] = q1.h; o.h[2] = q2.h; o.h[3] = q3.h;
+    o.m[0] = q0.m; o.m[1] = q1.m; o.m[2] = q2.m; o.m[3] = q3.m;
+    o.l[0] = q0.l; o.l[1] = q1.l; o.l[2] = q2.l; o.l[3] = q3.l;
+    return o;
+}
+// acc += W . X over one k-step of 32 with both operands split: the six part products of weight >= 2^-16, small ones first
+__device__ __forceinline__ f32x4 split_mfma(const u32x4 *w, const Split3x4 &x, f32x4 acc) {
+    const bf16x8 wh = __builtin_bit_cast(bf16x8, w[0]), wm = __builtin_bit_cast(bf16x8, w[64]), wl = __builtin_bit_cast(bf16x8, w[128]);
+    const bf16x8 xh = __builtin_bit_cast(bf16x8, x.h), xm = __builtin_bit_cast(bf16x8, x.m), xl = __builtin_bit_cast(bf16x8, x.l);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wm, xh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc, 0, 0, 0);
+    return acc;
+}
+
 template <int MAXT, int PT, bool SCATTER, bool SPLIT>
 __global__ __launch_bounds__(256) void chain_pipe_kernel(const ChainArgs a) {
     extern __shared__ __attribute__((aligned(16))) float w_lds[];
@@ -589,6 +612,11 @@ struct DualArgs {
     int dot_off, dot_bias_off, dot_act;
     const float *wpack; int wpack_floats;
     float *out; int64_t ldo; int64_t P;
+    const int32_t *out_index;             // pair p is written to out row out_index[p] (a pair list kept in another order), or NULL
+    // split-product form (dual_chain_split_kernel): LDS holds bf16 fragments [layer][m][s][part][lane] (16 bytes each) followed by an f32
+    // tail with the biases and the 1-unit layer; *_frag = first fragment triple of a layer, *_tail = float offset inside the tail
+    int n_frag, tail_floats;
+    int bw_frag[2][CHAIN_MAX_LAYERS], bb_tail[2][CHAIN_MAX_LAYERS], tw_frag[CHAIN_MAX_LAYERS], tb_tail[CHAIN_MAX_LAYERS], dot_tail, dot_bias_tail;
 };
 
 template <int PT>
@@ -724,7 +752,7 @@ __global__ __launch_bounds__(1024) void dual_chain_kernel(const DualArgs a) {
             sacc += __shfl_xor(sacc, 16, 64);
             sacc += __shfl_xor(sacc, 32, 64);
             const int64_t p = base + 16 * pt + col;
-            if (g == 0 && p < a.P) a.out[p * a.ldo] = chain_act(sacc + bd, a.dot_act);
+            if (g == 0 && p < a.P) a.out[(a.out_index ? (int64_t)a.out_index[p] : p) * a.ldo] = chain_act(sacc + bd, a.dot_act);
         }
     }
 }
@@ -836,7 +864,137 @@ __global__ __launch_bounds__(1024) void dual_chain_full_kernel(const DualArgs a)
         }
         sacc += __shfl_xor(sacc, 16, 64);
         sacc += __shfl_xor(sacc, 32, 64);
-        if (g == 0 && ok) a.out[p * a.ldo] = chain_act(sacc + w_lds[a.dot_bias_off], a.dot_act);
+        if (g == 0 && ok) a.out[(a.out_index ? (int64_t)a.out_index[p] : p) * a.ldo] = chain_act(sacc + w_lds[a.dot_bias_off], a.dot_act);
+    }
+}
+
+// The same head with its products on the bf16 matrix instruction, both operands split three ways (the pair-stage kernel's SPLIT form
+// above: f32-accurate, 6 MFMAs of 16 cycles per k-step of 32 instead of 8 of 32 cycles).  The f32 weight blob (84 KB for the 64-wide
+// stacks) is split by the workgroup into 126 KB of bf16 fragments at its start, straight from global memory — blob and fragments
+// would not fit the LDS together; biases and the 1-unit layer stay f32 in a small tail.  AMAR_PAIR_MFMA=f32 keeps the f32 kernel.
+__global__ __launch_bounds__(1024) void dual_chain_split_kernel(const DualArgs a) {
+    constexpr int T = 4, KS = 2;
+    extern __shared__ __attribute__((aligned(16))) float w_lds[];
+    u32x4 *frag = reinterpret_cast<u32x4 *>(w_lds);
+    float *tail = w_lds + (size_t)a.n_frag * 3 * 64 * 4;
+    const int lane = threadIdx.x & 63, g = lane >> 4, col = lane & 15;
+    const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
+    {
+        // fragment triple f of a layer with KT input tiles: (m, s) = (f / (KT/2), f % (KT/2)); its two f32 tiles are 2s and 2s + 1
+        auto build = [&](int w_off, int kt, int frag0) {
+            const int ks = kt / 2;
+            for (int f = wave; f < T * ks; f += wpb) {
+                const int m = f / ks, sk = f % ks;
+                const float *wl = a.wpack + w_off + ((size_t)(m * kt + 2 * sk) * 64 + lane) * 4;
+                const Split3x4 q = split_tiles(*reinterpret_cast<const f32x4 *>(wl), *reinterpret_cast<const f32x4 *>(wl + 256));
+                u32x4 *dst = frag + (size_t)(frag0 + f) * 3 * 64 + lane;
+                dst[0] = q.h; dst[64] = q.m; dst[128] = q.l;
+            }
+        };
+        for (int br = 0; br < 2; ++br)
+            for (int l = 0; l < a.n_branch; ++l) build(a.bw_off[br][l], T, a.bw_frag[br][l]);
+        for (int l = 0; l < a.n_trunk; ++l) build(a.tw_off[l], l == 0 ? 2 * T : T, a.tw_frag[l]);
+        for (int i = threadIdx.x; i < 16 * T; i += blockDim.x) {
+            for (int br = 0; br < 2; ++br)
+                for (int l = 0; l < a.n_branch; ++l) tail[a.bb_tail[br][l] + i] = a.wpack[a.bb_off[br][l] + i];
+            for (int l = 0; l < a.n_trunk; ++l) tail[a.tb_tail[l] + i] = a.wpack[a.tbias_off[l] + i];
+            tail[a.dot_tail + i] = a.wpack[a.dot_off + i];
+        }
+        if (threadIdx.x == 0) tail[a.dot_bias_tail] = a.wpack[a.dot_bias_off];
+    }
+    __syncthreads();
+    const int64_t wave0 = (int64_t)blockIdx.x * wpb + wave;
+    const int64_t stride = (int64_t)gridDim.x * wpb * 16;
+
+    for (int64_t base = wave0 * 16; base < a.P; base += stride) {
+        const int64_t p = base + col;
+        const bool ok = p < a.P;                               // pairs past the end read row 0 and are never stored
+        f32x4 va[2][T], vb[2][T];
+#pragma unroll
+        for (int br = 0; br < 2; ++br) {
+            const uint32_t ra = ok ? (uint32_t)(a.ida[br][p] - a.base_a[br]) : 0u;
+            const uint32_t rb = ok ? (uint32_t)(a.idb[br][p] - a.base_b[br]) : 0u;
+            const float *pa = a.A[br] + (uint64_t)ra * (uint32_t)a.lda[br] + 4 * g;
+            const float *pb = a.B[br] + (uint64_t)rb * (uint32_t)a.ldb[br] + 4 * g;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                va[br][t] = *reinterpret_cast<const f32x4 *>(pa + 16 * t);
+                vb[br][t] = *reinterpret_cast<const f32x4 *>(pb + 16 * t);
+            }
+        }
+        Split3x4 xq[2][KS];                                    // the branches' outputs, split: the trunk's first layer reads all four k-steps
+#pragma unroll
+        for (int br = 0; br < 2; ++br) {
+            f32x4 xb[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                f32x4 v = va[br][t] + vb[br][t];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = relu_bits(v[r]);
+                xb[t] = v;
+            }
+#pragma unroll
+            for (int sk = 0; sk < KS; ++sk) xq[br][sk] = split_tiles(xb[2 * sk], xb[2 * sk + 1]);
+            for (int l = 0; l < a.n_branch; ++l) {
+                const u32x4 *fl = frag + (size_t)a.bw_frag[br][l] * 3 * 64 + lane;
+                const float *bl = tail + a.bb_tail[br][l];
+                f32x4 y[T];
+#pragma unroll
+                for (int m = 0; m < T; ++m) {
+                    y[m] = *reinterpret_cast<const f32x4 *>(bl + 16 * m + 4 * g);
+#pragma unroll
+                    for (int sk = 0; sk < KS; ++sk) y[m] = split_mfma(fl + (m * KS + sk) * 3 * 64, xq[br][sk], y[m]);
+                }
+#pragma unroll
+                for (int m = 0; m < T; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) y[m][r] = relu_bits(y[m][r]);
+#pragma unroll
+                for (int sk = 0; sk < KS; ++sk) xq[br][sk] = split_tiles(y[2 * sk], y[2 * sk + 1]);
+            }
+        }
+        // ---- trunk: the first layer reads [xa || xb] (four k-steps), later layers two
+        f32x4 x[T];
+        Split3x4 xt[KS];
+        for (int l = 0; l < a.n_trunk; ++l) {
+            const u32x4 *fl = frag + (size_t)a.tw_frag[l] * 3 * 64 + lane;
+            const float *bl = tail + a.tb_tail[l];
+            f32x4 y[T];
+            if (l == 0) {
+#pragma unroll
+                for (int m = 0; m < T; ++m) {
+                    y[m] = *reinterpret_cast<const f32x4 *>(bl + 16 * m + 4 * g);
+#pragma unroll
+                    for (int sk = 0; sk < 2 * KS; ++sk) y[m] = split_mfma(fl + (m * 2 * KS + sk) * 3 * 64, xq[sk / KS][sk % KS], y[m]);
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < T; ++m) {
+                    y[m] = *reinterpret_cast<const f32x4 *>(bl + 16 * m + 4 * g);
+#pragma unroll
+                    for (int sk = 0; sk < KS; ++sk) y[m] = split_mfma(fl + (m * KS + sk) * 3 * 64, xt[sk], y[m]);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < T; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[m][r] = relu_bits(y[m][r]);
+            if (l + 1 < a.n_trunk) {
+#pragma unroll
+                for (int sk = 0; sk < KS; ++sk) xt[sk] = split_tiles(x[2 * sk], x[2 * sk + 1]);
+            }
+        }
+        const float *wd = tail + a.dot_tail;
+        float sacc = 0.f;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wd + 16 * t + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sacc = fmaf(x[t][r], w4[r], sacc);
+        }
+        sacc += __shfl_xor(sacc, 16, 64);
+        sacc += __shfl_xor(sacc, 32, 64);
+        if (g == 0 && ok) a.out[(a.out_index ? (int64_t)a.out_index[p] : p) * a.ldo] = chain_act(sacc + tail[a.dot_bias_tail], a.dot_act);
     }
 }
 
@@ -1095,6 +1253,16 @@ int amar_dual_chain_f32(const float *const *A, const int64_t *lda, const int32_t
                         int32_t D, int32_t in_act, int32_t n_branch, const int32_t *branch_acts,
                         const int32_t *trunk_dims, const int32_t *trunk_acts, int32_t n_trunk,
                         const float *wpack, float *out, int64_t ldo, int64_t P, amar_stream_t stream) {
+    return amar_dual_chain_indexed_f32(A, lda, ida, base_a, B, ldb, idb, base_b, D, in_act, n_branch, branch_acts, trunk_dims, trunk_acts,
+                                       n_trunk, wpack, out, ldo, nullptr, P, stream);
+}
+
+// The same head on a pair list kept in another order (models/basic.py:PairPlan): pair p is written to out[out_index[p] * ldo].
+int amar_dual_chain_indexed_f32(const float *const *A, const int64_t *lda, const int32_t *const *ida, const int32_t *base_a,
+                                const float *const *B, const int64_t *ldb, const int32_t *const *idb, const int32_t *base_b,
+                                int32_t D, int32_t in_act, int32_t n_branch, const int32_t *branch_acts,
+                                const int32_t *trunk_dims, const int32_t *trunk_acts, int32_t n_trunk,
+                                const float *wpack, float *out, int64_t ldo, const int32_t *out_index, int64_t P, amar_stream_t stream) {
     if (P < 0 || !A || !B || !lda || !ldb || !ida || !idb || !base_a || !base_b || !wpack || !out || !trunk_dims || !trunk_acts)
         return AMAR_EINVAL;
     if (D < 4 || (D & 3) || n_branch < 0 || n_branch > CHAIN_MAX_LAYERS || (n_branch && !branch_acts)) return AMAR_EINVAL;
@@ -1130,7 +1298,7 @@ int amar_dual_chain_f32(const float *const *A, const int64_t *lda, const int32_t
     a.dot_off = off; off += 16 * a.tt;
     a.dot_bias_off = off; off += 4;
     a.dot_act = trunk_acts[n_trunk - 1];
-    a.wpack = wpack; a.wpack_floats = off; a.out = out; a.ldo = ldo; a.P = P;
+    a.wpack = wpack; a.wpack_floats = off; a.out = out; a.ldo = ldo; a.P = P; a.out_index = out_index;
     if ((size_t)off * sizeof(float) > 150 * 1024) return AMAR_EUNSUPPORTED;
     if (P == 0) return AMAR_OK;
     const size_t lds_bytes = (size_t)off * sizeof(float);
@@ -1144,6 +1312,24 @@ int amar_dual_chain_f32(const float *const *A, const int64_t *lda, const int32_t
     for (int b = 0; b < 2; ++b) full = full && lda[b] < (1ll << 32) && ldb[b] < (1ll << 32);
     for (int l = 0; l < n_branch; ++l) full = full && branch_acts[l] == AMAR_ACT_RELU;
     for (int l = 0; l < n_trunk - 1; ++l) full = full && trunk_acts[l] == AMAR_ACT_RELU;
+    // the 64-wide head on the split products (see dual_chain_split_kernel); AMAR_PAIR_MFMA=f32: the f32 instruction
+    static const bool f32_only = getenv("AMAR_PAIR_MFMA") && !strcmp(getenv("AMAR_PAIR_MFMA"), "f32");
+    if (full && !f32_only && n_branch >= 1) {
+        int nf = 0, tl = 0;
+        for (int b = 0; b < 2; ++b)
+            for (int l = 0; l < n_branch; ++l) { a.bw_frag[b][l] = nf; nf += 4 * 2; a.bb_tail[b][l] = tl; tl += 64; }
+        for (int l = 0; l < a.n_trunk; ++l) { a.tw_frag[l] = nf; nf += 4 * (l == 0 ? 4 : 2); a.tb_tail[l] = tl; tl += 64; }
+        a.dot_tail = tl; tl += 64; a.dot_bias_tail = tl; tl += 4;
+        a.n_frag = nf; a.tail_floats = tl;
+        const size_t bytes = (size_t)nf * 3 * 1024 + (size_t)tl * sizeof(float);
+        if (bytes <= 160 * 1024) {
+            static bool lds_ok[AMAR_MAX_DEVICES];
+            if (bytes > 64 * 1024)                                    // (allowed once per device, for the largest image)
+                if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dual_chain_split_kernel), 160 * 1024, lds_ok)) return rc;
+            hipLaunchKernelGGL(dual_chain_split_kernel, dim3((unsigned)blocks), dim3(THREADS), bytes, static_cast<hipStream_t>(stream), a);
+            return amar_check_launch();
+        }
+    }
     auto kern = full ? dual_chain_full_kernel : dual_chain_kernel<PT>;
     if (lds_bytes > 64 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess)

@@ -213,11 +213,13 @@ class PairPlan:
         # over 48 MB are each a line fetched and written back: 0.19 ms of the 0.60 ms launch at ml1m(s=64), memory-side work next to
         # the gathers'.  Instead the kernel stores to mid[mid_index[.]], a scratch vector ordered by (WINDOW of the final position, XCD,
         # list position) — each XCD appends to one open line per window, which its L2 completes —, and amar_scatter_f32 finishes inside
-        # the windows, one window per XCD at a time (window_off).  AMAR_PAIR_WINDOW=0: the direct store.
+        # the windows, one window per XCD at a time (window_off).  Only for long lists: up to a few million scores the destination
+        # mostly stays in the L2s and the direct store is the faster one (a rank of 4: 3.0 M pairs 0.115 against 0.125 ms; a rank of
+        # 2: 6.0 M pairs 0.289 against 0.242 ms) — AMAR_PAIR_WINDOW_MIN pairs (default 4 Mi); AMAR_PAIR_WINDOW=0: always direct.
         self.window = int(os.environ.get('AMAR_PAIR_WINDOW', str(1 << 16)))
         self.mid_index = self.final_index = self.window_off = self.mid = None
         self.n_windows = 0
-        if self.window > 0 and p > 2 * self.window:
+        if self.window > 0 and p > 2 * self.window and p >= int(os.environ.get('AMAR_PAIR_WINDOW_MIN', str(1 << 22))):
             n_win = -(-p // self.window)
             key = (src // self.window) * self.N_XCD + (pos // self.CHUNK) % self.N_XCD
             by_key = torch.argsort(key * p + pos)

@@ -208,8 +208,11 @@ class HybridCBRS(Model):
         self.__dict__['_dual_cache'] = (key, plan)
         return plan
 
-    def score_towers(self, towers, u_ids, i_ids, u_base=0, i_base=0):
-        """dense3a / dense3b over the fused (concatenated) tower rows of each pair, then the classifier."""
+    def score_towers(self, towers, u_ids, i_ids, u_base=0, i_base=0, pair_plan=None):
+        """dense3a / dense3b over the fused (concatenated) tower rows of each pair, then the classifier.  `pair_plan`
+        (models/basic.py:PairPlan of the same id lists; used by the fused two-branch head only): the launch walks the list in the
+        plan's XCD-affine order — four 256-byte rows per pair out of tables that together exceed the L2s — and the scores return to
+        the caller's order in the plan's two steps."""
         tug, tig, tub, tib, folded = towers
         if self.feature_based:
             args1 = dict(ids_a=u_ids, base_a=u_base, ids_b=i_ids, base_b=i_base)
@@ -235,6 +238,19 @@ class HybridCBRS(Model):
         if plan is not None:
             m = args1['ids_a'].numel() if args1['ids_a'] is not None else in1[0].shape[0]
             out = torch.empty((m, 1), dtype=torch.float32, device=in1[0].device)
+            if pair_plan is not None and u_ids is not None and i_ids is not None:
+                pair_plan.check(u_ids, i_ids)
+                pu, pi = pair_plan.u_ids, pair_plan.i_ids
+                ia, ib = ((pu, pu), (pi, pi)) if self.feature_based else ((pu, pi), (pu, pi))
+                two_step = pair_plan.mid_index is not None
+                capi.dual_chain((in1[0], in2[0]), (in1[1], in2[1]), ia, ib,
+                                (args1['base_a'], args2['base_a']), (args1['base_b'], args2['base_b']),
+                                plan['D'], plan['in_act'], plan['branch_acts'], plan['trunk_dims'], plan['trunk_acts'], plan['wpack'],
+                                pair_plan.mid.view(-1, 1) if two_step else out,
+                                out_index=pair_plan.mid_index if two_step else pair_plan.out_index)
+                if two_step:
+                    capi.scatter(pair_plan.mid, pair_plan.final_index, out, pair_plan.window_off, pair_plan.n_windows)
+                return out
             capi.dual_chain((in1[0], in2[0]), (in1[1], in2[1]), (args1['ids_a'], args2['ids_a']), (args1['ids_b'], args2['ids_b']),
                             (args1['base_a'], args2['base_a']), (args1['base_b'], args2['base_b']),
                             plan['D'], plan['in_act'], plan['branch_acts'], plan['trunk_dims'], plan['trunk_acts'], plan['wpack'], out)

@@ -268,7 +268,7 @@ class PartitionedGCNRunner:
         self.u_ids = u_ids[mine].to(torch.int32).contiguous()            # the reference's ids, unchanged
         self.i_ids = i_ids[mine].to(torch.int32).contiguous()
         self.pair_plan = None
-        if self.ops is capi and not self.hybrid and os.environ.get('AMAR_PAIR_PLAN', '1') != '0' and self.u_ids.numel() >= (1 << 16):
+        if self.ops is capi and os.environ.get('AMAR_PAIR_PLAN', '1') != '0' and self.u_ids.numel() >= (1 << 16):
             from deep_cbrs_amar_renaissance_amd.models.basic import PairPlan
             self.pair_plan = PairPlan(self.u_ids, self.i_ids)
         # item-row gathers behind the next kernels: only with a real process group (stand-ins copy synchronously)
@@ -510,7 +510,8 @@ class PartitionedGCNRunner:
                 ib_wait.wait()
             towers = rs.towers(u_table, i_table, bert[self.u_lo:self.u_hi], bert[self.i_lo:self.i_lo + self.n_items], ib_done=ib_full)
             self._mark('towers')
-            out = rs.score_towers(towers, self.u_ids, self.i_ids, self.u_lo, self.i_lo)
+            kw = {'pair_plan': self.pair_plan} if self.pair_plan is not None else {}
+            out = rs.score_towers(towers, self.u_ids, self.i_ids, self.u_lo, self.i_lo, **kw)
         else:
             tu = rs.tower('u', u_table)
             self._mark('user_tower')

@@ -286,6 +286,14 @@ int amar_dual_chain_f32(const float *const *A, const int64_t *lda, const int32_t
                         int32_t D, int32_t in_act, int32_t n_branch, const int32_t *branch_acts,
                         const int32_t *trunk_dims, const int32_t *trunk_acts, int32_t n_trunk,
                         const float *wpack, float *out, int64_t ldo, int64_t P, amar_stream_t stream);
+/* The same on a pair list kept in another order (pair p is written to out[out_index[p] * ldo]; out_index == NULL: in place),
+ * like amar_chain_indexed_f32. */
+int amar_dual_chain_indexed_f32(const float *const *A, const int64_t *lda, const int32_t *const *ida, const int32_t *base_a,
+                                const float *const *B, const int64_t *ldb, const int32_t *const *idb, const int32_t *base_b,
+                                int32_t D, int32_t in_act, int32_t n_branch, const int32_t *branch_acts,
+                                const int32_t *trunk_dims, const int32_t *trunk_acts, int32_t n_trunk,
+                                const float *wpack, float *out, int64_t ldo, const int32_t *out_index, int64_t P,
+                                amar_stream_t stream);
 
 /* Concatenate / ReductionLayer as layout operations (src/layers/reduction.py:15-33,
  * src/layers/fusion.py:51-53): copy a [n_rows, width] block between two strided matrices

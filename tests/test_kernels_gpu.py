@@ -1125,11 +1125,14 @@ def test_weighted_sum_reduction_kernels(hip, n, L, width):
         hip.reduce_layers_wsum(torch.zeros((4, 9 * 4), device=DEV), 9, 4, torch.ones(9, device=DEV), torch.empty((4, 4), device=DEV))   # > 8 terms
 
 
-def test_pair_plan_scores_equal_direct(hip):
+@pytest.mark.parametrize('two_step', [False, True])
+def test_pair_plan_scores_equal_direct(hip, two_step, monkeypatch):
     """models.basic.PairPlan: the XCD-affine item-range order of a pair list + out_index gives the same bits, in the caller's
-    order, as scoring the list directly; positions p with (p >> 7) % 8 == x only see items of the x-th item range."""
+    order, as scoring the list directly; positions p with (p >> 7) % 8 == x only see items of the x-th item range.  two_step: the
+    scores return through the window streams and amar_scatter_f32 (long lists; forced here) instead of the direct scattered store."""
     from deep_cbrs_amar_renaissance_amd import engine
     from deep_cbrs_amar_renaissance_amd.models import basic
+    monkeypatch.setenv('AMAR_PAIR_WINDOW_MIN', '0' if two_step else str(1 << 30))
     engine.set_seed(3)
     nu, ni, P = 5000, 3000, 200_001
     rs = basic.BasicRS([24, 24], [48, 48])
@@ -1149,6 +1152,13 @@ def test_pair_plan_scores_equal_direct(hip):
     hi = torch.stack([plan.i_ids[xcd == x].max() for x in range(8)])
     lo = torch.stack([plan.i_ids[xcd == x].min() for x in range(8)])
     assert bool((lo[1:] >= hi[:-1]).all())                              # item ranges of consecutive XCDs do not overlap (they may touch)
+    assert (plan.mid_index is not None) == two_step
+    if two_step:                                                          # mid_index o final_index == out_index, windows cover the list
+        assert torch.equal(plan.final_index[plan.mid_index.long()], plan.out_index)
+        off = plan.window_off.cpu().tolist()
+        assert off[0] == 0 and off[-1] == P and len(off) == plan.n_windows + 1 and all(b >= a for a, b in zip(off, off[1:]))
+        win = plan.final_index.long() // plan.window
+        assert bool((win[1:] >= win[:-1]).all())                          # the scratch vector is ordered by window of the final position
     got = rs.score_towers(tw, u, i, 0, nu, pair_plan=plan)
     assert torch.equal(got, ref)
     with pytest.raises(ValueError):

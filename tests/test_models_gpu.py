@@ -163,6 +163,62 @@ def test_faithful_equals_hoisted_and_predict(hip, ml1m_s1):
     assert 0 < loss < 5 and 0 <= acc <= 1
 
 
+@pytest.mark.parametrize('feature_based', [True, False])
+@pytest.mark.parametrize('two_step', [False, True])
+def test_hybrid_pair_stage_on_prepared_list(hip, ml1m_s1, feature_based, two_step, monkeypatch):
+    """The fused two-branch head (amar_dual_chain_indexed_f32) on a PairPlan of the pair list returns the bits of the direct call, in
+    the caller's order; its scores — products on the split-bf16 matrix instruction — stay within 1e-6 of a float64 evaluation of the
+    same towers."""
+    from deep_cbrs_amar_renaissance_amd.models import hybrid, basic
+    from deep_cbrs_amar_renaissance_amd.data import synthetic
+    DEV = torch.device('cuda')
+    monkeypatch.setenv('AMAR_PAIR_WINDOW_MIN', '0' if two_step else str(1 << 30))
+    cfg = dict(GRID1, dense_units=[[24, 24], [256, 64], [64, 64]], clf_units=[64, 64], feature_based=feature_based)
+    n_ent = len(ml1m_s1['users']) + len(ml1m_s1['items'])
+    nu = len(ml1m_s1['users'])
+    bert = torch.from_numpy(synthetic.entity_embeddings(n_ent, 768, 'bert')).to(DEV)
+    model = hybrid.HybridBertGCN(ml1m_s1['adj_ui'], **cfg)
+    model.rs.build_head(model.gnn.output_dim(), 768)
+    helpers.randomize_biases(model, seed=23)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(24)
+    P = 150_001
+    u = torch.randint(0, nu, (P,), device=DEV, generator=g, dtype=torch.int32)
+    i = (torch.randint(0, n_ent - nu, (P,), device=DEV, generator=g, dtype=torch.int32) + nu).to(torch.int32)
+    emb = model.gnn(None)
+    rs = model.rs
+    tw = rs.towers(emb[:nu], emb[nu:], bert[:nu], bert[nu:])
+    assert tw[4]                                                          # folded: the fused head runs
+    direct = rs.score_towers(tw, u, i, 0, nu)
+    plan = basic.PairPlan(u, i)
+    assert (plan.mid_index is not None) == two_step
+    assert torch.equal(rs.score_towers(tw, u, i, 0, nu, pair_plan=plan), direct)
+    # float64 evaluation of the pair stage from the same tower tables
+    dp = rs._dual_plan()
+    assert dp is not None
+    tug, tig, tub, tib = [t.double() for t in tw[:4]]
+    ul, il = u.long(), (i - nu).long()
+    if feature_based:
+        x1, x2 = torch.relu(tug[ul] + tig[il]), torch.relu(tub[ul] + tib[il])
+    else:
+        x1, x2 = torch.relu(tug[ul] + tub[ul]), torch.relu(tig[il] + tib[il])
+    kb = lambda l: (l.kernel.detach().double(), l.bias.detach().double())
+    for net, name in ((rs.dense3a, 'x1'), (rs.dense3b, 'x2')):
+        x = x1 if name == 'x1' else x2
+        for l in list(net.layers)[1:]:
+            k, b = kb(l)
+            x = torch.relu(x @ k + b)
+        x1, x2 = (x, x2) if name == 'x1' else (x1, x)
+    x = torch.cat([x1, x2], 1)
+    layers = list(rs.clf.layers)
+    for l in layers[:-1]:
+        k, b = kb(l)
+        x = torch.relu(x @ k + b)
+    k, b = kb(layers[-1])
+    ref = torch.sigmoid(x @ k + b)
+    assert float((direct.double() - ref).abs().max()) < 1e-6
+
+
 def test_hybrid_bert_gcn(hip, ml1m_s1):
     from deep_cbrs_amar_renaissance_amd.models import hybrid
     from deep_cbrs_amar_renaissance_amd.data import synthetic

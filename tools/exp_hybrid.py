@@ -39,6 +39,15 @@ def main():
     med_t, _ = timeit(lambda: rs.towers(emb[:nu], emb[nu:], bert[:nu], bert[nu:]), reps=5)
     med_p, _ = timeit(lambda: rs.score_towers(tw, u, i, 0, nu), reps=5)
     print('  all four entity towers: {:.3f} ms; pair stage ({} pairs): {:.3f} ms = {:.2f} G pairs/s'.format(med_t, P, med_p, P / med_p / 1e6), flush=True)
+    from deep_cbrs_amar_renaissance_amd.models.basic import PairPlan
+    g = torch.Generator(device=dev); g.manual_seed(42)
+    perm = torch.randperm(P, device=dev, generator=g)
+    us, it = u[perm].contiguous(), i[perm].contiguous()
+    med_s, _ = timeit(lambda: rs.score_towers(tw, us, it, 0, nu), reps=5)
+    plan = PairPlan(us, it)
+    med_q, _ = timeit(lambda: rs.score_towers(tw, us, it, 0, nu, pair_plan=plan), reps=5)
+    same = torch.equal(rs.score_towers(tw, us, it, 0, nu), rs.score_towers(tw, us, it, 0, nu, pair_plan=plan))
+    print('  shuffled pair list: {:.3f} ms; with the prepared list (PairPlan, two-step way back): {:.3f} ms; same bits: {}'.format(med_s, med_q, same), flush=True)
     model.gnn.hoist = True
     med_all, _ = timeit(lambda: model((u, i, None, None)), reps=5)
     print('  hoisted call (cached propagation + towers): {:.3f} ms'.format(med_all))

@@ -1,2 +1,3 @@
 set -u
-for wg in 32 64 128; do echo "== AMAR_SCATTER_WG=$wg"; AMAR_SCATTER_WG=$wg AMAR_PAIR_PROJ=0 python tools/exp_pair_parts.py 64 48 2>&1 | grep "window"; done
+echo "== split"; python tools/exp_hybrid.py 64 2>&1 | grep -v amdgpu.ids
+echo "== f32"; AMAR_PAIR_MFMA=f32 python tools/exp_hybrid.py 64 2>&1 | grep -v amdgpu.ids

@@ -345,19 +345,33 @@ def hybrid_head(dev, scale):
     flop_bert_u = nu * (768 * 256 + 256 * 64) * 2.0
     tw = rs.towers(emb[:nu], emb[nu:], bert[:nu], bert[nu:])
     ms_towers = timed(lambda: rs.towers(emb[:nu], emb[nu:], bert[:nu], bert[nu:]))
-    ms_pairs = timed(lambda: rs.score_towers(tw, u, i, 0, nu))
+    from deep_cbrs_amar_renaissance_amd.models.basic import PairPlan
+    plan = PairPlan(u, i)                                              # the pair list does not change between steps: prepared once
+    ms_pairs = timed(lambda: rs.score_towers(tw, u, i, 0, nu, pair_plan=plan))
     flop_pair = 2 * (2 * 64 * 64 + 128 * 64 + 64 * 64 + 64)            # dense3a/3b second layers + clf 128-64-64-1 per pair
+    f32_form = os.environ.get('AMAR_PAIR_MFMA') == 'f32'
+    f32_dense = os.environ.get('AMAR_DENSE_SPLIT') == '0'
+    split_note = ('products on v_mfma_f32_*_bf16 with both operands split three ways (x = hi + mid + lo exactly, six part products in '
+                  'f32: as accurate as the f32 instruction, DESIGN 4b); tflops = the f32 work it stands for, so mfma_frac — against '
+                  'the F32 MFMA peak — may exceed 1')
+    del plan
     del model, bert, tw, emb
     torch.cuda.empty_cache()
     return {'config': 'econfigs/hybrid-gnn.yaml grid1: HybridBertGCN d=8 L=2, dense [[24,24],[256,64],[64,64]], clf [64,64], 768-d BERT, ml1m(s={})'.format(scale),
-            'bert_tower': {'kernel': 'dense_mfma128_kernel / dense_mfma_kernel (amar_dense_f32): 768->256->64 over the {} user rows'.format(nu),
+            'bert_tower': {'kernel': ('dense_mfma128_kernel' if f32_dense else 'dense_split128_kernel (amar_dense_split_f32)') +
+                                     ' / dense_mfma_kernel (amar_dense_f32): 768->256->64 over the {} user rows'.format(nu),
                            'ms': ms_bert_u, 'tflops': flop_bert_u / ms_bert_u / 1e9, 'peak_tflops': MFMA_F32_PEAK_TFLOPS,
-                           'mfma_frac': flop_bert_u / ms_bert_u / 1e9 / MFMA_F32_PEAK_TFLOPS},
+                           'mfma_frac': flop_bert_u / ms_bert_u / 1e9 / MFMA_F32_PEAK_TFLOPS,
+                           'note': None if f32_dense else 'first layer: ' + split_note},
             'entity_towers_ms': ms_towers,
-            'pair_stage': {'kernel': 'dual_chain_full_kernel (amar_dual_chain_f32)', 'pairs': p, 'ms': ms_pairs,
+            'pair_stage': {'kernel': ('dual_chain_full_kernel' if f32_form else 'dual_chain_split_kernel') +
+                                     ' (amar_dual_chain_indexed_f32 on the prepared pair list) + scatter_windows_kernel', 'pairs': p, 'ms': ms_pairs,
                            'pairs_per_s': p / ms_pairs * 1e3, 'flop_per_pair': flop_pair,
                            'tflops': p * flop_pair / ms_pairs / 1e9, 'peak_tflops': MFMA_F32_PEAK_TFLOPS,
-                           'mfma_frac': p * flop_pair / ms_pairs / 1e9 / MFMA_F32_PEAK_TFLOPS}}
+                           'mfma_frac': p * flop_pair / ms_pairs / 1e9 / MFMA_F32_PEAK_TFLOPS,
+                           'note': None if f32_form else split_note,
+                           'executed_bf16_tflops': None if f32_form else p * (6 * flop_pair) / ms_pairs / 1e9,
+                           'bf16_peak_tflops': MFMA_BF16_PEAK_TFLOPS}}
 
 
 def train_true_size():

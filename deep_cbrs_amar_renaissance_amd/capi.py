@@ -45,6 +45,9 @@ SIGNATURES = {
     'amar_sage_tail_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I32, _P, _P, _I32, _P, _I64, _I64, _P]),
     'amar_gat_layer_f32': (ctypes.c_int, [_P, _P, _P, _I64, _I32, _P, _P, _P, _P, _I64, _I32, _I32, _P]),
     'amar_dense_f32': (ctypes.c_int, [_P, _I64, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _P]),
+    'amar_dense_split_bytes': (ctypes.c_int64, [_I32, _I32]),
+    'amar_dense_split_pack_f32': (ctypes.c_int, [_P, _I32, _I32, _P]),
+    'amar_dense_split_f32': (ctypes.c_int, [_P, _I64, _P, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _P]),
     'amar_chain_pack_floats': (ctypes.c_int64, [_P, _I32]),
     'amar_chain_pack_f32': (ctypes.c_int, [_P, _P, _P, _I32, _P]),
     'amar_chain_f32': (ctypes.c_int, [_P, _I64, _I32, _P, _I32, _P, _I64, _I32, _P, _I32, _I32, _I32, _P, _P, _P, _I32, _P, _I64, _I64, _P]),
@@ -490,6 +493,38 @@ def dense(X, W, bias, Y, act='relu', ids=None, w_transposed=False):
         _ptr(W, torch.float32, 'W'), _ptr(bias, torch.float32, 'bias'), _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y'),
         M, K, N, ACT_CODES[act] | (DENSE_WT if w_transposed else 0), _stream())
     _check(code, 'amar_dense_f32')
+
+
+def dense_split_supported(K, N):
+    """amar_dense_split_f32 takes this layer (the wide layers of the content towers); AMAR_DENSE_SPLIT=0 keeps the f32 instruction."""
+    return K % 32 == 0 and N % 128 == 0 and K >= 32 and os.environ.get('AMAR_DENSE_SPLIT', '1') != '0'
+
+
+def dense_split_pack(W):
+    """Kernel [K, N] (host numpy float32) -> the pre-split image of amar_dense_split_pack_f32 as a uint8 numpy array."""
+    import numpy as np
+    W = np.ascontiguousarray(W, dtype=np.float32)
+    K, N = W.shape
+    lib = load()
+    nbytes = int(lib.amar_dense_split_bytes(K, N))
+    if nbytes < 0:
+        _check(nbytes, 'amar_dense_split_bytes')
+    out = np.empty(nbytes, dtype=np.uint8)
+    _check(lib.amar_dense_split_pack_f32(W.ctypes.data, K, N, out.ctypes.data), 'amar_dense_split_pack_f32')
+    return out
+
+
+def dense_split(X, Wq, K, N, bias, Y, act='relu', ids=None):
+    """Y = act(X[ids] . W + bias) with W pre-split (dense_split_pack, on the device as uint8): amar_dense_split_f32."""
+    M = ids.numel() if ids is not None else X.shape[0]
+    if X.shape[1] != K or tuple(Y.shape) != (M, N) or Wq.numel() != K * N * 6 or Wq.dtype != torch.uint8 or not Wq.is_contiguous():
+        raise ValueError("dense_split: X [*, K], Wq of K N 6 bytes, Y [M, N] expected")
+    if bias is not None and (bias.numel() != N or not bias.is_contiguous()):
+        raise ValueError("dense_split: bias must be a contiguous [N] vector")
+    code = load().amar_dense_split_f32(
+        _ptr(X, torch.float32, 'X'), _ld(X, 'X'), _ptr(ids, torch.int32, 'ids'), _ptr(Wq, torch.uint8, 'Wq'),
+        _ptr(bias, torch.float32, 'bias'), _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y'), M, K, N, ACT_CODES[act], _stream())
+    _check(code, 'amar_dense_split_f32')
 
 
 CHAIN_MAX_WIDTH, CHAIN_MAX_LAYERS = 128, 8

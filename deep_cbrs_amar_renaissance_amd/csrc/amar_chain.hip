@@ -346,17 +346,21 @@ __global__ __launch_bounds__(256) void chain_rows_kernel(const ChainArgs a) {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// a, b -> (hi, mid, lo) bf16 pairs, a in the low half
+// a, b -> (hi, mid, lo) bf16 pairs, a in the low half.  The two remainders of a level come from ONE packed subtraction.
 struct Split3 { uint32_t h, m, l; };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ Split3 split_pair(float a, float b) {
-    const uint32_t ab = __float_as_uint(a), bb = __float_as_uint(b);
+    const f32x2 x = {a, b};
+    const u32x2 xb = __builtin_bit_cast(u32x2, x);
     Split3 q;
-    q.h = __builtin_amdgcn_perm(bb, ab, 0x07060302u);
-    const float a1 = a - __uint_as_float(ab & 0xffff0000u), b1 = b - __uint_as_float(bb & 0xffff0000u);
-    const uint32_t a1b = __float_as_uint(a1), b1b = __float_as_uint(b1);
-    q.m = __builtin_amdgcn_perm(b1b, a1b, 0x07060302u);
-    const float a2 = a1 - __uint_as_float(a1b & 0xffff0000u), b2 = b1 - __uint_as_float(b1b & 0xffff0000u);
-    q.l = __builtin_amdgcn_perm(__float_as_uint(b2), __float_as_uint(a2), 0x07060302u);
+    q.h = __builtin_amdgcn_perm(xb[1], xb[0], 0x07060302u);
+    const f32x2 r1 = x - __builtin_bit_cast(f32x2, xb & 0xffff0000u);
+    const u32x2 r1b = __builtin_bit_cast(u32x2, r1);
+    q.m = __builtin_amdgcn_perm(r1b[1], r1b[0], 0x07060302u);
+    const f32x2 r2 = r1 - __builtin_bit_cast(f32x2, r1b & 0xffff0000u);
+    const u32x2 r2b = __builtin_bit_cast(u32x2, r2);
+    q.l = __builtin_amdgcn_perm(r2b[1], r2b[0], 0x07060302u);
     return q;
 }
 

@@ -11,6 +11,7 @@
 //   is a conflict-free ds_read_b32 for A and B alike.
 #include "amar_common.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -242,6 +243,136 @@ __global__ __launch_bounds__(256) void dense_mfma128_kernel(const DenseArgs a) {
 #undef AMAR_D128_FETCH
 #undef AMAR_D128_STAGE_X
 
+// ---- the same 128 x 128 tile with its products on the bf16 matrix instruction, both operands split three ways -----------------
+// A finite f32 is exactly hi + mid + lo with each part its next 8 significand bits; bf16 x bf16 products are exact in f32 and the
+// matrix pipe accumulates in f32; the six part products of weight >= 2^-16 are taken, small ones first, so a term x.w is off by at
+// most 3 . 2^-24 |x.w| — the size of its own f32 rounding (csrc/amar_chain.hip has the same form for the scoring heads).  Six
+// v_mfma_f32_32x32x16_bf16 (32 cycles each) cover k = 16 where the f32 instruction needs eight of 64 cycles, and a bf16 MFMA holds
+// the SIMD's vector issue for 8 of its 32 cycles only: the splitting of the X tile (5 VALU instructions per value, once per value
+// for all 128 columns) runs beside the matrix pipe.  W arrives pre-split (amar_dense_split_pack_f32: per (column block, k-tile of
+// 32) one 24 KB image in the order of the LDS tile); X is split on its way from the staging registers to the LDS.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+struct DenseSplitArgs {
+    const float *X; int64_t ldx; const int32_t *ids;
+    const u32x4 *Wq; const float *bias; float *Y; int64_t ldy;
+    int64_t M; int K; int N; int act; int n_col_blocks;
+};
+
+struct Parts { uint32_t h, m, l; };
+__device__ __forceinline__ Parts split2(float a, float b) {       // (a, b) -> bf16 pairs (a in the low half) of the three parts
+    const f32x2 x = {a, b};
+    const u32x2 xb = __builtin_bit_cast(u32x2, x);
+    Parts q;
+    q.h = __builtin_amdgcn_perm(xb[1], xb[0], 0x07060302u);
+    const f32x2 r1 = x - __builtin_bit_cast(f32x2, xb & 0xffff0000u);
+    const u32x2 r1b = __builtin_bit_cast(u32x2, r1);
+    q.m = __builtin_amdgcn_perm(r1b[1], r1b[0], 0x07060302u);
+    const f32x2 r2 = r1 - __builtin_bit_cast(f32x2, r1b & 0xffff0000u);
+    const u32x2 r2b = __builtin_bit_cast(u32x2, r2);
+    q.l = __builtin_amdgcn_perm(r2b[1], r2b[0], 0x07060302u);
+    return q;
+}
+
+constexpr int SPLIT_IMG = 3 * 2 * 2 * 128;                          // 16-byte entries of one operand image: [part][k-step][k half][row or column]
+
+__global__ __launch_bounds__(256) void dense_split128_kernel(const DenseSplitArgs a) {
+    __shared__ u32x4 As[SPLIT_IMG];
+    __shared__ u32x4 Bs[SPLIT_IMG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t L = blockIdx.x;                                  // XCD-affine tile order, as in dense_mfma_kernel
+    const int64_t j = L >> 3;
+    const int64_t m_blk = (j / a.n_col_blocks) * 8 + (L & 7);
+    if (m_blk * BM >= a.M) return;
+    const int64_t m0 = m_blk * BM;
+    const int n_blk = (int)(j % a.n_col_blocks), n0 = n_blk * BN2;
+    const int n_kt = a.K / 32;
+
+    // X staging: thread -> row xr, the 16 floats of k-step xs of the k-tile (both halves of 8)
+    const int xr = tid & 127, xs = tid >> 7;
+    const int64_t m = m0 + xr, mc = m < a.M ? m : a.M - 1;
+    const float *xp = a.X + (a.ids ? (int64_t)a.ids[mc] : mc) * a.ldx + 16 * xs;
+    const u32x4 *wimg = a.Wq + (size_t)n_blk * n_kt * SPLIT_IMG + tid;
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[c][r] = 0.f;
+
+    float4 xa[4];
+    u32x4 wb[6];
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xa[q] = *reinterpret_cast<const float4 *>(xp + 32 * kt + 4 * q);
+#pragma unroll
+        for (int q = 0; q < 6; ++q) wb[q] = wimg[(size_t)kt * SPLIT_IMG + 256 * q];
+    };
+    fetch(0);
+    const int frag = (lane >> 5) * 128 + (lane & 31);               // this lane's entry inside a [k half][row or column] plane
+    for (int kt = 0; kt < n_kt; ++kt) {
+        __syncthreads();                                            // previous tile fully consumed
+        // (splitting behind the MFMAs of the tile before, outside the two barriers, holds the parts in 24 more registers: 190 VGPRs,
+        // two waves per SIMD instead of three, 1.07 against 1.03 ms for the 768 -> 256 layer)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const float4 v0 = xa[2 * hf], v1 = xa[2 * hf + 1];
+            const Parts q0 = split2(v0.x, v0.y), q1 = split2(v0.z, v0.w), q2 = split2(v1.x, v1.y), q3 = split2(v1.z, v1.w);
+            u32x4 h, mm, lo;
+            h[0] = q0.h; h[1] = q1.h; h[2] = q2.h; h[3] = q3.h;
+            mm[0] = q0.m; mm[1] = q1.m; mm[2] = q2.m; mm[3] = q3.m;
+            lo[0] = q0.l; lo[1] = q1.l; lo[2] = q2.l; lo[3] = q3.l;
+            As[((0 * 2 + xs) * 2 + hf) * 128 + xr] = h;
+            As[((1 * 2 + xs) * 2 + hf) * 128 + xr] = mm;
+            As[((2 * 2 + xs) * 2 + hf) * 128 + xr] = lo;
+        }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Bs[tid + 256 * q] = wb[q];
+        __syncthreads();
+        if (kt + 1 < n_kt) fetch(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            // wave (wr, wc) owns rows 64 wr .. +63 against columns 64 wc .. +63: 6 + 6 fragment reads feed 24 MFMAs (32 rows against all
+            // 128 columns would read 3 + 12: the LDS, not the matrix pipe, set the pace of this loop)
+            bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    af[q][p] = __builtin_bit_cast(bf16x8, As[p * 512 + ks * 256 + frag + 64 * (wave >> 1) + 32 * q]);
+                    bf[q][p] = __builtin_bit_cast(bf16x8, Bs[p * 512 + ks * 256 + frag + 64 * (wave & 1) + 32 * q]);
+                }
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb) {
+                    f32x16 v = acc[2 * rb + cb];
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb][2], bf[cb][0], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb][0], bf[cb][2], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb][1], bf[cb][1], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb][1], bf[cb][0], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb][0], bf[cb][1], v, 0, 0, 0);
+                    v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rb][0], bf[cb][0], v, 0, 0, 0);
+                    acc[2 * rb + cb] = v;
+                }
+        }
+    }
+    const int col = lane & 31;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int n = n0 + 64 * (wave & 1) + 32 * (c & 1) + col;
+        const float b = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t mr = m0 + 64 * (wave >> 1) + 32 * (c >> 1) + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (mr < a.M) a.Y[mr * a.ldy + n] = apply_act(acc[c][r] + b, a.act);
+        }
+    }
+}
+
 // ---- per-user top-k --------------------------------------------------------------------------
 // One wave per user.  Round t picks the best pair that comes strictly after round t-1's winner in
 // the order (score descending, item id ascending); items are distinct within a user.
@@ -324,6 +455,59 @@ int amar_dense_f32(const float *X, int64_t ldx, const int32_t *ids,
     else if (vx) hipLaunchKernelGGL((dense_mfma_kernel<true, false>), grid, block, 0, st, a);
     else if (vw) hipLaunchKernelGGL((dense_mfma_kernel<false, true>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((dense_mfma_kernel<false, false>), grid, block, 0, st, a);
+    return amar_check_launch();
+}
+
+// W [K, N] (row-major f32) -> the pre-split image dense_split128_kernel stages: for every (column block of 128, k-tile of 32) one
+// [part][k-step of 16][k half of 8][column] array of 8 bf16 (k ascending); K % 32 == 0, N % 128 == 0.  HOST arrays.
+int64_t amar_dense_split_bytes(int32_t K, int32_t N) {
+    if (K < 32 || N < 128 || (K & 31) || (N & 127)) return AMAR_EUNSUPPORTED;
+    return (int64_t)K * N * 6;
+}
+
+int amar_dense_split_pack_f32(const float *W, int32_t K, int32_t N, void *out) {
+    if (!W || !out) return AMAR_EINVAL;
+    if (K < 32 || N < 128 || (K & 31) || (N & 127)) return AMAR_EUNSUPPORTED;
+    uint16_t *o = static_cast<uint16_t *>(out);
+    const int n_kt = K / 32;
+    for (int nb = 0; nb < N / 128; ++nb)
+        for (int kt = 0; kt < n_kt; ++kt) {
+            uint16_t *img = o + ((size_t)nb * n_kt + kt) * SPLIT_IMG * 8;
+            for (int ks = 0; ks < 2; ++ks)
+                for (int hf = 0; hf < 2; ++hf)
+                    for (int col = 0; col < 128; ++col)
+                        for (int jj = 0; jj < 8; ++jj) {
+                            const float w = W[(size_t)(32 * kt + 16 * ks + 8 * hf + jj) * N + 128 * nb + col];
+                            uint32_t wbits; memcpy(&wbits, &w, 4);
+                            const uint32_t hb = wbits & 0xffff0000u;
+                            float hf32; memcpy(&hf32, &hb, 4);
+                            const float r1 = w - hf32;
+                            uint32_t r1b; memcpy(&r1b, &r1, 4);
+                            const uint32_t mb = r1b & 0xffff0000u;
+                            float mf32; memcpy(&mf32, &mb, 4);
+                            const float r2 = r1 - mf32;
+                            uint32_t r2b; memcpy(&r2b, &r2, 4);
+                            const size_t e = ((size_t)(ks * 2 + hf) * 128 + col) * 8 + jj;
+                            img[e] = (uint16_t)(hb >> 16);
+                            img[(size_t)1 * 2 * 2 * 128 * 8 + e] = (uint16_t)(mb >> 16);
+                            img[(size_t)2 * 2 * 2 * 128 * 8 + e] = (uint16_t)(r2b >> 16);
+                        }
+        }
+    return AMAR_OK;
+}
+
+// amar_dense_f32 on the split products (see dense_split128_kernel): Wq = amar_dense_split_pack_f32's image on the DEVICE.
+int amar_dense_split_f32(const float *X, int64_t ldx, const int32_t *ids, const void *Wq, const float *bias, float *Y, int64_t ldy,
+                         int64_t M, int32_t K, int32_t N, int32_t act, amar_stream_t stream) {
+    if (M < 0 || K < 1 || N < 1 || !X || !Wq || !Y || ldx < K || ldy < N) return AMAR_EINVAL;
+    if (act != AMAR_ACT_NONE && act != AMAR_ACT_RELU && act != AMAR_ACT_SIGMOID) return AMAR_EINVAL;
+    if ((K & 31) || (N & 127) || (ldx & 3) || !amar_aligned16(X) || !amar_aligned16(Wq)) return AMAR_EUNSUPPORTED;
+    if (M == 0) return AMAR_OK;
+    const int64_t gx = (M + BM - 1) / BM;
+    const int64_t total = ((gx + 7) / 8) * 8 * (N / BN2);
+    if (total > 0x7fffffffLL) return AMAR_EUNSUPPORTED;
+    DenseSplitArgs a{X, ldx, ids, static_cast<const u32x4 *>(Wq), bias, Y, ldy, M, K, N, act, N / BN2};
+    hipLaunchKernelGGL(dense_split128_kernel, dim3((unsigned)total), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return amar_check_launch();
 }
 

@@ -28,6 +28,17 @@ class Dense(Layer):
         m = ids.numel() if ids is not None else x.shape[0]
         if out is None:
             out = torch.empty((m, self.units), dtype=torch.float32, device=x.device)
+        k, n = self.kernel.shape
+        if capi.dense_split_supported(int(k), int(n)) and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0 and x.is_cuda:
+            # wide layers (the 768 -> 256 of the content towers): products on the bf16 matrix instruction with both operands split
+            # three ways — f32-accurate (include/amar_hip.h); the kernel's split image is rebuilt when the weights change
+            version = (id(self.kernel), self.kernel._version)
+            cache = self.__dict__.get('_split_image')
+            if cache is None or cache[0] != version:
+                image = torch.from_numpy(capi.dense_split_pack(self.kernel.detach().cpu().numpy())).to(self.kernel.device)
+                cache = self.__dict__['_split_image'] = (version, image)
+            capi.dense_split(x, cache[1], int(k), int(n), self.bias, out, act=self.activation, ids=ids)
+            return out
         capi.dense(x, self.kernel, self.bias, out, act=self.activation, ids=ids)
         return out
 

@@ -220,6 +220,17 @@ int amar_dense_f32(const float *X, int64_t ldx, const int32_t *ids,
                    const float *W, const float *bias, float *Y, int64_t ldy,
                    int64_t M, int32_t K, int32_t N, int32_t act, amar_stream_t stream);
 
+/* The same layer with its products on the bf16 matrix instruction and BOTH operands split three ways (x = hi + mid + lo
+ * exactly, six part products accumulated in f32: as accurate as the f32 instruction, 2.7 times fewer matrix-pipe cycles) for
+ * the wide layers of the content towers (768 -> 256 of src/models/hybrid.py:52-58).  K % 32 == 0, N % 128 == 0, ldx % 4 == 0,
+ * 16-byte aligned X; other shapes return AMAR_EUNSUPPORTED (use amar_dense_f32).  Wq is the layer's kernel pre-split by
+ * amar_dense_split_pack_f32 (HOST in, HOST out of amar_dense_split_bytes(K, N) bytes — once per weight update), copied to
+ * the device by the caller. */
+int64_t amar_dense_split_bytes(int32_t K, int32_t N);
+int amar_dense_split_pack_f32(const float *W, int32_t K, int32_t N, void *out);
+int amar_dense_split_f32(const float *X, int64_t ldx, const int32_t *ids, const void *Wq, const float *bias,
+                         float *Y, int64_t ldy, int64_t M, int32_t K, int32_t N, int32_t act, amar_stream_t stream);
+
 /* Fused gather + Concatenate + Dense stack (BasicRS / HybridCBRS towers and classifiers:
  * src/models/basic.py:31-37,72-75, src/models/hybrid.py:72-89, src/models/dense.py:4-17).
  * For every row p < P:

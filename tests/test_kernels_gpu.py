@@ -1202,6 +1202,37 @@ def test_pair_stage_split_products_against_f32_and_f64(hip, width):
     assert float((got - f32).abs().max()) < 5e-7
 
 
+@pytest.mark.parametrize('M,K,N,act,use_ids', [(1000, 768, 256, 'relu', True), (129, 64, 128, None, False), (4097, 256, 384, 'sigmoid', False),
+                                                (1, 32, 128, 'relu', True)])
+def test_dense_split_products(hip, M, K, N, act, use_ids):
+    """amar_dense_split_f32 (bf16 matrix instruction, both operands split three ways) against a float64 product and against
+    amar_dense_f32 (exact f32 MFMA): no less accurate, rows gathered by id, output into a column slice of a wider buffer."""
+    from deep_cbrs_amar_renaissance_amd import capi
+    g = torch.Generator(device=DEV)
+    g.manual_seed(31 + M)
+    rows = M + 37 if use_ids else M
+    X = torch.randn((rows, K), device=DEV, generator=g) * 0.7
+    W = (torch.rand((K, N), device=DEV, generator=g) - 0.5) * (2.0 / K ** 0.5)
+    b = torch.randn(N, device=DEV, generator=g) * 0.1
+    ids = torch.randint(0, rows, (M,), device=DEV, generator=g, dtype=torch.int32) if use_ids else None
+    assert capi.dense_split_supported(K, N)
+    Wq = torch.from_numpy(capi.dense_split_pack(W.cpu().numpy())).to(DEV)
+    wide = torch.full((M, N + 8), 7.0, device=DEV)
+    capi.dense_split(X, Wq, K, N, b, wide[:, 4:4 + N], act=act, ids=ids)
+    assert float((wide[:, :4] - 7.0).abs().max()) == 0.0 and float((wide[:, 4 + N:] - 7.0).abs().max()) == 0.0
+    got = wide[:, 4:4 + N]
+    f32 = torch.empty((M, N), device=DEV)
+    capi.dense(X, W, b, f32, act=act, ids=ids)
+    xs = X[ids.long()] if use_ids else X
+    ref = xs.double() @ W.double() + b.double()
+    ref = torch.relu(ref) if act == 'relu' else (torch.sigmoid(ref) if act == 'sigmoid' else ref)
+    e_split, e_f32 = (got.double() - ref).abs(), (f32.double() - ref).abs()
+    scale = float(ref.abs().max()) + 1.0
+    assert float(e_split.max()) < 4e-6 * scale
+    assert float(e_split.mean()) < 1.5 * float(e_f32.mean()) + 1e-9        # as accurate as the f32 instruction
+    assert not capi.dense_split_supported(K + 4, N) and not capi.dense_split_supported(K, N + 64)
+
+
 def test_scatter_by_windows(hip):
     """amar_scatter_f32: dst[index[t]] = src[t], visited window by window; any window table gives the same result as none."""
     from deep_cbrs_amar_renaissance_amd import capi

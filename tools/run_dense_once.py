@@ -20,3 +20,9 @@ for _ in range(5):
     capi.dense(x, w, b, y, act='relu')
 t, tmin = timeit(lambda: capi.dense(x, w, b, y, act='relu'), reps=10)
 print('dense %d x %d -> %d: %.4f ms (min %.4f) = %.1f TFLOP/s' % (M, K, N, t, tmin, 2.0 * M * K * N / t / 1e9), flush=True)
+if capi.dense_split_supported(K, N):
+    wq = torch.from_numpy(capi.dense_split_pack(w.cpu().numpy())).to(dev)
+    y2 = torch.empty_like(y)
+    t, tmin = timeit(lambda: capi.dense_split(x, wq, K, N, b, y2, act='relu'), reps=10)
+    print('dense_split %d x %d -> %d: %.4f ms (min %.4f) = %.1f TFLOP/s (f32-equivalent); max |diff| to the f32 form %.3e' %
+          (M, K, N, t, tmin, 2.0 * M * K * N / t / 1e9, float((y2 - y).abs().max())), flush=True)

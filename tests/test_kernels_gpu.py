@@ -1233,6 +1233,35 @@ def test_dense_split_products(hip, M, K, N, act, use_ids):
     assert not capi.dense_split_supported(K + 4, N) and not capi.dense_split_supported(K, N + 64)
 
 
+def test_round3_entry_points_reject_bad_arguments(hip):
+    """Argument checks of the entry points added in round 3 (AMAR_EINVAL -> ValueError, AMAR_EUNSUPPORTED -> AmarError): nothing is
+    launched on a refused call."""
+    import ctypes
+    from deep_cbrs_amar_renaissance_amd import capi
+    lib = capi.load()
+    x = torch.zeros((8, 64), device=DEV)
+    y = torch.zeros((8, 128), device=DEV)
+    wq = torch.zeros(64 * 128 * 6, dtype=torch.uint8, device=DEV)
+    idx = torch.arange(8, dtype=torch.int32, device=DEV)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    assert lib.amar_dense_split_bytes(64, 128) == 64 * 128 * 6
+    assert lib.amar_dense_split_bytes(48, 128) == -2 and lib.amar_dense_split_bytes(64, 64) == -2          # K % 32, N % 128
+    assert lib.amar_dense_split_f32(p(x), 64, None, p(wq), None, p(y), 128, 8, 48, 128, 0, None) == -2     # unsupported shape
+    assert lib.amar_dense_split_f32(p(x), 64, None, None, None, p(y), 128, 8, 64, 128, 0, None) == -1      # no weights
+    assert lib.amar_dense_split_f32(p(x), 32, None, p(wq), None, p(y), 128, 8, 64, 128, 0, None) == -1     # ldx < K
+    assert lib.amar_dense_split_f32(p(x), 64, None, p(wq), None, p(y), 128, 8, 64, 128, 7, None) == -1     # unknown activation
+    assert lib.amar_dense_split_f32(p(x), 64, None, p(wq), None, p(y), 128, 0, 64, 128, 0, None) == 0      # no rows: nothing to do
+    assert lib.amar_dense_split_pack_f32(None, 64, 128, None) == -1
+    src = torch.zeros(8, device=DEV)
+    dst = torch.zeros(8, device=DEV)
+    assert lib.amar_scatter_f32(p(src), p(idx), p(dst), 1, 8, None, 0, None) == -1                          # no windows
+    assert lib.amar_scatter_f32(p(src), None, p(dst), 1, 8, None, 1, None) == -1
+    assert lib.amar_scatter_f32(p(src), p(idx), p(dst), 0, 8, None, 1, None) == -1
+    assert lib.amar_scatter_f32(p(src), p(idx), p(dst), 1, 0, None, 1, None) == 0
+    with pytest.raises(ValueError):
+        capi.dense_split(x, wq[:-6], 64, 128, None, y)
+
+
 def test_scatter_by_windows(hip):
     """amar_scatter_f32: dst[index[t]] = src[t], visited window by window; any window table gives the same result as none."""
     from deep_cbrs_amar_renaissance_amd import capi

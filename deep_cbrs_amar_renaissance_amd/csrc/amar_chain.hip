@@ -876,13 +876,17 @@ __global__ __launch_bounds__(1024) void dual_chain_full_kernel(const DualArgs a)
 // above: f32-accurate, 6 MFMAs of 16 cycles per k-step of 32 instead of 8 of 32 cycles).  The f32 weight blob (84 KB for the 64-wide
 // stacks) is split by the workgroup into 126 KB of bf16 fragments at its start, straight from global memory — blob and fragments
 // would not fit the LDS together; biases and the 1-unit layer stay f32 in a small tail.  AMAR_PAIR_MFMA=f32 keeps the f32 kernel.
-__global__ __launch_bounds__(1024) void dual_chain_split_kernel(const DualArgs a) {
+// PT pair tiles of 16 per wave and iteration, THREADS per workgroup (1 024 with PT = 1; 512 with PT = 2: the 128 registers a lane of a
+// 1 024-thread workgroup may hold do not fit two tiles): a weight fragment read from the LDS feeds PT tiles' MFMAs.
+template <int PT, int THREADS>
+__global__ __launch_bounds__(THREADS) void dual_chain_split_kernel(const DualArgs a) {
     constexpr int T = 4, KS = 2;
     extern __shared__ __attribute__((aligned(16))) float w_lds[];
     u32x4 *frag = reinterpret_cast<u32x4 *>(w_lds);
     float *tail = w_lds + (size_t)a.n_frag * 3 * 64 * 4;
     const int lane = threadIdx.x & 63, g = lane >> 4, col = lane & 15;
-    const int wpb = blockDim.x >> 6, wave = threadIdx.x >> 6;
+    constexpr int wpb = THREADS / 64;
+    const int wave = threadIdx.x >> 6;
     {
         // fragment triple f of a layer with KT input tiles: (m, s) = (f / (KT/2), f % (KT/2)); its two f32 tiles are 2s and 2s + 1
         auto build = [&](int w_off, int kt, int frag0) {
@@ -898,7 +902,7 @@ __global__ __launch_bounds__(1024) void dual_chain_split_kernel(const DualArgs a
         for (int br = 0; br < 2; ++br)
             for (int l = 0; l < a.n_branch; ++l) build(a.bw_off[br][l], T, a.bw_frag[br][l]);
         for (int l = 0; l < a.n_trunk; ++l) build(a.tw_off[l], l == 0 ? 2 * T : T, a.tw_frag[l]);
-        for (int i = threadIdx.x; i < 16 * T; i += blockDim.x) {
+        for (int i = threadIdx.x; i < 16 * T; i += THREADS) {
             for (int br = 0; br < 2; ++br)
                 for (int l = 0; l < a.n_branch; ++l) tail[a.bb_tail[br][l] + i] = a.wpack[a.bb_off[br][l] + i];
             for (int l = 0; l < a.n_trunk; ++l) tail[a.tb_tail[l] + i] = a.wpack[a.tbias_off[l] + i];
@@ -908,97 +912,112 @@ __global__ __launch_bounds__(1024) void dual_chain_split_kernel(const DualArgs a
     }
     __syncthreads();
     const int64_t wave0 = (int64_t)blockIdx.x * wpb + wave;
-    const int64_t stride = (int64_t)gridDim.x * wpb * 16;
+    const int64_t stride = (int64_t)gridDim.x * wpb * 16 * PT;
 
-    for (int64_t base = wave0 * 16; base < a.P; base += stride) {
-        const int64_t p = base + col;
-        const bool ok = p < a.P;                               // pairs past the end read row 0 and are never stored
-        f32x4 va[2][T], vb[2][T];
+    // y[m][pt] += W(m, k-step) . x[pt]: one fragment triple from the LDS, the six part products of every tile (small ones first)
+    auto layer_step = [&](const u32x4 *w, const Split3x4 (&x)[PT], f32x4 (&y)[PT]) {
+        const bf16x8 wh = __builtin_bit_cast(bf16x8, w[0]), wm = __builtin_bit_cast(bf16x8, w[64]), wl = __builtin_bit_cast(bf16x8, w[128]);
+#define AMAR_DUAL_MFMA(W, PART)                                                                                                  \
+    _Pragma("unroll") for (int pt = 0; pt < PT; ++pt)                                                                            \
+        y[pt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W, __builtin_bit_cast(bf16x8, x[pt].PART), y[pt], 0, 0, 0)
+        AMAR_DUAL_MFMA(wl, h); AMAR_DUAL_MFMA(wh, l); AMAR_DUAL_MFMA(wm, m); AMAR_DUAL_MFMA(wm, h); AMAR_DUAL_MFMA(wh, m); AMAR_DUAL_MFMA(wh, h);
+#undef AMAR_DUAL_MFMA
+    };
+
+    for (int64_t base = wave0 * 16 * PT; base < a.P; base += stride) {
+        Split3x4 xq[2][KS][PT];                                // the branches' outputs, split: the trunk's first layer reads all four k-steps
 #pragma unroll
         for (int br = 0; br < 2; ++br) {
-            const uint32_t ra = ok ? (uint32_t)(a.ida[br][p] - a.base_a[br]) : 0u;
-            const uint32_t rb = ok ? (uint32_t)(a.idb[br][p] - a.base_b[br]) : 0u;
-            const float *pa = a.A[br] + (uint64_t)ra * (uint32_t)a.lda[br] + 4 * g;
-            const float *pb = a.B[br] + (uint64_t)rb * (uint32_t)a.ldb[br] + 4 * g;
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                va[br][t] = *reinterpret_cast<const f32x4 *>(pa + 16 * t);
-                vb[br][t] = *reinterpret_cast<const f32x4 *>(pb + 16 * t);
+            for (int pt = 0; pt < PT; ++pt) {
+                const int64_t p = base + 16 * pt + col;
+                const bool ok = p < a.P;                       // pairs past the end read row 0 and are never stored
+                const uint32_t ra = ok ? (uint32_t)(a.ida[br][p] - a.base_a[br]) : 0u;
+                const uint32_t rb = ok ? (uint32_t)(a.idb[br][p] - a.base_b[br]) : 0u;
+                const float *pa = a.A[br] + (uint64_t)ra * (uint32_t)a.lda[br] + 4 * g;
+                const float *pb = a.B[br] + (uint64_t)rb * (uint32_t)a.ldb[br] + 4 * g;
+                f32x4 xb[T];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    f32x4 v = *reinterpret_cast<const f32x4 *>(pa + 16 * t) + *reinterpret_cast<const f32x4 *>(pb + 16 * t);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = relu_bits(v[r]);
+                    xb[t] = v;
+                }
+#pragma unroll
+                for (int sk = 0; sk < KS; ++sk) xq[br][sk][pt] = split_tiles(xb[2 * sk], xb[2 * sk + 1]);
             }
-        }
-        Split3x4 xq[2][KS];                                    // the branches' outputs, split: the trunk's first layer reads all four k-steps
-#pragma unroll
-        for (int br = 0; br < 2; ++br) {
-            f32x4 xb[T];
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                f32x4 v = va[br][t] + vb[br][t];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = relu_bits(v[r]);
-                xb[t] = v;
-            }
-#pragma unroll
-            for (int sk = 0; sk < KS; ++sk) xq[br][sk] = split_tiles(xb[2 * sk], xb[2 * sk + 1]);
             for (int l = 0; l < a.n_branch; ++l) {
                 const u32x4 *fl = frag + (size_t)a.bw_frag[br][l] * 3 * 64 + lane;
                 const float *bl = tail + a.bb_tail[br][l];
-                f32x4 y[T];
+                f32x4 y[T][PT];
 #pragma unroll
                 for (int m = 0; m < T; ++m) {
-                    y[m] = *reinterpret_cast<const f32x4 *>(bl + 16 * m + 4 * g);
+                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bl + 16 * m + 4 * g);
 #pragma unroll
-                    for (int sk = 0; sk < KS; ++sk) y[m] = split_mfma(fl + (m * KS + sk) * 3 * 64, xq[br][sk], y[m]);
+                    for (int pt = 0; pt < PT; ++pt) y[m][pt] = b4;
+#pragma unroll
+                    for (int sk = 0; sk < KS; ++sk) layer_step(fl + (m * KS + sk) * 3 * 64, xq[br][sk], y[m]);
                 }
 #pragma unroll
-                for (int m = 0; m < T; ++m)
+                for (int pt = 0; pt < PT; ++pt) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) y[m][r] = relu_bits(y[m][r]);
+                    for (int m = 0; m < T; ++m)
 #pragma unroll
-                for (int sk = 0; sk < KS; ++sk) xq[br][sk] = split_tiles(y[2 * sk], y[2 * sk + 1]);
+                        for (int r = 0; r < 4; ++r) y[m][pt][r] = relu_bits(y[m][pt][r]);
+#pragma unroll
+                    for (int sk = 0; sk < KS; ++sk) xq[br][sk][pt] = split_tiles(y[2 * sk][pt], y[2 * sk + 1][pt]);
+                }
             }
         }
         // ---- trunk: the first layer reads [xa || xb] (four k-steps), later layers two
-        f32x4 x[T];
-        Split3x4 xt[KS];
+        f32x4 x[T][PT];
+        Split3x4 xt[KS][PT];
         for (int l = 0; l < a.n_trunk; ++l) {
             const u32x4 *fl = frag + (size_t)a.tw_frag[l] * 3 * 64 + lane;
             const float *bl = tail + a.tb_tail[l];
-            f32x4 y[T];
-            if (l == 0) {
+            f32x4 y[T][PT];
 #pragma unroll
-                for (int m = 0; m < T; ++m) {
-                    y[m] = *reinterpret_cast<const f32x4 *>(bl + 16 * m + 4 * g);
+            for (int m = 0; m < T; ++m) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4 *>(bl + 16 * m + 4 * g);
 #pragma unroll
-                    for (int sk = 0; sk < 2 * KS; ++sk) y[m] = split_mfma(fl + (m * 2 * KS + sk) * 3 * 64, xq[sk / KS][sk % KS], y[m]);
-                }
-            } else {
+                for (int pt = 0; pt < PT; ++pt) y[m][pt] = b4;
+                if (l == 0) {
 #pragma unroll
-                for (int m = 0; m < T; ++m) {
-                    y[m] = *reinterpret_cast<const f32x4 *>(bl + 16 * m + 4 * g);
+                    for (int sk = 0; sk < 2 * KS; ++sk) layer_step(fl + (m * 2 * KS + sk) * 3 * 64, xq[sk / KS][sk % KS], y[m]);
+                } else {
 #pragma unroll
-                    for (int sk = 0; sk < KS; ++sk) y[m] = split_mfma(fl + (m * KS + sk) * 3 * 64, xt[sk], y[m]);
+                    for (int sk = 0; sk < KS; ++sk) layer_step(fl + (m * KS + sk) * 3 * 64, xt[sk], y[m]);
                 }
             }
 #pragma unroll
-            for (int m = 0; m < T; ++m)
+            for (int pt = 0; pt < PT; ++pt) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) x[m][r] = relu_bits(y[m][r]);
-            if (l + 1 < a.n_trunk) {
+                for (int m = 0; m < T; ++m)
 #pragma unroll
-                for (int sk = 0; sk < KS; ++sk) xt[sk] = split_tiles(x[2 * sk], x[2 * sk + 1]);
+                    for (int r = 0; r < 4; ++r) x[m][pt][r] = relu_bits(y[m][pt][r]);
+                if (l + 1 < a.n_trunk) {
+#pragma unroll
+                    for (int sk = 0; sk < KS; ++sk) xt[sk][pt] = split_tiles(x[2 * sk][pt], x[2 * sk + 1][pt]);
+                }
             }
         }
         const float *wd = tail + a.dot_tail;
-        float sacc = 0.f;
+        f32x4 w4[T];
 #pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const f32x4 w4 = *reinterpret_cast<const f32x4 *>(wd + 16 * t + 4 * g);
+        for (int t = 0; t < T; ++t) w4[t] = *reinterpret_cast<const f32x4 *>(wd + 16 * t + 4 * g);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sacc = fmaf(x[t][r], w4[r], sacc);
+        for (int pt = 0; pt < PT; ++pt) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sacc = fmaf(x[t][pt][r], w4[t][r], sacc);
+            sacc += __shfl_xor(sacc, 16, 64);
+            sacc += __shfl_xor(sacc, 32, 64);
+            const int64_t p = base + 16 * pt + col;
+            if (g == 0 && p < a.P) a.out[(a.out_index ? (int64_t)a.out_index[p] : p) * a.ldo] = chain_act(sacc + tail[a.dot_bias_tail], a.dot_act);
         }
-        sacc += __shfl_xor(sacc, 16, 64);
-        sacc += __shfl_xor(sacc, 32, 64);
-        if (g == 0 && ok) a.out[(a.out_index ? (int64_t)a.out_index[p] : p) * a.ldo] = chain_act(sacc + tail[a.dot_bias_tail], a.dot_act);
     }
 }
 
@@ -1328,9 +1347,20 @@ int amar_dual_chain_indexed_f32(const float *const *A, const int64_t *lda, const
         const size_t bytes = (size_t)nf * 3 * 1024 + (size_t)tl * sizeof(float);
         if (bytes <= 160 * 1024) {
             static bool lds_ok[AMAR_MAX_DEVICES];
-            if (bytes > 64 * 1024)                                    // (allowed once per device, for the largest image)
-                if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dual_chain_split_kernel), 160 * 1024, lds_ok)) return rc;
-            hipLaunchKernelGGL(dual_chain_split_kernel, dim3((unsigned)blocks), dim3(THREADS), bytes, static_cast<hipStream_t>(stream), a);
+            // two pair tiles per wave in 512-thread workgroups (AMAR_DUAL_PT=1: one tile per wave, 1 024 threads)
+            static const bool pt1 = getenv("AMAR_DUAL_PT") && atoi(getenv("AMAR_DUAL_PT")) == 1;
+            static bool lds_ok2[AMAR_MAX_DEVICES];
+            if (pt1) {
+                if (bytes > 64 * 1024)                                // (allowed once per device, for the largest image)
+                    if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dual_chain_split_kernel<1, 1024>), 160 * 1024, lds_ok)) return rc;
+                hipLaunchKernelGGL((dual_chain_split_kernel<1, 1024>), dim3((unsigned)blocks), dim3(1024), bytes, static_cast<hipStream_t>(stream), a);
+            } else {
+                if (bytes > 64 * 1024)
+                    if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dual_chain_split_kernel<2, 512>), 160 * 1024, lds_ok2)) return rc;
+                int64_t blocks2 = (P + 8 * 32 - 1) / (8 * 32);
+                if (blocks2 > 1024) blocks2 = 1024;
+                hipLaunchKernelGGL((dual_chain_split_kernel<2, 512>), dim3((unsigned)blocks2), dim3(512), bytes, static_cast<hipStream_t>(stream), a);
+            }
             return amar_check_launch();
         }
     }

@@ -39,6 +39,9 @@ def main():
     med_t, _ = timeit(lambda: rs.towers(emb[:nu], emb[nu:], bert[:nu], bert[nu:]), reps=5)
     med_p, _ = timeit(lambda: rs.score_towers(tw, u, i, 0, nu), reps=5)
     print('  all four entity towers: {:.3f} ms; pair stage ({} pairs): {:.3f} ms = {:.2f} G pairs/s'.format(med_t, P, med_p, P / med_p / 1e6), flush=True)
+    z_u, z_i = torch.zeros_like(u), torch.full_like(i, nu)
+    med_z, _ = timeit(lambda: rs.score_towers(tw, z_u, z_i, 0, nu), reps=5)
+    print('  pair stage with every pair reading row 0 of each table (no memory system): {:.3f} ms'.format(med_z), flush=True)
     from deep_cbrs_amar_renaissance_amd.models.basic import PairPlan
     g = torch.Generator(device=dev); g.manual_seed(42)
     perm = torch.randperm(P, device=dev, generator=g)

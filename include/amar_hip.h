@@ -246,6 +246,11 @@ int amar_dense_split_f32(const float *X, int64_t ldx, const int32_t *ids, const 
  * amar_chain_pack_floats / amar_chain_pack_f32 run on the HOST (host pointers): kernels[l] is the
  * row-major [dims[l], dims[l+1]] Keras kernel, biases[l] its bias; the blob is then copied to
  * the device by the caller.
+ * Arithmetic: f32 values and f32 sums throughout.  The pair-stage form (sum_inputs with both id lists, ReLU, equal
+ * layer widths of 48 or 64, a trailing 1-unit layer) and amar_dual_chain_f32's 64-wide form take their PRODUCTS on
+ * the bf16 matrix instruction with both operands split into three bf16 parts (x = hi + mid + lo exactly; six part
+ * products accumulated in f32): a term x.w is off by at most 3 * 2^-24 |x.w| — as close to a float64 evaluation as the
+ * f32 instruction, not bit-identical to it.  Environment AMAR_PAIR_MFMA=f32 keeps v_mfma_f32_16x16x4_f32 everywhere.
  */
 int64_t amar_chain_pack_floats(const int32_t *dims, int32_t n_layers);
 int amar_chain_pack_f32(const float *const *kernels, const float *const *biases, const int32_t *dims,

@@ -758,7 +758,11 @@ def main():
             'value': n_pairs * args.steps / dt, 'unit': 'pairs/s', 'csrc_sha': csrc_sha(),
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True,
-            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32',
+            'dtype_note': 'f32 values and f32 sums everywhere; the pair stage takes its products on the bf16 matrix instruction with both operands '
+                          'split into three bf16 parts (x = hi + mid + lo exactly, six part products accumulated in f32): as close to a float64 '
+                          'evaluation as the f32 instruction (DESIGN 4b); AMAR_PAIR_MFMA=f32 / AMAR_DENSE_SPLIT=0 select v_mfma_f32_*_f32',
+            'data': 'synthetic',
             'config': {'workload': 'ml1m(s={}) user-item graph: N={} nodes, nnz(A_hat)={}, {} test pairs; '
                                    'econfigs/basic-gnn.yaml grid1 BasicGCN d=8 L=2 concat, dense [24,24], clf [48,48]; '
                                    'one propagation + per-entity towers + all pairs (shuffled order) per step (hoisted)'.format(args.scale, n_nodes, nnz, n_pairs),

@@ -876,8 +876,8 @@ __global__ __launch_bounds__(1024) void dual_chain_full_kernel(const DualArgs a)
 // above: f32-accurate, 6 MFMAs of 16 cycles per k-step of 32 instead of 8 of 32 cycles).  The f32 weight blob (84 KB for the 64-wide
 // stacks) is split by the workgroup into 126 KB of bf16 fragments at its start, straight from global memory — blob and fragments
 // would not fit the LDS together; biases and the 1-unit layer stay f32 in a small tail.  AMAR_PAIR_MFMA=f32 keeps the f32 kernel.
-// PT pair tiles of 16 per wave and iteration, THREADS per workgroup (1 024 with PT = 1; 512 with PT = 2: the 128 registers a lane of a
-// 1 024-thread workgroup may hold do not fit two tiles): a weight fragment read from the LDS feeds PT tiles' MFMAs.
+// PT pair tiles of 16 per wave and iteration, THREADS per workgroup (the 126 KB of fragments allow one workgroup per CU, so THREADS sets
+// the waves per SIMD and the registers a lane may hold: 768 -> 3 waves, 168 registers, PT = 1 — the default, see the launcher).
 template <int PT, int THREADS>
 __global__ __launch_bounds__(THREADS) void dual_chain_split_kernel(const DualArgs a) {
     constexpr int T = 4, KS = 2;
@@ -1347,19 +1347,29 @@ int amar_dual_chain_indexed_f32(const float *const *A, const int64_t *lda, const
         const size_t bytes = (size_t)nf * 3 * 1024 + (size_t)tl * sizeof(float);
         if (bytes <= 160 * 1024) {
             static bool lds_ok[AMAR_MAX_DEVICES];
-            // two pair tiles per wave in 512-thread workgroups (AMAR_DUAL_PT=1: one tile per wave, 1 024 threads)
-            static const bool pt1 = getenv("AMAR_DUAL_PT") && atoi(getenv("AMAR_DUAL_PT")) == 1;
-            static bool lds_ok2[AMAR_MAX_DEVICES];
-            if (pt1) {
+            // one pair tile per wave in 768-thread workgroups: three waves per SIMD with up to 168 registers each (164 used, no spills) —
+            // 1 024 threads leave a lane 128 registers (25 spilled), two tiles per wave in 512 threads need 256 (two waves per SIMD, which do
+            // not cover the un-prefetched gathers at the top of an iteration: 35 % of a wave's time in s_waitcnt).  ml1m(s=64), prepared
+            // list: 2.70 ms against 2.82 (two tiles, 512 threads) and 2.93 (1 024 threads).  AMAR_DUAL_PT=1 / 2: those forms.
+            static const int dual_pt = getenv("AMAR_DUAL_PT") ? atoi(getenv("AMAR_DUAL_PT")) : 0;
+            static bool lds_ok2[AMAR_MAX_DEVICES], lds_ok3[AMAR_MAX_DEVICES];
+            hipStream_t st = static_cast<hipStream_t>(stream);
+            if (dual_pt == 1) {
                 if (bytes > 64 * 1024)                                // (allowed once per device, for the largest image)
                     if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dual_chain_split_kernel<1, 1024>), 160 * 1024, lds_ok)) return rc;
-                hipLaunchKernelGGL((dual_chain_split_kernel<1, 1024>), dim3((unsigned)blocks), dim3(1024), bytes, static_cast<hipStream_t>(stream), a);
-            } else {
+                hipLaunchKernelGGL((dual_chain_split_kernel<1, 1024>), dim3((unsigned)blocks), dim3(1024), bytes, st, a);
+            } else if (dual_pt == 2) {
                 if (bytes > 64 * 1024)
                     if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dual_chain_split_kernel<2, 512>), 160 * 1024, lds_ok2)) return rc;
                 int64_t blocks2 = (P + 8 * 32 - 1) / (8 * 32);
                 if (blocks2 > 1024) blocks2 = 1024;
-                hipLaunchKernelGGL((dual_chain_split_kernel<2, 512>), dim3((unsigned)blocks2), dim3(512), bytes, static_cast<hipStream_t>(stream), a);
+                hipLaunchKernelGGL((dual_chain_split_kernel<2, 512>), dim3((unsigned)blocks2), dim3(512), bytes, st, a);
+            } else {
+                if (bytes > 64 * 1024)
+                    if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dual_chain_split_kernel<1, 768>), 160 * 1024, lds_ok3)) return rc;
+                int64_t blocks3 = (P + 12 * 16 - 1) / (12 * 16);
+                if (blocks3 > 1024) blocks3 = 1024;
+                hipLaunchKernelGGL((dual_chain_split_kernel<1, 768>), dim3((unsigned)blocks3), dim3(768), bytes, st, a);
             }
             return amar_check_launch();
         }

@@ -226,3 +226,52 @@ def test_full_size_gat_and_sage_on_the_lds_tiled_walk(hip, big, monkeypatch):
         y1.data_ptr(), c, 1, n, n, 0, None)
     torch.cuda.synchronize()
     assert code == 0 and float((y1 - y0).abs().max()) < 2e-6
+
+
+def test_full_size_hybrid_head_properties(hip, big):
+    """The hybrid head at the bench's size (12.1 M pairs, 768-d content rows): scores on the prepared pair list (XCD-affine order, two-step
+    way back) equal the direct call bit for bit; any permutation of the pair list permutes the scores; a sample agrees with a float64
+    evaluation of the pair stage from the same tower tables within 1e-6 (the north star's bar is 1e-4)."""
+    from deep_cbrs_amar_renaissance_amd import engine
+    from deep_cbrs_amar_renaissance_amd.models import hybrid, basic
+    engine.set_seed(43)
+    dev = big['a'].rowptr.device
+    nu, ni, n = big['n_users'], big['n_items'], big['n']
+    model = hybrid.HybridBertGCN(big['a'], embedding_dim=8, n_hiddens=[8, 8], dense_units=[[24, 24], [256, 64], [64, 64]], clf_units=[64, 64],
+                                 feature_based=True)
+    g = torch.Generator(device=dev); g.manual_seed(44)
+    bert = torch.randn((n, 768), device=dev, generator=g) * 0.5
+    model.rs.build_head(model.gnn.output_dim(), 768)
+    test = big['test']
+    p = int(test.shape[0])
+    perm = torch.randperm(p, device=dev, generator=g)
+    u = test[perm, 0].to(torch.int32).contiguous()
+    i = test[perm, 1].to(torch.int32).contiguous()
+    emb = model.gnn(None)
+    rs = model.rs
+    tw = rs.towers(emb[:nu], emb[nu:], bert[:nu], bert[nu:])
+    assert tw[4]
+    direct = rs.score_towers(tw, u, i, 0, nu)
+    assert direct.shape == (p, 1) and bool(torch.isfinite(direct).all()) and float(direct.min()) >= 0 and float(direct.max()) <= 1
+    plan = basic.PairPlan(u, i)
+    assert plan.mid_index is not None                                   # a list this long returns through the window streams
+    assert torch.equal(rs.score_towers(tw, u, i, 0, nu, pair_plan=plan), direct)
+    perm2 = torch.randperm(p, device=dev, generator=g)
+    assert torch.equal(rs.score_towers(tw, u[perm2].contiguous(), i[perm2].contiguous(), 0, nu), direct[perm2])
+    # float64 pair stage on a sample
+    sel = perm2[:20000]
+    tug, tig, tub, tib = [t.double() for t in tw[:4]]
+    ul, il = u[sel].long(), (i[sel] - nu).long()
+    x1, x2 = torch.relu(tug[ul] + tig[il]), torch.relu(tub[ul] + tib[il])
+    kb = lambda l: (l.kernel.detach().double(), l.bias.detach().double())
+    for l in list(rs.dense3a.layers)[1:]:
+        k, b = kb(l); x1 = torch.relu(x1 @ k + b)
+    for l in list(rs.dense3b.layers)[1:]:
+        k, b = kb(l); x2 = torch.relu(x2 @ k + b)
+    x = torch.cat([x1, x2], 1)
+    layers = list(rs.clf.layers)
+    for l in layers[:-1]:
+        k, b = kb(l); x = torch.relu(x @ k + b)
+    k, b = kb(layers[-1])
+    ref = torch.sigmoid(x @ k + b)
+    assert float((direct[sel].double() - ref).abs().max()) < 1e-6

@@ -165,46 +165,49 @@ def cpu_baseline(s1, headline=None):
         hoisted()
         adt, areps = timed(hoisted, 3.0, 3)
     err = float(np.abs(scores.reshape(-1) - s1['gpu_scores'].reshape(-1)).max())
-    out = {'value': len(u) / dt, 'unit': 'pairs/s', 'cores': 1, 'kind': 'port',
-           'sample': 'ml1m(s=1), the graph / weights / {} test pairs of the ml1m_s1 GPU leg: 2-layer GCN propagation + all pairs, '
-                     'hoisted, {} reps of {:.3f} s on one thread'.format(len(u), reps, dt),
-           'faithful': {'value': len(u) / fdt, 'unit': 'pairs/s', 'cores': 1, 'batch': 2048,
-                        'sample': 'propagation re-run per 2048-pair batch (basic.py:61-63), {} passes of {:.2f} s'.format(freps, fdt)},
-           'all_cores': {'value': len(u) / adt, 'unit': 'pairs/s', 'cores': threads, 'usable_cores': cores, 'host_cpus': os.cpu_count(),
-                         'pool_sweep_pairs_per_s': {str(p): len(u) / t for p, t in sweep.items()},
-                         'sample': 'the same hoisted pass with the BLAS pool that serves it best, {} threads of {} usable ({} reps of {:.3f} s); '
-                                   'scipy\'s CSR product stays single-threaded'.format(threads, cores, areps, adt)},
-           'max_abs_score_diff_vs_gpu': err}
-    if headline is not None:
-        from scipy import sparse
-        hg, hh, hu, hi_ = headline['gnn'], headline['head'], headline['u'], headline['i']
-        rowptr, colidx, vals = headline['a_hat']
-        ah = sparse.csr_matrix((vals, colidx, rowptr), shape=(len(rowptr) - 1, len(rowptr) - 1))
-        e1 = propagate(ah, hg)                                      # (untimed: warms the pages; also the sweep's input)
-        hsweep = {}
-        for pool in sorted({p for p in (8, 32, 64, 128) if p <= cores}):      # a 1 Mi-pair batch has work for a larger pool than ml1m(s=1)
-            with threadpool_limits(limits=pool):
-                t0 = time.perf_counter()
-                om.basic_rs(e1[hu[:1 << 20]], e1[hi_[:1 << 20]], hh)
-                hsweep[pool] = time.perf_counter() - t0
-        threads = min(hsweep, key=hsweep.get) if hsweep else 1
-        del e1
-        with threadpool_limits(limits=threads):
+    s1_legs = {'workload': 'ml1m(s=1): the graph / weights / {} test pairs of the ml1m_s1 GPU leg'.format(len(u)),
+               'one_core': {'value': len(u) / dt, 'unit': 'pairs/s', 'cores': 1,
+                            'sample': '2-layer GCN propagation + all pairs, hoisted, {} reps of {:.3f} s on one thread'.format(reps, dt)},
+               'faithful': {'value': len(u) / fdt, 'unit': 'pairs/s', 'cores': 1, 'batch': 2048,
+                            'sample': 'propagation re-run per 2048-pair batch (basic.py:61-63), {} passes of {:.2f} s'.format(freps, fdt)},
+               'best_pool': {'value': len(u) / adt, 'unit': 'pairs/s', 'cores': threads, 'usable_cores': cores, 'host_cpus': os.cpu_count(),
+                             'pool_sweep_pairs_per_s': {str(p): len(u) / t for p, t in sweep.items()},
+                             'sample': 'the same hoisted pass on the BLAS pool that serves it best — a sweep, NOT all cores: {} threads of {} usable '
+                                       '({} reps of {:.3f} s); scipy\'s CSR product stays single-threaded'.format(threads, cores, areps, adt)},
+               'max_abs_score_diff_vs_gpu': err}
+    if headline is None:
+        out = dict(s1_legs['one_core'], kind='port', workload=s1_legs['workload'], max_abs_score_diff_vs_gpu=err, ml1m_s1=s1_legs)
+        return out
+    from scipy import sparse
+    hg, hh, hu, hi_ = headline['gnn'], headline['head'], headline['u'], headline['i']
+    rowptr, colidx, vals = headline['a_hat']
+    ah = sparse.csr_matrix((vals, colidx, rowptr), shape=(len(rowptr) - 1, len(rowptr) - 1))
+    e1 = propagate(ah, hg)                                          # (untimed: warms the pages; also the sweep's input)
+    hsweep = {}
+    for pool in sorted({p for p in (8, 32, 64, 128) if p <= cores}):          # a 1 Mi-pair batch has work for a larger pool than ml1m(s=1)
+        with threadpool_limits(limits=pool):
             t0 = time.perf_counter()
-            e = propagate(ah, hg)
-            t_prop = time.perf_counter() - t0
-            worst = 0.0
-            for lo in range(0, len(hu), 1 << 20):                   # pair batches bound the host memory, not the arithmetic
-                sc = om.basic_rs(e[hu[lo:lo + (1 << 20)]], e[hi_[lo:lo + (1 << 20)]], hh)
-                worst = max(worst, float(np.abs(sc.reshape(-1) - headline['gpu_scores'][lo:lo + (1 << 20)].reshape(-1)).max()))
-            hdt = time.perf_counter() - t0
-        out['headline_workload'] = {'value': len(hu) / hdt, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port',
-                                    'sample': 'ONE hoisted repetition on the headline workload itself ({}): propagation {:.2f} s (scipy CSR product, one thread), '
-                                              'all {} pairs in 1 Mi-pair batches on a BLAS pool of {} threads, {:.2f} s in all; A_hat is the '
-                                              'device-built matrix copied to the host (bit-identical to the oracle\'s gcn_filter: '
-                                              'tests/test_models_gpu.py::test_device_gcn_filter_matches_host)'.format(
-                                                  headline['workload'], t_prop, len(hu), threads, hdt),
-                                    'max_abs_score_diff_vs_gpu': worst}
+            om.basic_rs(e1[hu[:1 << 20]], e1[hi_[:1 << 20]], hh)
+            hsweep[pool] = time.perf_counter() - t0
+    threads = min(hsweep, key=hsweep.get) if hsweep else 1
+    del e1
+    with threadpool_limits(limits=threads):
+        t0 = time.perf_counter()
+        e = propagate(ah, hg)
+        t_prop = time.perf_counter() - t0
+        worst = 0.0
+        for lo in range(0, len(hu), 1 << 20):                       # pair batches bound the host memory, not the arithmetic
+            sc = om.basic_rs(e[hu[lo:lo + (1 << 20)]], e[hi_[lo:lo + (1 << 20)]], hh)
+            worst = max(worst, float(np.abs(sc.reshape(-1) - headline['gpu_scores'][lo:lo + (1 << 20)].reshape(-1)).max()))
+        hdt = time.perf_counter() - t0
+    # the headline figure is LIKE FOR LIKE: the workload `value` is quoted on; the ml1m(s=1) legs (one core, faithful, pool sweep) nest below
+    out = {'value': len(hu) / hdt, 'unit': 'pairs/s', 'cores': threads, 'kind': 'port', 'workload': headline['workload'],
+           'sample': 'ONE hoisted repetition on the headline workload itself ({}): propagation {:.2f} s (scipy CSR product, one thread), '
+                     'all {} pairs in 1 Mi-pair batches on a BLAS pool of {} threads (the fastest of a sweep over {}), {:.2f} s in all; A_hat is the '
+                     'device-built matrix copied to the host (bit-identical to the oracle\'s gcn_filter: '
+                     'tests/test_models_gpu.py::test_device_gcn_filter_matches_host)'.format(
+                         headline['workload'], t_prop, len(hu), threads, sorted(hsweep), hdt),
+           'max_abs_score_diff_vs_gpu': worst, 'ml1m_s1': s1_legs}
     return out
 
 
@@ -352,26 +355,37 @@ def hybrid_head(dev, scale):
     f32_form = os.environ.get('AMAR_PAIR_MFMA') == 'f32'
     f32_dense = os.environ.get('AMAR_DENSE_SPLIT') == '0'
     split_note = ('products on v_mfma_f32_*_bf16 with both operands split three ways (x = hi + mid + lo exactly, six part products in '
-                  'f32: as accurate as the f32 instruction, DESIGN 4b); tflops = the f32 work it stands for, so mfma_frac — against '
-                  'the F32 MFMA peak — may exceed 1')
+                  'f32: as accurate as the f32 instruction, DESIGN 4b): mfma_frac = the time the matrix pipe needs for the EXECUTED '
+                  'instructions at their own dense peaks (bf16 2 500 TFLOP/s, f32 157.3) over the elapsed time — a utilisation, never above 1; '
+                  'f32_equiv_tflops is the f32 work the launch stands for (secondary)')
+    # executed instructions: a split product is six bf16 part products; the 256 -> 64 layer of the tower stays on the f32 instruction
+    l1, l2 = nu * 768 * 256 * 2.0, nu * 256 * 64 * 2.0
+    pipe_ms_bert = 1e3 * ((l1 / (MFMA_F32_PEAK_TFLOPS * 1e12) if f32_dense else 6 * l1 / (MFMA_BF16_PEAK_TFLOPS * 1e12)) + l2 / (MFMA_F32_PEAK_TFLOPS * 1e12))
+    pipe_ms_pairs = 1e3 * p * (flop_pair / (MFMA_F32_PEAK_TFLOPS * 1e12) if f32_form else 6 * flop_pair / (MFMA_BF16_PEAK_TFLOPS * 1e12))
     del plan
     del model, bert, tw, emb
     torch.cuda.empty_cache()
     return {'config': 'econfigs/hybrid-gnn.yaml grid1: HybridBertGCN d=8 L=2, dense [[24,24],[256,64],[64,64]], clf [64,64], 768-d BERT, ml1m(s={})'.format(scale),
             'bert_tower': {'kernel': ('dense_mfma128_kernel' if f32_dense else 'dense_split128_kernel (amar_dense_split_f32)') +
                                      ' / dense_mfma_kernel (amar_dense_f32): 768->256->64 over the {} user rows'.format(nu),
-                           'ms': ms_bert_u, 'tflops': flop_bert_u / ms_bert_u / 1e9, 'peak_tflops': MFMA_F32_PEAK_TFLOPS,
-                           'mfma_frac': flop_bert_u / ms_bert_u / 1e9 / MFMA_F32_PEAK_TFLOPS,
+                           'ms': ms_bert_u, 'mfma_frac': pipe_ms_bert / ms_bert_u,
+                           'executed': {'first_layer': 'v_mfma_f32_32x32x2_f32' if f32_dense else 'v_mfma_f32_32x32x16_bf16 x 6 part products',
+                                        'first_layer_tflops': (1 if f32_dense else 6) * l1 / ms_bert_u / 1e9,
+                                        'first_layer_peak_tflops': MFMA_F32_PEAK_TFLOPS if f32_dense else MFMA_BF16_PEAK_TFLOPS,
+                                        'second_layer': 'v_mfma_f32_32x32x2_f32', 'note': 'tflops over the time of BOTH layers'},
+                           'f32_equiv_tflops': flop_bert_u / ms_bert_u / 1e9, 'f32_peak_tflops': MFMA_F32_PEAK_TFLOPS,
                            'note': None if f32_dense else 'first layer: ' + split_note},
             'entity_towers_ms': ms_towers,
             'pair_stage': {'kernel': ('dual_chain_full_kernel' if f32_form else 'dual_chain_split_kernel') +
                                      ' (amar_dual_chain_indexed_f32 on the prepared pair list) + scatter_windows_kernel', 'pairs': p, 'ms': ms_pairs,
                            'pairs_per_s': p / ms_pairs * 1e3, 'flop_per_pair': flop_pair,
-                           'tflops': p * flop_pair / ms_pairs / 1e9, 'peak_tflops': MFMA_F32_PEAK_TFLOPS,
-                           'mfma_frac': p * flop_pair / ms_pairs / 1e9 / MFMA_F32_PEAK_TFLOPS,
-                           'note': None if f32_form else split_note,
-                           'executed_bf16_tflops': None if f32_form else p * (6 * flop_pair) / ms_pairs / 1e9,
-                           'bf16_peak_tflops': MFMA_BF16_PEAK_TFLOPS}}
+                           'mfma_frac': pipe_ms_pairs / ms_pairs,
+                           'executed_tflops': p * (1 if f32_form else 6) * flop_pair / ms_pairs / 1e9,
+                           'executed_peak_tflops': MFMA_F32_PEAK_TFLOPS if f32_form else MFMA_BF16_PEAK_TFLOPS,
+                           'executed_instruction': 'v_mfma_f32_16x16x4_f32' if f32_form else 'v_mfma_f32_16x16x32_bf16 x 6 part products',
+                           'f32_equiv_tflops': p * flop_pair / ms_pairs / 1e9, 'f32_peak_tflops': MFMA_F32_PEAK_TFLOPS,
+                           'pmc_busy_frac_note': 'matrix pipe busy 0.45-0.50 by SQ_VALU_MFMA_BUSY_CYCLES (profiles/r3_exp_pair_split.txt)',
+                           'note': None if f32_form else split_note}}
 
 
 def train_true_size():
@@ -521,11 +535,60 @@ def wider_layers(dev, scale, steps):
     return out
 
 
+def model_families(dev, scale, steps):
+    """The other layer kinds of econfigs/basic-gnn.yaml (model.name: basic.BasicLightGCN / BasicGraphSage / BasicGAT, grid1 dims) at
+    the same ml1m(s): the hoisted step replayed from a hipGraph, and the propagation alone (HIP events over eager steps).  GraphSAGE
+    and GAT take the raw symmetric edge list (gnn.py:316-319, 349-352), LightGCN the gcn-filtered matrix."""
+    from deep_cbrs_amar_renaissance_amd import engine, parallel
+    from deep_cbrs_amar_renaissance_amd.data import synthetic
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter_device, DeviceCSR
+    data = synthetic.ml1m_device(scale, device=dev)
+    nu, ni = data['n_users'], data['n_items']
+    n = nu + ni
+    a_hat = gcn_filter_device(data['train_pos'][:, 0], data['train_pos'][:, 1], n)
+    rp = a_hat.rowptr.long()
+    rows = torch.repeat_interleave(torch.arange(n, device=dev), rp[1:] - rp[:-1])
+    keep = rows != a_hat.colidx.long()
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(torch.bincount(rows[keep], minlength=n), 0)
+    edges = DeviceCSR(rowptr.to(torch.int32), a_hat.colidx[keep].contiguous(), None, (n, n))
+    edges.row_breaks = (nu,)
+    u, i = shuffled_test_pairs(data, dev)
+    p = int(u.numel())
+    del data, rows, keep, rp
+    out = {'config': 'econfigs/basic-gnn.yaml grid1 dims (d=8, L=2, dense [24,24], clf [48,48]) at ml1m(s={}), {} test pairs'.format(scale, p)}
+    cfg = dict(GRID1, aggregate='mean', dropout_rate=0.0)
+    for name, adj in (('BasicLightGCN', a_hat), ('BasicGraphSage', edges), ('BasicGAT', edges)):
+        engine.set_seed(42)
+        model = getattr(basic, name)(adj, **cfg)
+        model.n_users, model.n_items = nu, ni
+        runner = parallel.SingleRunner(model, u, i)
+        for _ in range(5):
+            runner.step()
+        prop_ms = runner.last_propagation_ms()
+        for _ in range(40):
+            runner.step_graphed()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            runner.step_graphed()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        out[name] = {'ms_per_step': 1e3 * dt, 'pairs_per_s': p / dt, 'propagation_ms': prop_ms}
+        del runner, model
+        for key in ('_lt_cache', '_lt_mean_cache', '_lt_gat_cache'):
+            adj.__dict__.pop(key, None)
+        torch.cuda.empty_cache()
+    return out
+
+
 def value_spread(scale):
-    """min / max ms per step of the default run over the boxes of the build session (profiles/r3_bench_repeats.json, written by
+    """min / max ms per step of the default run over the boxes of the build session (profiles/r<round>_bench_repeats.json, written by
     tools/collect_spread.py from the bench.py lines of different gpurun boxes), with the csrc/ hash it was measured at."""
-    path = os.path.join(ROOT, 'profiles', 'r3_bench_repeats.json')
-    if not os.path.exists(path):
+    paths = [os.path.join(ROOT, 'profiles', 'r{}_bench_repeats.json'.format(r)) for r in (4, 3)]
+    path = next((q for q in paths if os.path.exists(q)), None)
+    if path is None:
         return None
     rep = json.load(open(path))
     if rep.get('scale') != scale:
@@ -825,20 +888,19 @@ def main():
                                  'traffic': pmc.get('pair_stage_traffic_bytes_per_launch') if pmc else None, 'traffic_source': traffic_source,
                                  # the same launch against the matrix-pipe peaks: the f32 work it stands for against the f32 MFMA peak
                                  # (v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s dense), and what it executes against the dense bf16 peak
-                                 'mfma': {'flop_per_pair': flop_pair,
-                                          'flop_note': 'per-pair f32 work after hoisting the towers and the first classifier layer per entity '
-                                                       '(SURVEY 8(d) counts 13 920 flop/pair for the un-hoisted head; test_faithful_equals_hoisted_and_predict keeps the two equal)',
-                                          'achieved_tflops': pairs_local * flop_pair / (pms * 1e-3) / 1e12,
-                                          'peak_tflops': MFMA_F32_PEAK_TFLOPS,
-                                          'frac': pairs_local * flop_pair / (pms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                                          'frac_note': 'f32-equivalent work over the f32 MFMA peak: what an exact-f32 formulation could reach at most is 1',
-                                          'executed': None if f32_form else {
-                                              'instruction': 'v_mfma_f32_16x16x32_bf16, six part products per f32 product, k padded 48 -> 64',
-                                              'flop_per_pair': bf16_flop_pair,
-                                              'achieved_tflops': pairs_local * bf16_flop_pair / (pms * 1e-3) / 1e12,
-                                              'peak_tflops': MFMA_BF16_PEAK_TFLOPS,
-                                              'frac': pairs_local * bf16_flop_pair / (pms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS},
-                                          'pmc_busy_frac': pmc.get('pair_stage_mfma_busy_frac') if pmc else None}}
+                                 'mfma': {'frac': (pairs_local * flop_pair / (pms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS) if f32_form else
+                                                  (pairs_local * bf16_flop_pair / (pms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS),
+                                          'frac_note': 'EXECUTED matrix instructions over the dense peak of that instruction ({}): a utilisation'.format(
+                                              'v_mfma_f32_16x16x4_f32, 157.3 TFLOP/s' if f32_form else 'v_mfma_f32_16x16x32_bf16, 2 500 TFLOP/s; six part products per f32 product, k padded 48 -> 64'),
+                                          'executed_flop_per_pair': flop_pair if f32_form else bf16_flop_pair,
+                                          'executed_tflops': pairs_local * (flop_pair if f32_form else bf16_flop_pair) / (pms * 1e-3) / 1e12,
+                                          'executed_peak_tflops': MFMA_F32_PEAK_TFLOPS if f32_form else MFMA_BF16_PEAK_TFLOPS,
+                                          'pmc_busy_frac': pmc.get('pair_stage_mfma_busy_frac') if pmc else None,
+                                          'f32_equiv': {'flop_per_pair': flop_pair,
+                                                        'flop_note': 'per-pair f32 work after hoisting the towers and the first classifier layer per entity '
+                                                                     '(SURVEY 8(d) counts 13 920 flop/pair for the un-hoisted head; test_faithful_equals_hoisted_and_predict keeps the two equal)',
+                                                        'tflops': pairs_local * flop_pair / (pms * 1e-3) / 1e12, 'f32_peak_tflops': MFMA_F32_PEAK_TFLOPS,
+                                                        'note': 'the f32 work the launch stands for (secondary; an exact-f32 formulation tops out at the f32 peak)'}}}
         if world == 1 and not args.no_cpu_baseline:
             # the headline workload's own inputs for the CPU leg (host copies), before the GPU objects go
             from tests import helpers
@@ -851,6 +913,7 @@ def main():
             out['wider_layers'] = wider_layers(dev, args.scale, args.steps)
             out['hybrid_head'] = hybrid_head(dev, args.scale)
             out['uip_graph'] = uip_graph(dev, args.scale, args.steps)
+            out['model_families'] = model_families(dev, args.scale, args.steps)
             out['ml1m_s1'], s1 = ml1m_true_size(dev)
             out['train_s1'] = train_true_size()
             out['cpu_baseline'] = cpu_baseline(s1, headline)

@@ -212,7 +212,7 @@ def spmm_sj(sj, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc
 
 
 def spmm_xs(xs, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc_div=None, Wnext=None, Hnext=None,
-            prescaled=False, scale_next=False):
+            prescaled=False, scale_next=False, xself=None):
     """Y = A.X on the XCD-sliced image `xs` of A (utilities.math.XcdSliced): per-slice partial products with
     XCD <-> L2 affinity, then the combine kernel with the epilogues of spmm_csr / gcn_layer.
 
@@ -220,10 +220,13 @@ def spmm_xs(xs, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc
     table (the fused GCN chain keeps it so with `scale_next`), otherwise one row_affine pass makes it here.
 
     `xs` may also be an LDS-tiled image (utilities.lds_tiled.LdsTiled, what DeviceCSR.tiled_image returns where the
-    column-ordered form pays): the call is then amar_spmm_lt_f32, same keywords."""
+    column-ordered form pays): the call is then amar_spmm_lt_f32, same keywords.
+
+    `xself` ([n_rows, F], same leading dimension as X): where the rows' OWN entries of X are read from, instead of
+    X[diag_offset:] — a row block of a partition whose own rows of the gathered table may not have landed yet (parallel.py)."""
     if hasattr(xs, 'words'):
         return spmm_lt(xs, X, Y, bias=bias, relu=relu, acc_in=acc_in, acc_out=acc_out, acc_div=acc_div, Wnext=Wnext, Hnext=Hnext,
-                       prescaled=prescaled, scale_next=scale_next)
+                       prescaled=prescaled, scale_next=scale_next, xself=xself)
     n_rows = xs.shape[0]
     F = X.shape[1]
     flags = (SPMM_BIAS if bias is not None else 0) | (SPMM_RELU if relu else 0)
@@ -255,7 +258,7 @@ def spmm_xs(xs, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc
     code = load().amar_spmm_xs_f32(
         _ptr(xs.diag, torch.float32, 'diag'), _ptr(xs.rowptr, torch.int32, 'rowptr'), _ptr(xs.colidx, torch.int32, 'colidx'),
         _ptr(xs.vals, torch.float32, 'vals'), _ptr(row_scale, torch.float32, 'row_scale'), xs.n_slices,
-        _ptr(X, torch.float32, 'X'), _ld(X, 'X'), X.shape[0], _ptr(X[diag_offset:], torch.float32, 'X') if diag_offset else None,
+        _ptr(X, torch.float32, 'X'), _ld(X, 'X'), X.shape[0], _xself_ptr(xself, X, diag_offset, n_rows, prescaled or row_scale is None),
         _ptr(P, torch.float32, 'partials'),
         _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y') if Y is not None else 0,
         n_rows, F, flags, _ptr(bias, torch.float32, 'bias'),
@@ -267,8 +270,19 @@ def spmm_xs(xs, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc
     _check(code, 'amar_spmm_xs_f32')
 
 
+def _xself_ptr(xself, X, diag_offset, n_rows, usable):
+    """The pointer the SpMM kernels read the rows' own entries of X through: `xself` when given, else X[diag_offset:] (None: X)."""
+    if xself is None:
+        return _ptr(X[diag_offset:], torch.float32, 'X') if diag_offset else None
+    if not usable:
+        raise ValueError("xself needs the table as the kernel gathers it (prescaled=True on a value-free image)")
+    if tuple(xself.shape) != (n_rows, X.shape[1]) or _ld(xself, 'xself') != _ld(X, 'X'):
+        raise ValueError("xself must be [n_rows, F] with the leading dimension of X")
+    return _ptr(xself, torch.float32, 'xself')
+
+
 def spmm_lt(lt, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc_div=None, Wnext=None, Hnext=None,
-            prescaled=False, scale_next=False, sage_tail=None):
+            prescaled=False, scale_next=False, sage_tail=None, xself=None):
     """Y = A.X on the LDS-tiled image `lt` of a value-free A = S C S (utilities.lds_tiled.LdsTiled): one launch, the
     row tile's sums in LDS, gathers in column order.  Keywords as spmm_xs (`prescaled`: X already holds S.X).
     sage_tail = (kernel [2F, F], bias [F]) on GraphSAGE's mean-aggregate image: Y = relu(l2_normalize([X || mean] . kernel + bias))
@@ -317,7 +331,7 @@ def spmm_lt(lt, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc
         _ptr(lt.words, torch.int32, 'words'), _ptr(lt.stream_start, torch.int32, 'stream_start'),
         _ptr(lt.wsteps, torch.int32, 'wsteps'), _ptr(lt.tile_row0, torch.int32, 'tile_row0'), _ptr(lt.n_win, torch.int32, 'n_win'),
         _ptr(lt.vstart, torch.int32, 'vstart'), _ptr(lt.vcount, torch.int32, 'vcount'), lt.n_tiles, lt.maxwin1, lt.pace_every, _ptr(lt.diag, torch.float32, 'diag'), _ptr(lt.row_scale, torch.float32, 'row_scale'),
-        _ptr(X, torch.float32, 'X'), _ld(X, 'X'), X.shape[0], _ptr(X[off:], torch.float32, 'X') if off else None,
+        _ptr(X, torch.float32, 'X'), _ld(X, 'X'), X.shape[0], _xself_ptr(xself, X, off, n_rows, prescaled),
         _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y') if Y is not None else 0,
         n_rows, F, flags, _ptr(bias, torch.float32, 'bias'),
         _ptr(acc_in, torch.float32, 'acc_in'), _ld(acc_in, 'acc_in') if acc_in is not None else 0,
@@ -567,9 +581,13 @@ class ConcatTable:
 
     def __init__(self, tables):
         tables = list(tables)
+        if not tables:
+            raise ValueError("ConcatTable: at least one table expected")
         rows = int(tables[0].shape[0])
-        if not tables or any(t.dim() != 2 or int(t.shape[0]) != rows or t.shape[1] % 4 or t.dtype != torch.float32 for t in tables):
-            raise ValueError("ConcatTable: float32 [rows, w] tables with equal row counts and widths that are multiples of 4 expected")
+        if any(t.dim() != 2 or int(t.shape[0]) != rows or t.dtype != torch.float32 for t in tables):
+            raise ValueError("ConcatTable: float32 [rows, w] tables with equal row counts expected")
+        # the segment-reading kernel moves float4s: tables whose widths are not multiples of 4 are assembled once instead (`chain`)
+        self.in_place = all(int(t.shape[1]) % 4 == 0 for t in tables)
         self.segments = tables
         self.shape = (rows, sum(int(t.shape[1]) for t in tables))
         self.device, self.dtype = tables[0].device, torch.float32
@@ -617,7 +635,7 @@ def chain(A, wpack, dims, acts, out, ids_a=None, base_a=0, B=None, ids_b=None, b
     (amar_chain_indexed_f32: a pair list kept in XCD-affine order, scores back in the caller's order).
     A may be a ConcatTable (per-layer tables read in place: amar_chain_segments_f32)."""
     if isinstance(A, ConcatTable):
-        if B is None and not sum_inputs and out_index is None and chain_segments(A, wpack, dims, acts, out, ids=ids_a, base=base_a):
+        if A.in_place and B is None and not sum_inputs and out_index is None and chain_segments(A, wpack, dims, acts, out, ids=ids_a, base=base_a):
             return
         A = A.materialize()
     P = out.shape[0]

@@ -648,9 +648,16 @@ constexpr int LT_CHUNK = 256;                      // entries per index chunk: 6
 #define LT_PREFETCH 2                              // index chunks in flight per wave ahead of the one being issued
 #endif
 
+// Virtual row v of a tile belongs to wave v % 16; its LDS row is WAVE-MAJOR (round 4): wave * RW + v / 16.  A step's address is then
+// one v_bfe_u32 + one v_lshl_add_u32 on a per-lane constant; rounds 2-3 interleaved the waves' rows with a rotation
+// (l * 16 + (w + l) % 16: five instructions per step).  Bank-wise the two are alike: a wave's rows of a step are random either way.
+#ifndef AMAR_LT_WAVE_MAJOR
+#define AMAR_LT_WAVE_MAJOR 1
+#endif
+template <int RW>
 __device__ __forceinline__ int lt_lds_row(int v) {                    // virtual row -> row of the LDS tile (see lds_tiled.py)
     const int w = v & (LT_WAVES - 1), l = v / LT_WAVES;
-    return l * LT_WAVES + ((w + l) & (LT_WAVES - 1));
+    return AMAR_LT_WAVE_MAJOR ? w * RW + l : l * LT_WAVES + ((w + l) & (LT_WAVES - 1));
 }
 
 // ABL (development, tools/exp_lt.py): 1 = no atomic path, 2 = no LDS read-add-write, 4 = no gathers (timing only: wrong sums)
@@ -700,7 +707,7 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE, AMAR_LT_MIN_WAVES) void spmm_
             const int row = r0 + lr;
             const float as = a.s_self_rows[row];
             const int v0 = a.vstart[row], v1 = lr + 1 < nr ? a.vstart[row + 1] : vt;
-            for (int v = v0; v < v1; ++v) side[lt_lds_row(v)].y = as;
+            for (int v = v0; v < v1; ++v) side[lt_lds_row<RW>(v)].y = as;
         }
         __syncthreads();
     }
@@ -737,8 +744,8 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE, AMAR_LT_MIN_WAVES) void spmm_
     };
     auto accumulate = [&](int slot) {
         const int w = wd[slot];
-        const int lrow = (int)(((unsigned)w >> a.cbits) & LMASK);
-        const int lds_row = lrow * LT_WAVES + ((wave + lrow) & (LT_WAVES - 1));
+        const int lrow = (int)__builtin_amdgcn_ubfe((unsigned)w, (unsigned)a.cbits, (unsigned)lt_bits(RW));   // (w >> cbits) & LMASK as one v_bfe_u32
+        const int lds_row = AMAR_LT_WAVE_MAJOR ? wave * RW + lrow : lrow * LT_WAVES + ((wave + lrow) & (LT_WAVES - 1));
         float *yp = ytile + lds_row * F + 4 * q;
         float4 xv = x[slot];
         if (ABL & 2) {                                                // keep the gathers alive without LDS traffic
@@ -902,7 +909,7 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE, AMAR_LT_MIN_WAVES) void spmm_
                 acc[qq] = make_float4(ws * xs.x, ws * xs.y, ws * xs.z, ws * xs.w);
             }
             for (int v = v0; v < v1; ++v) {
-                const int lv = lt_lds_row(v);
+                const int lv = lt_lds_row<RW>(v);
                 const float *yp = ytile + lv * F;
 #pragma unroll
                 for (int qq = 0; qq < LPN; ++qq) acc[qq] = f4_add(acc[qq], *reinterpret_cast<const float4 *>(yp + 4 * qq));
@@ -943,7 +950,7 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE, AMAR_LT_MIN_WAVES) void spmm_
                 acc[qq] = make_float4(d * xs.x, d * xs.y, d * xs.z, d * xs.w);
             }
             for (int v = v0; v < v1; ++v) {
-                const float *yp = ytile + lt_lds_row(v) * F;
+                const float *yp = ytile + lt_lds_row<RW>(v) * F;
 #pragma unroll
                 for (int qq = 0; qq < LPN; ++qq) acc[qq] = f4_add(acc[qq], *reinterpret_cast<const float4 *>(yp + 4 * qq));
             }
@@ -1034,8 +1041,21 @@ int launch_spmm_lt(const LtArgs &a, int n_tiles, int off32, bool fuse, int varia
             return amar_check_launch();
         }
     }
-    if constexpr (F >= 16) {
+    if constexpr (F >= 8) {
         if (nopairs && off32 != 0) {                                  // an image without implicit pairs: the lean step (see PAIRS above)
+            if constexpr (F == 8) {                                   // development variants of the pair-free F = 8 kernel (tools/exp_lt8.py)
+                if (variant && off32 == 2 && !fuse) {
+                    switch (variant) {
+                    case 2:  AMAR_LT_LAUNCH_P(2, false, 4, 0, 0, false, false); break;      // unpaced
+                    case 3:  AMAR_LT_LAUNCH_P(2, false, 8, 1, 0, false, false); break;      // 7 steps ahead
+                    case 22: AMAR_LT_LAUNCH_P(2, false, 4, 1, 2, false, false); break;      // no LDS update (wrong sums)
+                    case 24: AMAR_LT_LAUNCH_P(2, false, 4, 1, 4, false, false); break;      // no gathers, paced (wrong sums)
+                    case 35: AMAR_LT_LAUNCH_P(2, false, 4, 0, 5, false, false); break;      // no gathers, no atomics, unpaced
+                    default: return AMAR_EINVAL;
+                    }
+                    return amar_check_launch();
+                }
+            }
             static const int uenv = getenv("AMAR_LT_U") ? atoi(getenv("AMAR_LT_U")) : 0;      // development: steps of gathers in flight
             if (uenv == 8 && off32 == 2) {
                 if (fuse) AMAR_LT_LAUNCH_P(2, true, 8, 1, 0, false, false); else AMAR_LT_LAUNCH_P(2, false, 8, 1, 0, false, false);

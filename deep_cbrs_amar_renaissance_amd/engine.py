@@ -152,6 +152,18 @@ def capture_graph(fn):
     return graph, out
 
 
+
+class _RenamedArchive:
+    """An .npz archive seen under other key names (Model.load_weights(name_map=...))."""
+
+    def __init__(self, archive, new_to_old):
+        self._archive, self._map = archive, dict(new_to_old)
+        self.files = list(self._map)
+
+    def __getitem__(self, key):
+        return self._archive[self._map[key]]
+
+
 class Model(Layer):
     """Keras ``Model`` protocol used by the reference driver (experiment.py:155-198)."""
 
@@ -275,11 +287,13 @@ class Model(Layer):
 
     # -- weights export / import -----------------------------------------------------------------
     def keras_variable_names(self):
-        """[(name, parameter)] for every weight, named as Keras names variables of a subclassed model: '<layer name>/<variable>:0',
-        the layer name being Keras' automatic one — the class name in snake_case with a per-class counter in creation order
-        ('dense', 'dense_1', ..., 'gcn_conv', 'gcn_conv_1', 'sequential_gnn').  The reference keeps its trained models through
-        mlflow.tensorflow.autolog() (utilities/utils.py:108); its checkpoints are not available here, so these strings follow
-        Keras' naming rules as documented, not a file of the reference."""
+        """[(name, parameter)] for every weight under a REPO-NATIVE naming scheme in Keras' style: '<layer>/<variable>:0', the layer
+        name being the class name in snake_case with a per-model, per-class counter in creation order ('dense', 'dense_1', ...,
+        'gcn_conv', 'gcn_conv_1', 'sequential_gnn').  These are NOT the keys of a tf.keras checkpoint of the reference: Keras puts the
+        variables of nested subclassed models under nested name scopes ('basic_gcn/basic_rs/sequential/dense/kernel:0') and numbers
+        layers with counters that are global to the session.  The archive matches a model of the same architecture by these names,
+        shapes and order; importing real Keras weights needs a name map (`load_weights(path, name_map=...)`).  The reference keeps its
+        trained models through mlflow.tensorflow.autolog() (utilities/utils.py:108); none of its checkpoints is available here."""
         import re
         counters, out = {}, []
         for module in self.modules():
@@ -298,10 +312,15 @@ class Model(Layer):
         arrays = {name: prm.detach().cpu().numpy() for name, prm in self.keras_variable_names()}
         np.savez(path if str(path).endswith('.npz') else str(path) + '.npz', **arrays)
 
-    def load_weights(self, path):
+    def load_weights(self, path, name_map=None):
         """Read the archive `save_weights` wrote into this model's weights (same architecture: names and shapes must match).
+        `name_map`: {archive key: this model's name} (or a callable key -> name) for archives keyed differently — e.g. arrays exported
+        from a real tf.keras model of the reference, whose variable names carry nested scopes and session-global counters.
         Every weight's version counter moves, so hoisted tables, packed Dense blobs and captured graphs are rebuilt on next use."""
         z = np.load(path if str(path).endswith('.npz') else str(path) + '.npz')
+        if name_map is not None:
+            rename = name_map if callable(name_map) else (lambda k: name_map.get(k, k))
+            z = _RenamedArchive(z, {rename(k): k for k in z.files})
         names = self.keras_variable_names()
         missing = [n for n, _ in names if n not in z.files]
         extra = sorted(set(z.files) - {n for n, _ in names})

@@ -6,20 +6,27 @@ is row-separable, the scoring head is pair-separable.
 
 `TypedPartition`: every node TYPE (users | items [| properties]; one type when the model does not know its split) is cut into
 `world` blocks of equal height, a rank owns one block of each type.  `PartitionedGCNRunner` runs a step on it so that nothing
-passes over the whole node table except the layer-1 prologue:
+passes over the whole node table except the layer-1 prologue, and (round 4) so that the per-layer exchange hides behind compute:
 
-* the table a layer gathers from is made by the PRODUCER of the previous layer from its own rows and all-gathered in a rank-major
-  layout — GCN: H_{l+1} = S (X_l W_{l+1}) straight out of the fused SpMM's epilogue (amar_spmm_lt_f32 / amar_spmm_xs_f32);
-  LightGCN: S X_l; DGCF: X_l sigmoid(w_{l+1}); GraphSAGE: X_l; GAT: X_l W_{l+1} with its neighbour scalars;
-* the ITEM rows of every X_l (all the item tower reads) are gathered on the side, asynchronously: they hide behind the next
-  layer's SpMM and the user tower; 'mean' stacks accumulate on the rank's own rows and gather the items' mean once;
+* the table a layer gathers from is TYPE-MAJOR — [all users | all items | all properties], each type padded to world x its block
+  height — and is made by the PRODUCER of the previous layer from its own rows, one all-gather PER NODE TYPE landing in place
+  (GCN: H_{l+1} = S (X_l W_{l+1}) straight out of the fused SpMM's epilogue; LightGCN: S X_l; DGCF: X_l sigmoid(w_{l+1});
+  GraphSAGE: X_l; GAT: X_l W_{l+1} with its neighbour scalars);
+* a layer runs as one launch per node type (tiles never straddle a type anyway), in an order that alternates from layer to layer:
+  [users, properties | items] then [items | users, properties] ...  The adjacency of a rating graph is bipartite / tripartite —
+  user rows read item columns only, item rows read user and property columns, property rows item columns — so the section a
+  phase produces first is gathered while the layer's other phase runs, and the next layer starts with the phase that needs
+  exactly that section; the rows' own entries (the diagonal of A_hat) are read from the rank's own block, not from the table;
+* the ITEM rows of every X_l (all the item tower reads) are gathered on the side, asynchronously; 'mean' stacks accumulate on
+  the rank's own rows and gather the items' mean once; the last layer skips node types no tower reads (properties);
 * the towers read [X_0 || X_1 || ... ] in place from the per-layer tables (capi.ConcatTable -> amar_chain_segments_f32): the
   user tower over the rank's own users only (pairs follow their user's owner), the item tower over all items; hybrid heads run
   the item-side BERT tower on the rank's own items and gather its output;
-* ids stay the reference's ids: the only remapped index space is the column index of the local CSR block.
+* ids stay the reference's ids: the only remapped index space is the column index of the local CSR blocks.
 
 (Rounds 1-2 split rows into equal-nnz ranges in a padded index space, gathered every layer's own block and re-ran X.W over the
-whole table on every rank: DESIGN.md 6 keeps the numbers.)
+whole table on every rank; round 3 had rank-major tables, one launch per layer and an exposed all-gather between the layers:
+DESIGN.md 6 keeps the numbers.)
 
 ``ops`` is the kernel provider (the ctypes binding by default); tests inject a CPU stand-in to
 exercise the partition / exchange logic under ``gloo`` without a GPU.
@@ -43,9 +50,11 @@ class TypedPartition:
 
     Type t with n_t nodes is cut into `world` contiguous blocks of EQUAL HEIGHT h_t = ceil(n_t / world) (only a type's last
     blocks can be short or empty); rank r owns block r of every type.  A rank's rows, in local order, are
-    [its users | its items | its properties], each padded to h_t rows: R = sum(h_t) rows per rank, and the gathered tables the
-    SpMM reads from are RANK-MAJOR, [world * R, C] — `all_gather_into_tensor` of the ranks' [R, C] blocks lands in place.
-    Node j of type t sits at row  (j' // h_t) * R + off_t + j' % h_t,  j' = j - first id of type t.
+    [its users | its items | its properties], each padded to h_t rows: R = sum(h_t) rows per rank.  The gathered tables the
+    SpMM reads from are TYPE-MAJOR, [world * R, C]: section t = rows [toff_t, toff_t + world * h_t) holds type t in id order
+    (block r of the type at toff_t + r * h_t), so `all_gather_into_tensor` of the ranks' [h_t, C] blocks of ONE type lands in
+    place and a layer's exchange is one collective per node type — each can start as soon as that type's rows are done.
+    Node j of type t sits at row  toff_t + (j - first id of type t).
     Because a type's blocks are equally tall, its rows taken out of the ranks' blocks in rank order ARE the type in id order
     (plus padding at the very end): the all-gather of the item parts of the blocks is the item table in the reference's own
     item order, and a rank's user rows are a contiguous range of user ids — towers and pair ids need no remapping.
@@ -62,72 +71,106 @@ class TypedPartition:
         for h in self.h:
             self.off.append(self.off[-1] + h)
         self.R = self.off[-1]
+        self.toff = [self.world * o for o in self.off]               # first row of every type's section in the gathered tables
 
     def owned(self, rank, t):
         """[lo, hi) of the ids of type t that rank owns (empty when the type ran out before this rank's block)."""
         lo = min(self.tb[t] + rank * self.h[t], self.tb[t + 1])
         return lo, min(lo + self.h[t], self.tb[t + 1])
 
+    def section(self, t):
+        """[lo, hi) of the rows of type t's section in the type-major tables."""
+        return self.toff[t], self.toff[t + 1]
+
+    def block_row0(self, rank, t):
+        """First row of rank's block of type t in the type-major tables."""
+        return self.toff[t] + rank * self.h[t]
+
     def padded_index(self, ids):
-        """Global node ids (int tensor) -> rows of the rank-major [world * R, *] tables."""
+        """Global node ids (int tensor) -> rows of the type-major [world * R, *] tables."""
         ids = ids.to(torch.int64)
         dev = ids.device
         tb = torch.tensor(self.tb, dtype=torch.int64, device=dev)
         t = (torch.searchsorted(tb, ids, right=True) - 1).clamp_(0, self.T - 1)
-        h = torch.tensor(self.h, dtype=torch.int64, device=dev)[t]
-        j = ids - tb[t]
-        return (j // h) * self.R + torch.tensor(self.off[:-1], dtype=torch.int64, device=dev)[t] + j % h
+        return torch.tensor(self.toff[:-1], dtype=torch.int64, device=dev)[t] + ids - tb[t]
 
     def node_of_row(self, device):
-        """int32 [world * R]: the node id held by every row of the rank-major tables, -1 for padding rows."""
+        """int32 [world * R]: the node id held by every row of the type-major tables, -1 for padding rows."""
         out = torch.full((self.world * self.R,), -1, dtype=torch.int32, device=device)
         ids = torch.arange(self.n, device=device)
         out[self.padded_index(ids)] = ids.to(torch.int32)
         return out
 
     def pad_vector(self, v):
-        """[n] per-node vector -> [world * R] in the rank-major layout (padding rows zero)."""
+        """[n] per-node vector -> [world * R] in the type-major layout (padding rows zero)."""
         out = torch.zeros(self.world * self.R, dtype=v.dtype, device=v.device)
         out[self.padded_index(torch.arange(self.n, device=v.device))] = v
         return out
 
-    def local_block(self, a, rank):
-        """The rank's rows of `a` (a square DeviceCSR over the n nodes) as an [R, world * R] DeviceCSR in local row order, column
-        indices in the rank-major layout; carries what the tiled images need of a row block: `diag_offset` (column of local row 0's
-        own entry), `row_breaks` (local rows where the node type changes), and the value-free factors when `a` has them."""
+    def type_of_row(self, rows):
+        """Node type of rows of the type-major tables (int64 tensor -> int64 tensor)."""
+        toff = torch.tensor(self.toff, dtype=torch.int64, device=rows.device)
+        return (torch.searchsorted(toff, rows.to(torch.int64), right=True) - 1).clamp_(0, self.T - 1)
+
+    def local_block(self, a, rank, t):
+        """The rank's rows of node type t of `a` (a square DeviceCSR over the n nodes) as an [h_t, world * R] DeviceCSR, column
+        indices in the type-major layout; carries what the tiled images need of a row block: `diag_offset` (column of row 0's
+        own entry: the block's rows are contiguous in the tables), `active_cols` (columns of the sections it touches: what its
+        entry density is measured against), `reads` (the node types its off-diagonal entries fall in), and the value-free
+        factors when `a` has them."""
         dev = a.rowptr.device
         rp = a.rowptr.to(torch.int64)
-        deg = torch.zeros(self.R, dtype=torch.int64, device=dev)
-        cols, vals, mult = [], [], []
-        for t in range(self.T):
-            lo, hi = self.owned(rank, t)
-            if hi <= lo:
-                continue
-            p0, p1 = int(rp[lo]), int(rp[hi])
-            deg[self.off[t]:self.off[t] + hi - lo] = rp[lo + 1:hi + 1] - rp[lo:hi]
-            cols.append(self.padded_index(a.colidx[p0:p1]).to(torch.int32))
-            if a.vals is not None:
-                vals.append(a.vals[p0:p1])
-            if getattr(a, 'mult', None) is not None:
-                mult.append(a.mult[p0:p1])
-        rowptr = torch.zeros(self.R + 1, dtype=torch.int64, device=dev)
-        rowptr[1:] = torch.cumsum(deg, 0)
+        h = self.h[t]
+        lo, hi = self.owned(rank, t)
+        deg = torch.zeros(h, dtype=torch.int64, device=dev)
         empty = torch.zeros(0, dtype=torch.int32, device=dev)
-        local = DeviceCSR(rowptr.to(torch.int32).contiguous(), torch.cat(cols).contiguous() if cols else empty,
-                          (torch.cat(vals).contiguous() if vals else torch.zeros(0, dtype=torch.float32, device=dev)) if a.vals is not None else None,
-                          (self.R, self.world * self.R), gcn_filtered=a.gcn_filtered)
-        local.diag_offset = rank * self.R
-        local.row_breaks = tuple(self.off[1:-1])
+        cols, vals, mult = empty, None, None
+        if hi > lo:
+            p0, p1 = int(rp[lo]), int(rp[hi])
+            deg[:hi - lo] = rp[lo + 1:hi + 1] - rp[lo:hi]
+            cols = self.padded_index(a.colidx[p0:p1]).to(torch.int32).contiguous()
+            vals = a.vals[p0:p1].contiguous() if a.vals is not None else None
+            mult = a.mult[p0:p1].contiguous() if getattr(a, 'mult', None) is not None else None
+        elif a.vals is not None:
+            vals = torch.zeros(0, dtype=torch.float32, device=dev)
+        rowptr = torch.zeros(h + 1, dtype=torch.int64, device=dev)
+        rowptr[1:] = torch.cumsum(deg, 0)
+        local = DeviceCSR(rowptr.to(torch.int32).contiguous(), cols, vals, (h, self.world * self.R), gcn_filtered=a.gcn_filtered)
+        local.diag_offset = self.block_row0(rank, t)
+        local.row_breaks = ()
+        # the node types the block's OFF-diagonal entries fall in (a rating graph: users -> items, items -> users + properties, ...)
+        rows_of = torch.repeat_interleave(torch.arange(h, device=dev), deg)
+        off_diag = cols.long() != rows_of + local.diag_offset
+        touched = torch.unique(self.type_of_row(cols.long()[off_diag])).tolist() if cols.numel() else []
+        local.reads = tuple(int(x) for x in touched)
+        local.has_diagonal = bool((~off_diag).any()) if cols.numel() else False
+        local.active_cols = max(1, sum(self.toff[x + 1] - self.toff[x] for x in set(local.reads) | {t}))
         if getattr(a, 'dinv', None) is not None and getattr(a, 'mult', None) is not None:
-            local.dinv = self.pad_vector(a.dinv).contiguous()
-            local.mult = torch.cat(mult).contiguous() if mult else empty
+            local.dinv = self._padded_dinv(a)
+            local.mult = mult if mult is not None else empty
         return local
+
+    def _padded_dinv(self, a):
+        cache = self.__dict__.setdefault('_dinv_cache', {})
+        key = id(a)
+        if key not in cache:
+            cache.clear()
+            cache[key] = self.pad_vector(a.dinv).contiguous()
+        return cache[key]
 
     def nnz_imbalance(self, rowptr):
         """max over ranks of the rank's non-zero count / the mean: 1.0 = perfectly balanced."""
         rp = rowptr.to(torch.int64).cpu()
         per = [sum(int(rp[hi] - rp[lo]) for lo, hi in (self.owned(r, t) for t in range(self.T))) for r in range(self.world)]
         return max(per) * self.world / max(1, sum(per))
+
+    def pair_imbalance(self, u_ids):
+        """max over ranks of the pairs a rank scores (pairs follow their user's owner) / the mean."""
+        if u_ids.numel() == 0:
+            return 1.0
+        owner = ((u_ids.to(torch.int64) - self.tb[0]) // self.h[0]).clamp_(0, self.world - 1)
+        per = torch.bincount(owner, minlength=self.world)
+        return float(per.max()) * self.world / float(per.sum())
 
 
 class SharedDeviceCollectives:
@@ -251,15 +294,25 @@ class PartitionedGCNRunner:
         else:                                    # unknown split: one node type; "users" are whoever the pairs name first, "items" every node
             nu, ni, bounds, self.item_type = 0, n, [0, n], 0
         self.part = self.tpart = TypedPartition(bounds, self.world)
-        self.csr = self.tpart.local_block(a, self.rank)
+        self.split_known = known
+        # one row block per node type: a layer runs as one launch per type (tiles never straddle a type anyway)
+        self.blocks = [self.tpart.local_block(a, self.rank, t) for t in range(self.tpart.T)]
+        self.csr = self.blocks[0]                               # (the user block: what tools and tests look at first)
         self.local_rows = sum(hi - lo for lo, hi in (self.tpart.owned(self.rank, t) for t in range(self.tpart.T)))
-        self.local_nnz = self.csr.nnz
+        self.local_nnz = sum(b.nnz for b in self.blocks)
         self.nnz_imbalance = self.tpart.nnz_imbalance(a.rowptr)
+        self.pair_imbalance = self.tpart.pair_imbalance(u_ids) if known else 1.0
+        if self.pair_imbalance > 1.15 and self.rank == 0:
+            import warnings
+            warnings.warn("partitioned run: pairs per rank are unbalanced (max / mean = {:.2f}): user activity follows the user ids; a "
+                          "degree-interleaved relabelling of the users at load time would balance the equal-height blocks".format(self.pair_imbalance))
         self.widths = self.seq.layer_widths()
         dev = u_ids.device
         self.row_ids = self.tpart.node_of_row(dev)
         self.row_ids0 = self.row_ids.clamp(min=0).contiguous()           # (padding rows copy node 0: finite values nobody gathers)
-        self.local_ids0 = self.row_ids0[self.rank * self.tpart.R:(self.rank + 1) * self.tpart.R].contiguous()
+        # the node held by every LOCAL row (users | items | properties of this rank, each padded to its block height)
+        self.local_ids0 = torch.cat([self.row_ids0[self.tpart.block_row0(self.rank, t):self.tpart.block_row0(self.rank, t) + self.tpart.h[t]]
+                                     for t in range(self.tpart.T)]).contiguous()
         # pairs follow their user: the rank scores the pairs of the users it owns, so its user tower reads its own rows only
         self.u_lo, self.u_hi = self.tpart.owned(self.rank, 0)
         self.i_lo, self.n_items = nu, ni
@@ -287,99 +340,160 @@ class PartitionedGCNRunner:
             e.record()
             self._marks.append((name, e))
 
+    # -- the schedule of a layer ------------------------------------------------------------------------------------
+    def phase_order(self, k):
+        """Node types in the order layer k (0-based) runs them.  With a known user / item split the order alternates:
+        even layers [users, properties..., items], odd layers [items, users, properties...] — the section of the next gathered
+        table a layer finishes FIRST is in flight while its other phase runs, and the next layer starts with the phase that reads
+        that section (user and property rows read item columns only, item rows read user and property columns)."""
+        T, item = self.tpart.T, self.item_type
+        if T == 1:
+            return [0]
+        others = [t for t in range(T) if t != item]
+        return others + [item] if k % 2 == 0 else [item] + others
+
+    def needed_types(self, last):
+        """Node types whose rows of a layer anybody reads: all of them feed the next layer; of the LAST layer the towers read
+        users and items only (the 1.1 M property rows of a user-item-property graph at ml1m(s=64) are a quarter of its rows)."""
+        T = self.tpart.T
+        if not last or T == 1 or not self.split_known:
+            return set(range(T))
+        return {0, self.item_type}
+
+    def _wait_sections(self, handles, k, types):
+        """Make the compute stream wait for the all-gathers of table k's sections `types` (each is waited for once)."""
+        for t in types:
+            w = handles.pop((k, t), None)
+            if w is not None:
+                w.wait()
+
     def propagate_typed(self):
         """One propagation on the typed partition.  Returns (x_local, x_items).  'concatenation' stacks (GCN, GraphSAGE, GAT): per
         layer l = 1..L the rank's own [R, C_l] block of X_l (local row order: users | items | properties, each padded to its block
-        height) and the all-gathered item rows [world * h_items, C_l] (the reference's item order; rows past n_items are padding) —
-        X_0 is the node table itself.  'mean' stacks (LightGCN, DGCF): one entry each, the mean over the layers.
-        Every kind follows the same scheme: a rank-major table T_l [world * R, C] the next layer gathers from, made by the PRODUCER
+        height; the last layer's property rows are not computed: nobody reads them) and the all-gathered item rows
+        [world * h_items, C_l] (the reference's item order; rows past n_items are padding) — X_0 is the node table itself.
+        'mean' stacks (LightGCN, DGCF): one entry each, the mean over the layers.
+        Every kind follows the same scheme: a type-major table T_l [world * R, C] the next layer gathers from, made by the PRODUCER
         from its own rows of X_l (GCN: S (X_l W_{l+1}) in the SpMM epilogue; LightGCN: S X_l; DGCF: X_l sigmoid(w_{l+1}); GraphSAGE:
-        X_l; GAT: X_l W_{l+1} and its neighbour scalars) and all-gathered — no rank passes over the whole table after the prologue."""
+        X_l; GAT: X_l W_{l+1} and its neighbour scalars), one all-gather per node type issued as soon as the type's launch is
+        enqueued and waited for by the first launch of the next layer that reads that section."""
         ops, tp, dev = self.ops, self.tpart, self.seq.embeddings.device
         layers, widths = list(self.seq.seq_layers), self.widths
-        n_tab, R, lo = self.world * tp.R, tp.R, self.rank * tp.R
+        n_tab, R = self.world * tp.R, tp.R
         emb = self.seq.embeddings.detach()
-        i0, hi_ = tp.off[self.item_type], tp.h[self.item_type]
-        x_local, x_items, pending = [], [], []
+        item = self.item_type
+        i0, hi_ = tp.off[item], tp.h[item]
+        x_local, x_items, pending, handles = [], [], [], {}
+        n_l = len(layers)
+        rows_of = [slice(tp.off[t], tp.off[t] + tp.h[t]) for t in range(tp.T)]           # a type's rows in the local [R, *] buffers
+        sect_of = [slice(*tp.section(t)) for t in range(tp.T)]                            # ... its section of a gathered table
+        own_of = [slice(tp.block_row0(self.rank, t), tp.block_row0(self.rank, t) + tp.h[t]) for t in range(tp.T)]
 
         def gather_items(key, block):                                   # the item rows of a local [R, C] block, behind the next kernels
             xi = self._buffer(('xi', key), (self.world * hi_, block.shape[1]))
             pending.append(self._gather(xi, block[i0:i0 + hi_], defer=True))
             x_items.append(xi)
 
-        def gather_table(key, block):                                    # a local [R, ...] block -> the rank-major table every rank reads
-            full = self._buffer(('t', key), (n_tab,) + tuple(block.shape[1:]))
-            self._gather(full, block)
-            return full
+        def gather_section(k, t, table, block):                        # type t's rows of a local [R, ...] block -> its section of table k
+            handles[(k, t)] = self._gather(table[sect_of[t]], block[rows_of[t]], defer=True)
+
+        def reads_of(t, own_landed):
+            """Sections of the gathered table a launch over type t's rows reads: where its off-diagonal entries fall, plus its own
+            section unless the launch takes the rows' own entries from the rank's own block (`xself`)."""
+            r = set(self.blocks[t].reads)
+            if own_landed:
+                r.add(t)
+            return r
 
         if self.kind == 'gcn':
             tiled = [self._use_xs(w) for w in widths[1:]]
-            images = [self.csr.tiled_image(w) if t else None for w, t in zip(widths[1:], tiled)]
-            pre = all(tiled) and all(im.row_scale is not None for im in images)   # the chain of gathered tables stays pre-scaled by d^-1/2
+            images = [[self.blocks[t].tiled_image(w) if use else None for t in range(tp.T)] for w, use in zip(widths[1:], tiled)]
+            pre = all(tiled) and all(im.row_scale is not None for ims in images for im in ims)   # the chain of gathered tables stays pre-scaled by d^-1/2
             h = self._buffer(('t', 0), (n_tab, widths[1]))
-            ops.rowwise_xw(emb, layers[0].kernel, h, row_ids=self.row_ids, row_scale=images[0].col_scale if pre else None)
+            ops.rowwise_xw(emb, layers[0].kernel, h, row_ids=self.row_ids, row_scale=images[0][0].col_scale if pre else None)
             self._mark('prologue')
+            hl_prev = None
             for k, layer in enumerate(layers):
-                nxt = layers[k + 1] if k + 1 < len(layers) else None
+                last = k == n_l - 1
+                nxt = layers[k + 1] if not last else None
                 y = self._buffer(('y', k), (R, widths[k + 1]), zero=True)
                 hn = self._buffer(('hl', k + 1), (R, widths[k + 2]), zero=True) if nxt is not None else None
-                if tiled[k]:
-                    ops.spmm_xs(images[k], h, y, bias=layer.bias, relu=True, Wnext=nxt.kernel if nxt is not None else None, Hnext=hn,
-                                prescaled=pre, scale_next=pre and nxt is not None)
-                else:
-                    ops.gcn_layer(self.csr.rowptr, self.csr.colidx, self.csr.vals, h, layer.bias, y,
-                                  Wnext=nxt.kernel if nxt is not None else None, Hnext=hn)
-                self._mark('spmm')
-                wait_h = None
-                if nxt is not None:
-                    h = self._buffer(('t', k + 1), (n_tab, widths[k + 2]))
-                    wait_h = self._gather(h, hn, defer=True)
-                gather_items(k, y)
-                if wait_h is not None:
-                    wait_h.wait()
-                self._mark('exchange')
+                h_next = self._buffer(('t', k + 1), (n_tab, widths[k + 2])) if nxt is not None else None
+                need = self.needed_types(last)
+                for t in self.phase_order(k):
+                    if t not in need:
+                        continue
+                    blk, rs = self.blocks[t], rows_of[t]
+                    own_local = tiled[k] and pre and hl_prev is not None          # the diagonal term from the rank's own block of H_k
+                    if k > 0:
+                        self._wait_sections(handles, k, reads_of(t, not own_local and blk.has_diagonal))
+                        self._mark('exchange')
+                    if tiled[k]:
+                        ops.spmm_xs(images[k][t], h, y[rs], bias=layer.bias, relu=True, Wnext=nxt.kernel if nxt is not None else None,
+                                    Hnext=hn[rs] if hn is not None else None, prescaled=pre, scale_next=pre and nxt is not None,
+                                    xself=hl_prev[rs] if own_local else None)
+                    else:
+                        ops.gcn_layer(blk.rowptr, blk.colidx, blk.vals, h, layer.bias, y[rs],
+                                      Wnext=nxt.kernel if nxt is not None else None, Hnext=hn[rs] if hn is not None else None)
+                    self._mark('spmm')
+                    if nxt is not None:
+                        gather_section(k + 1, t, h_next, hn)
+                    if t == item:
+                        gather_items(k, y)
+                    self._mark('exchange')
+                if k > 0:
+                    self._wait_sections(handles, k, range(tp.T))                  # (sections nobody read: drained before the table is reused)
+                h, hl_prev = h_next, hn
                 x_local.append(y)
 
         elif self.kind in ('lightgcn', 'dgcf'):
             d = widths[0]
             tiled = self._use_xs(d)
-            image = self.csr.tiled_image(d) if tiled else None
-            value_free = image is not None and image.row_scale is not None
-            t = self._buffer(('t', 0), (n_tab, d))
+            images = [self.blocks[t].tiled_image(d) if tiled else None for t in range(tp.T)]
+            value_free = tiled and all(im.row_scale is not None for im in images)
+            tab = self._buffer(('t', 0), (n_tab, d))
             if self.kind == 'dgcf':                                      # layer 1 gathers X_0 . sigmoid(w_1)
                 gated = self._buffer(('g0',), (emb.shape[0], d))
                 ops.locality_scale(emb, layers[0].w.detach().view(-1), gated)
-                ops.copy_columns(gated, t, ids=self.row_ids0)
+                ops.copy_columns(gated, tab, ids=self.row_ids0)
             elif value_free:                                             # ... S X_0 (the identity kernel keeps the bits of X_0)
-                ops.rowwise_xw(emb, self._identity(d, dev), t, row_ids=self.row_ids, row_scale=image.col_scale)
+                ops.rowwise_xw(emb, self._identity(d, dev), tab, row_ids=self.row_ids, row_scale=images[0].col_scale)
             else:
-                ops.copy_columns(emb, t, ids=self.row_ids0)
+                ops.copy_columns(emb, tab, ids=self.row_ids0)
             acc = self._buffer(('acc', 0), (R, d))
             ops.copy_columns(emb, acc, ids=self.local_ids0)              # the running sum starts at the rank's own rows of X_0
             self._mark('prologue')
-            n_l = len(layers)
             for k, layer in enumerate(layers):
                 last = k == n_l - 1
                 y = None if last else self._buffer(('y', k), (R, d), zero=True)
                 acc_out = self._buffer(('acc', k + 1), (R, d))
-                kw = dict(acc_in=acc, acc_out=acc_out, acc_div=n_l + 1 if last else None)
-                if tiled:
-                    ops.spmm_xs(image, t, y, prescaled=value_free, **kw)
-                else:
-                    ops.spmm_csr(self.csr.rowptr, self.csr.colidx, self.csr.vals, t, y, **kw)
-                acc = acc_out
-                self._mark('spmm')
-                if not last:
-                    if self.kind == 'dgcf':
-                        nxt_local = self._buffer(('tl', k + 1), (R, d))
-                        ops.locality_scale(y, self._gate_local(k + 1, layers[k + 1]), nxt_local)
-                    elif value_free:
-                        nxt_local = self._buffer(('tl', k + 1), (R, d))
-                        ops.row_affine(y, image.row_scale, nxt_local)
+                nxt_local = None if last else (self._buffer(('tl', k + 1), (R, d)) if (self.kind == 'dgcf' or value_free) else y)
+                tab_next = None if last else self._buffer(('t', k + 1), (n_tab, d))
+                gate = self._gate_local(k + 1, layers[k + 1]) if (self.kind == 'dgcf' and not last) else None
+                need = self.needed_types(last)
+                for t in self.phase_order(k):
+                    if t not in need:
+                        continue
+                    blk, rs = self.blocks[t], rows_of[t]
+                    if k > 0:
+                        self._wait_sections(handles, k, reads_of(t, True))
+                        self._mark('exchange')
+                    kw = dict(acc_in=acc[rs], acc_out=acc_out[rs], acc_div=n_l + 1 if last else None)
+                    if tiled:
+                        ops.spmm_xs(images[t], tab, y[rs] if y is not None else None, prescaled=value_free, **kw)
                     else:
-                        nxt_local = y
-                    t = gather_table(k + 1, nxt_local)
-                    self._mark('exchange')
+                        ops.spmm_csr(blk.rowptr, blk.colidx, blk.vals, tab, y[rs] if y is not None else None, **kw)
+                    self._mark('spmm')
+                    if not last:
+                        if self.kind == 'dgcf':
+                            ops.locality_scale(y[rs], gate[rs], nxt_local[rs])
+                        elif value_free:
+                            ops.row_affine(y[rs], images[t].row_scale, nxt_local[rs])
+                        gather_section(k + 1, t, tab_next, nxt_local)
+                        self._mark('exchange')
+                if k > 0:
+                    self._wait_sections(handles, k, range(tp.T))
+                acc, tab = acc_out, tab_next
             gather_items('mean', acc)
             self._mark('exchange')
             x_local.append(acc)
@@ -387,54 +501,74 @@ class PartitionedGCNRunner:
         else:                                                            # GraphSAGE / GAT: edge-list graphs, layers gather X_l (GAT: X_l W)
             x0 = self._buffer(('t', 0), (n_tab, widths[0]))
             ops.copy_columns(emb, x0, ids=self.row_ids0)
-            t = x0
+            tab = x0
             if self.kind == 'gat':
                 l0, c = layers[0], widths[1]
-                t = self._buffer(('h', 0), (n_tab, c))
+                tab = self._buffer(('h', 0), (n_tab, c))
                 s_self, s_neigh = self._buffer(('ss', 0), (n_tab,)), self._buffer(('sn', 0), (n_tab,))
-                ops.rowwise_xw(x0, l0.kernel.view(-1, c), t, a_self=l0.attn_kernel_self.view(c), a_neigh=l0.attn_kernel_neighs.view(c),
+                ops.rowwise_xw(x0, l0.kernel.view(-1, c), tab, a_self=l0.attn_kernel_self.view(c), a_neigh=l0.attn_kernel_neighs.view(c),
                                s_self=s_self, s_neigh=s_neigh)
             self._mark('prologue')
             for k, layer in enumerate(layers):
                 f, c = widths[k], widths[k + 1]
-                last = k == len(layers) - 1
+                last = k == n_l - 1
                 y = self._buffer(('y', k), (R, c), zero=True)
-                if self.kind == 'sage':
-                    agg = self._buffer(('agg', k), (R, f))
-                    ops.spmm_xs(self.csr.tiled_mean_image(f, layer.self_loops), t, agg, prescaled=True)
-                    if ops.sage_tail_supported(f, c):
-                        ops.sage_tail(t[lo:lo + R], agg, layer.kernel, layer.bias, y)
-                    else:
-                        xa = self._buffer(('xa', k), (R, 2 * f))
-                        ops.copy_columns(t[lo:lo + R], xa[:, :f])
-                        ops.copy_columns(agg, xa[:, f:])
-                        z = self._buffer(('z', k), (R, c))
-                        ops.dense(xa, layer.kernel, layer.bias, z, act=None)
-                        nrm, inv = self._buffer(('nrm', k), (R, c)), self._buffer(('inv', k), (R,))
-                        ops.l2norm_fwd(z, nrm, inv, y, act='relu')
-                else:
-                    lt = self.csr.tiled_gat_image(c)
-                    if lt is not None:
-                        ops.gat_lt(lt, self.csr, t, s_self, s_neigh, layer.bias, y, self_loop=layer.add_self_loops)
-                    else:
-                        ops.gat_xs(self.csr.xcd_sliced(), t, s_self, s_neigh, layer.bias, y, self_loop=layer.add_self_loops)
-                self._mark('spmm')
-                gather_items(k, y)
+                need = self.needed_types(last)
                 if not last:
                     if self.kind == 'sage':
-                        t = gather_table(k + 1, y)
+                        tab_next = self._buffer(('t', k + 1), (n_tab, c))
                     else:                                                # the producer's X_l . W_{l+1} and attention scalars, own rows only
                         nxt, c2 = layers[k + 1], widths[k + 2]
+                        tab_next = self._buffer(('h', k + 1), (n_tab, c2))
                         h_local = self._buffer(('hl', k + 1), (R, c2))
-                        s_self = self._buffer(('ss', k + 1), (n_tab,), zero=True)
+                        ss_next = self._buffer(('ss', k + 1), (n_tab,), zero=True)
+                        sn_next = self._buffer(('sn', k + 1), (n_tab,))
                         sn_local = self._buffer(('snl', k + 1), (R,))
-                        ops.rowwise_xw(y, nxt.kernel.view(-1, c2), h_local, a_self=nxt.attn_kernel_self.view(c2),
-                                       a_neigh=nxt.attn_kernel_neighs.view(c2), s_self=s_self[lo:lo + R], s_neigh=sn_local)
-                        t = gather_table(('h', k + 1), h_local)
-                        s_neigh = gather_table(('sn', k + 1), sn_local)
-                self._mark('exchange')
+                if k > 0:                                                # (these kinds read their own rows from the table, and GAT reduces s_neigh over
+                    self._wait_sections(handles, k, range(tp.T))         #  all of it: every section of table k lands before the layer starts)
+                    self._wait_sections(handles, ('sn', k), range(tp.T))
+                    self._mark('exchange')
+                for t in self.phase_order(k):
+                    if t not in need:
+                        continue
+                    blk, rs, own = self.blocks[t], rows_of[t], own_of[t]
+                    if self.kind == 'sage':
+                        agg = self._buffer(('agg', k), (R, f))
+                        ops.spmm_xs(blk.tiled_mean_image(f, layer.self_loops), tab, agg[rs], prescaled=True)
+                        if ops.sage_tail_supported(f, c):
+                            ops.sage_tail(tab[own], agg[rs], layer.kernel, layer.bias, y[rs])
+                        else:
+                            xa = self._buffer(('xa', k), (R, 2 * f))
+                            ops.copy_columns(tab[own], xa[rs][:, :f])
+                            ops.copy_columns(agg[rs], xa[rs][:, f:])
+                            z = self._buffer(('z', k), (R, c))
+                            ops.dense(xa[rs], layer.kernel, layer.bias, z[rs], act=None)
+                            nrm, inv = self._buffer(('nrm', k), (R, c)), self._buffer(('inv', k), (R,))
+                            ops.l2norm_fwd(z[rs], nrm[rs], inv[rs], y[rs], act='relu')
+                    else:
+                        lt = blk.tiled_gat_image(c)
+                        if lt is not None:
+                            ops.gat_lt(lt, blk, tab, s_self, s_neigh, layer.bias, y[rs], self_loop=layer.add_self_loops)
+                        else:
+                            ops.gat_xs(blk.xcd_sliced(), tab, s_self, s_neigh, layer.bias, y[rs], self_loop=layer.add_self_loops)
+                    self._mark('spmm')
+                    if t == item:
+                        gather_items(k, y)
+                    if not last:
+                        if self.kind == 'sage':
+                            gather_section(k + 1, t, tab_next, y)
+                        else:
+                            ops.rowwise_xw(y[rs], nxt.kernel.view(-1, c2), h_local[rs], a_self=nxt.attn_kernel_self.view(c2),
+                                           a_neigh=nxt.attn_kernel_neighs.view(c2), s_self=ss_next[own], s_neigh=sn_local[rs])
+                            gather_section(k + 1, t, tab_next, h_local)
+                            handles[(('sn', k + 1), t)] = self._gather(sn_next[sect_of[t]], sn_local[rs], defer=True)
+                    self._mark('exchange')
+                if not last:
+                    tab = tab_next
+                    if self.kind == 'gat':
+                        s_self, s_neigh = ss_next, sn_next
                 x_local.append(y)
-        self._pending = [w for w in pending if w is not None]
+        self._pending = [w for w in pending if w is not None] + [w for w in handles.values() if w is not None]
         return x_local, x_items
 
     def _identity(self, d, dev):
@@ -477,7 +611,8 @@ class PartitionedGCNRunner:
         self._marks = []
         self._mark('start')
         ib_wait = ib_full = None
-        if self.hybrid and os.environ.get('AMAR_HYBRID_ITEM_TOWER', 'sharded') == 'sharded':      # (every rank takes part: it is a collective)
+        # (a model that does not know its user / item split has ONE node type: no item blocks to shard the tower over — replicated)
+        if self.hybrid and self.split_known and os.environ.get('AMAR_HYBRID_ITEM_TOWER', 'sharded') == 'sharded':      # (every rank takes part: it is a collective)
             if self.model.bert_table is None:
                 raise ValueError("the hybrid model needs its BERT table registered (set_bert_table) for the partitioned run")
             if not self.model.rs.built:
@@ -593,8 +728,9 @@ class PartitionedGCNRunner:
         return None if ph is None else ph['prologue_ms'] + ph['local_spmm_ms'] + ph['exchange_ms']
 
     def describe(self):
-        return ('node-range partition over {} GPUs (equal-height blocks per node type, nnz imbalance {:.3f}), per layer one RCCL all-gather of '
-                'the next gathered table + one of the item rows, pairs sharded by the same user ranges').format(self.world, self.nnz_imbalance)
+        return ('node-range partition over {} GPUs (equal-height blocks per node type, nnz imbalance {:.3f}, pair imbalance {:.3f}), per layer one '
+                'launch and one RCCL all-gather per node type (the next gathered table, type-major) + one of the item rows, in flight behind the '
+                'other types\' launches; pairs sharded by the same user ranges').format(self.world, self.nnz_imbalance, self.pair_imbalance)
 
 
 def make_runner(model, u_ids, i_ids, rank=0, world=1, dist=None):

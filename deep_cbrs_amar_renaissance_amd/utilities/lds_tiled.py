@@ -73,6 +73,57 @@ def _run_starts(first, idx):
     return starts[torch.searchsorted(starts, idx, right=True) - 1]
 
 
+def _spread_repeats(dest, lrow_s, tw_s, stream_start, cnt_tw, eps, rw, total, passes):
+    """Round 4: move the REPEATS of a virtual row inside a step (what an image without pairs sends to the LDS-atomic path: 4 % of
+    the entries of ml1m(s=64) with single-step windows) one to three steps down the wave's stream, each trading places with the
+    entry in its slot there — if neither then repeats a row of its new step.  The walk stays in column order to within three
+    steps of a wave for a few per cent of its entries; whatever still collides afterwards is flagged as before (the flags are
+    taken from the final positions, so the result never depends on this heuristic)."""
+    m = int(dest.numel())
+    if m < 2 or passes <= 0:
+        return dest
+    dev = dest.device
+    idx = torch.arange(m, device=dev)
+    stream_end = (stream_start + cnt_tw)[tw_s]                         # first position past the real entries of the entry's stream
+    for p in range(passes):
+        key = (dest // eps) * rw + lrow_s
+        o = torch.argsort(key * eps + dest % eps)
+        ko = key[o]
+        first = torch.ones(m, dtype=torch.bool, device=dev)
+        first[1:] = ko[1:] != ko[:-1]
+        rank_o = idx - _run_starts(first, idx)
+        sel = torch.nonzero(rank_o >= 1).view(-1)
+        if sel.numel() == 0:
+            break
+        e, r = o[sel], rank_o[sel]
+        is_mover = torch.zeros(m, dtype=torch.bool, device=dev)
+        is_mover[e] = True
+        pp = dest[e] + ((r - 1 + p) % 3 + 1) * eps
+        ok = pp < stream_end[e]
+        e, pp = e[ok], pp[ok]
+        inv = torch.full((total,), -1, dtype=torch.int64, device=dev)
+        inv[dest] = idx
+        pe = inv[pp]
+
+        def present(k):
+            i = torch.searchsorted(ko, k).clamp_(max=m - 1)
+            return ko[i] == k
+        ok = (pe >= 0) & ~is_mover[pe.clamp(min=0)]
+        ok &= ~present((pp // eps) * rw + lrow_s[e]) & ~present((dest[e] // eps) * rw + lrow_s[pe.clamp(min=0)])
+        e, pp, pe = e[ok], pp[ok], pe[ok]
+        if e.numel() == 0:
+            continue
+        so = torch.argsort(pp)                                        # one mover per target position
+        pps = pp[so]
+        keep = torch.ones(pps.numel(), dtype=torch.bool, device=dev)
+        keep[1:] = pps[1:] != pps[:-1]
+        e, pp, pe = e[so][keep], pps[keep], pe[so][keep]
+        back = dest[e].clone()
+        dest[e] = pp
+        dest[pe] = back
+    return dest
+
+
 def supported(F, n_cols, rw=None):
     return F in (4, 8, 16, 32) and n_cols <= (1 << geometry(F, rw)[2])
 
@@ -101,13 +152,20 @@ class LdsTiled:
 
     @classmethod
     def build(cls, rows, cols, n_rows, n_cols, F, diag, row_scale, col_scale, diag_offset=0, window_entries=None, n_cu=N_CU,
-              split=SPLIT, balance=True, row_breaks=(), rw=None, split_growth=2.0, pairs=None):
+              split=SPLIT, balance=True, row_breaks=(), rw=None, split_growth=2.0, pairs=None, layout=None, sub_window=None, spread=None):
         """`rows`/`cols`: int64 device tensors of the unit-weight off-diagonal entries (multiplicities expanded).
         `rw`: LDS rows per wave when the tile is smaller than the plain sum's (GAT mode); `split_growth`: factor by which the
         virtual-row length grows while the tiles do not fit the LDS (longer virtual rows repeat more often inside a step).
         `pairs`: whether the repeat in the slot right after a row's first entry of a step is left to the kernel's in-register
         pair (default: F < 16 — at 8 entries per step such repeats are 0.1 % of the entries and the pair logic a third of a step's
         instructions; AMAR_LT_PAIRS=0|1 overrides).  An image without pairs runs with AMAR_SPMM_LT_NOPAIRS.
+        `layout`: how a (wave, window) list is laid out over its steps.  'deal' (rounds 2-3): sorted by virtual row and dealt
+        slot-major over the steps the list covers, so that a row's repeats land in different steps.  'defer' (round 4): the list
+        keeps COLUMN order at the granularity of `sub_window` entries of the tile, and only the REPEATS of a virtual row inside
+        the list are moved — the k-th occurrence of a row goes behind all (k-1)-th occurrences — so that a window can span several
+        steps per wave (one barrier per window, few repeats inside a step: no implicit pairs needed) while the entries of a step
+        still come from one sub-window's column range (what keeps the L1 footprint of a step small).
+        `spread`: passes of `_spread_repeats` over the finished layout (images without pairs).
         `row_breaks`: rows at which a tile must end (node-type boundaries of a bipartite / tripartite graph with grouped ids:
         a tile that straddles one walks two column ranges at half the density each and runs ~25 % longer than its peers)."""
         dev = rows.device
@@ -269,10 +327,48 @@ class LdsTiled:
         # c. order inside a (tile, wave, window) list: by virtual row; then deal the list's entries to its stream positions
         #    slot-major over the steps the list covers, so that neighbours (same virtual row) land in different steps
         tw = tile * W + wave
+        if layout is None:
+            layout = os.environ.get('AMAR_LT_LAYOUT', 'deal')
+        if layout == 'count':
+            # windows by COUNT (round 4): window k of a wave = entries [k, k + 1) * S * EPS of the wave's OWN stream in column order,
+            # S = window_entries / (W * EPS) steps — every wave runs exactly S steps between two barriers.  With windows cut by
+            # column (the other layouts) a wave holds 32 S +- 6 sqrt(S) entries of a window, i.e. S - 1, S or S + 1 steps, and the
+            # barrier waits for the slowest: with the gathers compiled out that alone took the walk from 0.126 to 0.180 ms per
+            # ml1m(s=64) layer.  The price: the waves' column positions drift apart like a random walk (+- sqrt(k) * 6 entries after k
+            # steps: a few windows over a 2 300-row tile), which the L1 sharing has to bear.
+            spw = max(1, window_entries // (W * eps)) * eps          # entries per wave and window
+            o = torch.argsort(tw * n_cols + cols)
+            cnt_s = torch.bincount(tw, minlength=T * W)
+            start_s = torch.cumsum(cnt_s, 0) - cnt_s
+            win = torch.empty(m, dtype=torch.int64, device=dev)
+            win[o] = (idx - start_s[tw[o]]) // spw
+            del o
+            n_win = ((cnt_s + spw - 1) // spw).view(T, W).max(1).values if T else n_win
+            maxwin = max(1, int(n_win.max())) if T else 1
+            layout = 'deal'
         lst = tw * maxwin + win
         if T * W * maxwin * rw >= (1 << 62):
             raise ValueError("LT image: sort key overflow")
-        order = torch.argsort(lst * rw + lrow)
+        defer = layout == 'defer'
+        if defer:
+            sub_window = int(sub_window or os.environ.get('AMAR_LT_SUB_WINDOW', 0) or W * eps)
+            n_sub = max(1, -(-window_entries // sub_window))
+            o1 = torch.argsort(tile * n_cols + cols)                   # (column position inside the tile) // sub_window
+            sw = torch.empty(m, dtype=torch.int64, device=dev)
+            sw[o1] = ((idx - tile_start[tile[o1]]) % window_entries) // sub_window
+            del o1
+            o2 = torch.argsort((lst * rw + lrow) * n_sub + sw)         # occurrence number of the virtual row inside its list
+            k2 = (lst * rw + lrow)[o2]
+            first2 = torch.ones(m, dtype=torch.bool, device=dev)
+            if m > 1:
+                first2[1:] = k2[1:] != k2[:-1]
+            occ = torch.empty(m, dtype=torch.int64, device=dev)
+            occ[o2] = (idx - _run_starts(first2, idx)).clamp_(max=1023)
+            del o2, k2, first2
+            order = torch.argsort(((lst * 1024 + occ) * n_sub + sw) * rw + lrow)
+            del occ, sw
+        else:
+            order = torch.argsort(lst * rw + lrow)
         cnt_tw = torch.bincount(tw, minlength=T * W)
         len_tw = (cnt_tw + CHUNK - 1) // CHUNK * CHUNK
         stream_start = torch.cumsum(len_tw, 0) - len_tw
@@ -283,10 +379,18 @@ class LdsTiled:
         tw_s = tw[order]
         rel = idx - cnt_start[tw_s]                                   # position inside the (tile, wave) stream, list after list
         lst_s = lst[order]
-        deal = torch.argsort((lst_s * eps + rel % eps) * (int(len_tw.max()) // eps + 1) + rel // eps)
-        dest = stream_start[tw_s] + rel[deal]                         # i-th entry of the sorted order takes the i-th dealt position
-        del deal, rel
+        if defer:
+            dest = stream_start[tw_s] + rel                           # the sorted order IS the stream order
+        else:
+            deal = torch.argsort((lst_s * eps + rel % eps) * (int(len_tw.max()) // eps + 1) + rel // eps)
+            dest = stream_start[tw_s] + rel[deal]                     # i-th entry of the sorted order takes the i-th dealt position
+            del deal
+        del rel
         lrow_s = lrow[order]
+        if spread is None:
+            spread = int(os.environ.get('AMAR_LT_SPREAD', 0))
+        if spread:
+            dest = _spread_repeats(dest, lrow_s, tw_s, stream_start, cnt_tw, eps, rw, total, int(spread))
         word = (lrow_s << cbits) | cols[order]
         # d. inside every step: the first entry of a virtual row is plain; the one in the next slot (same DPP row) is an implicit
         #    pair; every other repeat is flagged

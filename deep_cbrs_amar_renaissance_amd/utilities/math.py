@@ -249,7 +249,7 @@ def _edge_list_lt_density(a, F):
     forced = os.environ.get('AMAR_SPMM_LT')
     if forced == '0' or not lds_tiled.supported(F, a.shape[1]):
         return False
-    return forced == '1' or a.nnz >= LT_MIN_DENSITY * lds_tiled.N_CU * a.shape[1]
+    return forced == '1' or a.nnz >= LT_MIN_DENSITY * lds_tiled.N_CU * getattr(a, 'active_cols', a.shape[1])
 
 
 def _csr_sliced(self, F):
@@ -452,7 +452,7 @@ def lt_eligible(a, F):
         return False
     if forced == '1':
         return True
-    return F in (8, 16, 32) and a.nnz >= LT_MIN_DENSITY * lds_tiled.N_CU * a.shape[1]
+    return F in (8, 16, 32) and a.nnz >= LT_MIN_DENSITY * lds_tiled.N_CU * getattr(a, 'active_cols', a.shape[1])
 
 
 def infer_row_breaks(rows, cols, n):
@@ -490,7 +490,7 @@ def _csr_tiled_mean_image(self, F, self_loops=True):
     from deep_cbrs_amar_renaissance_amd.utilities import lds_tiled
     forced = os.environ.get('AMAR_SPMM_LT')
     ok = forced != '0' and self.vals is None and lds_tiled.supported(F, self.shape[1]) and \
-        (forced == '1' or (F in (8, 16, 32) and self.nnz >= LT_MIN_DENSITY * lds_tiled.N_CU * self.shape[1]))
+        (forced == '1' or (F in (8, 16, 32) and self.nnz >= LT_MIN_DENSITY * lds_tiled.N_CU * getattr(self, 'active_cols', self.shape[1])))
     if not ok:
         return self.xcd_sliced_mean(self_loops)
     cache = self.__dict__.setdefault('_lt_mean_cache', {})
@@ -520,7 +520,7 @@ def _csr_tiled_gat_image(self, C):
     forced = os.environ.get('AMAR_SPMM_LT')
     rw = lds_tiled.GAT_ROWS_PER_WAVE.get(C)
     ok = forced != '0' and self.vals is None and rw is not None and lds_tiled.supported(C, self.shape[1], rw) and \
-        (forced == '1' or self.nnz >= LT_MIN_DENSITY * lds_tiled.N_CU * self.shape[1])
+        (forced == '1' or self.nnz >= LT_MIN_DENSITY * lds_tiled.N_CU * getattr(self, 'active_cols', self.shape[1]))
     if not ok:
         return None
     cache = self.__dict__.setdefault('_lt_gat_cache', {})

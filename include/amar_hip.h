@@ -225,7 +225,11 @@ int amar_dense_f32(const float *X, int64_t ldx, const int32_t *ids,
  * the wide layers of the content towers (768 -> 256 of src/models/hybrid.py:52-58).  K % 32 == 0, N % 128 == 0, ldx % 4 == 0,
  * 16-byte aligned X; other shapes return AMAR_EUNSUPPORTED (use amar_dense_f32).  Wq is the layer's kernel pre-split by
  * amar_dense_split_pack_f32 (HOST in, HOST out of amar_dense_split_bytes(K, N) bytes — once per weight update), copied to
- * the device by the caller. */
+ * the device by the caller.
+ * PRECONDITION: finite inputs.  The split x = hi + mid + lo is exact for finite x only; an infinite activation or weight gives
+ * mid = Inf - Inf = NaN, so a product that the f32 instruction would return as +-Inf (or saturate) comes back NaN here.  NaN
+ * inputs propagate as NaN in both forms.  The same holds for the split-product forms of amar_chain_f32 / amar_dual_chain_f32
+ * (the default of the pair stages; AMAR_PAIR_MFMA=f32 / AMAR_DENSE_SPLIT=0 select the f32 instruction). */
 int64_t amar_dense_split_bytes(int32_t K, int32_t N);
 int amar_dense_split_pack_f32(const float *W, int32_t K, int32_t N, void *out);
 int amar_dense_split_f32(const float *X, int64_t ldx, const int32_t *ids, const void *Wq, const float *bias,

@@ -75,6 +75,53 @@ def test_full_size_spmm_properties(hip, big, monkeypatch):
         assert np.abs(ax_xs[r].double().cpu().numpy() - want).max() <= 1e-5 * max(1e-3, np.abs(want).max())
 
 
+def test_full_size_headline_layer_on_the_lds_tiled_walk(hip, big):
+    """The HEADLINE kernel at the headline size: `spmm_lt_kernel<8>` on the image `tiled_image(8)` dispatches to at ml1m(s=64) — the
+    F = 8 layers of econfigs/basic-gnn.yaml grid1, what bench.py's `roofline` object times — as the plain product and as the fused
+    GCN layer (bias, ReLU, concat-slice store, next layer's X.W pre-scaled), against the row-streaming CSR kernel, the eigenvector
+    of A_hat, 300 sampled rows in float64, run-to-run bit reproducibility, and the un-fused sequence of the epilogue."""
+    a, n = big['a'], big['n']
+    dev = a.rowptr.device
+    F = 8
+    lt = a.tiled_image(F)
+    assert hasattr(lt, 'words'), "ml1m(s=64), F = 8 must dispatch to the LDS-tiled image"
+    g = torch.Generator(device=dev); g.manual_seed(80)
+    x = torch.randn((n, F), device=dev, generator=g)
+    y_lt, y_csr, y_again = (torch.empty((n, F), device=dev) for _ in range(3))
+    hip.spmm_xs(lt, x, y_lt)
+    hip.spmm_csr(a.rowptr, a.colidx, a.vals, x, y_csr)
+    assert _rel(y_lt, y_csr) < 2e-6
+    hip.spmm_xs(lt, x, y_again)
+    assert torch.equal(y_lt, y_again), "the LT walk must be bitwise reproducible run to run"
+    v = (1.0 / a.dinv).view(-1, 1).repeat(1, F).contiguous()
+    av = torch.empty_like(v)
+    hip.spmm_xs(lt, v, av)
+    assert _rel(av, v) < 1e-5
+    rows = np.random.default_rng(8).integers(0, n, 300)
+    rp = a.rowptr.long()
+    xd = x.double().cpu().numpy()
+    for r in rows.tolist():
+        lo, hi = int(rp[r]), int(rp[r + 1])
+        cols = a.colidx[lo:hi].long().cpu().numpy()
+        vals = a.vals[lo:hi].double().cpu().numpy()
+        want = (vals[:, None] * xd[cols]).sum(0)
+        assert np.abs(y_lt[r].double().cpu().numpy() - want).max() <= 1e-5 * max(1e-3, np.abs(want).max())
+    # the fused GCN layer as the chain makes it: Y = relu(A_hat H + b) into a slice of the [N, 24] concat buffer, H_next = S (Y W)
+    b = torch.rand(F, device=dev, generator=g) - 0.5
+    w = (torch.rand((F, F), device=dev, generator=g) - 0.5).contiguous()
+    h0 = torch.empty_like(x)
+    hip.row_affine(x, lt.col_scale, h0)
+    cat = torch.zeros((n, 3 * F), device=dev)
+    h1 = torch.empty((n, F), device=dev)
+    hip.spmm_xs(lt, h0, cat[:, F:2 * F], bias=b, relu=True, Wnext=w, Hnext=h1, prescaled=True, scale_next=True)
+    y1 = cat[:, F:2 * F].contiguous()
+    assert _rel(y1, torch.clamp(y_lt + b, min=0)) < 1e-6
+    assert float(cat[:, :F].abs().max()) == 0.0 and float(cat[:, 2 * F:].abs().max()) == 0.0     # the slice store stays in its columns
+    h_ref = torch.empty_like(h1)
+    hip.rowwise_xw(y1, w, h_ref, row_scale=lt.row_scale)
+    assert _rel(h1, h_ref) < 1e-6
+
+
 @pytest.mark.parametrize('F', [16, 32])
 def test_full_size_wide_layers_on_the_lds_tiled_walk(hip, big, F):
     """The F = 16 / 32 layers of econfigs/basic-gnn.yaml grid2 / grid3 at the bench's full size, on the image they dispatch to (the

@@ -76,7 +76,7 @@ def walk(lt, xs, rw=None):
                     vals[j - 1] += xs[col[j]]
                 plain = ~flag & ~paired
                 assert len(set(lrow[plain & real])) == (plain & real).sum(), "plain entries of a step must hit distinct rows"
-                ldsrow = lrow * W + (w + lrow) % W
+                ldsrow = w * rw + lrow                               # wave-major LDS rows (csrc lt_lds_row)
                 for j in np.where(plain)[0]:
                     tile[ldsrow[j]] += vals[j]
                 for j in np.where(flag)[0]:
@@ -88,7 +88,7 @@ def walk(lt, xs, rw=None):
             v0 = vstart[r0 + lr]
             v1 = vstart[r0 + lr + 1] if lr + 1 < nr else vcount[t]
             for v in range(v0, v1):
-                y[r0 + lr] += tile[(v // W) * W + (v % W + v // W) % W]
+                y[r0 + lr] += tile[(v % W) * rw + v // W]
     assert stats['pairs'] == lt.n_pairs and stats['flagged'] == lt.n_flagged
     d, sc, off = lt.diag.numpy(), lt.row_scale.numpy(), lt.diag_offset
     return sc[:, None] * (d[:, None] * xs[off:off + n_rows] + y)
@@ -122,6 +122,65 @@ def test_lt_image_without_pairs(F, pairs):
     lt = lds_tiled.LdsTiled.build(rows, cols, n, n, F, diag, csr.dinv, csr.dinv, off, n_cu=3, pairs=pairs)
     assert lt.pairs == pairs and (pairs or lt.n_pairs == 0)
     x = np.random.default_rng(2).standard_normal((n, F)).astype(np.float32)
+    xs = (csr.dinv.numpy()[:, None] * x).astype(np.float32)
+    np.testing.assert_allclose(walk(lt, xs), a_hat.astype(np.float64) @ x.astype(np.float64), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize('F,n_cu,window,sub', [(8, 4, 256, 64), (8, 1, 2048, 512), (8, 3, None, None), (16, 2, 512, 128)])
+def test_lt_image_deferred_repeats(F, n_cu, window, sub):
+    """layout='defer' (round 4): a window's list keeps column order by sub-window and moves only the repeats of a virtual row behind
+    the first occurrences; built without pairs.  Same product, same invariants; fewer flagged entries than the dealt image of
+    single-step windows, which is what the form is for."""
+    csr, a_hat = _gcn_csr(700, 300, 30000, seed=F + n_cu)
+    rows, cols, diag, off = _unit_entries(csr, True)
+    n = csr.shape[0]
+    lt = lds_tiled.LdsTiled.build(rows, cols, n, n, F, diag, csr.dinv, csr.dinv, off, window_entries=window, n_cu=n_cu, pairs=False,
+                                  layout='defer', sub_window=sub)
+    assert not lt.pairs and lt.n_pairs == 0
+    x = np.random.default_rng(1).standard_normal((n, F)).astype(np.float32)
+    xs = (csr.dinv.numpy()[:, None] * x).astype(np.float32)
+    np.testing.assert_allclose(walk(lt, xs), a_hat.astype(np.float64) @ x.astype(np.float64), rtol=2e-5, atol=2e-6)
+    if window is not None and window >= 4 * (sub or 0):
+        dealt = lds_tiled.LdsTiled.build(rows, cols, n, n, F, diag, csr.dinv, csr.dinv, off, window_entries=sub, n_cu=n_cu, pairs=False)
+        assert lt.n_flagged < dealt.n_flagged
+
+
+@pytest.mark.parametrize('F,n_cu,window,layout', [(8, 4, 64, 'deal'), (8, 2, None, 'deal'), (8, 3, 256, 'defer'), (16, 2, 64, 'deal')])
+def test_lt_image_spread_repeats(F, n_cu, window, layout):
+    """spread=3 (round 4): repeats of a row inside a step trade places with entries a few steps down the stream; the image stays
+    a permutation of the same entries (same product), and fewer entries are left for the LDS-atomic path."""
+    csr, a_hat = _gcn_csr(700, 300, 30000, seed=F + n_cu)
+    rows, cols, diag, off = _unit_entries(csr, True)
+    n = csr.shape[0]
+    kw = dict(window_entries=window, n_cu=n_cu, pairs=False, layout=layout, sub_window=64 if layout == 'defer' else None)
+    plain = lds_tiled.LdsTiled.build(rows, cols, n, n, F, diag, csr.dinv, csr.dinv, off, **kw)
+    lt = lds_tiled.LdsTiled.build(rows, cols, n, n, F, diag, csr.dinv, csr.dinv, off, spread=3, **kw)
+    assert lt.n_entries == plain.n_entries and lt.words.numel() == plain.words.numel()
+    assert lt.n_flagged < plain.n_flagged or plain.n_flagged == 0
+    x = np.random.default_rng(1).standard_normal((n, F)).astype(np.float32)
+    xs = (csr.dinv.numpy()[:, None] * x).astype(np.float32)
+    np.testing.assert_allclose(walk(lt, xs), a_hat.astype(np.float64) @ x.astype(np.float64), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize('F,n_cu,window', [(8, 4, 1024), (8, 2, 512), (16, 3, 512), (8, 1, 4096)])
+def test_lt_image_windows_by_count(F, n_cu, window):
+    """layout='count' (round 4): every wave runs the same number of steps between two barriers — a window is a fixed number of
+    the wave's own entries, not a column range of the tile.  Same product; the window table is k * S steps for every wave."""
+    csr, a_hat = _gcn_csr(700, 300, 30000, seed=F + n_cu)
+    rows, cols, diag, off = _unit_entries(csr, True)
+    n = csr.shape[0]
+    lt = lds_tiled.LdsTiled.build(rows, cols, n, n, F, diag, csr.dinv, csr.dinv, off, window_entries=window, n_cu=n_cu, pairs=False,
+                                  layout='count', spread=2)
+    eps = lds_tiled.geometry(F)[0]
+    S = max(1, window // (lds_tiled.WAVES * eps))
+    for t in range(lt.n_tiles):
+        nwin = int(lt.n_win[t])
+        for w in range(lds_tiled.WAVES):
+            tab = lt.wsteps[t, w].numpy()
+            total = int(tab[nwin])
+            full = [k * S for k in range(nwin + 1) if k * S <= total - lds_tiled.CHUNK // eps]
+            assert list(tab[:len(full)]) == full                    # (the last windows of a stream stop at its own length)
+    x = np.random.default_rng(1).standard_normal((n, F)).astype(np.float32)
     xs = (csr.dinv.numpy()[:, None] * x).astype(np.float32)
     np.testing.assert_allclose(walk(lt, xs), a_hat.astype(np.float64) @ x.astype(np.float64), rtol=2e-5, atol=2e-6)
 

@@ -19,11 +19,11 @@ GRID6 = dict(GRID1, embedding_dim=32, n_hiddens=[32, 32, 32], n_layers=3, dense_
 
 
 TOPK_PARITY_JSON = 'gpurun_out/topk_parity.json'     # per case: users without a near-tie, lists differing from the fp32 / fp64 oracle
-TOPK_MAX_DIFFERING = 10                               # observed over all cases and boxes: 0-6 of 6 035 users (profiles/r3_topk_parity.json)
+TOPK_MAX_DIFFERING = 8                                # observed over all cases and boxes: 0-6 of 6 035 users (profiles/r3_topk_parity.json, r4_topk_parity.json)
 
 
 def _record_topk_parity(label, k, entry):
-    """Append one case to the JSON the GPU run leaves under gpurun_out/ (copied to profiles/r3_topk_parity.json by the builder)."""
+    """Append one case to the JSON the GPU run leaves under gpurun_out/ (copied to profiles/r<round>_topk_parity.json by the builder)."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,7 +1,7 @@
 """CPU, world_size 2 and 3 over gloo: the typed node-range partition + per-layer all-gather logic.
 
 The HIP kernels cannot run here, so the runner's kernel provider is replaced by a numpy stand-in
-(test infrastructure) while partitioning, the rank-major block layout, CSR column remapping and the
+(test infrastructure) while partitioning, the type-major table layout, the per-type row blocks, CSR column remapping and the
 collectives are the shipped code.  Each rank's own blocks and gathered tables must equal the
 single-process oracle propagation.
 """
@@ -135,9 +135,10 @@ def test_typed_partition_matches_oracle(tmp_path, world):
             cols = slice(8 * (k + 1), 8 * (k + 2))
             # the gathered item rows are the item table in the reference's item order, on every rank
             assert helpers.rel_err(z['xi%d' % k][:ni], want[nu:nu + ni, cols]) < 1e-5
-            # the rank's own block, type after type at the block offsets
+            # the rank's own block, type after type at the block offsets (the LAST layer's property rows are not computed: no tower reads them)
             for t, (lo, hi) in enumerate(z['owned']):
-                assert helpers.rel_err(z['xl%d' % k][z['off'][t]:z['off'][t] + hi - lo], want[lo:hi, cols]) < 1e-5
+                if hi > lo and not (k == 1 and t == 2):
+                    assert helpers.rel_err(z['xl%d' % k][z['off'][t]:z['off'][t] + hi - lo], want[lo:hi, cols]) < 1e-5
         ulo, uhi = z['owned'][0]
         assert ((z['u_ids'] >= ulo) & (z['u_ids'] < uhi)).all()                     # pairs follow their user's owner
         assert np.array_equal(z['u_ids'], g['u_ids'][z['pair_index']]) and np.array_equal(z['i_ids'], g['i_ids'][z['pair_index']])
@@ -146,7 +147,8 @@ def test_typed_partition_matches_oracle(tmp_path, world):
         # LightGCN: the mean over the layers for the rank's own rows and, gathered, for every item
         assert helpers.rel_err(z['light_items'][:ni], want_light[nu:nu + ni]) < 1e-5
         for t, (lo, hi) in enumerate(z['owned']):
-            assert helpers.rel_err(z['light_local'][z['off'][t]:z['off'][t] + hi - lo], want_light[lo:hi]) < 1e-5
+            if hi > lo and t != 2:                                                   # (properties stop one layer early: nobody reads their mean)
+                assert helpers.rel_err(z['light_local'][z['off'][t]:z['off'][t] + hi - lo], want_light[lo:hi]) < 1e-5
         # no user / item split known: one type, the "item" gather is the whole table
         lo, hi = z['blind_rows']
         for k in range(2):
@@ -176,7 +178,8 @@ def test_typed_partition_layout():
             for r, (lo, hi) in enumerate(spans):
                 if hi > lo:
                     assert lo - bounds[t] == r * tp.h[t]
-                    assert torch.equal(p[lo:hi], r * tp.R + tp.off[t] + torch.arange(hi - lo))
+                    assert torch.equal(p[lo:hi], tp.toff[t] + r * tp.h[t] + torch.arange(hi - lo))        # type-major: block r of section t
+                    assert tp.block_row0(r, t) == tp.toff[t] + r * tp.h[t] and tp.section(t) == (tp.toff[t], tp.toff[t] + world * tp.h[t])
         assert world * tp.R - n <= sum(world for _ in range(tp.T)) + sum(tp.h)   # padding: O(world) rows per type (+ a short last block)
 
 

@@ -59,6 +59,7 @@ def parse_args():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--scale', type=int, default=64, help='ml1m(s) scale factor of the synthetic graph (64; 256 = the larger scaling workload)')
     ap.add_argument('--no-cpu-baseline', action='store_true', help='skip the ml1m(s=1), hybrid-head and CPU legs')
+    ap.add_argument('--no-s256', action='store_true', help='skip the ml1m(s=256) leg (the larger scaling workload, run by default next to --scale 64)')
     return ap.parse_args()
 
 
@@ -583,6 +584,81 @@ def model_families(dev, scale, steps):
     return out
 
 
+def larger_scale_leg(scale, steps, rank, world, local_rank, multi, rehearse):
+    """The same step on ml1m(scale) (default 256: 2.36 M nodes, 224 M non-zeros, 48 M pairs — the node tables leave the 32 MB of L2),
+    timed by the same protocol as the headline (graph replay, barrier + synchronize on both sides, MAX over ranks): at N > 1 the
+    exchange is 4x the bytes on 4x the compute, which is where >= 5x at 8 GPUs is reachable; at N = 1 it is the
+    single-GPU time the scaling of this leg is measured against."""
+    from deep_cbrs_amar_renaissance_amd import engine, parallel
+    from deep_cbrs_amar_renaissance_amd.data import synthetic
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter_device
+    dev = torch.device('cuda', local_rank)
+    cdev = 'cpu' if rehearse else dev
+    engine.set_seed(42)
+    data = synthetic.ml1m_device(scale, device=dev)
+    n = data['n_users'] + data['n_items']
+    a_hat = gcn_filter_device(data['train_pos'][:, 0], data['train_pos'][:, 1], n)
+    model = basic.BasicGCN(a_hat, **GRID1)
+    model.n_users, model.n_items = data['n_users'], data['n_items']
+    u, i = shuffled_test_pairs(data, dev)
+    n_pairs = int(u.numel())
+    del data
+    torch.cuda.empty_cache()
+    if world == 1 and multi:                                       # AMAR_FORCE_DIST: the partitioned runner + RCCL with a single rank
+        runner = parallel.PartitionedGCNRunner(model, u, i, rank, world)
+    else:
+        runner = parallel.make_runner(model, u, i, rank, world, dist=parallel.SharedDeviceCollectives(rank, world) if rehearse else None)
+
+    def barrier():
+        if multi:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    for _ in range(5):
+        runner.step()
+    barrier()
+    phases = runner.phase_times() if hasattr(runner, 'phase_times') else None
+    step, graphed = runner.step, False
+    if os.environ.get('AMAR_STEP_GRAPH', '1') != '0' and not rehearse:
+        ok = 1
+        try:
+            runner.capture_step()
+        except Exception as exc:
+            sys.stderr.write("bench.py: rank {}: hipGraph capture of the ml1m(s={}) step failed ({}); timing eager steps\n".format(rank, scale, exc))
+            ok = 0
+        if multi:
+            flag = torch.tensor([ok], device=cdev, dtype=torch.int32)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok:
+            step, graphed = runner.step_graphed, True
+    for _ in range(20):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    per_rank = None
+    if multi:
+        t = torch.tensor([dt], device=cdev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t[0].item())
+        per_rank = [None] * world
+        torch.distributed.all_gather_object(per_rank, dict(phases or {}, rank=rank, rows=int(runner.local_rows), nnz=int(runner.local_nnz),
+                                                             pairs=int(runner.u_ids.numel())))
+    out = {'workload': 'ml1m(s={}) user-item graph: N={} nodes, nnz(A_hat)={}, {} test pairs; same model and step as the headline'.format(
+               scale, n, a_hat.nnz, n_pairs),
+           'scale': scale, 'n_gpus': world, 'steps': steps, 'ms_per_step': 1e3 * dt / steps, 'value': n_pairs * steps / dt, 'unit': 'pairs/s',
+           'replayed_from_hipgraph': graphed, 'parallelism': runner.describe()}
+    if per_rank is not None:
+        out['per_rank'] = per_rank
+    del runner, model, a_hat, u, i
+    torch.cuda.empty_cache()
+    return out
+
+
 def value_spread(scale):
     """min / max ms per step of the default run over the boxes of the build session (profiles/r<round>_bench_repeats.json, written by
     tools/collect_spread.py from the bench.py lines of different gpurun boxes), with the csrc/ hash it was measured at."""
@@ -813,6 +889,10 @@ def main():
     kernel_names = {'sj': 'spmm_sj_kernel<8>', 'xs': 'spmm_xs_partial_kernel<8> + spmm_xs_combine_kernel<8>', 'csr': 'spmm_stream_kernel<8>',
                     'lt': 'spmm_lt_kernel<8> (LDS-tiled, one launch)', 'none': 'none'}
 
+    s256 = None
+    if args.scale == 64 and not args.no_s256 and not rehearse:     # every rank takes part (its collectives); rank 0 reports
+        s256 = larger_scale_leg(256, args.steps, rank, world, local_rank, multi, rehearse)
+
     if rank == 0:
         # what the dispatched image actually streams per launch (the 8(d) formula counts a canonical 8-byte CSR entry)
         image_entry_bytes = {'csr': 8, 'sj': 8, 'xs': 4, 'lt': 4, 'none': 0}[kind]
@@ -844,15 +924,18 @@ def main():
                       'host_enqueue_ms_per_step': 1e3 * eager_host_dt / args.steps,
                       'note': 'the same K steps launched one kernel at a time, each SpMM / pair-stage launch bracketed by HIP events'},
         }
+        if s256 is not None:
+            out['s256'] = s256
         spread = value_spread(args.scale)
         if spread is not None and not multi:
             out['value_spread_boxes'] = spread
         if per_rank is not None:
             out['per_rank'] = {'ranks': per_rank,
                                'note': 'one EAGER step by phase on every rank, HIP events on the compute stream: local_spmm_ms and pair_stage_ms '
-                                       'shrink with the rank count, replicated_ms (X_0 . W_1 over all rows + the item tower) does not, exchange_ms is '
-                                       'the time the compute stream spent issuing and waiting for all-gathers (the item-row gathers overlap the next '
-                                       'SpMM / the user tower)'}
+                                       'shrink with the rank count, replicated_ms (X_0 . W_1 over all rows + the item tower) does not, exposed_exchange_ms '
+                                       '(= exchange_ms) is the time the compute stream spent issuing all-gathers and waiting for the sections it needs next: '
+                                       'a layer runs one launch per node type and gathers each type\'s section of the next table behind the other types\' launches '
+                                       '(parallel.py), so what shows here is the part of the exchange compute did not cover'}
         if kind == 'lt' and not multi:
             out['roofline_onchip'] = onchip_floor(capi, a_hat, f, nnz_local, avg_ms, pmc)
         pair_ms = [e0.elapsed_time(e1) for e0, e1 in pair_events]

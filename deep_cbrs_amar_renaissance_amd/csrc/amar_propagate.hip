@@ -716,7 +716,10 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE, AMAR_LT_MIN_WAVES) void spmm_
     const int32_t *stream = a.words + a.stream_start[t * LT_WAVES + wave];
     const int32_t *ws = a.wsteps + ((int64_t)t * LT_WAVES + wave) * a.maxwin1;     // the wave's window table [maxwin1]
     const int nwin = a.n_win[t];
-    const int n_chunks = __builtin_amdgcn_readfirstlane(ws[nwin]) / CS;
+    // entry n_win of the window table: the steps that hold entries of the stream (round 4: exact; the stream itself stays padded to
+    // whole chunks, but the steps of the padding are not walked — a 190-row tile of an 8-rank block has ~860 entries per wave, 1 024 padded)
+    const int n_steps = __builtin_amdgcn_readfirstlane(ws[nwin]);
+    const int n_chunks = (n_steps + CS - 1) / CS;
     int32_t *ring = ring_all + wave * LT_CHUNK;
     const unsigned cmask = (1u << a.cbits) - 1u;
 
@@ -834,8 +837,8 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE, AMAR_LT_MIN_WAVES) void spmm_
                 refill(next);                                         // (past the last chunk: stale words, valid columns, never added)
                 if (c + 1 + PF < n_chunks) next = load_chunk(c + 1 + PF);
             }
-            issue((js + G) % CS, (js + G) % U);
-            accumulate(js % U);
+            issue((js + G) % CS, (js + G) % U);                       // (unconditional: the counted waits rely on a static load sequence)
+            if (c * CS + js < n_steps) accumulate(js % U);
             pace(c * CS + js + 1);
         }
     };
@@ -871,6 +874,51 @@ __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE, AMAR_LT_MIN_WAVES) void spmm_
     // four-entry rows spent a quarter of its time in these).
     const int vtile = a.vcount[t];
     constexpr int EK = SAGE ? 1 : F <= 8 ? 4 : F == 16 ? 2 : 1, ETH = LT_WAVES * AMAR_WAVE;   // (the SAGE tail needs the registers itself)
+    // Short tiles (round 4: the per-type row blocks of an 8-rank partition are 100-190 rows of up to ten virtual rows each): with one
+    // thread per row nine tenths of the workgroup idle while a hundred threads walk their virtual rows one LDS round trip at a time —
+    // 14 k of a 70 k-cycle tile.  2, 4, 8 or 16 lanes share a row instead (as many as the workgroup has for the tile's rows), each
+    // summing every G-th virtual row, folded with a butterfly; the group's first lane finishes the row.  (The sums of a row are then
+    // taken in another order than in a tall tile: fixed by the tile's height, so a launch stays reproducible bit for bit.)
+    if constexpr (!GAT && !SAGE) {
+        const int lg = nr * 16 <= ETH ? 4 : nr * 8 <= ETH ? 3 : nr * 4 <= ETH ? 2 : nr * 2 <= ETH ? 1 : 0;
+        if (lg > 0) {
+            const int lr = (int)threadIdx.x >> lg, g = (int)threadIdx.x & ((1 << lg) - 1);
+            const bool live = lr < nr;
+            const int row = r0 + (live ? lr : 0);
+            const int v0 = a.vstart[row], v1 = !live ? v0 : (lr + 1 < nr ? a.vstart[row + 1] : vtile);
+            const float d = a.diag[row], sc = a.row_scale[row];
+            float4 xs[LPN], acc[LPN];
+#pragma unroll
+            for (int qq = 0; qq < LPN; ++qq) {
+                xs[qq] = *reinterpret_cast<const float4 *>(a.Xself + (int64_t)row * a.e.ldx + 4 * qq);
+                acc[qq] = f4_zero();
+            }
+            for (int v = v0 + g; v < v1; v += 1 << lg) {
+                const float *yp = ytile + lt_lds_row<RW>(v) * F;
+#pragma unroll
+                for (int qq = 0; qq < LPN; ++qq) acc[qq] = f4_add(acc[qq], *reinterpret_cast<const float4 *>(yp + 4 * qq));
+            }
+            for (int m = 1; m < (1 << lg); m <<= 1)
+#pragma unroll
+                for (int qq = 0; qq < LPN; ++qq) {
+                    acc[qq].x += __shfl_xor(acc[qq].x, m, AMAR_WAVE); acc[qq].y += __shfl_xor(acc[qq].y, m, AMAR_WAVE);
+                    acc[qq].z += __shfl_xor(acc[qq].z, m, AMAR_WAVE); acc[qq].w += __shfl_xor(acc[qq].w, m, AMAR_WAVE);
+                }
+            if (live && g == 0) {
+#pragma unroll
+                for (int qq = 0; qq < LPN; ++qq) {
+                    acc[qq].x = sc * fmaf(d, xs[qq].x, acc[qq].x); acc[qq].y = sc * fmaf(d, xs[qq].y, acc[qq].y);
+                    acc[qq].z = sc * fmaf(d, xs[qq].z, acc[qq].z); acc[qq].w = sc * fmaf(d, xs[qq].w, acc[qq].w);
+                }
+                lane_row_epilogue<F, FUSE_NEXT>(a.e, row, acc, WN_LDS ? wn_lds : nullptr);
+            }
+#ifdef AMAR_LT_STAMPS
+            __syncthreads();
+            LT_STAMP(3);
+#endif
+            return;
+        }
+    }
     for (int base = threadIdx.x; base < nr; base += EK * ETH) {
     int ev0[EK], ev1[EK];
     float ed[EK], esc[EK], eas[GAT ? EK : 1], ebs[GAT ? EK : 1];

@@ -49,105 +49,134 @@ class TypedPartition:
     """Node-range partition of a graph whose ids are grouped by node TYPE (users | items [| properties], loaders.py:43-68).
 
     Type t with n_t nodes is cut into `world` contiguous blocks of EQUAL HEIGHT h_t = ceil(n_t / world) (only a type's last
-    blocks can be short or empty); rank r owns block r of every type.  A rank's rows, in local order, are
-    [its users | its items | its properties], each padded to h_t rows: R = sum(h_t) rows per rank.  The gathered tables the
-    SpMM reads from are TYPE-MAJOR, [world * R, C]: section t = rows [toff_t, toff_t + world * h_t) holds type t in id order
-    (block r of the type at toff_t + r * h_t), so `all_gather_into_tensor` of the ranks' [h_t, C] blocks of ONE type lands in
-    place and a layer's exchange is one collective per node type — each can start as soon as that type's rows are done.
-    Node j of type t sits at row  toff_t + (j - first id of type t).
+    blocks can be short or empty); rank r owns block r of every type.  Node types are bundled into GROUPS (`groups`, a list of
+    lists of types; default: every type its own group).  A rank's rows, in local order, are its blocks group after group, type
+    after type inside a group, each padded to h_t rows: R = sum(h_t) rows per rank.  The gathered tables the SpMM reads from,
+    [world * R, C], are GROUP-MAJOR: section g = rows [goff_g, goff_g + world * R_g) holds the ranks' [R_g, C] blocks of group g
+    in rank order (R_g = the group's rows per rank), so `all_gather_into_tensor` of the ranks' blocks of ONE group lands in place:
+      * one group of all types = the rank-major tables of round 3 — one launch and one collective per layer;
+      * one group per type (or [users, properties | items]) = type-major tables — a layer runs one launch per group and each
+        group's collective can start as soon as its launch is enqueued (PartitionedGCNRunner: the exchange behind compute).
+    Node j of type t (group g) sits at row  goff_g + (j' // h_t) * R_g + o_t + j' % h_t,  j' = j - first id of type t, o_t = the
+    type's offset inside its group's block.
     Because a type's blocks are equally tall, its rows taken out of the ranks' blocks in rank order ARE the type in id order
     (plus padding at the very end): the all-gather of the item parts of the blocks is the item table in the reference's own
     item order, and a rank's user rows are a contiguous range of user ids — towers and pair ids need no remapping.
     Against the equal-nnz row ranges of rounds 1-2 the padded index space is N + O(world) rows instead of 1.3 N at ml1m(s=64);
     the price is that non-zeros are balanced only as far as degrees are unrelated to id order (`nnz_imbalance`)."""
 
-    def __init__(self, type_bounds, world):
+    def __init__(self, type_bounds, world, groups=None):
         tb = [int(b) for b in type_bounds]
         if len(tb) < 2 or tb[0] != 0 or any(tb[k] > tb[k + 1] for k in range(len(tb) - 1)):
             raise ValueError("type_bounds must be an ascending list starting at 0")
         self.tb, self.world, self.n, self.T = tb, int(world), tb[-1], len(tb) - 1
         self.h = [max(1, -(-(tb[t + 1] - tb[t]) // self.world)) for t in range(self.T)]
-        self.off = [0]
-        for h in self.h:
-            self.off.append(self.off[-1] + h)
-        self.R = self.off[-1]
-        self.toff = [self.world * o for o in self.off]               # first row of every type's section in the gathered tables
+        self.groups = [[t] for t in range(self.T)] if groups is None else [[int(t) for t in g] for g in groups]
+        if sorted(t for g in self.groups for t in g) != list(range(self.T)):
+            raise ValueError("groups must hold every node type exactly once")
+        self.G = len(self.groups)
+        self.group_of, self.in_group = [0] * self.T, [0] * self.T    # a type's group / its offset inside the group's block
+        self.off = [0] * self.T                                       # ... its offset in the rank's local row order
+        self.gh, self.goff, self.loff = [], [], []                    # per group: rows per rank, first table row, first local row
+        local = 0
+        for g, types in enumerate(self.groups):
+            self.loff.append(local)
+            inside = 0
+            for t in types:
+                self.group_of[t], self.in_group[t], self.off[t] = g, inside, local + inside
+                inside += self.h[t]
+            self.gh.append(inside)
+            self.goff.append(self.world * local)
+            local += inside
+        self.R = local
+        self.goff.append(self.world * self.R)
 
     def owned(self, rank, t):
         """[lo, hi) of the ids of type t that rank owns (empty when the type ran out before this rank's block)."""
         lo = min(self.tb[t] + rank * self.h[t], self.tb[t + 1])
         return lo, min(lo + self.h[t], self.tb[t + 1])
 
-    def section(self, t):
-        """[lo, hi) of the rows of type t's section in the type-major tables."""
-        return self.toff[t], self.toff[t + 1]
+    def section(self, g):
+        """[lo, hi) of the rows of group g's section in the gathered tables."""
+        return self.goff[g], self.goff[g + 1]
 
-    def block_row0(self, rank, t):
-        """First row of rank's block of type t in the type-major tables."""
-        return self.toff[t] + rank * self.h[t]
+    def block_row0(self, rank, g):
+        """First row of rank's block of group g in the gathered tables."""
+        return self.goff[g] + rank * self.gh[g]
+
+    def local_rows(self, g):
+        """[lo, hi) of group g's rows in the rank's local row order."""
+        return self.loff[g], self.loff[g] + self.gh[g]
 
     def padded_index(self, ids):
-        """Global node ids (int tensor) -> rows of the type-major [world * R, *] tables."""
+        """Global node ids (int tensor) -> rows of the group-major [world * R, *] tables."""
         ids = ids.to(torch.int64)
         dev = ids.device
-        tb = torch.tensor(self.tb, dtype=torch.int64, device=dev)
-        t = (torch.searchsorted(tb, ids, right=True) - 1).clamp_(0, self.T - 1)
-        return torch.tensor(self.toff[:-1], dtype=torch.int64, device=dev)[t] + ids - tb[t]
+        as_t = lambda v: torch.tensor(v, dtype=torch.int64, device=dev)
+        t = (torch.searchsorted(as_t(self.tb), ids, right=True) - 1).clamp_(0, self.T - 1)
+        j = ids - as_t(self.tb)[t]
+        h = as_t(self.h)[t]
+        g = as_t(self.group_of)[t]
+        return as_t(self.goff[:-1])[g] + (j // h) * as_t(self.gh)[g] + as_t(self.in_group)[t] + j % h
 
     def node_of_row(self, device):
-        """int32 [world * R]: the node id held by every row of the type-major tables, -1 for padding rows."""
+        """int32 [world * R]: the node id held by every row of the gathered tables, -1 for padding rows."""
         out = torch.full((self.world * self.R,), -1, dtype=torch.int32, device=device)
         ids = torch.arange(self.n, device=device)
         out[self.padded_index(ids)] = ids.to(torch.int32)
         return out
 
     def pad_vector(self, v):
-        """[n] per-node vector -> [world * R] in the type-major layout (padding rows zero)."""
+        """[n] per-node vector -> [world * R] in the layout of the gathered tables (padding rows zero)."""
         out = torch.zeros(self.world * self.R, dtype=v.dtype, device=v.device)
         out[self.padded_index(torch.arange(self.n, device=v.device))] = v
         return out
 
-    def type_of_row(self, rows):
-        """Node type of rows of the type-major tables (int64 tensor -> int64 tensor)."""
-        toff = torch.tensor(self.toff, dtype=torch.int64, device=rows.device)
-        return (torch.searchsorted(toff, rows.to(torch.int64), right=True) - 1).clamp_(0, self.T - 1)
+    def group_of_row(self, rows):
+        """Group (section) of rows of the gathered tables (int64 tensor -> int64 tensor)."""
+        goff = torch.tensor(self.goff, dtype=torch.int64, device=rows.device)
+        return (torch.searchsorted(goff, rows.to(torch.int64), right=True) - 1).clamp_(0, self.G - 1)
 
-    def local_block(self, a, rank, t):
-        """The rank's rows of node type t of `a` (a square DeviceCSR over the n nodes) as an [h_t, world * R] DeviceCSR, column
-        indices in the type-major layout; carries what the tiled images need of a row block: `diag_offset` (column of row 0's
-        own entry: the block's rows are contiguous in the tables), `active_cols` (columns of the sections it touches: what its
-        entry density is measured against), `reads` (the node types its off-diagonal entries fall in), and the value-free
-        factors when `a` has them."""
+    def local_block(self, a, rank, g):
+        """The rank's rows of group g of `a` (a square DeviceCSR over the n nodes) as an [R_g, world * R] DeviceCSR in local row
+        order, column indices in the layout of the gathered tables; carries what the tiled images need of a row block:
+        `diag_offset` (column of row 0's own entry: the block's rows are contiguous in the tables), `row_breaks` (rows where the
+        node type changes), `active_cols` (columns of the sections it touches: what its entry density is measured against),
+        `reads` (the groups its off-diagonal entries fall in), and the value-free factors when `a` has them."""
         dev = a.rowptr.device
         rp = a.rowptr.to(torch.int64)
-        h = self.h[t]
-        lo, hi = self.owned(rank, t)
-        deg = torch.zeros(h, dtype=torch.int64, device=dev)
+        hg = self.gh[g]
+        deg = torch.zeros(hg, dtype=torch.int64, device=dev)
         empty = torch.zeros(0, dtype=torch.int32, device=dev)
-        cols, vals, mult = empty, None, None
-        if hi > lo:
+        cols, vals, mult = [], [], []
+        for t in self.groups[g]:
+            lo, hi = self.owned(rank, t)
+            if hi <= lo:
+                continue
             p0, p1 = int(rp[lo]), int(rp[hi])
-            deg[:hi - lo] = rp[lo + 1:hi + 1] - rp[lo:hi]
-            cols = self.padded_index(a.colidx[p0:p1]).to(torch.int32).contiguous()
-            vals = a.vals[p0:p1].contiguous() if a.vals is not None else None
-            mult = a.mult[p0:p1].contiguous() if getattr(a, 'mult', None) is not None else None
-        elif a.vals is not None:
-            vals = torch.zeros(0, dtype=torch.float32, device=dev)
-        rowptr = torch.zeros(h + 1, dtype=torch.int64, device=dev)
+            deg[self.in_group[t]:self.in_group[t] + hi - lo] = rp[lo + 1:hi + 1] - rp[lo:hi]
+            cols.append(self.padded_index(a.colidx[p0:p1]).to(torch.int32))
+            if a.vals is not None:
+                vals.append(a.vals[p0:p1])
+            if getattr(a, 'mult', None) is not None:
+                mult.append(a.mult[p0:p1])
+        rowptr = torch.zeros(hg + 1, dtype=torch.int64, device=dev)
         rowptr[1:] = torch.cumsum(deg, 0)
-        local = DeviceCSR(rowptr.to(torch.int32).contiguous(), cols, vals, (h, self.world * self.R), gcn_filtered=a.gcn_filtered)
-        local.diag_offset = self.block_row0(rank, t)
-        local.row_breaks = ()
-        # the node types the block's OFF-diagonal entries fall in (a rating graph: users -> items, items -> users + properties, ...)
-        rows_of = torch.repeat_interleave(torch.arange(h, device=dev), deg)
-        off_diag = cols.long() != rows_of + local.diag_offset
-        touched = torch.unique(self.type_of_row(cols.long()[off_diag])).tolist() if cols.numel() else []
-        local.reads = tuple(int(x) for x in touched)
-        local.has_diagonal = bool((~off_diag).any()) if cols.numel() else False
-        local.active_cols = max(1, sum(self.toff[x + 1] - self.toff[x] for x in set(local.reads) | {t}))
+        colidx = torch.cat(cols).contiguous() if cols else empty
+        local = DeviceCSR(rowptr.to(torch.int32).contiguous(), colidx,
+                          (torch.cat(vals).contiguous() if vals else torch.zeros(0, dtype=torch.float32, device=dev)) if a.vals is not None else None,
+                          (hg, self.world * self.R), gcn_filtered=a.gcn_filtered)
+        local.diag_offset = self.block_row0(rank, g)
+        local.row_breaks = tuple(self.in_group[t] for t in self.groups[g][1:])
+        # the groups the block's OFF-diagonal entries fall in (a rating graph: users -> items, items -> users + properties, ...)
+        rows_of = torch.repeat_interleave(torch.arange(hg, device=dev), deg)
+        off_diag = colidx.long() != rows_of + local.diag_offset
+        local.reads = tuple(int(x) for x in torch.unique(self.group_of_row(colidx.long()[off_diag])).tolist()) if colidx.numel() else ()
+        local.has_diagonal = bool((~off_diag).any()) if colidx.numel() else False
+        local.active_cols = max(1, sum(self.goff[x + 1] - self.goff[x] for x in set(local.reads) | {g}))
         if getattr(a, 'dinv', None) is not None and getattr(a, 'mult', None) is not None:
             local.dinv = self._padded_dinv(a)
-            local.mult = mult if mult is not None else empty
+            local.mult = torch.cat(mult).contiguous() if mult else empty
         return local
 
     def _padded_dinv(self, a):
@@ -293,11 +322,12 @@ class PartitionedGCNRunner:
             bounds, self.item_type = [0, nu, nu + ni] + ([n] if n > nu + ni else []), 1
         else:                                    # unknown split: one node type; "users" are whoever the pairs name first, "items" every node
             nu, ni, bounds, self.item_type = 0, n, [0, n], 0
-        self.part = self.tpart = TypedPartition(bounds, self.world)
         self.split_known = known
-        # one row block per node type: a layer runs as one launch per type (tiles never straddle a type anyway)
-        self.blocks = [self.tpart.local_block(a, self.rank, t) for t in range(self.tpart.T)]
-        self.csr = self.blocks[0]                               # (the user block: what tools and tests look at first)
+        self.widths = self.seq.layer_widths()
+        self.part = self.tpart = TypedPartition(bounds, self.world, groups=self._choose_groups(bounds, a))
+        # one row block per GROUP of node types: a layer runs as one launch per group (tiles never straddle a type anyway)
+        self.blocks = [self.tpart.local_block(a, self.rank, g) for g in range(self.tpart.G)]
+        self.csr = self.blocks[0]                               # (the first block: what tools and tests look at)
         self.local_rows = sum(hi - lo for lo, hi in (self.tpart.owned(self.rank, t) for t in range(self.tpart.T)))
         self.local_nnz = sum(b.nnz for b in self.blocks)
         self.nnz_imbalance = self.tpart.nnz_imbalance(a.rowptr)
@@ -306,13 +336,12 @@ class PartitionedGCNRunner:
             import warnings
             warnings.warn("partitioned run: pairs per rank are unbalanced (max / mean = {:.2f}): user activity follows the user ids; a "
                           "degree-interleaved relabelling of the users at load time would balance the equal-height blocks".format(self.pair_imbalance))
-        self.widths = self.seq.layer_widths()
         dev = u_ids.device
         self.row_ids = self.tpart.node_of_row(dev)
         self.row_ids0 = self.row_ids.clamp(min=0).contiguous()           # (padding rows copy node 0: finite values nobody gathers)
         # the node held by every LOCAL row (users | items | properties of this rank, each padded to its block height)
-        self.local_ids0 = torch.cat([self.row_ids0[self.tpart.block_row0(self.rank, t):self.tpart.block_row0(self.rank, t) + self.tpart.h[t]]
-                                     for t in range(self.tpart.T)]).contiguous()
+        self.local_ids0 = torch.cat([self.row_ids0[self.tpart.block_row0(self.rank, g):self.tpart.block_row0(self.rank, g) + self.tpart.gh[g]]
+                                     for g in range(self.tpart.G)]).contiguous()
         # pairs follow their user: the rank scores the pairs of the users it owns, so its user tower reads its own rows only
         self.u_lo, self.u_hi = self.tpart.owned(self.rank, 0)
         self.i_lo, self.n_items = nu, ni
@@ -325,7 +354,7 @@ class PartitionedGCNRunner:
             from deep_cbrs_amar_renaissance_amd.models.basic import PairPlan
             self.pair_plan = PairPlan(self.u_ids, self.i_ids)
         # item-row gathers behind the next kernels: only with a real process group (stand-ins copy synchronously)
-        self.async_exchange = self.dist is torch.distributed and os.environ.get('AMAR_EXCHANGE_ASYNC', '1') != '0'
+        self.async_exchange = getattr(self.dist, 'supports_async', self.dist is torch.distributed) and os.environ.get('AMAR_EXCHANGE_ASYNC', '1') != '0'
 
     def _gather(self, out, inp, defer=False):
         """all_gather_into_tensor of equal blocks; defer=True: issued on the collective's own stream, returns the handle to wait on."""
@@ -341,24 +370,33 @@ class PartitionedGCNRunner:
             self._marks.append((name, e))
 
     # -- the schedule of a layer ------------------------------------------------------------------------------------
-    def phase_order(self, k):
-        """Node types in the order layer k (0-based) runs them.  With a known user / item split the order alternates:
-        even layers [users, properties..., items], odd layers [items, users, properties...] — the section of the next gathered
-        table a layer finishes FIRST is in flight while its other phase runs, and the next layer starts with the phase that reads
-        that section (user and property rows read item columns only, item rows read user and property columns)."""
-        T, item = self.tpart.T, self.item_type
-        if T == 1:
-            return [0]
-        others = [t for t in range(T) if t != item]
-        return others + [item] if k % 2 == 0 else [item] + others
+    PHASE_MIN_BYTES = 4 << 20
 
-    def needed_types(self, last):
-        """Node types whose rows of a layer anybody reads: all of them feed the next layer; of the LAST layer the towers read
-        users and items only (the 1.1 M property rows of a user-item-property graph at ml1m(s=64) are a quarter of its rows)."""
-        T = self.tpart.T
-        if not last or T == 1 or not self.split_known:
-            return set(range(T))
-        return {0, self.item_type}
+    def _choose_groups(self, bounds, a):
+        """How the node types are bundled into launches (TypedPartition `groups`).  PHASED: [users, properties... | items] — a layer is
+        two launches and two all-gathers, each section in flight behind the other group's launch; it hides the exchange but pays
+        for two short launches per layer (fixed costs per launch, tiles half as tall).  UNPHASED: all types in one group — one
+        launch per layer on tiles twice as tall, the layer's all-gather exposed between the layers (round 3's scheme).
+        Measured with an emulated wire (tools/exp_rank_of_n.py): at ml1m(s=64) on 8 ranks (2.4 MB per rank and layer)
+        the phases cost more than they hide; from about 4 MB per rank and layer on they win.  AMAR_PART_PHASES=0|1 overrides."""
+        T = len(bounds) - 1
+        if T == 1:
+            return [[0]]
+        forced = os.environ.get('AMAR_PART_PHASES')
+        per_rank = -(-int(a.shape[0]) // self.world) * max(self.widths[1:] or [self.widths[0]]) * 4
+        phased = forced == '1' or (forced != '0' and per_rank >= self.PHASE_MIN_BYTES)
+        if not phased:
+            return [list(range(T))]
+        return [[t for t in range(T) if t != self.item_type], [self.item_type]]
+
+    def phase_order(self, k):
+        """Groups in the order layer k (0-based) runs them.  Phased, the order alternates: even layers [users (+ properties), items],
+        odd layers [items, users (+ properties)] — the section of the next gathered table a layer finishes FIRST is in flight while
+        its other launch runs, and the next layer starts with the launch that reads that section (user and property rows read item
+        columns only, item rows read user and property columns)."""
+        G = self.tpart.G
+        order = list(range(G))
+        return order if k % 2 == 0 else order[::-1]
 
     def _wait_sections(self, handles, k, types):
         """Make the compute stream wait for the all-gathers of table k's sections `types` (each is waited for once)."""
@@ -369,14 +407,13 @@ class PartitionedGCNRunner:
 
     def propagate_typed(self):
         """One propagation on the typed partition.  Returns (x_local, x_items).  'concatenation' stacks (GCN, GraphSAGE, GAT): per
-        layer l = 1..L the rank's own [R, C_l] block of X_l (local row order: users | items | properties, each padded to its block
-        height; the last layer's property rows are not computed: nobody reads them) and the all-gathered item rows
-        [world * h_items, C_l] (the reference's item order; rows past n_items are padding) — X_0 is the node table itself.
-        'mean' stacks (LightGCN, DGCF): one entry each, the mean over the layers.
-        Every kind follows the same scheme: a type-major table T_l [world * R, C] the next layer gathers from, made by the PRODUCER
+        layer l = 1..L the rank's own [R, C_l] block of X_l (local row order: the partition's groups, users first, each type padded
+        to its block height) and the all-gathered item rows [world * h_items, C_l] (the reference's item order; rows past n_items
+        are padding) — X_0 is the node table itself.  'mean' stacks (LightGCN, DGCF): one entry each, the mean over the layers.
+        Every kind follows the same scheme: a group-major table T_l [world * R, C] the next layer gathers from, made by the PRODUCER
         from its own rows of X_l (GCN: S (X_l W_{l+1}) in the SpMM epilogue; LightGCN: S X_l; DGCF: X_l sigmoid(w_{l+1}); GraphSAGE:
-        X_l; GAT: X_l W_{l+1} and its neighbour scalars), one all-gather per node type issued as soon as the type's launch is
-        enqueued and waited for by the first launch of the next layer that reads that section."""
+        X_l; GAT: X_l W_{l+1} and its neighbour scalars), one all-gather per group issued as soon as the group's launch is enqueued
+        and waited for by the first launch of the next layer that reads that section."""
         ops, tp, dev = self.ops, self.tpart, self.seq.embeddings.device
         layers, widths = list(self.seq.seq_layers), self.widths
         n_tab, R = self.world * tp.R, tp.R
@@ -384,30 +421,31 @@ class PartitionedGCNRunner:
         item = self.item_type
         i0, hi_ = tp.off[item], tp.h[item]
         x_local, x_items, pending, handles = [], [], [], {}
-        n_l = len(layers)
-        rows_of = [slice(tp.off[t], tp.off[t] + tp.h[t]) for t in range(tp.T)]           # a type's rows in the local [R, *] buffers
-        sect_of = [slice(*tp.section(t)) for t in range(tp.T)]                            # ... its section of a gathered table
-        own_of = [slice(tp.block_row0(self.rank, t), tp.block_row0(self.rank, t) + tp.h[t]) for t in range(tp.T)]
+        n_l, G = len(layers), tp.G
+        rows_of = [slice(*tp.local_rows(g)) for g in range(G)]                             # a group's rows in the local [R, *] buffers
+        sect_of = [slice(*tp.section(g)) for g in range(G)]                                # ... its section of a gathered table
+        own_of = [slice(tp.block_row0(self.rank, g), tp.block_row0(self.rank, g) + tp.gh[g]) for g in range(G)]
+        item_group = tp.group_of[item]
 
         def gather_items(key, block):                                   # the item rows of a local [R, C] block, behind the next kernels
             xi = self._buffer(('xi', key), (self.world * hi_, block.shape[1]))
             pending.append(self._gather(xi, block[i0:i0 + hi_], defer=True))
             x_items.append(xi)
 
-        def gather_section(k, t, table, block):                        # type t's rows of a local [R, ...] block -> its section of table k
-            handles[(k, t)] = self._gather(table[sect_of[t]], block[rows_of[t]], defer=True)
+        def gather_section(k, g, table, block):                        # group g's rows of a local [R, ...] block -> its section of table k
+            handles[(k, g)] = self._gather(table[sect_of[g]], block[rows_of[g]], defer=True)
 
-        def reads_of(t, own_landed):
-            """Sections of the gathered table a launch over type t's rows reads: where its off-diagonal entries fall, plus its own
+        def reads_of(g, own_landed):
+            """Sections of the gathered table a launch over group g's rows reads: where its off-diagonal entries fall, plus its own
             section unless the launch takes the rows' own entries from the rank's own block (`xself`)."""
-            r = set(self.blocks[t].reads)
+            r = set(self.blocks[g].reads)
             if own_landed:
-                r.add(t)
+                r.add(g)
             return r
 
         if self.kind == 'gcn':
             tiled = [self._use_xs(w) for w in widths[1:]]
-            images = [[self.blocks[t].tiled_image(w) if use else None for t in range(tp.T)] for w, use in zip(widths[1:], tiled)]
+            images = [[self.blocks[g].tiled_image(w) if use else None for g in range(G)] for w, use in zip(widths[1:], tiled)]
             pre = all(tiled) and all(im.row_scale is not None for ims in images for im in ims)   # the chain of gathered tables stays pre-scaled by d^-1/2
             h = self._buffer(('t', 0), (n_tab, widths[1]))
             ops.rowwise_xw(emb, layers[0].kernel, h, row_ids=self.row_ids, row_scale=images[0][0].col_scale if pre else None)
@@ -419,17 +457,14 @@ class PartitionedGCNRunner:
                 y = self._buffer(('y', k), (R, widths[k + 1]), zero=True)
                 hn = self._buffer(('hl', k + 1), (R, widths[k + 2]), zero=True) if nxt is not None else None
                 h_next = self._buffer(('t', k + 1), (n_tab, widths[k + 2])) if nxt is not None else None
-                need = self.needed_types(last)
-                for t in self.phase_order(k):
-                    if t not in need:
-                        continue
-                    blk, rs = self.blocks[t], rows_of[t]
+                for g in self.phase_order(k):
+                    blk, rs = self.blocks[g], rows_of[g]
                     own_local = tiled[k] and pre and hl_prev is not None          # the diagonal term from the rank's own block of H_k
                     if k > 0:
-                        self._wait_sections(handles, k, reads_of(t, not own_local and blk.has_diagonal))
+                        self._wait_sections(handles, k, reads_of(g, not own_local and blk.has_diagonal))
                         self._mark('exchange')
                     if tiled[k]:
-                        ops.spmm_xs(images[k][t], h, y[rs], bias=layer.bias, relu=True, Wnext=nxt.kernel if nxt is not None else None,
+                        ops.spmm_xs(images[k][g], h, y[rs], bias=layer.bias, relu=True, Wnext=nxt.kernel if nxt is not None else None,
                                     Hnext=hn[rs] if hn is not None else None, prescaled=pre, scale_next=pre and nxt is not None,
                                     xself=hl_prev[rs] if own_local else None)
                     else:
@@ -437,19 +472,19 @@ class PartitionedGCNRunner:
                                       Wnext=nxt.kernel if nxt is not None else None, Hnext=hn[rs] if hn is not None else None)
                     self._mark('spmm')
                     if nxt is not None:
-                        gather_section(k + 1, t, h_next, hn)
-                    if t == item:
+                        gather_section(k + 1, g, h_next, hn)
+                    if g == item_group:
                         gather_items(k, y)
                     self._mark('exchange')
                 if k > 0:
-                    self._wait_sections(handles, k, range(tp.T))                  # (sections nobody read: drained before the table is reused)
+                    self._wait_sections(handles, k, range(G))                     # (sections nobody read: drained before the table is reused)
                 h, hl_prev = h_next, hn
                 x_local.append(y)
 
         elif self.kind in ('lightgcn', 'dgcf'):
             d = widths[0]
             tiled = self._use_xs(d)
-            images = [self.blocks[t].tiled_image(d) if tiled else None for t in range(tp.T)]
+            images = [self.blocks[g].tiled_image(d) if tiled else None for g in range(G)]
             value_free = tiled and all(im.row_scale is not None for im in images)
             tab = self._buffer(('t', 0), (n_tab, d))
             if self.kind == 'dgcf':                                      # layer 1 gathers X_0 . sigmoid(w_1)
@@ -470,17 +505,14 @@ class PartitionedGCNRunner:
                 nxt_local = None if last else (self._buffer(('tl', k + 1), (R, d)) if (self.kind == 'dgcf' or value_free) else y)
                 tab_next = None if last else self._buffer(('t', k + 1), (n_tab, d))
                 gate = self._gate_local(k + 1, layers[k + 1]) if (self.kind == 'dgcf' and not last) else None
-                need = self.needed_types(last)
-                for t in self.phase_order(k):
-                    if t not in need:
-                        continue
-                    blk, rs = self.blocks[t], rows_of[t]
+                for g in self.phase_order(k):
+                    blk, rs = self.blocks[g], rows_of[g]
                     if k > 0:
-                        self._wait_sections(handles, k, reads_of(t, True))
+                        self._wait_sections(handles, k, reads_of(g, True))
                         self._mark('exchange')
                     kw = dict(acc_in=acc[rs], acc_out=acc_out[rs], acc_div=n_l + 1 if last else None)
                     if tiled:
-                        ops.spmm_xs(images[t], tab, y[rs] if y is not None else None, prescaled=value_free, **kw)
+                        ops.spmm_xs(images[g], tab, y[rs] if y is not None else None, prescaled=value_free, **kw)
                     else:
                         ops.spmm_csr(blk.rowptr, blk.colidx, blk.vals, tab, y[rs] if y is not None else None, **kw)
                     self._mark('spmm')
@@ -488,11 +520,11 @@ class PartitionedGCNRunner:
                         if self.kind == 'dgcf':
                             ops.locality_scale(y[rs], gate[rs], nxt_local[rs])
                         elif value_free:
-                            ops.row_affine(y[rs], images[t].row_scale, nxt_local[rs])
-                        gather_section(k + 1, t, tab_next, nxt_local)
+                            ops.row_affine(y[rs], images[g].row_scale, nxt_local[rs])
+                        gather_section(k + 1, g, tab_next, nxt_local)
                         self._mark('exchange')
                 if k > 0:
-                    self._wait_sections(handles, k, range(tp.T))
+                    self._wait_sections(handles, k, range(G))
                 acc, tab = acc_out, tab_next
             gather_items('mean', acc)
             self._mark('exchange')
@@ -513,7 +545,6 @@ class PartitionedGCNRunner:
                 f, c = widths[k], widths[k + 1]
                 last = k == n_l - 1
                 y = self._buffer(('y', k), (R, c), zero=True)
-                need = self.needed_types(last)
                 if not last:
                     if self.kind == 'sage':
                         tab_next = self._buffer(('t', k + 1), (n_tab, c))
@@ -525,13 +556,11 @@ class PartitionedGCNRunner:
                         sn_next = self._buffer(('sn', k + 1), (n_tab,))
                         sn_local = self._buffer(('snl', k + 1), (R,))
                 if k > 0:                                                # (these kinds read their own rows from the table, and GAT reduces s_neigh over
-                    self._wait_sections(handles, k, range(tp.T))         #  all of it: every section of table k lands before the layer starts)
-                    self._wait_sections(handles, ('sn', k), range(tp.T))
+                    self._wait_sections(handles, k, range(G))            #  all of it: every section of table k lands before the layer starts)
+                    self._wait_sections(handles, ('sn', k), range(G))
                     self._mark('exchange')
-                for t in self.phase_order(k):
-                    if t not in need:
-                        continue
-                    blk, rs, own = self.blocks[t], rows_of[t], own_of[t]
+                for g in self.phase_order(k):
+                    blk, rs, own = self.blocks[g], rows_of[g], own_of[g]
                     if self.kind == 'sage':
                         agg = self._buffer(('agg', k), (R, f))
                         ops.spmm_xs(blk.tiled_mean_image(f, layer.self_loops), tab, agg[rs], prescaled=True)
@@ -552,16 +581,16 @@ class PartitionedGCNRunner:
                         else:
                             ops.gat_xs(blk.xcd_sliced(), tab, s_self, s_neigh, layer.bias, y[rs], self_loop=layer.add_self_loops)
                     self._mark('spmm')
-                    if t == item:
+                    if g == item_group:
                         gather_items(k, y)
                     if not last:
                         if self.kind == 'sage':
-                            gather_section(k + 1, t, tab_next, y)
+                            gather_section(k + 1, g, tab_next, y)
                         else:
                             ops.rowwise_xw(y[rs], nxt.kernel.view(-1, c2), h_local[rs], a_self=nxt.attn_kernel_self.view(c2),
                                            a_neigh=nxt.attn_kernel_neighs.view(c2), s_self=ss_next[own], s_neigh=sn_local[rs])
-                            gather_section(k + 1, t, tab_next, h_local)
-                            handles[(('sn', k + 1), t)] = self._gather(sn_next[sect_of[t]], sn_local[rs], defer=True)
+                            gather_section(k + 1, g, tab_next, h_local)
+                            handles[(('sn', k + 1), g)] = self._gather(sn_next[sect_of[g]], sn_local[rs], defer=True)
                     self._mark('exchange')
                 if not last:
                     tab = tab_next
@@ -662,7 +691,9 @@ class PartitionedGCNRunner:
     def phase_times(self):
         """Milliseconds of the last eager step by phase (HIP events on the compute stream): `replicated` = work every rank repeats
         whatever the world size (X_0 . W_1 over all rows, the item tower), `local` = work that shrinks with it (SpMM blocks, user
-        tower, pair stage), `exchange` = time the compute stream spent issuing and waiting for all-gathers."""
+        tower, pair stage), `exchange` = `exposed_exchange` = time the compute stream spent issuing all-gathers and WAITING for the
+        sections / item rows it needs next (the collectives themselves run on RCCL's stream behind the other types' launches: what
+        shows here is the part of the exchange that compute did not cover, plus the host-side issue gaps of an eager step)."""
         if not getattr(self, '_marks', None):
             return None
         self._marks[-1][1].synchronize()
@@ -670,7 +701,7 @@ class PartitionedGCNRunner:
         for (_, e0), (name, e1) in zip(self._marks[:-1], self._marks[1:]):
             out[name] = out.get(name, 0.0) + e0.elapsed_time(e1)
         spmm, pairs = out.get('spmm', 0.0), out.get('pairs', 0.0)
-        return {'local_spmm_ms': spmm, 'exchange_ms': out.get('exchange', 0.0),
+        return {'local_spmm_ms': spmm, 'exchange_ms': out.get('exchange', 0.0), 'exposed_exchange_ms': out.get('exchange', 0.0),
                 'replicated_ms': out.get('prologue', 0.0) + out.get('item_tower', 0.0),
                 'user_tower_ms': out.get('user_tower', 0.0), 'towers_ms': out.get('towers', 0.0) + out.get('item_bert', 0.0), 'pair_stage_ms': pairs,
                 'prologue_ms': out.get('prologue', 0.0), 'item_tower_ms': out.get('item_tower', 0.0)}
@@ -728,9 +759,12 @@ class PartitionedGCNRunner:
         return None if ph is None else ph['prologue_ms'] + ph['local_spmm_ms'] + ph['exchange_ms']
 
     def describe(self):
-        return ('node-range partition over {} GPUs (equal-height blocks per node type, nnz imbalance {:.3f}, pair imbalance {:.3f}), per layer one '
-                'launch and one RCCL all-gather per node type (the next gathered table, type-major) + one of the item rows, in flight behind the '
-                'other types\' launches; pairs sharded by the same user ranges').format(self.world, self.nnz_imbalance, self.pair_imbalance)
+        how = ('per layer one launch and one RCCL all-gather per group of node types {} (the next gathered table, group-major), each in flight '
+               'behind the other group\'s launch'.format(self.tpart.groups) if self.tpart.G > 1 else
+               'per layer one launch and one RCCL all-gather of the next gathered table (rank-major)')
+        return ('node-range partition over {} GPUs (equal-height blocks per node type, nnz imbalance {:.3f}, pair imbalance {:.3f}), {} + one '
+                'all-gather of the item rows behind the next kernels; pairs sharded by the same user ranges').format(
+                    self.world, self.nnz_imbalance, self.pair_imbalance, how)
 
 
 def make_runner(model, u_ids, i_ids, rank=0, world=1, dist=None):

@@ -32,7 +32,7 @@ Layout (all int32, device):
                   row of the wave; column 0)
     stream_start  [T*W]              first word of every (tile, wave) stream
     wsteps        [T, W, maxwin+1]   step index (stream-relative) at which window w of the tile begins for the
-                                     wave; entry n_win[t] holds the stream's padded step count
+                                     wave; entry n_win[t] holds the number of steps that hold entries of the stream
     tile_row0     [T+1]              row range of every tile;  n_win [T]
     vstart        [n_rows+1]         first virtual row of every row, numbered from 0 inside its tile
                                      (vstart[tile_row0[t]] = 0; the last row of a tile ends at vstart_end[t])
@@ -424,7 +424,7 @@ class LdsTiled:
         e0 = torch.cumsum(cnt, 2) - cnt                               # entries of the stream before the window
         wsteps = torch.empty((T, W, maxwin + 1), dtype=torch.int64, device=dev)
         wsteps[:, :, :maxwin] = e0 // eps
-        end_steps = (len_tw // eps).view(T, W, 1)
+        end_steps = ((cnt_tw + eps - 1) // eps).view(T, W, 1)          # the steps that hold entries (the padding's steps are not walked)
         beyond = torch.arange(maxwin + 1, device=dev).view(1, 1, -1) >= n_win.view(T, 1, 1)
         wsteps = torch.where(beyond, end_steps.expand(T, W, maxwin + 1), wsteps)
         return cls(F, words, stream_start.to(torch.int32), wsteps.to(torch.int32).contiguous(),

@@ -374,7 +374,7 @@ class _LockstepGather:
                                   'BasicGCN-ranges-xs', 'BasicGCN-ranges-xs-valuefree', 'BasicGCN-ranges-lt-valuefree',
                                   'BasicGAT-ranges-lt', 'BasicGraphSage-lt', 'BasicLightGCN-ranges', 'BasicDGCF-ranges', 'BasicGraphSage-ranges'])
 def test_partitioned_runner_with_real_kernels(hip, world, case, monkeypatch):
-    """parallel.PartitionedGCNRunner (typed node-range partition, rank-major gathered tables, per-layer gathers) driving the real HIP
+    """parallel.PartitionedGCNRunner (typed node-range partition, group-major gathered tables, per-layer gathers) driving the real HIP
     kernels: `world` rank threads on one GPU, the collective replaced by an in-process copy.  Every rank's own blocks, gathered item
     rows and the scores of its pair shard must match the single-GPU model — all five layer kinds, with and without a known user / item
     split, on every image form of the row blocks.  'HybridBertGCN-uip' is the shape of BASELINE config 4
@@ -417,6 +417,8 @@ def test_partitioned_runner_with_real_kernels(hip, world, case, monkeypatch):
             monkeypatch.setenv('AMAR_XS_VALUES', '1')          # ... in their valued form (the host filter keeps the factors too now)
         if '-lt' in case:
             monkeypatch.setenv('AMAR_SPMM_LT', '1')            # ... or on the LDS-tiled walk (a graph this small fails the density rule)
+    # both schedules of a layer: one launch + one gather per group of node types (the exchange behind compute), or one of each per layer
+    monkeypatch.setenv('AMAR_PART_PHASES', '1' if world in (2, 8) else '0')
     fake = _LockstepGather(world)
     results, errors = [None] * world, []
 

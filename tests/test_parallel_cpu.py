@@ -66,10 +66,10 @@ class NumpyOps:
         out.copy_((a if b is None else a + b) * scale[:, None])
 
 
-def _typed_worker(rank, world, port, out_dir):
+def _typed_worker(rank, world, port, out_dir, phases):
     """The typed partition (GCN stack of a model that knows its user / item split): equal-height blocks per node type, per layer one
     all-gather of the next gathered table and one of the item rows."""
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), AMAR_PART_PHASES=phases)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         from deep_cbrs_amar_renaissance_amd import engine, parallel
@@ -81,7 +81,7 @@ def _typed_worker(rank, world, port, out_dir):
         helpers.randomize_biases(model, seed=3)
         u, i = torch.from_numpy(g['u_ids']), torch.from_numpy(g['i_ids'])
         runner = parallel.PartitionedGCNRunner(model, u, i, rank, world, ops=NumpyOps, dist=dist, timing=False)
-        assert runner.typed
+        assert runner.typed and runner.tpart.G == (2 if phases == '1' else 1)
         x_local, x_items = runner.propagate_typed()
         runner.wait_exchange()
         # LightGCN ('mean' over the layers, accumulated on the rank's own rows) on the same partition; and a model that does not know
@@ -110,13 +110,14 @@ def _typed_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(180)
+@pytest.mark.parametrize('phases', ['1', '0'])
 @pytest.mark.parametrize('world', [2, 3])
-def test_typed_partition_matches_oracle(tmp_path, world):
+def test_typed_partition_matches_oracle(tmp_path, world, phases):
     from oracle import models as om
     from deep_cbrs_amar_renaissance_amd import engine
     from deep_cbrs_amar_renaissance_amd.models import basic
     from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter
-    mp.spawn(_typed_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_typed_worker, args=(world, _free_port(), str(tmp_path), phases), nprocs=world, join=True)
     engine.set_seed(42)
     g = helpers.tiny_graph(n_users=70, n_items=45, n_ratings=1500, seed=8, n_props=25, n_links=90)
     model = basic.BasicGCN(g['adj'], **GRID1)
@@ -135,9 +136,9 @@ def test_typed_partition_matches_oracle(tmp_path, world):
             cols = slice(8 * (k + 1), 8 * (k + 2))
             # the gathered item rows are the item table in the reference's item order, on every rank
             assert helpers.rel_err(z['xi%d' % k][:ni], want[nu:nu + ni, cols]) < 1e-5
-            # the rank's own block, type after type at the block offsets (the LAST layer's property rows are not computed: no tower reads them)
+            # the rank's own block, type after type at the block offsets
             for t, (lo, hi) in enumerate(z['owned']):
-                if hi > lo and not (k == 1 and t == 2):
+                if hi > lo:
                     assert helpers.rel_err(z['xl%d' % k][z['off'][t]:z['off'][t] + hi - lo], want[lo:hi, cols]) < 1e-5
         ulo, uhi = z['owned'][0]
         assert ((z['u_ids'] >= ulo) & (z['u_ids'] < uhi)).all()                     # pairs follow their user's owner
@@ -147,7 +148,7 @@ def test_typed_partition_matches_oracle(tmp_path, world):
         # LightGCN: the mean over the layers for the rank's own rows and, gathered, for every item
         assert helpers.rel_err(z['light_items'][:ni], want_light[nu:nu + ni]) < 1e-5
         for t, (lo, hi) in enumerate(z['owned']):
-            if hi > lo and t != 2:                                                   # (properties stop one layer early: nobody reads their mean)
+            if hi > lo:
                 assert helpers.rel_err(z['light_local'][z['off'][t]:z['off'][t] + hi - lo], want_light[lo:hi]) < 1e-5
         # no user / item split known: one type, the "item" gather is the whole table
         lo, hi = z['blind_rows']
@@ -164,23 +165,37 @@ def test_typed_partition_matches_oracle(tmp_path, world):
 def test_typed_partition_layout():
     from deep_cbrs_amar_renaissance_amd.parallel import TypedPartition
     for bounds, world in (([0, 70, 115, 140], 4), ([0, 6036, 9228], 8), ([0, 3, 5], 8), ([0, 10, 10, 17], 2)):
-        tp = TypedPartition(bounds, world)
-        n = bounds[-1]
-        ids = torch.arange(n)
-        p = tp.padded_index(ids)
-        assert len(torch.unique(p)) == n and int(p.max()) < world * tp.R
-        assert torch.equal(tp.node_of_row('cpu')[p].long(), ids) and int((tp.node_of_row('cpu') >= 0).sum()) == n
-        for t in range(tp.T):
-            spans = [tp.owned(r, t) for r in range(world)]
-            assert spans[0][0] == bounds[t] and spans[-1][1] == bounds[t + 1]
-            assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:])) and all(hi - lo <= tp.h[t] for lo, hi in spans)
-            # a type's rows, taken out of the blocks in rank order, are the type in id order: block r starts at r * h_t
-            for r, (lo, hi) in enumerate(spans):
-                if hi > lo:
-                    assert lo - bounds[t] == r * tp.h[t]
-                    assert torch.equal(p[lo:hi], tp.toff[t] + r * tp.h[t] + torch.arange(hi - lo))        # type-major: block r of section t
-                    assert tp.block_row0(r, t) == tp.toff[t] + r * tp.h[t] and tp.section(t) == (tp.toff[t], tp.toff[t] + world * tp.h[t])
-        assert world * tp.R - n <= sum(world for _ in range(tp.T)) + sum(tp.h)   # padding: O(world) rows per type (+ a short last block)
+        T = len(bounds) - 1
+        for groups in (None, [list(range(T))]) + (([[0, 2], [1]],) if T == 3 else ()):
+            tp = TypedPartition(bounds, world, groups=groups)
+            n = bounds[-1]
+            ids = torch.arange(n)
+            p = tp.padded_index(ids)
+            assert len(torch.unique(p)) == n and int(p.max()) < world * tp.R
+            assert torch.equal(tp.node_of_row('cpu')[p].long(), ids) and int((tp.node_of_row('cpu') >= 0).sum()) == n
+            assert tp.R == sum(tp.h) and tp.goff[-1] == world * tp.R and sum(tp.gh) == tp.R
+            for t in range(tp.T):
+                g = tp.group_of[t]
+                spans = [tp.owned(r, t) for r in range(world)]
+                assert spans[0][0] == bounds[t] and spans[-1][1] == bounds[t + 1]
+                assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:])) and all(hi - lo <= tp.h[t] for lo, hi in spans)
+                # a type's rows, taken out of the blocks in rank order, are the type in id order: block r starts at r * h_t
+                for r, (lo, hi) in enumerate(spans):
+                    if hi > lo:
+                        assert lo - bounds[t] == r * tp.h[t]
+                        # group-major tables: rank r's block of group g starts at block_row0(r, g), the type at its offset inside the block
+                        assert torch.equal(p[lo:hi], tp.block_row0(r, g) + tp.in_group[t] + torch.arange(hi - lo))
+                        assert tp.section(g)[0] <= int(p[lo]) and int(p[hi - 1]) < tp.section(g)[1]
+                        assert torch.equal(tp.group_of_row(p[lo:hi]), torch.full((hi - lo,), g))
+            if groups is None:                                      # one group per type: type-major, a type's section IS the type in id order
+                for t in range(tp.T):
+                    assert torch.equal(p[bounds[t]:bounds[t + 1]], tp.goff[t] + torch.arange(bounds[t + 1] - bounds[t]))
+            elif len(groups) == 1:                                  # one group: the rank-major layout of round 3
+                for t in range(tp.T):
+                    for r in range(world):
+                        lo, hi = tp.owned(r, t)
+                        assert torch.equal(p[lo:hi], r * tp.R + tp.off[t] + torch.arange(hi - lo))
+            assert world * tp.R - n <= sum(world for _ in range(tp.T)) + sum(tp.h)   # padding: O(world) rows per type (+ a short last block)
 
 
 def _free_port():

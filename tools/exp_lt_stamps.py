@@ -50,13 +50,14 @@ def main():
         world = int(sys.argv[4]) if len(sys.argv) > 4 else 8
         rank = int(sys.argv[5]) if len(sys.argv) > 5 else 0
         tp = TypedPartition([0, data['n_users'], n], world)
-        blk = tp.local_block(a, rank)
+        blk = tp.local_block(a, rank, int(os.environ.get('EXP_TYPE', 0)))       # (round 4: one row block per node type)
+        os.environ['AMAR_SPMM_LT'] = '1'
         img = blk.tiled_image(F)
         x = torch.randn((world * tp.R, F), device=dev)
-        y = torch.empty((tp.R, F), device=dev)
+        y = torch.empty((blk.shape[0], F), device=dev)
         run = lambda: capi.spmm_xs(img, x, y, prescaled=True)
-        breaks = blk.row_breaks
-        n = tp.R
+        breaks = ()
+        n = blk.shape[0]
     elif what == 'gat':
         from tools.exp_gat_lt import edge_csr
         os.environ['AMAR_SPMM_LT'] = '1'

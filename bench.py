@@ -752,7 +752,8 @@ def main():
         if rehearse:
             dist.init_process_group('gloo')
         else:
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+            import datetime
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank), timeout=datetime.timedelta(seconds=300))   # (a stuck collective ends the run instead of hanging it)
 
     from deep_cbrs_amar_renaissance_amd import capi, engine
     from deep_cbrs_amar_renaissance_amd.data import synthetic
@@ -873,7 +874,22 @@ def main():
         t = torch.tensor([dt, eager_dt], device=cdev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt, eager_dt = float(t[0].item()), float(t[1].item())
-        mine = dict(phases or {}, rank=rank, rows=int(runner.local_rows), nnz=int(runner.local_nnz), pairs=int(runner.u_ids.numel()))
+        # Self-check of the partitioned step (after the timed region): every rank runs the SINGLE-GPU step on the same inputs once (it
+        # holds the whole graph) and compares the scores of its own pair shard — the multi-rank exchange has nothing else to vouch
+        # for it on a node the builder never had (the oracle-checked tests cover 2-3 ranks over gloo and rank threads on one GPU).
+        diff = float('nan')
+        if hasattr(runner, 'pair_index') and os.environ.get('AMAR_BENCH_SELF_CHECK', '1') != '0':
+            try:
+                ref = parallel.SingleRunner(model, u_all, i_all).step().view(-1)
+                got = runner.step().view(-1)
+                diff = float((got - ref[runner.pair_index]).abs().max()) if got.numel() else 0.0
+                del ref, got
+            except Exception as exc:
+                sys.stderr.write("bench.py: rank {}: self-check against the single-GPU step failed to run ({})\n".format(rank, exc))
+            a_hat.__dict__.pop('_lt_cache', None)
+            torch.cuda.empty_cache()
+        mine = dict(phases or {}, rank=rank, rows=int(runner.local_rows), nnz=int(runner.local_nnz), pairs=int(runner.u_ids.numel()),
+                    max_abs_score_diff_vs_single_gpu=diff)
         per_rank = [None] * world
         torch.distributed.all_gather_object(per_rank, mine)
 
@@ -930,6 +946,11 @@ def main():
         if spread is not None and not multi:
             out['value_spread_boxes'] = spread
         if per_rank is not None:
+            diffs = [r.get('max_abs_score_diff_vs_single_gpu', float('nan')) for r in per_rank]
+            out['multi_rank_parity'] = {'max_abs_score_diff_vs_single_gpu': max(diffs) if all(d == d for d in diffs) else None,
+                                        'ok': bool(all(d == d and d < 1e-5 for d in diffs)),
+                                        'note': 'every rank re-ran the single-GPU step on the same inputs after the timed region and compared the scores of its pair shard '
+                                                '(two fp32 summation orders of the same arithmetic: expected <= 1e-6)'}
             out['per_rank'] = {'ranks': per_rank,
                                'note': 'one EAGER step by phase on every rank, HIP events on the compute stream: local_spmm_ms and pair_stage_ms '
                                        'shrink with the rank count, replicated_ms (X_0 . W_1 over all rows + the item tower) does not, exposed_exchange_ms '

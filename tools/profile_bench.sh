@@ -7,7 +7,7 @@ OUT=$1; SCALE=${2:-64}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 ROOT=$(pwd)
-ARGS="$ROOT/bench.py --scale $SCALE --steps 5 --warmup 2 --no-cpu-baseline"
+ARGS="$ROOT/bench.py --scale $SCALE --steps 5 --warmup 2 --no-cpu-baseline --no-s256"
 cd /tmp
 echo "== kernel trace" ; date
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/trace" -- python $ARGS > "$ROOT/$OUT/trace.log" 2>&1

@@ -152,7 +152,7 @@ class LdsTiled:
 
     @classmethod
     def build(cls, rows, cols, n_rows, n_cols, F, diag, row_scale, col_scale, diag_offset=0, window_entries=None, n_cu=N_CU,
-              split=SPLIT, balance=True, row_breaks=(), rw=None, split_growth=2.0, pairs=None, layout=None, sub_window=None, spread=None):
+              split=SPLIT, balance=True, row_breaks=(), rw=None, split_growth=2.0, pairs=None, layout=None, sub_window=None, spread=None, colsort=None):
         """`rows`/`cols`: int64 device tensors of the unit-weight off-diagonal entries (multiplicities expanded).
         `rw`: LDS rows per wave when the tile is smaller than the plain sum's (GAT mode); `split_growth`: factor by which the
         virtual-row length grows while the tiles do not fit the LDS (longer virtual rows repeat more often inside a step).
@@ -391,6 +391,19 @@ class LdsTiled:
             spread = int(os.environ.get('AMAR_LT_SPREAD', 0))
         if spread:
             dest = _spread_repeats(dest, lrow_s, tw_s, stream_start, cnt_tw, eps, rw, total, int(spread))
+        if colsort is None:
+            colsort = os.environ.get('AMAR_LT_COLSORT') == '1'
+        if colsort and pairs is False and m:
+            # inside a step the slots are interchangeable once no pair logic reads them: order a step's entries by COLUMN, so that
+            # entries of one 128-byte line of X sit in neighbouring lanes of the gather (development: does the L1's tag path care?)
+            step_ = dest // eps
+            o5 = torch.argsort(step_ * n_cols + cols[order])
+            s5 = step_[o5]
+            first5 = torch.ones(m, dtype=torch.bool, device=dev)
+            first5[1:] = s5[1:] != s5[:-1]
+            dest = dest.clone()
+            dest[o5] = s5 * eps + (idx - _run_starts(first5, idx))
+            del o5, s5, first5, step_
         word = (lrow_s << cbits) | cols[order]
         # d. inside every step: the first entry of a virtual row is plain; the one in the next slot (same DPP row) is an implicit
         #    pair; every other repeat is flagged

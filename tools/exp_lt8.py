@@ -58,6 +58,8 @@ def main():
         kw = {}
         if int(spread):
             kw['spread'] = int(spread)
+        if layout.endswith('+c'):
+            layout, kw['colsort'] = layout[:-2], True
         if layout != 'deal':
             kw.update(layout=layout, sub_window=int(sub) or None)
         t0 = time.perf_counter()

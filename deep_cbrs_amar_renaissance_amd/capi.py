@@ -64,6 +64,8 @@ SIGNATURES = {
     'amar_act_bwd_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I32, _I32, _P]),
     'amar_wgrad_scratch_floats': (ctypes.c_int64, [_I64, _I32, _I32]),
     'amar_wgrad_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I32, _I32, _P, _P, _P, _P]),
+    'amar_dense_bwd_workspace_floats': (ctypes.c_int64, [_I64, _I32, _I32]),
+    'amar_dense_bwd_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I32, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _P]),
     'amar_bce_grad_f32': (ctypes.c_int, [_P, _I64, _P, _P, _P, _I64, _P]),
     'amar_scatter_add_rows_f32': (ctypes.c_int, [_P, _I64, _P, _I32, _P, _I64, _I64, _I32, _P]),
     'amar_add_inplace_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I32, _F32, _P]),
@@ -832,6 +834,48 @@ def wgrad(X, dZ, dW=None, db=None):
                               _ptr(dZ, torch.float32, 'dZ'), _ld(dZ, 'dZ'), M, K, N,
                               _ptr(dW, torch.float32, 'dW'), _ptr(db, torch.float32, 'db'), _ptr(scratch), _stream())
     _check(code, 'amar_wgrad_f32')
+
+
+def dense_bwd_supported(K, N):
+    """amar_dense_bwd_f32 can take this layer (act', dX, dW, db: two launches instead of four)."""
+    return 1 <= K <= 128 and 1 <= N <= 128
+
+
+def dense_bwd_enabled():
+    """Whether the training tapes use amar_dense_bwd_f32 (AMAR_DENSE_BWD=1).  Off by default: measured at ml1m(s=1), BasicGCN 16 x 2,
+    batch 1 024 (tools/exp_train.py 1 table5, same box): 0.48 s per epoch with it, 0.46 without — a replayed training batch is not
+    bound by its launch count."""
+    return os.environ.get('AMAR_DENSE_BWD', '0') == '1'
+
+
+def dense_bwd_workspace(M, K, N, device):
+    """A workspace for dense_bwd calls of this shape (allocate once, reuse every batch: it holds the workgroups' partial gradients)."""
+    n = int(load().amar_dense_bwd_workspace_floats(int(M), int(K), int(N)))
+    return torch.zeros(max(n, 4), dtype=torch.float32, device=device)
+
+
+def dense_bwd(X, Y, dY, W, act, workspace, dX=None, dW=None, db=None):
+    """The reverse pass of one Dense layer in two launches instead of four (amar_dense_bwd_f32): dZ = dY * act'(Y); dX = dZ . W^T; dW = X^T . dZ;
+    db = column sums of dZ.  Y is the layer's OUTPUT (None with act None: dY already is dZ); any of dX / dW / db may be None."""
+    M, N = dY.shape
+    K = W.shape[0] if W is not None else X.shape[1]
+    if dX is not None and (W is None or tuple(W.shape) != (K, N) or not W.is_contiguous() or tuple(dX.shape) != (M, K)):
+        raise ValueError("dense_bwd: W [K, N] contiguous and dX [M, K] expected")
+    if dW is not None and (X is None or tuple(X.shape) != (M, K) or tuple(dW.shape) != (K, N) or not dW.is_contiguous()):
+        raise ValueError("dense_bwd: X [M, K] and dW [K, N] contiguous expected")
+    if db is not None and (db.numel() != N or not db.is_contiguous()):
+        raise ValueError("dense_bwd: db must be a contiguous [N] vector")
+    if Y is not None and tuple(Y.shape) != (M, N):
+        raise ValueError("dense_bwd: Y [M, N] expected")
+    lib = load()
+    if workspace is None or workspace.numel() < lib.amar_dense_bwd_workspace_floats(M, K, N):
+        raise ValueError("dense_bwd: workspace too small (capi.dense_bwd_workspace)")
+    code = lib.amar_dense_bwd_f32(
+        _ptr(X, torch.float32, 'X'), _ld(X, 'X') if X is not None else 0, _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y') if Y is not None else 0,
+        _ptr(dY, torch.float32, 'dY'), _ld(dY, 'dY'), _ptr(W, torch.float32, 'W'), ACT_CODES[act],
+        _ptr(dX, torch.float32, 'dX'), _ld(dX, 'dX') if dX is not None else 0, _ptr(dW, torch.float32, 'dW'), _ptr(db, torch.float32, 'db'),
+        _ptr(workspace, torch.float32, 'workspace'), M, K, N, _stream())
+    _check(code, 'amar_dense_bwd_f32')
 
 
 def bce_grad(p, y, dz, loss_terms):

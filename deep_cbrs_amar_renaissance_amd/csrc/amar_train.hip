@@ -504,9 +504,160 @@ unsigned grid1d(int64_t total) {
     return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
 }
 
+// ---- the reverse pass of ONE Dense layer in two launches (round 4) -------------------------------------------------------------------
+// dZ = dY * act'(Y);  dX = dZ . W^T;  dW = X^T . dZ;  db = column sums of dZ  — what act_bwd + wgrad (two launches) + dense(W^T) did in
+// four launches of 5-10 us each, ~30 launches of a ~90-launch training batch at ml1m(s=1) (a batch is launch-latency, not throughput).
+// A workgroup owns 64 S rows (S sub-tiles of 64, so that at most 32 workgroups leave partials): X, dZ and W tiles in LDS, both products on
+// v_mfma_f32_16x16x4_f32 (round 3's attempt did them with scalar LDS-fed FMAs), dW accumulated in registers over the sub-tiles; its
+// K x N partial of dW and its partial of db go to the workspace, which reduce_partials2_kernel adds in workgroup order — a fixed
+// order: the gradients are reproducible bit for bit, no float atomics.  (A first version let the LAST workgroup to finish add the
+// partials behind a ticket: one workgroup adding 16 x 2 352 values from other XCDs' L2s took longer than the launch it saved —
+// 0.74 s per epoch against 0.50 with the separate kernels.)
+constexpr int DB_ROWS = 64, DB_MAXD = 128, DB_THREADS = 256, DB_MAX_GROUPS = 32;
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+struct DenseBwdArgs {
+    const float *X; int64_t ldx; const float *Y; int64_t ldy; const float *dY; int64_t lddy; const float *W;
+    float *dX; int64_t lddx; float *part_w; float *part_b; int64_t M; int K, N, act, subtiles;
+};
+
+__host__ __device__ inline int dense_bwd_subtiles(int64_t M) {
+    const int64_t tiles = (M + DB_ROWS - 1) / DB_ROWS;
+    return (int)((tiles + DB_MAX_GROUPS - 1) / DB_MAX_GROUPS < 1 ? 1 : (tiles + DB_MAX_GROUPS - 1) / DB_MAX_GROUPS);
+}
+
+template <int MAXT>                                                   // 16 x 16 tiles of dW per wave (4 waves): 4 covers K, N <= 64
+__global__ __launch_bounds__(DB_THREADS) void dense_bwd_kernel(const DenseBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float db_lds[];
+    const int Kp = (a.K + 15) & ~15, Np = (a.N + 15) & ~15;
+    const int sx = Kp + 2, sz = Np + 2, sw = Np + 2;                  // row strides: (stride / 2) odd -> the column walks of the MFMA operands spread over the banks
+    float *xs = db_lds;                                               // [64][sx]   X tile (zero beyond K and M)
+    float *zs = xs + DB_ROWS * sx;                                    // [64][sz]   dZ tile
+    float *ws = zs + DB_ROWS * sz;                                    // [Kp][sw]   W (zero beyond K, N)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, l4 = lane >> 4;
+    const int kt_n = Kp >> 4, nt_n = Np >> 4;
+    if (a.W)
+        for (int e = tid; e < Kp * Np; e += DB_THREADS) {
+            const int k = e / Np, n = e - k * Np;
+            ws[k * sw + n] = (k < a.K && n < a.N) ? a.W[(int64_t)k * a.N + n] : 0.f;
+        }
+    v4f accw[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) accw[t] = v4f{0.f, 0.f, 0.f, 0.f};
+    float accb = 0.f;
+    for (int sub = 0; sub < a.subtiles; ++sub) {
+        const int64_t r0 = ((int64_t)blockIdx.x * a.subtiles + sub) * DB_ROWS;
+        if (r0 >= a.M) break;
+        __syncthreads();                                             // (the previous sub-tile's operands are no longer read)
+        for (int e = tid; e < DB_ROWS * Np; e += DB_THREADS) {
+            const int r = e / Np, n = e - r * Np;
+            const int64_t m = r0 + r;
+            float v = 0.f;
+            if (m < a.M && n < a.N) v = act_grad(a.dY[m * a.lddy + n], a.Y ? a.Y[m * a.ldy + n] : 0.f, a.Y ? a.act : AMAR_ACT_NONE);
+            zs[r * sz + n] = v;
+        }
+        if (a.X)
+            for (int e = tid; e < DB_ROWS * Kp; e += DB_THREADS) {
+                const int r = e / Kp, k = e - r * Kp;
+                const int64_t m = r0 + r;
+                xs[r * sx + k] = (m < a.M && k < a.K) ? a.X[m * a.ldx + k] : 0.f;
+            }
+        __syncthreads();
+        // dX tile [64 x K] = dZ [64 x N] . W^T [N x K]: A[m][n] = dZ, B[n][k] = W[k][n]
+        if (a.dX)
+            for (int tile = wave; tile < 4 * kt_n; tile += DB_THREADS / 64) {
+                const int mt = tile / kt_n, kt = tile - mt * kt_n;
+                v4f acc = {0.f, 0.f, 0.f, 0.f};
+                const float *ap = zs + (16 * mt + l16) * sz + l4, *bp = ws + (16 * kt + l16) * sw + l4;
+                for (int n0 = 0; n0 < Np; n0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[n0], bp[n0], acc, 0, 0, 0);
+                const int col = 16 * kt + l16;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t m = r0 + 16 * mt + 4 * l4 + i;
+                    if (m < a.M && col < a.K) a.dX[m * a.lddx + col] = acc[i];
+                }
+            }
+        // dW [K x N] += X^T [K x 64] . dZ [64 x N]: A[k][r] = X[r][k], B[r][n] = dZ[r][n]; tile t of this wave = wave + 4 t
+        if (a.part_w) {
+#pragma unroll
+            for (int t = 0; t < MAXT; ++t) {
+                const int tile = wave + (DB_THREADS / 64) * t;
+                if (tile < kt_n * nt_n) {
+                    const int kt = tile / nt_n, nt = tile - kt * nt_n;
+                    const float *ap = xs + l4 * sx + 16 * kt + l16, *bp = zs + l4 * sz + 16 * nt + l16;
+                    v4f acc = accw[t];
+                    for (int r = 0; r < DB_ROWS; r += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[r * sx], bp[r * sz], acc, 0, 0, 0);
+                    accw[t] = acc;
+                }
+            }
+        }
+        if (a.part_b && tid < a.N)
+            for (int r = 0; r < DB_ROWS; ++r) accb += zs[r * sz + tid];
+    }
+    if (a.part_w) {
+        float *mine = a.part_w + (int64_t)blockIdx.x * a.K * a.N;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) {
+            const int tile = wave + (DB_THREADS / 64) * t;
+            if (tile < kt_n * nt_n) {
+                const int kt = tile / nt_n, nt = tile - kt * nt_n, n = 16 * nt + l16;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = 16 * kt + 4 * l4 + i;
+                    if (k < a.K && n < a.N) mine[(int64_t)k * a.N + n] = accw[t][i];
+                }
+            }
+        }
+    }
+    if (a.part_b && tid < a.N) a.part_b[(int64_t)blockIdx.x * a.N + tid] = accb;
+}
+
 }  // namespace
 
 extern "C" {
+
+int64_t amar_dense_bwd_workspace_floats(int64_t M, int32_t K, int32_t N) {
+    if (M < 0 || K < 0 || N < 1) return AMAR_EINVAL;
+    const int64_t rows = (int64_t)DB_ROWS * dense_bwd_subtiles(M);
+    return 4 + ((M + rows - 1) / rows) * ((int64_t)K * N + N);
+}
+
+int amar_dense_bwd_f32(const float *X, int64_t ldx, const float *Y, int64_t ldy, const float *dY, int64_t lddy, const float *W,
+                       int32_t act, float *dX, int64_t lddx, float *dW, float *db, float *workspace,
+                       int64_t M, int32_t K, int32_t N, amar_stream_t stream) {
+    if (M < 0 || K < 1 || N < 1 || !dY || lddy < N || (!dX && !dW && !db)) return AMAR_EINVAL;
+    if (Y && ldy < N) return AMAR_EINVAL;
+    if (act != AMAR_ACT_NONE && act != AMAR_ACT_RELU && act != AMAR_ACT_SIGMOID) return AMAR_EINVAL;
+    if (act != AMAR_ACT_NONE && !Y) return AMAR_EINVAL;
+    if (dX && (!W || lddx < K)) return AMAR_EINVAL;
+    if (dW && (!X || ldx < K)) return AMAR_EINVAL;
+    if ((dW || db) && !workspace) return AMAR_EINVAL;
+    if (K > DB_MAXD || N > DB_MAXD) return AMAR_EUNSUPPORTED;
+    if (M == 0) return AMAR_EUNSUPPORTED;                             // (an empty batch: the separate kernels define the zero gradients)
+    const int sub = dense_bwd_subtiles(M);
+    const int64_t groups = (M + (int64_t)DB_ROWS * sub - 1) / ((int64_t)DB_ROWS * sub);
+    float *part_w = dW ? workspace + 4 : nullptr;
+    float *part_b = db ? workspace + 4 + (dW ? groups * (int64_t)K * N : 0) : nullptr;
+    DenseBwdArgs a{dW ? X : nullptr, ldx, act != AMAR_ACT_NONE ? Y : nullptr, ldy, dY, lddy, dX ? W : nullptr, dX, lddx, part_w, part_b, M, K, N, act, sub};
+    const int Kp = (K + 15) & ~15, Np = (N + 15) & ~15;
+    const size_t lds = ((size_t)DB_ROWS * (Kp + 2) + (size_t)DB_ROWS * (Np + 2) + (size_t)Kp * (Np + 2)) * sizeof(float);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if ((Kp >> 4) * (Np >> 4) <= 16) {
+        static bool allowed[AMAR_MAX_DEVICES] = {};
+        if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_bwd_kernel<4>), lds, allowed)) return rc;
+        hipLaunchKernelGGL(dense_bwd_kernel<4>, dim3((unsigned)groups), dim3(DB_THREADS), lds, st, a);
+    } else {
+        static bool allowed[AMAR_MAX_DEVICES] = {};
+        if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_bwd_kernel<16>), lds, allowed)) return rc;
+        hipLaunchKernelGGL(dense_bwd_kernel<16>, dim3((unsigned)groups), dim3(DB_THREADS), lds, st, a);
+    }
+    if (dW && db) hipLaunchKernelGGL(reduce_partials2_kernel, dim3(grid1d((int64_t)K * N + N)), dim3(256), 0, st, part_w, (int64_t)K * N, dW,
+                                     part_b, (int64_t)N, db, (int)groups);
+    else if (dW) hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid1d((int64_t)K * N)), dim3(256), 0, st, part_w, (int)groups, (int64_t)K * N, dW);
+    else if (db) hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid1d((int64_t)N)), dim3(256), 0, st, part_b, (int)groups, (int64_t)N, db);
+    return amar_check_launch();
+}
 
 int amar_act_bwd_f32(const float *dY, int64_t ldd, const float *Y, int64_t ldy, float *dZ, int64_t ldz,
                      int64_t M, int32_t N, int32_t act, amar_stream_t stream) {

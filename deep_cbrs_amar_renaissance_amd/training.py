@@ -55,6 +55,15 @@ class _DenseTape:
     def __init__(self, stack):
         self.layers = list(stack.layers)
         self.inputs, self.outputs = [], []
+        self._workspaces = {}
+
+    def _workspace(self, k, m, kk, n, device):
+        """The workspace of layer k's fused reverse pass for batches of m rows (allocated at the first batch of that shape — an eager
+        one — and reused by every later batch, captured ones included)."""
+        key = (k, int(m), int(kk), int(n))
+        if key not in self._workspaces:
+            self._workspaces[key] = capi.dense_bwd_workspace(m, kk, n, device)
+        return self._workspaces[key]
 
     def forward(self, x):
         self.inputs, self.outputs = [], []
@@ -72,6 +81,20 @@ class _DenseTape:
         need_input_grad is False: constant inputs such as the BERT rows)."""
         for k in range(len(self.layers) - 1, -1, -1):
             layer, x, y = self.layers[k], self.inputs[k], self.outputs[k]
+            kk, n = layer.kernel.shape
+            if capi.dense_bwd_enabled() and capi.dense_bwd_supported(kk, n) and x.shape[0] > 0:
+                # act', dX, dW, db in two launches (amar_dense_bwd_f32; round 4 — four launches of 5-10 us each before)
+                need_dx = not (k == 0 and not need_input_grad)
+                act = None if (last_is_dz and k == len(self.layers) - 1) else layer.activation
+                dw, db = torch.empty_like(layer.kernel), torch.empty_like(layer.bias)
+                dx = torch.empty((x.shape[0], kk), dtype=torch.float32, device=x.device) if need_dx else None
+                capi.dense_bwd(x, y if act is not None else None, dy, layer.kernel.detach() if need_dx else None, act,
+                               self._workspace(k, x.shape[0], kk, n, x.device), dX=dx, dW=dw, db=db)
+                grads[layer.kernel], grads[layer.bias] = dw, db
+                if not need_dx:
+                    return None
+                dy = dx
+                continue
             if last_is_dz and k == len(self.layers) - 1:
                 dz = dy
             else:
@@ -247,6 +270,13 @@ class _StackTape:
             self.inv_cnt = (1.0 / (deg + 1.0)) if self.self_loops else torch.where(deg > 0, 1.0 / deg.clamp(min=1.0), torch.zeros_like(deg))
             self.inv_cnt = self.inv_cnt.contiguous()
         self.cat = self.tape = None
+        self._workspaces = {}
+
+    def _workspace(self, k, m, kk, n, device):
+        key = (k, int(m), int(kk), int(n))
+        if key not in self._workspaces:
+            self._workspaces[key] = capi.dense_bwd_workspace(m, kk, n, device)
+        return self._workspaces[key]
 
     def _slices(self, t):
         offs = self.offs
@@ -350,11 +380,14 @@ class _StackTape:
                 dh = torch.empty((n, c), dtype=torch.float32, device=dev)
                 _spmm(a, dzk, dh)                                     # A_hat^T = A_hat
                 dw, db = torch.empty_like(layer.kernel), torch.empty_like(layer.bias)
-                capi.wgrad(sl(k), dh, dw, None)
+                back = torch.empty((n, f), dtype=torch.float32, device=dev)
+                if capi.dense_bwd_enabled() and capi.dense_bwd_supported(f, c) and n > 0:         # dW = X_k^T . dH and dH . W^T fused
+                    capi.dense_bwd(sl(k), None, dh, layer.kernel.detach(), None, self._workspace(k, n, f, c, dev), dX=back, dW=dw)
+                else:
+                    capi.wgrad(sl(k), dh, dw, None)
+                    capi.dense(dh, layer.kernel.detach(), None, back, act=None, w_transposed=True)
                 capi.wgrad(None, dzk, None, db)
                 grads[layer.kernel], grads[layer.bias] = dw, db
-                back = torch.empty((n, f), dtype=torch.float32, device=dev)
-                capi.dense(dh, layer.kernel.detach(), None, back, act=None, w_transposed=True)
                 capi.add_inplace(dsl(k), back)
             elif self.kind == 'lightgcn':
                 back = torch.empty((n, f), dtype=torch.float32, device=dev)

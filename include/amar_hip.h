@@ -448,6 +448,19 @@ int amar_locality_scale_bwd_f32(const float *dOut, int64_t ldd, const float *X, 
 int amar_act_bwd_f32(const float *dY, int64_t ldd, const float *Y, int64_t ldy, float *dZ, int64_t ldz,
                      int64_t M, int32_t N, int32_t act, amar_stream_t stream);
 int64_t amar_wgrad_scratch_floats(int64_t M, int32_t K, int32_t N);
+/* The reverse pass of ONE Dense layer (Keras Dense inside model.fit: src/models/dense.py:4-17, src/experiment.py:183-188) in two launches
+ * instead of four:
+ *     dZ = dY * act'(Y)   (Y = the layer's OUTPUT; act == AMAR_ACT_NONE or Y == NULL: dY already is dZ)
+ *     dX[M, K] = dZ . W^T (dX == NULL: skipped)      dW[K, N] = X^T . dZ (dW == NULL: skipped)      db[N] = column sums of dZ (or NULL)
+ * Both products on the f32 matrix instruction; at most 32 workgroups leave partial weight / bias gradients in the workspace, which the
+ * second launch adds in workgroup order (a FIXED order: no float atomics, results reproducible bit for bit).
+ * K, N <= 128 (wider layers: AMAR_EUNSUPPORTED — use amar_act_bwd_f32 + amar_wgrad_f32 + amar_dense_f32 with AMAR_DENSE_WT).
+ * workspace: amar_dense_bwd_workspace_floats(M, K, N) floats owned by the caller (scratch: any contents); two calls in flight on
+ * different streams must not share one. */
+int64_t amar_dense_bwd_workspace_floats(int64_t M, int32_t K, int32_t N);
+int amar_dense_bwd_f32(const float *X, int64_t ldx, const float *Y, int64_t ldy, const float *dY, int64_t lddy, const float *W,
+                       int32_t act, float *dX, int64_t lddx, float *dW, float *db, float *workspace,
+                       int64_t M, int32_t K, int32_t N, amar_stream_t stream);
 int amar_wgrad_f32(const float *X, int64_t ldx, const float *dZ, int64_t ldz, int64_t M, int32_t K, int32_t N,
                    float *dW, float *db, float *scratch, amar_stream_t stream);
 int amar_bce_grad_f32(const float *p, int64_t ldp, const float *y, float *dz, float *loss_terms, int64_t B, amar_stream_t stream);

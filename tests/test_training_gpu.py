@@ -99,6 +99,56 @@ def test_training_kernels(hip):
     assert helpers.rel_err(md.cpu().numpy(), m2) < 1e-6 and helpers.rel_err(vd.cpu().numpy(), v2) < 1e-6
 
 
+@pytest.mark.parametrize('M,K,N,act', [(1024, 48, 48, 'relu'), (85, 96, 64, 'relu'), (1024, 64, 1, 'sigmoid'), (1024, 64, 1, None),
+                                         (9228, 16, 16, None), (1, 24, 24, 'relu'), (300, 128, 128, 'relu'), (64, 5, 3, 'sigmoid'), (40000, 32, 8, 'relu')])
+def test_dense_bwd_fused(hip, M, K, N, act):
+    """amar_dense_bwd_f32 (round 4: the reverse pass of one Dense layer in two launches instead of four — act', dX = dZ . W^T, dW = X^T . dZ, db) against
+    float64 arithmetic and against the separate kernels it replaces; strided operands (column slices of wider buffers, as the
+    classifier's split input gradient and the GCN stack's concat buffer are); any of the outputs left out; called twice on one
+    workspace with bit-identical results."""
+    rng = np.random.default_rng(M + K + N)
+    xw = rng.standard_normal((M, K + 8)).astype(np.float32)            # X is a column slice of a wider buffer
+    w = (rng.standard_normal((K, N)) * 0.3).astype(np.float32)
+    z = (xw[:, 4:4 + K].astype(np.float64) @ w + rng.standard_normal(N) * 0.1)
+    y = (np.maximum(z, 0) if act == 'relu' else 1 / (1 + np.exp(-z)) if act == 'sigmoid' else z).astype(np.float32)
+    dyw = rng.standard_normal((M, N + 4)).astype(np.float32)           # ... and so is dY
+    x_d, y_d, dy_d, w_d = _t(xw)[:, 4:4 + K], _t(y), _t(dyw)[:, 2:2 + N], _t(w)
+    dy64, y64 = dyw[:, 2:2 + N].astype(np.float64), y.astype(np.float64)
+    dz = dy64 * (y64 > 0) if act == 'relu' else dy64 * y64 * (1 - y64) if act == 'sigmoid' else dy64
+    want_dx, want_dw, want_db = dz @ w.astype(np.float64).T, xw[:, 4:4 + K].astype(np.float64).T @ dz, dz.sum(0)
+    assert hip.dense_bwd_supported(K, N)
+    ws = hip.dense_bwd_workspace(M, K, N, DEV)
+    dxw = torch.zeros((M, K + 3), device=DEV)
+    dx, dw, db = dxw[:, 1:1 + K], torch.empty((K, N), device=DEV), torch.empty(N, device=DEV)
+    hip.dense_bwd(x_d, y_d if act is not None else None, dy_d, w_d, act, ws, dX=dx, dW=dw, db=db)
+    tol = 3e-6
+    assert helpers.rel_err(dx.cpu().numpy(), want_dx) < tol and helpers.rel_err(dw.cpu().numpy(), want_dw) < tol
+    assert helpers.rel_err(db.cpu().numpy(), want_db) < tol
+    assert float(dxw[:, 0].abs().max()) == 0 and float(dxw[:, 1 + K:].abs().max()) == 0        # the strided store stays in its columns
+    dx2, dw2, db2 = torch.empty((M, K), device=DEV), torch.empty((K, N), device=DEV), torch.empty(N, device=DEV)
+    hip.dense_bwd(x_d, y_d if act is not None else None, dy_d, w_d, act, ws, dX=dx2, dW=dw2, db=db2)
+    assert torch.equal(dx2, dx) and torch.equal(dw2, dw) and torch.equal(db2, db)
+    # outputs left out: only the weight gradients (a first layer over constant inputs), only dX + dW (a GCN layer's X_k^T . dH and dH . W^T)
+    dw3, db3 = torch.empty((K, N), device=DEV), torch.empty(N, device=DEV)
+    hip.dense_bwd(x_d, y_d if act is not None else None, dy_d, None, act, ws, dW=dw3, db=db3)
+    assert torch.equal(dw3, dw) and torch.equal(db3, db)
+    dx4, dw4 = torch.empty((M, K), device=DEV), torch.empty((K, N), device=DEV)
+    hip.dense_bwd(x_d, y_d if act is not None else None, dy_d, w_d, act, ws, dX=dx4, dW=dw4)
+    assert torch.equal(dx4, dx) and torch.equal(dw4, dw)
+    # against the kernels it replaces (other summation orders: tolerance, not bits)
+    dz_d = torch.empty((M, N), device=DEV)
+    if act is not None:
+        hip.act_bwd(dy_d, y_d, dz_d, act)
+    else:
+        dz_d.copy_(dy_d)
+    dw5, db5, dx5 = torch.empty((K, N), device=DEV), torch.empty(N, device=DEV), torch.empty((M, K), device=DEV)
+    hip.wgrad(x_d, dz_d, dw5, db5)
+    hip.dense(dz_d, w_d, None, dx5, act=None, w_transposed=True)
+    assert helpers.rel_err(dw.cpu().numpy(), dw5.cpu().numpy().astype(np.float64)) < tol
+    assert helpers.rel_err(dx.cpu().numpy(), dx5.cpu().numpy().astype(np.float64)) < tol
+    assert not hip.dense_bwd_supported(768, 256)                       # the content towers' wide layers keep the separate kernels
+
+
 def test_sage_training_kernels(hip):
     rng = np.random.default_rng(1)
     M, W = 777, 12
@@ -190,10 +240,12 @@ def _flatten_oracle_grads(model, grads):
     return out
 
 
+@pytest.mark.parametrize('fused', [False, True])
 @pytest.mark.parametrize('cls', ['BasicGCN', 'BasicLightGCN'])
 @pytest.mark.parametrize('graph', ['ui', 'uip'])
-def test_gradients_match_oracle(hip, cls, graph):
+def test_gradients_match_oracle(hip, cls, graph, fused, monkeypatch):
     from deep_cbrs_amar_renaissance_amd import engine, training
+    monkeypatch.setenv('AMAR_DENSE_BWD', '1' if fused else '0')     # the tapes on amar_dense_bwd_f32 (off by default: no faster) or on the separate kernels
     from deep_cbrs_amar_renaissance_amd.models import basic
     engine.set_seed(5)
     g = helpers.tiny_graph(n_users=80, n_items=60, n_ratings=1500, seed=9,

@@ -67,6 +67,8 @@ def main():
                                       row_breaks=getattr(a, 'row_breaks', ()), pairs=bool(int(pairs)), **kw)
         if int(pace):
             lt.pace_every = int(pace)
+        if os.environ.get('EXP_NTILES'):                         # only the first tiles of the image (half the CUs idle: how much of a tile's time is the shared L2?)
+            lt.n_tiles = min(lt.n_tiles, int(os.environ['EXP_NTILES']))
         torch.cuda.synchronize()
         t_build = time.perf_counter() - t0
         if int(variant):

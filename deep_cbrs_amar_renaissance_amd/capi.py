@@ -214,7 +214,7 @@ def spmm_sj(sj, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc
 
 
 def spmm_xs(xs, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc_div=None, Wnext=None, Hnext=None,
-            prescaled=False, scale_next=False, xself=None):
+            prescaled=False, scale_next=False, xself=None, rows_needed=None):
     """Y = A.X on the XCD-sliced image `xs` of A (utilities.math.XcdSliced): per-slice partial products with
     XCD <-> L2 affinity, then the combine kernel with the epilogues of spmm_csr / gcn_layer.
 
@@ -228,7 +228,7 @@ def spmm_xs(xs, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc
     X[diag_offset:] — a row block of a partition whose own rows of the gathered table may not have landed yet (parallel.py)."""
     if hasattr(xs, 'words'):
         return spmm_lt(xs, X, Y, bias=bias, relu=relu, acc_in=acc_in, acc_out=acc_out, acc_div=acc_div, Wnext=Wnext, Hnext=Hnext,
-                       prescaled=prescaled, scale_next=scale_next, xself=xself)
+                       prescaled=prescaled, scale_next=scale_next, xself=xself, rows_needed=rows_needed)
     n_rows = xs.shape[0]
     F = X.shape[1]
     flags = (SPMM_BIAS if bias is not None else 0) | (SPMM_RELU if relu else 0)
@@ -284,7 +284,7 @@ def _xself_ptr(xself, X, diag_offset, n_rows, usable):
 
 
 def spmm_lt(lt, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc_div=None, Wnext=None, Hnext=None,
-            prescaled=False, scale_next=False, sage_tail=None, xself=None):
+            prescaled=False, scale_next=False, sage_tail=None, xself=None, rows_needed=None):
     """Y = A.X on the LDS-tiled image `lt` of a value-free A = S C S (utilities.lds_tiled.LdsTiled): one launch, the
     row tile's sums in LDS, gathers in column order.  Keywords as spmm_xs (`prescaled`: X already holds S.X).
     sage_tail = (kernel [2F, F], bias [F]) on GraphSAGE's mean-aggregate image: Y = relu(l2_normalize([X || mean] . kernel + bias))
@@ -329,10 +329,20 @@ def spmm_lt(lt, X, Y=None, bias=None, relu=False, acc_in=None, acc_out=None, acc
     if not getattr(lt, 'pairs', True):
         flags |= SPMM_LT_NOPAIRS
     off = lt.diag_offset
+    n_tiles = lt.n_tiles
+    if rows_needed is not None and rows_needed < n_rows:
+        # only the tiles that hold rows [0, rows_needed): the rows of the others are left as they are (the last layer of a
+        # user-item-property graph: no tower reads its property rows — models/gnn.py `rows_needed`)
+        cache = lt.__dict__.setdefault('_tiles_for_rows', {})
+        if rows_needed not in cache:
+            cache[rows_needed] = int((lt.tile_row0[:-1] < int(rows_needed)).sum())
+        n_tiles = cache[rows_needed]
+        if n_tiles == 0:
+            return
     code = load().amar_spmm_lt_f32(
         _ptr(lt.words, torch.int32, 'words'), _ptr(lt.stream_start, torch.int32, 'stream_start'),
         _ptr(lt.wsteps, torch.int32, 'wsteps'), _ptr(lt.tile_row0, torch.int32, 'tile_row0'), _ptr(lt.n_win, torch.int32, 'n_win'),
-        _ptr(lt.vstart, torch.int32, 'vstart'), _ptr(lt.vcount, torch.int32, 'vcount'), lt.n_tiles, lt.maxwin1, lt.pace_every, _ptr(lt.diag, torch.float32, 'diag'), _ptr(lt.row_scale, torch.float32, 'row_scale'),
+        _ptr(lt.vstart, torch.int32, 'vstart'), _ptr(lt.vcount, torch.int32, 'vcount'), n_tiles, lt.maxwin1, lt.pace_every, _ptr(lt.diag, torch.float32, 'diag'), _ptr(lt.row_scale, torch.float32, 'row_scale'),
         _ptr(X, torch.float32, 'X'), _ld(X, 'X'), X.shape[0], _xself_ptr(xself, X, off, n_rows, prescaled),
         _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y') if Y is not None else 0,
         n_rows, F, flags, _ptr(bias, torch.float32, 'bias'),

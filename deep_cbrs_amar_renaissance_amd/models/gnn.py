@@ -152,9 +152,12 @@ class SequentialGNN(Model):
                 h_next = torch.empty((n, widths[k + 2]), dtype=torch.float32, device=dev) if nxt is not None else None
                 kind = spmm_kind(a, widths[k + 1])
                 if kind == 'xs':
+                    # rows_needed (set by a scoring runner that knows which rows its towers read): the LAST layer's rows past it —
+                    # the property rows of a user-item-property graph, a quarter of its tiles — are not computed
                     capi.spmm_xs(a.tiled_image(widths[k + 1]), h, slices[k + 1], bias=layer.bias, relu=True,
                                  Wnext=nxt.kernel if nxt is not None else None, Hnext=h_next,
-                                 prescaled=pre, scale_next=pre and nxt is not None)
+                                 prescaled=pre, scale_next=pre and nxt is not None,
+                                 rows_needed=getattr(self, 'rows_needed', None) if nxt is None else None)
                 elif kind == 'sj':
                     capi.spmm_sj(a.sliced(widths[k + 1]), h, slices[k + 1], bias=layer.bias, relu=True,
                                  Wnext=nxt.kernel if nxt is not None else None, Hnext=h_next)

@@ -233,10 +233,25 @@ class SingleRunner:
             from deep_cbrs_amar_renaissance_amd.models.basic import PairPlan
             self.pair_plan = PairPlan(u_ids, i_ids)
 
+    def _propagate(self):
+        """model.gnn(None) for a scoring step: the towers read user and item rows only, so the LAST layer's rows past them (the
+        property rows of a user-item-property graph) need not be computed — `rows_needed` on the stack for the duration of the call
+        (the table a caller of model.gnn(None) gets is always complete)."""
+        seq = getattr(self.model.gnn, 'gnn_layers', None)
+        nu, ni = self.model.n_users, self.model.n_items
+        hint = seq is not None and nu is not None and ni is not None and os.environ.get('AMAR_ROWS_NEEDED', '1') != '0'
+        if hint:
+            seq.rows_needed = int(nu) + int(ni)
+        try:
+            return self.model.gnn(None)
+        finally:
+            if hint:
+                seq.rows_needed = None
+
     def step(self):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        emb = self.model.gnn(None)
+        emb = self._propagate()
         e1.record()
         self._events = (e0, e1)
         return self._score(emb)
@@ -258,7 +273,7 @@ class SingleRunner:
             from deep_cbrs_amar_renaissance_amd.engine import capture_graph
 
             def body():
-                emb = self.model.gnn(None)
+                emb = self._propagate()
                 return self._score(emb)
             state['graph'], state['out'] = capture_graph(body)
             state['key'] = key

@@ -148,6 +148,48 @@ def test_layer_by_layer_equals_fused(hip):
     assert torch.equal(fused, torch.cat(parts, dim=1))
 
 
+def test_scoring_runner_skips_the_last_layers_unread_rows(hip, monkeypatch):
+    """parallel.SingleRunner on a user-item-PROPERTY graph (round 4): the towers read user and item rows only, so the last layer's
+    property tiles are not launched (`rows_needed` on the stack for the duration of the runner's propagation, LDS-tiled image).  The
+    scores are the bits of the full propagation's, and model.gnn(None) still returns a complete table afterwards."""
+    from deep_cbrs_amar_renaissance_amd import engine, parallel
+    from deep_cbrs_amar_renaissance_amd.models import basic
+    from deep_cbrs_amar_renaissance_amd.utilities.math import gcn_filter_device
+    engine.set_seed(11)
+    g = helpers.tiny_graph(n_users=300, n_items=200, n_ratings=9000, seed=12, n_props=400, n_links=1500)
+    coo = g['adj'].tocoo()
+    keep = coo.row < coo.col
+    adj = gcn_filter_device(torch.from_numpy(coo.row[keep].astype(np.int64)).cuda(), torch.from_numpy(coo.col[keep].astype(np.int64)).cuda(), coo.shape[0])
+    monkeypatch.setenv('AMAR_SPMM_KIND', 'xs')
+    monkeypatch.setenv('AMAR_SPMM_LT', '1')                    # (a graph this small fails the density rule)
+    model = basic.BasicGCN(adj, **GRID1)
+    model.n_users, model.n_items = 300, 200
+    helpers.randomize_biases(model, seed=4)
+    rng = np.random.default_rng(0)
+    u = torch.from_numpy(rng.integers(0, 300, 4000).astype(np.int32)).cuda()
+    i = torch.from_numpy(rng.integers(300, 500, 4000).astype(np.int32)).cuda()
+    lt = adj.tiled_image(8)
+    assert hasattr(lt, 'words') and int((lt.tile_row0[:-1] < 500).sum()) < lt.n_tiles, "the property rows must have tiles of their own"
+    runner = parallel.SingleRunner(model, u, i)
+    monkeypatch.setenv('AMAR_ROWS_NEEDED', '0')
+    full = runner.step().clone()
+    monkeypatch.setenv('AMAR_ROWS_NEEDED', '1')
+    skipped = runner.step().clone()
+    assert torch.equal(skipped, full)
+    replayed = runner.step_graphed().clone()
+    assert torch.equal(replayed, full)
+    want = model((u, i))
+    assert torch.equal(full.view(-1), want.view(-1))
+    table = model.gnn(None)                                     # outside the runner: every row of every layer
+    e_want = om_propagate(g['adj'], model)
+    assert helpers.rel_err(table.cpu().numpy(), e_want) < 2e-6
+
+
+def om_propagate(adj, model):
+    from oracle import models as om
+    return om.propagate(adj, helpers.gnn_to_oracle(model.gnn), np.float64)
+
+
 def test_faithful_equals_hoisted_and_predict(hip, ml1m_s1):
     """Per-batch re-propagation (basic.py:61-63) and the hoisted single propagation give identical scores."""
     from deep_cbrs_amar_renaissance_amd.models import basic

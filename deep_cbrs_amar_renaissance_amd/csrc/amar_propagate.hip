@@ -682,7 +682,6 @@ __device__ __forceinline__ int lt_lds_row(int v) {                    // virtual
 template <int F, int OFF32, bool FUSE_NEXT, int U, int PACE, int ABL = 0, bool GAT = false, bool SAGE = false, bool PAIRS = true>
 __global__ __launch_bounds__(LT_WAVES * AMAR_WAVE, AMAR_LT_MIN_WAVES) void spmm_lt_kernel(const LtArgs a) {
     constexpr int LPN = F / 4, EPS = AMAR_WAVE / LPN, RW = GAT ? lt_gat_rw(F) : LT_TILE_BYTES / (4 * F * LT_WAVES), CS = LT_CHUNK / EPS;
-    constexpr unsigned LMASK = (1u << lt_bits(RW)) - 1u;
     constexpr int G = U - 1;                                          // steps of gathers in flight ahead of the accumulation
     static_assert(CS % U == 0 && G < CS, "register slots of the in-flight steps must be static inside a chunk");
     extern __shared__ __attribute__((aligned(16))) float lt_lds[];

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Collects the default bench.py lines of this session's gpurun boxes (gpurun_out/**/bench*.json, one fresh box per gpurun call) that
-were measured on the CURRENT csrc/ sources into profiles/r3_bench_repeats.json — what bench.py reports as `value_spread_boxes`.
+were measured on the CURRENT csrc/ sources into profiles/r4_bench_repeats.json (round 3: r3_bench_repeats.json) — what bench.py reports as `value_spread_boxes`.
 Every bench line carries `csrc_sha` (bench.py), so lines of older builds are left out.  usage: python tools/collect_spread.py"""
 import glob
 import json
@@ -14,7 +14,7 @@ import bench
 def main():
     sha = bench.csrc_sha()
     runs = []
-    for path in sorted(glob.glob(os.path.join(ROOT, 'gpurun_out', '**', 'bench*.json'), recursive=True)):
+    for path in sorted(glob.glob(os.path.join(ROOT, 'gpurun_out', '**', '*bench*.json'), recursive=True)):
         try:
             lines = [l for l in open(path).read().splitlines() if l.startswith('{')]
             d = json.loads(lines[-1])
@@ -31,7 +31,7 @@ def main():
     out = {'scale': 64, 'csrc_sha': sha, 'boxes': len(runs), 'min_ms_per_step': min(ms), 'max_ms_per_step': max(ms),
            'min_value': min(r['value'] for r in runs), 'max_value': max(r['value'] for r in runs), 'runs': runs,
            'note': 'default `python bench.py` lines of this build on different gpurun boxes (one fresh MI355X box per call)'}
-    json.dump(out, open(os.path.join(ROOT, 'profiles', 'r3_bench_repeats.json'), 'w'), indent=1)
+    json.dump(out, open(os.path.join(ROOT, 'profiles', 'r4_bench_repeats.json'), 'w'), indent=1)
     print(json.dumps(out, indent=1))
 
 

@@ -16,13 +16,16 @@ Workload: ml1m(s) graph of MovieLens-1M shape scaled by s (default 64: |U| = 386
 under torchrun (WORLD_SIZE set) it is one rank.  Rank 0 prints ONE JSON line.  Extra objects:
 `roofline` (dominant kernel = the fused GCN SpMM layer, algorithmic bytes nnz*8 + (N+1)*4 + 2*N*F*4
 per launch over its HIP-event time), `roofline_onchip` (the same launch against the DISPATCHED kernel's own on-chip
-floors: its L2 request count from this build's counters and its measured no-gather time), `wider_layers` (the fused layer of
-econfigs/basic-gnn.yaml grid2 / grid3: F = 16 / 32 at the same scale), `pair_stage`, `hybrid_head` (econfigs/hybrid-gnn.yaml
-grid1 head at the same scale: MFMA utilisation), `uip_graph` (econfigs/basic-gnn-uip-2relconf.yaml grid1: the same model on
-the user-item-property graph), `train_s1` (one `fit()` epoch at the reference's real size), `ml1m_s1` (the reference's real size) and
-`cpu_baseline` (the oracle on the host: one core and all usable cores on the SAME ml1m(s=1) inputs, plus one hoisted repetition on
-the headline workload itself with the score difference against the GPU leg).  With N > 1 ranks: `per_rank` (every rank's
-local_spmm_ms / exchange_ms / replicated_ms of an eager step).
+floors: its L2 request count from this build's counters and its measured no-gather time), `s256` (the same step on ml1m(s=256):
+the larger scaling workload, single-GPU and multi-rank), `wider_layers` (the fused layer of econfigs/basic-gnn.yaml grid2 / grid3:
+F = 16 / 32 at the same scale), `pair_stage`, `hybrid_head` (econfigs/hybrid-gnn.yaml grid1 head at the same scale: MFMA utilisation
+as EXECUTED instructions over the dense peak of that instruction), `uip_graph` (econfigs/basic-gnn-uip-2relconf.yaml grid1: the same
+model on the user-item-property graph), `model_families` (BasicLightGCN / BasicGraphSage / BasicGAT steps at the same scale),
+`train_s1` (one `fit()` epoch at the reference's real size), `ml1m_s1` (the reference's real size) and `cpu_baseline` — the oracle on
+the host: `value` / `cores` / `sample` are ONE hoisted repetition ON THE HEADLINE WORKLOAD (threads stated, score difference against
+the GPU leg), the ml1m(s=1) legs (one core, faithful, the BLAS pool sweep) nest under `ml1m_s1`.  With N > 1 ranks: `per_rank` (every
+rank's local_spmm_ms / exposed_exchange_ms / replicated_ms of an eager step and its score difference against the single-GPU step)
+and `multi_rank_parity`.
 """
 import argparse
 import hashlib

@@ -64,7 +64,9 @@ SIGNATURES = {
     'amar_act_bwd_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _I64, _I32, _I32, _P]),
     'amar_wgrad_scratch_floats': (ctypes.c_int64, [_I64, _I32, _I32]),
     'amar_wgrad_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I32, _I32, _P, _P, _P, _P]),
+    'amar_dense_stack_f32': (ctypes.c_int, [_P, _I64, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I64, _P]),
     'amar_dense_bwd_workspace_floats': (ctypes.c_int64, [_I64, _I32, _I32]),
+    'amar_dense_bwd_groups': (ctypes.c_int64, [_I64]),
     'amar_dense_bwd_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I32, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _P]),
     'amar_bce_grad_f32': (ctypes.c_int, [_P, _I64, _P, _P, _P, _I64, _P]),
     'amar_scatter_add_rows_f32': (ctypes.c_int, [_P, _I64, _P, _I32, _P, _I64, _I64, _I32, _P]),
@@ -776,10 +778,21 @@ def adam_dev(w, g, m, v, state, beta_1, beta_2, epsilon, l2=0.0):
     _check(code, 'amar_adam_dev_f32')
 
 
+class DeferredGradient:
+    """A weight / bias gradient still in partial sums: `partials` [groups, n] (a view of a dense_bwd workspace), to be added in group
+    order by its consumer (adam_slot_table -> amar_adam_multi_f32's g_groups).  `materialize()` adds them on the spot."""
+
+    def __init__(self, partials, groups, shape):
+        self.partials, self.groups, self.shape = partials, int(groups), tuple(shape)
+
+    def materialize(self):
+        return self.partials.view(self.groups, -1).sum(0).view(self.shape)
+
+
 class AdamSlot(ctypes.Structure):
     """include/amar_hip.h: amar_adam_slot"""
     _fields_ = [('w', ctypes.c_void_p), ('g', ctypes.c_void_p), ('m', ctypes.c_void_p), ('v', ctypes.c_void_p),
-                ('n', ctypes.c_int64), ('first_block', ctypes.c_int64), ('l2', ctypes.c_float), ('pad_', ctypes.c_float)]
+                ('n', ctypes.c_int64), ('first_block', ctypes.c_int64), ('l2', ctypes.c_float), ('g_groups', ctypes.c_int32)]
 
 
 def adam_slot_table(entries):
@@ -787,10 +800,17 @@ def adam_slot_table(entries):
     table = (AdamSlot * len(entries))()
     block = 0
     for k, (w, g, m, v, l2) in enumerate(entries):
+        groups = 0
+        if isinstance(g, DeferredGradient):                          # partial gradients [groups][n] left by dense_bwd(defer=True)
+            g, groups = g.partials, g.groups
+            if g.numel() != groups * w.numel():
+                raise ValueError("adam_slot_table: deferred gradient of the wrong size")
+        elif g.numel() != w.numel():
+            raise ValueError("adam_slot_table: gradient of the wrong size")
         if not (w.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()) or \
-                not (w.numel() == g.numel() == m.numel() == v.numel()):
+                not (w.numel() == m.numel() == v.numel()):
             raise ValueError("adam_slot_table: contiguous tensors of equal size expected")
-        table[k] = AdamSlot(w.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), w.numel(), block, float(l2), 0.0)
+        table[k] = AdamSlot(w.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), w.numel(), block, float(l2), int(groups))
         block += (w.numel() + 1023) // 1024
     host = torch.frombuffer(bytearray(bytes(table)), dtype=torch.uint8).clone()
     return host, block
@@ -846,16 +866,53 @@ def wgrad(X, dZ, dW=None, db=None):
     _check(code, 'amar_wgrad_f32')
 
 
+def dense_stack_supported(dims):
+    """amar_dense_stack_f32 takes a stack of these widths (at most 4 layers, every width <= 128)."""
+    return 2 <= len(dims) <= 5 and all(1 <= int(d) <= 128 for d in dims)
+
+
+def dense_stack(X, weights, biases, acts, outs, ids=None, xcopy=None):
+    """A Dense stack forward in one launch with every layer's output kept (amar_dense_stack_f32): y_0 = X[ids], outs[l] = act_l(y_l . W_l + b_l).
+    outs[l] may be column slices of wider buffers; xcopy ([M, K_0]): also receives the gathered input rows."""
+    n = len(weights)
+    M = int(ids.numel()) if ids is not None else int(X.shape[0])
+    dims = [int(weights[0].shape[0])] + [int(w.shape[1]) for w in weights]
+    if X.shape[1] != dims[0] or len(biases) != n or len(acts) != n or len(outs) != n:
+        raise ValueError("dense_stack: X [*, K_0] and one kernel / bias / activation / output per layer expected")
+    for l, (w, b, y) in enumerate(zip(weights, biases, outs)):
+        if tuple(w.shape) != (dims[l], dims[l + 1]) or not w.is_contiguous() or tuple(y.shape) != (M, dims[l + 1]):
+            raise ValueError("dense_stack: layer {}: W [K, N] contiguous and Y [M, N] expected".format(l))
+        if b is not None and (b.numel() != dims[l + 1] or not b.is_contiguous()):
+            raise ValueError("dense_stack: layer {}: bias must be a contiguous [N] vector".format(l))
+    if xcopy is not None and tuple(xcopy.shape) != (M, dims[0]):
+        raise ValueError("dense_stack: xcopy must be [M, K_0]")
+    arr_p = ctypes.c_void_p * n
+    wp = arr_p(*[_ptr(w, torch.float32, 'W') for w in weights])
+    bp = arr_p(*[_ptr(b, torch.float32, 'bias') for b in biases])
+    yp = arr_p(*[_ptr(y, torch.float32, 'Y') for y in outs])
+    ld = (ctypes.c_int64 * n)(*[_ld(y, 'Y') for y in outs])
+    dm = (ctypes.c_int32 * (n + 1))(*dims)
+    ac = (ctypes.c_int32 * n)(*[ACT_CODES[a] for a in acts])
+    code = load().amar_dense_stack_f32(_ptr(X, torch.float32, 'X'), _ld(X, 'X'), _ptr(ids, torch.int32, 'ids'),
+                                       _ptr(xcopy, torch.float32, 'xcopy'), _ld(xcopy, 'xcopy') if xcopy is not None else 0, n,
+                                       wp, bp, dm, ac, yp, ld, M, _stream())
+    _check(code, 'amar_dense_stack_f32')
+
+
 def dense_bwd_supported(K, N):
     """amar_dense_bwd_f32 can take this layer (act', dX, dW, db: two launches instead of four)."""
     return 1 <= K <= 128 and 1 <= N <= 128
 
 
 def dense_bwd_enabled():
-    """Whether the training tapes use amar_dense_bwd_f32 (AMAR_DENSE_BWD=1).  Off by default: measured at ml1m(s=1), BasicGCN 16 x 2,
-    batch 1 024 (tools/exp_train.py 1 table5, same box): 0.48 s per epoch with it, 0.46 without — a replayed training batch is not
-    bound by its launch count."""
-    return os.environ.get('AMAR_DENSE_BWD', '0') == '1'
+    """Whether the training tapes use amar_dense_bwd_f32 (AMAR_DENSE_BWD=0: the separate kernels).  Measured at ml1m(s=1), BasicGCN
+    16 x 2, batch 1 024 (tools/profile_train.sh): 703 ms of kernel time per 1 482 batches against 768."""
+    return os.environ.get('AMAR_DENSE_BWD', '1') != '0'
+
+
+def dense_stack_enabled():
+    """Whether the training tapes run a Dense stack's forward as ONE launch (amar_dense_stack_f32; AMAR_DENSE_STACK=0: layer by layer)."""
+    return os.environ.get('AMAR_DENSE_STACK', '1') != '0'
 
 
 def dense_bwd_workspace(M, K, N, device):
@@ -864,7 +921,10 @@ def dense_bwd_workspace(M, K, N, device):
     return torch.zeros(max(n, 4), dtype=torch.float32, device=device)
 
 
-def dense_bwd(X, Y, dY, W, act, workspace, dX=None, dW=None, db=None):
+DENSE_BWD_DEFER = 0x100
+
+
+def dense_bwd(X, Y, dY, W, act, workspace, dX=None, dW=None, db=None, defer=False):
     """The reverse pass of one Dense layer in two launches instead of four (amar_dense_bwd_f32): dZ = dY * act'(Y); dX = dZ . W^T; dW = X^T . dZ;
     db = column sums of dZ.  Y is the layer's OUTPUT (None with act None: dY already is dZ); any of dX / dW / db may be None."""
     M, N = dY.shape
@@ -882,10 +942,17 @@ def dense_bwd(X, Y, dY, W, act, workspace, dX=None, dW=None, db=None):
         raise ValueError("dense_bwd: workspace too small (capi.dense_bwd_workspace)")
     code = lib.amar_dense_bwd_f32(
         _ptr(X, torch.float32, 'X'), _ld(X, 'X') if X is not None else 0, _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y') if Y is not None else 0,
-        _ptr(dY, torch.float32, 'dY'), _ld(dY, 'dY'), _ptr(W, torch.float32, 'W'), ACT_CODES[act],
+        _ptr(dY, torch.float32, 'dY'), _ld(dY, 'dY'), _ptr(W, torch.float32, 'W'), ACT_CODES[act] | (DENSE_BWD_DEFER if defer else 0),
         _ptr(dX, torch.float32, 'dX'), _ld(dX, 'dX') if dX is not None else 0, _ptr(dW, torch.float32, 'dW'), _ptr(db, torch.float32, 'db'),
         _ptr(workspace, torch.float32, 'workspace'), M, K, N, _stream())
     _check(code, 'amar_dense_bwd_f32')
+    if defer:
+        # defer=True: dW / db are NOT written; the partial sums stay in the workspace — returned as DeferredGradients (dW's, db's)
+        g = int(lib.amar_dense_bwd_groups(M))
+        nw = g * K * N if dW is not None else 0
+        return (DeferredGradient(workspace[4:4 + nw], g, (K, N)) if dW is not None else None,
+                DeferredGradient(workspace[4 + nw:4 + nw + g * N], g, (N,)) if db is not None else None)
+    return None
 
 
 def bce_grad(p, y, dz, loss_terms):

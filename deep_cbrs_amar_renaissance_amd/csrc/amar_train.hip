@@ -471,7 +471,9 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const amar_adam_slot *_
         const int64_t i = base + r * 256 + threadIdx.x;
         if (i < sl.n) {
             const float wi = sl.w[i];
-            const float gi = sl.g[i] + l2x2 * wi;
+            float gsum = sl.g[i];
+            for (int c = 1; c < sl.g_groups; ++c) gsum += sl.g[(int64_t)c * sl.n + i];      // deferred partial gradients, in group order
+            const float gi = gsum + l2x2 * wi;
             const float mi = b1 * sl.m[i] + (1.f - b1) * gi;
             const float vi = b2 * sl.v[i] + (1.f - b2) * gi * gi;
             sl.m[i] = mi; sl.v[i] = vi;
@@ -526,7 +528,31 @@ __host__ __device__ inline int dense_bwd_subtiles(int64_t M) {
     return (int)((tiles + DB_MAX_GROUPS - 1) / DB_MAX_GROUPS < 1 ? 1 : (tiles + DB_MAX_GROUPS - 1) / DB_MAX_GROUPS);
 }
 
-template <int MAXT>                                                   // 16 x 16 tiles of dW per wave (4 waves): 4 covers K, N <= 64
+// stage a [rows x cols] tile (cols a multiple of 4 floats, 16-byte aligned source rows) into LDS with row stride `stride`: every
+// thread issues ALL its 16-byte loads before the first LDS store (a loop of load -> store pairs with a run-time trip count serialised
+// the tile's memory round trips: 19 us per launch for three 12 KB tiles)
+template <int MAXP, typename LOAD>
+__device__ __forceinline__ void stage_tile(float *lds, int stride, int rows, int cols_p, int tid, LOAD load) {
+    const int c4n = cols_p >> 2;                                      // float4 columns (<= 32)
+    const int lg = c4n <= 4 ? 2 : c4n <= 8 ? 3 : c4n <= 16 ? 4 : 5;   // threads per row, rounded up to a power of two
+    const int c4 = tid & ((1 << lg) - 1), r_in = tid >> lg, rpp = DB_THREADS >> lg;
+    float4 v[MAXP];
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+        const int r = r_in + p * rpp;
+        v[p] = (r < rows && c4 < c4n) ? load(r, 4 * c4) : f4_zero();
+    }
+#pragma unroll
+    for (int p = 0; p < MAXP; ++p) {
+        const int r = r_in + p * rpp;
+        if (r < rows && c4 < c4n) {
+            float *d = lds + r * stride + 4 * c4;
+            d[0] = v[p].x; d[1] = v[p].y; d[2] = v[p].z; d[3] = v[p].w;
+        }
+    }
+}
+
+template <int MAXT, bool VEC>                                         // MAXT: 16 x 16 tiles of dW per wave (4 waves): 4 covers K, N <= 64
 __global__ __launch_bounds__(DB_THREADS) void dense_bwd_kernel(const DenseBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float db_lds[];
     const int Kp = (a.K + 15) & ~15, Np = (a.N + 15) & ~15;
@@ -537,11 +563,18 @@ __global__ __launch_bounds__(DB_THREADS) void dense_bwd_kernel(const DenseBwdArg
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, l4 = lane >> 4;
     const int kt_n = Kp >> 4, nt_n = Np >> 4;
-    if (a.W)
-        for (int e = tid; e < Kp * Np; e += DB_THREADS) {
-            const int k = e / Np, n = e - k * Np;
-            ws[k * sw + n] = (k < a.K && n < a.N) ? a.W[(int64_t)k * a.N + n] : 0.f;
+    if (a.W) {
+        if (VEC) {
+            auto ldw = [&](int k, int n) { return (k < a.K && n < a.N) ? *reinterpret_cast<const float4 *>(a.W + (int64_t)k * a.N + n) : f4_zero(); };
+            stage_tile<8>(ws, sw, Kp < 64 ? Kp : 64, Np, tid, ldw);
+            if (Kp > 64) stage_tile<8>(ws + 64 * sw, sw, Kp - 64, Np, tid, [&](int k, int n) { return ldw(k + 64, n); });
+        } else {
+            for (int e = tid; e < Kp * Np; e += DB_THREADS) {
+                const int k = e / Np, n = e - k * Np;
+                ws[k * sw + n] = (k < a.K && n < a.N) ? a.W[(int64_t)k * a.N + n] : 0.f;
+            }
         }
+    }
     v4f accw[MAXT];
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) accw[t] = v4f{0.f, 0.f, 0.f, 0.f};
@@ -550,19 +583,35 @@ __global__ __launch_bounds__(DB_THREADS) void dense_bwd_kernel(const DenseBwdArg
         const int64_t r0 = ((int64_t)blockIdx.x * a.subtiles + sub) * DB_ROWS;
         if (r0 >= a.M) break;
         __syncthreads();                                             // (the previous sub-tile's operands are no longer read)
-        for (int e = tid; e < DB_ROWS * Np; e += DB_THREADS) {
-            const int r = e / Np, n = e - r * Np;
-            const int64_t m = r0 + r;
-            float v = 0.f;
-            if (m < a.M && n < a.N) v = act_grad(a.dY[m * a.lddy + n], a.Y ? a.Y[m * a.ldy + n] : 0.f, a.Y ? a.act : AMAR_ACT_NONE);
-            zs[r * sz + n] = v;
-        }
-        if (a.X)
-            for (int e = tid; e < DB_ROWS * Kp; e += DB_THREADS) {
-                const int r = e / Kp, k = e - r * Kp;
+        if (VEC) {
+            stage_tile<8>(zs, sz, DB_ROWS, Np, tid, [&](int r, int n) {
                 const int64_t m = r0 + r;
-                xs[r * sx + k] = (m < a.M && k < a.K) ? a.X[m * a.ldx + k] : 0.f;
+                if (m >= a.M || n >= a.N) return f4_zero();
+                const float4 dy = *reinterpret_cast<const float4 *>(a.dY + m * a.lddy + n);
+                if (!a.Y) return dy;
+                const float4 y = *reinterpret_cast<const float4 *>(a.Y + m * a.ldy + n);
+                return make_float4(act_grad(dy.x, y.x, a.act), act_grad(dy.y, y.y, a.act), act_grad(dy.z, y.z, a.act), act_grad(dy.w, y.w, a.act));
+            });
+            if (a.X)
+                stage_tile<8>(xs, sx, DB_ROWS, Kp, tid, [&](int r, int k) {
+                    const int64_t m = r0 + r;
+                    return (m < a.M && k < a.K) ? *reinterpret_cast<const float4 *>(a.X + m * a.ldx + k) : f4_zero();
+                });
+        } else {
+            for (int e = tid; e < DB_ROWS * Np; e += DB_THREADS) {
+                const int r = e / Np, n = e - r * Np;
+                const int64_t m = r0 + r;
+                float v = 0.f;
+                if (m < a.M && n < a.N) v = act_grad(a.dY[m * a.lddy + n], a.Y ? a.Y[m * a.ldy + n] : 0.f, a.Y ? a.act : AMAR_ACT_NONE);
+                zs[r * sz + n] = v;
             }
+            if (a.X)
+                for (int e = tid; e < DB_ROWS * Kp; e += DB_THREADS) {
+                    const int r = e / Kp, k = e - r * Kp;
+                    const int64_t m = r0 + r;
+                    xs[r * sx + k] = (m < a.M && k < a.K) ? a.X[m * a.ldx + k] : 0.f;
+                }
+        }
         __syncthreads();
         // dX tile [64 x K] = dZ [64 x N] . W^T [N x K]: A[m][n] = dZ, B[n][k] = W[k][n]
         if (a.dX)
@@ -570,6 +619,7 @@ __global__ __launch_bounds__(DB_THREADS) void dense_bwd_kernel(const DenseBwdArg
                 const int mt = tile / kt_n, kt = tile - mt * kt_n;
                 v4f acc = {0.f, 0.f, 0.f, 0.f};
                 const float *ap = zs + (16 * mt + l16) * sz + l4, *bp = ws + (16 * kt + l16) * sw + l4;
+#pragma unroll 4
                 for (int n0 = 0; n0 < Np; n0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[n0], bp[n0], acc, 0, 0, 0);
                 const int col = 16 * kt + l16;
 #pragma unroll
@@ -587,6 +637,7 @@ __global__ __launch_bounds__(DB_THREADS) void dense_bwd_kernel(const DenseBwdArg
                     const int kt = tile / nt_n, nt = tile - kt * nt_n;
                     const float *ap = xs + l4 * sx + 16 * kt + l16, *bp = zs + l4 * sz + 16 * nt + l16;
                     v4f acc = accw[t];
+#pragma unroll 4
                     for (int r = 0; r < DB_ROWS; r += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[r * sx], bp[r * sz], acc, 0, 0, 0);
                     accw[t] = acc;
                 }
@@ -613,9 +664,136 @@ __global__ __launch_bounds__(DB_THREADS) void dense_bwd_kernel(const DenseBwdArg
     if (a.part_b && tid < a.N) a.part_b[(int64_t)blockIdx.x * a.N + tid] = accb;
 }
 
+// ---- a whole Dense stack forward in one launch, every layer's output kept (round 4) ---------------------------------------------------
+// What fit()'s forward pass runs per tower / classifier: y_0 = X[ids], y_{l+1} = act_l(y_l . W_l + b_l), all y_l written out (the reverse
+// pass reads them).  One launch per stack instead of one per layer plus the row gather and the concat copies: a 64-row tile walks the
+// layers with its activations in LDS (two buffers in turn) and the layer's kernel staged next to them; products on v_mfma_f32_16x16x4_f32
+// in ascending k, bias and activation after the sum (the order of operations of amar_dense_f32).
+constexpr int DS_MAX_LAYERS = 4;
+struct DenseStackArgs {
+    const float *X; int64_t ldx; const int32_t *ids; float *Xcopy; int64_t ldxc;
+    const float *W[DS_MAX_LAYERS]; const float *bias[DS_MAX_LAYERS]; float *Y[DS_MAX_LAYERS]; int64_t ldy[DS_MAX_LAYERS];
+    int dims[DS_MAX_LAYERS + 1]; int act[DS_MAX_LAYERS]; int n_layers; int64_t M; int maxd; int vec_x; int vec_w[DS_MAX_LAYERS];
+};
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == AMAR_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == AMAR_ACT_SIGMOID) return 1.f / (1.f + __expf(-v));
+    return v;
+}
+
+__global__ __launch_bounds__(DB_THREADS) void dense_stack_kernel(const DenseStackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float ds_lds[];
+    const int sa = a.maxd + 2;                                        // activation row stride ((stride / 2) odd: maxd is a multiple of 16)
+    float *cur = ds_lds, *nxt = cur + DB_ROWS * sa, *ws = nxt + DB_ROWS * sa;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, l4 = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * DB_ROWS;
+    {
+        const int K = a.dims[0], Kp = (K + 15) & ~15;
+        if (a.vec_x) {
+            stage_tile<8>(cur, sa, DB_ROWS, Kp, tid, [&](int r, int k) {
+                const int64_t m = r0 + r;
+                if (m >= a.M || k >= K) return f4_zero();
+                const float4 v = *reinterpret_cast<const float4 *>(a.X + (a.ids ? (int64_t)a.ids[m] : m) * a.ldx + k);
+                if (a.Xcopy) *reinterpret_cast<float4 *>(a.Xcopy + m * a.ldxc + k) = v;
+                return v;
+            });
+        } else {
+            for (int e = tid; e < DB_ROWS * Kp; e += DB_THREADS) {
+                const int r = e / Kp, k = e - r * Kp;
+                const int64_t m = r0 + r;
+                float v = 0.f;
+                if (m < a.M && k < K) {
+                    v = a.X[(a.ids ? (int64_t)a.ids[m] : m) * a.ldx + k];
+                    if (a.Xcopy) a.Xcopy[m * a.ldxc + k] = v;
+                }
+                cur[r * sa + k] = v;
+            }
+        }
+    }
+    for (int l = 0; l < a.n_layers; ++l) {
+        const int K = a.dims[l], N = a.dims[l + 1], Kp = (K + 15) & ~15, Np = (N + 15) & ~15, sw = Np + 2;
+        if (a.vec_w[l]) {
+            const float *w = a.W[l];
+            auto ldw = [&](int k, int n) { return (k < K && n < N) ? *reinterpret_cast<const float4 *>(w + (int64_t)k * N + n) : f4_zero(); };
+            stage_tile<8>(ws, sw, Kp < 64 ? Kp : 64, Np, tid, ldw);
+            if (Kp > 64) stage_tile<8>(ws + 64 * sw, sw, Kp - 64, Np, tid, [&](int k, int n) { return ldw(k + 64, n); });
+        } else {
+            for (int e = tid; e < Kp * Np; e += DB_THREADS) {
+                const int k = e / Np, n = e - k * Np;
+                ws[k * sw + n] = (k < K && n < N) ? a.W[l][(int64_t)k * N + n] : 0.f;
+            }
+        }
+        __syncthreads();
+        const int nt_n = Np >> 4;
+        for (int tile = wave; tile < 4 * nt_n; tile += DB_THREADS / 64) {
+            const int mt = tile / nt_n, nt = tile - mt * nt_n;
+            v4f acc = {0.f, 0.f, 0.f, 0.f};
+            const float *ap = cur + (16 * mt + l16) * sa + l4, *bp = ws + l4 * sw + 16 * nt + l16;
+#pragma unroll 4
+            for (int k0 = 0; k0 < Kp; k0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[k0], bp[k0 * sw], acc, 0, 0, 0);
+            const int n = 16 * nt + l16;
+            const float b = (n < N && a.bias[l]) ? a.bias[l][n] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 16 * mt + 4 * l4 + i;
+                const int64_t m = r0 + r;
+                const float y = n < N ? act_apply(acc[i] + b, a.act[l]) : 0.f;
+                nxt[r * sa + n] = y;
+                if (m < a.M && n < N) a.Y[l][m * a.ldy[l] + n] = y;
+            }
+        }
+        __syncthreads();
+        float *t = cur; cur = nxt; nxt = t;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int amar_dense_stack_f32(const float *X, int64_t ldx, const int32_t *ids, float *Xcopy, int64_t ldxc, int32_t n_layers,
+                         const float *const *W, const float *const *bias, const int32_t *dims, const int32_t *acts,
+                         float *const *Y, const int64_t *ldy, int64_t M, amar_stream_t stream) {
+    if (M < 0 || !X || n_layers < 1 || !W || !bias || !dims || !acts || !Y || !ldy) return AMAR_EINVAL;
+    if (n_layers > DS_MAX_LAYERS) return AMAR_EUNSUPPORTED;
+    DenseStackArgs a{};
+    a.X = X; a.ldx = ldx; a.ids = ids; a.Xcopy = Xcopy; a.ldxc = ldxc; a.n_layers = n_layers; a.M = M;
+    int maxd = 16;
+    for (int l = 0; l <= n_layers; ++l) {
+        if (dims[l] < 1) return AMAR_EINVAL;
+        if (dims[l] > DB_MAXD) return AMAR_EUNSUPPORTED;
+        a.dims[l] = dims[l];
+        const int dp = (dims[l] + 15) & ~15;
+        if (dp > maxd) maxd = dp;
+    }
+    if (ldx < dims[0] || (Xcopy && ldxc < dims[0])) return AMAR_EINVAL;
+    int maxw = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        if (!W[l] || !Y[l] || ldy[l] < dims[l + 1]) return AMAR_EINVAL;
+        if (acts[l] != AMAR_ACT_NONE && acts[l] != AMAR_ACT_RELU && acts[l] != AMAR_ACT_SIGMOID) return AMAR_EINVAL;
+        a.W[l] = W[l]; a.bias[l] = bias[l]; a.Y[l] = Y[l]; a.ldy[l] = ldy[l]; a.act[l] = acts[l];
+        a.vec_w[l] = ((dims[l + 1] & 3) == 0 && amar_aligned16(W[l])) ? 1 : 0;
+        const int w = ((dims[l] + 15) & ~15) * (((dims[l + 1] + 15) & ~15) + 2);
+        if (w > maxw) maxw = w;
+    }
+    a.maxd = maxd;
+    a.vec_x = ((dims[0] & 3) == 0 && (ldx & 3) == 0 && amar_aligned16(X) && (!Xcopy || ((ldxc & 3) == 0 && amar_aligned16(Xcopy)))) ? 1 : 0;
+    if (M == 0) return AMAR_OK;
+    const int64_t groups = (M + DB_ROWS - 1) / DB_ROWS;
+    if (groups > 0x7fffffff) return AMAR_EUNSUPPORTED;
+    const size_t lds = ((size_t)2 * DB_ROWS * (maxd + 2) + (size_t)maxw) * sizeof(float);
+    static bool allowed[AMAR_MAX_DEVICES] = {};
+    if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_stack_kernel), lds, allowed)) return rc;
+    hipLaunchKernelGGL(dense_stack_kernel, dim3((unsigned)groups), dim3(DB_THREADS), lds, static_cast<hipStream_t>(stream), a);
+    return amar_check_launch();
+}
+
+int64_t amar_dense_bwd_groups(int64_t M) {
+    if (M < 0) return AMAR_EINVAL;
+    const int64_t rows = (int64_t)DB_ROWS * dense_bwd_subtiles(M);
+    return (M + rows - 1) / rows;
+}
 
 int64_t amar_dense_bwd_workspace_floats(int64_t M, int32_t K, int32_t N) {
     if (M < 0 || K < 0 || N < 1) return AMAR_EINVAL;
@@ -626,6 +804,8 @@ int64_t amar_dense_bwd_workspace_floats(int64_t M, int32_t K, int32_t N) {
 int amar_dense_bwd_f32(const float *X, int64_t ldx, const float *Y, int64_t ldy, const float *dY, int64_t lddy, const float *W,
                        int32_t act, float *dX, int64_t lddx, float *dW, float *db, float *workspace,
                        int64_t M, int32_t K, int32_t N, amar_stream_t stream) {
+    const bool defer = (act & AMAR_DENSE_BWD_DEFER) != 0;
+    act &= ~AMAR_DENSE_BWD_DEFER;
     if (M < 0 || K < 1 || N < 1 || !dY || lddy < N || (!dX && !dW && !db)) return AMAR_EINVAL;
     if (Y && ldy < N) return AMAR_EINVAL;
     if (act != AMAR_ACT_NONE && act != AMAR_ACT_RELU && act != AMAR_ACT_SIGMOID) return AMAR_EINVAL;
@@ -643,15 +823,20 @@ int amar_dense_bwd_f32(const float *X, int64_t ldx, const float *Y, int64_t ldy,
     const int Kp = (K + 15) & ~15, Np = (N + 15) & ~15;
     const size_t lds = ((size_t)DB_ROWS * (Kp + 2) + (size_t)DB_ROWS * (Np + 2) + (size_t)Kp * (Np + 2)) * sizeof(float);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if ((Kp >> 4) * (Np >> 4) <= 16) {
-        static bool allowed[AMAR_MAX_DEVICES] = {};
-        if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_bwd_kernel<4>), lds, allowed)) return rc;
-        hipLaunchKernelGGL(dense_bwd_kernel<4>, dim3((unsigned)groups), dim3(DB_THREADS), lds, st, a);
-    } else {
-        static bool allowed[AMAR_MAX_DEVICES] = {};
-        if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_bwd_kernel<16>), lds, allowed)) return rc;
-        hipLaunchKernelGGL(dense_bwd_kernel<16>, dim3((unsigned)groups), dim3(DB_THREADS), lds, st, a);
-    }
+    // 16-byte loads where every operand allows them (K, N and the leading dimensions multiples of 4 floats, 16-byte aligned bases)
+    const bool vec = (K & 3) == 0 && (N & 3) == 0 && (lddy & 3) == 0 && amar_aligned16(dY) && (!a.Y || ((ldy & 3) == 0 && amar_aligned16(Y))) &&
+                     (!a.X || ((ldx & 3) == 0 && amar_aligned16(X))) && (!a.W || amar_aligned16(W));
+    const bool small = (Kp >> 4) * (Np >> 4) <= 16;
+#define AMAR_DB_LAUNCH(MT, VV)                                                                                           \
+    do {                                                                                                                 \
+        static bool allowed[AMAR_MAX_DEVICES] = {};                                                                      \
+        if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_bwd_kernel<MT, VV>), lds, allowed)) return rc;   \
+        hipLaunchKernelGGL((dense_bwd_kernel<MT, VV>), dim3((unsigned)groups), dim3(DB_THREADS), lds, st, a);             \
+    } while (0)
+    if (small) { if (vec) AMAR_DB_LAUNCH(4, true); else AMAR_DB_LAUNCH(4, false); }
+    else { if (vec) AMAR_DB_LAUNCH(16, true); else AMAR_DB_LAUNCH(16, false); }
+#undef AMAR_DB_LAUNCH
+    if (defer) return amar_check_launch();                          // the partials stay in the workspace (amar_adam_multi_f32 adds them)
     if (dW && db) hipLaunchKernelGGL(reduce_partials2_kernel, dim3(grid1d((int64_t)K * N + N)), dim3(256), 0, st, part_w, (int64_t)K * N, dW,
                                      part_b, (int64_t)N, db, (int)groups);
     else if (dW) hipLaunchKernelGGL(reduce_partials_kernel, dim3(grid1d((int64_t)K * N)), dim3(256), 0, st, part_w, (int)groups, (int64_t)K * N, dW);

@@ -56,6 +56,7 @@ class _DenseTape:
         self.layers = list(stack.layers)
         self.inputs, self.outputs = [], []
         self._workspaces = {}
+        self.defer_reduce = False                                    # set by Trainer._graph_body (see capi.DeferredGradient)
 
     def _workspace(self, k, m, kk, n, device):
         """The workspace of layer k's fused reverse pass for batches of m rows (allocated at the first batch of that shape — an eager
@@ -65,10 +66,28 @@ class _DenseTape:
             self._workspaces[key] = capi.dense_bwd_workspace(m, kk, n, device)
         return self._workspaces[key]
 
-    def forward(self, x):
+    def forward(self, x, ids=None, out_last=None):
+        """y = stack(x[ids]) keeping every layer's input and output.  ids: gather the input rows first; out_last: where the last
+        layer's output goes (a column slice of a concatenation buffer).  Stacks of at most four layers no wider than 128 run as ONE
+        launch (amar_dense_stack_f32, round 4: gather, layers and the concat store together); others layer by layer."""
+        m = int(ids.numel()) if ids is not None else int(x.shape[0])
+        dev = x.device
+        dims = [int(self.layers[0].kernel.shape[0])] + [int(l.units) for l in self.layers]
+        outs = [torch.empty((m, l.units), dtype=torch.float32, device=dev) for l in self.layers]
+        if out_last is not None:
+            outs[-1] = out_last
+        if capi.dense_stack_enabled() and capi.dense_stack_supported(dims) and m > 0:
+            xin = torch.empty((m, dims[0]), dtype=torch.float32, device=dev) if ids is not None else None
+            capi.dense_stack(x, [l.kernel.detach() for l in self.layers], [l.bias.detach() for l in self.layers],
+                             [l.activation for l in self.layers], outs, ids=ids, xcopy=xin)
+            self.inputs, self.outputs = [xin if ids is not None else x] + outs[:-1], outs
+            return outs[-1]
+        if ids is not None:
+            gathered = torch.empty((m, dims[0]), dtype=torch.float32, device=dev)
+            capi.copy_columns(x, gathered, ids=ids)
+            x = gathered
         self.inputs, self.outputs = [], []
-        for layer in self.layers:
-            y = torch.empty((x.shape[0], layer.units), dtype=torch.float32, device=x.device)
+        for layer, y in zip(self.layers, outs):
             capi.dense(x, layer.kernel, layer.bias, y, act=layer.activation)
             self.inputs.append(x)
             self.outputs.append(y)
@@ -88,9 +107,10 @@ class _DenseTape:
                 act = None if (last_is_dz and k == len(self.layers) - 1) else layer.activation
                 dw, db = torch.empty_like(layer.kernel), torch.empty_like(layer.bias)
                 dx = torch.empty((x.shape[0], kk), dtype=torch.float32, device=x.device) if need_dx else None
-                capi.dense_bwd(x, y if act is not None else None, dy, layer.kernel.detach() if need_dx else None, act,
-                               self._workspace(k, x.shape[0], kk, n, x.device), dX=dx, dW=dw, db=db)
-                grads[layer.kernel], grads[layer.bias] = dw, db
+                lazy = capi.dense_bwd(x, y if act is not None else None, dy, layer.kernel.detach() if need_dx else None, act,
+                                      self._workspace(k, x.shape[0], kk, n, x.device), dX=dx, dW=dw, db=db, defer=self.defer_reduce)
+                # (defer_reduce: the partial sums stay in the workspace and the batch's ONE Adam launch adds them — no reduction launch)
+                grads[layer.kernel], grads[layer.bias] = lazy if lazy is not None else (dw, db)
                 if not need_dx:
                     return None
                 dy = dx
@@ -124,10 +144,16 @@ class _BasicHead:
     def __init__(self, rs):
         self.unet, self.inet, self.clf = _DenseTape(rs.unet), _DenseTape(rs.inet), _DenseTape(rs.clf)
 
-    def forward(self, gu, gi, bert):
-        tu, ti = self.unet.forward(gu), self.inet.forward(gi)
-        self.d = tu.shape[1]
-        return self.clf.forward(_concat(tu, ti))
+    def forward(self, gu, gi, bert, ids=None):
+        """ids = (u, i): gu and gi are node tables and the towers gather their rows themselves; the towers' last layers store straight
+        into the two halves of the classifier's input (no concat copies)."""
+        d = int(self.unet.layers[-1].units)
+        b = int(ids[0].numel()) if ids is not None else int(gu.shape[0])
+        cat = torch.empty((b, 2 * d), dtype=torch.float32, device=gu.device)
+        self.unet.forward(gu, ids=ids[0] if ids is not None else None, out_last=cat[:, :d])
+        self.inet.forward(gi, ids=ids[1] if ids is not None else None, out_last=cat[:, d:])
+        self.d = d
+        return self.clf.forward(cat)
 
     def backward(self, dz, grads, need_input_grad=True):
         """dz = dL/d(last pre-activation). Returns (dL/dE[u], dL/dE[i]) (None, None when the inputs are constants)."""
@@ -271,6 +297,7 @@ class _StackTape:
             self.inv_cnt = self.inv_cnt.contiguous()
         self.cat = self.tape = None
         self._workspaces = {}
+        self.defer_reduce = False
 
     def _workspace(self, k, m, kk, n, device):
         key = (k, int(m), int(kk), int(n))
@@ -382,7 +409,10 @@ class _StackTape:
                 dw, db = torch.empty_like(layer.kernel), torch.empty_like(layer.bias)
                 back = torch.empty((n, f), dtype=torch.float32, device=dev)
                 if capi.dense_bwd_enabled() and capi.dense_bwd_supported(f, c) and n > 0:         # dW = X_k^T . dH and dH . W^T fused
-                    capi.dense_bwd(sl(k), None, dh, layer.kernel.detach(), None, self._workspace(k, n, f, c, dev), dX=back, dW=dw)
+                    lazy = capi.dense_bwd(sl(k), None, dh, layer.kernel.detach(), None, self._workspace(k, n, f, c, dev), dX=back, dW=dw,
+                                          defer=self.defer_reduce)
+                    if lazy is not None:
+                        dw = lazy[0]
                 else:
                     capi.wgrad(sl(k), dh, dw, None)
                     capi.dense(dh, layer.kernel.detach(), None, back, act=None, w_transposed=True)
@@ -510,13 +540,16 @@ class Trainer:
         dev = self.device
         e = self._propagation_forward()                              # full-graph propagation, every batch (basic.py:61-63)
         f = e.shape[1]
-        gu = torch.empty((b, f), dtype=torch.float32, device=dev)
-        gi = torch.empty((b, f), dtype=torch.float32, device=dev)
-        capi.copy_columns(e, gu, ids=u)
-        capi.copy_columns(e, gi, ids=i)
-        if self.hybrid:
-            rows = (self._bert_rows(u, rows[0] if rows else None), self._bert_rows(i, rows[1] if rows else None))
-        p = self.head.forward(gu, gi, rows)
+        if isinstance(self.head, _BasicHead) and not self.hybrid:    # the towers gather E[u], E[i] themselves (one launch per stack)
+            p = self.head.forward(e, e, rows, ids=(u, i))
+        else:
+            gu = torch.empty((b, f), dtype=torch.float32, device=dev)
+            gi = torch.empty((b, f), dtype=torch.float32, device=dev)
+            capi.copy_columns(e, gu, ids=u)
+            capi.copy_columns(e, gi, ids=i)
+            if self.hybrid:
+                rows = (self._bert_rows(u, rows[0] if rows else None), self._bert_rows(i, rows[1] if rows else None))
+            p = self.head.forward(gu, gi, rows)
         # ---- loss and its gradient through the final sigmoid
         dz = torch.empty((b, 1), dtype=torch.float32, device=dev)
         terms = torch.empty(b, dtype=torch.float32, device=dev)
@@ -547,12 +580,19 @@ class Trainer:
     # -- one batch as a hipGraph ------------------------------------------------------------------------------------
     def _graph_body(self):
         g = self._g
-        terms, grads = self._forward_backward(g['u'], g['i'], g['y'], (g['ub'], g['ib']) if g['ub'] is not None else None)
+        tapes = self._all_tapes()
+        for t in tapes:                                              # weight-gradient partials stay partial: the Adam launch below adds them
+            t.defer_reduce = True
+        try:
+            terms, grads = self._forward_backward(g['u'], g['i'], g['y'], (g['ub'], g['ib']) if g['ub'] is not None else None)
+        finally:
+            for t in tapes:
+                t.defer_reduce = False
         capi.adam_advance(self._adam_state, self.lr, self.b1, self.b2)
         # one launch updates every parameter (a table of slots, uploaded by a captured copy from pinned memory: the
         # gradient buffers of this graph have fixed addresses) and adds the regularisation loss; one more adds the data loss
-        entries = [(prm.data.view(-1), grads[prm].contiguous().view(-1), self.m[prm].view(-1), self.v[prm].view(-1), self._l2(prm))
-                   for prm in self.params]
+        entries = [(prm.data.view(-1), grads[prm] if isinstance(grads[prm], capi.DeferredGradient) else grads[prm].contiguous().view(-1),
+                    self.m[prm].view(-1), self.v[prm].view(-1), self._l2(prm)) for prm in self.params]
         host, blocks = capi.adam_slot_table(entries)
         g['slot_host'][:host.numel()].copy_(host)                    # pinned buffer allocated before the capture began
         g['slot_dev'] = torch.empty(host.numel(), dtype=torch.uint8, device=self._adam_state.device)
@@ -608,6 +648,16 @@ class Trainer:
         g['graph'].replay()
         self.t += 1
         self._dev_t = self.t
+
+    def _all_tapes(self):
+        """Every tape of the trainer that owns a fused reverse pass (Dense stacks of the head, convolution stacks)."""
+        out = list(getattr(self, 'tapes', []) or [])
+        head = getattr(self, 'head', None)
+        for name in ('unet', 'inet', 'clf'):
+            if hasattr(head, name):
+                out.append(getattr(head, name))
+        out.extend(getattr(head, 't', {}).values() if isinstance(getattr(head, 't', None), dict) else [])
+        return [t for t in out if hasattr(t, 'defer_reduce')]
 
     def pop_loss_sum(self):
         """Sum over the batches since the last call of (batch loss x batch size); one host synchronisation."""

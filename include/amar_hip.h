@@ -448,6 +448,14 @@ int amar_locality_scale_bwd_f32(const float *dOut, int64_t ldd, const float *X, 
 int amar_act_bwd_f32(const float *dY, int64_t ldd, const float *Y, int64_t ldy, float *dZ, int64_t ldz,
                      int64_t M, int32_t N, int32_t act, amar_stream_t stream);
 int64_t amar_wgrad_scratch_floats(int64_t M, int32_t K, int32_t N);
+/* A whole Dense stack forward in ONE launch with every layer's output kept (what model.fit's forward pass needs of a tower / classifier:
+ * src/models/dense.py:4-17 called from src/models/basic.py:31-37): y_0 = X[ids] (ids == NULL: X), y_{l+1} = act_l(y_l . W_l + b_l) written to
+ * Y[l] (leading dimension ldy[l]: a column slice of a wider buffer realises `Concatenate`), l < n_layers <= 4, every width <= 128
+ * (else AMAR_EUNSUPPORTED: layer by layer with amar_dense_f32).  W, bias, Y, ldy, dims (n_layers + 1 widths), acts: HOST arrays of device
+ * pointers / values.  Xcopy != NULL: the gathered input rows are also written there (the reverse pass multiplies by them). */
+int amar_dense_stack_f32(const float *X, int64_t ldx, const int32_t *ids, float *Xcopy, int64_t ldxc, int32_t n_layers,
+                         const float *const *W, const float *const *bias, const int32_t *dims, const int32_t *acts,
+                         float *const *Y, const int64_t *ldy, int64_t M, amar_stream_t stream);
 /* The reverse pass of ONE Dense layer (Keras Dense inside model.fit: src/models/dense.py:4-17, src/experiment.py:183-188) in two launches
  * instead of four:
  *     dZ = dY * act'(Y)   (Y = the layer's OUTPUT; act == AMAR_ACT_NONE or Y == NULL: dY already is dZ)
@@ -456,7 +464,12 @@ int64_t amar_wgrad_scratch_floats(int64_t M, int32_t K, int32_t N);
  * second launch adds in workgroup order (a FIXED order: no float atomics, results reproducible bit for bit).
  * K, N <= 128 (wider layers: AMAR_EUNSUPPORTED — use amar_act_bwd_f32 + amar_wgrad_f32 + amar_dense_f32 with AMAR_DENSE_WT).
  * workspace: amar_dense_bwd_workspace_floats(M, K, N) floats owned by the caller (scratch: any contents); two calls in flight on
- * different streams must not share one. */
+ * different streams must not share one.
+ * act | AMAR_DENSE_BWD_DEFER: the second launch is left out — dW / db (still non-NULL to request them) are NOT written; the partials stay
+ * in the workspace as  workspace + 4: [G][K * N] (if dW)  then [G][N] (if db),  G = amar_dense_bwd_groups(M), for a consumer that adds them
+ * itself (amar_adam_multi_f32 with g_groups = G). */
+#define AMAR_DENSE_BWD_DEFER 0x100
+int64_t amar_dense_bwd_groups(int64_t M);
 int64_t amar_dense_bwd_workspace_floats(int64_t M, int32_t K, int32_t N);
 int amar_dense_bwd_f32(const float *X, int64_t ldx, const float *Y, int64_t ldy, const float *dY, int64_t lddy, const float *W,
                        int32_t act, float *dX, int64_t lddx, float *dW, float *db, float *workspace,
@@ -486,7 +499,10 @@ int amar_adam_advance_f32(float *state, float learning_rate, float beta_1, float
  * first_block_{k+1}) of 1024 elements each, first_block_0 = 0, total_blocks = sum of ceil(n / 1024)); the update of
  * amar_adam_dev_f32.  If loss_acc != NULL, reg_scale * l2 * sum(w^2) of the pre-update weights is added to *loss_acc (the
  * regularisation part of the loss Keras reports).  amar_sum_into_f32: *acc += scale * sum(x) (the data part). */
-typedef struct amar_adam_slot { float *w; const float *g; float *m; float *v; int64_t n; int64_t first_block; float l2; float pad_; } amar_adam_slot;
+typedef struct amar_adam_slot { float *w; const float *g; float *m; float *v; int64_t n; int64_t first_block; float l2; int32_t g_groups; } amar_adam_slot;
+/* g_groups == 0: g[n] is the gradient.  g_groups = G > 0: g holds G partial gradients [G][n] (what amar_dense_bwd_f32 leaves in its
+ * workspace with AMAR_DENSE_BWD_DEFER) and the gradient is their sum in the order 0 .. G-1 — the reduction launch of every layer folded
+ * into the one Adam launch (same order of additions as the explicit reduction: the same bits). */
 int amar_adam_multi_f32(const amar_adam_slot *slots, int32_t n_slots, int64_t total_blocks, const float *state, float beta_1,
                         float beta_2, float epsilon, float reg_scale, float *loss_acc, amar_stream_t stream);
 int amar_sum_into_f32(const float *x, int64_t n, float scale, float *acc, amar_stream_t stream);

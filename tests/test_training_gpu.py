@@ -149,6 +149,40 @@ def test_dense_bwd_fused(hip, M, K, N, act):
     assert not hip.dense_bwd_supported(768, 256)                       # the content towers' wide layers keep the separate kernels
 
 
+@pytest.mark.parametrize('M,dims,acts,gather', [(1024, [24, 24, 24], ['relu', 'relu'], True), (85, [96, 64, 64, 1], ['relu', 'relu', 'sigmoid'], False),
+                                               (1024, [48, 48, 48, 48, 1], ['relu', 'relu', 'relu', 'sigmoid'], False), (3, [5, 7, 3], ['relu', None], True),
+                                               (300, [128, 128, 16], ['relu', 'relu'], False)])
+def test_dense_stack_one_launch(hip, M, dims, acts, gather):
+    """amar_dense_stack_f32 (round 4: a Dense stack's forward in one launch, every layer's output kept, optional row gather and a strided
+    last output) against float64 and against amar_dense_f32 layer by layer."""
+    rng = np.random.default_rng(M + sum(dims))
+    n_src = 500
+    x = rng.standard_normal((n_src if gather else M, dims[0])).astype(np.float32)
+    ids = rng.integers(0, n_src, M).astype(np.int32) if gather else None
+    ws = [(rng.standard_normal((dims[l], dims[l + 1])) * 0.3).astype(np.float32) for l in range(len(acts))]
+    bs = [(rng.standard_normal(dims[l + 1]) * 0.1).astype(np.float32) for l in range(len(acts))]
+    assert hip.dense_stack_supported(dims)
+    outs = [torch.empty((M, d), device=DEV) for d in dims[1:]]
+    wide = torch.zeros((M, dims[-1] + 5), device=DEV)                  # the last output is a column slice of a wider buffer
+    outs[-1] = wide[:, 2:2 + dims[-1]]
+    xcopy = torch.empty((M, dims[0]), device=DEV) if gather else None
+    hip.dense_stack(_t(x), [_t(w) for w in ws], [_t(b) for b in bs], acts, outs, ids=_t(ids) if gather else None, xcopy=xcopy)
+    cur = x[ids].astype(np.float64) if gather else x.astype(np.float64)
+    if gather:
+        assert np.array_equal(xcopy.cpu().numpy(), x[ids])
+    ref_in = _t(x[ids] if gather else x)
+    for l, act in enumerate(acts):
+        z = cur @ ws[l].astype(np.float64) + bs[l]
+        cur = np.maximum(z, 0) if act == 'relu' else 1 / (1 + np.exp(-z)) if act == 'sigmoid' else z
+        assert helpers.rel_err(outs[l].cpu().numpy(), cur) < 3e-6, l
+        ref = torch.empty((M, dims[l + 1]), device=DEV)
+        hip.dense(ref_in, _t(ws[l]), _t(bs[l]), ref, act=act)
+        assert helpers.rel_err(outs[l].cpu().numpy(), ref.cpu().numpy().astype(np.float64)) < 3e-6, l
+        ref_in = ref
+    assert float(wide[:, :2].abs().max()) == 0 and float(wide[:, 2 + dims[-1]:].abs().max()) == 0
+    assert not hip.dense_stack_supported([768, 256, 64]) and not hip.dense_stack_supported([8, 8, 8, 8, 8, 8])
+
+
 def test_sage_training_kernels(hip):
     rng = np.random.default_rng(1)
     M, W = 777, 12
@@ -245,7 +279,8 @@ def _flatten_oracle_grads(model, grads):
 @pytest.mark.parametrize('graph', ['ui', 'uip'])
 def test_gradients_match_oracle(hip, cls, graph, fused, monkeypatch):
     from deep_cbrs_amar_renaissance_amd import engine, training
-    monkeypatch.setenv('AMAR_DENSE_BWD', '1' if fused else '0')     # the tapes on amar_dense_bwd_f32 (off by default: no faster) or on the separate kernels
+    monkeypatch.setenv('AMAR_DENSE_BWD', '1' if fused else '0')     # the tapes on amar_dense_bwd_f32 / amar_dense_stack_f32 (the default) or on the separate kernels
+    monkeypatch.setenv('AMAR_DENSE_STACK', '1' if fused else '0')
     from deep_cbrs_amar_renaissance_amd.models import basic
     engine.set_seed(5)
     g = helpers.tiny_graph(n_users=80, n_items=60, n_ratings=1500, seed=9,

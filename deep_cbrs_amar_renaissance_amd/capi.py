@@ -67,7 +67,7 @@ SIGNATURES = {
     'amar_dense_stack_f32': (ctypes.c_int, [_P, _I64, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I64, _P]),
     'amar_dense_bwd_workspace_floats': (ctypes.c_int64, [_I64, _I32, _I32]),
     'amar_dense_bwd_groups': (ctypes.c_int64, [_I64]),
-    'amar_dense_bwd_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I32, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _P]),
+    'amar_dense_bwd_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I32, _P, _I64, _P, _P, _P, _I64, _P, _I64, _I32, _I32, _P]),
     'amar_bce_grad_f32': (ctypes.c_int, [_P, _I64, _P, _P, _P, _I64, _P]),
     'amar_scatter_add_rows_f32': (ctypes.c_int, [_P, _I64, _P, _I32, _P, _I64, _I64, _I32, _P]),
     'amar_add_inplace_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I32, _F32, _P]),
@@ -924,11 +924,14 @@ def dense_bwd_workspace(M, K, N, device):
 DENSE_BWD_DEFER = 0x100
 
 
-def dense_bwd(X, Y, dY, W, act, workspace, dX=None, dW=None, db=None, defer=False):
+DENSE_BWD_ACCUM_DX = 0x200
+
+
+def dense_bwd(X, Y, dY, W, act, workspace, dX=None, dW=None, db=None, defer=False, dZ=None, accumulate_dx=False, K=None):
     """The reverse pass of one Dense layer in two launches instead of four (amar_dense_bwd_f32): dZ = dY * act'(Y); dX = dZ . W^T; dW = X^T . dZ;
     db = column sums of dZ.  Y is the layer's OUTPUT (None with act None: dY already is dZ); any of dX / dW / db may be None."""
     M, N = dY.shape
-    K = W.shape[0] if W is not None else X.shape[1]
+    K = W.shape[0] if W is not None else (X.shape[1] if X is not None else int(K or 1))    # (K only sizes the workspace when neither is given)
     if dX is not None and (W is None or tuple(W.shape) != (K, N) or not W.is_contiguous() or tuple(dX.shape) != (M, K)):
         raise ValueError("dense_bwd: W [K, N] contiguous and dX [M, K] expected")
     if dW is not None and (X is None or tuple(X.shape) != (M, K) or tuple(dW.shape) != (K, N) or not dW.is_contiguous()):
@@ -937,13 +940,17 @@ def dense_bwd(X, Y, dY, W, act, workspace, dX=None, dW=None, db=None, defer=Fals
         raise ValueError("dense_bwd: db must be a contiguous [N] vector")
     if Y is not None and tuple(Y.shape) != (M, N):
         raise ValueError("dense_bwd: Y [M, N] expected")
+    if dZ is not None and tuple(dZ.shape) != (M, N):
+        raise ValueError("dense_bwd: dZ [M, N] expected")
     lib = load()
     if workspace is None or workspace.numel() < lib.amar_dense_bwd_workspace_floats(M, K, N):
         raise ValueError("dense_bwd: workspace too small (capi.dense_bwd_workspace)")
     code = lib.amar_dense_bwd_f32(
         _ptr(X, torch.float32, 'X'), _ld(X, 'X') if X is not None else 0, _ptr(Y, torch.float32, 'Y'), _ld(Y, 'Y') if Y is not None else 0,
-        _ptr(dY, torch.float32, 'dY'), _ld(dY, 'dY'), _ptr(W, torch.float32, 'W'), ACT_CODES[act] | (DENSE_BWD_DEFER if defer else 0),
+        _ptr(dY, torch.float32, 'dY'), _ld(dY, 'dY'), _ptr(W, torch.float32, 'W'),
+        ACT_CODES[act] | (DENSE_BWD_DEFER if defer else 0) | (DENSE_BWD_ACCUM_DX if accumulate_dx else 0),
         _ptr(dX, torch.float32, 'dX'), _ld(dX, 'dX') if dX is not None else 0, _ptr(dW, torch.float32, 'dW'), _ptr(db, torch.float32, 'db'),
+        _ptr(dZ, torch.float32, 'dZ'), _ld(dZ, 'dZ') if dZ is not None else 0,
         _ptr(workspace, torch.float32, 'workspace'), M, K, N, _stream())
     _check(code, 'amar_dense_bwd_f32')
     if defer:

@@ -521,6 +521,7 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 struct DenseBwdArgs {
     const float *X; int64_t ldx; const float *Y; int64_t ldy; const float *dY; int64_t lddy; const float *W;
     float *dX; int64_t lddx; float *part_w; float *part_b; int64_t M; int K, N, act, subtiles;
+    float *dZ; int64_t lddz; int accum_dx;
 };
 
 __host__ __device__ inline int dense_bwd_subtiles(int64_t M) {
@@ -532,16 +533,21 @@ __host__ __device__ inline int dense_bwd_subtiles(int64_t M) {
 // thread issues ALL its 16-byte loads before the first LDS store (a loop of load -> store pairs with a run-time trip count serialised
 // the tile's memory round trips: 19 us per launch for three 12 KB tiles)
 template <int MAXP, typename LOAD>
-__device__ __forceinline__ void stage_tile(float *lds, int stride, int rows, int cols_p, int tid, LOAD load) {
+__device__ __forceinline__ void stage_load(float4 (&v)[MAXP], int rows, int cols_p, int tid, LOAD load) {
     const int c4n = cols_p >> 2;                                      // float4 columns (<= 32)
     const int lg = c4n <= 4 ? 2 : c4n <= 8 ? 3 : c4n <= 16 ? 4 : 5;   // threads per row, rounded up to a power of two
     const int c4 = tid & ((1 << lg) - 1), r_in = tid >> lg, rpp = DB_THREADS >> lg;
-    float4 v[MAXP];
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) {
         const int r = r_in + p * rpp;
         v[p] = (r < rows && c4 < c4n) ? load(r, 4 * c4) : f4_zero();
     }
+}
+template <int MAXP>
+__device__ __forceinline__ void stage_store(const float4 (&v)[MAXP], float *lds, int stride, int rows, int cols_p, int tid) {
+    const int c4n = cols_p >> 2;
+    const int lg = c4n <= 4 ? 2 : c4n <= 8 ? 3 : c4n <= 16 ? 4 : 5;
+    const int c4 = tid & ((1 << lg) - 1), r_in = tid >> lg, rpp = DB_THREADS >> lg;
 #pragma unroll
     for (int p = 0; p < MAXP; ++p) {
         const int r = r_in + p * rpp;
@@ -550,6 +556,12 @@ __device__ __forceinline__ void stage_tile(float *lds, int stride, int rows, int
             d[0] = v[p].x; d[1] = v[p].y; d[2] = v[p].z; d[3] = v[p].w;
         }
     }
+}
+template <int MAXP, typename LOAD>
+__device__ __forceinline__ void stage_tile(float *lds, int stride, int rows, int cols_p, int tid, LOAD load) {
+    float4 v[MAXP];
+    stage_load<MAXP>(v, rows, cols_p, tid, load);
+    stage_store<MAXP>(v, lds, stride, rows, cols_p, tid);
 }
 
 template <int MAXT, bool VEC>                                         // MAXT: 16 x 16 tiles of dW per wave (4 waves): 4 covers K, N <= 64
@@ -563,11 +575,12 @@ __global__ __launch_bounds__(DB_THREADS) void dense_bwd_kernel(const DenseBwdArg
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, l4 = lane >> 4;
     const int kt_n = Kp >> 4, nt_n = Np >> 4;
+    float4 vw[8];                                                     // the kernel's first 64 rows: requested here, stored with the first sub-tile's operands
     if (a.W) {
         if (VEC) {
             auto ldw = [&](int k, int n) { return (k < a.K && n < a.N) ? *reinterpret_cast<const float4 *>(a.W + (int64_t)k * a.N + n) : f4_zero(); };
-            stage_tile<8>(ws, sw, Kp < 64 ? Kp : 64, Np, tid, ldw);
             if (Kp > 64) stage_tile<8>(ws + 64 * sw, sw, Kp - 64, Np, tid, [&](int k, int n) { return ldw(k + 64, n); });
+            stage_load<8>(vw, Kp < 64 ? Kp : 64, Np, tid, ldw);
         } else {
             for (int e = tid; e < Kp * Np; e += DB_THREADS) {
                 const int k = e / Np, n = e - k * Np;
@@ -583,20 +596,31 @@ __global__ __launch_bounds__(DB_THREADS) void dense_bwd_kernel(const DenseBwdArg
         const int64_t r0 = ((int64_t)blockIdx.x * a.subtiles + sub) * DB_ROWS;
         if (r0 >= a.M) break;
         __syncthreads();                                             // (the previous sub-tile's operands are no longer read)
-        if (VEC) {
-            stage_tile<8>(zs, sz, DB_ROWS, Np, tid, [&](int r, int n) {
+        if (VEC) {                                                  // every 16-byte load of both tiles is issued before the first LDS store
+            float4 vz[8], vy[8], vx[8];
+            stage_load<8>(vz, DB_ROWS, Np, tid, [&](int r, int n) {
                 const int64_t m = r0 + r;
-                if (m >= a.M || n >= a.N) return f4_zero();
-                const float4 dy = *reinterpret_cast<const float4 *>(a.dY + m * a.lddy + n);
-                if (!a.Y) return dy;
-                const float4 y = *reinterpret_cast<const float4 *>(a.Y + m * a.ldy + n);
-                return make_float4(act_grad(dy.x, y.x, a.act), act_grad(dy.y, y.y, a.act), act_grad(dy.z, y.z, a.act), act_grad(dy.w, y.w, a.act));
+                return (m < a.M && n < a.N) ? *reinterpret_cast<const float4 *>(a.dY + m * a.lddy + n) : f4_zero();
             });
+            if (a.Y)
+                stage_load<8>(vy, DB_ROWS, Np, tid, [&](int r, int n) {
+                    const int64_t m = r0 + r;
+                    return (m < a.M && n < a.N) ? *reinterpret_cast<const float4 *>(a.Y + m * a.ldy + n) : f4_zero();
+                });
             if (a.X)
-                stage_tile<8>(xs, sx, DB_ROWS, Kp, tid, [&](int r, int k) {
+                stage_load<8>(vx, DB_ROWS, Kp, tid, [&](int r, int k) {
                     const int64_t m = r0 + r;
                     return (m < a.M && k < a.K) ? *reinterpret_cast<const float4 *>(a.X + m * a.ldx + k) : f4_zero();
                 });
+            if (a.Y) {
+#pragma unroll
+                for (int p = 0; p < 8; ++p)
+                    vz[p] = make_float4(act_grad(vz[p].x, vy[p].x, a.act), act_grad(vz[p].y, vy[p].y, a.act),
+                                        act_grad(vz[p].z, vy[p].z, a.act), act_grad(vz[p].w, vy[p].w, a.act));
+            }
+            stage_store<8>(vz, zs, sz, DB_ROWS, Np, tid);
+            if (a.X) stage_store<8>(vx, xs, sx, DB_ROWS, Kp, tid);
+            if (a.W && sub == 0) stage_store<8>(vw, ws, sw, Kp < 64 ? Kp : 64, Np, tid);
         } else {
             for (int e = tid; e < DB_ROWS * Np; e += DB_THREADS) {
                 const int r = e / Np, n = e - r * Np;
@@ -613,6 +637,11 @@ __global__ __launch_bounds__(DB_THREADS) void dense_bwd_kernel(const DenseBwdArg
                 }
         }
         __syncthreads();
+        if (a.dZ)                                                     // the pre-activation gradient itself (a GCN layer feeds it to A_hat)
+            for (int e = tid; e < DB_ROWS * a.N; e += DB_THREADS) {
+                const int r = e / a.N, n = e - r * a.N;
+                if (r0 + r < a.M) a.dZ[(r0 + r) * a.lddz + n] = zs[r * sz + n];
+            }
         // dX tile [64 x K] = dZ [64 x N] . W^T [N x K]: A[m][n] = dZ, B[n][k] = W[k][n]
         if (a.dX)
             for (int tile = wave; tile < 4 * kt_n; tile += DB_THREADS / 64) {
@@ -625,7 +654,7 @@ __global__ __launch_bounds__(DB_THREADS) void dense_bwd_kernel(const DenseBwdArg
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int64_t m = r0 + 16 * mt + 4 * l4 + i;
-                    if (m < a.M && col < a.K) a.dX[m * a.lddx + col] = acc[i];
+                    if (m < a.M && col < a.K) { float *o = a.dX + m * a.lddx + col; *o = a.accum_dx ? *o + acc[i] : acc[i]; }
                 }
             }
         // dW [K x N] += X^T [K x 64] . dZ [64 x N]: A[k][r] = X[r][k], B[r][n] = dZ[r][n]; tile t of this wave = wave + 4 t
@@ -643,8 +672,14 @@ __global__ __launch_bounds__(DB_THREADS) void dense_bwd_kernel(const DenseBwdArg
                 }
             }
         }
-        if (a.part_b && tid < a.N)
-            for (int r = 0; r < DB_ROWS; ++r) accb += zs[r * sz + tid];
+        if (a.part_b && tid < a.N) {                               // (four independent chains; a fixed order: (r0 + r1) + (r2 + r3) per 4 rows)
+            float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+#pragma unroll 4
+            for (int r = 0; r < DB_ROWS; r += 4) {
+                b0 += zs[r * sz + tid]; b1 += zs[(r + 1) * sz + tid]; b2 += zs[(r + 2) * sz + tid]; b3 += zs[(r + 3) * sz + tid];
+            }
+            accb += (b0 + b1) + (b2 + b3);
+        }
     }
     if (a.part_w) {
         float *mine = a.part_w + (int64_t)blockIdx.x * a.K * a.N;
@@ -688,8 +723,26 @@ __global__ __launch_bounds__(DB_THREADS) void dense_stack_kernel(const DenseStac
     float *cur = ds_lds, *nxt = cur + DB_ROWS * sa, *ws = nxt + DB_ROWS * sa;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, l4 = lane >> 4;
     const int64_t r0 = (int64_t)blockIdx.x * DB_ROWS;
+    // a layer's kernel [Kp x Np] into `ws`: by 16-byte loads where its width allows (the first 64 rows may arrive in registers,
+    // requested while the previous layer's products ran)
+    auto w_load = [&](int l, int k_lo, int rows, float4 (&v)[8]) {
+        const int K = a.dims[l], N = a.dims[l + 1], Np = (N + 15) & ~15;
+        const float *w = a.W[l];
+        stage_load<8>(v, rows, Np, tid, [&](int k, int n) {
+            return (k_lo + k < K && n < N) ? *reinterpret_cast<const float4 *>(w + (int64_t)(k_lo + k) * N + n) : f4_zero();
+        });
+    };
+    auto w_scalar = [&](int l) {
+        const int K = a.dims[l], N = a.dims[l + 1], Kp = (K + 15) & ~15, Np = (N + 15) & ~15, sw = Np + 2;
+        for (int e = tid; e < Kp * Np; e += DB_THREADS) {
+            const int k = e / Np, n = e - k * Np;
+            ws[k * sw + n] = (k < K && n < N) ? a.W[l][(int64_t)k * N + n] : 0.f;
+        }
+    };
+    float4 wreg[8];
     {
-        const int K = a.dims[0], Kp = (K + 15) & ~15;
+        const int K = a.dims[0], Kp = (K + 15) & ~15, Np1 = (a.dims[1] + 15) & ~15;
+        if (a.vec_w[0]) w_load(0, 0, Kp < 64 ? Kp : 64, wreg);       // (requested together with the input tile)
         if (a.vec_x) {
             stage_tile<8>(cur, sa, DB_ROWS, Kp, tid, [&](int r, int k) {
                 const int64_t m = r0 + r;
@@ -710,21 +763,16 @@ __global__ __launch_bounds__(DB_THREADS) void dense_stack_kernel(const DenseStac
                 cur[r * sa + k] = v;
             }
         }
+        if (a.vec_w[0]) {
+            stage_store<8>(wreg, ws, Np1 + 2, Kp < 64 ? Kp : 64, Np1, tid);
+            if (Kp > 64) { w_load(0, 64, Kp - 64, wreg); stage_store<8>(wreg, ws + 64 * (Np1 + 2), Np1 + 2, Kp - 64, Np1, tid); }
+        } else w_scalar(0);
     }
     for (int l = 0; l < a.n_layers; ++l) {
         const int K = a.dims[l], N = a.dims[l + 1], Kp = (K + 15) & ~15, Np = (N + 15) & ~15, sw = Np + 2;
-        if (a.vec_w[l]) {
-            const float *w = a.W[l];
-            auto ldw = [&](int k, int n) { return (k < K && n < N) ? *reinterpret_cast<const float4 *>(w + (int64_t)k * N + n) : f4_zero(); };
-            stage_tile<8>(ws, sw, Kp < 64 ? Kp : 64, Np, tid, ldw);
-            if (Kp > 64) stage_tile<8>(ws + 64 * sw, sw, Kp - 64, Np, tid, [&](int k, int n) { return ldw(k + 64, n); });
-        } else {
-            for (int e = tid; e < Kp * Np; e += DB_THREADS) {
-                const int k = e / Np, n = e - k * Np;
-                ws[k * sw + n] = (k < K && n < N) ? a.W[l][(int64_t)k * N + n] : 0.f;
-            }
-        }
-        __syncthreads();
+        __syncthreads();                                             // `cur` and `ws` of this layer are in place
+        const bool more = l + 1 < a.n_layers, pre = more && a.vec_w[l + 1];
+        if (pre) w_load(l + 1, 0, Np < 64 ? Np : 64, wreg);          // the next layer's kernel (its K = this N) travels while the products run
         const int nt_n = Np >> 4;
         for (int tile = wave; tile < 4 * nt_n; tile += DB_THREADS / 64) {
             const int mt = tile / nt_n, nt = tile - mt * nt_n;
@@ -743,7 +791,14 @@ __global__ __launch_bounds__(DB_THREADS) void dense_stack_kernel(const DenseStac
                 if (m < a.M && n < N) a.Y[l][m * a.ldy[l] + n] = y;
             }
         }
-        __syncthreads();
+        __syncthreads();                                             // every wave is done with `ws`
+        if (more) {
+            const int Np2 = (a.dims[l + 2] + 15) & ~15;
+            if (pre) {
+                stage_store<8>(wreg, ws, Np2 + 2, Np < 64 ? Np : 64, Np2, tid);
+                if (Np > 64) { w_load(l + 1, 64, Np - 64, wreg); stage_store<8>(wreg, ws + 64 * (Np2 + 2), Np2 + 2, Np - 64, Np2, tid); }
+            } else w_scalar(l + 1);
+        }
         float *t = cur; cur = nxt; nxt = t;
     }
 }
@@ -802,11 +857,12 @@ int64_t amar_dense_bwd_workspace_floats(int64_t M, int32_t K, int32_t N) {
 }
 
 int amar_dense_bwd_f32(const float *X, int64_t ldx, const float *Y, int64_t ldy, const float *dY, int64_t lddy, const float *W,
-                       int32_t act, float *dX, int64_t lddx, float *dW, float *db, float *workspace,
+                       int32_t act, float *dX, int64_t lddx, float *dW, float *db, float *dZ, int64_t lddz, float *workspace,
                        int64_t M, int32_t K, int32_t N, amar_stream_t stream) {
-    const bool defer = (act & AMAR_DENSE_BWD_DEFER) != 0;
-    act &= ~AMAR_DENSE_BWD_DEFER;
-    if (M < 0 || K < 1 || N < 1 || !dY || lddy < N || (!dX && !dW && !db)) return AMAR_EINVAL;
+    const bool defer = (act & AMAR_DENSE_BWD_DEFER) != 0, accum = (act & AMAR_DENSE_BWD_ACCUM_DX) != 0;
+    act &= ~(AMAR_DENSE_BWD_DEFER | AMAR_DENSE_BWD_ACCUM_DX);
+    if (M < 0 || K < 1 || N < 1 || !dY || lddy < N || (!dX && !dW && !db && !dZ)) return AMAR_EINVAL;
+    if (dZ && lddz < N) return AMAR_EINVAL;
     if (Y && ldy < N) return AMAR_EINVAL;
     if (act != AMAR_ACT_NONE && act != AMAR_ACT_RELU && act != AMAR_ACT_SIGMOID) return AMAR_EINVAL;
     if (act != AMAR_ACT_NONE && !Y) return AMAR_EINVAL;
@@ -819,12 +875,13 @@ int amar_dense_bwd_f32(const float *X, int64_t ldx, const float *Y, int64_t ldy,
     const int64_t groups = (M + (int64_t)DB_ROWS * sub - 1) / ((int64_t)DB_ROWS * sub);
     float *part_w = dW ? workspace + 4 : nullptr;
     float *part_b = db ? workspace + 4 + (dW ? groups * (int64_t)K * N : 0) : nullptr;
-    DenseBwdArgs a{dW ? X : nullptr, ldx, act != AMAR_ACT_NONE ? Y : nullptr, ldy, dY, lddy, dX ? W : nullptr, dX, lddx, part_w, part_b, M, K, N, act, sub};
+    DenseBwdArgs a{dW ? X : nullptr, ldx, act != AMAR_ACT_NONE ? Y : nullptr, ldy, dY, lddy, dX ? W : nullptr, dX, lddx, part_w, part_b, M, K, N, act, sub,
+                   dZ, lddz, accum ? 1 : 0};
     const int Kp = (K + 15) & ~15, Np = (N + 15) & ~15;
     const size_t lds = ((size_t)DB_ROWS * (Kp + 2) + (size_t)DB_ROWS * (Np + 2) + (size_t)Kp * (Np + 2)) * sizeof(float);
     hipStream_t st = static_cast<hipStream_t>(stream);
     // 16-byte loads where every operand allows them (K, N and the leading dimensions multiples of 4 floats, 16-byte aligned bases)
-    const bool vec = (K & 3) == 0 && (N & 3) == 0 && (lddy & 3) == 0 && amar_aligned16(dY) && (!a.Y || ((ldy & 3) == 0 && amar_aligned16(Y))) &&
+    const bool vec = ((K & 3) == 0 || (!a.X && !a.W)) && (N & 3) == 0 && (lddy & 3) == 0 && amar_aligned16(dY) && (!a.Y || ((ldy & 3) == 0 && amar_aligned16(Y))) &&
                      (!a.X || ((ldx & 3) == 0 && amar_aligned16(X))) && (!a.W || amar_aligned16(W));
     const bool small = (Kp >> 4) * (Np >> 4) <= 16;
 #define AMAR_DB_LAUNCH(MT, VV)                                                                                           \

@@ -28,7 +28,7 @@ import numpy as np
 import torch
 
 from deep_cbrs_amar_renaissance_amd import capi
-from deep_cbrs_amar_renaissance_amd.engine import ids_to_device, to_device_tensor
+from deep_cbrs_amar_renaissance_amd.engine import ids_to_device, to_device_tensor, upload_ids
 from deep_cbrs_amar_renaissance_amd.layers.dgcf_conv import DGCFConv
 from deep_cbrs_amar_renaissance_amd.layers.gat_conv import GATConv
 from deep_cbrs_amar_renaissance_amd.layers.gcn_conv import GCNConv
@@ -403,22 +403,29 @@ class _StackTape:
             f, c = widths[k], widths[k + 1]
             if self.kind == 'gcn':
                 dzk = torch.empty((n, c), dtype=torch.float32, device=dev)
-                capi.act_bwd(dsl(k + 1), sl(k + 1), dzk, 'relu')
+                dw, db = torch.empty_like(layer.kernel), torch.empty_like(layer.bias)
+                fused = capi.dense_bwd_enabled() and capi.dense_bwd_supported(f, c) and n > 0
+                if fused:                                             # act', its bias gradient and dZ in one launch
+                    lazy = capi.dense_bwd(None, sl(k + 1), dsl(k + 1), None, 'relu', self._workspace(('b', k), n, 1, c, dev), db=db, dZ=dzk,
+                                          defer=self.defer_reduce, K=1)
+                    if lazy is not None:
+                        db = lazy[1]
+                else:
+                    capi.act_bwd(dsl(k + 1), sl(k + 1), dzk, 'relu')
                 dh = torch.empty((n, c), dtype=torch.float32, device=dev)
                 _spmm(a, dzk, dh)                                     # A_hat^T = A_hat
-                dw, db = torch.empty_like(layer.kernel), torch.empty_like(layer.bias)
-                back = torch.empty((n, f), dtype=torch.float32, device=dev)
-                if capi.dense_bwd_enabled() and capi.dense_bwd_supported(f, c) and n > 0:         # dW = X_k^T . dH and dH . W^T fused
-                    lazy = capi.dense_bwd(sl(k), None, dh, layer.kernel.detach(), None, self._workspace(k, n, f, c, dev), dX=back, dW=dw,
-                                          defer=self.defer_reduce)
+                if fused:                                             # dW = X_k^T . dH, and dH . W^T added straight into the slice's gradient
+                    lazy = capi.dense_bwd(sl(k), None, dh, layer.kernel.detach(), None, self._workspace(k, n, f, c, dev), dX=dsl(k), dW=dw,
+                                          defer=self.defer_reduce, accumulate_dx=True)
                     if lazy is not None:
                         dw = lazy[0]
                 else:
+                    back = torch.empty((n, f), dtype=torch.float32, device=dev)
                     capi.wgrad(sl(k), dh, dw, None)
                     capi.dense(dh, layer.kernel.detach(), None, back, act=None, w_transposed=True)
-                capi.wgrad(None, dzk, None, db)
+                    capi.wgrad(None, dzk, None, db)
+                    capi.add_inplace(dsl(k), back)
                 grads[layer.kernel], grads[layer.bias] = dw, db
-                capi.add_inplace(dsl(k), back)
             elif self.kind == 'lightgcn':
                 back = torch.empty((n, f), dtype=torch.float32, device=dev)
                 _spmm(a, dsl(k + 1), back)
@@ -637,9 +644,9 @@ class Trainer:
             self._graphs[key] = g
         self._g = g
         n_nodes = self.seq.adj_matrix.shape[0] if getattr(self, 'seq', None) is not None else None
-        g['u'].copy_(ids_to_device(u_ids, n_nodes))
-        g['i'].copy_(ids_to_device(i_ids, n_nodes))
-        g['y'].copy_(to_device_tensor(np.asarray(y, dtype=np.float32) if not isinstance(y, torch.Tensor) else y))
+        upload_ids(g['u'], u_ids, n_nodes)                           # one host-to-device copy each, straight into the graph's buffers
+        upload_ids(g['i'], i_ids, n_nodes)
+        g['y'].copy_(y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32)))
         if with_blocks:
             g['ub'].copy_(to_device_tensor(bert[0]))
             g['ib'].copy_(to_device_tensor(bert[1]))

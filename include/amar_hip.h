@@ -469,10 +469,14 @@ int amar_dense_stack_f32(const float *X, int64_t ldx, const int32_t *ids, float 
  * in the workspace as  workspace + 4: [G][K * N] (if dW)  then [G][N] (if db),  G = amar_dense_bwd_groups(M), for a consumer that adds them
  * itself (amar_adam_multi_f32 with g_groups = G). */
 #define AMAR_DENSE_BWD_DEFER 0x100
+/* act | AMAR_DENSE_BWD_ACCUM_DX: dX += dZ . W^T instead of dX = (a layer whose input already carries a gradient: the concat slices of a
+ * convolution stack).  dZ != NULL: the pre-activation gradient dZ itself is also written ([M, N], leading dimension lddz) — a GCN layer
+ * multiplies it by A_hat before the weight gradient — so that act', its bias gradient and dZ are one launch (X, W, dX, dW all NULL). */
+#define AMAR_DENSE_BWD_ACCUM_DX 0x200
 int64_t amar_dense_bwd_groups(int64_t M);
 int64_t amar_dense_bwd_workspace_floats(int64_t M, int32_t K, int32_t N);
 int amar_dense_bwd_f32(const float *X, int64_t ldx, const float *Y, int64_t ldy, const float *dY, int64_t lddy, const float *W,
-                       int32_t act, float *dX, int64_t lddx, float *dW, float *db, float *workspace,
+                       int32_t act, float *dX, int64_t lddx, float *dW, float *db, float *dZ, int64_t lddz, float *workspace,
                        int64_t M, int32_t K, int32_t N, amar_stream_t stream);
 int amar_wgrad_f32(const float *X, int64_t ldx, const float *dZ, int64_t ldz, int64_t M, int32_t K, int32_t N,
                    float *dW, float *db, float *scratch, amar_stream_t stream);

@@ -135,6 +135,17 @@ def test_dense_bwd_fused(hip, M, K, N, act):
     dx4, dw4 = torch.empty((M, K), device=DEV), torch.empty((K, N), device=DEV)
     hip.dense_bwd(x_d, y_d if act is not None else None, dy_d, w_d, act, ws, dX=dx4, dW=dw4)
     assert torch.equal(dx4, dx) and torch.equal(dw4, dw)
+    # dZ itself as an output (act', the bias gradient and dZ in one launch: what a GCN layer's reverse pass starts with), the input
+    # gradient ACCUMULATED into a buffer that already carries one, and deferred partial sums (what the Adam launch adds itself)
+    dz6, db6 = torch.empty((M, N), device=DEV), torch.empty(N, device=DEV)
+    hip.dense_bwd(None, y_d if act is not None else None, dy_d, None, act, ws, db=db6, dZ=dz6, K=1)
+    assert helpers.rel_err(dz6.cpu().numpy(), dz) < 1e-6 and torch.equal(db6, db)
+    dx7 = torch.ones((M, K), device=DEV)
+    hip.dense_bwd(x_d, y_d if act is not None else None, dy_d, w_d, act, ws, dX=dx7, accumulate_dx=True)
+    assert helpers.rel_err(dx7.cpu().numpy() - 1.0, want_dx) < 1e-5
+    lazy_w, lazy_b = hip.dense_bwd(x_d, y_d if act is not None else None, dy_d, w_d, act, ws, dX=dx2, dW=dw2, db=db2, defer=True)
+    assert torch.equal(lazy_w.materialize(), dw) is not None and helpers.rel_err(lazy_w.materialize().cpu().numpy(), want_dw) < tol
+    assert helpers.rel_err(lazy_b.materialize().cpu().numpy(), want_db) < tol and lazy_w.groups == lazy_b.groups >= 1
     # against the kernels it replaces (other summation orders: tolerance, not bits)
     dz_d = torch.empty((M, N), device=DEV)
     if act is not None:

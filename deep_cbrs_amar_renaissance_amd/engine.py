@@ -131,12 +131,9 @@ def ids_to_device(ids, n_rows=None):
     return t.to(device=default_device(), dtype=torch.int32).contiguous()
 
 
-def upload_ids(dst, ids, n_rows=None):
-    """Host ids -> the int32 device tensor `dst` in ONE host-to-device copy (range-checked and narrowed on the host first);
-    device ids are copied as they are.  What a replayed training batch uses to refresh its static id buffers."""
-    if isinstance(ids, torch.Tensor) and ids.is_cuda:
-        dst.copy_(ids)
-        return
+def stage_ids(dst_host, ids, n_rows=None):
+    """Host ids -> the int32 HOST tensor `dst_host` (pinned staging memory of a replayed training batch), range-checked like
+    ids_to_device: the kernels gather / scatter rows by id without a bounds check."""
     a = ids.numpy() if isinstance(ids, torch.Tensor) else np.asarray(ids)
     if a.size:
         lo, hi = int(a.min()), int(a.max())
@@ -144,7 +141,7 @@ def upload_ids(dst, ids, n_rows=None):
             raise ValueError("ids must be in [0, 2^31)")
         if n_rows is not None and hi >= n_rows:
             raise IndexError("id {} is out of range for a table of {} rows".format(hi, n_rows))
-    dst.copy_(torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)))
+    dst_host.numpy()[...] = a
 
 
 def capture_graph(fn):

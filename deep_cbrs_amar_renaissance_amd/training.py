@@ -28,7 +28,7 @@ import numpy as np
 import torch
 
 from deep_cbrs_amar_renaissance_amd import capi
-from deep_cbrs_amar_renaissance_amd.engine import ids_to_device, to_device_tensor, upload_ids
+from deep_cbrs_amar_renaissance_amd.engine import ids_to_device, stage_ids, to_device_tensor
 from deep_cbrs_amar_renaissance_amd.layers.dgcf_conv import DGCFConv
 from deep_cbrs_amar_renaissance_amd.layers.gat_conv import GATConv
 from deep_cbrs_amar_renaissance_amd.layers.gcn_conv import GCNConv
@@ -635,6 +635,12 @@ class Trainer:
                            'ub': torch.zeros((b, d), dtype=torch.float32, device=dev) if with_blocks else None,
                            'ib': torch.zeros((b, d), dtype=torch.float32, device=dev) if with_blocks else None}
             g['slot_host'] = torch.empty(64 * len(self.params) + 64, dtype=torch.uint8).pin_memory()   # >= sizeof(amar_adam_slot) per parameter
+            # pinned staging for the batch's ids and labels, four sets in turn: the uploads are asynchronous, so the host prepares
+            # batch k + 1 while the device still runs batch k (a pageable copy_ made the host wait for the stream every batch:
+            # 0.13 ms of a 0.52 ms batch at ml1m(s=1))
+            g['stage'] = [{'u': torch.empty(b, dtype=torch.int32).pin_memory(), 'i': torch.empty(b, dtype=torch.int32).pin_memory(),
+                           'y': torch.empty(b, dtype=torch.float32).pin_memory(), 'done': torch.cuda.Event()} for _ in range(4)]
+            g['turn'] = 0
             from deep_cbrs_amar_renaissance_amd.engine import capture_graph
 
             def body():
@@ -644,9 +650,21 @@ class Trainer:
             self._graphs[key] = g
         self._g = g
         n_nodes = self.seq.adj_matrix.shape[0] if getattr(self, 'seq', None) is not None else None
-        upload_ids(g['u'], u_ids, n_nodes)                           # one host-to-device copy each, straight into the graph's buffers
-        upload_ids(g['i'], i_ids, n_nodes)
-        g['y'].copy_(y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32)))
+        st = g['stage'][g['turn'] % len(g['stage'])]
+        g['turn'] += 1
+        st['done'].synchronize()                                     # (the uploads that last used this staging set have landed)
+        for name, src in (('u', u_ids), ('i', i_ids)):
+            if isinstance(src, torch.Tensor) and src.is_cuda:
+                g[name].copy_(src)
+            else:
+                stage_ids(st[name], src, n_nodes)                    # range check + int32 on the host, into pinned memory
+                g[name].copy_(st[name], non_blocking=True)
+        if isinstance(y, torch.Tensor) and y.is_cuda:
+            g['y'].copy_(y)
+        else:
+            st['y'].numpy()[...] = y.numpy() if isinstance(y, torch.Tensor) else np.asarray(y, dtype=np.float32)
+            g['y'].copy_(st['y'], non_blocking=True)
+        st['done'].record()
         if with_blocks:
             g['ub'].copy_(to_device_tensor(bert[0]))
             g['ib'].copy_(to_device_tensor(bert[1]))

@@ -65,6 +65,8 @@ SIGNATURES = {
     'amar_wgrad_scratch_floats': (ctypes.c_int64, [_I64, _I32, _I32]),
     'amar_wgrad_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I32, _I32, _P, _P, _P, _P]),
     'amar_dense_stack_f32': (ctypes.c_int, [_P, _I64, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    'amar_dense_stack_bwd_workspace_floats': (ctypes.c_int64, [_I64, _I32, _P]),
+    'amar_dense_stack_bwd_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _I32, _I64, _P]),
     'amar_dense_bwd_workspace_floats': (ctypes.c_int64, [_I64, _I32, _I32]),
     'amar_dense_bwd_groups': (ctypes.c_int64, [_I64]),
     'amar_dense_bwd_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _P, _I64, _P, _I32, _P, _I64, _P, _P, _P, _I64, _P, _I64, _I32, _I32, _P]),
@@ -897,6 +899,61 @@ def dense_stack(X, weights, biases, acts, outs, ids=None, xcopy=None):
                                        _ptr(xcopy, torch.float32, 'xcopy'), _ld(xcopy, 'xcopy') if xcopy is not None else 0, n,
                                        wp, bp, dm, ac, yp, ld, M, _stream())
     _check(code, 'amar_dense_stack_f32')
+
+
+def dense_stack_bwd_supported(dims, M):
+    """amar_dense_stack_bwd_f32 takes this stack (at most 4 layers no wider than 128, batch-sized operands: M <= 4 096 rows)."""
+    return dense_stack_supported(dims) and 1 <= int(M) <= 4096 and os.environ.get('AMAR_DENSE_STACK_BWD', '1') != '0'
+
+
+def dense_stack_bwd_workspace(M, dims, device):
+    n = len(dims) - 1
+    dm = (ctypes.c_int32 * (n + 1))(*[int(d) for d in dims])
+    floats = int(load().amar_dense_stack_bwd_workspace_floats(int(M), n, dm))
+    return torch.empty(max(floats, 4), dtype=torch.float32, device=device)
+
+
+def dense_stack_bwd(dYtop, Ytop, inputs, weights, acts, workspace, dWs, dbs, dX0=None, defer=False):
+    """The reverse pass of a Dense stack in one launch (amar_dense_stack_bwd_f32).  inputs[l] = layer l's input, Ytop = the last layer's
+    output (None: dYtop already is the last pre-activation's gradient).  defer=True: dWs / dbs are not written; returns one
+    (DeferredGradient dW, DeferredGradient db) per layer."""
+    n = len(weights)
+    M = int(dYtop.shape[0])
+    dims = [int(weights[0].shape[0])] + [int(w.shape[1]) for w in weights]
+    if len(inputs) != n or len(acts) != n or len(dWs) != n or len(dbs) != n or dYtop.shape[1] != dims[-1]:
+        raise ValueError("dense_stack_bwd: one input / kernel / activation / dW / db per layer and dYtop [M, N_last] expected")
+    for l in range(n):
+        if tuple(inputs[l].shape) != (M, dims[l]) or tuple(weights[l].shape) != (dims[l], dims[l + 1]) or not weights[l].is_contiguous() or \
+                tuple(dWs[l].shape) != (dims[l], dims[l + 1]) or not dWs[l].is_contiguous() or dbs[l].numel() != dims[l + 1]:
+            raise ValueError("dense_stack_bwd: layer {}: shapes".format(l))
+    if dX0 is not None and tuple(dX0.shape) != (M, dims[0]):
+        raise ValueError("dense_stack_bwd: dX0 must be [M, K_0]")
+    arr_p = ctypes.c_void_p * n
+    xp = arr_p(*[_ptr(x, torch.float32, 'X') for x in inputs])
+    lx = (ctypes.c_int64 * n)(*[_ld(x, 'X') for x in inputs])
+    wp = arr_p(*[_ptr(w, torch.float32, 'W') for w in weights])
+    dwp = arr_p(*[_ptr(w, torch.float32, 'dW') for w in dWs])
+    dbp = arr_p(*[_ptr(b, torch.float32, 'db') for b in dbs])
+    dm = (ctypes.c_int32 * (n + 1))(*dims)
+    ac = (ctypes.c_int32 * n)(*[ACT_CODES[a] for a in acts])
+    lib = load()
+    if workspace.numel() < lib.amar_dense_stack_bwd_workspace_floats(M, n, dm):
+        raise ValueError("dense_stack_bwd: workspace too small (capi.dense_stack_bwd_workspace)")
+    code = lib.amar_dense_stack_bwd_f32(_ptr(dYtop, torch.float32, 'dYtop'), _ld(dYtop, 'dYtop'), _ptr(Ytop, torch.float32, 'Ytop'),
+                                        _ld(Ytop, 'Ytop') if Ytop is not None else 0, n, xp, lx, wp, dm, ac,
+                                        _ptr(dX0, torch.float32, 'dX0'), _ld(dX0, 'dX0') if dX0 is not None else 0, dwp, dbp,
+                                        _ptr(workspace, torch.float32, 'workspace'), DENSE_BWD_DEFER if defer else 0, M, _stream())
+    _check(code, 'amar_dense_stack_bwd_f32')
+    if not defer:
+        return None
+    g = (M + 63) // 64
+    out, off = [], 4
+    for l in range(n):
+        kn, nn = dims[l] * dims[l + 1], dims[l + 1]
+        out.append((DeferredGradient(workspace[off:off + g * kn], g, (dims[l], dims[l + 1])),
+                    DeferredGradient(workspace[off + g * kn:off + g * (kn + nn)], g, (nn,))))
+        off += g * (kn + nn)
+    return out
 
 
 def dense_bwd_supported(K, N):

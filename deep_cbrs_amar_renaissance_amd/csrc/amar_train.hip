@@ -803,6 +803,162 @@ __global__ __launch_bounds__(DB_THREADS) void dense_stack_kernel(const DenseStac
     }
 }
 
+// ---- the reverse pass of a whole Dense stack in one launch (round 4) ------------------------------------------------------------------
+// A 64-row tile walks the layers from the last to the first: dZ_l in LDS, dW_l / db_l partials out, dX_l = dZ_l . W_l^T in registers,
+// dZ_{l-1} = dX_l * act'(y_{l-1}) — and y_{l-1} IS layer l's input, already staged for the weight gradient.  One launch per tower /
+// classifier instead of one amar_dense_bwd_f32 per layer; the partials are added by amar_adam_multi_f32 (or by one reduction per layer).
+struct DenseStackBwdArgs {
+    const float *dYtop; int64_t lddy; const float *Ytop; int64_t ldytop;
+    const float *X[DS_MAX_LAYERS]; int64_t ldx[DS_MAX_LAYERS]; const float *W[DS_MAX_LAYERS];
+    float *part_w[DS_MAX_LAYERS]; float *part_b[DS_MAX_LAYERS]; float *dX0; int64_t lddx0;
+    int dims[DS_MAX_LAYERS + 1]; int act[DS_MAX_LAYERS]; int vec_x[DS_MAX_LAYERS]; int vec_w[DS_MAX_LAYERS]; int vec_top;
+    int n_layers; int64_t M; int maxd;
+};
+
+__global__ __launch_bounds__(DB_THREADS) void dense_stack_bwd_kernel(const DenseStackBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sb_lds[];
+    const int smax = a.maxd + 2;
+    float *xs = sb_lds, *zs = xs + DB_ROWS * smax, *ws = zs + DB_ROWS * smax;      // X_l tile, dZ_l tile, W_l (each with its layer's stride)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, l4 = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * DB_ROWS;
+    const int L = a.n_layers;
+    {   // dZ of the last layer: dYtop * act'(Ytop) (Ytop == NULL: dYtop already is dZ)
+        const int N = a.dims[L], Np = (N + 15) & ~15, sz = Np + 2, actl = a.act[L - 1];
+        if (a.vec_top) {
+            float4 vz[8], vy[8];
+            stage_load<8>(vz, DB_ROWS, Np, tid, [&](int r, int n) {
+                const int64_t m = r0 + r;
+                return (m < a.M && n < N) ? *reinterpret_cast<const float4 *>(a.dYtop + m * a.lddy + n) : f4_zero();
+            });
+            if (a.Ytop) {
+                stage_load<8>(vy, DB_ROWS, Np, tid, [&](int r, int n) {
+                    const int64_t m = r0 + r;
+                    return (m < a.M && n < N) ? *reinterpret_cast<const float4 *>(a.Ytop + m * a.ldytop + n) : f4_zero();
+                });
+#pragma unroll
+                for (int p = 0; p < 8; ++p)
+                    vz[p] = make_float4(act_grad(vz[p].x, vy[p].x, actl), act_grad(vz[p].y, vy[p].y, actl),
+                                        act_grad(vz[p].z, vy[p].z, actl), act_grad(vz[p].w, vy[p].w, actl));
+            }
+            stage_store<8>(vz, zs, sz, DB_ROWS, Np, tid);
+        } else {
+            for (int e = tid; e < DB_ROWS * Np; e += DB_THREADS) {
+                const int r = e / Np, n = e - r * Np;
+                const int64_t m = r0 + r;
+                float v = 0.f;
+                if (m < a.M && n < N) v = a.Ytop ? act_grad(a.dYtop[m * a.lddy + n], a.Ytop[m * a.ldytop + n], actl) : a.dYtop[m * a.lddy + n];
+                zs[r * sz + n] = v;
+            }
+        }
+    }
+    for (int l = L - 1; l >= 0; --l) {
+        const int K = a.dims[l], N = a.dims[l + 1], Kp = (K + 15) & ~15, Np = (N + 15) & ~15, sx = Kp + 2, sz = Np + 2, sw = Np + 2;
+        const int kt_n = Kp >> 4, nt_n = Np >> 4;
+        // stage X_l and W_l (the previous iteration's last barrier guarantees nobody reads xs / ws any more)
+        if (a.vec_x[l]) {
+            const float *x = a.X[l];
+            const int64_t ld = a.ldx[l];
+            stage_tile<8>(xs, sx, DB_ROWS, Kp, tid, [&](int r, int k) {
+                const int64_t m = r0 + r;
+                return (m < a.M && k < K) ? *reinterpret_cast<const float4 *>(x + m * ld + k) : f4_zero();
+            });
+        } else {
+            for (int e = tid; e < DB_ROWS * Kp; e += DB_THREADS) {
+                const int r = e / Kp, k = e - r * Kp;
+                const int64_t m = r0 + r;
+                xs[r * sx + k] = (m < a.M && k < K) ? a.X[l][m * a.ldx[l] + k] : 0.f;
+            }
+        }
+        const bool need_dx = l > 0 || a.dX0 != nullptr;
+        if (need_dx) {
+            if (a.vec_w[l]) {
+                const float *w = a.W[l];
+                auto ldw = [&](int k, int n) { return (k < K && n < N) ? *reinterpret_cast<const float4 *>(w + (int64_t)k * N + n) : f4_zero(); };
+                stage_tile<8>(ws, sw, Kp < 64 ? Kp : 64, Np, tid, ldw);
+                if (Kp > 64) stage_tile<8>(ws + 64 * sw, sw, Kp - 64, Np, tid, [&](int k, int n) { return ldw(k + 64, n); });
+            } else {
+                for (int e = tid; e < Kp * Np; e += DB_THREADS) {
+                    const int k = e / Np, n = e - k * Np;
+                    ws[k * sw + n] = (k < K && n < N) ? a.W[l][(int64_t)k * N + n] : 0.f;
+                }
+            }
+        }
+        __syncthreads();
+        // dW_l partial [K x N] = X_l^T . dZ_l, db_l partial
+        if (a.part_w[l]) {
+            float *mine = a.part_w[l] + (int64_t)blockIdx.x * K * N;
+            for (int tile = wave; tile < kt_n * nt_n; tile += DB_THREADS / 64) {
+                const int kt = tile / nt_n, nt = tile - kt * nt_n;
+                const float *ap = xs + l4 * sx + 16 * kt + l16, *bp = zs + l4 * sz + 16 * nt + l16;
+                v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+                for (int r = 0; r < DB_ROWS; r += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[r * sx], bp[r * sz], acc, 0, 0, 0);
+                const int n = 16 * nt + l16;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = 16 * kt + 4 * l4 + i;
+                    if (k < K && n < N) mine[(int64_t)k * N + n] = acc[i];
+                }
+            }
+        }
+        if (a.part_b[l] && tid < N) {
+            float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+#pragma unroll 4
+            for (int r = 0; r < DB_ROWS; r += 4) {
+                b0 += zs[r * sz + tid]; b1 += zs[(r + 1) * sz + tid]; b2 += zs[(r + 2) * sz + tid]; b3 += zs[(r + 3) * sz + tid];
+            }
+            a.part_b[l][(int64_t)blockIdx.x * N + tid] = (b0 + b1) + (b2 + b3);
+        }
+        // dX_l [64 x K] = dZ_l . W_l^T in registers: this wave's tiles are wave, wave + 4, ... (at most 8: K <= 128)
+        v4f dxa[8];
+        if (need_dx) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int tile = wave + (DB_THREADS / 64) * t;
+                dxa[t] = v4f{0.f, 0.f, 0.f, 0.f};
+                if (tile < 4 * kt_n) {
+                    const int mt = tile / kt_n, kt = tile - mt * kt_n;
+                    const float *ap = zs + (16 * mt + l16) * sz + l4, *bp = ws + (16 * kt + l16) * sw + l4;
+                    v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+                    for (int n0 = 0; n0 < Np; n0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[n0], bp[n0], acc, 0, 0, 0);
+                    dxa[t] = acc;
+                }
+            }
+        }
+        __syncthreads();                                             // every read of zs (and ws) of this layer is done
+        if (l > 0) {                                                 // dZ_{l-1} = dX_l * act'(y_{l-1}), y_{l-1} = X_l (in xs), into zs with stride Kp + 2
+            const int actp = a.act[l - 1];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int tile = wave + (DB_THREADS / 64) * t;
+                if (tile < 4 * kt_n) {
+                    const int mt = tile / kt_n, kt = tile - mt * kt_n, col = 16 * kt + l16;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int r = 16 * mt + 4 * l4 + i;
+                        zs[r * sx + col] = col < K ? act_grad(dxa[t][i], xs[r * sx + col], actp) : 0.f;
+                    }
+                }
+            }
+            __syncthreads();                                         // zs of layer l - 1 complete; xs / ws free for the next staging
+        } else if (a.dX0) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int tile = wave + (DB_THREADS / 64) * t;
+                if (tile < 4 * kt_n) {
+                    const int mt = tile / kt_n, kt = tile - mt * kt_n, col = 16 * kt + l16;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int64_t m = r0 + 16 * mt + 4 * l4 + i;
+                        if (m < a.M && col < K) a.dX0[m * a.lddx0 + col] = dxa[t][i];
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -841,6 +997,59 @@ int amar_dense_stack_f32(const float *X, int64_t ldx, const int32_t *ids, float 
     static bool allowed[AMAR_MAX_DEVICES] = {};
     if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_stack_kernel), lds, allowed)) return rc;
     hipLaunchKernelGGL(dense_stack_kernel, dim3((unsigned)groups), dim3(DB_THREADS), lds, static_cast<hipStream_t>(stream), a);
+    return amar_check_launch();
+}
+
+int64_t amar_dense_stack_bwd_workspace_floats(int64_t M, int32_t n_layers, const int32_t *dims) {
+    if (M < 0 || n_layers < 1 || n_layers > DS_MAX_LAYERS || !dims) return AMAR_EINVAL;
+    const int64_t groups = (M + DB_ROWS - 1) / DB_ROWS;
+    int64_t total = 4;
+    for (int l = 0; l < n_layers; ++l) total += groups * ((int64_t)dims[l] * dims[l + 1] + dims[l + 1]);
+    return total;
+}
+
+int amar_dense_stack_bwd_f32(const float *dYtop, int64_t lddy, const float *Ytop, int64_t ldytop, int32_t n_layers,
+                             const float *const *X, const int64_t *ldx, const float *const *W, const int32_t *dims, const int32_t *acts,
+                             float *dX0, int64_t lddx0, float *const *dW, float *const *db, float *workspace, int32_t flags,
+                             int64_t M, amar_stream_t stream) {
+    if (M < 1 || !dYtop || n_layers < 1 || !X || !ldx || !W || !dims || !acts || !dW || !db || !workspace) return AMAR_EINVAL;
+    if (n_layers > DS_MAX_LAYERS) return AMAR_EUNSUPPORTED;
+    const int64_t groups = (M + DB_ROWS - 1) / DB_ROWS;
+    if (groups > 64) return AMAR_EUNSUPPORTED;                       // (batch-sized operands: one 64-row tile per workgroup, no sub-tiles)
+    DenseStackBwdArgs a{};
+    a.dYtop = dYtop; a.lddy = lddy; a.Ytop = Ytop; a.ldytop = ldytop; a.dX0 = dX0; a.lddx0 = lddx0; a.n_layers = n_layers; a.M = M;
+    int maxd = 16;
+    for (int l = 0; l <= n_layers; ++l) {
+        if (dims[l] < 1) return AMAR_EINVAL;
+        if (dims[l] > DB_MAXD) return AMAR_EUNSUPPORTED;
+        a.dims[l] = dims[l];
+        if (((dims[l] + 15) & ~15) > maxd) maxd = (dims[l] + 15) & ~15;
+    }
+    if (lddy < dims[n_layers] || (Ytop && ldytop < dims[n_layers]) || (dX0 && lddx0 < dims[0])) return AMAR_EINVAL;
+    a.vec_top = ((dims[n_layers] & 3) == 0 && (lddy & 3) == 0 && amar_aligned16(dYtop) && (!Ytop || ((ldytop & 3) == 0 && amar_aligned16(Ytop)))) ? 1 : 0;
+    float *p = workspace + 4;
+    int maxw = 0;
+    for (int l = 0; l < n_layers; ++l) {
+        if (!X[l] || !W[l] || !dW[l] || !db[l] || ldx[l] < dims[l]) return AMAR_EINVAL;
+        if (acts[l] != AMAR_ACT_NONE && acts[l] != AMAR_ACT_RELU && acts[l] != AMAR_ACT_SIGMOID) return AMAR_EINVAL;
+        a.X[l] = X[l]; a.ldx[l] = ldx[l]; a.W[l] = W[l]; a.act[l] = acts[l];
+        a.vec_x[l] = ((dims[l] & 3) == 0 && (ldx[l] & 3) == 0 && amar_aligned16(X[l])) ? 1 : 0;
+        a.vec_w[l] = ((dims[l + 1] & 3) == 0 && amar_aligned16(W[l])) ? 1 : 0;
+        a.part_w[l] = p; p += groups * (int64_t)dims[l] * dims[l + 1];
+        a.part_b[l] = p; p += groups * (int64_t)dims[l + 1];
+        const int w = ((dims[l] + 15) & ~15) * (((dims[l + 1] + 15) & ~15) + 2);
+        if (w > maxw) maxw = w;
+    }
+    a.maxd = maxd;
+    const size_t lds = ((size_t)2 * DB_ROWS * (maxd + 2) + (size_t)maxw) * sizeof(float);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    static bool allowed[AMAR_MAX_DEVICES] = {};
+    if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_stack_bwd_kernel), lds, allowed)) return rc;
+    hipLaunchKernelGGL(dense_stack_bwd_kernel, dim3((unsigned)groups), dim3(DB_THREADS), lds, st, a);
+    if (!(flags & AMAR_DENSE_BWD_DEFER))
+        for (int l = 0; l < n_layers; ++l)
+            hipLaunchKernelGGL(reduce_partials2_kernel, dim3(grid1d((int64_t)dims[l] * dims[l + 1] + dims[l + 1])), dim3(256), 0, st, a.part_w[l],
+                               (int64_t)dims[l] * dims[l + 1], dW[l], a.part_b[l], (int64_t)dims[l + 1], db[l], (int)groups);
     return amar_check_launch();
 }
 

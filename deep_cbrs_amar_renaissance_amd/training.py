@@ -94,10 +94,26 @@ class _DenseTape:
             x = y
         return x
 
-    def backward(self, dy, grads, last_is_dz=False, need_input_grad=True):
+    def backward(self, dy, grads, last_is_dz=False, need_input_grad=True, dx_out=None):
         """dy: gradient w.r.t. the stack's output (or, with last_is_dz, already w.r.t. the last pre-activation).
         Fills grads[param] for every kernel/bias; returns the gradient w.r.t. the stack's input (None when
         need_input_grad is False: constant inputs such as the BERT rows)."""
+        m = int(dy.shape[0])
+        dims = [int(self.layers[0].kernel.shape[0])] + [int(l.units) for l in self.layers]
+        if capi.dense_bwd_enabled() and capi.dense_stack_bwd_supported(dims, m):
+            # the whole stack's reverse pass in ONE launch (amar_dense_stack_bwd_f32): dZ walks the layers in LDS
+            dev = dy.device
+            key = ('stack', m)
+            if key not in self._workspaces:
+                self._workspaces[key] = capi.dense_stack_bwd_workspace(m, dims, dev)
+            dws = [torch.empty_like(l.kernel) for l in self.layers]
+            dbs = [torch.empty_like(l.bias) for l in self.layers]
+            dx0 = (dx_out if dx_out is not None else torch.empty((m, dims[0]), dtype=torch.float32, device=dev)) if need_input_grad else None
+            lazy = capi.dense_stack_bwd(dy, None if last_is_dz else self.outputs[-1], self.inputs, [l.kernel.detach() for l in self.layers],
+                                        [l.activation for l in self.layers], self._workspaces[key], dws, dbs, dX0=dx0, defer=self.defer_reduce)
+            for k, layer in enumerate(self.layers):
+                grads[layer.kernel], grads[layer.bias] = lazy[k] if lazy is not None else (dws[k], dbs[k])
+            return dx0
         for k in range(len(self.layers) - 1, -1, -1):
             layer, x, y = self.layers[k], self.inputs[k], self.outputs[k]
             kk, n = layer.kernel.shape
@@ -106,7 +122,7 @@ class _DenseTape:
                 need_dx = not (k == 0 and not need_input_grad)
                 act = None if (last_is_dz and k == len(self.layers) - 1) else layer.activation
                 dw, db = torch.empty_like(layer.kernel), torch.empty_like(layer.bias)
-                dx = torch.empty((x.shape[0], kk), dtype=torch.float32, device=x.device) if need_dx else None
+                dx = (dx_out if (k == 0 and dx_out is not None) else torch.empty((x.shape[0], kk), dtype=torch.float32, device=x.device)) if need_dx else None
                 lazy = capi.dense_bwd(x, y if act is not None else None, dy, layer.kernel.detach() if need_dx else None, act,
                                       self._workspace(k, x.shape[0], kk, n, x.device), dX=dx, dW=dw, db=db, defer=self.defer_reduce)
                 # (defer_reduce: the partial sums stay in the workspace and the batch's ONE Adam launch adds them — no reduction launch)
@@ -125,7 +141,7 @@ class _DenseTape:
             grads[layer.kernel], grads[layer.bias] = dw, db
             if k == 0 and not need_input_grad:
                 return None
-            dx = torch.empty((x.shape[0], layer.kernel.shape[0]), dtype=torch.float32, device=x.device)
+            dx = dx_out if (k == 0 and dx_out is not None) else torch.empty((x.shape[0], layer.kernel.shape[0]), dtype=torch.float32, device=x.device)
             capi.dense(dz, layer.kernel.detach(), None, dx, act=None, w_transposed=True)
             dy = dx
         return dy
@@ -155,11 +171,11 @@ class _BasicHead:
         self.d = d
         return self.clf.forward(cat)
 
-    def backward(self, dz, grads, need_input_grad=True):
-        """dz = dL/d(last pre-activation). Returns (dL/dE[u], dL/dE[i]) (None, None when the inputs are constants)."""
+    def backward(self, dz, grads, need_input_grad=True, dx_out=(None, None)):
+        """dz = dL/d(last pre-activation). Returns (dL/dE[u], dL/dE[i]) (None, None when the inputs are constants); dx_out: where to."""
         dcat = self.clf.backward(dz, grads, last_is_dz=True)
-        return (self.unet.backward(dcat[:, :self.d], grads, need_input_grad=need_input_grad),
-                self.inet.backward(dcat[:, self.d:], grads, need_input_grad=need_input_grad))
+        return (self.unet.backward(dcat[:, :self.d], grads, need_input_grad=need_input_grad, dx_out=dx_out[0]),
+                self.inet.backward(dcat[:, self.d:], grads, need_input_grad=need_input_grad, dx_out=dx_out[1]))
 
 
 class _FusionTape:
@@ -540,7 +556,7 @@ class Trainer:
         capi.copy_columns(table, rows, ids=ids)
         return rows
 
-    def _forward_backward(self, u, i, yv, rows):
+    def _forward_backward(self, u, i, yv, rows, ui=None):
         """Device-only body of a batch (no host synchronisation, fixed shapes -> capturable as a hipGraph):
         returns (per-pair loss terms [B], {param: gradient})."""
         b = u.numel()
@@ -562,10 +578,18 @@ class Trainer:
         terms = torch.empty(b, dtype=torch.float32, device=dev)
         capi.bce_grad(p, yv, dz, terms)
         grads = {}
-        dgu, dgi = self.head.backward(dz, grads)
         de = torch.zeros((e.shape[0], f), dtype=torch.float32, device=dev)
-        capi.scatter_add_rows(dgu, u, de)
-        capi.scatter_add_rows(dgi, i, de)
+        both = None
+        if ui is not None and isinstance(self.head, _BasicHead) and not self.hybrid and 2 * b <= 8192:
+            # ui = [u ; i] (a replayed batch's id buffer): the towers leave their input gradients in the two halves of one
+            # buffer and ONE launch adds them to the node table's gradient (user and item ids never meet: same sums, same order)
+            both = torch.empty((2 * b, f), dtype=torch.float32, device=dev)
+            self.head.backward(dz, grads, dx_out=(both[:b], both[b:]))
+            capi.scatter_add_rows(both, ui, de)
+        else:
+            dgu, dgi = self.head.backward(dz, grads)
+            capi.scatter_add_rows(dgu, u, de)
+            capi.scatter_add_rows(dgi, i, de)
         self._propagation_backward(e, de, grads)
         return terms, grads
 
@@ -591,7 +615,7 @@ class Trainer:
         for t in tapes:                                              # weight-gradient partials stay partial: the Adam launch below adds them
             t.defer_reduce = True
         try:
-            terms, grads = self._forward_backward(g['u'], g['i'], g['y'], (g['ub'], g['ib']) if g['ub'] is not None else None)
+            terms, grads = self._forward_backward(g['u'], g['i'], g['y'], (g['ub'], g['ib']) if g['ub'] is not None else None, ui=g['ui'])
         finally:
             for t in tapes:
                 t.defer_reduce = False
@@ -602,9 +626,10 @@ class Trainer:
                     self.m[prm].view(-1), self.v[prm].view(-1), self._l2(prm)) for prm in self.params]
         host, blocks = capi.adam_slot_table(entries)
         g['slot_host'][:host.numel()].copy_(host)                    # pinned buffer allocated before the capture began
-        g['slot_dev'] = torch.empty(host.numel(), dtype=torch.uint8, device=self._adam_state.device)
-        g['slot_dev'].copy_(g['slot_host'][:host.numel()], non_blocking=True)
-        g['keep'] = entries                                          # the slots point into these tensors
+        g['slot_bytes'] = int(host.numel())                          # uploaded ONCE, right after the capture (train_batch_graphed), into a
+        g['keep'] = entries                                          # buffer allocated BEFORE it (memory of the capture's own pool is reused
+        #                                                              by the graph's temporaries): the table never changes — the slots point
+        #                                                              into tensors of the graph
         batch = float(g['u'].numel())
         capi.sum_into(terms, self._loss_sum)                         # sum of the per-pair terms = data loss x batch size
         capi.adam_multi(g['slot_dev'], len(entries), blocks, self._adam_state, self.b1, self.b2, self.eps,
@@ -630,11 +655,13 @@ class Trainer:
                 self._eager_loss += self.train_batch(u_ids, i_ids, y, bert=bert) * b
                 return
             d = int(np.asarray(bert[0]).shape[1]) if with_blocks else 0
-            g = self._g = {'u': torch.zeros(b, dtype=torch.int32, device=dev), 'i': torch.zeros(b, dtype=torch.int32, device=dev),
+            ui = torch.zeros(2 * b, dtype=torch.int32, device=dev)   # u and i side by side: one scatter of both towers' input gradients
+            g = self._g = {'ui': ui, 'u': ui[:b], 'i': ui[b:],
                            'y': torch.zeros(b, dtype=torch.float32, device=dev),
                            'ub': torch.zeros((b, d), dtype=torch.float32, device=dev) if with_blocks else None,
                            'ib': torch.zeros((b, d), dtype=torch.float32, device=dev) if with_blocks else None}
             g['slot_host'] = torch.empty(64 * len(self.params) + 64, dtype=torch.uint8).pin_memory()   # >= sizeof(amar_adam_slot) per parameter
+            g['slot_dev'] = torch.empty(64 * len(self.params) + 64, dtype=torch.uint8, device=dev)
             # pinned staging for the batch's ids and labels, four sets in turn: the uploads are asynchronous, so the host prepares
             # batch k + 1 while the device still runs batch k (a pageable copy_ made the host wait for the stream every batch:
             # 0.13 ms of a 0.52 ms batch at ml1m(s=1))
@@ -647,6 +674,7 @@ class Trainer:
                 with torch.no_grad():
                     self._graph_body()
             g['graph'], _ = capture_graph(body)
+            g['slot_dev'][:g['slot_bytes']].copy_(g['slot_host'][:g['slot_bytes']])   # the Adam slot table of this graph (fixed addresses): once, not per replay
             self._graphs[key] = g
         self._g = g
         n_nodes = self.seq.adj_matrix.shape[0] if getattr(self, 'seq', None) is not None else None

@@ -456,6 +456,18 @@ int64_t amar_wgrad_scratch_floats(int64_t M, int32_t K, int32_t N);
 int amar_dense_stack_f32(const float *X, int64_t ldx, const int32_t *ids, float *Xcopy, int64_t ldxc, int32_t n_layers,
                          const float *const *W, const float *const *bias, const int32_t *dims, const int32_t *acts,
                          float *const *Y, const int64_t *ldy, int64_t M, amar_stream_t stream);
+/* The reverse pass of a whole Dense stack (a tower / the classifier of src/models/basic.py:11-37 inside model.fit) in ONE launch: from
+ * dYtop = d(loss)/d(last output) (Ytop = that output; Ytop == NULL: dYtop is already the last pre-activation's gradient) down to
+ * dX0 = d(loss)/d(stack input) (or NULL), leaving every layer's dW[l] [K_l, N_l] and db[l] [N_l].  X[l] = layer l's input (X[l+1] is layer
+ * l's output), W, dims (n_layers + 1 widths), acts as in amar_dense_stack_f32; n_layers <= 4, widths <= 128, M <= 4 096 rows (else
+ * AMAR_EUNSUPPORTED: layer by layer).  workspace: amar_dense_stack_bwd_workspace_floats(M, n_layers, dims) floats of scratch.
+ * flags & AMAR_DENSE_BWD_DEFER: dW / db are not written; layer l's partials stay at  workspace + 4 + sum_{j<l} G (K_j N_j + N_j):
+ * [G][K_l N_l] then [G][N_l],  G = ceil(M / 64)  (amar_adam_multi_f32 with g_groups = G adds them). */
+int64_t amar_dense_stack_bwd_workspace_floats(int64_t M, int32_t n_layers, const int32_t *dims);
+int amar_dense_stack_bwd_f32(const float *dYtop, int64_t lddy, const float *Ytop, int64_t ldytop, int32_t n_layers,
+                             const float *const *X, const int64_t *ldx, const float *const *W, const int32_t *dims, const int32_t *acts,
+                             float *dX0, int64_t lddx0, float *const *dW, float *const *db, float *workspace, int32_t flags,
+                             int64_t M, amar_stream_t stream);
 /* The reverse pass of ONE Dense layer (Keras Dense inside model.fit: src/models/dense.py:4-17, src/experiment.py:183-188) in two launches
  * instead of four:
  *     dZ = dY * act'(Y)   (Y = the layer's OUTPUT; act == AMAR_ACT_NONE or Y == NULL: dY already is dZ)

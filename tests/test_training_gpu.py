@@ -194,6 +194,52 @@ def test_dense_stack_one_launch(hip, M, dims, acts, gather):
     assert not hip.dense_stack_supported([768, 256, 64]) and not hip.dense_stack_supported([8, 8, 8, 8, 8, 8])
 
 
+@pytest.mark.parametrize('M,dims,acts,top_is_dz', [(1024, [24, 24, 24], ['relu', 'relu'], False), (85, [96, 64, 64, 1], ['relu', 'relu', 'sigmoid'], True),
+                                                  (1000, [48, 48, 48, 48, 1], ['relu', 'relu', 'relu', 'sigmoid'], True), (3, [5, 7, 3], ['relu', None], False),
+                                                  (300, [128, 128, 16], ['relu', 'relu'], False)])
+def test_dense_stack_bwd_one_launch(hip, M, dims, acts, top_is_dz):
+    """amar_dense_stack_bwd_f32 (round 4: the reverse pass of a whole Dense stack in one launch) against float64: every layer's dW and
+    db, the input gradient, with the top gradient given w.r.t. the last output or w.r.t. its pre-activation; strided top operands;
+    deferred partial sums equal the reduced gradients."""
+    rng = np.random.default_rng(M + sum(dims))
+    L = len(acts)
+    ws = [(rng.standard_normal((dims[l], dims[l + 1])) * 0.3).astype(np.float32) for l in range(L)]
+    bs = [(rng.standard_normal(dims[l + 1]) * 0.1).astype(np.float32) for l in range(L)]
+    xs = [rng.standard_normal((M, dims[0])).astype(np.float32)]
+    for l, act in enumerate(acts):                                     # forward in float32 on the host: the tape's saved activations
+        z = xs[-1].astype(np.float64) @ ws[l] + bs[l]
+        xs.append((np.maximum(z, 0) if act == 'relu' else 1 / (1 + np.exp(-z)) if act == 'sigmoid' else z).astype(np.float32))
+    wide = rng.standard_normal((M, dims[-1] + 4)).astype(np.float32)   # the top gradient is a column slice of a wider buffer
+    top = wide[:, 4:]
+    g = top.astype(np.float64)
+    want_dw, want_db = [None] * L, [None] * L
+    for l in range(L - 1, -1, -1):
+        y = xs[l + 1].astype(np.float64)
+        if not (top_is_dz and l == L - 1):
+            g = g * (y > 0) if acts[l] == 'relu' else g * y * (1 - y) if acts[l] == 'sigmoid' else g
+        want_dw[l], want_db[l] = xs[l].astype(np.float64).T @ g, g.sum(0)
+        g = g @ ws[l].astype(np.float64).T
+    want_dx = g
+    assert hip.dense_stack_bwd_supported(dims, M)
+    wk = hip.dense_stack_bwd_workspace(M, dims, DEV)
+    ins = [_t(x) for x in xs[:-1]]
+    dws, dbs = [torch.empty((dims[l], dims[l + 1]), device=DEV) for l in range(L)], [torch.empty(dims[l + 1], device=DEV) for l in range(L)]
+    dx0 = torch.empty((M, dims[0]), device=DEV)
+    top_d = _t(wide)[:, 4:]
+    hip.dense_stack_bwd(top_d, None if top_is_dz else _t(xs[-1]), ins, [_t(w) for w in ws], acts, wk, dws, dbs, dX0=dx0)
+    tol = 5e-6
+    assert helpers.rel_err(dx0.cpu().numpy(), want_dx) < tol
+    for l in range(L):
+        assert helpers.rel_err(dws[l].cpu().numpy(), want_dw[l]) < tol, l
+        assert helpers.rel_err(dbs[l].cpu().numpy(), want_db[l]) < tol, l
+    lazy = hip.dense_stack_bwd(top_d, None if top_is_dz else _t(xs[-1]), ins, [_t(w) for w in ws], acts, wk,
+                               [torch.empty_like(w) for w in dws], [torch.empty_like(b) for b in dbs], dX0=None, defer=True)
+    for l in range(L):
+        assert helpers.rel_err(lazy[l][0].materialize().cpu().numpy(), dws[l].cpu().numpy().astype(np.float64)) < 1e-6
+        assert helpers.rel_err(lazy[l][1].materialize().cpu().numpy(), dbs[l].cpu().numpy().astype(np.float64)) < 1e-6
+    assert not hip.dense_stack_bwd_supported(dims, 5000) and not hip.dense_stack_bwd_supported([768, 256, 64], 100)
+
+
 def test_sage_training_kernels(hip):
     rng = np.random.default_rng(1)
     M, W = 777, 12
@@ -292,6 +338,7 @@ def test_gradients_match_oracle(hip, cls, graph, fused, monkeypatch):
     from deep_cbrs_amar_renaissance_amd import engine, training
     monkeypatch.setenv('AMAR_DENSE_BWD', '1' if fused else '0')     # the tapes on amar_dense_bwd_f32 / amar_dense_stack_f32 (the default) or on the separate kernels
     monkeypatch.setenv('AMAR_DENSE_STACK', '1' if fused else '0')
+    monkeypatch.setenv('AMAR_DENSE_STACK_BWD', '1' if fused else '0')
     from deep_cbrs_amar_renaissance_amd.models import basic
     engine.set_seed(5)
     g = helpers.tiny_graph(n_users=80, n_items=60, n_ratings=1500, seed=9,

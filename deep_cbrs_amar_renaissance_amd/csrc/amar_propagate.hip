@@ -156,18 +156,25 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * AMAR_WAVE) void spmm_stream_kerne
                 if (pt + 64 + lane < p1) { cnxt = a.colidx[pt + 64 + lane]; if (HAS_VALS) vnxt = a.vals[pt + 64 + lane]; }
             }
             const int hi = min(row_end, pt + 64);
-            for (int base = pos; base < hi; base += 2 * NS) {
+            // GPI gathers in flight per pass: a whole 64-entry tile from F = 16 on (round 4: with two, a wave walking the heaviest row
+            // of ml1m(s=1) — 1 400 entries, 16 per gather at F = 16 — paid 44 dependent memory round trips: the 15 us of every
+            // propagation launch of a training batch); each slot still adds its entries in the same order (s, s + NS, s + 2 NS, ...)
+            constexpr int GPI = LPN <= 2 ? 2 : (LPN >= 8 ? 8 : LPN);
+            for (int base = pos; base < hi; base += GPI * NS) {
                 // map tile positions back to the row-relative slot order: position p belongs to slot (p - row_beg) % NS
                 const int i0 = base + ((slot - (base - row_beg)) & (NS - 1));
-                const int i1 = i0 + NS;
-                const int c0 = __shfl(ccur, (i0 - pt) & 63, 64), c1 = __shfl(ccur, (i1 - pt) & 63, 64);
-                float v0 = 1.f, v1 = 1.f;
-                if (HAS_VALS) { v0 = __shfl(vcur, (i0 - pt) & 63, 64); v1 = __shfl(vcur, (i1 - pt) & 63, 64); }
-                float4 x0 = f4_zero(), x1 = f4_zero();
-                if (i0 < hi) x0 = *reinterpret_cast<const float4 *>(a.X + (int64_t)c0 * a.ldx + 4 * q);
-                if (i1 < hi) x1 = *reinterpret_cast<const float4 *>(a.X + (int64_t)c1 * a.ldx + 4 * q);
-                if (i0 < hi) acc = f4_fma(v0, x0, acc);
-                if (i1 < hi) acc = f4_fma(v1, x1, acc);
+                float4 xg[GPI];
+                float vg[GPI];
+#pragma unroll
+                for (int j = 0; j < GPI; ++j) {
+                    const int ij = i0 + j * NS;
+                    const int cj = __shfl(ccur, (ij - pt) & 63, 64);
+                    vg[j] = HAS_VALS ? __shfl(vcur, (ij - pt) & 63, 64) : 1.f;
+                    xg[j] = ij < hi ? *reinterpret_cast<const float4 *>(a.X + (int64_t)cj * a.ldx + 4 * q) : f4_zero();
+                }
+#pragma unroll
+                for (int j = 0; j < GPI; ++j)
+                    if (i0 + j * NS < hi) acc = f4_fma(vg[j], xg[j], acc);
             }
             pos = hi;
         }

@@ -515,7 +515,7 @@ unsigned grid1d(int64_t total) {
 // order: the gradients are reproducible bit for bit, no float atomics.  (A first version let the LAST workgroup to finish add the
 // partials behind a ticket: one workgroup adding 16 x 2 352 values from other XCDs' L2s took longer than the launch it saved —
 // 0.74 s per epoch against 0.50 with the separate kernels.)
-constexpr int DB_ROWS = 64, DB_MAXD = 128, DB_THREADS = 256, DB_MAX_GROUPS = 32;
+constexpr int DB_ROWS = 64, DB_MAXD = 128, DB_THREADS = 256, DB_MAX_GROUPS = 256;   // (partials are added by the Adam launch: many short workgroups beat few long ones)
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct DenseBwdArgs {

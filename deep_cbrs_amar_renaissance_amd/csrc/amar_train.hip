@@ -465,20 +465,44 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const amar_adam_slot *_
     const amar_adam_slot sl = slots[sidx];
     const float lr_t = state[1], l2x2 = 2.f * sl.l2;
     const int64_t base = ((int64_t)blockIdx.x - sl.first_block) * 1024;
+    // all sixteen loads of the block's four elements per thread first, then the deferred partial gradients four groups at a time
+    // (loads before adds, the adds in group order): written as one load -> add chain per element, the 16 partials of a Dense kernel's
+    // gradient were 16 dependent memory round trips — 30 us of every training batch, whatever the model's size
+    float wi[4], gs[4], mi[4], vi[4];
+    int64_t idx[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        idx[r] = base + r * 256 + threadIdx.x;
+        const bool ok = idx[r] < sl.n;
+        wi[r] = ok ? sl.w[idx[r]] : 0.f;
+        gs[r] = ok ? sl.g[idx[r]] : 0.f;
+        mi[r] = ok ? sl.m[idx[r]] : 0.f;
+        vi[r] = ok ? sl.v[idx[r]] : 0.f;
+    }
+    for (int c = 1; c < sl.g_groups; c += 4) {
+        float part[4][4];
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                part[cc][r] = (c + cc < sl.g_groups && idx[r] < sl.n) ? sl.g[(int64_t)(c + cc) * sl.n + idx[r]] : 0.f;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc)
+            if (c + cc < sl.g_groups) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gs[r] += part[cc][r];
+            }
+    }
     float sq = 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int64_t i = base + r * 256 + threadIdx.x;
-        if (i < sl.n) {
-            const float wi = sl.w[i];
-            float gsum = sl.g[i];
-            for (int c = 1; c < sl.g_groups; ++c) gsum += sl.g[(int64_t)c * sl.n + i];      // deferred partial gradients, in group order
-            const float gi = gsum + l2x2 * wi;
-            const float mi = b1 * sl.m[i] + (1.f - b1) * gi;
-            const float vi = b2 * sl.v[i] + (1.f - b2) * gi * gi;
-            sl.m[i] = mi; sl.v[i] = vi;
-            sl.w[i] = wi - lr_t * mi / (sqrtf(vi) + eps);
-            sq = fmaf(wi, wi, sq);
+        if (idx[r] < sl.n) {
+            const float gi = gs[r] + l2x2 * wi[r];
+            const float m1 = b1 * mi[r] + (1.f - b1) * gi;
+            const float v1 = b2 * vi[r] + (1.f - b2) * gi * gi;
+            sl.m[idx[r]] = m1; sl.v[idx[r]] = v1;
+            sl.w[idx[r]] = wi[r] - lr_t * m1 / (sqrtf(v1) + eps);
+            sq = fmaf(wi[r], wi[r], sq);
         }
     }
     if (loss_acc && sl.l2 != 0.f) {                                  // block sum, one atomic per block
@@ -524,9 +548,44 @@ struct DenseBwdArgs {
     float *dZ; int64_t lddz; int accum_dx;
 };
 
-__host__ __device__ inline int dense_bwd_subtiles(int64_t M) {
+// How a call over M rows is cut (round 4, second half).  Up to DB_MAX_GROUPS tiles of 64 rows: one workgroup and one partial per tile (the
+// batch-sized calls of a training step; the Adam launch adds the partials).  Beyond that — the GCN layers' reverse pass runs over every
+// NODE of the graph, 590 592 rows at ml1m(s=64) — the launch still takes one workgroup per tile (two tiles past 8 192 workgroups) and a
+// second launch folds the raw partials, `fold` at a time and in workgroup order, into at most DB_MAX_GROUPS partials: with 256 workgroups
+// walking 36 tiles each, one after the other behind a barrier, such a call took 119 us for 57 MB of operands.
+constexpr int DB_MAX_LAUNCH_GROUPS = 8192;
+struct DenseBwdPlan { int sub; int64_t launch_groups; int fold; int64_t out_groups; };
+inline DenseBwdPlan dense_bwd_plan(int64_t M) {
     const int64_t tiles = (M + DB_ROWS - 1) / DB_ROWS;
-    return (int)((tiles + DB_MAX_GROUPS - 1) / DB_MAX_GROUPS < 1 ? 1 : (tiles + DB_MAX_GROUPS - 1) / DB_MAX_GROUPS);
+    DenseBwdPlan p;
+    p.sub = (int)((tiles + DB_MAX_LAUNCH_GROUPS - 1) / DB_MAX_LAUNCH_GROUPS);
+    if (p.sub < 1) p.sub = 1;
+    p.launch_groups = (tiles + p.sub - 1) / p.sub;
+    p.fold = p.launch_groups > DB_MAX_GROUPS ? (int)((p.launch_groups + DB_MAX_GROUPS - 1) / DB_MAX_GROUPS) : 1;
+    p.out_groups = (p.launch_groups + p.fold - 1) / p.fold;
+    return p;
+}
+
+// out[g][e] = raw[g fold][e] + raw[g fold + 1][e] + ... (the last group may be short), for the weight and the bias partials in one launch
+__global__ __launch_bounds__(256) void fold_partials2_kernel(const float *__restrict__ raw_w, int64_t size_w, float *__restrict__ out_w,
+                                                             const float *__restrict__ raw_b, int64_t size_b, float *__restrict__ out_b,
+                                                             int64_t n_raw, int fold, int64_t n_out) {
+    const int64_t per = size_w + size_b, total = n_out * per;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t g = t / per, e = t - g * per;
+        const bool is_w = e < size_w;
+        const int64_t size = is_w ? size_w : size_b, idx = is_w ? e : e - size_w;
+        const float *src = (is_w ? raw_w : raw_b) + g * fold * size + idx;
+        const int64_t n = n_raw - g * fold < fold ? n_raw - g * fold : fold;
+        float s = 0.f;
+        int64_t c = 0;
+        for (; c + 4 <= n; c += 4) {                                  // loads first, adds in order
+            const float v0 = src[c * size], v1 = src[(c + 1) * size], v2 = src[(c + 2) * size], v3 = src[(c + 3) * size];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; c < n; ++c) s += src[c * size];
+        (is_w ? out_w : out_b)[g * size + idx] = s;
+    }
 }
 
 // stage a [rows x cols] tile (cols a multiple of 4 floats, 16-byte aligned source rows) into LDS with row stride `stride`: every
@@ -1055,14 +1114,13 @@ int amar_dense_stack_bwd_f32(const float *dYtop, int64_t lddy, const float *Ytop
 
 int64_t amar_dense_bwd_groups(int64_t M) {
     if (M < 0) return AMAR_EINVAL;
-    const int64_t rows = (int64_t)DB_ROWS * dense_bwd_subtiles(M);
-    return (M + rows - 1) / rows;
+    return dense_bwd_plan(M).out_groups;
 }
 
 int64_t amar_dense_bwd_workspace_floats(int64_t M, int32_t K, int32_t N) {
     if (M < 0 || K < 0 || N < 1) return AMAR_EINVAL;
-    const int64_t rows = (int64_t)DB_ROWS * dense_bwd_subtiles(M);
-    return 4 + ((M + rows - 1) / rows) * ((int64_t)K * N + N);
+    const DenseBwdPlan p = dense_bwd_plan(M);
+    return 4 + (p.out_groups + (p.fold > 1 ? p.launch_groups : 0)) * ((int64_t)K * N + N);   // the partials a caller sees first, the raw ones behind them
 }
 
 int amar_dense_bwd_f32(const float *X, int64_t ldx, const float *Y, int64_t ldy, const float *dY, int64_t lddy, const float *W,
@@ -1080,11 +1138,19 @@ int amar_dense_bwd_f32(const float *X, int64_t ldx, const float *Y, int64_t ldy,
     if ((dW || db) && !workspace) return AMAR_EINVAL;
     if (K > DB_MAXD || N > DB_MAXD) return AMAR_EUNSUPPORTED;
     if (M == 0) return AMAR_EUNSUPPORTED;                             // (an empty batch: the separate kernels define the zero gradients)
-    const int sub = dense_bwd_subtiles(M);
-    const int64_t groups = (M + (int64_t)DB_ROWS * sub - 1) / ((int64_t)DB_ROWS * sub);
-    float *part_w = dW ? workspace + 4 : nullptr;
-    float *part_b = db ? workspace + 4 + (dW ? groups * (int64_t)K * N : 0) : nullptr;
-    DenseBwdArgs a{dW ? X : nullptr, ldx, act != AMAR_ACT_NONE ? Y : nullptr, ldy, dY, lddy, dX ? W : nullptr, dX, lddx, part_w, part_b, M, K, N, act, sub,
+    const DenseBwdPlan plan = dense_bwd_plan(M);
+    const int sub = plan.sub;
+    const int64_t groups = plan.out_groups, launch_groups = plan.launch_groups;
+    const int64_t size_w = dW ? (int64_t)K * N : 0, size_b = db ? (int64_t)N : 0;
+    float *part_w = dW ? workspace + 4 : nullptr;                    // [groups][K N], then [groups][N]: what the caller (or the Adam launch) adds
+    float *part_b = db ? workspace + 4 + groups * size_w : nullptr;
+    float *raw_w = part_w, *raw_b = part_b;                          // where the workgroups write: the same, unless a fold launch follows
+    if (plan.fold > 1) {
+        float *raw = workspace + 4 + groups * ((int64_t)K * N + N);
+        raw_w = dW ? raw : nullptr;
+        raw_b = db ? raw + launch_groups * size_w : nullptr;
+    }
+    DenseBwdArgs a{dW ? X : nullptr, ldx, act != AMAR_ACT_NONE ? Y : nullptr, ldy, dY, lddy, dX ? W : nullptr, dX, lddx, raw_w, raw_b, M, K, N, act, sub,
                    dZ, lddz, accum ? 1 : 0};
     const int Kp = (K + 15) & ~15, Np = (N + 15) & ~15;
     const size_t lds = ((size_t)DB_ROWS * (Kp + 2) + (size_t)DB_ROWS * (Np + 2) + (size_t)Kp * (Np + 2)) * sizeof(float);
@@ -1097,11 +1163,14 @@ int amar_dense_bwd_f32(const float *X, int64_t ldx, const float *Y, int64_t ldy,
     do {                                                                                                                 \
         static bool allowed[AMAR_MAX_DEVICES] = {};                                                                      \
         if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_bwd_kernel<MT, VV>), lds, allowed)) return rc;   \
-        hipLaunchKernelGGL((dense_bwd_kernel<MT, VV>), dim3((unsigned)groups), dim3(DB_THREADS), lds, st, a);             \
+        hipLaunchKernelGGL((dense_bwd_kernel<MT, VV>), dim3((unsigned)launch_groups), dim3(DB_THREADS), lds, st, a);      \
     } while (0)
     if (small) { if (vec) AMAR_DB_LAUNCH(4, true); else AMAR_DB_LAUNCH(4, false); }
     else { if (vec) AMAR_DB_LAUNCH(16, true); else AMAR_DB_LAUNCH(16, false); }
 #undef AMAR_DB_LAUNCH
+    if (plan.fold > 1 && (dW || db))
+        hipLaunchKernelGGL(fold_partials2_kernel, dim3(grid1d(groups * (size_w + size_b))), dim3(256), 0, st, raw_w, size_w, part_w, raw_b, size_b, part_b,
+                           launch_groups, plan.fold, groups);
     if (defer) return amar_check_launch();                          // the partials stay in the workspace (amar_adam_multi_f32 adds them)
     if (dW && db) hipLaunchKernelGGL(reduce_partials2_kernel, dim3(grid1d((int64_t)K * N + N)), dim3(256), 0, st, part_w, (int64_t)K * N, dW,
                                      part_b, (int64_t)N, db, (int)groups);

@@ -100,7 +100,8 @@ def test_training_kernels(hip):
 
 
 @pytest.mark.parametrize('M,K,N,act', [(1024, 48, 48, 'relu'), (85, 96, 64, 'relu'), (1024, 64, 1, 'sigmoid'), (1024, 64, 1, None),
-                                         (9228, 16, 16, None), (1, 24, 24, 'relu'), (300, 128, 128, 'relu'), (64, 5, 3, 'sigmoid'), (40000, 32, 8, 'relu')])
+                                         (9228, 16, 16, None), (1, 24, 24, 'relu'), (300, 128, 128, 'relu'), (64, 5, 3, 'sigmoid'), (40000, 32, 8, 'relu'),
+                                         (600001, 8, 8, 'relu')])                     # (a convolution layer's reverse pass over every node: folded partials, two tiles per workgroup)
 def test_dense_bwd_fused(hip, M, K, N, act):
     """amar_dense_bwd_f32 (round 4: the reverse pass of one Dense layer in two launches instead of four — act', dX = dZ . W^T, dW = X^T . dZ, db) against
     float64 arithmetic and against the separate kernels it replaces; strided operands (column slices of wider buffers, as the
@@ -145,7 +146,7 @@ def test_dense_bwd_fused(hip, M, K, N, act):
     assert helpers.rel_err(dx7.cpu().numpy() - 1.0, want_dx) < 1e-5
     lazy_w, lazy_b = hip.dense_bwd(x_d, y_d if act is not None else None, dy_d, w_d, act, ws, dX=dx2, dW=dw2, db=db2, defer=True)
     assert torch.equal(lazy_w.materialize(), dw) is not None and helpers.rel_err(lazy_w.materialize().cpu().numpy(), want_dw) < tol
-    assert helpers.rel_err(lazy_b.materialize().cpu().numpy(), want_db) < tol and lazy_w.groups == lazy_b.groups >= 1
+    assert helpers.rel_err(lazy_b.materialize().cpu().numpy(), want_db) < tol and 1 <= lazy_w.groups == lazy_b.groups <= 256
     # against the kernels it replaces (other summation orders: tolerance, not bits)
     dz_d = torch.empty((M, N), device=DEV)
     if act is not None:

@@ -758,6 +758,109 @@ __global__ __launch_bounds__(DB_THREADS) void dense_bwd_kernel(const DenseBwdArg
     if (a.part_b && tid < a.N) a.part_b[(int64_t)blockIdx.x * a.N + tid] = accb;
 }
 
+// The same reverse pass for calls over MANY rows with NARROW operands (K, N <= 32, multiples of 4): the reverse pass of a convolution layer
+// runs over every node of the graph — 590 592 rows of 8 floats at ml1m(s=64) — where the tile kernel above (256 threads staging a 64 x 8
+// tile through the LDS for two 16 x 16 x 4 matrix instructions) is all latency: 85 us per call for 57-76 MB of operands.  Here NP / 4
+// threads share a row: each loads the row of dZ (and of X), keeps the outer-product accumulators of its own four dW columns (K float4) in
+// registers over a grid-stride walk of the rows, and computes the dX quads it owns against W read from the LDS.  A workgroup's partial =
+// butterfly over the lanes of a wave, then the four waves in order: a fixed order, reproducible bit for bit.
+template <int KP, int NP>
+__global__ __launch_bounds__(256) void dense_bwd_rows_kernel(const DenseBwdArgs a) {
+    constexpr int T = NP / 4, RPB = 256 / T, KQ = KP / 4;
+    __shared__ __attribute__((aligned(16))) float wt[NP][KP];        // W transposed: wt[n][k] (zero beyond K, N)
+    __shared__ float red[4][KP * NP + NP];
+    const int tid = threadIdx.x, t = tid % T, rl = tid / T, lane = tid & 63, wave = tid >> 6;
+    if (a.W) {
+        for (int e = tid; e < KP * NP; e += 256) {
+            const int k = e / NP, n = e - k * NP;
+            wt[n][k] = (k < a.K && n < a.N) ? a.W[(int64_t)k * a.N + n] : 0.f;
+        }
+        __syncthreads();
+    }
+    float4 accw[KP];
+#pragma unroll
+    for (int k = 0; k < KP; ++k) accw[k] = f4_zero();
+    float4 accb = f4_zero();
+    const int n0 = 4 * t;
+    for (int64_t row = (int64_t)blockIdx.x * RPB + rl; row < a.M; row += (int64_t)gridDim.x * RPB) {
+        float4 g[T];
+#pragma unroll
+        for (int j = 0; j < T; ++j) g[j] = 4 * j < a.N ? *reinterpret_cast<const float4 *>(a.dY + row * a.lddy + 4 * j) : f4_zero();
+        if (a.Y) {
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+                if (4 * j < a.N) {
+                    const float4 y = *reinterpret_cast<const float4 *>(a.Y + row * a.ldy + 4 * j);
+                    g[j] = make_float4(act_grad(g[j].x, y.x, a.act), act_grad(g[j].y, y.y, a.act), act_grad(g[j].z, y.z, a.act), act_grad(g[j].w, y.w, a.act));
+                }
+            }
+        }
+        float4 gq = f4_zero();                                       // this thread's own quad of dZ (a static pick: no dynamic register index)
+#pragma unroll
+        for (int j = 0; j < T; ++j) if (j == t) gq = g[j];
+        if (a.dZ && n0 < a.N) *reinterpret_cast<float4 *>(a.dZ + row * a.lddz + n0) = gq;
+        accb.x += gq.x; accb.y += gq.y; accb.z += gq.z; accb.w += gq.w;
+        if (a.X) {
+            float4 x[KQ];
+#pragma unroll
+            for (int j = 0; j < KQ; ++j) x[j] = 4 * j < a.K ? *reinterpret_cast<const float4 *>(a.X + row * a.ldx + 4 * j) : f4_zero();
+#pragma unroll
+            for (int j = 0; j < KQ; ++j) {
+                accw[4 * j + 0] = f4_fma(x[j].x, gq, accw[4 * j + 0]);
+                accw[4 * j + 1] = f4_fma(x[j].y, gq, accw[4 * j + 1]);
+                accw[4 * j + 2] = f4_fma(x[j].z, gq, accw[4 * j + 2]);
+                accw[4 * j + 3] = f4_fma(x[j].w, gq, accw[4 * j + 3]);
+            }
+        }
+        if (a.dX) {
+            for (int q = t; q < KQ; q += T) {                        // dX[row][4 q .. 4 q + 3] = sum over n of dZ[n] * W[k][n]
+                float4 acc = f4_zero();
+#pragma unroll
+                for (int j = 0; j < T; ++j) {
+                    acc = f4_fma(g[j].x, *reinterpret_cast<const float4 *>(&wt[4 * j + 0][4 * q]), acc);
+                    acc = f4_fma(g[j].y, *reinterpret_cast<const float4 *>(&wt[4 * j + 1][4 * q]), acc);
+                    acc = f4_fma(g[j].z, *reinterpret_cast<const float4 *>(&wt[4 * j + 2][4 * q]), acc);
+                    acc = f4_fma(g[j].w, *reinterpret_cast<const float4 *>(&wt[4 * j + 3][4 * q]), acc);
+                }
+                if (4 * q < a.K) {
+                    float4 *o = reinterpret_cast<float4 *>(a.dX + row * a.lddx + 4 * q);
+                    if (a.accum_dx) { const float4 old = *o; acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w; }
+                    *o = acc;
+                }
+            }
+        }
+    }
+    // the workgroup's partial: lanes that share a column quad (lane = t mod T) first, then the waves in order
+    if (a.part_w) {
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            float4 v = accw[k];
+#pragma unroll
+            for (int off = T; off < 64; off <<= 1) {
+                v.x += __shfl_xor(v.x, off, 64); v.y += __shfl_xor(v.y, off, 64); v.z += __shfl_xor(v.z, off, 64); v.w += __shfl_xor(v.w, off, 64);
+            }
+            if (lane < T) *reinterpret_cast<float4 *>(&red[wave][k * NP + n0]) = v;
+        }
+    }
+    if (a.part_b) {
+        float4 v = accb;
+#pragma unroll
+        for (int off = T; off < 64; off <<= 1) {
+            v.x += __shfl_xor(v.x, off, 64); v.y += __shfl_xor(v.y, off, 64); v.z += __shfl_xor(v.z, off, 64); v.w += __shfl_xor(v.w, off, 64);
+        }
+        if (lane < T) *reinterpret_cast<float4 *>(&red[wave][KP * NP + n0]) = v;
+    }
+    __syncthreads();
+    if (a.part_w)
+        for (int e = tid; e < a.K * a.N; e += 256) {
+            const int k = e / a.N, n = e - k * a.N;
+            a.part_w[(int64_t)blockIdx.x * a.K * a.N + e] = ((red[0][k * NP + n] + red[1][k * NP + n]) + red[2][k * NP + n]) + red[3][k * NP + n];
+        }
+    if (a.part_b && tid < a.N)
+        a.part_b[(int64_t)blockIdx.x * a.N + tid] = ((red[0][KP * NP + tid] + red[1][KP * NP + tid]) + red[2][KP * NP + tid]) + red[3][KP * NP + tid];
+}
+
+
 // ---- a whole Dense stack forward in one launch, every layer's output kept (round 4) ---------------------------------------------------
 // What fit()'s forward pass runs per tower / classifier: y_0 = X[ids], y_{l+1} = act_l(y_l . W_l + b_l), all y_l written out (the reverse
 // pass reads them).  One launch per stack instead of one per layer plus the row gather and the concat copies: a 64-row tile walks the
@@ -1120,7 +1223,7 @@ int64_t amar_dense_bwd_groups(int64_t M) {
 int64_t amar_dense_bwd_workspace_floats(int64_t M, int32_t K, int32_t N) {
     if (M < 0 || K < 0 || N < 1) return AMAR_EINVAL;
     const DenseBwdPlan p = dense_bwd_plan(M);
-    return 4 + (p.out_groups + (p.fold > 1 ? p.launch_groups : 0)) * ((int64_t)K * N + N);   // the partials a caller sees first, the raw ones behind them
+    return 4 + (p.out_groups + (p.fold > 1 ? p.out_groups * p.fold : 0)) * ((int64_t)K * N + N);   // the partials a caller sees first, the raw ones behind them
 }
 
 int amar_dense_bwd_f32(const float *X, int64_t ldx, const float *Y, int64_t ldy, const float *dY, int64_t lddy, const float *W,
@@ -1140,37 +1243,62 @@ int amar_dense_bwd_f32(const float *X, int64_t ldx, const float *Y, int64_t ldy,
     if (M == 0) return AMAR_EUNSUPPORTED;                             // (an empty batch: the separate kernels define the zero gradients)
     const DenseBwdPlan plan = dense_bwd_plan(M);
     const int sub = plan.sub;
-    const int64_t groups = plan.out_groups, launch_groups = plan.launch_groups;
+    const int64_t groups = plan.out_groups;
     const int64_t size_w = dW ? (int64_t)K * N : 0, size_b = db ? (int64_t)N : 0;
+    const int Kp = (K + 15) & ~15, Np = (N + 15) & ~15;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // 16-byte loads where every operand allows them (K, N and the leading dimensions multiples of 4 floats, 16-byte aligned bases)
+    const bool use_x = dW != nullptr, use_w = dX != nullptr, use_y = act != AMAR_ACT_NONE;
+    const bool vec = ((K & 3) == 0 || (!use_x && !use_w)) && (N & 3) == 0 && (lddy & 3) == 0 && amar_aligned16(dY) && (!use_y || ((ldy & 3) == 0 && amar_aligned16(Y))) &&
+                     (!use_x || ((ldx & 3) == 0 && amar_aligned16(X))) && (!use_w || amar_aligned16(W));
+    // many rows of narrow operands (a convolution layer's reverse pass over every node): the row-walking kernel, `fold` of its workgroups
+    // per partial the caller sees (AMAR_DENSE_BWD_ROWS_OFF: the tile kernel, for A/B timing)
+    static const bool rows_off = getenv("AMAR_DENSE_BWD_ROWS_OFF") != nullptr;
+    const bool rows_form = plan.fold > 1 && vec && K <= 32 && N <= 32 && (!dX || ((lddx & 3) == 0 && amar_aligned16(dX))) &&
+                           (!dZ || ((lddz & 3) == 0 && amar_aligned16(dZ))) && !rows_off;
+    const int fold = rows_form ? (plan.fold < 8 ? plan.fold : 8) : plan.fold;
+    const int64_t n_raw = rows_form ? groups * fold : plan.launch_groups;      // workgroups of the main launch = raw partials
     float *part_w = dW ? workspace + 4 : nullptr;                    // [groups][K N], then [groups][N]: what the caller (or the Adam launch) adds
     float *part_b = db ? workspace + 4 + groups * size_w : nullptr;
     float *raw_w = part_w, *raw_b = part_b;                          // where the workgroups write: the same, unless a fold launch follows
     if (plan.fold > 1) {
         float *raw = workspace + 4 + groups * ((int64_t)K * N + N);
         raw_w = dW ? raw : nullptr;
-        raw_b = db ? raw + launch_groups * size_w : nullptr;
+        raw_b = db ? raw + n_raw * size_w : nullptr;
     }
-    DenseBwdArgs a{dW ? X : nullptr, ldx, act != AMAR_ACT_NONE ? Y : nullptr, ldy, dY, lddy, dX ? W : nullptr, dX, lddx, raw_w, raw_b, M, K, N, act, sub,
+    DenseBwdArgs a{use_x ? X : nullptr, ldx, use_y ? Y : nullptr, ldy, dY, lddy, use_w ? W : nullptr, dX, lddx, raw_w, raw_b, M, K, N, act, sub,
                    dZ, lddz, accum ? 1 : 0};
-    const int Kp = (K + 15) & ~15, Np = (N + 15) & ~15;
-    const size_t lds = ((size_t)DB_ROWS * (Kp + 2) + (size_t)DB_ROWS * (Np + 2) + (size_t)Kp * (Np + 2)) * sizeof(float);
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    // 16-byte loads where every operand allows them (K, N and the leading dimensions multiples of 4 floats, 16-byte aligned bases)
-    const bool vec = ((K & 3) == 0 || (!a.X && !a.W)) && (N & 3) == 0 && (lddy & 3) == 0 && amar_aligned16(dY) && (!a.Y || ((ldy & 3) == 0 && amar_aligned16(Y))) &&
-                     (!a.X || ((ldx & 3) == 0 && amar_aligned16(X))) && (!a.W || amar_aligned16(W));
-    const bool small = (Kp >> 4) * (Np >> 4) <= 16;
+    if (rows_form) {
+#define AMAR_DBR_LAUNCH(KK, NN) hipLaunchKernelGGL((dense_bwd_rows_kernel<KK, NN>), dim3((unsigned)n_raw), dim3(256), 0, st, a)
+        const int kc = K <= 8 ? 0 : (K <= 16 ? 1 : 2), nc = N <= 8 ? 0 : (N <= 16 ? 1 : 2);
+        switch (3 * kc + nc) {
+        case 0: AMAR_DBR_LAUNCH(8, 8); break;
+        case 1: AMAR_DBR_LAUNCH(8, 16); break;
+        case 2: AMAR_DBR_LAUNCH(8, 32); break;
+        case 3: AMAR_DBR_LAUNCH(16, 8); break;
+        case 4: AMAR_DBR_LAUNCH(16, 16); break;
+        case 5: AMAR_DBR_LAUNCH(16, 32); break;
+        case 6: AMAR_DBR_LAUNCH(32, 8); break;
+        case 7: AMAR_DBR_LAUNCH(32, 16); break;
+        default: AMAR_DBR_LAUNCH(32, 32); break;
+        }
+#undef AMAR_DBR_LAUNCH
+    } else {
+        const size_t lds = ((size_t)DB_ROWS * (Kp + 2) + (size_t)DB_ROWS * (Np + 2) + (size_t)Kp * (Np + 2)) * sizeof(float);
+        const bool small = (Kp >> 4) * (Np >> 4) <= 16;
 #define AMAR_DB_LAUNCH(MT, VV)                                                                                           \
     do {                                                                                                                 \
         static bool allowed[AMAR_MAX_DEVICES] = {};                                                                      \
         if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_bwd_kernel<MT, VV>), lds, allowed)) return rc;   \
-        hipLaunchKernelGGL((dense_bwd_kernel<MT, VV>), dim3((unsigned)launch_groups), dim3(DB_THREADS), lds, st, a);      \
+        hipLaunchKernelGGL((dense_bwd_kernel<MT, VV>), dim3((unsigned)n_raw), dim3(DB_THREADS), lds, st, a);             \
     } while (0)
-    if (small) { if (vec) AMAR_DB_LAUNCH(4, true); else AMAR_DB_LAUNCH(4, false); }
-    else { if (vec) AMAR_DB_LAUNCH(16, true); else AMAR_DB_LAUNCH(16, false); }
+        if (small) { if (vec) AMAR_DB_LAUNCH(4, true); else AMAR_DB_LAUNCH(4, false); }
+        else { if (vec) AMAR_DB_LAUNCH(16, true); else AMAR_DB_LAUNCH(16, false); }
 #undef AMAR_DB_LAUNCH
+    }
     if (plan.fold > 1 && (dW || db))
         hipLaunchKernelGGL(fold_partials2_kernel, dim3(grid1d(groups * (size_w + size_b))), dim3(256), 0, st, raw_w, size_w, part_w, raw_b, size_b, part_b,
-                           launch_groups, plan.fold, groups);
+                           n_raw, fold, groups);
     if (defer) return amar_check_launch();                          // the partials stay in the workspace (amar_adam_multi_f32 adds them)
     if (dW && db) hipLaunchKernelGGL(reduce_partials2_kernel, dim3(grid1d((int64_t)K * N + N)), dim3(256), 0, st, part_w, (int64_t)K * N, dW,
                                      part_b, (int64_t)N, db, (int)groups);

@@ -465,45 +465,78 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const amar_adam_slot *_
     const amar_adam_slot sl = slots[sidx];
     const float lr_t = state[1], l2x2 = 2.f * sl.l2;
     const int64_t base = ((int64_t)blockIdx.x - sl.first_block) * 1024;
-    // all sixteen loads of the block's four elements per thread first, then the deferred partial gradients four groups at a time
-    // (loads before adds, the adds in group order): written as one load -> add chain per element, the 16 partials of a Dense kernel's
-    // gradient were 16 dependent memory round trips — 30 us of every training batch, whatever the model's size
+    // all loads of the block's four elements per thread first, then the deferred partial gradients four groups at a time (loads before
+    // adds, the adds in group order): written as one load -> add chain per element, the 16 partials of a Dense kernel's gradient were 16
+    // dependent memory round trips — 30 us of every training batch, whatever the model's size.  Slots whose arrays allow it (16-byte
+    // aligned, n a multiple of 4: every table and kernel of the models here) move 16 bytes per lane — a thread then owns four NEIGHBOURING
+    // elements instead of four 256 apart; each element's arithmetic is the same either way.
+    const bool vec = (sl.n & 3) == 0 && ((reinterpret_cast<uintptr_t>(sl.w) | reinterpret_cast<uintptr_t>(sl.g) | reinterpret_cast<uintptr_t>(sl.m) |
+                                          reinterpret_cast<uintptr_t>(sl.v)) & 15u) == 0;
     float wi[4], gs[4], mi[4], vi[4];
     int64_t idx[4];
+    if (vec) {
+        const int64_t i0 = base + 4 * threadIdx.x;
+        const bool ok = i0 < sl.n;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        idx[r] = base + r * 256 + threadIdx.x;
-        const bool ok = idx[r] < sl.n;
-        wi[r] = ok ? sl.w[idx[r]] : 0.f;
-        gs[r] = ok ? sl.g[idx[r]] : 0.f;
-        mi[r] = ok ? sl.m[idx[r]] : 0.f;
-        vi[r] = ok ? sl.v[idx[r]] : 0.f;
-    }
-    for (int c = 1; c < sl.g_groups; c += 4) {
-        float part[4][4];
+        for (int r = 0; r < 4; ++r) idx[r] = ok ? i0 + r : sl.n;
+        const float4 w4 = ok ? *reinterpret_cast<const float4 *>(sl.w + i0) : f4_zero(), g4 = ok ? *reinterpret_cast<const float4 *>(sl.g + i0) : f4_zero();
+        const float4 m4 = ok ? *reinterpret_cast<const float4 *>(sl.m + i0) : f4_zero(), v4 = ok ? *reinterpret_cast<const float4 *>(sl.v + i0) : f4_zero();
+        wi[0] = w4.x; wi[1] = w4.y; wi[2] = w4.z; wi[3] = w4.w;  gs[0] = g4.x; gs[1] = g4.y; gs[2] = g4.z; gs[3] = g4.w;
+        mi[0] = m4.x; mi[1] = m4.y; mi[2] = m4.z; mi[3] = m4.w;  vi[0] = v4.x; vi[1] = v4.y; vi[2] = v4.z; vi[3] = v4.w;
+        for (int c = 1; c < sl.g_groups; c += 4) {
+            float4 part[4];
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc)
+            for (int cc = 0; cc < 4; ++cc)
+                part[cc] = (c + cc < sl.g_groups && ok) ? *reinterpret_cast<const float4 *>(sl.g + (int64_t)(c + cc) * sl.n + i0) : f4_zero();
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                part[cc][r] = (c + cc < sl.g_groups && idx[r] < sl.n) ? sl.g[(int64_t)(c + cc) * sl.n + idx[r]] : 0.f;
+            for (int cc = 0; cc < 4; ++cc)
+                if (c + cc < sl.g_groups) { gs[0] += part[cc].x; gs[1] += part[cc].y; gs[2] += part[cc].z; gs[3] += part[cc].w; }
+        }
+    } else {
 #pragma unroll
-        for (int cc = 0; cc < 4; ++cc)
-            if (c + cc < sl.g_groups) {
+        for (int r = 0; r < 4; ++r) {
+            idx[r] = base + r * 256 + threadIdx.x;
+            const bool ok = idx[r] < sl.n;
+            wi[r] = ok ? sl.w[idx[r]] : 0.f;
+            gs[r] = ok ? sl.g[idx[r]] : 0.f;
+            mi[r] = ok ? sl.m[idx[r]] : 0.f;
+            vi[r] = ok ? sl.v[idx[r]] : 0.f;
+        }
+        for (int c = 1; c < sl.g_groups; c += 4) {
+            float part[4][4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) gs[r] += part[cc][r];
-            }
+            for (int cc = 0; cc < 4; ++cc)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    part[cc][r] = (c + cc < sl.g_groups && idx[r] < sl.n) ? sl.g[(int64_t)(c + cc) * sl.n + idx[r]] : 0.f;
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+                if (c + cc < sl.g_groups) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gs[r] += part[cc][r];
+                }
+        }
     }
     float sq = 0.f;
+    float wo[4], mo[4], vo[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        if (idx[r] < sl.n) {
-            const float gi = gs[r] + l2x2 * wi[r];
-            const float m1 = b1 * mi[r] + (1.f - b1) * gi;
-            const float v1 = b2 * vi[r] + (1.f - b2) * gi * gi;
-            sl.m[idx[r]] = m1; sl.v[idx[r]] = v1;
-            sl.w[idx[r]] = wi[r] - lr_t * m1 / (sqrtf(v1) + eps);
-            sq = fmaf(wi[r], wi[r], sq);
+        const float gi = gs[r] + l2x2 * wi[r];
+        mo[r] = b1 * mi[r] + (1.f - b1) * gi;
+        vo[r] = b2 * vi[r] + (1.f - b2) * gi * gi;
+        wo[r] = wi[r] - lr_t * mo[r] / (sqrtf(vo[r]) + eps);
+        if (idx[r] < sl.n) sq = fmaf(wi[r], wi[r], sq);
+    }
+    if (vec) {
+        if (idx[0] < sl.n) {
+            *reinterpret_cast<float4 *>(sl.m + idx[0]) = make_float4(mo[0], mo[1], mo[2], mo[3]);
+            *reinterpret_cast<float4 *>(sl.v + idx[0]) = make_float4(vo[0], vo[1], vo[2], vo[3]);
+            *reinterpret_cast<float4 *>(sl.w + idx[0]) = make_float4(wo[0], wo[1], wo[2], wo[3]);
         }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (idx[r] < sl.n) { sl.m[idx[r]] = mo[r]; sl.v[idx[r]] = vo[r]; sl.w[idx[r]] = wo[r]; }
     }
     if (loss_acc && sl.l2 != 0.f) {                                  // block sum, one atomic per block
         __shared__ float red[4];
@@ -539,7 +572,12 @@ unsigned grid1d(int64_t total) {
 // order: the gradients are reproducible bit for bit, no float atomics.  (A first version let the LAST workgroup to finish add the
 // partials behind a ticket: one workgroup adding 16 x 2 352 values from other XCDs' L2s took longer than the launch it saved —
 // 0.74 s per epoch against 0.50 with the separate kernels.)
-constexpr int DB_ROWS = 64, DB_MAXD = 128, DB_THREADS = 256, DB_MAX_GROUPS = 256;   // (partials are added by the Adam launch: many short workgroups beat few long ones)
+constexpr int DB_ROWS = 64, DB_MAXD = 128, DB_THREADS = 256;
+// partials a call leaves for its consumer (the Adam launch adds them, one thread per element, in group order).  16 = the tiles of a
+// 1 024-row batch.  It was 256: the weight gradient of a convolution layer over the 9 228 nodes of ml1m(s=1) then reached the Adam launch
+// as 145 partials (243 at s=64) of 64-256 elements — one workgroup adding them in dependent rounds of four: 30 us of a 37 us launch (s=1)
+// and 60 of 96 (s=64), found only when the launch was timed on a graph 64 times larger and did not get 64 times longer.
+constexpr int DB_MAX_GROUPS = 16;
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct DenseBwdArgs {
@@ -549,10 +587,11 @@ struct DenseBwdArgs {
 };
 
 // How a call over M rows is cut (round 4, second half).  Up to DB_MAX_GROUPS tiles of 64 rows: one workgroup and one partial per tile (the
-// batch-sized calls of a training step; the Adam launch adds the partials).  Beyond that — the GCN layers' reverse pass runs over every
-// NODE of the graph, 590 592 rows at ml1m(s=64) — the launch still takes one workgroup per tile (two tiles past 8 192 workgroups) and a
-// second launch folds the raw partials, `fold` at a time and in workgroup order, into at most DB_MAX_GROUPS partials: with 256 workgroups
-// walking 36 tiles each, one after the other behind a barrier, such a call took 119 us for 57 MB of operands.
+// batch-sized calls of a training step; the Adam launch adds the partials).  Beyond that — the reverse pass of a convolution layer runs
+// over every NODE of the graph, 590 592 rows at ml1m(s=64) — the launch still takes one workgroup per tile (two tiles past 8 192
+// workgroups; the row-walking kernel below: `fold` workgroups per partial) and a second launch folds the raw partials, `fold` at a time
+// and in workgroup order, into at most DB_MAX_GROUPS: with 256 workgroups walking 36 tiles each, one after the other behind a barrier,
+// such a call took 119 us for 57 MB of operands.
 constexpr int DB_MAX_LAUNCH_GROUPS = 8192;
 struct DenseBwdPlan { int sub; int64_t launch_groups; int fold; int64_t out_groups; };
 inline DenseBwdPlan dense_bwd_plan(int64_t M) {
@@ -579,9 +618,12 @@ __global__ __launch_bounds__(256) void fold_partials2_kernel(const float *__rest
         const int64_t n = n_raw - g * fold < fold ? n_raw - g * fold : fold;
         float s = 0.f;
         int64_t c = 0;
-        for (; c + 4 <= n; c += 4) {                                  // loads first, adds in order
-            const float v0 = src[c * size], v1 = src[(c + 1) * size], v2 = src[(c + 2) * size], v3 = src[(c + 3) * size];
-            s += v0; s += v1; s += v2; s += v3;
+        for (; c + 8 <= n; c += 8) {                                  // loads first, adds in order
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = src[(c + j) * size];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
         }
         for (; c < n; ++c) s += src[c * size];
         (is_w ? out_w : out_b)[g * size + idx] = s;
@@ -1256,7 +1298,7 @@ int amar_dense_bwd_f32(const float *X, int64_t ldx, const float *Y, int64_t ldy,
     static const bool rows_off = getenv("AMAR_DENSE_BWD_ROWS_OFF") != nullptr;
     const bool rows_form = plan.fold > 1 && vec && K <= 32 && N <= 32 && (!dX || ((lddx & 3) == 0 && amar_aligned16(dX))) &&
                            (!dZ || ((lddz & 3) == 0 && amar_aligned16(dZ))) && !rows_off;
-    const int fold = rows_form ? (plan.fold < 8 ? plan.fold : 8) : plan.fold;
+    const int fold = rows_form ? (plan.fold < 64 ? plan.fold : 64) : plan.fold;
     const int64_t n_raw = rows_form ? groups * fold : plan.launch_groups;      // workgroups of the main launch = raw partials
     float *part_w = dW ? workspace + 4 : nullptr;                    // [groups][K N], then [groups][N]: what the caller (or the Adam launch) adds
     float *part_b = db ? workspace + 4 + groups * size_w : nullptr;

@@ -473,9 +473,9 @@ int amar_dense_stack_bwd_f32(const float *dYtop, int64_t lddy, const float *Ytop
  *     dZ = dY * act'(Y)   (Y = the layer's OUTPUT; act == AMAR_ACT_NONE or Y == NULL: dY already is dZ)
  *     dX[M, K] = dZ . W^T (dX == NULL: skipped)      dW[K, N] = X^T . dZ (dW == NULL: skipped)      db[N] = column sums of dZ (or NULL)
  * Both products on the f32 matrix instruction; the workgroups (one per 64 rows) leave partial weight / bias gradients in the workspace, which
- * the second launch adds in workgroup order (a FIXED order: no float atomics, results reproducible bit for bit).  Past 256 workgroups (M >
- * 16 384: the reverse pass of a convolution layer runs over every node of the graph) a launch in between folds the raw partials, in
- * workgroup order, into at most 256.
+ * the second launch adds in workgroup order (a FIXED order: no float atomics, results reproducible bit for bit).  Past 16 workgroups (M >
+ * 1 024: the reverse pass of a convolution layer runs over every node of the graph) a launch in between folds the raw partials, in
+ * workgroup order, into at most 16 (G below), and operands of at most 32 columns take a row-walking kernel instead of the tile kernel.
  * K, N <= 128 (wider layers: AMAR_EUNSUPPORTED — use amar_act_bwd_f32 + amar_wgrad_f32 + amar_dense_f32 with AMAR_DENSE_WT).
  * workspace: amar_dense_bwd_workspace_floats(M, K, N) floats owned by the caller (scratch: any contents); two calls in flight on
  * different streams must not share one.

@@ -147,7 +147,7 @@ def test_dense_bwd_fused(hip, M, K, N, act):
     assert helpers.rel_err(dx7.cpu().numpy() - 1.0, want_dx) < 1e-5
     lazy_w, lazy_b = hip.dense_bwd(x_d, y_d if act is not None else None, dy_d, w_d, act, ws, dX=dx2, dW=dw2, db=db2, defer=True)
     assert torch.equal(lazy_w.materialize(), dw) is not None and helpers.rel_err(lazy_w.materialize().cpu().numpy(), want_dw) < tol
-    assert helpers.rel_err(lazy_b.materialize().cpu().numpy(), want_db) < tol and 1 <= lazy_w.groups == lazy_b.groups <= 256
+    assert helpers.rel_err(lazy_b.materialize().cpu().numpy(), want_db) < tol and 1 <= lazy_w.groups == lazy_b.groups <= 16
     # against the kernels it replaces (other summation orders: tolerance, not bits)
     dz_d = torch.empty((M, N), device=DEV)
     if act is not None:

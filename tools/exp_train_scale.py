@@ -26,7 +26,7 @@ def main():
     data = synthetic.ml1m_device(scale, device=dev)
     n = data['n_users'] + data['n_items']
     a = gcn_filter_device(data['train_pos'][:, 0], data['train_pos'][:, 1], n)
-    model = basic.BasicGCN(a, embedding_dim=d, n_hiddens=[d, d], dense_units=[3 * d, 3 * d], clf_units=[48, 48], l2_regularizer=1e-4)
+    model = basic.BasicGCN(a, embedding_dim=d, n_hiddens=[d, d], dense_units=[3 * d, 3 * d], clf_units=[48, 48], l2_regularizer=float(os.environ.get('EXP_L2', '1e-4')))
     model.n_users, model.n_items = data['n_users'], data['n_items']
     tr = training.Trainer(model, learning_rate=1e-3)
     gen = torch.Generator(device=dev)

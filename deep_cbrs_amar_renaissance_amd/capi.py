@@ -65,7 +65,9 @@ SIGNATURES = {
     'amar_wgrad_scratch_floats': (ctypes.c_int64, [_I64, _I32, _I32]),
     'amar_wgrad_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I32, _I32, _P, _P, _P, _P]),
     'amar_dense_stack_f32': (ctypes.c_int, [_P, _I64, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    'amar_dense_stack_pair_f32': (ctypes.c_int, [_P, _P, _P]),
     'amar_dense_stack_bwd_workspace_floats': (ctypes.c_int64, [_I64, _I32, _P]),
+    'amar_dense_stack_bwd_pair_f32': (ctypes.c_int, [_P, _P, _P]),
     'amar_dense_stack_bwd_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _I32, _I64, _P]),
     'amar_dense_bwd_workspace_floats': (ctypes.c_int64, [_I64, _I32, _I32]),
     'amar_dense_bwd_groups': (ctypes.c_int64, [_I64]),
@@ -873,9 +875,8 @@ def dense_stack_supported(dims):
     return 2 <= len(dims) <= 5 and all(1 <= int(d) <= 128 for d in dims)
 
 
-def dense_stack(X, weights, biases, acts, outs, ids=None, xcopy=None):
-    """A Dense stack forward in one launch with every layer's output kept (amar_dense_stack_f32): y_0 = X[ids], outs[l] = act_l(y_l . W_l + b_l).
-    outs[l] may be column slices of wider buffers; xcopy ([M, K_0]): also receives the gathered input rows."""
+def _dense_stack_args(X, weights, biases, acts, outs, ids=None, xcopy=None):
+    """The argument list of amar_dense_stack_f32 (without the stream) for one stack, checked."""
     n = len(weights)
     M = int(ids.numel()) if ids is not None else int(X.shape[0])
     dims = [int(weights[0].shape[0])] + [int(w.shape[1]) for w in weights]
@@ -895,10 +896,45 @@ def dense_stack(X, weights, biases, acts, outs, ids=None, xcopy=None):
     ld = (ctypes.c_int64 * n)(*[_ld(y, 'Y') for y in outs])
     dm = (ctypes.c_int32 * (n + 1))(*dims)
     ac = (ctypes.c_int32 * n)(*[ACT_CODES[a] for a in acts])
-    code = load().amar_dense_stack_f32(_ptr(X, torch.float32, 'X'), _ld(X, 'X'), _ptr(ids, torch.int32, 'ids'),
-                                       _ptr(xcopy, torch.float32, 'xcopy'), _ld(xcopy, 'xcopy') if xcopy is not None else 0, n,
-                                       wp, bp, dm, ac, yp, ld, M, _stream())
-    _check(code, 'amar_dense_stack_f32')
+    return [_ptr(X, torch.float32, 'X'), _ld(X, 'X'), _ptr(ids, torch.int32, 'ids'), _ptr(xcopy, torch.float32, 'xcopy'),
+            _ld(xcopy, 'xcopy') if xcopy is not None else 0, n, wp, bp, dm, ac, yp, ld, M]
+
+
+def dense_stack(X, weights, biases, acts, outs, ids=None, xcopy=None):
+    """A Dense stack forward in one launch with every layer's output kept (amar_dense_stack_f32): y_0 = X[ids], outs[l] = act_l(y_l . W_l + b_l).
+    outs[l] may be column slices of wider buffers; xcopy ([M, K_0]): also receives the gathered input rows."""
+    args = _dense_stack_args(X, weights, biases, acts, outs, ids=ids, xcopy=xcopy)
+    _check(load().amar_dense_stack_f32(*args, _stream()), 'amar_dense_stack_f32')
+
+
+class DenseStackDesc(ctypes.Structure):
+    """include/amar_hip.h: amar_dense_stack_desc"""
+    _fields_ = [('X', ctypes.c_void_p), ('ldx', ctypes.c_int64), ('ids', ctypes.c_void_p), ('Xcopy', ctypes.c_void_p), ('ldxc', ctypes.c_int64),
+                ('n_layers', ctypes.c_int32), ('W', ctypes.c_void_p), ('bias', ctypes.c_void_p), ('dims', ctypes.c_void_p), ('acts', ctypes.c_void_p),
+                ('Y', ctypes.c_void_p), ('ldy', ctypes.c_void_p), ('M', ctypes.c_int64)]
+
+
+class DenseStackBwdDesc(ctypes.Structure):
+    """include/amar_hip.h: amar_dense_stack_bwd_desc"""
+    _fields_ = [('dYtop', ctypes.c_void_p), ('lddy', ctypes.c_int64), ('Ytop', ctypes.c_void_p), ('ldytop', ctypes.c_int64), ('n_layers', ctypes.c_int32),
+                ('X', ctypes.c_void_p), ('ldx', ctypes.c_void_p), ('W', ctypes.c_void_p), ('dims', ctypes.c_void_p), ('acts', ctypes.c_void_p),
+                ('dX0', ctypes.c_void_p), ('lddx0', ctypes.c_int64), ('dW', ctypes.c_void_p), ('db', ctypes.c_void_p), ('workspace', ctypes.c_void_p),
+                ('flags', ctypes.c_int32), ('M', ctypes.c_int64)]
+
+
+def _as_pointer(v):
+    """ctypes arrays (host arrays of device pointers / values) and c_void_p values as plain addresses for a Structure field."""
+    if isinstance(v, ctypes.Array):
+        return ctypes.cast(v, ctypes.c_void_p).value
+    return v.value if isinstance(v, ctypes.c_void_p) else v
+
+
+def dense_stack_pair(first, second):
+    """Two independent Dense stacks forward in ONE launch (amar_dense_stack_pair_f32).  first / second: dicts of dense_stack's arguments
+    (X, weights, biases, acts, outs, ids, xcopy).  Same results as two dense_stack calls."""
+    a0, a1 = _dense_stack_args(**first), _dense_stack_args(**second)
+    d0, d1 = DenseStackDesc(*[_as_pointer(v) for v in a0]), DenseStackDesc(*[_as_pointer(v) for v in a1])
+    _check(load().amar_dense_stack_pair_f32(ctypes.byref(d0), ctypes.byref(d1), _stream()), 'amar_dense_stack_pair_f32')
 
 
 def dense_stack_bwd_supported(dims, M):
@@ -913,10 +949,8 @@ def dense_stack_bwd_workspace(M, dims, device):
     return torch.empty(max(floats, 4), dtype=torch.float32, device=device)
 
 
-def dense_stack_bwd(dYtop, Ytop, inputs, weights, acts, workspace, dWs, dbs, dX0=None, defer=False):
-    """The reverse pass of a Dense stack in one launch (amar_dense_stack_bwd_f32).  inputs[l] = layer l's input, Ytop = the last layer's
-    output (None: dYtop already is the last pre-activation's gradient).  defer=True: dWs / dbs are not written; returns one
-    (DeferredGradient dW, DeferredGradient db) per layer."""
+def _dense_stack_bwd_args(dYtop, Ytop, inputs, weights, acts, workspace, dWs, dbs, dX0=None, defer=False):
+    """The argument list of amar_dense_stack_bwd_f32 (without the stream) for one stack, checked, and its (n, M, dims)."""
     n = len(weights)
     M = int(dYtop.shape[0])
     dims = [int(weights[0].shape[0])] + [int(w.shape[1]) for w in weights]
@@ -936,16 +970,15 @@ def dense_stack_bwd(dYtop, Ytop, inputs, weights, acts, workspace, dWs, dbs, dX0
     dbp = arr_p(*[_ptr(b, torch.float32, 'db') for b in dbs])
     dm = (ctypes.c_int32 * (n + 1))(*dims)
     ac = (ctypes.c_int32 * n)(*[ACT_CODES[a] for a in acts])
-    lib = load()
-    if workspace.numel() < lib.amar_dense_stack_bwd_workspace_floats(M, n, dm):
+    if workspace.numel() < load().amar_dense_stack_bwd_workspace_floats(M, n, dm):
         raise ValueError("dense_stack_bwd: workspace too small (capi.dense_stack_bwd_workspace)")
-    code = lib.amar_dense_stack_bwd_f32(_ptr(dYtop, torch.float32, 'dYtop'), _ld(dYtop, 'dYtop'), _ptr(Ytop, torch.float32, 'Ytop'),
-                                        _ld(Ytop, 'Ytop') if Ytop is not None else 0, n, xp, lx, wp, dm, ac,
-                                        _ptr(dX0, torch.float32, 'dX0'), _ld(dX0, 'dX0') if dX0 is not None else 0, dwp, dbp,
-                                        _ptr(workspace, torch.float32, 'workspace'), DENSE_BWD_DEFER if defer else 0, M, _stream())
-    _check(code, 'amar_dense_stack_bwd_f32')
-    if not defer:
-        return None
+    args = [_ptr(dYtop, torch.float32, 'dYtop'), _ld(dYtop, 'dYtop'), _ptr(Ytop, torch.float32, 'Ytop'), _ld(Ytop, 'Ytop') if Ytop is not None else 0,
+            n, xp, lx, wp, dm, ac, _ptr(dX0, torch.float32, 'dX0'), _ld(dX0, 'dX0') if dX0 is not None else 0, dwp, dbp,
+            _ptr(workspace, torch.float32, 'workspace'), DENSE_BWD_DEFER if defer else 0, M]
+    return args, (n, M, dims)
+
+
+def _deferred_stack_gradients(workspace, n, M, dims):
     g = (M + 63) // 64
     out, off = [], 4
     for l in range(n):
@@ -954,6 +987,25 @@ def dense_stack_bwd(dYtop, Ytop, inputs, weights, acts, workspace, dWs, dbs, dX0
                     DeferredGradient(workspace[off + g * kn:off + g * (kn + nn)], g, (nn,))))
         off += g * (kn + nn)
     return out
+
+
+def dense_stack_bwd(dYtop, Ytop, inputs, weights, acts, workspace, dWs, dbs, dX0=None, defer=False):
+    """The reverse pass of a Dense stack in one launch (amar_dense_stack_bwd_f32).  inputs[l] = layer l's input, Ytop = the last layer's
+    output (None: dYtop already is the last pre-activation's gradient).  defer=True: dWs / dbs are not written; returns one
+    (DeferredGradient dW, DeferredGradient db) per layer."""
+    args, (n, M, dims) = _dense_stack_bwd_args(dYtop, Ytop, inputs, weights, acts, workspace, dWs, dbs, dX0=dX0, defer=defer)
+    _check(load().amar_dense_stack_bwd_f32(*args, _stream()), 'amar_dense_stack_bwd_f32')
+    return _deferred_stack_gradients(workspace, n, M, dims) if defer else None
+
+
+def dense_stack_bwd_pair(first, second):
+    """The reverse passes of two independent Dense stacks in ONE launch (amar_dense_stack_bwd_pair_f32).  first / second: dicts of
+    dense_stack_bwd's arguments.  Returns the two results dense_stack_bwd would have returned."""
+    (a0, m0), (a1, m1) = _dense_stack_bwd_args(**first), _dense_stack_bwd_args(**second)
+    d0, d1 = DenseStackBwdDesc(*[_as_pointer(v) for v in a0]), DenseStackBwdDesc(*[_as_pointer(v) for v in a1])
+    _check(load().amar_dense_stack_bwd_pair_f32(ctypes.byref(d0), ctypes.byref(d1), _stream()), 'amar_dense_stack_bwd_pair_f32')
+    return (_deferred_stack_gradients(first['workspace'], *m0) if first.get('defer') else None,
+            _deferred_stack_gradients(second['workspace'], *m1) if second.get('defer') else None)
 
 
 def dense_bwd_supported(K, N):

@@ -483,13 +483,13 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const amar_adam_slot *_
         const float4 m4 = ok ? *reinterpret_cast<const float4 *>(sl.m + i0) : f4_zero(), v4 = ok ? *reinterpret_cast<const float4 *>(sl.v + i0) : f4_zero();
         wi[0] = w4.x; wi[1] = w4.y; wi[2] = w4.z; wi[3] = w4.w;  gs[0] = g4.x; gs[1] = g4.y; gs[2] = g4.z; gs[3] = g4.w;
         mi[0] = m4.x; mi[1] = m4.y; mi[2] = m4.z; mi[3] = m4.w;  vi[0] = v4.x; vi[1] = v4.y; vi[2] = v4.z; vi[3] = v4.w;
-        for (int c = 1; c < sl.g_groups; c += 4) {
-            float4 part[4];
+        for (int c = 1; c < sl.g_groups; c += 16) {                  // sixteen groups in flight
+            float4 part[16];
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc)
+            for (int cc = 0; cc < 16; ++cc)
                 part[cc] = (c + cc < sl.g_groups && ok) ? *reinterpret_cast<const float4 *>(sl.g + (int64_t)(c + cc) * sl.n + i0) : f4_zero();
 #pragma unroll
-            for (int cc = 0; cc < 4; ++cc)
+            for (int cc = 0; cc < 16; ++cc)
                 if (c + cc < sl.g_groups) { gs[0] += part[cc].x; gs[1] += part[cc].y; gs[2] += part[cc].z; gs[3] += part[cc].w; }
         }
     } else {
@@ -573,11 +573,11 @@ unsigned grid1d(int64_t total) {
 // partials behind a ticket: one workgroup adding 16 x 2 352 values from other XCDs' L2s took longer than the launch it saved —
 // 0.74 s per epoch against 0.50 with the separate kernels.)
 constexpr int DB_ROWS = 64, DB_MAXD = 128, DB_THREADS = 256;
-// partials a call leaves for its consumer (the Adam launch adds them, one thread per element, in group order).  16 = the tiles of a
-// 1 024-row batch.  It was 256: the weight gradient of a convolution layer over the 9 228 nodes of ml1m(s=1) then reached the Adam launch
-// as 145 partials (243 at s=64) of 64-256 elements — one workgroup adding them in dependent rounds of four: 30 us of a 37 us launch (s=1)
-// and 60 of 96 (s=64), found only when the launch was timed on a graph 64 times larger and did not get 64 times longer.
-constexpr int DB_MAX_GROUPS = 16;
+// partials a call leaves for its consumer (the Adam launch adds them, one thread per element, in group order, sixteen loads in flight).
+// 64 = the tiles of a 4 096-row batch.  It was 256, added four at a time: the weight gradient of a convolution layer over the 9 228 nodes
+// of ml1m(s=1) then reached the Adam launch as 145 partials (243 at s=64) of 64-256 elements — one workgroup adding them in dependent
+// rounds: 30 us of a 37 us launch (s=1), found only when the launch was timed on a graph 64 times larger and did not get 64 times longer.
+constexpr int DB_MAX_GROUPS = 64;
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 struct DenseBwdArgs {
@@ -921,12 +921,12 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     return v;
 }
 
-__global__ __launch_bounds__(DB_THREADS) void dense_stack_kernel(const DenseStackArgs a) {
+__device__ __forceinline__ void dense_stack_body(const DenseStackArgs &a, const int block) {
     extern __shared__ __attribute__((aligned(16))) float ds_lds[];
     const int sa = a.maxd + 2;                                        // activation row stride ((stride / 2) odd: maxd is a multiple of 16)
     float *cur = ds_lds, *nxt = cur + DB_ROWS * sa, *ws = nxt + DB_ROWS * sa;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, l4 = lane >> 4;
-    const int64_t r0 = (int64_t)blockIdx.x * DB_ROWS;
+    const int64_t r0 = (int64_t)block * DB_ROWS;
     // a layer's kernel [Kp x Np] into `ws`: by 16-byte loads where its width allows (the first 64 rows may arrive in registers,
     // requested while the previous layer's products ran)
     auto w_load = [&](int l, int k_lo, int rows, float4 (&v)[8]) {
@@ -1007,6 +1007,16 @@ __global__ __launch_bounds__(DB_THREADS) void dense_stack_kernel(const DenseStac
     }
 }
 
+__global__ __launch_bounds__(DB_THREADS) void dense_stack_kernel(const DenseStackArgs a) { dense_stack_body(a, (int)blockIdx.x); }
+
+// two INDEPENDENT stacks in one launch (the user and the item tower of a training batch: 16 workgroups each, 18 us each as launches of
+// their own — a batch at ml1m(s=1) is a chain of such latencies): the first `split` workgroups run the first stack
+struct DenseStackPair { DenseStackArgs s0, s1; int split; };
+__global__ __launch_bounds__(DB_THREADS) void dense_stack_pair_kernel(const DenseStackPair p) {
+    if ((int)blockIdx.x < p.split) dense_stack_body(p.s0, (int)blockIdx.x);
+    else dense_stack_body(p.s1, (int)blockIdx.x - p.split);
+}
+
 // ---- the reverse pass of a whole Dense stack in one launch (round 4) ------------------------------------------------------------------
 // A 64-row tile walks the layers from the last to the first: dZ_l in LDS, dW_l / db_l partials out, dX_l = dZ_l . W_l^T in registers,
 // dZ_{l-1} = dX_l * act'(y_{l-1}) — and y_{l-1} IS layer l's input, already staged for the weight gradient.  One launch per tower /
@@ -1019,12 +1029,12 @@ struct DenseStackBwdArgs {
     int n_layers; int64_t M; int maxd;
 };
 
-__global__ __launch_bounds__(DB_THREADS) void dense_stack_bwd_kernel(const DenseStackBwdArgs a) {
+__device__ __forceinline__ void dense_stack_bwd_body(const DenseStackBwdArgs &a, const int block) {
     extern __shared__ __attribute__((aligned(16))) float sb_lds[];
     const int smax = a.maxd + 2;
     float *xs = sb_lds, *zs = xs + DB_ROWS * smax, *ws = zs + DB_ROWS * smax;      // X_l tile, dZ_l tile, W_l (each with its layer's stride)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, l4 = lane >> 4;
-    const int64_t r0 = (int64_t)blockIdx.x * DB_ROWS;
+    const int64_t r0 = (int64_t)block * DB_ROWS;
     const int L = a.n_layers;
     {   // dZ of the last layer: dYtop * act'(Ytop) (Ytop == NULL: dYtop already is dZ)
         const int N = a.dims[L], Np = (N + 15) & ~15, sz = Np + 2, actl = a.act[L - 1];
@@ -1090,7 +1100,7 @@ __global__ __launch_bounds__(DB_THREADS) void dense_stack_bwd_kernel(const Dense
         __syncthreads();
         // dW_l partial [K x N] = X_l^T . dZ_l, db_l partial
         if (a.part_w[l]) {
-            float *mine = a.part_w[l] + (int64_t)blockIdx.x * K * N;
+            float *mine = a.part_w[l] + (int64_t)block * K * N;
             for (int tile = wave; tile < kt_n * nt_n; tile += DB_THREADS / 64) {
                 const int kt = tile / nt_n, nt = tile - kt * nt_n;
                 const float *ap = xs + l4 * sx + 16 * kt + l16, *bp = zs + l4 * sz + 16 * nt + l16;
@@ -1111,7 +1121,7 @@ __global__ __launch_bounds__(DB_THREADS) void dense_stack_bwd_kernel(const Dense
             for (int r = 0; r < DB_ROWS; r += 4) {
                 b0 += zs[r * sz + tid]; b1 += zs[(r + 1) * sz + tid]; b2 += zs[(r + 2) * sz + tid]; b3 += zs[(r + 3) * sz + tid];
             }
-            a.part_b[l][(int64_t)blockIdx.x * N + tid] = (b0 + b1) + (b2 + b3);
+            a.part_b[l][(int64_t)block * N + tid] = (b0 + b1) + (b2 + b3);
         }
         // dX_l [64 x K] = dZ_l . W_l^T in registers: this wave's tiles are wave, wave + 4, ... (at most 8: K <= 128)
         v4f dxa[8];
@@ -1163,16 +1173,24 @@ __global__ __launch_bounds__(DB_THREADS) void dense_stack_bwd_kernel(const Dense
     }
 }
 
+__global__ __launch_bounds__(DB_THREADS) void dense_stack_bwd_kernel(const DenseStackBwdArgs a) { dense_stack_bwd_body(a, (int)blockIdx.x); }
+
+struct DenseStackBwdPair { DenseStackBwdArgs s0, s1; int split; };
+__global__ __launch_bounds__(DB_THREADS) void dense_stack_bwd_pair_kernel(const DenseStackBwdPair p) {
+    if ((int)blockIdx.x < p.split) dense_stack_bwd_body(p.s0, (int)blockIdx.x);
+    else dense_stack_bwd_body(p.s1, (int)blockIdx.x - p.split);
+}
+
 }  // namespace
 
 extern "C" {
 
-int amar_dense_stack_f32(const float *X, int64_t ldx, const int32_t *ids, float *Xcopy, int64_t ldxc, int32_t n_layers,
-                         const float *const *W, const float *const *bias, const int32_t *dims, const int32_t *acts,
-                         float *const *Y, const int64_t *ldy, int64_t M, amar_stream_t stream) {
+static int build_dense_stack(const float *X, int64_t ldx, const int32_t *ids, float *Xcopy, int64_t ldxc, int32_t n_layers,
+                             const float *const *W, const float *const *bias, const int32_t *dims, const int32_t *acts,
+                             float *const *Y, const int64_t *ldy, int64_t M, DenseStackArgs &a, size_t &lds, int64_t &groups) {
     if (M < 0 || !X || n_layers < 1 || !W || !bias || !dims || !acts || !Y || !ldy) return AMAR_EINVAL;
     if (n_layers > DS_MAX_LAYERS) return AMAR_EUNSUPPORTED;
-    DenseStackArgs a{};
+    a = DenseStackArgs{};
     a.X = X; a.ldx = ldx; a.ids = ids; a.Xcopy = Xcopy; a.ldxc = ldxc; a.n_layers = n_layers; a.M = M;
     int maxd = 16;
     for (int l = 0; l <= n_layers; ++l) {
@@ -1194,13 +1212,41 @@ int amar_dense_stack_f32(const float *X, int64_t ldx, const int32_t *ids, float 
     }
     a.maxd = maxd;
     a.vec_x = ((dims[0] & 3) == 0 && (ldx & 3) == 0 && amar_aligned16(X) && (!Xcopy || ((ldxc & 3) == 0 && amar_aligned16(Xcopy)))) ? 1 : 0;
+    groups = (M + DB_ROWS - 1) / DB_ROWS;
+    if (groups > 0x3fffffff) return AMAR_EUNSUPPORTED;
+    lds = ((size_t)2 * DB_ROWS * (maxd + 2) + (size_t)maxw) * sizeof(float);
+    return AMAR_OK;
+}
+
+int amar_dense_stack_f32(const float *X, int64_t ldx, const int32_t *ids, float *Xcopy, int64_t ldxc, int32_t n_layers,
+                         const float *const *W, const float *const *bias, const int32_t *dims, const int32_t *acts,
+                         float *const *Y, const int64_t *ldy, int64_t M, amar_stream_t stream) {
+    DenseStackArgs a;
+    size_t lds = 0;
+    int64_t groups = 0;
+    if (const int rc = build_dense_stack(X, ldx, ids, Xcopy, ldxc, n_layers, W, bias, dims, acts, Y, ldy, M, a, lds, groups)) return rc;
     if (M == 0) return AMAR_OK;
-    const int64_t groups = (M + DB_ROWS - 1) / DB_ROWS;
-    if (groups > 0x7fffffff) return AMAR_EUNSUPPORTED;
-    const size_t lds = ((size_t)2 * DB_ROWS * (maxd + 2) + (size_t)maxw) * sizeof(float);
     static bool allowed[AMAR_MAX_DEVICES] = {};
     if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_stack_kernel), lds, allowed)) return rc;
     hipLaunchKernelGGL(dense_stack_kernel, dim3((unsigned)groups), dim3(DB_THREADS), lds, static_cast<hipStream_t>(stream), a);
+    return amar_check_launch();
+}
+
+int amar_dense_stack_pair_f32(const amar_dense_stack_desc *s0, const amar_dense_stack_desc *s1, amar_stream_t stream) {
+    if (!s0 || !s1) return AMAR_EINVAL;
+    DenseStackPair p;
+    size_t lds0 = 0, lds1 = 0;
+    int64_t g0 = 0, g1 = 0;
+    if (const int rc = build_dense_stack(s0->X, s0->ldx, s0->ids, s0->Xcopy, s0->ldxc, s0->n_layers, s0->W, s0->bias, s0->dims, s0->acts, s0->Y, s0->ldy,
+                                         s0->M, p.s0, lds0, g0)) return rc;
+    if (const int rc = build_dense_stack(s1->X, s1->ldx, s1->ids, s1->Xcopy, s1->ldxc, s1->n_layers, s1->W, s1->bias, s1->dims, s1->acts, s1->Y, s1->ldy,
+                                         s1->M, p.s1, lds1, g1)) return rc;
+    if (g0 + g1 == 0) return AMAR_OK;
+    p.split = (int)g0;
+    const size_t lds = lds0 > lds1 ? lds0 : lds1;
+    static bool allowed[AMAR_MAX_DEVICES] = {};
+    if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_stack_pair_kernel), lds, allowed)) return rc;
+    hipLaunchKernelGGL(dense_stack_pair_kernel, dim3((unsigned)(g0 + g1)), dim3(DB_THREADS), lds, static_cast<hipStream_t>(stream), p);
     return amar_check_launch();
 }
 
@@ -1212,15 +1258,15 @@ int64_t amar_dense_stack_bwd_workspace_floats(int64_t M, int32_t n_layers, const
     return total;
 }
 
-int amar_dense_stack_bwd_f32(const float *dYtop, int64_t lddy, const float *Ytop, int64_t ldytop, int32_t n_layers,
-                             const float *const *X, const int64_t *ldx, const float *const *W, const int32_t *dims, const int32_t *acts,
-                             float *dX0, int64_t lddx0, float *const *dW, float *const *db, float *workspace, int32_t flags,
-                             int64_t M, amar_stream_t stream) {
+static int build_dense_stack_bwd(const float *dYtop, int64_t lddy, const float *Ytop, int64_t ldytop, int32_t n_layers,
+                                 const float *const *X, const int64_t *ldx, const float *const *W, const int32_t *dims, const int32_t *acts,
+                                 float *dX0, int64_t lddx0, float *const *dW, float *const *db, float *workspace, int64_t M,
+                                 DenseStackBwdArgs &a, size_t &lds, int64_t &groups) {
     if (M < 1 || !dYtop || n_layers < 1 || !X || !ldx || !W || !dims || !acts || !dW || !db || !workspace) return AMAR_EINVAL;
     if (n_layers > DS_MAX_LAYERS) return AMAR_EUNSUPPORTED;
-    const int64_t groups = (M + DB_ROWS - 1) / DB_ROWS;
+    groups = (M + DB_ROWS - 1) / DB_ROWS;
     if (groups > 64) return AMAR_EUNSUPPORTED;                       // (batch-sized operands: one 64-row tile per workgroup, no sub-tiles)
-    DenseStackBwdArgs a{};
+    a = DenseStackBwdArgs{};
     a.dYtop = dYtop; a.lddy = lddy; a.Ytop = Ytop; a.ldytop = ldytop; a.dX0 = dX0; a.lddx0 = lddx0; a.n_layers = n_layers; a.M = M;
     int maxd = 16;
     for (int l = 0; l <= n_layers; ++l) {
@@ -1245,15 +1291,49 @@ int amar_dense_stack_bwd_f32(const float *dYtop, int64_t lddy, const float *Ytop
         if (w > maxw) maxw = w;
     }
     a.maxd = maxd;
-    const size_t lds = ((size_t)2 * DB_ROWS * (maxd + 2) + (size_t)maxw) * sizeof(float);
+    lds = ((size_t)2 * DB_ROWS * (maxd + 2) + (size_t)maxw) * sizeof(float);
+    return AMAR_OK;
+}
+
+static void reduce_stack_partials(const DenseStackBwdArgs &a, const int32_t *dims, float *const *dW, float *const *db, int64_t groups, hipStream_t st) {
+    for (int l = 0; l < a.n_layers; ++l)
+        hipLaunchKernelGGL(reduce_partials2_kernel, dim3(grid1d((int64_t)dims[l] * dims[l + 1] + dims[l + 1])), dim3(256), 0, st, a.part_w[l],
+                           (int64_t)dims[l] * dims[l + 1], dW[l], a.part_b[l], (int64_t)dims[l + 1], db[l], (int)groups);
+}
+
+int amar_dense_stack_bwd_f32(const float *dYtop, int64_t lddy, const float *Ytop, int64_t ldytop, int32_t n_layers,
+                             const float *const *X, const int64_t *ldx, const float *const *W, const int32_t *dims, const int32_t *acts,
+                             float *dX0, int64_t lddx0, float *const *dW, float *const *db, float *workspace, int32_t flags,
+                             int64_t M, amar_stream_t stream) {
+    DenseStackBwdArgs a;
+    size_t lds = 0;
+    int64_t groups = 0;
+    if (const int rc = build_dense_stack_bwd(dYtop, lddy, Ytop, ldytop, n_layers, X, ldx, W, dims, acts, dX0, lddx0, dW, db, workspace, M, a, lds, groups)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
     static bool allowed[AMAR_MAX_DEVICES] = {};
     if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_stack_bwd_kernel), lds, allowed)) return rc;
     hipLaunchKernelGGL(dense_stack_bwd_kernel, dim3((unsigned)groups), dim3(DB_THREADS), lds, st, a);
-    if (!(flags & AMAR_DENSE_BWD_DEFER))
-        for (int l = 0; l < n_layers; ++l)
-            hipLaunchKernelGGL(reduce_partials2_kernel, dim3(grid1d((int64_t)dims[l] * dims[l + 1] + dims[l + 1])), dim3(256), 0, st, a.part_w[l],
-                               (int64_t)dims[l] * dims[l + 1], dW[l], a.part_b[l], (int64_t)dims[l + 1], db[l], (int)groups);
+    if (!(flags & AMAR_DENSE_BWD_DEFER)) reduce_stack_partials(a, dims, dW, db, groups, st);
+    return amar_check_launch();
+}
+
+int amar_dense_stack_bwd_pair_f32(const amar_dense_stack_bwd_desc *s0, const amar_dense_stack_bwd_desc *s1, amar_stream_t stream) {
+    if (!s0 || !s1) return AMAR_EINVAL;
+    DenseStackBwdPair p;
+    size_t lds0 = 0, lds1 = 0;
+    int64_t g0 = 0, g1 = 0;
+    if (const int rc = build_dense_stack_bwd(s0->dYtop, s0->lddy, s0->Ytop, s0->ldytop, s0->n_layers, s0->X, s0->ldx, s0->W, s0->dims, s0->acts, s0->dX0,
+                                             s0->lddx0, s0->dW, s0->db, s0->workspace, s0->M, p.s0, lds0, g0)) return rc;
+    if (const int rc = build_dense_stack_bwd(s1->dYtop, s1->lddy, s1->Ytop, s1->ldytop, s1->n_layers, s1->X, s1->ldx, s1->W, s1->dims, s1->acts, s1->dX0,
+                                             s1->lddx0, s1->dW, s1->db, s1->workspace, s1->M, p.s1, lds1, g1)) return rc;
+    p.split = (int)g0;
+    const size_t lds = lds0 > lds1 ? lds0 : lds1;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    static bool allowed[AMAR_MAX_DEVICES] = {};
+    if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_stack_bwd_pair_kernel), lds, allowed)) return rc;
+    hipLaunchKernelGGL(dense_stack_bwd_pair_kernel, dim3((unsigned)(g0 + g1)), dim3(DB_THREADS), lds, st, p);
+    if (!(s0->flags & AMAR_DENSE_BWD_DEFER)) reduce_stack_partials(p.s0, s0->dims, s0->dW, s0->db, g0, st);
+    if (!(s1->flags & AMAR_DENSE_BWD_DEFER)) reduce_stack_partials(p.s1, s1->dims, s1->dW, s1->db, g1, st);
     return amar_check_launch();
 }
 
@@ -1298,12 +1378,15 @@ int amar_dense_bwd_f32(const float *X, int64_t ldx, const float *Y, int64_t ldy,
     static const bool rows_off = getenv("AMAR_DENSE_BWD_ROWS_OFF") != nullptr;
     const bool rows_form = plan.fold > 1 && vec && K <= 32 && N <= 32 && (!dX || ((lddx & 3) == 0 && amar_aligned16(dX))) &&
                            (!dZ || ((lddz & 3) == 0 && amar_aligned16(dZ))) && !rows_off;
-    const int fold = rows_form ? (plan.fold < 64 ? plan.fold : 64) : plan.fold;
+    // the row-walking kernel up to 32 768 rows: one workgroup per partial the caller sees, no fold launch (9 228 rows at ml1m(s=1): 49
+    // workgroups of three passes); beyond: up to 64 workgroups per partial
+    const bool need_fold = plan.fold > 1 && !(rows_form && M <= 32768);
+    const int fold = !need_fold ? 1 : rows_form ? (plan.fold < 64 ? plan.fold : 64) : plan.fold;
     const int64_t n_raw = rows_form ? groups * fold : plan.launch_groups;      // workgroups of the main launch = raw partials
     float *part_w = dW ? workspace + 4 : nullptr;                    // [groups][K N], then [groups][N]: what the caller (or the Adam launch) adds
     float *part_b = db ? workspace + 4 + groups * size_w : nullptr;
     float *raw_w = part_w, *raw_b = part_b;                          // where the workgroups write: the same, unless a fold launch follows
-    if (plan.fold > 1) {
+    if (need_fold) {
         float *raw = workspace + 4 + groups * ((int64_t)K * N + N);
         raw_w = dW ? raw : nullptr;
         raw_b = db ? raw + n_raw * size_w : nullptr;
@@ -1338,7 +1421,7 @@ int amar_dense_bwd_f32(const float *X, int64_t ldx, const float *Y, int64_t ldy,
         else { if (vec) AMAR_DB_LAUNCH(16, true); else AMAR_DB_LAUNCH(16, false); }
 #undef AMAR_DB_LAUNCH
     }
-    if (plan.fold > 1 && (dW || db))
+    if (need_fold && (dW || db))
         hipLaunchKernelGGL(fold_partials2_kernel, dim3(grid1d(groups * (size_w + size_b))), dim3(256), 0, st, raw_w, size_w, part_w, raw_b, size_b, part_b,
                            n_raw, fold, groups);
     if (defer) return amar_check_launch();                          // the partials stay in the workspace (amar_adam_multi_f32 adds them)

@@ -66,22 +66,49 @@ class _DenseTape:
             self._workspaces[key] = capi.dense_bwd_workspace(m, kk, n, device)
         return self._workspaces[key]
 
+    def _stack_spec(self, x, ids, out_last):
+        """The arguments of the one-launch forward (capi.dense_stack) for this call, or None where the stack runs layer by layer."""
+        m = int(ids.numel()) if ids is not None else int(x.shape[0])
+        dims = [int(self.layers[0].kernel.shape[0])] + [int(l.units) for l in self.layers]
+        if not (capi.dense_stack_enabled() and capi.dense_stack_supported(dims) and m > 0):
+            return None
+        dev = x.device
+        outs = [torch.empty((m, l.units), dtype=torch.float32, device=dev) for l in self.layers]
+        if out_last is not None:
+            outs[-1] = out_last
+        xin = torch.empty((m, dims[0]), dtype=torch.float32, device=dev) if ids is not None else None
+        return dict(X=x, weights=[l.kernel.detach() for l in self.layers], biases=[l.bias.detach() for l in self.layers],
+                    acts=[l.activation for l in self.layers], outs=outs, ids=ids, xcopy=xin)
+
+    def _stack_done(self, spec):
+        outs = spec['outs']
+        self.inputs, self.outputs = [spec['xcopy'] if spec['ids'] is not None else spec['X']] + outs[:-1], outs
+        return outs[-1]
+
+    @staticmethod
+    def forward_pair(first, first_args, second, second_args):
+        """Two independent stacks (the user and the item tower) in ONE launch where both take the one-launch forward
+        (capi.dense_stack_pair; AMAR_DENSE_PAIR=0: one launch each).  *_args = (x, ids, out_last)."""
+        s0, s1 = first._stack_spec(*first_args), second._stack_spec(*second_args)
+        if s0 is not None and s1 is not None and os.environ.get('AMAR_DENSE_PAIR', '1') != '0':
+            capi.dense_stack_pair(s0, s1)
+            return first._stack_done(s0), second._stack_done(s1)
+        return first.forward(*first_args), second.forward(*second_args)
+
     def forward(self, x, ids=None, out_last=None):
         """y = stack(x[ids]) keeping every layer's input and output.  ids: gather the input rows first; out_last: where the last
         layer's output goes (a column slice of a concatenation buffer).  Stacks of at most four layers no wider than 128 run as ONE
         launch (amar_dense_stack_f32, round 4: gather, layers and the concat store together); others layer by layer."""
+        spec = self._stack_spec(x, ids, out_last)
+        if spec is not None:
+            capi.dense_stack(**spec)
+            return self._stack_done(spec)
         m = int(ids.numel()) if ids is not None else int(x.shape[0])
         dev = x.device
         dims = [int(self.layers[0].kernel.shape[0])] + [int(l.units) for l in self.layers]
         outs = [torch.empty((m, l.units), dtype=torch.float32, device=dev) for l in self.layers]
         if out_last is not None:
             outs[-1] = out_last
-        if capi.dense_stack_enabled() and capi.dense_stack_supported(dims) and m > 0:
-            xin = torch.empty((m, dims[0]), dtype=torch.float32, device=dev) if ids is not None else None
-            capi.dense_stack(x, [l.kernel.detach() for l in self.layers], [l.bias.detach() for l in self.layers],
-                             [l.activation for l in self.layers], outs, ids=ids, xcopy=xin)
-            self.inputs, self.outputs = [xin if ids is not None else x] + outs[:-1], outs
-            return outs[-1]
         if ids is not None:
             gathered = torch.empty((m, dims[0]), dtype=torch.float32, device=dev)
             capi.copy_columns(x, gathered, ids=ids)
@@ -94,26 +121,47 @@ class _DenseTape:
             x = y
         return x
 
+    def _stack_bwd_spec(self, dy, last_is_dz, need_input_grad, dx_out):
+        """The arguments of the one-launch reverse pass (capi.dense_stack_bwd) for this call, or None where it runs layer by layer."""
+        m = int(dy.shape[0])
+        dims = [int(self.layers[0].kernel.shape[0])] + [int(l.units) for l in self.layers]
+        if not (capi.dense_bwd_enabled() and capi.dense_stack_bwd_supported(dims, m)):
+            return None
+        dev = dy.device
+        key = ('stack', m)
+        if key not in self._workspaces:
+            self._workspaces[key] = capi.dense_stack_bwd_workspace(m, dims, dev)
+        dws = [torch.empty_like(l.kernel) for l in self.layers]
+        dbs = [torch.empty_like(l.bias) for l in self.layers]
+        dx0 = (dx_out if dx_out is not None else torch.empty((m, dims[0]), dtype=torch.float32, device=dev)) if need_input_grad else None
+        return dict(dYtop=dy, Ytop=None if last_is_dz else self.outputs[-1], inputs=self.inputs, weights=[l.kernel.detach() for l in self.layers],
+                    acts=[l.activation for l in self.layers], workspace=self._workspaces[key], dWs=dws, dbs=dbs, dX0=dx0, defer=self.defer_reduce)
+
+    def _stack_bwd_done(self, spec, lazy, grads):
+        for k, layer in enumerate(self.layers):
+            grads[layer.kernel], grads[layer.bias] = lazy[k] if lazy is not None else (spec['dWs'][k], spec['dbs'][k])
+        return spec['dX0']
+
+    @staticmethod
+    def backward_pair(first, dy_first, second, dy_second, grads, need_input_grad=True, dx_out=(None, None)):
+        """The reverse passes of two independent stacks in ONE launch where both take the one-launch form (capi.dense_stack_bwd_pair)."""
+        s0 = first._stack_bwd_spec(dy_first, False, need_input_grad, dx_out[0])
+        s1 = second._stack_bwd_spec(dy_second, False, need_input_grad, dx_out[1])
+        if s0 is not None and s1 is not None and os.environ.get('AMAR_DENSE_PAIR', '1') != '0':
+            lazy0, lazy1 = capi.dense_stack_bwd_pair(s0, s1)
+            return first._stack_bwd_done(s0, lazy0, grads), second._stack_bwd_done(s1, lazy1, grads)
+        return (first.backward(dy_first, grads, need_input_grad=need_input_grad, dx_out=dx_out[0]),
+                second.backward(dy_second, grads, need_input_grad=need_input_grad, dx_out=dx_out[1]))
+
     def backward(self, dy, grads, last_is_dz=False, need_input_grad=True, dx_out=None):
         """dy: gradient w.r.t. the stack's output (or, with last_is_dz, already w.r.t. the last pre-activation).
         Fills grads[param] for every kernel/bias; returns the gradient w.r.t. the stack's input (None when
         need_input_grad is False: constant inputs such as the BERT rows)."""
         m = int(dy.shape[0])
-        dims = [int(self.layers[0].kernel.shape[0])] + [int(l.units) for l in self.layers]
-        if capi.dense_bwd_enabled() and capi.dense_stack_bwd_supported(dims, m):
+        spec = self._stack_bwd_spec(dy, last_is_dz, need_input_grad, dx_out)
+        if spec is not None:
             # the whole stack's reverse pass in ONE launch (amar_dense_stack_bwd_f32): dZ walks the layers in LDS
-            dev = dy.device
-            key = ('stack', m)
-            if key not in self._workspaces:
-                self._workspaces[key] = capi.dense_stack_bwd_workspace(m, dims, dev)
-            dws = [torch.empty_like(l.kernel) for l in self.layers]
-            dbs = [torch.empty_like(l.bias) for l in self.layers]
-            dx0 = (dx_out if dx_out is not None else torch.empty((m, dims[0]), dtype=torch.float32, device=dev)) if need_input_grad else None
-            lazy = capi.dense_stack_bwd(dy, None if last_is_dz else self.outputs[-1], self.inputs, [l.kernel.detach() for l in self.layers],
-                                        [l.activation for l in self.layers], self._workspaces[key], dws, dbs, dX0=dx0, defer=self.defer_reduce)
-            for k, layer in enumerate(self.layers):
-                grads[layer.kernel], grads[layer.bias] = lazy[k] if lazy is not None else (dws[k], dbs[k])
-            return dx0
+            return self._stack_bwd_done(spec, capi.dense_stack_bwd(**spec), grads)
         for k in range(len(self.layers) - 1, -1, -1):
             layer, x, y = self.layers[k], self.inputs[k], self.outputs[k]
             kk, n = layer.kernel.shape
@@ -166,16 +214,15 @@ class _BasicHead:
         d = int(self.unet.layers[-1].units)
         b = int(ids[0].numel()) if ids is not None else int(gu.shape[0])
         cat = torch.empty((b, 2 * d), dtype=torch.float32, device=gu.device)
-        self.unet.forward(gu, ids=ids[0] if ids is not None else None, out_last=cat[:, :d])
-        self.inet.forward(gi, ids=ids[1] if ids is not None else None, out_last=cat[:, d:])
+        _DenseTape.forward_pair(self.unet, (gu, ids[0] if ids is not None else None, cat[:, :d]),
+                                self.inet, (gi, ids[1] if ids is not None else None, cat[:, d:]))      # (both towers: one launch)
         self.d = d
         return self.clf.forward(cat)
 
     def backward(self, dz, grads, need_input_grad=True, dx_out=(None, None)):
         """dz = dL/d(last pre-activation). Returns (dL/dE[u], dL/dE[i]) (None, None when the inputs are constants); dx_out: where to."""
         dcat = self.clf.backward(dz, grads, last_is_dz=True)
-        return (self.unet.backward(dcat[:, :self.d], grads, need_input_grad=need_input_grad, dx_out=dx_out[0]),
-                self.inet.backward(dcat[:, self.d:], grads, need_input_grad=need_input_grad, dx_out=dx_out[1]))
+        return _DenseTape.backward_pair(self.unet, dcat[:, :self.d], self.inet, dcat[:, self.d:], grads, need_input_grad=need_input_grad, dx_out=dx_out)
 
 
 class _FusionTape:

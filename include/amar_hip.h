@@ -456,6 +456,14 @@ int64_t amar_wgrad_scratch_floats(int64_t M, int32_t K, int32_t N);
 int amar_dense_stack_f32(const float *X, int64_t ldx, const int32_t *ids, float *Xcopy, int64_t ldxc, int32_t n_layers,
                          const float *const *W, const float *const *bias, const int32_t *dims, const int32_t *acts,
                          float *const *Y, const int64_t *ldy, int64_t M, amar_stream_t stream);
+/* Two INDEPENDENT stacks in one launch — the user and the item tower of src/models/basic.py:31-35 inside model.fit: each is 16 workgroups
+ * of a 1 024-pair batch and ~18 us as a launch of its own, and a training batch at ML-1M size is a chain of such latencies.  A descriptor
+ * holds the arguments of amar_dense_stack_f32 (same meaning, same limits, same error codes); the results are those of two separate calls. */
+typedef struct amar_dense_stack_desc {
+    const float *X; int64_t ldx; const int32_t *ids; float *Xcopy; int64_t ldxc; int32_t n_layers;
+    const float *const *W; const float *const *bias; const int32_t *dims; const int32_t *acts; float *const *Y; const int64_t *ldy; int64_t M;
+} amar_dense_stack_desc;
+int amar_dense_stack_pair_f32(const amar_dense_stack_desc *s0, const amar_dense_stack_desc *s1, amar_stream_t stream);
 /* The reverse pass of a whole Dense stack (a tower / the classifier of src/models/basic.py:11-37 inside model.fit) in ONE launch: from
  * dYtop = d(loss)/d(last output) (Ytop = that output; Ytop == NULL: dYtop is already the last pre-activation's gradient) down to
  * dX0 = d(loss)/d(stack input) (or NULL), leaving every layer's dW[l] [K_l, N_l] and db[l] [N_l].  X[l] = layer l's input (X[l+1] is layer
@@ -468,14 +476,22 @@ int amar_dense_stack_bwd_f32(const float *dYtop, int64_t lddy, const float *Ytop
                              const float *const *X, const int64_t *ldx, const float *const *W, const int32_t *dims, const int32_t *acts,
                              float *dX0, int64_t lddx0, float *const *dW, float *const *db, float *workspace, int32_t flags,
                              int64_t M, amar_stream_t stream);
+/* ... and the reverse passes of two independent stacks in one launch (descriptor = the arguments of amar_dense_stack_bwd_f32; each stack
+ * with its own workspace; the partial sums of a stack without AMAR_DENSE_BWD_DEFER in `flags` are added by launches behind the shared one). */
+typedef struct amar_dense_stack_bwd_desc {
+    const float *dYtop; int64_t lddy; const float *Ytop; int64_t ldytop; int32_t n_layers;
+    const float *const *X; const int64_t *ldx; const float *const *W; const int32_t *dims; const int32_t *acts;
+    float *dX0; int64_t lddx0; float *const *dW; float *const *db; float *workspace; int32_t flags; int64_t M;
+} amar_dense_stack_bwd_desc;
+int amar_dense_stack_bwd_pair_f32(const amar_dense_stack_bwd_desc *s0, const amar_dense_stack_bwd_desc *s1, amar_stream_t stream);
 /* The reverse pass of ONE Dense layer (Keras Dense inside model.fit: src/models/dense.py:4-17, src/experiment.py:183-188) in two launches
  * instead of four:
  *     dZ = dY * act'(Y)   (Y = the layer's OUTPUT; act == AMAR_ACT_NONE or Y == NULL: dY already is dZ)
  *     dX[M, K] = dZ . W^T (dX == NULL: skipped)      dW[K, N] = X^T . dZ (dW == NULL: skipped)      db[N] = column sums of dZ (or NULL)
  * Both products on the f32 matrix instruction; the workgroups (one per 64 rows) leave partial weight / bias gradients in the workspace, which
- * the second launch adds in workgroup order (a FIXED order: no float atomics, results reproducible bit for bit).  Past 16 workgroups (M >
- * 1 024: the reverse pass of a convolution layer runs over every node of the graph) a launch in between folds the raw partials, in
- * workgroup order, into at most 16 (G below), and operands of at most 32 columns take a row-walking kernel instead of the tile kernel.
+ * the second launch adds in workgroup order (a FIXED order: no float atomics, results reproducible bit for bit).  Past 64 workgroups (M >
+ * 4 096: the reverse pass of a convolution layer runs over every node of the graph) operands of at most 32 columns take a row-walking
+ * kernel instead of the tile kernel, and a launch in between folds the raw partials, in workgroup order, into at most 64 (G below).
  * K, N <= 128 (wider layers: AMAR_EUNSUPPORTED — use amar_act_bwd_f32 + amar_wgrad_f32 + amar_dense_f32 with AMAR_DENSE_WT).
  * workspace: amar_dense_bwd_workspace_floats(M, K, N) floats owned by the caller (scratch: any contents); two calls in flight on
  * different streams must not share one.

@@ -147,7 +147,7 @@ def test_dense_bwd_fused(hip, M, K, N, act):
     assert helpers.rel_err(dx7.cpu().numpy() - 1.0, want_dx) < 1e-5
     lazy_w, lazy_b = hip.dense_bwd(x_d, y_d if act is not None else None, dy_d, w_d, act, ws, dX=dx2, dW=dw2, db=db2, defer=True)
     assert torch.equal(lazy_w.materialize(), dw) is not None and helpers.rel_err(lazy_w.materialize().cpu().numpy(), want_dw) < tol
-    assert helpers.rel_err(lazy_b.materialize().cpu().numpy(), want_db) < tol and 1 <= lazy_w.groups == lazy_b.groups <= 16
+    assert helpers.rel_err(lazy_b.materialize().cpu().numpy(), want_db) < tol and 1 <= lazy_w.groups == lazy_b.groups <= 64
     # against the kernels it replaces (other summation orders: tolerance, not bits)
     dz_d = torch.empty((M, N), device=DEV)
     if act is not None:
@@ -678,3 +678,63 @@ def test_randomised_gradient_sweep(hip):
             # (absolute floor: a bias gradient is a sum of +-0.5/B terms that may cancel to 1e-4 of their size — seen with
             # AMAR_TEST_SEED_OFFSET=3: 9.5e-8 off on a value of 2.6e-4, i.e. fp32 rounding of the un-cancelled terms)
             assert np.abs(got - gw).max() <= 3e-4 * np.abs(gw).max() + 3e-7, (case, cls, tuple(prm.shape))
+
+
+def test_dense_stack_pair_equals_two_launches(hip):
+    """amar_dense_stack_pair_f32 / amar_dense_stack_bwd_pair_f32 (round 4: the user and the item tower of a training batch in ONE launch each way)
+    against the two separate launches: every output, gradient and deferred partial sum bit for bit — stacks of different depth, width,
+    row count and input form (gathered rows / plain rows, a concat slice as the last output)."""
+    rng = np.random.default_rng(11)
+
+    def stack(dims, acts, M, gather):
+        table = _t(rng.standard_normal((500, dims[0])).astype(np.float32))
+        ids = _t(rng.integers(0, 500, M).astype(np.int32)) if gather else None
+        x = table if gather else _t(rng.standard_normal((M, dims[0])).astype(np.float32))
+        ws = [_t((rng.standard_normal((dims[l], dims[l + 1])) * 0.3).astype(np.float32)) for l in range(len(dims) - 1)]
+        bs = [_t((rng.standard_normal(dims[l + 1]) * 0.1).astype(np.float32)) for l in range(len(dims) - 1)]
+        return dict(x=x, ids=ids, ws=ws, bs=bs, acts=acts, dims=dims, M=M)
+
+    def fwd_spec(s, cat, lo):
+        outs = [torch.empty((s['M'], n), device=DEV) for n in s['dims'][1:]]
+        outs[-1] = cat[:s['M'], lo:lo + s['dims'][-1]]
+        xin = torch.empty((s['M'], s['dims'][0]), device=DEV) if s['ids'] is not None else None
+        return dict(X=s['x'], weights=s['ws'], biases=s['bs'], acts=s['acts'], outs=outs, ids=s['ids'], xcopy=xin)
+
+    for (d0, a0, m0, g0), (d1, a1, m1, g1) in ((([24, 24, 24], ['relu', 'relu'], 1024, True), ([24, 24, 24], ['relu', 'relu'], 1024, True)),
+                                               (([16, 48, 48], ['relu', 'relu'], 300, True), ([96, 64, 32, 48], ['relu', 'relu', None], 85, False))):
+        s0, s1 = stack(d0, a0, m0, g0), stack(d1, a1, m1, g1)
+        width = d0[-1] + d1[-1]
+        cat_a, cat_b = torch.zeros((max(m0, m1), width), device=DEV), torch.zeros((max(m0, m1), width), device=DEV)
+        fa0, fa1 = fwd_spec(s0, cat_a, 0), fwd_spec(s1, cat_a, d0[-1])
+        hip.dense_stack(**fa0)
+        hip.dense_stack(**fa1)
+        fb0, fb1 = fwd_spec(s0, cat_b, 0), fwd_spec(s1, cat_b, d0[-1])
+        hip.dense_stack_pair(fb0, fb1)
+        assert torch.equal(cat_a, cat_b)
+        for ya, yb in zip(fa0['outs'][:-1] + fa1['outs'][:-1], fb0['outs'][:-1] + fb1['outs'][:-1]):
+            assert torch.equal(ya, yb)
+        if fa0['xcopy'] is not None:
+            assert torch.equal(fa0['xcopy'], fb0['xcopy'])
+        # reverse passes: from a gradient of the concatenation down to the stacks' inputs
+        dcat = _t(rng.standard_normal((max(m0, m1), width)).astype(np.float32))
+
+        def bwd_spec(s, f, lo, defer):
+            inputs = [f['xcopy'] if s['ids'] is not None else s['x']] + f['outs'][:-1]
+            return dict(dYtop=dcat[:s['M'], lo:lo + s['dims'][-1]], Ytop=f['outs'][-1], inputs=inputs, weights=s['ws'], acts=s['acts'],
+                        workspace=hip.dense_stack_bwd_workspace(s['M'], s['dims'], DEV), dWs=[torch.empty_like(w) for w in s['ws']],
+                        dbs=[torch.empty_like(b) for b in s['bs']], dX0=torch.empty((s['M'], s['dims'][0]), device=DEV), defer=defer)
+        for defer in (False, True):
+            ba0, ba1 = bwd_spec(s0, fa0, 0, defer), bwd_spec(s1, fa1, d0[-1], defer)
+            la0, la1 = hip.dense_stack_bwd(**ba0), hip.dense_stack_bwd(**ba1)
+            bb0, bb1 = bwd_spec(s0, fa0, 0, defer), bwd_spec(s1, fa1, d0[-1], defer)
+            lb0, lb1 = hip.dense_stack_bwd_pair(bb0, bb1)
+            assert torch.equal(ba0['dX0'], bb0['dX0']) and torch.equal(ba1['dX0'], bb1['dX0'])
+            if defer:
+                for la, lb in ((la0, lb0), (la1, lb1)):
+                    for (wa, ba_), (wb, bb_) in zip(la, lb):
+                        assert wa.groups == wb.groups and torch.equal(wa.partials, wb.partials) and torch.equal(ba_.partials, bb_.partials)
+            else:
+                assert lb0 is None and lb1 is None
+                for a, b in ((ba0, bb0), (ba1, bb1)):
+                    for x, y in zip(a['dWs'] + a['dbs'], b['dWs'] + b['dbs']):
+                        assert torch.equal(x, y)

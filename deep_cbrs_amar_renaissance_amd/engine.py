@@ -144,6 +144,25 @@ def stage_ids(dst_host, ids, n_rows=None):
     dst_host.numpy()[...] = a
 
 
+def _drain_collective_watchdog():
+    """With an RCCL process group alive, wait until its watchdog thread has retired every collective issued so far.
+
+    torch's ProcessGroupNCCL keeps each eager collective's Work in a list that a watchdog thread walks every 100 ms, asking the
+    Work's end event whether it has completed (hipEventQuery).  While a stream capture in torch's default (global) error mode is in
+    progress, HIP refuses that query from ANY thread ("operation not permitted when stream is capturing"), the watchdog rethrows
+    and the process aborts — a race between the watchdog's period and the start of the capture that synchronising the device does
+    not close (the events are complete, but the list still holds them until the next walk).  Collectives issued INSIDE a capture are
+    not put on that list.  Three watchdog periods of sleep after the device is idle empty it."""
+    try:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or 'nccl' not in str(dist.get_backend()).lower():
+            return
+    except Exception:                                   # (no process group of this kind: nothing to wait for)
+        return
+    import time
+    time.sleep(0.35)
+
+
 def capture_graph(fn):
     """Capture `fn()`'s launches on the current device into a hipGraph; returns (graph, fn's result).
 
@@ -152,6 +171,7 @@ def capture_graph(fn):
     middle of the capture, which HIP rejects — the process aborts."""
     import gc
     torch.cuda.synchronize()
+    _drain_collective_watchdog()
     gc.collect()
     graph = torch.cuda.CUDAGraph()
     was_enabled = gc.isenabled()

@@ -79,6 +79,29 @@ def self_launch(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+def supervise(rank):
+    """More than one rank: the rank's work runs in a CHILD of this process, which itself never touches the GPU.  The multi-rank step
+    replayed from a hipGraph — RCCL collectives captured with the kernels — has only ever run with one rank or rehearsed on one GPU in
+    the builder's environment; a capture or replay that aborts or stalls on a real node (the process group's watchdog ends a stalled
+    collective after 300 s) would otherwise leave the scaling run without a line.  If the child fails and the graph was on, the
+    rank runs once more with eager steps (AMAR_STEP_GRAPH=0), and the line says so (`config.retry`).  Peers of a failed rank fail
+    too — their collectives break or time out — and meet it again in the second rendezvous, which waits up to 15 minutes."""
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, AMAR_BENCH_CHILD='1')
+    first = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    if first.returncode == 0 or os.environ.get('AMAR_STEP_GRAPH', '1') == '0':
+        sys.stdout.buffer.write(first.stdout)
+        sys.stdout.flush()
+        return first.returncode
+    sys.stderr.write("bench.py: rank {}: the run with the hipGraph-replayed step ended with code {}; once more with eager steps\n".format(rank, first.returncode))
+    sys.stderr.flush()
+    env.update(AMAR_STEP_GRAPH='0', AMAR_BENCH_RETRY='the run with the hipGraph-replayed step ended with code {} on rank {}'.format(first.returncode, rank))
+    second = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    sys.stdout.buffer.write(second.stdout)
+    sys.stdout.flush()
+    return second.returncode
+
+
 def csrc_sha():
     """Identity of the kernel sources a PMC profile belongs to: sha256 over csrc/*.hip, *.h (sorted), first 16 hex digits."""
     h = hashlib.sha256()
@@ -729,6 +752,11 @@ def main():
     rank = int(os.environ.get('RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if world > 1 and os.environ.get('AMAR_BENCH_CHILD') != '1' and os.environ.get('AMAR_BENCH_SUPERVISE', '1') != '0':
+        sys.exit(supervise(rank))
+    retry = os.environ.get('AMAR_BENCH_RETRY')
+    if os.environ.get('AMAR_BENCH_FAIL_FIRST') == '1' and not retry and world > 1:     # (tests: the supervisor's second attempt)
+        os._exit(134)
     if world != args.gpus:
         sys.exit("bench.py: --gpus {} but WORLD_SIZE={}: start it as `python bench.py --gpus N` (it launches its own ranks) or "
                  "under torchrun with --nproc-per-node equal to --gpus".format(args.gpus, world))
@@ -756,7 +784,7 @@ def main():
             dist.init_process_group('gloo')
         else:
             import datetime
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank), timeout=datetime.timedelta(seconds=300))   # (a stuck collective ends the run instead of hanging it)
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank), timeout=datetime.timedelta(seconds=900 if retry else 300))   # (a stuck collective ends the run instead of hanging it; a second attempt waits for the peers whose first one is still timing out)
 
     from deep_cbrs_amar_renaissance_amd import capi, engine
     from deep_cbrs_amar_renaissance_amd.data import synthetic
@@ -929,7 +957,8 @@ def main():
                                    'econfigs/basic-gnn.yaml grid1 BasicGCN d=8 L=2 concat, dense [24,24], clf [48,48]; '
                                    'one propagation + per-entity towers + all pairs (shuffled order) per step (hoisted)'.format(args.scale, n_nodes, nnz, n_pairs),
                        'scale': args.scale, 'parallelism': runner.describe() + (' (step replayed from a hipGraph)' if graph_step else '') +
-                       (' — one-GPU rehearsal over gloo: NOT a scaling measurement' if rehearse else '')},
+                       (' — one-GPU rehearsal over gloo: NOT a scaling measurement' if rehearse else ''),
+                       **({'retry': retry + ': eager steps timed'} if retry else {})},
             'roofline': {'bound': 'hbm', 'kernel': kernel_names[kind] + ' (fused GCN layer: SpMM + bias + ReLU + next X.W)', 'achieved': achieved,
                          'peak': HBM_PEAK_GBPS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBPS,
                          'traffic': pmc['traffic_bytes_per_launch'] if pmc else None, 'traffic_source': traffic_source,

@@ -82,3 +82,19 @@ def test_bench_launches_its_own_ranks(gpus):
     assert out['n_gpus'] == gpus and out['value'] > 0 and 'roofline' in out
     if gpus > 1:
         assert 'RCCL all-gather' in out['config']['parallelism']
+
+
+def test_bench_supervisor_runs_a_failed_rank_again_with_eager_steps():
+    """bench.py with more than one rank runs each rank's work in a child; a child that dies (here: on purpose, AMAR_BENCH_FAIL_FIRST) is
+    run once more with eager steps and the line says so — rehearsed with two ranks on one GPU."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', AMAR_REHEARSE_ONE_GPU='1', AMAR_BENCH_FAIL_FIRST='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'AMAR_STEP_GRAPH'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                        '--scale', '4', '--no-cpu-baseline'], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['value'] > 0 and 'eager steps timed' in out['config']['retry']
+    assert 'once more with eager steps' in r.stderr

@@ -441,7 +441,9 @@ int amar_dense_f32(const float *X, int64_t ldx, const int32_t *ids,
     const bool vw = (N & 3) == 0 && amar_aligned16(W);
     static const bool no_full = getenv("AMAR_DENSE_FULL") && atoi(getenv("AMAR_DENSE_FULL")) == 0;     // development switch (A/B timing)
     static const bool no_128 = getenv("AMAR_DENSE_128") && atoi(getenv("AMAR_DENSE_128")) == 0;        // ... the 128-column tile
-    if (vx && vw && !w_trans && K % BK == 0 && N % BN2 == 0 && !no_full && !no_128) {
+    // the 128-column tile only where it still fills the chip: a batch-sized product (1 024 rows x 768 -> 256: the first layer of a content
+    // tower inside model.fit) is 32 workgroups of it, each walking K alone on its CU — 64 us against 38 with the 64-column tile's 64 workgroups
+    if (vx && vw && !w_trans && K % BK == 0 && N % BN2 == 0 && !no_full && !no_128 && ((gx + 7) / 8) * 8 * (N / BN2) >= 256) {
         DenseArgs a2 = a;
         a2.n_col_blocks = N / BN2;
         const int64_t total2 = ((gx + 7) / 8) * 8 * a2.n_col_blocks;

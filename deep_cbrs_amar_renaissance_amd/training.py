@@ -291,12 +291,12 @@ class _HybridHead:
     def forward(self, gu, gi, bert):
         ub, ib = bert
         t = self.t
-        g1, g2 = t['dense1a'].forward(gu), t['dense1b'].forward(gi)
-        b1, b2 = t['dense2a'].forward(ub), t['dense2b'].forward(ib)
+        g1, g2 = _DenseTape.forward_pair(t['dense1a'], (gu, None, None), t['dense1b'], (gi, None, None))      # (independent stacks: one launch)
+        b1, b2 = _DenseTape.forward_pair(t['dense2a'], (ub, None, None), t['dense2b'], (ib, None, None))
         # feature based: (graph user, graph item) | (bert user, bert item); else per entity (hybrid.py:72-84)
         ins = ((g1, g2), (b1, b2)) if self.fb else ((g1, b1), (g2, b2))
-        x1 = t['dense3a'].forward(self.f1a.forward(*ins[0]))
-        x2 = t['dense3b'].forward(self.f1b.forward(*ins[1]))
+        fa, fb = self.f1a.forward(*ins[0]), self.f1b.forward(*ins[1])
+        x1, x2 = _DenseTape.forward_pair(t['dense3a'], (fa, None, None), t['dense3b'], (fb, None, None))
         x = self.f2.forward(x1, x2)
         if 'residual' in t:                                          # hybrid.py:86-89
             r = t['residual'].forward(x)
@@ -318,16 +318,16 @@ class _HybridHead:
             dx1, dx2 = dx1.contiguous().clone(), dx2.contiguous().clone()
             capi.add_inplace(dx1, skip)
             capi.add_inplace(dx2, skip)
-        da = self.f1a.backward(t['dense3a'].backward(dx1, grads), grads)
-        db = self.f1b.backward(t['dense3b'].backward(dx2, grads), grads)
+        d3a, d3b = _DenseTape.backward_pair(t['dense3a'], dx1, t['dense3b'], dx2, grads)
+        da = self.f1a.backward(d3a, grads)
+        db = self.f1b.backward(d3b, grads)
         if self.fb:
             (dg1, dg2), (db1, db2) = da, db
         else:
             (dg1, db1), (dg2, db2) = da, db
         t['dense2a'].backward(db1, grads, need_input_grad=False)
         t['dense2b'].backward(db2, grads, need_input_grad=False)
-        return (t['dense1a'].backward(dg1, grads, need_input_grad=need_input_grad),
-                t['dense1b'].backward(dg2, grads, need_input_grad=need_input_grad))
+        return _DenseTape.backward_pair(t['dense1a'], dg1, t['dense1b'], dg2, grads, need_input_grad=need_input_grad)
 
 
 class _StackTape:

@@ -467,3 +467,26 @@ def test_bench_profile_bookkeeping(tmp_path, monkeypatch):
     assert bench.value_spread(64)['stale'] is False and bench.value_spread(256) is None
     json.dump({'scale': 64, 'csrc_sha': 'x', 'boxes': 3}, open(tmp_path / 'profiles' / 'r3_bench_repeats.json', 'w'))
     assert bench.value_spread(64)['stale'] is True
+
+
+def test_dense_bwd_plan_host_functions():
+    """amar_dense_bwd_groups / amar_dense_bwd_workspace_floats are host-only: how a reverse-pass call over M rows is cut (no GPU needed).
+    At most 64 partials reach the consumer, one per 64-row tile up to 4 096 rows; the workspace holds them and, where a fold launch
+    follows, the raw partials of every workgroup behind them; both grow monotonically with M."""
+    import ctypes
+    from deep_cbrs_amar_renaissance_amd import capi
+    lib = capi.load()
+    prev_g, prev_w = 0, 0
+    for M in (1, 63, 64, 65, 1024, 4096, 4097, 9228, 16384, 40000, 590592, 600001, 5_000_000):
+        g = lib.amar_dense_bwd_groups(M)
+        tiles = -(-M // 64)
+        assert 1 <= g <= 64 and (g == tiles if tiles <= 64 else g > 32), (M, g)
+        w = lib.amar_dense_bwd_workspace_floats(M, 16, 8)
+        assert w >= 4 + g * (16 * 8 + 8) and (tiles <= 64) == (w == 4 + g * (16 * 8 + 8)), (M, w)
+        assert g >= prev_g or tiles > 64                                # (past 64 tiles the count is ceil(launch groups / fold): not monotone, still <= 64)
+        assert w >= prev_w
+        prev_g, prev_w = g, w
+    assert lib.amar_dense_bwd_groups(-1) < 0 and lib.amar_dense_bwd_workspace_floats(10, 4, 0) < 0
+    # the stack reverse pass: one partial per 64-row tile and layer
+    dims = (ctypes.c_int32 * 3)(24, 16, 8)
+    assert lib.amar_dense_stack_bwd_workspace_floats(1024, 2, dims) == 4 + 16 * (24 * 16 + 16 + 16 * 8 + 8)

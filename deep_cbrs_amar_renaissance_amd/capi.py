@@ -66,6 +66,7 @@ SIGNATURES = {
     'amar_wgrad_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I64, _I32, _I32, _P, _P, _P, _P]),
     'amar_dense_stack_f32': (ctypes.c_int, [_P, _I64, _P, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I64, _P]),
     'amar_dense_stack_pair_f32': (ctypes.c_int, [_P, _P, _P]),
+    'amar_dense_stack_bwd_groups': (ctypes.c_int64, [_I64]),
     'amar_dense_stack_bwd_workspace_floats': (ctypes.c_int64, [_I64, _I32, _P]),
     'amar_dense_stack_bwd_pair_f32': (ctypes.c_int, [_P, _P, _P]),
     'amar_dense_stack_bwd_f32': (ctypes.c_int, [_P, _I64, _P, _I64, _I32, _P, _P, _P, _P, _P, _P, _I64, _P, _P, _P, _I32, _I64, _P]),
@@ -979,7 +980,7 @@ def _dense_stack_bwd_args(dYtop, Ytop, inputs, weights, acts, workspace, dWs, db
 
 
 def _deferred_stack_gradients(workspace, n, M, dims):
-    g = (M + 63) // 64
+    g = int(load().amar_dense_stack_bwd_groups(int(M)))
     out, off = [], 4
     for l in range(n):
         kn, nn = dims[l] * dims[l + 1], dims[l + 1]

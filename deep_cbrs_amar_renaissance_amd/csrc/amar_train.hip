@@ -580,6 +580,30 @@ constexpr int DB_ROWS = 64, DB_MAXD = 128, DB_THREADS = 256;
 constexpr int DB_MAX_GROUPS = 64;
 typedef float v4f __attribute__((ext_vector_type(4)));
 
+// acc += A[., k] B[k, .] over k = 0 .. n - 1 (n a multiple of 16) on v_mfma_f32_16x16x4_f32, the lane's A element of step k at ap[k * as],
+// its B element at bp[k * bs].  The eight LDS reads of four instructions are issued together, and those of the NEXT four before the
+// current four run: written as `for (k += 4) acc = mfma(ap[k], bp[k], acc)` the compiler kept one instruction per iteration behind
+// its own two reads (#pragma unroll refused: "loop not unrolled") — ~200 clocks per step, 2 400 per 16 x 16 x 48 tile, which is where
+// the Dense-stack kernels of a training batch spent their time (tools/exp_ds_stamps.py).  Same order of accumulation: same bits.
+__device__ __forceinline__ v4f mfma_chain16(const float *ap, const int as, const float *bp, const int bs, const int n, v4f acc) {
+    float a0 = ap[0], a1 = ap[4 * as], a2 = ap[8 * as], a3 = ap[12 * as];
+    float b0 = bp[0], b1 = bp[4 * bs], b2 = bp[8 * bs], b3 = bp[12 * bs];
+    for (int k = 16; k < n; k += 16) {
+        const float c0 = ap[k * as], c1 = ap[(k + 4) * as], c2 = ap[(k + 8) * as], c3 = ap[(k + 12) * as];
+        const float d0 = bp[k * bs], d1 = bp[(k + 4) * bs], d2 = bp[(k + 8) * bs], d3 = bp[(k + 12) * bs];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc, 0, 0, 0);
+        a0 = c0; a1 = c1; a2 = c2; a3 = c3; b0 = d0; b1 = d1; b2 = d2; b3 = d3;
+    }
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, b3, acc, 0, 0, 0);
+    return acc;
+}
+
 struct DenseBwdArgs {
     const float *X; int64_t ldx; const float *Y; int64_t ldy; const float *dY; int64_t lddy; const float *W;
     float *dX; int64_t lddx; float *part_w; float *part_b; int64_t M; int K, N, act, subtiles;
@@ -749,8 +773,7 @@ __global__ __launch_bounds__(DB_THREADS) void dense_bwd_kernel(const DenseBwdArg
                 const int mt = tile / kt_n, kt = tile - mt * kt_n;
                 v4f acc = {0.f, 0.f, 0.f, 0.f};
                 const float *ap = zs + (16 * mt + l16) * sz + l4, *bp = ws + (16 * kt + l16) * sw + l4;
-#pragma unroll 4
-                for (int n0 = 0; n0 < Np; n0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[n0], bp[n0], acc, 0, 0, 0);
+                acc = mfma_chain16(ap, 1, bp, 1, Np, acc);
                 const int col = 16 * kt + l16;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -767,8 +790,7 @@ __global__ __launch_bounds__(DB_THREADS) void dense_bwd_kernel(const DenseBwdArg
                     const int kt = tile / nt_n, nt = tile - kt * nt_n;
                     const float *ap = xs + l4 * sx + 16 * kt + l16, *bp = zs + l4 * sz + 16 * nt + l16;
                     v4f acc = accw[t];
-#pragma unroll 4
-                    for (int r = 0; r < DB_ROWS; r += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[r * sx], bp[r * sz], acc, 0, 0, 0);
+                    acc = mfma_chain16(ap, sx, bp, sz, DB_ROWS, acc);
                     accw[t] = acc;
                 }
             }
@@ -909,6 +931,12 @@ __global__ __launch_bounds__(256) void dense_bwd_rows_kernel(const DenseBwdArgs 
 // layers with its activations in LDS (two buffers in turn) and the layer's kernel staged next to them; products on v_mfma_f32_16x16x4_f32
 // in ascending k, bias and activation after the sum (the order of operations of amar_dense_f32).
 constexpr int DS_MAX_LAYERS = 4;
+#ifdef AMAR_DS_STAMPS                                  // development build only (tools/exp_ds_stamps.py): cycle stamps of the stack kernels' phases
+__device__ unsigned long long ds_debug_stamps[64 * 16];
+#define DS_STAMP(i) do { if (threadIdx.x == 0 && block < 64) ds_debug_stamps[16 * block + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define DS_STAMP(i) do { } while (0)
+#endif
 struct DenseStackArgs {
     const float *X; int64_t ldx; const int32_t *ids; float *Xcopy; int64_t ldxc;
     const float *W[DS_MAX_LAYERS]; const float *bias[DS_MAX_LAYERS]; float *Y[DS_MAX_LAYERS]; int64_t ldy[DS_MAX_LAYERS];
@@ -921,12 +949,16 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     return v;
 }
 
+// ROWS = rows per workgroup: 64, or 16 for batch-sized operands (round 4: with 64, the four waves of a workgroup each walked 3-4 output
+// tiles one after the other per layer — ~2 000 clocks of epilogue and matrix-pipe latency per tile with nothing else on the CU to hide
+// it, tools/exp_ds_stamps.py; 16-row tiles make 64 workgroups of a 1 024-row batch, one tile per wave and layer)
+template <int ROWS>
 __device__ __forceinline__ void dense_stack_body(const DenseStackArgs &a, const int block) {
     extern __shared__ __attribute__((aligned(16))) float ds_lds[];
     const int sa = a.maxd + 2;                                        // activation row stride ((stride / 2) odd: maxd is a multiple of 16)
-    float *cur = ds_lds, *nxt = cur + DB_ROWS * sa, *ws = nxt + DB_ROWS * sa;
+    float *cur = ds_lds, *nxt = cur + ROWS * sa, *ws = nxt + ROWS * sa;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, l4 = lane >> 4;
-    const int64_t r0 = (int64_t)block * DB_ROWS;
+    const int64_t r0 = (int64_t)block * ROWS;
     // a layer's kernel [Kp x Np] into `ws`: by 16-byte loads where its width allows (the first 64 rows may arrive in registers,
     // requested while the previous layer's products ran)
     auto w_load = [&](int l, int k_lo, int rows, float4 (&v)[8]) {
@@ -944,11 +976,19 @@ __device__ __forceinline__ void dense_stack_body(const DenseStackArgs &a, const 
         }
     };
     float4 wreg[8];
+    DS_STAMP(0);
+    // every layer's bias: requested now, parked in the LDS behind the input tile's round trip (read per output tile inside the layer
+    // loop, a bias value was a global load whose latency each of a wave's tiles paid again: stamps, tools/exp_ds_stamps.py)
+    __shared__ float bias_s[DS_MAX_LAYERS][DB_MAXD];
+    float breg[DS_MAX_LAYERS];
+#pragma unroll
+    for (int l = 0; l < DS_MAX_LAYERS; ++l)
+        breg[l] = (l < a.n_layers && tid < a.dims[l + 1] && tid < DB_MAXD && a.bias[l]) ? a.bias[l][tid] : 0.f;
     {
         const int K = a.dims[0], Kp = (K + 15) & ~15, Np1 = (a.dims[1] + 15) & ~15;
         if (a.vec_w[0]) w_load(0, 0, Kp < 64 ? Kp : 64, wreg);       // (requested together with the input tile)
         if (a.vec_x) {
-            stage_tile<8>(cur, sa, DB_ROWS, Kp, tid, [&](int r, int k) {
+            stage_tile<8>(cur, sa, ROWS, Kp, tid, [&](int r, int k) {
                 const int64_t m = r0 + r;
                 if (m >= a.M || k >= K) return f4_zero();
                 const float4 v = *reinterpret_cast<const float4 *>(a.X + (a.ids ? (int64_t)a.ids[m] : m) * a.ldx + k);
@@ -956,7 +996,7 @@ __device__ __forceinline__ void dense_stack_body(const DenseStackArgs &a, const 
                 return v;
             });
         } else {
-            for (int e = tid; e < DB_ROWS * Kp; e += DB_THREADS) {
+            for (int e = tid; e < ROWS * Kp; e += DB_THREADS) {
                 const int r = e / Kp, k = e - r * Kp;
                 const int64_t m = r0 + r;
                 float v = 0.f;
@@ -971,31 +1011,42 @@ __device__ __forceinline__ void dense_stack_body(const DenseStackArgs &a, const 
             stage_store<8>(wreg, ws, Np1 + 2, Kp < 64 ? Kp : 64, Np1, tid);
             if (Kp > 64) { w_load(0, 64, Kp - 64, wreg); stage_store<8>(wreg, ws + 64 * (Np1 + 2), Np1 + 2, Kp - 64, Np1, tid); }
         } else w_scalar(0);
+        if (tid < DB_MAXD) {
+#pragma unroll
+            for (int l = 0; l < DS_MAX_LAYERS; ++l) bias_s[l][tid] = breg[l];
+        }
     }
     for (int l = 0; l < a.n_layers; ++l) {
         const int K = a.dims[l], N = a.dims[l + 1], Kp = (K + 15) & ~15, Np = (N + 15) & ~15, sw = Np + 2;
         __syncthreads();                                             // `cur` and `ws` of this layer are in place
+        DS_STAMP(1 + 3 * l);
         const bool more = l + 1 < a.n_layers, pre = more && a.vec_w[l + 1];
+        // this layer's descriptor fields in registers: read inside the store's `if`, each was a scalar load of its own per STORE (the
+        // compiler does not hoist loads out of a conditional): eight dependent ~250-clock round trips per output tile
+        float *const y_out = a.Y[l];
+        const int64_t ld_out = a.ldy[l], m_all = a.M;
+        const int act_l = a.act[l];
         if (pre) w_load(l + 1, 0, Np < 64 ? Np : 64, wreg);          // the next layer's kernel (its K = this N) travels while the products run
         const int nt_n = Np >> 4;
-        for (int tile = wave; tile < 4 * nt_n; tile += DB_THREADS / 64) {
+        for (int tile = wave; tile < (ROWS / 16) * nt_n; tile += DB_THREADS / 64) {
             const int mt = tile / nt_n, nt = tile - mt * nt_n;
             v4f acc = {0.f, 0.f, 0.f, 0.f};
             const float *ap = cur + (16 * mt + l16) * sa + l4, *bp = ws + l4 * sw + 16 * nt + l16;
-#pragma unroll 4
-            for (int k0 = 0; k0 < Kp; k0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[k0], bp[k0 * sw], acc, 0, 0, 0);
+            acc = mfma_chain16(ap, 1, bp, sw, Kp, acc);
             const int n = 16 * nt + l16;
-            const float b = (n < N && a.bias[l]) ? a.bias[l][n] : 0.f;
+            const float b = n < N ? bias_s[l][n] : 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 16 * mt + 4 * l4 + i;
                 const int64_t m = r0 + r;
-                const float y = n < N ? act_apply(acc[i] + b, a.act[l]) : 0.f;
+                const float y = n < N ? act_apply(acc[i] + b, act_l) : 0.f;
                 nxt[r * sa + n] = y;
-                if (m < a.M && n < N) a.Y[l][m * a.ldy[l] + n] = y;
+                if (m < m_all && n < N) y_out[m * ld_out + n] = y;
             }
         }
+        DS_STAMP(2 + 3 * l);
         __syncthreads();                                             // every wave is done with `ws`
+        DS_STAMP(3 + 3 * l);
         if (more) {
             const int Np2 = (a.dims[l + 2] + 15) & ~15;
             if (pre) {
@@ -1005,16 +1056,19 @@ __device__ __forceinline__ void dense_stack_body(const DenseStackArgs &a, const 
         }
         float *t = cur; cur = nxt; nxt = t;
     }
+    DS_STAMP(15);
 }
 
-__global__ __launch_bounds__(DB_THREADS) void dense_stack_kernel(const DenseStackArgs a) { dense_stack_body(a, (int)blockIdx.x); }
+template <int ROWS>
+__global__ __launch_bounds__(DB_THREADS) void dense_stack_kernel(const DenseStackArgs a) { dense_stack_body<ROWS>(a, (int)blockIdx.x); }
 
 // two INDEPENDENT stacks in one launch (the user and the item tower of a training batch: 16 workgroups each, 18 us each as launches of
 // their own — a batch at ml1m(s=1) is a chain of such latencies): the first `split` workgroups run the first stack
 struct DenseStackPair { DenseStackArgs s0, s1; int split; };
+template <int ROWS>
 __global__ __launch_bounds__(DB_THREADS) void dense_stack_pair_kernel(const DenseStackPair p) {
-    if ((int)blockIdx.x < p.split) dense_stack_body(p.s0, (int)blockIdx.x);
-    else dense_stack_body(p.s1, (int)blockIdx.x - p.split);
+    if ((int)blockIdx.x < p.split) dense_stack_body<ROWS>(p.s0, (int)blockIdx.x);
+    else dense_stack_body<ROWS>(p.s1, (int)blockIdx.x - p.split);
 }
 
 // ---- the reverse pass of a whole Dense stack in one launch (round 4) ------------------------------------------------------------------
@@ -1029,23 +1083,24 @@ struct DenseStackBwdArgs {
     int n_layers; int64_t M; int maxd;
 };
 
+template <int ROWS>                                 // rows per workgroup = rows per weight-gradient partial: 64, or 16 for batches of at most 1 024 rows
 __device__ __forceinline__ void dense_stack_bwd_body(const DenseStackBwdArgs &a, const int block) {
     extern __shared__ __attribute__((aligned(16))) float sb_lds[];
     const int smax = a.maxd + 2;
-    float *xs = sb_lds, *zs = xs + DB_ROWS * smax, *ws = zs + DB_ROWS * smax;      // X_l tile, dZ_l tile, W_l (each with its layer's stride)
+    float *xs = sb_lds, *zs = xs + ROWS * smax, *ws = zs + ROWS * smax;      // X_l tile, dZ_l tile, W_l (each with its layer's stride)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, l4 = lane >> 4;
-    const int64_t r0 = (int64_t)block * DB_ROWS;
+    const int64_t r0 = (int64_t)block * ROWS;
     const int L = a.n_layers;
     {   // dZ of the last layer: dYtop * act'(Ytop) (Ytop == NULL: dYtop already is dZ)
         const int N = a.dims[L], Np = (N + 15) & ~15, sz = Np + 2, actl = a.act[L - 1];
         if (a.vec_top) {
             float4 vz[8], vy[8];
-            stage_load<8>(vz, DB_ROWS, Np, tid, [&](int r, int n) {
+            stage_load<8>(vz, ROWS, Np, tid, [&](int r, int n) {
                 const int64_t m = r0 + r;
                 return (m < a.M && n < N) ? *reinterpret_cast<const float4 *>(a.dYtop + m * a.lddy + n) : f4_zero();
             });
             if (a.Ytop) {
-                stage_load<8>(vy, DB_ROWS, Np, tid, [&](int r, int n) {
+                stage_load<8>(vy, ROWS, Np, tid, [&](int r, int n) {
                     const int64_t m = r0 + r;
                     return (m < a.M && n < N) ? *reinterpret_cast<const float4 *>(a.Ytop + m * a.ldytop + n) : f4_zero();
                 });
@@ -1054,9 +1109,9 @@ __device__ __forceinline__ void dense_stack_bwd_body(const DenseStackBwdArgs &a,
                     vz[p] = make_float4(act_grad(vz[p].x, vy[p].x, actl), act_grad(vz[p].y, vy[p].y, actl),
                                         act_grad(vz[p].z, vy[p].z, actl), act_grad(vz[p].w, vy[p].w, actl));
             }
-            stage_store<8>(vz, zs, sz, DB_ROWS, Np, tid);
+            stage_store<8>(vz, zs, sz, ROWS, Np, tid);
         } else {
-            for (int e = tid; e < DB_ROWS * Np; e += DB_THREADS) {
+            for (int e = tid; e < ROWS * Np; e += DB_THREADS) {
                 const int r = e / Np, n = e - r * Np;
                 const int64_t m = r0 + r;
                 float v = 0.f;
@@ -1072,12 +1127,12 @@ __device__ __forceinline__ void dense_stack_bwd_body(const DenseStackBwdArgs &a,
         if (a.vec_x[l]) {
             const float *x = a.X[l];
             const int64_t ld = a.ldx[l];
-            stage_tile<8>(xs, sx, DB_ROWS, Kp, tid, [&](int r, int k) {
+            stage_tile<8>(xs, sx, ROWS, Kp, tid, [&](int r, int k) {
                 const int64_t m = r0 + r;
                 return (m < a.M && k < K) ? *reinterpret_cast<const float4 *>(x + m * ld + k) : f4_zero();
             });
         } else {
-            for (int e = tid; e < DB_ROWS * Kp; e += DB_THREADS) {
+            for (int e = tid; e < ROWS * Kp; e += DB_THREADS) {
                 const int r = e / Kp, k = e - r * Kp;
                 const int64_t m = r0 + r;
                 xs[r * sx + k] = (m < a.M && k < K) ? a.X[l][m * a.ldx[l] + k] : 0.f;
@@ -1105,8 +1160,7 @@ __device__ __forceinline__ void dense_stack_bwd_body(const DenseStackBwdArgs &a,
                 const int kt = tile / nt_n, nt = tile - kt * nt_n;
                 const float *ap = xs + l4 * sx + 16 * kt + l16, *bp = zs + l4 * sz + 16 * nt + l16;
                 v4f acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-                for (int r = 0; r < DB_ROWS; r += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[r * sx], bp[r * sz], acc, 0, 0, 0);
+                acc = mfma_chain16(ap, sx, bp, sz, ROWS, acc);
                 const int n = 16 * nt + l16;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -1118,7 +1172,7 @@ __device__ __forceinline__ void dense_stack_bwd_body(const DenseStackBwdArgs &a,
         if (a.part_b[l] && tid < N) {
             float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
 #pragma unroll 4
-            for (int r = 0; r < DB_ROWS; r += 4) {
+            for (int r = 0; r < ROWS; r += 4) {
                 b0 += zs[r * sz + tid]; b1 += zs[(r + 1) * sz + tid]; b2 += zs[(r + 2) * sz + tid]; b3 += zs[(r + 3) * sz + tid];
             }
             a.part_b[l][(int64_t)block * N + tid] = (b0 + b1) + (b2 + b3);
@@ -1130,12 +1184,11 @@ __device__ __forceinline__ void dense_stack_bwd_body(const DenseStackBwdArgs &a,
             for (int t = 0; t < 8; ++t) {
                 const int tile = wave + (DB_THREADS / 64) * t;
                 dxa[t] = v4f{0.f, 0.f, 0.f, 0.f};
-                if (tile < 4 * kt_n) {
+                if (tile < (ROWS / 16) * kt_n) {
                     const int mt = tile / kt_n, kt = tile - mt * kt_n;
                     const float *ap = zs + (16 * mt + l16) * sz + l4, *bp = ws + (16 * kt + l16) * sw + l4;
                     v4f acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-                    for (int n0 = 0; n0 < Np; n0 += 4) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[n0], bp[n0], acc, 0, 0, 0);
+                    acc = mfma_chain16(ap, 1, bp, 1, Np, acc);
                     dxa[t] = acc;
                 }
             }
@@ -1146,7 +1199,7 @@ __device__ __forceinline__ void dense_stack_bwd_body(const DenseStackBwdArgs &a,
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const int tile = wave + (DB_THREADS / 64) * t;
-                if (tile < 4 * kt_n) {
+                if (tile < (ROWS / 16) * kt_n) {
                     const int mt = tile / kt_n, kt = tile - mt * kt_n, col = 16 * kt + l16;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -1160,7 +1213,7 @@ __device__ __forceinline__ void dense_stack_bwd_body(const DenseStackBwdArgs &a,
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const int tile = wave + (DB_THREADS / 64) * t;
-                if (tile < 4 * kt_n) {
+                if (tile < (ROWS / 16) * kt_n) {
                     const int mt = tile / kt_n, kt = tile - mt * kt_n, col = 16 * kt + l16;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
@@ -1173,12 +1226,14 @@ __device__ __forceinline__ void dense_stack_bwd_body(const DenseStackBwdArgs &a,
     }
 }
 
-__global__ __launch_bounds__(DB_THREADS) void dense_stack_bwd_kernel(const DenseStackBwdArgs a) { dense_stack_bwd_body(a, (int)blockIdx.x); }
+template <int ROWS>
+__global__ __launch_bounds__(DB_THREADS) void dense_stack_bwd_kernel(const DenseStackBwdArgs a) { dense_stack_bwd_body<ROWS>(a, (int)blockIdx.x); }
 
 struct DenseStackBwdPair { DenseStackBwdArgs s0, s1; int split; };
+template <int ROWS>
 __global__ __launch_bounds__(DB_THREADS) void dense_stack_bwd_pair_kernel(const DenseStackBwdPair p) {
-    if ((int)blockIdx.x < p.split) dense_stack_bwd_body(p.s0, (int)blockIdx.x);
-    else dense_stack_bwd_body(p.s1, (int)blockIdx.x - p.split);
+    if ((int)blockIdx.x < p.split) dense_stack_bwd_body<ROWS>(p.s0, (int)blockIdx.x);
+    else dense_stack_bwd_body<ROWS>(p.s1, (int)blockIdx.x - p.split);
 }
 
 }  // namespace
@@ -1212,10 +1267,16 @@ static int build_dense_stack(const float *X, int64_t ldx, const int32_t *ids, fl
     }
     a.maxd = maxd;
     a.vec_x = ((dims[0] & 3) == 0 && (ldx & 3) == 0 && amar_aligned16(X) && (!Xcopy || ((ldxc & 3) == 0 && amar_aligned16(Xcopy)))) ? 1 : 0;
-    groups = (M + DB_ROWS - 1) / DB_ROWS;
-    if (groups > 0x3fffffff) return AMAR_EUNSUPPORTED;
+    groups = (M + DB_ROWS - 1) / DB_ROWS;                             // (for 64-row workgroups; the launchers below rescale for 16)
+    if (groups > 0x3fffffff / 4) return AMAR_EUNSUPPORTED;
     lds = ((size_t)2 * DB_ROWS * (maxd + 2) + (size_t)maxw) * sizeof(float);
     return AMAR_OK;
+}
+
+// batch-sized operands run in 16-row workgroups (see dense_stack_body); AMAR_DENSE_STACK_ROWS=64 keeps 64 (A/B timing)
+static bool dense_stack_small_rows(int64_t M) {
+    static const bool force64 = getenv("AMAR_DENSE_STACK_ROWS") && atoi(getenv("AMAR_DENSE_STACK_ROWS")) == 64;
+    return M <= 4096 && !force64;
 }
 
 int amar_dense_stack_f32(const float *X, int64_t ldx, const int32_t *ids, float *Xcopy, int64_t ldxc, int32_t n_layers,
@@ -1226,9 +1287,15 @@ int amar_dense_stack_f32(const float *X, int64_t ldx, const int32_t *ids, float 
     int64_t groups = 0;
     if (const int rc = build_dense_stack(X, ldx, ids, Xcopy, ldxc, n_layers, W, bias, dims, acts, Y, ldy, M, a, lds, groups)) return rc;
     if (M == 0) return AMAR_OK;
+    if (dense_stack_small_rows(M)) {
+        static bool allowed16[AMAR_MAX_DEVICES] = {};
+        if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_stack_kernel<16>), lds, allowed16)) return rc;
+        hipLaunchKernelGGL(dense_stack_kernel<16>, dim3((unsigned)((M + 15) / 16)), dim3(DB_THREADS), lds, static_cast<hipStream_t>(stream), a);
+        return amar_check_launch();
+    }
     static bool allowed[AMAR_MAX_DEVICES] = {};
-    if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_stack_kernel), lds, allowed)) return rc;
-    hipLaunchKernelGGL(dense_stack_kernel, dim3((unsigned)groups), dim3(DB_THREADS), lds, static_cast<hipStream_t>(stream), a);
+    if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_stack_kernel<64>), lds, allowed)) return rc;
+    hipLaunchKernelGGL(dense_stack_kernel<64>, dim3((unsigned)groups), dim3(DB_THREADS), lds, static_cast<hipStream_t>(stream), a);
     return amar_check_launch();
 }
 
@@ -1242,17 +1309,38 @@ int amar_dense_stack_pair_f32(const amar_dense_stack_desc *s0, const amar_dense_
     if (const int rc = build_dense_stack(s1->X, s1->ldx, s1->ids, s1->Xcopy, s1->ldxc, s1->n_layers, s1->W, s1->bias, s1->dims, s1->acts, s1->Y, s1->ldy,
                                          s1->M, p.s1, lds1, g1)) return rc;
     if (g0 + g1 == 0) return AMAR_OK;
-    p.split = (int)g0;
     const size_t lds = lds0 > lds1 ? lds0 : lds1;
+    if (dense_stack_small_rows(s0->M) && dense_stack_small_rows(s1->M)) {
+        g0 = (s0->M + 15) / 16; g1 = (s1->M + 15) / 16;
+        p.split = (int)g0;
+        static bool allowed16[AMAR_MAX_DEVICES] = {};
+        if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_stack_pair_kernel<16>), lds, allowed16)) return rc;
+        hipLaunchKernelGGL(dense_stack_pair_kernel<16>, dim3((unsigned)(g0 + g1)), dim3(DB_THREADS), lds, static_cast<hipStream_t>(stream), p);
+        return amar_check_launch();
+    }
+    p.split = (int)g0;
     static bool allowed[AMAR_MAX_DEVICES] = {};
-    if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_stack_pair_kernel), lds, allowed)) return rc;
-    hipLaunchKernelGGL(dense_stack_pair_kernel, dim3((unsigned)(g0 + g1)), dim3(DB_THREADS), lds, static_cast<hipStream_t>(stream), p);
+    if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_stack_pair_kernel<64>), lds, allowed)) return rc;
+    hipLaunchKernelGGL(dense_stack_pair_kernel<64>, dim3((unsigned)(g0 + g1)), dim3(DB_THREADS), lds, static_cast<hipStream_t>(stream), p);
     return amar_check_launch();
+}
+
+// rows per workgroup (= per partial) of the stack's reverse pass: 16 up to 1 024 rows (64 workgroups of a batch instead of 16: the same
+// latency argument as the forward's), else 64; AMAR_DENSE_STACK_ROWS=64 keeps 64
+static int dense_stack_bwd_rows(int64_t M) {
+    static const bool force64 = getenv("AMAR_DENSE_STACK_ROWS") && atoi(getenv("AMAR_DENSE_STACK_ROWS")) == 64;
+    return (M <= 1024 && !force64) ? 16 : DB_ROWS;
+}
+
+int64_t amar_dense_stack_bwd_groups(int64_t M) {
+    if (M < 0) return AMAR_EINVAL;
+    const int rows = dense_stack_bwd_rows(M);
+    return (M + rows - 1) / rows;
 }
 
 int64_t amar_dense_stack_bwd_workspace_floats(int64_t M, int32_t n_layers, const int32_t *dims) {
     if (M < 0 || n_layers < 1 || n_layers > DS_MAX_LAYERS || !dims) return AMAR_EINVAL;
-    const int64_t groups = (M + DB_ROWS - 1) / DB_ROWS;
+    const int64_t groups = amar_dense_stack_bwd_groups(M);
     int64_t total = 4;
     for (int l = 0; l < n_layers; ++l) total += groups * ((int64_t)dims[l] * dims[l + 1] + dims[l + 1]);
     return total;
@@ -1264,8 +1352,8 @@ static int build_dense_stack_bwd(const float *dYtop, int64_t lddy, const float *
                                  DenseStackBwdArgs &a, size_t &lds, int64_t &groups) {
     if (M < 1 || !dYtop || n_layers < 1 || !X || !ldx || !W || !dims || !acts || !dW || !db || !workspace) return AMAR_EINVAL;
     if (n_layers > DS_MAX_LAYERS) return AMAR_EUNSUPPORTED;
-    groups = (M + DB_ROWS - 1) / DB_ROWS;
-    if (groups > 64) return AMAR_EUNSUPPORTED;                       // (batch-sized operands: one 64-row tile per workgroup, no sub-tiles)
+    if (M > 4096) return AMAR_EUNSUPPORTED;                          // (batch-sized operands: one row tile per workgroup, no sub-tiles)
+    groups = amar_dense_stack_bwd_groups(M);
     a = DenseStackBwdArgs{};
     a.dYtop = dYtop; a.lddy = lddy; a.Ytop = Ytop; a.ldytop = ldytop; a.dX0 = dX0; a.lddx0 = lddx0; a.n_layers = n_layers; a.M = M;
     int maxd = 16;
@@ -1310,9 +1398,15 @@ int amar_dense_stack_bwd_f32(const float *dYtop, int64_t lddy, const float *Ytop
     int64_t groups = 0;
     if (const int rc = build_dense_stack_bwd(dYtop, lddy, Ytop, ldytop, n_layers, X, ldx, W, dims, acts, dX0, lddx0, dW, db, workspace, M, a, lds, groups)) return rc;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    static bool allowed[AMAR_MAX_DEVICES] = {};
-    if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_stack_bwd_kernel), lds, allowed)) return rc;
-    hipLaunchKernelGGL(dense_stack_bwd_kernel, dim3((unsigned)groups), dim3(DB_THREADS), lds, st, a);
+    if (dense_stack_bwd_rows(M) == 16) {
+        static bool allowed16[AMAR_MAX_DEVICES] = {};
+        if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_stack_bwd_kernel<16>), lds, allowed16)) return rc;
+        hipLaunchKernelGGL(dense_stack_bwd_kernel<16>, dim3((unsigned)groups), dim3(DB_THREADS), lds, st, a);
+    } else {
+        static bool allowed[AMAR_MAX_DEVICES] = {};
+        if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_stack_bwd_kernel<64>), lds, allowed)) return rc;
+        hipLaunchKernelGGL(dense_stack_bwd_kernel<64>, dim3((unsigned)groups), dim3(DB_THREADS), lds, st, a);
+    }
     if (!(flags & AMAR_DENSE_BWD_DEFER)) reduce_stack_partials(a, dims, dW, db, groups, st);
     return amar_check_launch();
 }
@@ -1329,9 +1423,16 @@ int amar_dense_stack_bwd_pair_f32(const amar_dense_stack_bwd_desc *s0, const ama
     p.split = (int)g0;
     const size_t lds = lds0 > lds1 ? lds0 : lds1;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    static bool allowed[AMAR_MAX_DEVICES] = {};
-    if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_stack_bwd_pair_kernel), lds, allowed)) return rc;
-    hipLaunchKernelGGL(dense_stack_bwd_pair_kernel, dim3((unsigned)(g0 + g1)), dim3(DB_THREADS), lds, st, p);
+    if (dense_stack_bwd_rows(s0->M) != dense_stack_bwd_rows(s1->M)) return AMAR_EUNSUPPORTED;     // (two stacks of one batch: the same row tile)
+    if (dense_stack_bwd_rows(s0->M) == 16) {
+        static bool allowed16[AMAR_MAX_DEVICES] = {};
+        if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_stack_bwd_pair_kernel<16>), lds, allowed16)) return rc;
+        hipLaunchKernelGGL(dense_stack_bwd_pair_kernel<16>, dim3((unsigned)(g0 + g1)), dim3(DB_THREADS), lds, st, p);
+    } else {
+        static bool allowed[AMAR_MAX_DEVICES] = {};
+        if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(dense_stack_bwd_pair_kernel<64>), lds, allowed)) return rc;
+        hipLaunchKernelGGL(dense_stack_bwd_pair_kernel<64>, dim3((unsigned)(g0 + g1)), dim3(DB_THREADS), lds, st, p);
+    }
     if (!(s0->flags & AMAR_DENSE_BWD_DEFER)) reduce_stack_partials(p.s0, s0->dims, s0->dW, s0->db, g0, st);
     if (!(s1->flags & AMAR_DENSE_BWD_DEFER)) reduce_stack_partials(p.s1, s1->dims, s1->dW, s1->db, g1, st);
     return amar_check_launch();
@@ -1631,5 +1732,11 @@ int amar_sum_into_f32(const float *x, int64_t n, float scale, float *acc, amar_s
     hipLaunchKernelGGL(sum_into_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), x, n, scale, acc);
     return amar_check_launch();
 }
+
+#ifdef AMAR_DS_STAMPS
+int amar_ds_debug_copy(unsigned long long *host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ds_debug_stamps), (size_t)n * sizeof(unsigned long long));
+}
+#endif
 
 }  // extern "C"

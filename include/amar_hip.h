@@ -470,7 +470,8 @@ int amar_dense_stack_pair_f32(const amar_dense_stack_desc *s0, const amar_dense_
  * l's output), W, dims (n_layers + 1 widths), acts as in amar_dense_stack_f32; n_layers <= 4, widths <= 128, M <= 4 096 rows (else
  * AMAR_EUNSUPPORTED: layer by layer).  workspace: amar_dense_stack_bwd_workspace_floats(M, n_layers, dims) floats of scratch.
  * flags & AMAR_DENSE_BWD_DEFER: dW / db are not written; layer l's partials stay at  workspace + 4 + sum_{j<l} G (K_j N_j + N_j):
- * [G][K_l N_l] then [G][N_l],  G = ceil(M / 64)  (amar_adam_multi_f32 with g_groups = G adds them). */
+ * [G][K_l N_l] then [G][N_l],  G = amar_dense_stack_bwd_groups(M)  (amar_adam_multi_f32 with g_groups = G adds them). */
+int64_t amar_dense_stack_bwd_groups(int64_t M);      /* G: the partials per layer a deferred call leaves (one per workgroup: 16 rows each up to M = 1 024, else 64) */
 int64_t amar_dense_stack_bwd_workspace_floats(int64_t M, int32_t n_layers, const int32_t *dims);
 int amar_dense_stack_bwd_f32(const float *dYtop, int64_t lddy, const float *Ytop, int64_t ldytop, int32_t n_layers,
                              const float *const *X, const int64_t *ldx, const float *const *W, const int32_t *dims, const int32_t *acts,

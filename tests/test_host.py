@@ -489,4 +489,6 @@ def test_dense_bwd_plan_host_functions():
     assert lib.amar_dense_bwd_groups(-1) < 0 and lib.amar_dense_bwd_workspace_floats(10, 4, 0) < 0
     # the stack reverse pass: one partial per 64-row tile and layer
     dims = (ctypes.c_int32 * 3)(24, 16, 8)
-    assert lib.amar_dense_stack_bwd_workspace_floats(1024, 2, dims) == 4 + 16 * (24 * 16 + 16 + 16 * 8 + 8)
+    g = lib.amar_dense_stack_bwd_groups(1024)
+    assert g in (16, 64) and lib.amar_dense_stack_bwd_groups(4096) == 64 and lib.amar_dense_stack_bwd_groups(1) == 1
+    assert lib.amar_dense_stack_bwd_workspace_floats(1024, 2, dims) == 4 + g * (24 * 16 + 16 + 16 * 8 + 8)

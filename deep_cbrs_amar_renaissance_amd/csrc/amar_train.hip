@@ -931,6 +931,73 @@ __global__ __launch_bounds__(256) void dense_bwd_rows_kernel(const DenseBwdArgs 
 // layers with its activations in LDS (two buffers in turn) and the layer's kernel staged next to them; products on v_mfma_f32_16x16x4_f32
 // in ascending k, bias and activation after the sum (the order of operations of amar_dense_f32).
 constexpr int DS_MAX_LAYERS = 4;
+// dW [K x N] = X^T . dZ (and db = column sums of dZ) for batch-sized M and WIDE layers (the 768 -> 256 -> 64 content towers of a hybrid model:
+// beyond the fused reverse-pass kernels' 128 columns).  A workgroup OWNS a 32 x 32 tile of dW and walks all M rows, 256 at a stage, the
+// next stage's 16-byte loads in flight while the matrix instructions of the current one run: no partial sums, no second launch, one
+// fixed order of additions.  (The round-2 path — scalar FMAs over row chunks + a reduction launch — took 19.5 + 4.9 us per call at
+// M = 1 024; a hybrid batch makes four.)
+constexpr int WM_ROWS = 256, WM_STRIDE = 34;
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(const float *__restrict__ X, int64_t ldx, const float *__restrict__ dZ, int64_t ldz,
+                                                         int64_t M, int K, int N, float *__restrict__ dW, float *__restrict__ db) {
+    extern __shared__ __attribute__((aligned(16))) float wm_lds[];
+    float *xs = wm_lds, *zs = wm_lds + WM_ROWS * WM_STRIDE;           // [256][34] each: 32 columns of X (k0 ..) and of dZ (n0 ..)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, l4 = lane >> 4;
+    const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int c4 = tid & 7, r_in = tid >> 3;                          // 8 threads per row of 32 floats, 32 rows per pass, 8 passes per stage
+    float4 vx[8], vz[8];
+    auto request = [&](int64_t row0) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const int64_t m = row0 + r_in + 32 * p;
+            const int k = k0 + 4 * c4, n = n0 + 4 * c4;
+            vx[p] = (m < M && k < K) ? *reinterpret_cast<const float4 *>(X + m * ldx + k) : f4_zero();
+            vz[p] = (m < M && n < N) ? *reinterpret_cast<const float4 *>(dZ + m * ldz + n) : f4_zero();
+        }
+    };
+    const int kt = wave >> 1, nt = wave & 1;
+    // four accumulators, one per 64 rows of a stage (added at the end: (0 + 1) + (2 + 3)): one chain of 64 dependent matrix instructions
+    // per stage ran at their latency, not at the pipe's rate
+    v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    request(0);
+    for (int64_t row0 = 0; row0 < M; row0 += WM_ROWS) {
+        __syncthreads();                                             // (the previous stage's tiles are no longer read)
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            float *dx = xs + (r_in + 32 * p) * WM_STRIDE + 4 * c4, *dz = zs + (r_in + 32 * p) * WM_STRIDE + 4 * c4;
+            dx[0] = vx[p].x; dx[1] = vx[p].y; dx[2] = vx[p].z; dx[3] = vx[p].w;
+            dz[0] = vz[p].x; dz[1] = vz[p].y; dz[2] = vz[p].z; dz[3] = vz[p].w;
+        }
+        __syncthreads();
+        if (row0 + WM_ROWS < M) request(row0 + WM_ROWS);
+        {
+            const float *ap = xs + l4 * WM_STRIDE + 16 * kt + l16, *bp = zs + l4 * WM_STRIDE + 16 * nt + l16;
+#pragma unroll 2
+            for (int r = 0; r < 64; r += 4) {
+                const float a0 = ap[r * WM_STRIDE], a1 = ap[(r + 64) * WM_STRIDE], a2 = ap[(r + 128) * WM_STRIDE], a3 = ap[(r + 192) * WM_STRIDE];
+                const float c0 = bp[r * WM_STRIDE], c1 = bp[(r + 64) * WM_STRIDE], c2 = bp[(r + 128) * WM_STRIDE], c3 = bp[(r + 192) * WM_STRIDE];
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, c0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, c1, acc1, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, c2, acc2, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, c3, acc3, 0, 0, 0);
+            }
+        }
+        if (db && blockIdx.x == 0 && tid < 32) {                     // (four independent chains, rows in order inside each: a fixed order)
+#pragma unroll 4
+            for (int r = 0; r < WM_ROWS; r += 4) {
+                b0 += zs[r * WM_STRIDE + tid]; b1 += zs[(r + 1) * WM_STRIDE + tid]; b2 += zs[(r + 2) * WM_STRIDE + tid]; b3 += zs[(r + 3) * WM_STRIDE + tid];
+            }
+        }
+    }
+    const int n = n0 + 16 * nt + l16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + 16 * kt + 4 * l4 + i;
+        if (k < K && n < N) dW[(int64_t)k * N + n] = (acc0[i] + acc1[i]) + (acc2[i] + acc3[i]);
+    }
+    if (db && blockIdx.x == 0 && tid < 32 && n0 + tid < N) db[n0 + tid] = (b0 + b1) + (b2 + b3);
+}
+
 #ifdef AMAR_DS_STAMPS                                  // development build only (tools/exp_ds_stamps.py): cycle stamps of the stack kernels' phases
 __device__ unsigned long long ds_debug_stamps[64 * 16];
 #define DS_STAMP(i) do { if (threadIdx.x == 0 && block < 64) ds_debug_stamps[16 * block + (i)] = __builtin_readcyclecounter(); } while (0)
@@ -1552,13 +1619,23 @@ int amar_wgrad_f32(const float *X, int64_t ldx, const float *dZ, int64_t ldz, in
                    float *dW, float *db, float *scratch, amar_stream_t stream) {
     if (M < 1 || N < 1 || !dZ || ldz < N || !scratch || (!dW && !db)) return AMAR_EINVAL;
     if (dW && (!X || K < 1 || ldx < K)) return AMAR_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // wide layers over batch-sized operands: every 32 x 32 tile of dW by one workgroup on the matrix instruction, nothing to reduce
+    static const bool no_mfma = getenv("AMAR_WGRAD_MFMA") && atoi(getenv("AMAR_WGRAD_MFMA")) == 0;      // development switch (A/B timing)
+    if (dW && !no_mfma && M <= 16384 && (K & 3) == 0 && (N & 3) == 0 && (ldx & 3) == 0 && (ldz & 3) == 0 && amar_aligned16(X) && amar_aligned16(dZ) &&
+        (int64_t)((K + 31) / 32) * ((N + 31) / 32) >= 16) {
+        const size_t lds = (size_t)2 * WM_ROWS * WM_STRIDE * sizeof(float);
+        static bool allowed[AMAR_MAX_DEVICES] = {};
+        if (const int rc = amar_allow_lds(reinterpret_cast<const void *>(wgrad_mfma_kernel), lds, allowed)) return rc;
+        hipLaunchKernelGGL(wgrad_mfma_kernel, dim3((unsigned)((K + 31) / 32), (unsigned)((N + 31) / 32)), dim3(256), lds, st, X, ldx, dZ, ldz, M, K, N, dW, db);
+        return amar_check_launch();
+    }
     const int Kk = dW ? K : 0;
     const int WG_ROWS = wg_rows(M);
     const int64_t chunks = (M + WG_ROWS - 1) / WG_ROWS;
     if (chunks > 0x7fffffff) return AMAR_EUNSUPPORTED;
     float *part_w = dW ? scratch : nullptr;
     float *part_b = db ? scratch + chunks * (int64_t)Kk * N : nullptr;
-    hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)chunks, (unsigned)(dW ? (K + 15) / 16 : 1), (unsigned)((N + 15) / 16));
     hipLaunchKernelGGL(wgrad_partial_kernel, grid, dim3(256), 0, st, dW ? X : nullptr, ldx, dZ, ldz, M, Kk ? Kk : 1, N, part_w, part_b, WG_ROWS);
     if (dW && db) hipLaunchKernelGGL(reduce_partials2_kernel, dim3(grid1d((int64_t)K * N + N)), dim3(256), 0, st, part_w, (int64_t)K * N, dW,

@@ -231,11 +231,22 @@ class _FusionTape:
     def __init__(self, fuse):
         self.fuse = fuse
 
-    def forward(self, a, b):
+    def plan_joined(self, rows, wa, wb, device):
+        """For a concatenating fusion: (buffer, left half, right half) for the producers of its operands to store into, else
+        (None, None, None) — round 4: the two column copies of every `Concatenate` of a hybrid head were 6 of a batch's 54 launches
+        (AMAR_FUSION_INPLACE=0: copies)."""
+        if self.fuse.method != 'concatenate' or os.environ.get('AMAR_FUSION_INPLACE', '1') == '0':
+            return None, None, None
+        buf = torch.empty((rows, wa + wb), dtype=torch.float32, device=device)
+        return buf, buf[:, :wa], buf[:, wa:]
+
+    def forward(self, a, b, joined=None):
+        """joined: the [rows, da + db] buffer whose two column halves a and b ALREADY are (their producers stored straight into
+        it: `plan_joined`) — a concatenation then has nothing to copy."""
         f = self.fuse
         self.da, self.db = a.shape[1], b.shape[1]
         if f.method == 'concatenate':
-            return _concat(a, b)
+            return joined if joined is not None else _concat(a, b)
         pa, pb = f.project(a, b)
         ta, tb = torch.empty_like(pa), torch.empty_like(pb)
         capi.dense(pa, f.att_weight, None, ta, act=None)
@@ -291,13 +302,21 @@ class _HybridHead:
     def forward(self, gu, gi, bert):
         ub, ib = bert
         t = self.t
-        g1, g2 = _DenseTape.forward_pair(t['dense1a'], (gu, None, None), t['dense1b'], (gi, None, None))      # (independent stacks: one launch)
-        b1, b2 = _DenseTape.forward_pair(t['dense2a'], (ub, None, None), t['dense2b'], (ib, None, None))
-        # feature based: (graph user, graph item) | (bert user, bert item); else per entity (hybrid.py:72-84)
+        rows, dev = int(gu.shape[0]), gu.device
+        w = {name: int(t[name].layers[-1].units) for name in ('dense1a', 'dense1b', 'dense2a', 'dense2b', 'dense3a', 'dense3b')}
+        # feature based: (graph user, graph item) | (bert user, bert item); else per entity (hybrid.py:72-84).  Concatenating fusions
+        # get their operands stored straight into the two halves of their output by the stacks that make them.
+        feeds = (('dense1a', 'dense1b'), ('dense2a', 'dense2b')) if self.fb else (('dense1a', 'dense2a'), ('dense1b', 'dense2b'))
+        ja, la, ra = self.f1a.plan_joined(rows, w[feeds[0][0]], w[feeds[0][1]], dev)
+        jb, lb, rb = self.f1b.plan_joined(rows, w[feeds[1][0]], w[feeds[1][1]], dev)
+        dest = {feeds[0][0]: la, feeds[0][1]: ra, feeds[1][0]: lb, feeds[1][1]: rb}
+        g1, g2 = _DenseTape.forward_pair(t['dense1a'], (gu, None, dest['dense1a']), t['dense1b'], (gi, None, dest['dense1b']))      # (independent stacks: one launch)
+        b1, b2 = _DenseTape.forward_pair(t['dense2a'], (ub, None, dest['dense2a']), t['dense2b'], (ib, None, dest['dense2b']))
         ins = ((g1, g2), (b1, b2)) if self.fb else ((g1, b1), (g2, b2))
-        fa, fb = self.f1a.forward(*ins[0]), self.f1b.forward(*ins[1])
-        x1, x2 = _DenseTape.forward_pair(t['dense3a'], (fa, None, None), t['dense3b'], (fb, None, None))
-        x = self.f2.forward(x1, x2)
+        fa, fb = self.f1a.forward(*ins[0], joined=ja), self.f1b.forward(*ins[1], joined=jb)
+        jc, lc, rc = self.f2.plan_joined(rows, w['dense3a'], w['dense3b'], dev) if 'residual' not in t else (None, None, None)
+        x1, x2 = _DenseTape.forward_pair(t['dense3a'], (fa, None, lc), t['dense3b'], (fb, None, rc))
+        x = self.f2.forward(x1, x2, joined=jc)
         if 'residual' in t:                                          # hybrid.py:86-89
             r = t['residual'].forward(x)
             self.s = torch.empty_like(r)

@@ -738,3 +738,24 @@ def test_dense_stack_pair_equals_two_launches(hip):
                 for a, b in ((ba0, bb0), (ba1, bb1)):
                     for x, y in zip(a['dWs'] + a['dbs'], b['dWs'] + b['dbs']):
                         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize('M,K,N', [(1024, 768, 256), (1000, 256, 64), (85, 768, 256), (3000, 132, 96), (1024, 768, 100)])
+def test_wgrad_wide_layers_on_the_matrix_instruction(hip, M, K, N):
+    """amar_wgrad_f32 for batch-sized wide layers (round 4: one workgroup per 32 x 32 tile of dW walks all rows on the f32 matrix instruction, no
+    partial sums): dW = X^T . dZ and db against float64, strided operands, called twice with identical bits, with and without db."""
+    rng = np.random.default_rng(M + K + N)
+    xw = rng.standard_normal((M, K + 8)).astype(np.float32)
+    dzw = rng.standard_normal((M, N + 4)).astype(np.float32)
+    x_d, dz_d = _t(xw)[:, 4:4 + K], _t(dzw)[:, 4:4 + N]
+    want_dw = xw[:, 4:4 + K].astype(np.float64).T @ dzw[:, 4:4 + N].astype(np.float64)
+    dw, db = torch.empty((K, N), device=DEV), torch.empty(N, device=DEV)
+    hip.wgrad(x_d, dz_d, dw, db)
+    assert helpers.rel_err(dw.cpu().numpy(), want_dw) < 3e-6
+    assert helpers.rel_err(db.cpu().numpy(), dzw[:, 4:4 + N].astype(np.float64).sum(0)) < 3e-6
+    dw2, db2 = torch.empty((K, N), device=DEV), torch.empty(N, device=DEV)
+    hip.wgrad(x_d, dz_d, dw2, db2)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    dw3 = torch.empty((K, N), device=DEV)
+    hip.wgrad(x_d, dz_d, dw3, None)
+    assert torch.equal(dw, dw3)

@@ -148,6 +148,78 @@ __global__ __launch_bounds__(256) void dense_mfma_kernel(const DenseArgs a) {
     }
 }
 
+// Batch-sized products of wide layers (1 024 rows x 768 -> 256: the first layer of a content tower inside model.fit or a per-batch
+// predict): the tiles above make 32 workgroups of such a product, each walking K alone on its CU with one k-tile in flight — 38 us
+// for 0.4 GFLOP.  Here a workgroup takes 64 rows x 64 columns (one 32 x 32 accumulator per wave: four times the workgroups), k-tiles of
+// 32 with TWO of them in flight ahead of the one being multiplied.  Guard-free like FULL (K a multiple of 32, N of 64, aligned
+// operands); the same instruction and the same (k, k + 1) pairing per step as the kernels above: bit-identical results.
+constexpr int SB = 64, SK = 32, SA_LD = SB + 4, SB_LD = SB;
+__global__ __launch_bounds__(256) void dense_mfma_small_kernel(const DenseArgs a) {
+    __shared__ float As[SK * SA_LD];                                 // [k][row] (transposed on the way in)
+    __shared__ float Bs[SK * SB_LD];                                 // [k][col]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t m0 = (int64_t)blockIdx.x * SB;
+    const int n0 = blockIdx.y * SB;
+    // staging: X tile = 64 rows x 8 float4 -> 2 per thread (rows xr, xr + 32); W tile = 32 k x 16 float4 -> 2 per thread (k rows wk, wk + 16)
+    const int xr = tid >> 3, xq = tid & 7, wk = tid >> 4, wq = tid & 15;
+    const float *xp[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int64_t m = m0 + xr + 32 * h, mc = m < a.M ? m : a.M - 1;          // (rows past M re-read row M - 1: dropped by the epilogue)
+        xp[h] = a.X + (a.ids ? (int64_t)a.ids[mc] : mc) * a.ldx + 4 * xq;
+    }
+    const float *wp = a.W + (int64_t)wk * a.N + n0 + 4 * wq;
+    float4 xa[2][2], wb[2][2];                                      // [slot][piece]: two k-tiles in flight
+    auto fetch = [&](int slot, int k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            xa[slot][h] = *reinterpret_cast<const float4 *>(xp[h] + k0);
+            wb[slot][h] = *reinterpret_cast<const float4 *>(wp + (int64_t)(k0 + 16 * h) * a.N);
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int row_half = wave >> 1, col_half = wave & 1;
+    auto multiply = [&](int slot) {
+        __syncthreads();                                             // previous tile fully consumed
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 v = xa[slot][h];
+            float *d = &As[(4 * xq) * SA_LD + xr + 32 * h];
+            d[0] = v.x; d[SA_LD] = v.y; d[2 * SA_LD] = v.z; d[3 * SA_LD] = v.w;
+            *reinterpret_cast<float4 *>(&Bs[(wk + 16 * h) * SB_LD + 4 * wq]) = wb[slot][h];
+        }
+        __syncthreads();
+    };
+    auto products = [&]() {
+#pragma unroll
+        for (int kk = 0; kk < SK; kk += 2) {
+            const int k = kk + (lane >> 5);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[k * SA_LD + 32 * row_half + (lane & 31)], Bs[k * SB_LD + 32 * col_half + (lane & 31)], acc, 0, 0, 0);
+        }
+    };
+    fetch(0, 0);
+    if (SK < a.K) fetch(1, SK);
+    for (int k0 = 0; k0 < a.K; k0 += 2 * SK) {                         // two k-tiles per trip: static register slots
+        multiply(0);
+        if (k0 + 2 * SK < a.K) fetch(0, k0 + 2 * SK);
+        products();
+        if (k0 + SK < a.K) {
+            multiply(1);
+            if (k0 + 3 * SK < a.K) fetch(1, k0 + 3 * SK);
+            products();
+        }
+    }
+    const int n = n0 + 32 * col_half + (lane & 31);
+    const float b = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + 32 * row_half + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < a.M) a.Y[m * a.ldy + n] = apply_act(acc[r] + b, a.act);
+    }
+}
+
 // The guard-free form on a 128 x 128 tile (N a multiple of 128: the 768 -> 256 BERT layers): every wave keeps its 32 rows against all
 // 128 columns in FOUR accumulators, so one A fragment read feeds four MFMAs (three LDS reads per four MFMAs instead of three per two)
 // and a k-tile's two barriers are paid once per 32 MFMAs per wave instead of once per 16.  Same k order per output: bit-identical.
@@ -440,6 +512,11 @@ int amar_dense_f32(const float *X, int64_t ldx, const int32_t *ids,
     const bool vx = (ldx & 3) == 0 && amar_aligned16(X);
     const bool vw = (N & 3) == 0 && amar_aligned16(W);
     static const bool no_full = getenv("AMAR_DENSE_FULL") && atoi(getenv("AMAR_DENSE_FULL")) == 0;     // development switch (A/B timing)
+    static const bool no_small = getenv("AMAR_DENSE_SMALL") && atoi(getenv("AMAR_DENSE_SMALL")) == 0;  // ... the batch-sized form
+    if (vx && vw && !w_trans && K % SK == 0 && N % SB == 0 && M <= 4096 && !no_full && !no_small) {
+        hipLaunchKernelGGL(dense_mfma_small_kernel, dim3((unsigned)((M + SB - 1) / SB), (unsigned)(N / SB)), block, 0, st, a);
+        return amar_check_launch();
+    }
     static const bool no_128 = getenv("AMAR_DENSE_128") && atoi(getenv("AMAR_DENSE_128")) == 0;        // ... the 128-column tile
     // the 128-column tile only where it still fills the chip: a batch-sized product (1 024 rows x 768 -> 256: the first layer of a content
     // tower inside model.fit) is 32 workgroups of it, each walking K alone on its CU — 64 us against 38 with the 64-column tile's 64 workgroups

@@ -1349,3 +1349,26 @@ def test_host_gcn_filter_route_keeps_the_factors(hip, monkeypatch):
     assert xs.vals is None and xs.row_scale is not None              # value-free XS image too
     hip.spmm_xs(xs, _t(x), y)
     assert rel_err(y.cpu().numpy(), a_hat.astype(np.float64) @ x.astype(np.float64)) < 2e-6
+
+
+@pytest.mark.parametrize('M,K,N,act,gather', [(1024, 768, 256, 'relu', False), (85, 256, 64, None, True), (2048, 64, 64, 'sigmoid', True), (1, 768, 256, 'relu', False)])
+def test_dense_batch_sized_wide_layers(hip, M, K, N, act, gather):
+    """amar_dense_f32 on batch-sized operands of wide layers (round 4: 64 x 64 tiles, two k-tiles in flight — dense_mfma_small_kernel) against
+    float64, and bit for bit against the same rows computed inside a larger product (the big-tile kernels): same instruction, same k order."""
+    rng = np.random.default_rng(M + K + N)
+    big = 6000
+    x = rng.standard_normal((big, K)).astype(np.float32)
+    w = (rng.standard_normal((K, N)) * 0.2).astype(np.float32)
+    b = (rng.standard_normal(N) * 0.1).astype(np.float32)
+    ids = rng.integers(0, big, big).astype(np.int32) if gather else None
+    x_d, w_d, b_d = _t(x), _t(w), _t(b)
+    ids_d = _t(ids) if gather else None
+    y_small = torch.empty((M, N), device=DEV)
+    hip.dense(x_d if gather else x_d[:M], w_d, b_d, y_small, act=act, ids=ids_d[:M] if gather else None)
+    src = x[ids[:M]] if gather else x[:M]
+    z = src.astype(np.float64) @ w.astype(np.float64) + b
+    want = np.maximum(z, 0) if act == 'relu' else 1 / (1 + np.exp(-z)) if act == 'sigmoid' else z
+    assert helpers.rel_err(y_small.cpu().numpy(), want) < 3e-6
+    y_big = torch.empty((big, N), device=DEV)
+    hip.dense(x_d, w_d, b_d, y_big, act=act, ids=ids_d)
+    assert torch.equal(y_big[:M], y_small)

@@ -721,9 +721,10 @@ class Trainer:
                 self._eager_loss += self.train_batch(u_ids, i_ids, y, bert=bert) * b
                 return
             d = int(np.asarray(bert[0]).shape[1]) if with_blocks else 0
-            ui = torch.zeros(2 * b, dtype=torch.int32, device=dev)   # u and i side by side: one scatter of both towers' input gradients
-            g = self._g = {'ui': ui, 'u': ui[:b], 'i': ui[b:],
-                           'y': torch.zeros(b, dtype=torch.float32, device=dev),
+            uiy = torch.zeros(3 * b, dtype=torch.int32, device=dev)  # u, i and the labels in ONE buffer: one upload per batch instead of three
+            ui = uiy[:2 * b]                                          # (u and i side by side: one scatter of both towers' input gradients)
+            g = self._g = {'uiy': uiy, 'ui': ui, 'u': ui[:b], 'i': ui[b:],
+                           'y': uiy[2 * b:].view(torch.float32),
                            'ub': torch.zeros((b, d), dtype=torch.float32, device=dev) if with_blocks else None,
                            'ib': torch.zeros((b, d), dtype=torch.float32, device=dev) if with_blocks else None}
             g['slot_host'] = torch.empty(64 * len(self.params) + 64, dtype=torch.uint8).pin_memory()   # >= sizeof(amar_adam_slot) per parameter
@@ -731,8 +732,10 @@ class Trainer:
             # pinned staging for the batch's ids and labels, four sets in turn: the uploads are asynchronous, so the host prepares
             # batch k + 1 while the device still runs batch k (a pageable copy_ made the host wait for the stream every batch:
             # 0.13 ms of a 0.52 ms batch at ml1m(s=1))
-            g['stage'] = [{'u': torch.empty(b, dtype=torch.int32).pin_memory(), 'i': torch.empty(b, dtype=torch.int32).pin_memory(),
-                           'y': torch.empty(b, dtype=torch.float32).pin_memory(), 'done': torch.cuda.Event()} for _ in range(4)]
+            g['stage'] = []
+            for _ in range(4):
+                host = torch.empty(3 * b, dtype=torch.int32).pin_memory()
+                g['stage'].append({'uiy': host, 'u': host[:b], 'i': host[b:2 * b], 'y': host[2 * b:].view(torch.float32), 'done': torch.cuda.Event()})
             g['turn'] = 0
             from deep_cbrs_amar_renaissance_amd.engine import capture_graph
 
@@ -747,17 +750,22 @@ class Trainer:
         st = g['stage'][g['turn'] % len(g['stage'])]
         g['turn'] += 1
         st['done'].synchronize()                                     # (the uploads that last used this staging set have landed)
-        for name, src in (('u', u_ids), ('i', i_ids)):
-            if isinstance(src, torch.Tensor) and src.is_cuda:
+        on_device = [isinstance(src, torch.Tensor) and src.is_cuda for src in (u_ids, i_ids, y)]
+        for name, src, dev_side in (('u', u_ids, on_device[0]), ('i', i_ids, on_device[1])):
+            if dev_side:
                 g[name].copy_(src)
             else:
                 stage_ids(st[name], src, n_nodes)                    # range check + int32 on the host, into pinned memory
-                g[name].copy_(st[name], non_blocking=True)
-        if isinstance(y, torch.Tensor) and y.is_cuda:
+                if any(on_device):
+                    g[name].copy_(st[name], non_blocking=True)
+        if on_device[2]:
             g['y'].copy_(y)
         else:
             st['y'].numpy()[...] = y.numpy() if isinstance(y, torch.Tensor) else np.asarray(y, dtype=np.float32)
-            g['y'].copy_(st['y'], non_blocking=True)
+            if any(on_device):
+                g['y'].copy_(st['y'], non_blocking=True)
+        if not any(on_device):
+            g['uiy'].copy_(st['uiy'], non_blocking=True)             # ids and labels of the batch: one asynchronous upload
         st['done'].record()
         if with_blocks:
             g['ub'].copy_(to_device_tensor(bert[0]))

@@ -517,10 +517,16 @@ class _StackTape:
                 dz = torch.empty((n, c), dtype=torch.float32, device=dev)
                 capi.l2norm_bwd(dsl(k + 1), nrm, inv, dz, act='relu')
                 dw, db = torch.empty_like(layer.kernel), torch.empty_like(layer.bias)
-                capi.wgrad(xa, dz, dw, db)
-                grads[layer.kernel], grads[layer.bias] = dw, db
                 dxa = torch.empty((n, 2 * f), dtype=torch.float32, device=dev)
-                capi.dense(dz, layer.kernel.detach(), None, dxa, act=None, w_transposed=True)
+                if capi.dense_bwd_enabled() and capi.dense_bwd_supported(2 * f, c) and n > 0:     # dW, db and dZ . W^T in one launch (round 4)
+                    lazy = capi.dense_bwd(xa, None, dz, layer.kernel.detach(), None, self._workspace(k, n, 2 * f, c, dev), dX=dxa, dW=dw, db=db,
+                                          defer=self.defer_reduce)
+                    if lazy is not None:
+                        dw, db = lazy
+                else:
+                    capi.wgrad(xa, dz, dw, db)
+                    capi.dense(dz, layer.kernel.detach(), None, dxa, act=None, w_transposed=True)
+                grads[layer.kernel], grads[layer.bias] = dw, db
                 capi.add_inplace(dsl(k), dxa[:, :f])
                 g = torch.empty((n, f), dtype=torch.float32, device=dev)
                 capi.row_affine(dxa[:, f:], self.inv_cnt, g)               # d(mean)/d(sum)
@@ -536,17 +542,26 @@ class _StackTape:
                                                 layer.attn_kernel_self.detach().view(c), layer.attn_kernel_neighs.detach().view(c),
                                                 self_loop=layer.add_self_loops)
                 db = torch.empty_like(layer.bias)
-                capi.wgrad(None, dout, None, db)
                 das, dan = torch.empty((c, 1), dtype=torch.float32, device=dev), torch.empty((c, 1), dtype=torch.float32, device=dev)
                 capi.wgrad(h, ds.view(n, 1), das, None)
                 capi.wgrad(h, dt.view(n, 1), dan, None)
                 dw = torch.empty((f, c), dtype=torch.float32, device=dev)
-                capi.wgrad(sl(k), dh, dw, None)
-                grads[layer.kernel], grads[layer.bias] = dw.view_as(layer.kernel), db
+                if capi.dense_bwd_enabled() and capi.dense_bwd_supported(f, c) and n > 0:
+                    # round 4: the bias gradient in one launch, and dW = X_k^T . dH with dH . W^T added straight into the slice's gradient in
+                    # one more (ten launches of a layer's reverse pass were weight-gradient partials and their reductions)
+                    lazy_b = capi.dense_bwd(None, None, dout, None, None, self._workspace(('b', k), n, 1, c, dev), db=db, defer=self.defer_reduce, K=1)
+                    lazy_w = capi.dense_bwd(sl(k), None, dh, w2d.contiguous(), None, self._workspace(k, n, f, c, dev), dX=dsl(k), dW=dw,
+                                            defer=self.defer_reduce, accumulate_dx=True)
+                    grads[layer.kernel] = lazy_w[0] if lazy_w is not None else dw.view_as(layer.kernel)
+                    grads[layer.bias] = lazy_b[1] if lazy_b is not None else db
+                else:
+                    capi.wgrad(None, dout, None, db)
+                    capi.wgrad(sl(k), dh, dw, None)
+                    grads[layer.kernel], grads[layer.bias] = dw.view_as(layer.kernel), db
+                    back = torch.empty((n, f), dtype=torch.float32, device=dev)
+                    capi.dense(dh, w2d.contiguous(), None, back, act=None, w_transposed=True)
+                    capi.add_inplace(dsl(k), back)
                 grads[layer.attn_kernel_self], grads[layer.attn_kernel_neighs] = das.view_as(layer.attn_kernel_self), dan.view_as(layer.attn_kernel_neighs)
-                back = torch.empty((n, f), dtype=torch.float32, device=dev)
-                capi.dense(dh, w2d.contiguous(), None, back, act=None, w_transposed=True)
-                capi.add_inplace(dsl(k), back)
             else:                                                    # dgcf
                 back = torch.empty((n, f), dtype=torch.float32, device=dev)
                 _spmm(a, dsl(k + 1), back)                # A_dgcf is symmetric

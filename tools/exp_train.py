@@ -23,10 +23,12 @@ def main():
     engine.set_seed(42)
     for name, cfg in (('BasicGCN 16x2 (Table 5)', dict(embedding_dim=16, n_hiddens=[16, 16], dense_units=[48, 48], clf_units=[64, 64], l2_regularizer=1e-4)),
                       ('BasicGCN 8x2 (grid1)', dict(embedding_dim=8, n_hiddens=[8, 8], dense_units=[24, 24], clf_units=[48, 48], l2_regularizer=1e-4)),
-                      ('BasicLightGCN 8x2', dict(embedding_dim=8, n_layers=2, dense_units=[24, 24], clf_units=[48, 48], l2_regularizer=1e-4))):
+                      ('BasicLightGCN 8x2', dict(embedding_dim=8, n_layers=2, dense_units=[24, 24], clf_units=[48, 48], l2_regularizer=1e-4)),
+                      ('BasicGraphSage 8x2', dict(embedding_dim=8, n_hiddens=[8, 8], dense_units=[24, 24], clf_units=[48, 48], l2_regularizer=1e-4)),
+                      ('BasicGAT 8x2', dict(embedding_dim=8, n_hiddens=[8, 8], dense_units=[24, 24], clf_units=[48, 48], l2_regularizer=1e-4))):
         if only_table5 and 'Table 5' not in name:
             continue
-        cls = basic.BasicLightGCN if 'Light' in name else basic.BasicGCN
+        cls = basic.BasicLightGCN if 'Light' in name else basic.BasicGraphSage if 'Sage' in name else basic.BasicGAT if 'GAT' in name else basic.BasicGCN
         model = cls(g['adj_ui'], **cfg)
         model.compile(loss='binary_crossentropy', optimizer=Adam(learning_rate=1e-3), metrics=['accuracy'])
         train = UserItemGraph(g['train'], g['users'], g['items'], g['adj_ui'], batch_size=1024, shuffle=True)

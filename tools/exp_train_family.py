@@ -1,0 +1,21 @@
+import os, sys, time
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
+import numpy as np, torch
+from deep_cbrs_amar_renaissance_amd import capi, engine
+from deep_cbrs_amar_renaissance_amd.data.datasets import UserItemGraph
+from deep_cbrs_amar_renaissance_amd.experiment import Adam
+from deep_cbrs_amar_renaissance_amd.models import basic
+from tests import helpers
+capi.load()
+g = helpers.ml1m_indexed(1)
+engine.set_seed(42)
+name = sys.argv[1]
+cls = getattr(basic, name)
+cfg = dict(embedding_dim=8, dense_units=[24, 24], clf_units=[48, 48], l2_regularizer=1e-4)
+if name == 'BasicLightGCN': cfg['n_layers'] = 2
+else: cfg['n_hiddens'] = [8, 8]
+model = cls(g['adj_ui'], **cfg)
+model.compile(loss='binary_crossentropy', optimizer=Adam(learning_rate=1e-3), metrics=['accuracy'])
+train = UserItemGraph(g['train'], g['users'], g['items'], g['adj_ui'], batch_size=1024, shuffle=True)
+model.fit(train, epochs=2, verbose=False)
+torch.cuda.synchronize()

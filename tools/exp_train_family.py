@@ -1,3 +1,7 @@
+#!/usr/bin/env python
+"""Two fit() epochs of ONE Basic* model family at ml1m(s=1) (d = 8 x 2, dense [24, 24], clf [48, 48], batch 1 024) — meant to run under
+rocprofv3 --kernel-trace --stats so that tools/train_launches.py <dir> 1482 lists the launches of a replayed batch.
+usage: python tools/exp_train_family.py <BasicGCN|BasicLightGCN|BasicGraphSage|BasicGAT>"""
 import os, sys, time
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import numpy as np, torch

@@ -608,6 +608,7 @@ struct DenseBwdArgs {
     const float *X; int64_t ldx; const float *Y; int64_t ldy; const float *dY; int64_t lddy; const float *W;
     float *dX; int64_t lddx; float *part_w; float *part_b; int64_t M; int K, N, act, subtiles;
     float *dZ; int64_t lddz; int accum_dx;
+    int x_scalar;                                                     // (row-walking kernel: X rows by single floats — K not a multiple of 4 or an unaligned X)
 };
 
 // How a call over M rows is cut (round 4, second half).  Up to DB_MAX_GROUPS tiles of 64 rows: one workgroup and one partial per tile (the
@@ -866,8 +867,16 @@ __global__ __launch_bounds__(256) void dense_bwd_rows_kernel(const DenseBwdArgs 
         accb.x += gq.x; accb.y += gq.y; accb.z += gq.z; accb.w += gq.w;
         if (a.X) {
             float4 x[KQ];
+            if (a.x_scalar) {                                        // (K = 1: the gradient of a GAT layer's attention vector is ds^T . H)
 #pragma unroll
-            for (int j = 0; j < KQ; ++j) x[j] = 4 * j < a.K ? *reinterpret_cast<const float4 *>(a.X + row * a.ldx + 4 * j) : f4_zero();
+                for (int j = 0; j < KQ; ++j) {
+                    const float *xr = a.X + row * a.ldx + 4 * j;
+                    x[j] = make_float4(4 * j < a.K ? xr[0] : 0.f, 4 * j + 1 < a.K ? xr[1] : 0.f, 4 * j + 2 < a.K ? xr[2] : 0.f, 4 * j + 3 < a.K ? xr[3] : 0.f);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < KQ; ++j) x[j] = 4 * j < a.K ? *reinterpret_cast<const float4 *>(a.X + row * a.ldx + 4 * j) : f4_zero();
+            }
 #pragma unroll
             for (int j = 0; j < KQ; ++j) {
                 accw[4 * j + 0] = f4_fma(x[j].x, gq, accw[4 * j + 0]);
@@ -1539,13 +1548,15 @@ int amar_dense_bwd_f32(const float *X, int64_t ldx, const float *Y, int64_t ldy,
     hipStream_t st = static_cast<hipStream_t>(stream);
     // 16-byte loads where every operand allows them (K, N and the leading dimensions multiples of 4 floats, 16-byte aligned bases)
     const bool use_x = dW != nullptr, use_w = dX != nullptr, use_y = act != AMAR_ACT_NONE;
-    const bool vec = ((K & 3) == 0 || (!use_x && !use_w)) && (N & 3) == 0 && (lddy & 3) == 0 && amar_aligned16(dY) && (!use_y || ((ldy & 3) == 0 && amar_aligned16(Y))) &&
-                     (!use_x || ((ldx & 3) == 0 && amar_aligned16(X))) && (!use_w || amar_aligned16(W));
+    const bool vec_rest = (N & 3) == 0 && (lddy & 3) == 0 && amar_aligned16(dY) && (!use_y || ((ldy & 3) == 0 && amar_aligned16(Y))) &&
+                          (!use_w || ((K & 3) == 0 && amar_aligned16(W)));
+    const bool vec_x = !use_x || ((K & 3) == 0 && (ldx & 3) == 0 && amar_aligned16(X));
+    const bool vec = vec_rest && vec_x;
     // many rows of narrow operands (a convolution layer's reverse pass over every node): the row-walking kernel, `fold` of its workgroups
     // per partial the caller sees (AMAR_DENSE_BWD_ROWS_OFF: the tile kernel, for A/B timing)
     static const bool rows_off = getenv("AMAR_DENSE_BWD_ROWS_OFF") != nullptr;
-    const bool rows_form = plan.fold > 1 && vec && K <= 32 && N <= 32 && (!dX || ((lddx & 3) == 0 && amar_aligned16(dX))) &&
-                           (!dZ || ((lddz & 3) == 0 && amar_aligned16(dZ))) && !rows_off;
+    const bool rows_form = plan.fold > 1 && vec_rest && K <= 32 && N <= 32 && (!dX || ((lddx & 3) == 0 && amar_aligned16(dX))) &&
+                           (!dZ || ((lddz & 3) == 0 && amar_aligned16(dZ))) && !rows_off;      // (X may be read by single floats there)
     // the row-walking kernel up to 32 768 rows: one workgroup per partial the caller sees, no fold launch (9 228 rows at ml1m(s=1): 49
     // workgroups of three passes); beyond: up to 64 workgroups per partial
     const bool need_fold = plan.fold > 1 && !(rows_form && M <= 32768);
@@ -1560,7 +1571,7 @@ int amar_dense_bwd_f32(const float *X, int64_t ldx, const float *Y, int64_t ldy,
         raw_b = db ? raw + n_raw * size_w : nullptr;
     }
     DenseBwdArgs a{use_x ? X : nullptr, ldx, use_y ? Y : nullptr, ldy, dY, lddy, use_w ? W : nullptr, dX, lddx, raw_w, raw_b, M, K, N, act, sub,
-                   dZ, lddz, accum ? 1 : 0};
+                   dZ, lddz, accum ? 1 : 0, vec_x ? 0 : 1};
     if (rows_form) {
 #define AMAR_DBR_LAUNCH(KK, NN) hipLaunchKernelGGL((dense_bwd_rows_kernel<KK, NN>), dim3((unsigned)n_raw), dim3(256), 0, st, a)
         const int kc = K <= 8 ? 0 : (K <= 16 ? 1 : 2), nc = N <= 8 ? 0 : (N <= 16 ? 1 : 2);

@@ -543,10 +543,17 @@ class _StackTape:
                                                 self_loop=layer.add_self_loops)
                 db = torch.empty_like(layer.bias)
                 das, dan = torch.empty((c, 1), dtype=torch.float32, device=dev), torch.empty((c, 1), dtype=torch.float32, device=dev)
-                capi.wgrad(h, ds.view(n, 1), das, None)
-                capi.wgrad(h, dt.view(n, 1), dan, None)
+                fused = capi.dense_bwd_enabled() and capi.dense_bwd_supported(f, c) and n > 0
+                if fused:                                             # H^T . ds as (ds^T . H)^T: a [1, c] weight gradient with X = ds, dZ = H — one launch each
+                    lazy_s = capi.dense_bwd(ds.view(n, 1), None, h, None, None, self._workspace(('s', k), n, 1, c, dev), dW=das.view(1, c), defer=self.defer_reduce)
+                    lazy_t = capi.dense_bwd(dt.view(n, 1), None, h, None, None, self._workspace(('t', k), n, 1, c, dev), dW=dan.view(1, c), defer=self.defer_reduce)
+                    if lazy_s is not None:
+                        das, dan = lazy_s[0], lazy_t[0]
+                else:
+                    capi.wgrad(h, ds.view(n, 1), das, None)
+                    capi.wgrad(h, dt.view(n, 1), dan, None)
                 dw = torch.empty((f, c), dtype=torch.float32, device=dev)
-                if capi.dense_bwd_enabled() and capi.dense_bwd_supported(f, c) and n > 0:
+                if fused:
                     # round 4: the bias gradient in one launch, and dW = X_k^T . dH with dH . W^T added straight into the slice's gradient in
                     # one more (ten launches of a layer's reverse pass were weight-gradient partials and their reductions)
                     lazy_b = capi.dense_bwd(None, None, dout, None, None, self._workspace(('b', k), n, 1, c, dev), db=db, defer=self.defer_reduce, K=1)
@@ -561,7 +568,8 @@ class _StackTape:
                     back = torch.empty((n, f), dtype=torch.float32, device=dev)
                     capi.dense(dh, w2d.contiguous(), None, back, act=None, w_transposed=True)
                     capi.add_inplace(dsl(k), back)
-                grads[layer.attn_kernel_self], grads[layer.attn_kernel_neighs] = das.view_as(layer.attn_kernel_self), dan.view_as(layer.attn_kernel_neighs)
+                grads[layer.attn_kernel_self] = das if isinstance(das, capi.DeferredGradient) else das.view_as(layer.attn_kernel_self)
+                grads[layer.attn_kernel_neighs] = dan if isinstance(dan, capi.DeferredGradient) else dan.view_as(layer.attn_kernel_neighs)
             else:                                                    # dgcf
                 back = torch.empty((n, f), dtype=torch.float32, device=dev)
                 _spmm(a, dsl(k + 1), back)                # A_dgcf is symmetric

@@ -102,7 +102,7 @@ def test_training_kernels(hip):
 @pytest.mark.parametrize('M,K,N,act', [(1024, 48, 48, 'relu'), (85, 96, 64, 'relu'), (1024, 64, 1, 'sigmoid'), (1024, 64, 1, None),
                                          (9228, 16, 16, None), (1, 24, 24, 'relu'), (300, 128, 128, 'relu'), (64, 5, 3, 'sigmoid'), (40000, 32, 8, 'relu'),
                                          (600001, 8, 8, 'relu'), (40000, 8, 8, 'relu'), (40000, 16, 16, None), (70000, 32, 32, 'relu'), (40000, 16, 8, 'sigmoid'),
-                                         (40000, 8, 32, None), (40000, 24, 12, 'relu'), (40000, 6, 8, 'relu')])                     # (a convolution layer's reverse pass over every node: folded partials, two tiles per workgroup)
+                                         (40000, 8, 32, None), (40000, 24, 12, 'relu'), (40000, 6, 8, 'relu'), (9228, 1, 8, None), (40000, 2, 16, None)])     # (K = 1: a GAT attention vector's gradient, X read by single floats)                     # (a convolution layer's reverse pass over every node: folded partials, two tiles per workgroup)
 def test_dense_bwd_fused(hip, M, K, N, act):
     """amar_dense_bwd_f32 (round 4: the reverse pass of one Dense layer in two launches instead of four — act', dX = dZ . W^T, dW = X^T . dZ, db) against
     float64 arithmetic and against the separate kernels it replaces; strided operands (column slices of wider buffers, as the

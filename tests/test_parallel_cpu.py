@@ -204,3 +204,26 @@ def _free_port():
     port = s.getsockname()[1]
     s.close()
     return port
+
+
+def test_bench_supervisor_flow_without_a_gpu():
+    """bench.py under a multi-rank launcher runs the rank's work in a child and repeats a failed graph-replayed run once with eager steps
+    (bench.supervise).  Without a GPU both children stop at `bench.py needs a GPU`: the parent must report the first failure, start the
+    second attempt with AMAR_STEP_GRAPH=0 and pass the second exit code on — and print nothing on stdout."""
+    import subprocess
+    import sys
+    import torch
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if torch.cuda.is_available():
+        pytest.skip("covers the no-GPU flow (tests/test_parallel_nccl_gpu.py has the GPU one)")
+    env = dict(os.environ, WORLD_SIZE='2', RANK='0', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29577')
+    for k in ('AMAR_BENCH_CHILD', 'AMAR_BENCH_RETRY', 'AMAR_STEP_GRAPH', 'AMAR_BENCH_SUPERVISE'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == ''
+    assert 'once more with eager steps' in r.stderr and r.stderr.count('AssertionError: bench.py needs a GPU') == 2, r.stderr[-1500:]
+    # with the graph already off there is nothing to fall back to: one attempt only
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       env=dict(env, AMAR_STEP_GRAPH='0'), cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'once more with eager steps' not in r.stderr and r.stderr.count('AssertionError: bench.py needs a GPU') == 1

@@ -759,3 +759,33 @@ def test_wgrad_wide_layers_on_the_matrix_instruction(hip, M, K, N):
     dw3 = torch.empty((K, N), device=DEV)
     hip.wgrad(x_d, dz_d, dw3, None)
     assert torch.equal(dw, dw3)
+
+
+def test_hybrid_fit_registers_the_bert_table_of_the_reference_sequence(hip, monkeypatch):
+    """fit() on the reference's own hybrid Sequence (ids + the BERT rows of the batch, gathered on the host from one table) registers that
+    table on the device once and reads the batches as ids only (round 4): the weights after two epochs equal those of the batches taken
+    as they come (AMAR_RESIDENT_BERT=0) — the same rows either way."""
+    import types
+    from deep_cbrs_amar_renaissance_amd import engine
+    from deep_cbrs_amar_renaissance_amd.data.datasets import UserItemGraphEmbeddings
+    from deep_cbrs_amar_renaissance_amd.models import hybrid
+    g = helpers.tiny_graph(n_users=60, n_items=50, n_ratings=1200, seed=1)
+    rng = np.random.default_rng(0)
+    table = rng.standard_normal((110, 24)).astype(np.float32)
+    ratings = np.stack([g['u_ids'], g['i_ids'], rng.integers(0, 2, len(g['u_ids']))], axis=1).astype(np.int64)
+    users, items = np.arange(60), np.arange(60, 110)
+
+    def run(resident):
+        monkeypatch.setenv('AMAR_RESIDENT_BERT', '1' if resident else '0')
+        engine.set_seed(2)
+        model = hybrid.HybridBertGCN(g['adj'], embedding_dim=8, n_hiddens=[8, 8], dense_units=[[16], [16], [16]], clf_units=[16],
+                                     feature_based=True, l2_regularizer=1e-5)
+        model.compile(optimizer=types.SimpleNamespace(learning_rate=5e-3, beta_1=0.9))
+        seq = UserItemGraphEmbeddings(ratings, users, items, g['adj'], table, batch_size=256, shuffle=True)
+        hist = model.fit(seq, epochs=2, verbose=False)['loss']
+        assert (getattr(model, 'bert_table', None) is not None) == resident
+        return hist, [p.detach().clone() for p in model.parameters()]
+    h0, w0 = run(False)
+    h1, w1 = run(True)
+    assert len(w0) == len(w1) and all(torch.allclose(a, b, rtol=0, atol=1e-7) for a, b in zip(w0, w1))
+    assert np.allclose(h0, h1, rtol=1e-6)

@@ -44,13 +44,17 @@ def main():
     if resident:
         model.set_bert_table(table)
     seq = Seq()
+    if os.environ.get('EXP_SEQ') == 'reference':                       # the reference's own Sequence class (ids + host-gathered BERT rows per batch)
+        from deep_cbrs_amar_renaissance_amd.data.datasets import UserItemGraphEmbeddings
+        seq = UserItemGraphEmbeddings(tr, g['users'], g['items'], g['adj_ui'], table, batch_size=bs, shuffle=True)
+        nb = len(seq)
     model.fit(seq, epochs=1, verbose=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     hist = model.fit(seq, epochs=epochs, verbose=False)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / epochs
-    print('HybridBertGCN grid1 (' + ('resident BERT table' if resident else 'BERT rows from the host per batch') + '): %.2f s/epoch (%d batches of %d): %.3f ms per batch, %.0f pairs/s; loss %.4f' % (dt, nb, bs, 1e3 * dt / nb, nb * bs / dt, hist['loss'][-1]), flush=True)
+    print('HybridBertGCN grid1 (' + ('reference Sequence, AMAR_RESIDENT_BERT=' + os.environ.get('AMAR_RESIDENT_BERT', '1') if os.environ.get('EXP_SEQ') == 'reference' else 'resident BERT table' if resident else 'BERT rows from the host per batch') + '): %.2f s/epoch (%d batches of %d): %.3f ms per batch, %.0f pairs/s; loss %.4f' % (dt, nb, bs, 1e3 * dt / nb, nb * bs / dt, hist['loss'][-1]), flush=True)
 
 
 if __name__ == '__main__':

@@ -18,7 +18,9 @@ does, `datasets.py:65-66`) or as a resident table + ids (``bert_table``), which 
 12.6 MB host->device copy per 2 048-pair batch.
 """
 import abc
+import os
 
+import numpy as np
 import torch
 
 from deep_cbrs_amar_renaissance_amd import capi
@@ -346,6 +348,30 @@ class HybridBertGNN(Model, abc.ABC):
         from deep_cbrs_amar_renaissance_amd import training
         return training.fit(self, sequence, epochs=epochs, **kwargs)
 
+    def resident_ids(self, sequence):
+        """The reference's hybrid batch Sequence (data.datasets.UserItemGraphEmbeddings: ids + the BERT rows of the batch, gathered on the
+        host from ONE table indexed by node id and uploaded every batch — 6 MB at batch 1 024) read as ids only: its table is registered
+        on the device once (`set_bert_table`) and the ids Sequence inside it is returned; None for any other Sequence or with
+        AMAR_RESIDENT_BERT=0 (the batches as they come).  The same rows either way, gathered on the device."""
+        from deep_cbrs_amar_renaissance_amd.data.datasets import UserItemGraphEmbeddings
+        if os.environ.get('AMAR_RESIDENT_BERT', '1') == '0' or not isinstance(sequence, UserItemGraphEmbeddings):
+            return None
+        table = getattr(sequence.embeddings, 'embeddings', None)
+        if not (isinstance(table, np.ndarray) and table.ndim == 2 and table.shape[0] >= len(sequence.users) + len(sequence.items)):
+            return None
+        if getattr(self, '_bert_table_source', None) is not table:
+            self.set_bert_table(np.ascontiguousarray(table, dtype=np.float32))
+            self._bert_table_source = table
+        return sequence.graph_ids
+
+    def predict(self, sequence, hoist=True, **kwargs):
+        """Model.predict; the reference's hybrid Sequence is read as ids against the resident table (`resident_ids`), so that the hoisted
+        pass evaluates the first-stage networks once per entity instead of once per pair of every batch."""
+        ids = self.resident_ids(sequence)
+        if ids is not None:
+            sequence = _IdsWithoutBlocks(ids)
+        return super().predict(sequence, hoist=hoist, **kwargs)
+
     def _hoist_begin(self, hoist):
         self.gnn.hoist = bool(hoist)
 
@@ -353,6 +379,20 @@ class HybridBertGNN(Model, abc.ABC):
         self.gnn.hoist = False
         self.gnn._hoisted = None
         self._towers = None
+
+
+class _IdsWithoutBlocks:
+    """A Sequence of (user ids, item ids) batches seen as hybrid batches whose BERT blocks are None (taken from the resident table)."""
+
+    def __init__(self, ids_sequence):
+        self.ids = ids_sequence
+
+    def __len__(self):
+        return len(self.ids)
+
+    def __getitem__(self, b):
+        (u, i), y = self.ids[b]
+        return (u, i, None, None), y
 
 
 def BasicGNNFactory(name, Parent, GNN):

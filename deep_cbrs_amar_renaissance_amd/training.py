@@ -948,16 +948,7 @@ def fit(model, sequence, epochs=1, callbacks=None, verbose=True, **kwargs):
     # batch's users and items — gathered on the host from ONE table indexed by node id and uploaded every batch (6 MB at batch 1 024).
     # That table is registered once on the device instead and the batches are read as ids only: the same rows, gathered there
     # (AMAR_RESIDENT_BERT=0: the batches as they come).  A replayed hybrid batch at ml1m(s=1): 0.41 against 0.71 ms.
-    ids_only = None
-    if hasattr(model, 'set_bert_table') and os.environ.get('AMAR_RESIDENT_BERT', '1') != '0':
-        from deep_cbrs_amar_renaissance_amd.data.datasets import UserItemGraphEmbeddings
-        table = getattr(getattr(sequence, 'embeddings', None), 'embeddings', None)
-        if isinstance(sequence, UserItemGraphEmbeddings) and isinstance(table, np.ndarray) and table.ndim == 2 and \
-                table.shape[0] >= len(sequence.users) + len(sequence.items):
-            if getattr(model, '_bert_table_source', None) is not table:
-                model.set_bert_table(np.ascontiguousarray(table, dtype=np.float32))
-                model._bert_table_source = table
-            ids_only = sequence.graph_ids
+    ids_only = model.resident_ids(sequence) if hasattr(model, 'resident_ids') else None
     trainer = getattr(model, '_trainer', None)
     if trainer is None:
         if hasattr(model.rs, 'dense1a') and not model.rs.built and len(sequence):

@@ -789,3 +789,30 @@ def test_hybrid_fit_registers_the_bert_table_of_the_reference_sequence(hip, monk
     h1, w1 = run(True)
     assert len(w0) == len(w1) and all(torch.allclose(a, b, rtol=0, atol=1e-7) for a, b in zip(w0, w1))
     assert np.allclose(h0, h1, rtol=1e-6)
+
+
+def test_hybrid_predict_reads_the_reference_sequence_as_ids(hip, monkeypatch):
+    """predict() on the reference's hybrid Sequence: ids against the table registered on the device (towers once per entity in the hoisted
+    pass) give the scores of the batches taken as they come (BERT rows gathered on the host, towers per pair) to fp32 rounding."""
+    from deep_cbrs_amar_renaissance_amd import engine
+    from deep_cbrs_amar_renaissance_amd.data.datasets import UserItemGraphEmbeddings
+    from deep_cbrs_amar_renaissance_amd.models import hybrid
+    g = helpers.tiny_graph(n_users=60, n_items=50, n_ratings=1200, seed=1)
+    rng = np.random.default_rng(0)
+    table = rng.standard_normal((110, 24)).astype(np.float32)
+    ratings = np.stack([g['u_ids'], g['i_ids'], rng.integers(0, 2, len(g['u_ids']))], axis=1).astype(np.int64)
+    users, items = np.arange(60), np.arange(60, 110)
+    engine.set_seed(3)
+    model = hybrid.HybridBertGCN(g['adj'], embedding_dim=8, n_hiddens=[8, 8], dense_units=[[16], [16], [16]], clf_units=[16],
+                                 feature_based=False, l2_regularizer=1e-5)
+    seq = UserItemGraphEmbeddings(ratings, users, items, g['adj'], table, batch_size=128, shuffle=False)
+    monkeypatch.setenv('AMAR_RESIDENT_BERT', '0')
+    plain = model.predict(seq)
+    assert getattr(model, 'bert_table', None) is None
+    helpers.randomize_biases(model, seed=2)
+    plain = model.predict(seq)
+    monkeypatch.setenv('AMAR_RESIDENT_BERT', '1')
+    resident = model.predict(seq)
+    assert model.bert_table is not None and resident.shape == plain.shape == (len(ratings), 1)
+    assert float(np.abs(resident - plain).max()) < 2e-6
+    assert float(np.abs(model.predict(seq, hoist=False) - plain).max()) < 2e-6

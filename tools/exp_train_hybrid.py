@@ -57,5 +57,31 @@ def main():
     print('HybridBertGCN grid1 (' + ('reference Sequence, AMAR_RESIDENT_BERT=' + os.environ.get('AMAR_RESIDENT_BERT', '1') if os.environ.get('EXP_SEQ') == 'reference' else 'resident BERT table' if resident else 'BERT rows from the host per batch') + '): %.2f s/epoch (%d batches of %d): %.3f ms per batch, %.0f pairs/s; loss %.4f' % (dt, nb, bs, 1e3 * dt / nb, nb * bs / dt, hist['loss'][-1]), flush=True)
 
 
+def predict_times():
+    """predict() of the test pairs through the reference's hybrid Sequence, BERT rows per batch against the registered table."""
+    from deep_cbrs_amar_renaissance_amd import capi, engine
+    from deep_cbrs_amar_renaissance_amd.data.datasets import UserItemGraphEmbeddings
+    from deep_cbrs_amar_renaissance_amd.models import hybrid
+    from tests import helpers
+    capi.load()
+    g = helpers.ml1m_indexed(1)
+    engine.set_seed(42)
+    model = hybrid.HybridBertGCN(g['adj_ui'], embedding_dim=8, n_hiddens=[8, 8], dense_units=[[24, 24], [256, 64], [64, 64]], clf_units=[64, 64],
+                                 feature_based=True, l2_regularizer=1e-4)
+    table = np.random.default_rng(0).standard_normal((g['adj_ui'].shape[0], 768)).astype(np.float32)
+    seq = UserItemGraphEmbeddings(np.asarray(g['test']), g['users'], g['items'], g['adj_ui'], table, batch_size=2048, shuffle=False)
+    for mode in ('0', '1'):
+        os.environ['AMAR_RESIDENT_BERT'] = mode
+        model.predict(seq)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = model.predict(seq)
+        torch.cuda.synchronize()
+        print('predict(), %d pairs in %d batches, AMAR_RESIDENT_BERT=%s: %.1f ms' % (len(out), len(seq), mode, 1e3 * (time.perf_counter() - t0)), flush=True)
+
+
 if __name__ == '__main__':
+    if os.environ.get('EXP_PREDICT') == '1':
+        predict_times()
+        sys.exit(0)
     main()

@@ -23,6 +23,7 @@ forms the softmax / attention-scalar gradients row-wise for both edge directions
 atomics).
 """
 import os
+import types
 
 import numpy as np
 import torch
@@ -899,6 +900,38 @@ class HeadTrainer(Trainer):
         self.m = {p: torch.zeros_like(p) for p in self.params}
         self.v = {p: torch.zeros_like(p) for p in self.params}
         self.head = _HybridHead(model) if self.hybrid else _BasicHead(model)
+        self.device = self.params[0].device
+        self.tables = None
+
+    # -- batches as ids against tables kept on the device (round 4) ---------------------------------------------------------------
+    def set_tables(self, tables):
+        """The embedding table(s) the batch Sequence gathers its rows from ([n, D] each: one for BasicRS, graph + BERT for HybridCBRS),
+        uploaded once.  Batches are then (user ids, item ids, labels): the rows are gathered on the device inside a replayed hipGraph
+        (Trainer.train_batch_graphed) instead of on the host and uploaded every batch — 25 epochs of HybridCBRS at ML-1M size took
+        35 s that way, more than any graph model."""
+        self.tables = [to_device_tensor(np.ascontiguousarray(t, dtype=np.float32)) for t in tables]
+        self.seq = types.SimpleNamespace(adj_matrix=types.SimpleNamespace(shape=(min(int(t.shape[0]) for t in self.tables),)))   # (range check of the ids)
+
+    def _rows_of(self, u, i):
+        out = []
+        for t in self.tables:
+            for ids in (u, i):
+                rows = torch.empty((ids.numel(), t.shape[1]), dtype=torch.float32, device=t.device)
+                capi.copy_columns(t, rows, ids=ids)
+                out.append(rows)
+        return out                                                   # (user, item) per table: [gu, gi] or [gu, gi, bu, bi]
+
+    def _forward_backward(self, u, i, yv, rows=None, ui=None):
+        """Trainer's per-batch core for ids: gather the rows, head forward, BCE, head reverse pass (the inputs are constants)."""
+        r = self._rows_of(u, i)
+        b = u.numel()
+        p = self.head.forward(r[0], r[1], (r[2], r[3]) if self.hybrid else None)
+        dz = torch.empty((b, 1), dtype=torch.float32, device=p.device)
+        terms = torch.empty(b, dtype=torch.float32, device=p.device)
+        capi.bce_grad(p, yv, dz, terms)
+        grads = {}
+        self.head.backward(dz, grads, need_input_grad=False)
+        return terms, grads
 
     def loss_and_grads(self, blocks, y):
         """blocks = (user rows, item rows) or (user graph, item graph, user BERT, item BERT), each [B, D]."""
@@ -915,8 +948,23 @@ class HeadTrainer(Trainer):
             loss = float(terms.sum().item()) / b
         return loss, grads
 
-    def train_batch(self, blocks, y):
-        loss, grads = self.loss_and_grads(blocks, y)
+    def train_batch(self, *args, bert=None):
+        """train_batch(blocks, y): the rows themselves; train_batch(u_ids, i_ids, y): ids against `set_tables` (eager: the first
+        batch of a shape before Trainer.train_batch_graphed captures)."""
+        if len(args) == 3:
+            u_ids, i_ids, y = args
+            n = self.seq.adj_matrix.shape[0]
+            u, i = ids_to_device(u_ids, n), ids_to_device(i_ids, n)
+            yv = to_device_tensor(np.asarray(y, dtype=np.float32) if not isinstance(y, torch.Tensor) else y)
+            with torch.no_grad():
+                terms, grads = self._forward_backward(u, i, yv)
+                loss = float(terms.sum().item()) / u.numel()
+                for prm in self.params:
+                    l2 = self._l2(prm)
+                    if l2:
+                        loss += l2 * float((prm.detach().double() ** 2).sum().item())
+        else:
+            loss, grads = self.loss_and_grads(*args)
         self.apply_gradients(grads)
         return loss
 
@@ -931,13 +979,42 @@ def fit(model, sequence, epochs=1, callbacks=None, verbose=True, **kwargs):
             if not model.built and len(sequence):
                 model(sequence[0][0])                          # one forward call builds every weight (as Keras does)
             trainer = model._trainer = HeadTrainer(model, **hp)
+        # the reference's Sequences of pre-computed rows (datasets.py:55-80) gather them on the host from one (BasicRS) or two
+        # (HybridCBRS) tables indexed by node id: the tables go to the device once and the batches are read as ids
+        # (AMAR_RESIDENT_ROWS=0: the batches as they come, eager)
+        from deep_cbrs_amar_renaissance_amd.data.datasets import HybridUserItemEmbeddings, UserItemEmbeddings
+        tables = None
+        if os.environ.get('AMAR_RESIDENT_ROWS', '1') != '0':
+            if type(sequence) is UserItemEmbeddings and not trainer.hybrid:
+                tables = [sequence.embeddings]
+            elif type(sequence) is HybridUserItemEmbeddings and trainer.hybrid:
+                tables = [sequence.graph_embeddings, sequence.bert_embeddings]
+            if tables is not None and not all(isinstance(t, np.ndarray) and t.ndim == 2 for t in tables):
+                tables = None
+        if tables is not None:
+            src = getattr(trainer, '_table_sources', None)
+            if src is None or len(src) != len(tables) or any(a is not b for a, b in zip(src, tables)):
+                trainer.set_tables(tables)
+                trainer._table_sources = tables
+        use_graph = tables is not None and os.environ.get('AMAR_TRAIN_GRAPH', '1') != '0'
         history = []
         for epoch in range(int(epochs)):
             total, count = 0.0, 0
             for b in range(len(sequence)):
-                blocks, y = sequence[b]
-                total += trainer.train_batch(blocks, y) * len(y)
+                if tables is not None:
+                    r = sequence._batch_ratings(b)
+                    u, i, y = r[:, 0], r[:, 1], r[:, 2]
+                    if use_graph:
+                        trainer.train_batch_graphed(u, i, y)
+                    else:
+                        total += trainer.train_batch(u, i, y) * len(y)
+                else:
+                    blocks, y = sequence[b]
+                    total += trainer.train_batch(blocks, y) * len(y)
                 count += len(y)
+            if use_graph:
+                total = trainer.pop_loss_sum()
+                trainer.touch_parameters()
             history.append(total / max(count, 1))
             if verbose:
                 print("Epoch {}/{} - loss: {:.4f}".format(epoch + 1, epochs, history[-1]))

@@ -816,3 +816,64 @@ def test_hybrid_predict_reads_the_reference_sequence_as_ids(hip, monkeypatch):
     assert model.bert_table is not None and resident.shape == plain.shape == (len(ratings), 1)
     assert float(np.abs(resident - plain).max()) < 2e-6
     assert float(np.abs(model.predict(seq, hoist=False) - plain).max()) < 2e-6
+
+
+@pytest.mark.parametrize('kind', ['basic', 'hybrid'])
+def test_head_only_models_train_from_resident_tables(hip, monkeypatch, kind):
+    """BasicRS / HybridCBRS (the reference's baselines on pre-computed embedding rows): fit() on the reference's Sequence classes keeps
+    their table(s) on the device and replays batches of ids from a hipGraph (round 4) — the weights after two epochs equal those of the
+    batches taken as they come (rows gathered on the host, eager), and the loss falls."""
+    import types
+    from deep_cbrs_amar_renaissance_amd import engine
+    from deep_cbrs_amar_renaissance_amd.data.datasets import HybridUserItemEmbeddings, UserItemEmbeddings
+    from deep_cbrs_amar_renaissance_amd.models import basic, hybrid
+    rng = np.random.default_rng(5)
+    n_users, n_items, n = 70, 50, 120
+    graph_table = rng.standard_normal((n, 16)).astype(np.float32)
+    bert_table = rng.standard_normal((n, 40)).astype(np.float32)
+    u = rng.integers(0, n_users, 900)
+    i = rng.integers(n_users, n, 900)
+    y = ((graph_table[u, 0] + graph_table[i, 1]) > 0).astype(np.int64)
+    ratings = np.stack([u, i, y], axis=1).astype(np.int64)
+    users, items = np.arange(n_users), np.arange(n_users, n)
+
+    def run(resident):
+        monkeypatch.setenv('AMAR_RESIDENT_ROWS', '1' if resident else '0')
+        engine.set_seed(4)
+        if kind == 'basic':
+            model = basic.BasicRS(dense_units=[16, 8], clf_units=[8])
+            seq = UserItemEmbeddings(ratings, users, items, graph_table, batch_size=128, shuffle=True)
+        else:
+            model = hybrid.HybridCBRS(dense_units=[[16, 8], [16, 8], [8, 8]], clf_units=[8], feature_based=True)
+            seq = HybridUserItemEmbeddings(ratings, users, items, graph_table, bert_table, batch_size=128, shuffle=True)
+        model.compile(optimizer=types.SimpleNamespace(learning_rate=5e-3, beta_1=0.9))
+        hist = model.fit(seq, epochs=3, verbose=False)['loss']
+        assert (getattr(model._trainer, 'tables', None) is not None) == resident
+        return hist, [p.detach().clone() for p in model.parameters()]
+    h0, w0 = run(False)
+    h1, w1 = run(True)
+    assert h1[-1] < h1[0]
+    # (eager batches reduce their weight-gradient partials in a launch of their own, replayed ones inside the Adam launch, and the two
+    # routes pick different Dense kernels: fp32 rounding that 20 Adam steps at lr 5e-3 spread to a few 1e-5)
+    # Adam's m / sqrt(v) turns those into up to ~lr per step on weights whose gradient is nearly zero: the weights agree to a few lr)
+    assert np.allclose(h0, h1, rtol=5e-4), (h0, h1)
+    assert len(w0) == len(w1) and all(torch.allclose(a, b, rtol=0, atol=1e-2) for a, b in zip(w0, w1))
+    # one batch, same weights: the gradients of ids against the resident tables equal those of the rows gathered on the host
+    monkeypatch.setenv('AMAR_RESIDENT_ROWS', '1')
+    engine.set_seed(4)
+    if kind == 'basic':
+        model = basic.BasicRS(dense_units=[16, 8], clf_units=[8])
+        blocks, tables = (graph_table[u[:100]], graph_table[i[:100]]), [graph_table]
+    else:
+        model = hybrid.HybridCBRS(dense_units=[[16, 8], [16, 8], [8, 8]], clf_units=[8], feature_based=True)
+        blocks, tables = (graph_table[u[:100]], graph_table[i[:100]], bert_table[u[:100]], bert_table[i[:100]]), [graph_table, bert_table]
+    from deep_cbrs_amar_renaissance_amd import training
+    model(blocks)
+    tr = training.HeadTrainer(model)
+    loss_rows, g_rows = tr.loss_and_grads(blocks, y[:100])
+    tr.set_tables(tables)
+    with torch.no_grad():
+        terms, g_ids = tr._forward_backward(_t(u[:100].astype(np.int32)), _t(i[:100].astype(np.int32)), _t(y[:100].astype(np.float32)))
+    assert abs(float(terms.sum()) / 100 - loss_rows) < 1e-6
+    for prm in tr.params:
+        assert torch.equal(g_rows[prm], g_ids[prm])

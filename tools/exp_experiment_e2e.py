@@ -23,15 +23,21 @@ def main():
     tmp = tempfile.mkdtemp(prefix='amar_e2e_')
     t0 = time.perf_counter()
     ds = synthetic.ml1m(1)
-    hybrid = name.startswith('hybrid.')
-    paths = synthetic.write_dataset(ds, os.path.join(tmp, 'datasets'), bert_dim=768 if hybrid else 32, kge_dim=32)
+    hybrid = name.startswith('hybrid.') and name != 'hybrid.HybridCBRS'
+    paths = synthetic.write_dataset(ds, os.path.join(tmp, 'datasets'), bert_dim=768 if name.startswith('hybrid.') else 32, kge_dim=32)
     t_files = time.perf_counter() - t0
     cfg = json.loads(json.dumps(BASE_CONFIG))
     cfg['dataset'].update({k: v for k, v in paths.items() if k != 'props_triples_filepath'})
     cfg['dataset']['load_function_name'] = 'load_user_item_graph_bert_embeddings' if hybrid else 'load_user_item_graph'
+    head_only = name in ('basic.BasicRS', 'hybrid.HybridCBRS')          # the reference's baselines on pre-computed embedding rows (no graph)
+    if head_only:
+        cfg['dataset']['load_function_name'] = 'load_graph_embeddings' if name == 'basic.BasicRS' else 'load_hybrid_embeddings'
     cfg['parameters']['epochs'] = epochs
-    cfg['model'].update({'name': name, 'embedding_dim': 8, 'n_hiddens': [8, 8], 'n_layers': 2, 'clf_units': [64, 64] if hybrid else [48, 48],
-                         'dense_units': [[24, 24], [256, 64], [64, 64]] if hybrid else [24, 24]})
+    if head_only:
+        cfg['model'].update({'name': name, 'dense_units': [64, 32] if name == 'basic.BasicRS' else [[64, 32], [64, 32], [32, 16]], 'clf_units': [16]})
+    else:
+        cfg['model'].update({'name': name, 'embedding_dim': 8, 'n_hiddens': [8, 8], 'n_layers': 2, 'clf_units': [64, 64] if hybrid else [48, 48],
+                             'dense_units': [[24, 24], [256, 64], [64, 64]] if hybrid else [24, 24]})
     open(os.path.join(tmp, 'config.yaml'), 'w').write(yaml.safe_dump(cfg))
     os.chdir(tmp)
     run_log = setup_mlflow('e2e', os.path.join(tmp, 'mlruns'))

@@ -32,6 +32,11 @@ def main():
     head_only = name in ('basic.BasicRS', 'hybrid.HybridCBRS')          # the reference's baselines on pre-computed embedding rows (no graph)
     if head_only:
         cfg['dataset']['load_function_name'] = 'load_graph_embeddings' if name == 'basic.BasicRS' else 'load_hybrid_embeddings'
+    if 'TS' in name or 'TW' in name:                                   # TwoStep / TwoWay stacks: (user-item, item-property[, user-property]) graphs
+        cfg['dataset'].update({'type_adjacency': 'unary-kg', 'props_triples_filepath': paths['props_triples_filepath']})
+        if 'TW' in name:
+            cfg['dataset']['user_properties'] = True
+            cfg['model']['user_item_node'] = 'concatenation'
     cfg['parameters']['epochs'] = epochs
     if head_only:
         cfg['model'].update({'name': name, 'dense_units': [64, 32] if name == 'basic.BasicRS' else [[64, 32], [64, 32], [32, 16]], 'clf_units': [16]})
